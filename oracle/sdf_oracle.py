@@ -1,0 +1,733 @@
+"""CPU ORACLE -- TEST INFRASTRUCTURE ONLY. Never imported by the product path.
+
+A torch-CPU restatement (fp64 by default, fp32 on request) of the reference's
+sphere-tracing primary-ray integrator and silhouette-reparameterisation
+gradient estimator.  Every function cites the reference file:line it follows
+(paths relative to /root/reference).  The reference obtains its gradients from
+Dr.Jit reverse-mode AD; this oracle obtains them from torch autograd applied to
+the same forward program with the same detach / replace_grad structure, so the
+backward here is *not* hand-derived (the product's HIP backward is).
+
+PARITY UNPINNED: the reference has no tests, golden vectors or fixtures, and
+Mitsuba 3 / Dr.Jit (un-vendored, unversioned `pip install mitsuba`,
+README.md:48) cannot be imported in the build container.  The third-party
+conventions on the path -- Dr.Jit `Texture3f` cubic B-spline lookups, Mitsuba's
+perspective sensor, Gaussian reconstruction filter, `ImageBlock.put`,
+`HDRFilm.develop`, `BoundingBox3f.ray_intersect` -- are restated below from their
+published algorithms (see each docstring) and are this repository's own spec.
+What IS pinned: the in-repo closed forms (`SphereSDF`, shapes.py:494-514),
+B-spline identities, the primal-invariance property of the estimator, and
+finite differences in the style of figures/result_utils.py:126-161 (see tests/).
+
+Only `tests/`, `__graft_entry__.smoke()` and `bench.py`'s cpu_baseline leg may
+import this file.
+"""
+import math
+
+import numpy as np
+import torch
+
+INF = float("inf")
+
+# --------------------------------------------------------------------------
+# Constants
+# --------------------------------------------------------------------------
+TRACE_EPS = 1e-6            # shapes.py:31
+EXTRA_THRESH = 0.05         # shapes.py:35
+SIL_WEIGHT_OFFSET = 0.05    # shapes.py:36
+SIL_WEIGHT_EPS = 1e-6       # shapes.py:37
+WEIGHT_POWER = 3            # shapes.py:38
+BBOX_DELTA = 0.05           # shapes.py:417
+BBOX_FADE_EPS = 0.01        # shapes.py:86
+EDGE_EPS = 0.01             # configs.py:21
+CLAMP_THRESH = 0.05         # configs.py:29
+NEAR_CLIP = 1e-2            # Mitsuba perspective sensor default
+FAR_CLIP = 1e4
+FOV_X = 39.0                # util.py:133
+FILTER_STDDEV = 0.5         # Mitsuba gaussian rfilter default
+FILTER_RADIUS = 2.0         # 4 * stddev
+BORDER = 2                  # rfilter border_size = ceil(radius - 0.5)
+
+SILHOUETTE = 0              # integrators/sdf_silhouette_reparam.py
+SIMPLE_SHADING = 1          # integrators/sdf_simple_shading_reparam.py
+
+
+def replace_grad(a, b):
+    """dr.replace_grad(a, b): value of `a`, gradient of `b`."""
+    return a.detach() + (b - b.detach())
+
+
+def drsign(x):
+    """dr.sign: copysign(1, x) -- sign(0) = +1 (differs from torch.sign)."""
+    return torch.where(x >= 0, torch.ones_like(x), -torch.ones_like(x))
+
+
+def dot(a, b):
+    return (a * b).sum(-1)
+
+
+# --------------------------------------------------------------------------
+# A1: Dr.Jit Texture3f cubic B-spline (shapes.py:420-450)
+# --------------------------------------------------------------------------
+def bspline_weights(a):
+    """Uniform cubic B-spline basis and its first two derivatives at fractional
+    offset `a` (taps i-1, i, i+1, i+2).  Dr.Jit texture.h `eval_cubic*`."""
+    a2 = a * a
+    a3 = a2 * a
+    w = torch.stack([-a3 + 3 * a2 - 3 * a + 1,
+                     3 * a3 - 6 * a2 + 4,
+                     -3 * a3 + 3 * a2 + 3 * a + 1,
+                     a3], -1) / 6.0
+    dw = torch.stack([-3 * a2 + 6 * a - 3,
+                      9 * a2 - 12 * a,
+                      -9 * a2 + 6 * a + 3,
+                      3 * a2], -1) / 6.0
+    ddw = torch.stack([1 - a, 3 * a - 2, 1 - 3 * a, a], -1)
+    return w, dw, ddw
+
+
+def eval_cubic(data, p, order=2):
+    """Tricubic B-spline lookup of `data` (Z,Y,X) at unit-cube points p (N,3)=(x,y,z).
+
+    Texel centres at (i+0.5)/res; indices clamped (wrap=Clamp); gradient is
+    multiplied by res, Hessian by res_i*res_j (Dr.Jit `eval_cubic_grad/hessian`).
+    Differentiable w.r.t. `data` and `p` (the weights are polynomials in p).
+    Returns v (N,), g (N,3), H (N,3,3) (g/H None if order is too low).
+    """
+    Z, Y, X = data.shape
+    res = torch.tensor([X, Y, Z], dtype=p.dtype)
+    pf = p * res - 0.5
+    fl = torch.floor(pf.detach())
+    alpha = pf - fl
+    i0 = fl.to(torch.int64) - 1                                   # (N,3)
+    offs = torch.arange(4)
+    ix = (i0[:, 0:1] + offs).clamp(0, X - 1)                      # (N,4)
+    iy = (i0[:, 1:2] + offs).clamp(0, Y - 1)
+    iz = (i0[:, 2:3] + offs).clamp(0, Z - 1)
+    lin = (iz[:, :, None, None] * Y + iy[:, None, :, None]) * X + ix[:, None, None, :]
+    taps = data.reshape(-1)[lin.reshape(-1)].reshape(-1, 4, 4, 4)  # [n, kz, jy, ix]
+    wx, dwx, ddwx = bspline_weights(alpha[:, 0])
+    wy, dwy, ddwy = bspline_weights(alpha[:, 1])
+    wz, dwz, ddwz = bspline_weights(alpha[:, 2])
+
+    def contract(az, ay, ax):
+        return torch.einsum('nkji,nk,nj,ni->n', taps, az, ay, ax)
+
+    v = contract(wz, wy, wx)
+    if order == 0:
+        return v, None, None
+    g = torch.stack([contract(wz, wy, dwx) * X,
+                     contract(wz, dwy, wx) * Y,
+                     contract(dwz, wy, wx) * Z], -1)
+    if order == 1:
+        return v, g, None
+    hxx = contract(wz, wy, ddwx) * (X * X)
+    hyy = contract(wz, ddwy, wx) * (Y * Y)
+    hzz = contract(ddwz, wy, wx) * (Z * Z)
+    hxy = contract(wz, dwy, dwx) * (X * Y)
+    hxz = contract(dwz, wy, dwx) * (X * Z)
+    hyz = contract(dwz, dwy, wx) * (Y * Z)
+    H = torch.stack([torch.stack([hxx, hxy, hxz], -1),
+                     torch.stack([hxy, hyy, hyz], -1),
+                     torch.stack([hxz, hyz, hzz], -1)], -2)
+    return v, g, H
+
+
+class Grid3d:
+    """shapes.py:375-483 without `to_world` (identity); `p` is the translation
+    parameter `sdf.p` (shapes.py:389, 412)."""
+
+    def __init__(self, data, p=None):
+        self.data = data
+        self.p = p if p is not None else torch.zeros(3, dtype=data.dtype)
+
+    def bbox(self):                                      # shapes.py:416-418
+        lo = torch.full((3,), -BBOX_DELTA, dtype=self.data.dtype)
+        hi = torch.full((3,), 1.0 + BBOX_DELTA, dtype=self.data.dtype)
+        return lo, hi
+
+    def eval(self, x):                                   # shapes.py:420-421
+        return eval_cubic(self.data, x - self.p, 0)[0]
+
+    def eval_and_grad(self, x):                          # shapes.py:430-436
+        v, g, _ = eval_cubic(self.data, x - self.p, 1)
+        return v, g
+
+    def eval_grad(self, x):                              # shapes.py:423-428
+        return eval_cubic(self.data, x - self.p, 1)[1]
+
+    def eval_all(self, x):                               # shapes.py:438-450
+        v, g, H = eval_cubic(self.data, x - self.p, 2)
+        return v, v.detach(), g, g.detach(), H
+
+
+class SphereSDF:
+    """shapes.py:486-536 (closed forms; 'only used for testing')."""
+
+    def __init__(self, p, r):
+        self.p, self.r = p, r
+
+    def bbox(self):                                      # shapes.py:530-532
+        c = self.p.detach()
+        return c - 0.5 - BBOX_DELTA, c + 0.5 + BBOX_DELTA
+
+    def eval(self, x):
+        return torch.linalg.norm(x - self.p, dim=-1) - self.r
+
+    def eval_and_grad(self, x):
+        n = x - self.p
+        nrm = torch.linalg.norm(n, dim=-1)
+        return nrm - self.r, n / nrm[:, None]
+
+    def eval_grad(self, x):
+        return self.eval_and_grad(x)[1]
+
+    def eval_all(self, x):
+        v, g = self.eval_and_grad(x)
+        n = (self.p - x).detach()                        # shapes.py:505-514
+        tmp = dot(n, n)
+        f = 1.0 / (tmp * torch.sqrt(tmp))
+        eye = torch.eye(3, dtype=x.dtype)
+        H = f[:, None, None] * (tmp[:, None, None] * eye - n[:, :, None] * n[:, None, :])
+        return v, v.detach(), g, g.detach(), H
+
+
+# --------------------------------------------------------------------------
+# A11: math_util.py
+# --------------------------------------------------------------------------
+def outer(a, b):                                         # math_util.py:20-24
+    return a[:, :, None] * b[:, None, :]
+
+
+def normalize_sqr(x):                                    # math_util.py:13-17
+    x2 = dot(x, x)
+    eye = torch.eye(3, dtype=x.dtype)
+    jac = eye / x2[:, None, None] - (2.0 / (x2 * x2))[:, None, None] * outer(x, x)
+    return x / x2[:, None], jac
+
+
+def closest_axis(min_dist):
+    """Axis one-hot used at math_util.py:36-39 and shapes.py:158-161 (strict <,
+    ties leave n = 0)."""
+    mx, my, mz = min_dist[:, 0], min_dist[:, 1], min_dist[:, 2]
+    n = torch.zeros_like(min_dist)
+    n[:, 0] = ((mx < my) & (mx < mz)).to(min_dist.dtype)
+    n[:, 1] = ((my < mz) & (my < mx)).to(min_dist.dtype)
+    n[:, 2] = ((mz < mx) & (mz < my)).to(min_dist.dtype)
+    return n
+
+
+def bbox_distance_inside_d(x, lo, hi):                   # math_util.py:31-41
+    dist = torch.clamp(torch.minimum((x - lo).min(-1).values, (hi - x).min(-1).values), min=0.0)
+    dmax = (hi - x).abs()
+    dmin = (lo - x).abs()
+    n = closest_axis(torch.minimum(dmin, dmax))
+    d = torch.where((dist > 0)[:, None], n * drsign(dmax - dmin), torch.zeros_like(n))
+    return dist, d
+
+
+# --------------------------------------------------------------------------
+# A2/A3/A5: SDFBase.ray_intersect (shapes.py:68-288)
+# --------------------------------------------------------------------------
+def bbox_ray_intersect(lo, hi, o, d):
+    """Mitsuba `BoundingBox3f::ray_intersect` (slab test) + `contains`
+    (shapes.py:130-132)."""
+    ok = ((d != 0) | (o > lo) | (o < hi)).all(-1)
+    rcp = 1.0 / d
+    t1 = (lo - o) * rcp
+    t2 = (hi - o) * rcp
+    mint = torch.minimum(t1, t2).max(-1).values
+    maxt = torch.maximum(t1, t2).min(-1).values
+    ok = ok & (maxt >= mint)
+    inside = ((o >= lo) & (o <= hi)).all(-1)
+    return ok, mint, maxt, inside
+
+
+def eval_trace_weight(d, i, lo, hi, x, v, g, H):         # shapes.py:68-113
+    n_dot_d = dot(g, d)
+    n_dot_n = dot(g, g)
+    ratio = n_dot_d / n_dot_n
+    denom = SIL_WEIGHT_EPS + v.abs() + SIL_WEIGHT_OFFSET * n_dot_d * ratio
+    dist_w = 1.0 / denom ** WEIGHT_POWER
+    bd, bd_d = bbox_distance_inside_d(x, lo, hi)
+    bw = torch.where(i > 0, torch.clamp(bd, max=BBOX_FADE_EPS) / BBOX_FADE_EPS, torch.ones_like(bd))
+    weight = dist_w * bw
+    bw_d = torch.where(((i > 0) & (bd < BBOX_FADE_EPS))[:, None], bd_d / BBOX_FADE_EPS, torch.zeros_like(bd_d))
+    grad = 2 * ratio[:, None] * (d - ratio[:, None] * g)
+    denom_d = drsign(v)[:, None] * g + SIL_WEIGHT_OFFSET * torch.einsum('ni,nij->nj', grad, H)
+    dist_w_d = (-WEIGHT_POWER * dist_w / denom)[:, None] * denom_d
+    weight_d = dist_w[:, None] * bw_d + bw[:, None] * dist_w_d
+    return weight, weight_d
+
+
+@torch.no_grad()
+def ray_intersect(sdf, o, d, ray_maxt, active=None, max_steps=100000):
+    """Differentiable sphere tracing, shapes.py:115-288.  Runs without autograd
+    (the reference calls it under dr.suspend_grad, warp.py:104-107).  Masked
+    loop semantics of mi.Loop: state of inactive lanes is frozen."""
+    N = o.shape[0]
+    dt = o.dtype
+    d = d / torch.linalg.norm(d, dim=-1, keepdim=True)             # :124
+    lo, hi = sdf.bbox()
+    hit_box, mint, maxt_box, inside = bbox_ray_intersect(lo, hi, o, d)
+    hit_box = hit_box & ((mint > 0) | inside)                       # :132
+    act = hit_box.clone() if active is None else (active & hit_box)
+    maxt = torch.minimum(maxt_box, ray_maxt)                        # :136
+    trace_eps = TRACE_EPS * torch.clamp(maxt, min=1.0)              # :137
+    its_t = torch.full((N,), INF, dtype=dt)
+    t = torch.where(inside, torch.zeros_like(mint), mint + 1e-5)    # :141
+    warp_t = torch.zeros(N, dtype=dt)
+    prev_sd = torch.zeros(N, dtype=dt)
+    prev_gc = torch.zeros(N, 3, dtype=dt)
+    wsum = torch.zeros(N, dtype=dt)
+    mixed = torch.zeros(N, 3, dtype=dt)
+    wdsum = torch.zeros(N, 3, dtype=dt)
+    it = torch.zeros(N, dtype=torch.int64)
+    ews = torch.zeros(N, dtype=dt)
+    ews_d = torch.zeros(N, 3, dtype=dt)
+    # entry-face derivative of t, :156-164
+    pb = o + t[:, None] * d
+    n = closest_axis(torch.minimum((lo - pb).abs(), (hi - pb).abs()))
+    ddn = dot(d, n)
+    t_d = torch.where((~inside & (ddn.abs() > 0))[:, None], -n / ddn[:, None] * t[:, None], torch.zeros_like(n))
+
+    steps = 0
+    while bool(act.any()) and steps < max_steps:
+        steps += 1
+        a = act.nonzero()[:, 0]
+        ta, da, oa = t[a], d[a], o[a]
+        x = oa + ta[:, None] * da
+        v, _, g, _, H = sdf.eval_all(x)                               # :178
+        hit = v < trace_eps[a]                                        # :185
+        its_a = torch.where(hit, ta, its_t[a])
+        sd = v.abs()
+        w, w_d = eval_trace_weight(da, it[a], lo, hi, x, v, g, H)     # :188
+        inv_den = 1.0 / torch.clamp(sd, max=EXTRA_THRESH)             # :198
+        diff = prev_sd[a] - sd
+        e = ews[a] + torch.where(diff >= 0, diff * inv_den, torch.zeros_like(diff))
+        e = torch.clamp(e, max=1.0)                                   # :201
+        cur = torch.where(hit, torch.zeros_like(sd), sd)              # :203
+        seg = 0.5 * (cur + prev_sd[a])
+        winc = seg * w * e                                            # :205-207
+        wsum_a = wsum[a] + winc
+        warp_a = warp_t[a] + winc * ta
+
+        tda = t_d[a]
+
+        def conv(f):                                                  # :126-127
+            return ta[:, None] * f + dot(da, f)[:, None] * tda
+
+        w_d = conv(w_d)
+        gc = conv(g)
+        seg_d = 0.5 * (gc + prev_gc[a])
+        sd_d = drsign(v)[:, None] * gc                                # :220-221
+        ewd = (prev_gc[a] - sd_d) * inv_den[:, None]
+        ewd = ewd - (diff * inv_den ** 2)[:, None] * torch.where((v < EXTRA_THRESH)[:, None], sd_d, torch.zeros_like(sd_d))
+        e_d = ews_d[a] + torch.where((diff > 0)[:, None], ewd, torch.zeros_like(ewd))
+        e_d = torch.where(((e >= 1.0) | (e <= 0.0))[:, None], torch.zeros_like(e_d), e_d)
+        w_d = w[:, None] * e_d + w_d * e[:, None]                     # :227
+        w = w * e
+        winc_d = w[:, None] * seg_d + w_d * seg[:, None]              # :230
+        mixed_a = mixed[a] + winc_d * ta[:, None] + (w * seg)[:, None] * tda
+        tda = tda + gc
+        wdsum_a = wdsum[a] + winc_d
+        tn = ta + cur
+        still = (tn <= maxt[a]) & ~hit                                # :238
+
+        its_t[a] = its_a; ews[a] = e; ews_d[a] = e_d; wsum[a] = wsum_a; warp_t[a] = warp_a
+        mixed[a] = mixed_a; t_d[a] = tda; wdsum[a] = wdsum_a; it[a] = it[a] + 1
+        t[a] = tn; prev_sd[a] = sd; prev_gc[a] = gc
+        act[a] = still
+
+    # refinement, :245-257
+    refining = torch.isfinite(its_t)
+    ri = torch.zeros(N, dtype=torch.int64)
+    while bool(refining.any()):
+        a = refining.nonzero()[:, 0]
+        md = sdf.eval(o[a] + its_t[a][:, None] * d[a])
+        its_t[a] = its_t[a] + md * (10.0 / (10.0 + ri[a].to(dt)))
+        keep = (md <= 0) | (md > trace_eps[a])
+        ri[a] = ri[a] + 1
+        keep = keep & (ri[a] < 10)
+        refining[a] = keep
+
+    inv = 1.0 / wsum                                                  # :259-261
+    warp_t = warp_t * inv
+    warp_t_d = (-warp_t[:, None] * wdsum + mixed) * inv[:, None]
+    ww = torch.clamp(wsum, 0.0, 1.0)                                  # :271-272
+    ww_d = torch.where(((wsum > 0) & (wsum < 1))[:, None], wdsum, torch.zeros_like(wdsum))
+    invalid = (wsum < 1e-7) | ~hit_box                                # :278-283
+    warp_t = torch.where(invalid, torch.full_like(warp_t, INF), warp_t)
+    warp_t_d = torch.where(invalid[:, None], torch.zeros_like(warp_t_d), warp_t_d)
+    ww = torch.where(invalid, torch.zeros_like(ww), ww)
+    ww_d = torch.where(invalid[:, None], torch.zeros_like(ww_d), ww_d)
+    return dict(its_t=its_t, warp_t=warp_t, warp_t_d=warp_t_d, warp_weight=ww,
+                warp_weight_d=ww_d, steps=it, weight_sum=wsum, refine_steps=ri)
+
+
+@torch.no_grad()
+def ray_intersect_non_diff(sdf, o, d, ray_maxt):
+    """shapes.py:290-339 (plain sphere tracing + refinement) -> its_t."""
+    N = o.shape[0]
+    dt = o.dtype
+    d = d / torch.linalg.norm(d, dim=-1, keepdim=True)
+    lo, hi = sdf.bbox()
+    hit_box, mint, maxt_box, inside = bbox_ray_intersect(lo, hi, o, d)
+    act = hit_box & ((mint > 0) | inside)
+    maxt = torch.minimum(maxt_box, ray_maxt)
+    trace_eps = TRACE_EPS * torch.clamp(maxt, min=1.0)
+    its_t = torch.full((N,), INF, dtype=dt)
+    t = torch.where(inside, torch.zeros_like(mint), mint + 1e-5)
+    steps = torch.zeros(N, dtype=torch.int64)
+    while bool(act.any()):
+        a = act.nonzero()[:, 0]
+        v = sdf.eval(o[a] + t[a][:, None] * d[a])
+        hit = v < trace_eps[a]
+        its_t[a] = torch.where(hit, t[a], its_t[a])
+        cur = torch.where(hit, torch.zeros_like(v), v.abs())
+        keep = (t[a] <= maxt[a]) & ~hit
+        t[a] = t[a] + cur
+        act[a] = keep & (t[a] <= maxt[a])
+        steps[a] += 1
+    refining = torch.isfinite(its_t)
+    ri = torch.zeros(N, dtype=torch.int64)
+    while bool(refining.any()):
+        a = refining.nonzero()[:, 0]
+        md = sdf.eval(o[a] + its_t[a][:, None] * d[a])
+        its_t[a] = its_t[a] + md * (10.0 / (10.0 + ri[a].to(dt)))
+        keep = (md <= 0) | (md > trace_eps[a])
+        ri[a] = ri[a] + 1
+        refining[a] = keep & (ri[a] < 10)
+    return dict(its_t=its_t, steps=steps, refine_steps=ri)
+
+
+# --------------------------------------------------------------------------
+# A8/A9/A10: WarpField2D (warp.py:7-128)
+# --------------------------------------------------------------------------
+def warp_weight_fn(sdf, x, v, g, edge_eps):                           # warp.py:25-39
+    lo, hi = sdf.bbox()
+    bd, bd_d = bbox_distance_inside_d(x, lo, hi)
+    use_eps = edge_eps <= bd
+    eps_dvec = torch.where(use_eps[:, None], torch.zeros_like(bd_d), bd_d)
+    eps = torch.minimum(edge_eps, bd)
+    inv = 1.0 / eps
+    sd = v.abs()
+    fac = 1 - sd * inv
+    w = torch.clamp(fac, min=0.0)
+    w_d = -drsign(v)[:, None] * g * inv[:, None] + (sd * inv ** 2)[:, None] * eps_dvec
+    w_d = torch.where((fac >= 0)[:, None], w_d, torch.zeros_like(w_d))
+    eps_d = torch.where(use_eps & (fac >= 0), sd * inv ** 2, torch.zeros_like(sd))
+    return w, w_d, eps_d
+
+
+def warp_eval(sdf, x, ray_d, t, dt_dx, ww, ww_d, active):             # warp.py:47-96
+    """Returns (warp_dir with value ray_d, div with analytic value) -- attached
+    to the grid through v and g at x (x itself is constant for primary rays)."""
+    active = active & torch.isfinite(t)
+    v, _, g, g_det, H = sdf.eval_all(x)
+    H = H.detach()
+    n_, jn = normalize_sqr(g_det)                                      # :55
+    warp = -n_ * v[:, None]
+    jac = -torch.matmul(jn, H) * v[:, None, None] - outer(n_, g)      # :57
+    w, w_grad, eps_grad = warp_weight_fn(sdf, x.detach(), v.detach(), g.detach(), EDGE_EPS * t.detach())
+    w_grad = w_grad + eps_grad[:, None] * ray_d * EDGE_EPS            # :70
+    w_grad = w_grad * ww[:, None] + w[:, None] * ww_d                 # :73
+    w = (w * ww).detach()
+    jac = outer(warp, w_grad) + w[:, None, None] * jac                # :77
+    warp = warp * w[:, None]
+    warp = replace_grad(torch.zeros_like(warp), warp)                 # :81
+    warp = ray_d * torch.clamp(t, min=CLAMP_THRESH)[:, None] + warp
+    warp = warp / torch.linalg.norm(warp, dim=-1, keepdim=True)
+    eye = torch.eye(3, dtype=x.dtype)
+    proj = torch.matmul(eye - outer(ray_d, ray_d), jac)               # :86
+    jac = proj + torch.matmul(proj, outer(ray_d, dt_dx / t[:, None]))
+    div = jac[:, 0, 0] + jac[:, 1, 1] + jac[:, 2, 2]
+    active = active & (w > 0)
+    div = torch.where(active, div, torch.zeros_like(div))
+    warp = torch.where(active[:, None], warp, ray_d)
+    return replace_grad(ray_d, warp), div, active
+
+
+def compute_surface_interaction(sdf, o, d, t, valid):                 # shapes.py:347-366
+    """Returns (t, p, n) of the hit with the reference's gradient structure.
+    `valid` lanes only (t finite); others get zeros."""
+    p = o + t[:, None] * d
+    v, g = sdf.eval_and_grad(p)
+    t_diff = v / dot(g, -d).detach()
+    t = replace_grad(t, t_diff)
+    p = o + t[:, None] * d
+    gn = sdf.eval_grad(p)
+    n = gn / torch.linalg.norm(gn, dim=-1, keepdim=True)
+    return t, p, n
+
+
+# --------------------------------------------------------------------------
+# A18/A19: cameras (util.py:84-138) + Mitsuba perspective sensor restatement
+# --------------------------------------------------------------------------
+def regular_camera_origins(n, angle_shift=0.0, radius=2.0, height_scale=1.0):
+    """util.py:84-112 with height_steps<=1 (the only branch get_regular_cameras
+    reaches: height_steps = int(n>1))."""
+    ang = (np.arange(n, dtype=np.float64) / n + angle_shift / n) * 2 * np.pi
+    elev = 1.15 / height_scale + np.sin(ang * n / 4) * 0.5
+    elev = np.clip(elev, 0.0, np.pi / 2 + 0.05)
+    o = np.stack([np.cos(ang) * np.sin(elev) * radius, np.cos(elev) * radius,
+                  np.sin(ang) * np.sin(elev) * radius], -1)
+    return o + np.array([0.5, 0.0, 0.5])
+
+
+class Camera:
+    """Mitsuba `perspective` sensor (fov along x, near 1e-2, far 1e4) with
+    `look_at(origin, target, up)`; camera axes: x = left, y = up', z = dir."""
+
+    def __init__(self, origin, target=(0.5, 0.5, 0.5), up=(0, 1, 0), fov=FOV_X, dtype=torch.float64):
+        o = np.asarray(origin, np.float64)
+        dirv = np.asarray(target, np.float64) - o
+        dirv /= np.linalg.norm(dirv)
+        left = np.cross(np.asarray(up, np.float64), dirv)
+        left /= np.linalg.norm(left)
+        newup = np.cross(dirv, left)
+        self.origin = torch.tensor(o, dtype=dtype)
+        self.R = torch.tensor(np.stack([left, newup, dirv], 1), dtype=dtype)   # columns
+        self.tan = math.tan(math.radians(fov) * 0.5)
+        self.dtype = dtype
+
+    def params(self):
+        """Flat float32[16]: origin(3) left(3) up(3) dir(3) tan, pad(3) -- the
+        layout handed to the C-ABI (include/dsdf.h: dsdf_camera)."""
+        R = self.R.numpy()
+        return np.concatenate([self.origin.numpy(), R[:, 0], R[:, 1], R[:, 2], [self.tan, 0, 0, 0]]).astype(np.float32)
+
+    def sample_ray(self, pos, W, H):
+        """`sample_ray_differential` for film position pos/(W,H) in [0,1]^2."""
+        aspect = W / H
+        sx = pos[:, 0] / W
+        sy = pos[:, 1] / H
+        dl = torch.stack([(1 - 2 * sx) * self.tan, (1 - 2 * sy) * self.tan / aspect, torch.ones_like(sx)], -1)
+        dl = dl / torch.linalg.norm(dl, dim=-1, keepdim=True)
+        d = dl @ self.R.T
+        near_t = NEAR_CLIP / dl[:, 2]
+        o = self.origin + d * near_t[:, None]
+        maxt = FAR_CLIP / dl[:, 2] - near_t
+        return o, d, maxt
+
+    def sample_direction(self, p, W, H):
+        """`sample_direction(it)`: film uv (pixels) + importance of point p."""
+        aspect = W / H
+        ref = (p - self.origin) @ self.R
+        cot = 1.0 / self.tan
+        sx = 0.5 - 0.5 * cot * ref[:, 0] / ref[:, 2]
+        sy = 0.5 - 0.5 * aspect * cot * ref[:, 1] / ref[:, 2]
+        ok = (ref[:, 2] >= NEAR_CLIP) & (ref[:, 2] <= FAR_CLIP)
+        ok = ok & (sx >= 0) & (sx <= 1) & (sy >= 0) & (sy <= 1)
+        uv = torch.stack([sx * W, sy * H], -1)
+        dist = torch.linalg.norm(ref, dim=-1)
+        area = (2 * self.tan) * (2 * self.tan / aspect)
+        imp = (1.0 / area) * (dist / ref[:, 2]) ** 3 / dist ** 2
+        return uv, torch.where(ok, imp, torch.zeros_like(imp))
+
+
+# --------------------------------------------------------------------------
+# Sampler: Mitsuba `independent` = PCG32 seeded by sample_tea_32
+# --------------------------------------------------------------------------
+def sample_tea_32(v0, v1, rounds=4):
+    v0 = np.asarray(v0, np.uint32).copy()
+    v1 = np.asarray(v1, np.uint32).copy()
+    s = np.uint32(0)
+    with np.errstate(over='ignore'):
+        for _ in range(rounds):
+            s = np.uint32(s + np.uint32(0x9e3779b9))
+            v0 += ((v1 << np.uint32(4)) + np.uint32(0xa341316c)) ^ (v1 + s) ^ ((v1 >> np.uint32(5)) + np.uint32(0xc8013ea4))
+            v1 += ((v0 << np.uint32(4)) + np.uint32(0xad90777d)) ^ (v0 + s) ^ ((v0 >> np.uint32(5)) + np.uint32(0x7e95761e))
+    return v0, v1
+
+
+PCG32_MULT = np.uint64(0x5851f42d4c957f2d)
+
+
+def _pcg32_step(state, inc):
+    with np.errstate(over='ignore'):
+        old = state
+        state = old * PCG32_MULT + inc
+        xs = (((old >> np.uint64(18)) ^ old) >> np.uint64(27)).astype(np.uint32)
+        rot = (old >> np.uint64(59)).astype(np.uint32)
+        out = (xs >> rot) | (xs << ((np.uint32(0) - rot) & np.uint32(31)))
+    return state, out
+
+
+def independent_sampler_2d(seed, n):
+    """First `next_2d()` of Mitsuba's independent sampler for lanes 0..n-1:
+    PCG32(initstate=v0, initseq=v1) with (v0,v1)=sample_tea_32(seed, lane);
+    next_float32 = (u32 >> 9 | 0x3f800000) - 1."""
+    idx = np.arange(n, dtype=np.uint32)
+    v0, v1 = sample_tea_32(np.full(n, seed, np.uint32), idx)
+    with np.errstate(over='ignore'):
+        inc = (v1.astype(np.uint64) << np.uint64(1)) | np.uint64(1)
+        state = np.zeros(n, np.uint64)
+        state, _ = _pcg32_step(state, inc)
+        state = state + v0.astype(np.uint64)
+        state, _ = _pcg32_step(state, inc)
+    out = []
+    for _ in range(2):
+        state, u = _pcg32_step(state, inc)
+        f = ((u >> np.uint32(9)) | np.uint32(0x3f800000)).view(np.float32) - np.float32(1.0)
+        out.append(f)
+    return np.stack(out, -1)
+
+
+# --------------------------------------------------------------------------
+# Film: Gaussian rfilter + ImageBlock.put + HDRFilm.develop
+# --------------------------------------------------------------------------
+def gaussian_filter(x):
+    alpha = -1.0 / (2.0 * FILTER_STDDEV ** 2)
+    return torch.clamp(torch.exp(alpha * x * x) - math.exp(alpha * FILTER_RADIUS ** 2), min=0.0)
+
+
+def block_put(block, uv, values, Wb, Hb):
+    """ImageBlock::put with a non-normalised separable filter; block is a flat
+    (Hb*Wb*C) tensor; returns the updated block (out-of-place index_add)."""
+    C = values.shape[1]
+    pos_f = uv + (BORDER - 0.5)
+    p0 = torch.ceil(pos_f.detach() - FILTER_RADIUS).to(torch.int64)
+    offs = torch.arange(4)
+    qx = p0[:, 0:1] + offs                                  # (N,4)
+    qy = p0[:, 1:2] + offs
+    wx = gaussian_filter(qx.to(uv.dtype) - pos_f[:, 0:1])
+    wy = gaussian_filter(qy.to(uv.dtype) - pos_f[:, 1:2])
+    okx = (qx >= 0) & (qx < Wb)
+    oky = (qy >= 0) & (qy < Hb)
+    w = wy[:, :, None] * wx[:, None, :]                      # (N,4,4)
+    ok = oky[:, :, None] & okx[:, None, :]
+    w = torch.where(ok, w, torch.zeros_like(w))
+    pix = qy.clamp(0, Hb - 1)[:, :, None] * Wb + qx.clamp(0, Wb - 1)[:, None, :]
+    idx = (pix[..., None] * C + torch.arange(C)).reshape(-1)
+    contrib = (w[..., None] * values[:, None, None, :]).reshape(-1)
+    return block.index_add(0, idx, contrib)
+
+
+def develop(block, W, H):
+    """HDRFilm::develop: crop border, rgb / (W==0 ? 1 : W)."""
+    Wb, Hb = W + 2 * BORDER, H + 2 * BORDER
+    b = block.reshape(Hb, Wb, 4)[BORDER:BORDER + H, BORDER:BORDER + W]
+    wgt = b[..., 3:4]
+    wgt = torch.where(wgt == 0, torch.ones_like(wgt), wgt)
+    return b[..., :3] / wgt
+
+
+# --------------------------------------------------------------------------
+# A12-A17: ReparamIntegrator.render / eval_sample + the two sample() bodies
+# --------------------------------------------------------------------------
+def lane_positions(W, H, spp, offsets):
+    """integrators/reparam.py:140-171: lane -> pixel, plus jitter."""
+    Wb, Hb = W + 2 * BORDER, H + 2 * BORDER
+    idx = torch.arange(Wb * Hb * spp) // spp
+    py = idx // Wb
+    px = idx - Wb * py
+    pos = torch.stack([px, py], -1).to(offsets.dtype) - BORDER
+    return pos + offsets
+
+
+def render(sdf, cam, W, H, spp, offsets, integrator=SILHOUETTE, reparam=True,
+           return_aux=False, chunk=1 << 17):
+    """One view.  offsets: (Wb*Hb*spp, 2) in [0,1) (the sampler's next_2d per
+    lane).  Returns image (H,W,3), differentiable w.r.t. sdf.data / sdf.p when
+    they require grad.  `reparam=False` gives the DummyWarpField path
+    (warp.py:179-196)."""
+    Wb, Hb = W + 2 * BORDER, H + 2 * BORDER
+    dt = offsets.dtype
+    pos_all = lane_positions(W, H, spp, offsets)
+    block = torch.zeros(Hb * Wb * 4, dtype=dt)
+    aux = dict(steps=0, lanes=0, bbox=0, hits=0, refine=0, warp_active=0)
+    light = torch.tensor([1.0, 1.0, 1.0], dtype=dt) / math.sqrt(3.0)
+    for s in range(0, pos_all.shape[0], chunk):
+        pos = pos_all[s:s + chunk]
+        o, d, maxt = cam.sample_ray(pos, W, H)                           # reparam.py:92-94
+        tr = ray_intersect(sdf, o, d, maxt)                              # warp.py:104-107
+        its_t = tr['its_t']
+        hit = torch.isfinite(its_t)
+        N = pos.shape[0]
+        d_att = d
+        div = torch.ones(N, dtype=dt)
+        if reparam:
+            fin = torch.isfinite(tr['warp_t'])
+            tw = torch.where(fin, tr['warp_t'], torch.ones_like(tr['warp_t']))   # sanitised; masked below
+            x = o + tw[:, None] * d
+            # (non-finite warp_t lanes are evaluated at a finite stand-in and masked
+            #  by `fin`, exactly the effect of `active &= dr.isfinite(t)`, warp.py:52)
+            wdir2, dv2, wact2 = warp_eval(sdf, x, d, tw, tr['warp_t_d'], tr['warp_weight'], tr['warp_weight_d'], fin)
+            d_att = wdir2                                                # warp.py:114
+            div = replace_grad(torch.ones(N, dtype=dt), dv2)             # warp.py:115
+            aux['warp_active'] += int(wact2.sum())
+        if integrator == SILHOUETTE:                                     # sdf_silhouette_reparam.py:20-22
+            val = hit.to(dt) * div
+        else:                                                            # sdf_simple_shading_reparam.py:20-22
+            ts = torch.where(hit, its_t, torch.ones_like(its_t))
+            _, _, n = compute_surface_interaction(sdf, o, d_att, ts, hit)
+            sh = torch.clamp(dot(n, light), min=0.0)
+            val = torch.where(hit, sh, torch.zeros_like(sh)) * div
+        rgb = val[:, None].expand(-1, 3)
+        # re-projection, reparam.py:99-105
+        uv, rw = cam.sample_direction(o + d_att, W, H)
+        rwn = torch.where(rw > 0, rw / rw.detach(), torch.ones_like(rw))
+        rwn = replace_grad(torch.ones_like(rwn), rwn)
+        rgb = rwn[:, None] * rgb
+        wch = replace_grad(torch.ones(N, dtype=dt), div * rwn)           # reparam.py:115
+        block = block_put(block, uv, torch.cat([rgb, wch[:, None]], 1), Wb, Hb)
+        aux['steps'] += int(tr['steps'].sum()); aux['lanes'] += N
+        aux['bbox'] += int((tr['steps'] > 0).sum()); aux['hits'] += int(hit.sum())
+        aux['refine'] += int(tr['refine_steps'].sum())
+    img = develop(block, W, H)
+    if return_aux:
+        return img, aux
+    return img
+
+
+def render_backward(sdf, cam, W, H, spp, offsets, grad_in, integrator=SILHOUETTE, reparam=True):
+    """integrators/reparam.py:187-190: re-render with AD, backward_from(image*grad_in).
+    Returns dL/d(sdf.data) (and accumulates into .grad of any leaf)."""
+    data = sdf.data
+    leaf = data.detach().clone().requires_grad_(True)
+    s2 = Grid3d(leaf, sdf.p)
+    img = render(s2, cam, W, H, spp, offsets, integrator, reparam)
+    (img * grad_in).sum().backward()
+    return leaf.grad if leaf.grad is not None else torch.zeros_like(leaf)
+
+
+# --------------------------------------------------------------------------
+# Synthetic inputs
+# --------------------------------------------------------------------------
+def sphere_grid(res, center=(0.5, 0.5, 0.5), radius=0.3, dtype=torch.float64):
+    """shapes.py:557-580 without the fastsweep pass."""
+    lin = np.linspace(0, 1, res)
+    z, y, x = np.meshgrid(lin, lin, lin, indexing='ij')
+    pts = np.stack([x, y, z], -1)
+    sd = np.linalg.norm(pts - np.asarray(center), axis=-1) - radius
+    return torch.tensor(sd.astype(np.float32)).to(dtype)
+
+
+def blob_grid(res, n=24, seed=0, dtype=torch.float64):
+    """Seeded union of spheres and tori ('dragon-like' structure without
+    assets), min-combined; clipped against the box SDF as variables.py:161-166,
+    185-187 does."""
+    rng = np.random.default_rng(seed)
+    lin = np.linspace(0, 1, res)
+    z, y, x = np.meshgrid(lin, lin, lin, indexing='ij')
+    pts = np.stack([x, y, z], -1)
+    sd = np.full((res, res, res), 1e9)
+    for k in range(n):
+        c = rng.uniform(0.3, 0.7, 3)
+        if k % 2 == 0:
+            r = rng.uniform(0.05, 0.12)
+            sd = np.minimum(sd, np.linalg.norm(pts - c, axis=-1) - r)
+        else:
+            R, r = rng.uniform(0.08, 0.16), rng.uniform(0.015, 0.035)
+            ax = k % 3
+            q = pts - c
+            others = [a for a in range(3) if a != ax]
+            ring = np.sqrt(q[..., others[0]] ** 2 + q[..., others[1]] ** 2) - R
+            sd = np.minimum(sd, np.sqrt(ring ** 2 + q[..., ax] ** 2) - r)
+    lin2 = np.linspace(-0.5, 0.5, res)
+    z, y, x = np.meshgrid(lin2, lin2, lin2, indexing='ij')
+    q = np.abs(np.stack([x, y, z], -1)) - 0.49
+    box = np.linalg.norm(np.maximum(q, 0), axis=-1) + np.minimum(q.max(-1), 0) - 0.01   # shapes.py:548-550
+    sd = np.maximum(sd, box)
+    return torch.tensor(sd.astype(np.float32)).to(dtype)
