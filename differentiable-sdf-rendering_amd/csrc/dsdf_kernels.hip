@@ -1,0 +1,462 @@
+// dsdf_kernels.hip -- gfx950 (MI355X / CDNA4) kernels + C-ABI of the hot path.
+//
+// Kernel inventory (DESIGN.md has the roofline for each):
+//   k_pad_grid          clamp-to-edge padded copy of sdf.data (Texture3f.set_tensor)
+//   k_eval_cubic        A1  tricubic B-spline value/gradient/Hessian at points
+//   k_trace             A2/A4/A5 per-ray sphere tracing (standalone entry)
+//   k_render_pass<DIFF> ray-gen + trace + shade + Gaussian splat; DIFF adds the
+//                       warp-t accumulators and emits a compacted backward queue
+//   k_develop           HDRFilm.develop
+//   k_develop_adjoint   adjoint of develop -> film-block adjoint
+//   k_backward          per queued sample: film-adjoint gather, warp/shading
+//                       adjoint, 64-tap atomic scatter into dL/dsdf
+//
+// wave = 64 lanes; one lane = one film sample, consecutive lanes = consecutive
+// samples of the same pixel (reference lane order, reparam.py:140-155), so for
+// spp % 64 == 0 every wave sits in one pixel: its 64 rays walk almost the same
+// voxels (L1/L2-coherent 16-byte row loads) and its film contribution collapses
+// to one 5x5x2 window, reduced across the wave before touching memory.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <string.h>
+#include "dsdf_lane.h"
+
+using namespace dsdf;
+
+#define DSDF_BLOCK 256
+
+struct AtomicAdd {
+    __device__ __forceinline__ void operator()(float *p, float v) const { atomicAdd(p, v); }
+};
+
+// ------------------------------------------------------------------ small kernels
+__global__ void k_pad_grid(const float *__restrict__ data, int rx, int ry, int rz, float *__restrict__ out) {
+    int sx = rx + 2 * DSDF_APRON, sy = ry + 2 * DSDF_APRON, sz = rz + 2 * DSDF_APRON;
+    size_t n = (size_t)sx * sy * sz;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        int x = (int)(i % sx);
+        size_t r = i / sx;
+        int y = (int)(r % sy), z = (int)(r / sy);
+        int cx = iclamp(x - DSDF_APRON, 0, rx - 1), cy = iclamp(y - DSDF_APRON, 0, ry - 1), cz = iclamp(z - DSDF_APRON, 0, rz - 1);
+        out[i] = data[((size_t)cz * ry + cy) * rx + cx];
+    }
+}
+
+__global__ void k_eval_cubic(GridView G, const float *__restrict__ pts, int64_t n, int order,
+                             float *__restrict__ v, float *__restrict__ g, float *__restrict__ H) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    V3 x = mk(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]);
+    float vv; V3 gg; float HH[6];
+    if (order == 0) eval_cubic<0>(G, x, vv, gg, HH);
+    else if (order == 1) eval_cubic<1>(G, x, vv, gg, HH);
+    else eval_cubic<2>(G, x, vv, gg, HH);
+    if (v) v[i] = vv;
+    if (order >= 1 && g) { g[3 * i] = gg.x; g[3 * i + 1] = gg.y; g[3 * i + 2] = gg.z; }
+    if (order >= 2 && H) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) H[6 * i + k] = HH[k];
+    }
+}
+
+__global__ void k_trace(GridView G, dsdf_params P, const float *__restrict__ ro, const float *__restrict__ rd,
+                        const float *__restrict__ maxt, int64_t n, int diff, float *its_t, float *warp_t,
+                        float *warp_t_d, float *ww, float *ww_d, int32_t *steps) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    V3 o = mk(ro[3 * i], ro[3 * i + 1], ro[3 * i + 2]), d = mk(rd[3 * i], rd[3 * i + 1], rd[3 * i + 2]);
+    TraceOut t;
+    if (diff) trace_diff(G, P, o, d, maxt[i], t); else trace_plain(G, P, o, d, maxt[i], t);
+    if (its_t) its_t[i] = t.its_t;
+    if (warp_t) warp_t[i] = t.warp_t;
+    if (ww) ww[i] = t.warp_weight;
+    if (steps) steps[i] = t.steps;
+    if (warp_t_d) { warp_t_d[3 * i] = t.warp_t_d.x; warp_t_d[3 * i + 1] = t.warp_t_d.y; warp_t_d[3 * i + 2] = t.warp_t_d.z; }
+    if (ww_d) { ww_d[3 * i] = t.warp_weight_d.x; ww_d[3 * i + 1] = t.warp_weight_d.y; ww_d[3 * i + 2] = t.warp_weight_d.z; }
+}
+
+// ------------------------------------------------------------------ wave helpers
+__device__ __forceinline__ int lane_id() {
+    return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+}
+
+// exclusive prefix count of set bits below this lane (v_mbcnt_lo/hi)
+__device__ __forceinline__ uint32_t mask_prefix(uint64_t m) {
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+
+__device__ __forceinline__ int wave_sum_i32(int v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+    return v;
+}
+
+// Transposed butterfly reduction: every lane brings 64 values, lane l leaves with
+// the wave-wide sum of slot l.  63 cross-lane exchanges instead of 64 x 6.
+template <int HALF>
+__device__ __forceinline__ void wave_transpose_step(float (&v)[64], int lane) {
+    const bool upper = (lane & HALF) != 0;
+#pragma unroll
+    for (int k = 0; k < HALF; ++k) {
+        float send = upper ? v[k] : v[k + HALF];
+        float keep = upper ? v[k + HALF] : v[k];
+        v[k] = keep + __shfl_xor(send, HALF);
+    }
+}
+__device__ __forceinline__ float wave_transpose_reduce(float (&v)[64], int lane) {
+    wave_transpose_step<32>(v, lane);
+    wave_transpose_step<16>(v, lane);
+    wave_transpose_step<8>(v, lane);
+    wave_transpose_step<4>(v, lane);
+    wave_transpose_step<2>(v, lane);
+    wave_transpose_step<1>(v, lane);
+    return v[0];
+}
+
+// Queue of samples that need the backward sweep (SoA, stride = cap).
+struct Queue {
+    uint32_t *count;
+    uint32_t *lane;
+    float *rec;       // 9 rows: its_t, warp_t, wtd.xyz, ww, wwd.xyz
+    uint32_t cap;
+};
+
+// ------------------------------------------------------------------ render pass
+template <bool DIFF>
+__global__ __launch_bounds__(DSDF_BLOCK) void k_render_pass(GridView G, dsdf_params P, ViewArgs A,
+                                                            float *__restrict__ block, Queue q,
+                                                            unsigned long long *stats, uint32_t n_lanes,
+                                                            int wave_uniform) {
+    uint32_t lane = blockIdx.x * DSDF_BLOCK + threadIdx.x;
+    const bool valid = lane < n_lanes;
+    if (!valid) lane = n_lanes - 1;   // keep the wave converged for the cross-lane code
+    const int lid = lane_id();
+    Lane L = lane_setup(A, P, lane);
+    TraceOut tr;
+    if (DIFF) trace_diff(G, P, L.ray.o, L.ray.d, L.ray.maxt, tr);
+    else trace_plain(G, P, L.ray.o, L.ray.d, L.ray.maxt, tr);
+    float val = shade_value(G, A, L, tr.its_t);
+    Reproj rp = reproject(A.cam, P, L.ray.o + L.ray.d, A.W, A.H);
+
+    if (wave_uniform) {
+        // all 64 lanes share (px,py): reduce the 5x5 window x {value, weight}
+        float pfx = rp.u + (DSDF_BORDER - 0.5f), pfy = rp.v + (DSDF_BORDER - 0.5f);
+        float fx[5], fy[5];
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            fx[i] = gauss_f((float)(L.px - 2 + i) - pfx);
+            fy[i] = gauss_f((float)(L.py - 2 + i) - pfy);
+        }
+        float v[64];
+#pragma unroll
+        for (int j = 0; j < 5; ++j)
+#pragma unroll
+            for (int i = 0; i < 5; ++i) {
+                float f = fx[i] * fy[j];
+                v[j * 5 + i] = f * val;
+                v[25 + j * 5 + i] = f;
+            }
+#pragma unroll
+        for (int k = 50; k < 64; ++k) v[k] = 0.f;
+        float total = wave_transpose_reduce(v, lid);
+        if (lid < 50) {
+            int ch = lid >= 25 ? 1 : 0;
+            int s = lid - 25 * ch;
+            int j = s / 5, i = s - 5 * j;
+            int qx = L.px - 2 + i, qy = L.py - 2 + j;
+            if (qx >= 0 && qx < A.Wb && qy >= 0 && qy < A.Hb && total != 0.f)
+                atomicAdd(block + 2 * ((size_t)qy * A.Wb + qx) + ch, total);
+        }
+    } else if (valid) {
+        splat_lane(block, A.Wb, A.Hb, rp.u, rp.v, val, AtomicAdd());
+    }
+
+    bool need = false;
+    if (DIFF) {
+        bool hit = tr.its_t < INFINITY;
+        bool warp_cand = (A.flags & DSDF_REPARAM) && (fabsf(tr.warp_t) < INFINITY) && (tr.warp_weight > 0.f);
+        need = valid && (warp_cand || (hit && A.integrator == DSDF_SIMPLE_SHADING));
+        // wavefront compaction: ballot + mbcnt prefix + one atomic per wave
+        uint64_t m = __ballot(need);
+        if (m) {
+            uint32_t base = 0;
+            int leader = __ffsll((unsigned long long)m) - 1;
+            if (lid == leader) base = atomicAdd(q.count, (uint32_t)__popcll(m));
+            base = __shfl(base, leader);
+            if (need) {
+                uint32_t idx = base + mask_prefix(m);
+                if (idx < q.cap) {
+                    q.lane[idx] = lane;
+                    float *r = q.rec + idx;
+                    size_t c = q.cap;
+                    r[0] = tr.its_t; r[c] = tr.warp_t;
+                    r[2 * c] = tr.warp_t_d.x; r[3 * c] = tr.warp_t_d.y; r[4 * c] = tr.warp_t_d.z;
+                    r[5 * c] = tr.warp_weight;
+                    r[6 * c] = tr.warp_weight_d.x; r[7 * c] = tr.warp_weight_d.y; r[8 * c] = tr.warp_weight_d.z;
+                }
+            }
+        }
+    }
+    if (stats) {
+        int s_bbox = wave_sum_i32(valid && tr.steps > 0 ? 1 : 0);
+        int s_steps = wave_sum_i32(valid ? tr.steps : 0);
+        int s_hit = wave_sum_i32(valid && tr.its_t < INFINITY ? 1 : 0);
+        int s_ref = wave_sum_i32(valid ? tr.refine_steps : 0);
+        int s_val = wave_sum_i32(valid ? 1 : 0);
+        int s_need = wave_sum_i32(need ? 1 : 0);
+        if (lid == 0) {
+            atomicAdd(stats + 0, (unsigned long long)s_val);
+            atomicAdd(stats + 1, (unsigned long long)s_bbox);
+            atomicAdd(stats + 2, (unsigned long long)s_steps);
+            atomicAdd(stats + 3, (unsigned long long)s_hit);
+            atomicAdd(stats + 4, (unsigned long long)s_ref);
+            atomicAdd(stats + 6, (unsigned long long)s_need);
+        }
+    }
+}
+
+// HDRFilm.develop: crop the border, value / (weight == 0 ? 1 : weight), R=G=B.
+__global__ void k_develop(const float *__restrict__ block, int W, int H, float *__restrict__ image) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= W * H) return;
+    int y = i / W, x = i - y * W;
+    int Wb = W + 2 * DSDF_BORDER;
+    float2 b = reinterpret_cast<const float2 *>(block)[(size_t)(y + DSDF_BORDER) * Wb + x + DSDF_BORDER];
+    float w = b.y == 0.f ? 1.f : b.y;
+    float v = b.x / w;
+    image[3 * (size_t)i] = v; image[3 * (size_t)i + 1] = v; image[3 * (size_t)i + 2] = v;
+}
+
+// Adjoint of develop: dL/d(value sum) = sum_c gI_c / w ; dL/d(weight sum) = -sum_c gI_c * s / w^2.
+__global__ void k_develop_adjoint(const float *__restrict__ block, const float *__restrict__ grad_image, int W, int H,
+                                  float *__restrict__ block_adj) {
+    int Wb = W + 2 * DSDF_BORDER, Hb = H + 2 * DSDF_BORDER;
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= Wb * Hb) return;
+    int qy = i / Wb, qx = i - qy * Wb;
+    int x = qx - DSDF_BORDER, y = qy - DSDF_BORDER;
+    float2 out = make_float2(0.f, 0.f);
+    if (x >= 0 && x < W && y >= 0 && y < H) {
+        const float *gi = grad_image + 3 * ((size_t)y * W + x);
+        float gs = gi[0] + gi[1] + gi[2];
+        float2 b = reinterpret_cast<const float2 *>(block)[i];
+        if (b.y == 0.f) out = make_float2(gs, 0.f);
+        else out = make_float2(gs / b.y, -gs * b.x / (b.y * b.y));
+    }
+    reinterpret_cast<float2 *>(block_adj)[i] = out;
+}
+
+__global__ __launch_bounds__(DSDF_BLOCK) void k_backward(GridView G, dsdf_params P, ViewArgs A, Queue q,
+                                                         const float *__restrict__ block_adj,
+                                                         float *__restrict__ grad_grid, unsigned long long *stats) {
+    uint32_t count = *q.count;
+    if (count > q.cap) count = q.cap;
+    uint32_t idx = blockIdx.x * DSDF_BLOCK + threadIdx.x;
+    bool did = false;
+    if (idx < count) {
+        uint32_t lane = q.lane[idx];
+        const float *r = q.rec + idx;
+        size_t c = q.cap;
+        TraceOut tr;
+        tr.its_t = r[0]; tr.warp_t = r[c];
+        tr.warp_t_d = mk(r[2 * c], r[3 * c], r[4 * c]);
+        tr.warp_weight = r[5 * c];
+        tr.warp_weight_d = mk(r[6 * c], r[7 * c], r[8 * c]);
+        tr.steps = 0; tr.refine_steps = 0; tr.weight_sum = 0.f;
+        Lane L = lane_setup(A, P, lane);
+        did = lane_backward(G, P, A, L, tr, block_adj, grad_grid, AtomicAdd());
+    }
+    if (stats) {
+        int s = wave_sum_i32(did ? 1 : 0);
+        if (lane_id() == 0 && s) atomicAdd(stats + 5, (unsigned long long)s);
+    }
+}
+
+// ------------------------------------------------------------------ host side
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char *msg) {
+    snprintf(g_err, sizeof(g_err), "%s", msg);
+    return code;
+}
+
+static int check_launch(const char *what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        snprintf(g_err, sizeof(g_err), "%s: %s", what, hipGetErrorString(e));
+        return DSDF_ERR_LAUNCH;
+    }
+    return DSDF_OK;
+}
+
+static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+struct Workspace {
+    float *block, *block_adj;
+    uint32_t *count, *qlane;
+    float *qrec;
+    uint32_t cap;
+    size_t bytes;
+};
+
+static Workspace carve(void *base, int W, int H, int spp) {
+    Workspace ws;
+    size_t Wb = W + 2 * DSDF_BORDER, Hb = H + 2 * DSDF_BORDER;
+    size_t nl = Wb * Hb * (size_t)spp;
+    size_t off = 0;
+    char *p = (char *)base;
+    ws.block = (float *)(p + off); off += align_up(Wb * Hb * 2 * sizeof(float), 256);
+    ws.block_adj = (float *)(p + off); off += align_up(Wb * Hb * 2 * sizeof(float), 256);
+    ws.count = (uint32_t *)(p + off); off += 256;
+    ws.qlane = (uint32_t *)(p + off); off += align_up(nl * sizeof(uint32_t), 256);
+    ws.qrec = (float *)(p + off); off += align_up(nl * 9 * sizeof(float), 256);
+    ws.cap = (uint32_t)nl;
+    ws.bytes = off;
+    return ws;
+}
+
+static ViewArgs make_view_args(const dsdf_camera &cam, int W, int H, int spp, const float *offsets, uint32_t seed,
+                               int integrator, int flags) {
+    ViewArgs A;
+    A.cam = cam; A.W = W; A.H = H; A.Wb = W + 2 * DSDF_BORDER; A.Hb = H + 2 * DSDF_BORDER; A.spp = spp;
+    A.integrator = integrator; A.flags = flags; A.seed = seed; A.offsets = offsets;
+    return A;
+}
+
+static int check_render_args(const float *padded, int rx, int ry, int rz, const dsdf_params *prm,
+                             const dsdf_camera *cams, int n_views, int W, int H, int spp, int integrator,
+                             void *workspace, size_t workspace_bytes) {
+    if (!padded || !prm || !cams || !workspace) return fail(DSDF_ERR_INVALID_ARG, "null pointer argument");
+    if (rx < 1 || ry < 1 || rz < 1 || n_views < 1 || W < 1 || H < 1 || spp < 1)
+        return fail(DSDF_ERR_INVALID_ARG, "non-positive size argument");
+    if (integrator != DSDF_SILHOUETTE && integrator != DSDF_SIMPLE_SHADING)
+        return fail(DSDF_ERR_INVALID_ARG, "unknown integrator id");
+    size_t nl = (size_t)(W + 2 * DSDF_BORDER) * (H + 2 * DSDF_BORDER) * (size_t)spp;
+    // reparam.py:48-50 wavefront-size limit
+    if (nl > 0x40000000ull) return fail(DSDF_ERR_INVALID_ARG, "wavefront size exceeds 0x40000000 lanes");
+    if (workspace_bytes < dsdf_render_workspace_size(W, H, spp)) return fail(DSDF_ERR_WORKSPACE, "workspace too small");
+    return DSDF_OK;
+}
+
+extern "C" {
+
+int dsdf_version(void) { return DSDF_VERSION; }
+const char *dsdf_last_error(void) { return g_err; }
+
+void dsdf_default_params(dsdf_params *p) {
+    memset(p, 0, sizeof(*p));
+    p->trace_eps = 1e-6f; p->extra_thresh = 0.05f; p->sil_weight_offset = 0.05f; p->sil_weight_epsilon = 1e-6f;
+    p->bbox_delta = 0.05f; p->edge_eps = 0.01f; p->clamping_thresh = 0.05f; p->near_clip = 1e-2f; p->far_clip = 1e4f;
+    p->weight_strategy = 6; p->refine_steps = 10;
+}
+
+size_t dsdf_padded_size(int rx, int ry, int rz) {
+    return (size_t)(rx + 2 * DSDF_APRON) * (ry + 2 * DSDF_APRON) * (rz + 2 * DSDF_APRON);
+}
+
+int dsdf_pad_grid(const float *data, int rx, int ry, int rz, float *padded, void *stream) {
+    if (!data || !padded || rx < 1 || ry < 1 || rz < 1) return fail(DSDF_ERR_INVALID_ARG, "dsdf_pad_grid: bad argument");
+    size_t n = dsdf_padded_size(rx, ry, rz);
+    int grid = (int)((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192);
+    hipLaunchKernelGGL(k_pad_grid, dim3(grid), dim3(256), 0, (hipStream_t)stream, data, rx, ry, rz, padded);
+    return check_launch("k_pad_grid");
+}
+
+int dsdf_eval_cubic(const float *padded, int rx, int ry, int rz, const dsdf_params *prm, const float *points,
+                    int64_t n, int order, float *v, float *g, float *H, void *stream) {
+    if (!padded || !prm || !points || n < 0 || order < 0 || order > 2)
+        return fail(DSDF_ERR_INVALID_ARG, "dsdf_eval_cubic: bad argument");
+    if (n == 0) return DSDF_OK;
+    GridView G = make_view(padded, rx, ry, rz, *prm);
+    hipLaunchKernelGGL(k_eval_cubic, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, G, points, n,
+                       order, v, g, H);
+    return check_launch("k_eval_cubic");
+}
+
+int dsdf_trace(const float *padded, int rx, int ry, int rz, const dsdf_params *prm, const float *rays_o,
+               const float *rays_d, const float *maxt, int64_t n, int differentiable, float *its_t, float *warp_t,
+               float *warp_t_d, float *warp_weight, float *warp_weight_d, int32_t *steps, void *stream) {
+    if (!padded || !prm || !rays_o || !rays_d || !maxt || n < 0) return fail(DSDF_ERR_INVALID_ARG, "dsdf_trace: bad argument");
+    if (n == 0) return DSDF_OK;
+    GridView G = make_view(padded, rx, ry, rz, *prm);
+    hipLaunchKernelGGL(k_trace, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, G, *prm, rays_o,
+                       rays_d, maxt, n, differentiable, its_t, warp_t, warp_t_d, warp_weight, warp_weight_d, steps);
+    return check_launch("k_trace");
+}
+
+size_t dsdf_render_workspace_size(int width, int height, int spp) {
+    if (width < 1 || height < 1 || spp < 1) return 0;
+    return carve(nullptr, width, height, spp).bytes;
+}
+
+int dsdf_render_forward(const float *padded, int rx, int ry, int rz, const dsdf_params *prm, const dsdf_camera *cams,
+                        int n_views, int width, int height, int spp, const float *offsets, const uint32_t *seeds,
+                        int integrator, int flags, float *image_out, void *workspace, size_t workspace_bytes,
+                        int64_t *stats, void *stream) {
+    int rc = check_render_args(padded, rx, ry, rz, prm, cams, n_views, width, height, spp, integrator, workspace,
+                               workspace_bytes);
+    if (rc) return rc;
+    if (!image_out) return fail(DSDF_ERR_INVALID_ARG, "dsdf_render_forward: image_out is null");
+    if (!offsets && !seeds) return fail(DSDF_ERR_INVALID_ARG, "dsdf_render_forward: need offsets or seeds");
+    hipStream_t st = (hipStream_t)stream;
+    Workspace ws = carve(workspace, width, height, spp);
+    GridView G = make_view(padded, rx, ry, rz, *prm);
+    size_t Wb = width + 2 * DSDF_BORDER, Hb = height + 2 * DSDF_BORDER;
+    uint32_t nl = (uint32_t)(Wb * Hb * spp);
+    Queue q; q.count = ws.count; q.lane = ws.qlane; q.rec = ws.qrec; q.cap = ws.cap;
+    for (int v = 0; v < n_views; ++v) {
+        ViewArgs A = make_view_args(cams[v], width, height, spp, offsets ? offsets + (size_t)v * nl * 2 : nullptr,
+                                    seeds ? seeds[v] : 0u, integrator, flags);
+        if (hipMemsetAsync(ws.block, 0, Wb * Hb * 2 * sizeof(float), st) != hipSuccess)
+            return fail(DSDF_ERR_LAUNCH, "hipMemsetAsync(block) failed");
+        hipLaunchKernelGGL(k_render_pass<false>, dim3((nl + DSDF_BLOCK - 1) / DSDF_BLOCK), dim3(DSDF_BLOCK), 0, st, G, *prm,
+                           A, ws.block, q, (unsigned long long *)stats, nl, (spp % 64 == 0) ? 1 : 0);
+        if ((rc = check_launch("k_render_pass<primal>"))) return rc;
+        hipLaunchKernelGGL(k_develop, dim3((width * height + 255) / 256), dim3(256), 0, st, ws.block, width, height,
+                           image_out + (size_t)v * width * height * 3);
+        if ((rc = check_launch("k_develop"))) return rc;
+    }
+    return DSDF_OK;
+}
+
+int dsdf_render_backward(const float *padded, int rx, int ry, int rz, const dsdf_params *prm, const dsdf_camera *cams,
+                         int n_views, int width, int height, int spp, const float *offsets, const uint32_t *seeds,
+                         int integrator, int flags, const float *grad_image, float *grad_grid, float *image_out,
+                         void *workspace, size_t workspace_bytes, int64_t *stats, void *stream) {
+    int rc = check_render_args(padded, rx, ry, rz, prm, cams, n_views, width, height, spp, integrator, workspace,
+                               workspace_bytes);
+    if (rc) return rc;
+    if (!grad_image || !grad_grid) return fail(DSDF_ERR_INVALID_ARG, "dsdf_render_backward: null gradient buffer");
+    if (!offsets && !seeds) return fail(DSDF_ERR_INVALID_ARG, "dsdf_render_backward: need offsets or seeds");
+    hipStream_t st = (hipStream_t)stream;
+    Workspace ws = carve(workspace, width, height, spp);
+    GridView G = make_view(padded, rx, ry, rz, *prm);
+    size_t Wb = width + 2 * DSDF_BORDER, Hb = height + 2 * DSDF_BORDER;
+    uint32_t nl = (uint32_t)(Wb * Hb * spp);
+    Queue q; q.count = ws.count; q.lane = ws.qlane; q.rec = ws.qrec; q.cap = ws.cap;
+    unsigned nblk = (nl + DSDF_BLOCK - 1) / DSDF_BLOCK;
+    for (int v = 0; v < n_views; ++v) {
+        ViewArgs A = make_view_args(cams[v], width, height, spp, offsets ? offsets + (size_t)v * nl * 2 : nullptr,
+                                    seeds ? seeds[v] : 0u, integrator, flags);
+        if (hipMemsetAsync(ws.block, 0, Wb * Hb * 2 * sizeof(float), st) != hipSuccess ||
+            hipMemsetAsync(ws.count, 0, 256, st) != hipSuccess)
+            return fail(DSDF_ERR_LAUNCH, "hipMemsetAsync(workspace) failed");
+        hipLaunchKernelGGL(k_render_pass<true>, dim3(nblk), dim3(DSDF_BLOCK), 0, st, G, *prm, A, ws.block, q,
+                           (unsigned long long *)stats, nl, (spp % 64 == 0) ? 1 : 0);
+        if ((rc = check_launch("k_render_pass<grad>"))) return rc;
+        if (image_out) {
+            hipLaunchKernelGGL(k_develop, dim3((width * height + 255) / 256), dim3(256), 0, st, ws.block, width, height,
+                               image_out + (size_t)v * width * height * 3);
+            if ((rc = check_launch("k_develop"))) return rc;
+        }
+        hipLaunchKernelGGL(k_develop_adjoint, dim3((unsigned)((Wb * Hb + 255) / 256)), dim3(256), 0, st, ws.block,
+                           grad_image + (size_t)v * width * height * 3, width, height, ws.block_adj);
+        if ((rc = check_launch("k_develop_adjoint"))) return rc;
+        hipLaunchKernelGGL(k_backward, dim3(nblk), dim3(DSDF_BLOCK), 0, st, G, *prm, A, q, ws.block_adj, grad_grid,
+                           (unsigned long long *)stats);
+        if ((rc = check_launch("k_backward"))) return rc;
+    }
+    return DSDF_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,186 @@
+// dsdf_lane.h -- one lane (= one film sample) of the integrator: forward value and
+// the hand-derived adjoint.  Host/device inline; see dsdf_math.h for the role of
+// the host build (test-only).
+//
+// Reference: python/integrators/reparam.py:82-185 (eval_sample/render),
+// sdf_silhouette_reparam.py:16-29, sdf_simple_shading_reparam.py:16-26,
+// warp.py:99-123, shapes.py:347-366.  The reference obtains the backward from
+// Dr.Jit AD; the adjoint below is derived by hand (DESIGN.md "Backward").
+#pragma once
+#include "dsdf_math.h"
+
+namespace dsdf {
+
+struct ViewArgs {
+    dsdf_camera cam;
+    int W, H, Wb, Hb, spp;
+    int integrator, flags;
+    uint32_t seed;
+    const float *offsets;   // per-lane (r0,r1) or nullptr -> built-in sampler
+};
+
+struct Lane {
+    int px, py;             // block pixel (0..Wb-1, 0..Hb-1)
+    CamRay ray;
+};
+
+// lane -> pixel, jitter, camera ray (reparam.py:140-171, 90-95)
+DSDF_HD Lane lane_setup(const ViewArgs &A, const dsdf_params &P, uint32_t lane) {
+    Lane L;
+    uint32_t pix = lane / (uint32_t)A.spp;
+    L.py = (int)(pix / (uint32_t)A.Wb);
+    L.px = (int)(pix - (uint32_t)L.py * (uint32_t)A.Wb);
+    float r0, r1;
+    if (A.offsets) { r0 = A.offsets[2 * (size_t)lane]; r1 = A.offsets[2 * (size_t)lane + 1]; }
+    else sampler_next_2d(A.seed, lane, r0, r1);
+    float fx = (float)(L.px - DSDF_BORDER) + r0;
+    float fy = (float)(L.py - DSDF_BORDER) + r1;
+    L.ray = camera_ray(A.cam, P, fx, fy, A.W, A.H);
+    return L;
+}
+
+DSDF_HD V3 light_dir() { const float s = 0.57735026918962576f; return mk(s, s, s); }
+
+// Value of the `sample()` body given the trace result.
+DSDF_HD float shade_value(const GridView &G, const ViewArgs &A, const Lane &L, float its_t) {
+    bool hit = its_t < INFINITY;
+    if (!hit) return 0.f;
+    if (A.integrator == DSDF_SILHOUETTE) return 1.f;
+    // simple shading: n = normalize(grad sdf(o + t d)) ; max(n.l, 0)
+    float v; V3 g; float H[6];
+    eval_cubic<1>(G, fma3(its_t, L.ray.d, L.ray.o), v, g, H);
+    V3 n = g * (1.f / sqrtf(dot(g, g)));
+    return fmaxf(dot(n, light_dir()), 0.f);
+}
+
+// ImageBlock::put for one lane: 4x4 window of the radius-2 Gaussian around
+// pos_f = uv + border - 0.5.  Internal film block has 2 channels (value, weight):
+// both integrators on the path emit R=G=B.
+template <class Adder>
+DSDF_HD void splat_lane(float *block, int Wb, int Hb, float u, float v, float val, Adder add) {
+    float pfx = u + (DSDF_BORDER - 0.5f), pfy = v + (DSDF_BORDER - 0.5f);
+    int x0 = (int)ceilf(pfx - DSDF_FILTER_RADIUS), y0 = (int)ceilf(pfy - DSDF_FILTER_RADIUS);
+    float wx[4], wy[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        wx[i] = gauss_f((float)(x0 + i) - pfx);
+        wy[i] = gauss_f((float)(y0 + i) - pfy);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        int qy = y0 + j;
+        if (qy < 0 || qy >= Hb) continue;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int qx = x0 + i;
+            if (qx < 0 || qx >= Wb) continue;
+            float f = wx[i] * wy[j];
+            if (f == 0.f) continue;
+            float *dst = block + 2 * ((size_t)qy * Wb + qx);
+            if (val != 0.f) add(dst, f * val);
+            add(dst + 1, f);
+        }
+    }
+}
+
+// Adjoint of one gradient-pass sample.  `tr` holds the (detached) trace outputs,
+// block_adj the adjoint of the 2-channel film block.  Accumulates into grad_grid.
+template <class Adder>
+DSDF_HD bool lane_backward(const GridView &G, const dsdf_params &P, const ViewArgs &A, const Lane &L,
+                           const TraceOut &tr, const float *block_adj, float *grad_grid, Adder add) {
+    const V3 o = L.ray.o, d = L.ray.d;
+    bool hit = tr.its_t < INFINITY;
+    // --- film adjoint gather (ImageBlock::put is linear in the values and
+    //     differentiable in the position through the filter weights)
+    Reproj rp = reproject(A.cam, P, o + d, A.W, A.H);
+    float pfx = rp.u + (DSDF_BORDER - 0.5f), pfy = rp.v + (DSDF_BORDER - 0.5f);
+    int x0 = (int)ceilf(pfx - DSDF_FILTER_RADIUS), y0 = (int)ceilf(pfy - DSDF_FILTER_RADIUS);
+    float val = 0.f;
+    V3 ghit = mk(0.f, 0.f, 0.f); float Hhit[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}; float vhit = 0.f;
+    V3 phit = o;
+    if (hit) {
+        if (A.integrator == DSDF_SILHOUETTE) val = 1.f;
+        else {
+            phit = fma3(tr.its_t, d, o);
+            eval_cubic<2>(G, phit, vhit, ghit, Hhit);
+            float gl = sqrtf(dot(ghit, ghit));
+            val = fmaxf(dot(ghit, light_dir()) / gl, 0.f);
+        }
+    }
+    float a_val = 0.f, a_w = 0.f, u_bar = 0.f, v_bar = 0.f;
+    float wx[4], wy[4], dwx[4], dwy[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        float rx = (float)(x0 + i) - pfx, ry = (float)(y0 + i) - pfy;
+        wx[i] = gauss_f(rx); dwx[i] = gauss_df(rx);
+        wy[i] = gauss_f(ry); dwy[i] = gauss_df(ry);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        int qy = y0 + j;
+        if (qy < 0 || qy >= A.Hb) continue;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int qx = x0 + i;
+            if (qx < 0 || qx >= A.Wb) continue;
+            const float *ba = block_adj + 2 * ((size_t)qy * A.Wb + qx);
+            float bs = ba[0], bw = ba[1];
+            float f = wx[i] * wy[j];
+            a_val = fmaf(f, bs, a_val);
+            a_w = fmaf(f, bw, a_w);
+            float s = bs * val + bw;                 // sum_c Bbar_c * a_c  (a_W = 1)
+            u_bar = fmaf(s, -dwx[i] * wy[j], u_bar); // d f / d u = -F'(rel_x) F(rel_y)
+            v_bar = fmaf(s, -wx[i] * dwy[j], v_bar);
+        }
+    }
+    // a_c = val * div * rw (c = value channel), a_W = div * rw; div, rw have value 1
+    float div_bar = val * a_val + a_w;
+    float rw_bar = rp.inside ? div_bar : 0.f;        // reparam.py:103 (select(rw>0, rw/detach(rw), 1))
+    // --- adjoint of the warped direction d' (value d): through uv and log importance
+    V3 dir_bar = mk(0.f, 0.f, 0.f);
+    {
+        float cot = 1.f / A.cam.tan_half_fov;
+        float iz = 1.f / rp.ref.z;
+        // u = W (0.5 - 0.5 cot x/z), v = H (0.5 - 0.5 aspect cot y/z), H*aspect = W
+        float ku = -0.5f * (float)A.W * cot, kv = ku;
+        V3 ref_bar = mk(u_bar * ku * iz, v_bar * kv * iz,
+                        -(u_bar * ku * rp.ref.x + v_bar * kv * rp.ref.y) * iz * iz);
+        // log rw = log dist - 3 log z
+        float id2 = 1.f / (rp.dist * rp.dist);
+        ref_bar = ref_bar + rw_bar * mk(rp.ref.x * id2, rp.ref.y * id2, rp.ref.z * id2 - 3.f * iz);
+        dir_bar = mk(A.cam.left[0] * ref_bar.x + A.cam.up[0] * ref_bar.y + A.cam.dir[0] * ref_bar.z,
+                     A.cam.left[1] * ref_bar.x + A.cam.up[1] * ref_bar.y + A.cam.dir[1] * ref_bar.z,
+                     A.cam.left[2] * ref_bar.x + A.cam.up[2] * ref_bar.y + A.cam.dir[2] * ref_bar.z);
+    }
+    bool did = false;
+    // --- shading channel (shapes.py:347-366): t = replace_grad(t, v(p)/c), n = normalize(grad(p))
+    if (hit && A.integrator == DSDF_SIMPLE_SHADING) {
+        float g2 = dot(ghit, ghit);
+        float gl = sqrtf(g2);
+        V3 n = ghit * (1.f / gl);
+        V3 l = light_dir();
+        float ndl = dot(n, l);
+        float s_bar = (ndl > 0.f) ? a_val : 0.f;                  // d max(n.l,0); a_val = sum over rgb handled in develop adjoint
+        V3 G_bar = (s_bar / gl) * (l - ndl * n);                  // (I - n n^T) l / |g|
+        V3 p_bar = symmul(Hhit, G_bar);
+        float c = dot(ghit, -d);
+        float t_bar = dot(p_bar, d);
+        float v0_bar = t_bar / c;
+        dir_bar = dir_bar + tr.its_t * p_bar + (v0_bar * tr.its_t) * ghit;
+        scatter_cubic(G, grad_grid, phit, v0_bar, G_bar, add);
+        did = true;
+    }
+    // --- warp channel
+    if (A.flags & DSDF_REPARAM) {
+        WarpCoef wc;
+        if (warp_coefficients(G, P, o, d, tr, wc)) {
+            float vw_bar = dot(wc.cdir, dir_bar) + wc.a * div_bar;
+            V3 gw_bar = div_bar * wc.b;
+            scatter_cubic(G, grad_grid, fma3(tr.warp_t, d, o), vw_bar, gw_bar, add);
+            did = true;
+        }
+    }
+    return did;
+}
+
+}  // namespace dsdf

@@ -1,0 +1,562 @@
+// dsdf_math.h -- per-ray arithmetic of the hot path (host/device inline functions).
+//
+// Used by the HIP kernels in dsdf_kernels.hip.  The same header is compiled for
+// the host by tests/harness (a TEST-ONLY build that lets the CPU test-suite check
+// this arithmetic against the oracle without a GPU; the product never loads it).
+//
+// Reference citations are relative to the reference root (python/...).
+#pragma once
+#include <math.h>
+#include <stdint.h>
+#include "../../include/dsdf.h"
+
+#if defined(__HIPCC__)
+#define DSDF_HD __host__ __device__ __forceinline__
+#else
+#define DSDF_HD inline
+#endif
+
+namespace dsdf {
+
+struct V3 { float x, y, z; };
+DSDF_HD V3 mk(float x, float y, float z) { V3 r; r.x = x; r.y = y; r.z = z; return r; }
+DSDF_HD V3 operator+(V3 a, V3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
+DSDF_HD V3 operator-(V3 a, V3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
+DSDF_HD V3 operator-(V3 a) { return mk(-a.x, -a.y, -a.z); }
+DSDF_HD V3 operator*(V3 a, float s) { return mk(a.x * s, a.y * s, a.z * s); }
+DSDF_HD V3 operator*(float s, V3 a) { return mk(a.x * s, a.y * s, a.z * s); }
+DSDF_HD V3 operator*(V3 a, V3 b) { return mk(a.x * b.x, a.y * b.y, a.z * b.z); }
+DSDF_HD float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+DSDF_HD V3 fma3(float s, V3 a, V3 b) { return mk(fmaf(s, a.x, b.x), fmaf(s, a.y, b.y), fmaf(s, a.z, b.z)); }
+DSDF_HD float drsign(float x) { return x >= 0.f ? 1.f : -1.f; }   // dr.sign: sign(0)=+1
+// symmetric 3x3 (xx,yy,zz,xy,xz,yz) times vector
+DSDF_HD V3 symmul(const float H[6], V3 a) {
+    return mk(H[0] * a.x + H[3] * a.y + H[4] * a.z,
+              H[3] * a.x + H[1] * a.y + H[5] * a.z,
+              H[4] * a.x + H[5] * a.y + H[2] * a.z);
+}
+
+// ---------------------------------------------------------------------------
+// Padded grid view.  padded[(z+3)*sxy + (y+3)*sx + (x+3)] = data[clamp(z),clamp(y),clamp(x)]
+// for -3 <= x <= rx+2: with the base tap index clamped to [-3, r-1] the four taps
+// per axis reproduce per-tap clamp-to-edge exactly (Dr.Jit wrap mode Clamp).
+// ---------------------------------------------------------------------------
+#define DSDF_APRON 3
+struct GridView {
+    const float *p;
+    int rx, ry, rz;
+    int sx, sxy;
+    float tx, ty, tz;   // sdf.p translation
+};
+
+DSDF_HD GridView make_view(const float *padded, int rx, int ry, int rz, const dsdf_params &prm) {
+    GridView g;
+    g.p = padded; g.rx = rx; g.ry = ry; g.rz = rz;
+    g.sx = rx + 2 * DSDF_APRON; g.sxy = g.sx * (ry + 2 * DSDF_APRON);
+    g.tx = prm.sdf_p[0]; g.ty = prm.sdf_p[1]; g.tz = prm.sdf_p[2];
+    return g;
+}
+
+// Uniform cubic B-spline basis (taps i-1..i+2) and derivatives; Dr.Jit texture.h.
+DSDF_HD void bspline_w(float a, float w[4]) {
+    float a2 = a * a, a3 = a2 * a;
+    const float s = 1.f / 6.f;
+    w[0] = s * (-a3 + 3.f * a2 - 3.f * a + 1.f);
+    w[1] = s * (3.f * a3 - 6.f * a2 + 4.f);
+    w[2] = s * (-3.f * a3 + 3.f * a2 + 3.f * a + 1.f);
+    w[3] = s * a3;
+}
+DSDF_HD void bspline_dw(float a, float w[4]) {
+    float a2 = a * a;
+    const float s = 1.f / 6.f;
+    w[0] = s * (-3.f * a2 + 6.f * a - 3.f);
+    w[1] = s * (9.f * a2 - 12.f * a);
+    w[2] = s * (-9.f * a2 + 6.f * a + 3.f);
+    w[3] = s * (3.f * a2);
+}
+DSDF_HD void bspline_ddw(float a, float w[4]) {
+    w[0] = 1.f - a; w[1] = 3.f * a - 2.f; w[2] = 1.f - 3.f * a; w[3] = a;
+}
+
+struct CubicSetup {
+    int ix, iy, iz;      // unclamped base tap index (floor(pf) - 1)
+    float ax, ay, az;    // fractional offsets
+};
+
+DSDF_HD int iclamp(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+DSDF_HD CubicSetup cubic_setup(const GridView &G, V3 x) {
+    // pf = (x - p) * res - 0.5 ; shapes.py:412 + Dr.Jit texel-centre convention
+    float pfx = fmaf(x.x - G.tx, (float)G.rx, -0.5f);
+    float pfy = fmaf(x.y - G.ty, (float)G.ry, -0.5f);
+    float pfz = fmaf(x.z - G.tz, (float)G.rz, -0.5f);
+    float fx = floorf(pfx), fy = floorf(pfy), fz = floorf(pfz);
+    CubicSetup s;
+    s.ax = pfx - fx; s.ay = pfy - fy; s.az = pfz - fz;
+    // guard against NaN/huge coordinates (masked lanes): clamp in float first
+    fx = fminf(fmaxf(fx, -1.0e6f), 1.0e6f); fy = fminf(fmaxf(fy, -1.0e6f), 1.0e6f); fz = fminf(fmaxf(fz, -1.0e6f), 1.0e6f);
+    if (!(fx == fx)) fx = 0.f; if (!(fy == fy)) fy = 0.f; if (!(fz == fz)) fz = 0.f;
+    s.ix = (int)fx - 1; s.iy = (int)fy - 1; s.iz = (int)fz - 1;
+    return s;
+}
+
+DSDF_HD void load_row4(const float *p, float r[4]) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+    f4u t = *reinterpret_cast<const f4u *>(p);
+    r[0] = t.x; r[1] = t.y; r[2] = t.z; r[3] = t.w;
+#else
+    r[0] = p[0]; r[1] = p[1]; r[2] = p[2]; r[3] = p[3];
+#endif
+}
+
+// A1: Grid3d.eval / eval_and_grad / eval_all (shapes.py:420-450).
+// ORDER 0: v; 1: v,g; 2: v,g,H (xx,yy,zz,xy,xz,yz).  Gradient scaled by res,
+// Hessian by res_i*res_j (Dr.Jit eval_cubic_grad / eval_cubic_hessian).
+template <int ORDER>
+DSDF_HD void eval_cubic(const GridView &G, V3 x, float &v, V3 &g, float H[6]) {
+    CubicSetup s = cubic_setup(G, x);
+    int bx = iclamp(s.ix, -DSDF_APRON, G.rx - 1) + DSDF_APRON;
+    int by = iclamp(s.iy, -DSDF_APRON, G.ry - 1) + DSDF_APRON;
+    int bz = iclamp(s.iz, -DSDF_APRON, G.rz - 1) + DSDF_APRON;
+    const float *base = G.p + (size_t)bz * G.sxy + (size_t)by * G.sx + bx;
+    float wx[4], wy[4], wz[4], dwx[4], dwy[4], dwz[4], ddwx[4], ddwy[4], ddwz[4];
+    bspline_w(s.ax, wx); bspline_w(s.ay, wy); bspline_w(s.az, wz);
+    if (ORDER >= 1) { bspline_dw(s.ax, dwx); bspline_dw(s.ay, dwy); bspline_dw(s.az, dwz); }
+    if (ORDER >= 2) { bspline_ddw(s.ax, ddwx); bspline_ddw(s.ay, ddwy); bspline_ddw(s.az, ddwz); }
+    float av = 0.f, agx = 0.f, agy = 0.f, agz = 0.f;
+    float axx = 0.f, ayy = 0.f, azz = 0.f, axy = 0.f, axz = 0.f, ayz = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        float y00 = 0.f, y01 = 0.f, y02 = 0.f, y10 = 0.f, y11 = 0.f, y20 = 0.f;  // y{dy}{dx}
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float r[4];
+            load_row4(base + k * G.sxy + j * G.sx, r);
+            float s0 = wx[0] * r[0] + wx[1] * r[1] + wx[2] * r[2] + wx[3] * r[3];
+            y00 = fmaf(wy[j], s0, y00);
+            if (ORDER >= 1) {
+                float s1 = dwx[0] * r[0] + dwx[1] * r[1] + dwx[2] * r[2] + dwx[3] * r[3];
+                y01 = fmaf(wy[j], s1, y01);
+                y10 = fmaf(dwy[j], s0, y10);
+                if (ORDER >= 2) {
+                    float s2 = ddwx[0] * r[0] + ddwx[1] * r[1] + ddwx[2] * r[2] + ddwx[3] * r[3];
+                    y02 = fmaf(wy[j], s2, y02);
+                    y11 = fmaf(dwy[j], s1, y11);
+                    y20 = fmaf(ddwy[j], s0, y20);
+                }
+            }
+        }
+        av = fmaf(wz[k], y00, av);
+        if (ORDER >= 1) {
+            agx = fmaf(wz[k], y01, agx);
+            agy = fmaf(wz[k], y10, agy);
+            agz = fmaf(dwz[k], y00, agz);
+            if (ORDER >= 2) {
+                axx = fmaf(wz[k], y02, axx);
+                ayy = fmaf(wz[k], y20, ayy);
+                azz = fmaf(ddwz[k], y00, azz);
+                axy = fmaf(wz[k], y11, axy);
+                axz = fmaf(dwz[k], y01, axz);
+                ayz = fmaf(dwz[k], y10, ayz);
+            }
+        }
+    }
+    v = av;
+    if (ORDER >= 1) {
+        float fx = (float)G.rx, fy = (float)G.ry, fz = (float)G.rz;
+        g = mk(agx * fx, agy * fy, agz * fz);
+        if (ORDER >= 2) {
+            H[0] = axx * fx * fx; H[1] = ayy * fy * fy; H[2] = azz * fz * fz;
+            H[3] = axy * fx * fy; H[4] = axz * fx * fz; H[5] = ayz * fy * fz;
+        }
+    }
+}
+
+DSDF_HD float eval_value(const GridView &G, V3 x) {
+    float v; V3 g; float H[6];
+    eval_cubic<0>(G, x, v, g, H);
+    return v;
+}
+
+// Adjoint of eval_cubic w.r.t. the grid: grad[tap] += cv*W + cg . (res * dW).
+// `add(ptr, val)` is an atomic add on the device.  Indices are clamped per tap
+// into the caller's unpadded (rz,ry,rx) gradient grid.
+template <class Adder>
+DSDF_HD void scatter_cubic(const GridView &G, float *grad, V3 x, float cv, V3 cg, Adder add) {
+    CubicSetup s = cubic_setup(G, x);
+    float wx[4], wy[4], wz[4], dwx[4], dwy[4], dwz[4];
+    bspline_w(s.ax, wx); bspline_w(s.ay, wy); bspline_w(s.az, wz);
+    bspline_dw(s.ax, dwx); bspline_dw(s.ay, dwy); bspline_dw(s.az, dwz);
+    float gx = cg.x * (float)G.rx, gy = cg.y * (float)G.ry, gz = cg.z * (float)G.rz;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        int zi = iclamp(s.iz + k, 0, G.rz - 1);
+        float azv = wz[k], azd = dwz[k] * gz;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int yi = iclamp(s.iy + j, 0, G.ry - 1);
+            float *row = grad + ((size_t)zi * G.ry + yi) * G.rx;
+            float c0 = azv * wy[j] * cv + azd * wy[j] + azv * dwy[j] * gy;   // multiplies wx
+            float c1 = azv * wy[j] * gx;                                     // multiplies dwx
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                int xi = iclamp(s.ix + i, 0, G.rx - 1);
+                add(row + xi, fmaf(c0, wx[i], c1 * dwx[i]));
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Bounding box helpers (Mitsuba BoundingBox3f::ray_intersect/contains;
+// math_util.py:31-41).  Grid3d.bbox() = unit cube +- delta (shapes.py:416-418).
+// ---------------------------------------------------------------------------
+DSDF_HD V3 closest_axis(V3 m) {
+    // strict '<' as in shapes.py:158-161 / math_util.py:36-39 (ties -> zero vector)
+    V3 n = mk(0.f, 0.f, 0.f);
+    if (m.x < m.y && m.x < m.z) n.x = 1.f;
+    if (m.y < m.z && m.y < m.x) n.y = 1.f;
+    if (m.z < m.x && m.z < m.y) n.z = 1.f;
+    return n;
+}
+
+DSDF_HD float bbox_distance_inside_d(V3 x, float lo, float hi, V3 &dd) {
+    float mlo = fminf(fminf(x.x - lo, x.y - lo), x.z - lo);
+    float mhi = fminf(fminf(hi - x.x, hi - x.y), hi - x.z);
+    float dist = fmaxf(0.f, fminf(mlo, mhi));
+    V3 dmax = mk(fabsf(hi - x.x), fabsf(hi - x.y), fabsf(hi - x.z));
+    V3 dmin = mk(fabsf(lo - x.x), fabsf(lo - x.y), fabsf(lo - x.z));
+    V3 n = closest_axis(mk(fminf(dmin.x, dmax.x), fminf(dmin.y, dmax.y), fminf(dmin.z, dmax.z)));
+    if (dist > 0.f)
+        dd = mk(n.x * drsign(dmax.x - dmin.x), n.y * drsign(dmax.y - dmin.y), n.z * drsign(dmax.z - dmin.z));
+    else
+        dd = mk(0.f, 0.f, 0.f);
+    return dist;
+}
+
+struct BoxHit { bool hit, inside; float mint, maxt; };
+
+DSDF_HD BoxHit bbox_ray_intersect(float lo, float hi, V3 o, V3 d) {
+    BoxHit b;
+    bool ok = (d.x != 0.f || o.x > lo || o.x < hi) && (d.y != 0.f || o.y > lo || o.y < hi) &&
+              (d.z != 0.f || o.z > lo || o.z < hi);
+    float rx = 1.f / d.x, ry = 1.f / d.y, rz = 1.f / d.z;
+    float t1x = (lo - o.x) * rx, t2x = (hi - o.x) * rx;
+    float t1y = (lo - o.y) * ry, t2y = (hi - o.y) * ry;
+    float t1z = (lo - o.z) * rz, t2z = (hi - o.z) * rz;
+    b.mint = fmaxf(fmaxf(fminf(t1x, t2x), fminf(t1y, t2y)), fminf(t1z, t2z));
+    b.maxt = fminf(fminf(fmaxf(t1x, t2x), fmaxf(t1y, t2y)), fmaxf(t1z, t2z));
+    b.hit = ok && (b.maxt >= b.mint);
+    b.inside = o.x >= lo && o.x <= hi && o.y >= lo && o.y <= hi && o.z >= lo && o.z <= hi;
+    return b;
+}
+
+// ---------------------------------------------------------------------------
+// A3: SDFBase.eval_trace_weight (shapes.py:68-113), analytic-gradient branch.
+// ---------------------------------------------------------------------------
+DSDF_HD float eval_trace_weight(const dsdf_params &P, V3 d, int i, float lo, float hi, V3 x,
+                                float v, V3 g, const float H[6], V3 &weight_d) {
+    float n_dot_d = dot(g, d);
+    float n_dot_n = dot(g, g);
+    float ratio = n_dot_d / n_dot_n;
+    float denom = P.sil_weight_epsilon + fabsf(v) + P.sil_weight_offset * n_dot_d * ratio;
+    float dist_w = 1.f / (denom * denom * denom);
+    V3 bd_d;
+    float bd = bbox_distance_inside_d(x, lo, hi, bd_d);
+    const float bbox_eps = 0.01f;
+    float bw = i > 0 ? fminf(bd, bbox_eps) / bbox_eps : 1.f;
+    V3 bw_d = (i > 0 && bd < bbox_eps) ? bd_d * (1.f / bbox_eps) : mk(0.f, 0.f, 0.f);
+    V3 grad = (2.f * ratio) * (d - ratio * g);
+    V3 denom_d = drsign(v) * g + P.sil_weight_offset * symmul(H, grad);
+    V3 dist_w_d = (-3.f * dist_w / denom) * denom_d;
+    weight_d = dist_w * bw_d + bw * dist_w_d;
+    return dist_w * bw;
+}
+
+struct TraceOut {
+    float its_t, warp_t, warp_weight, weight_sum;
+    V3 warp_t_d, warp_weight_d;
+    int steps, refine_steps;
+};
+
+// A5: refinement loop (shapes.py:245-257 / 323-334)
+DSDF_HD float refine_hit(const GridView &G, const dsdf_params &P, V3 o, V3 d, float its_t, float trace_eps, int &nref) {
+    nref = 0;
+    if (!(its_t < INFINITY)) return its_t;
+    bool refining = true;
+    int i = 0;
+    while (refining) {
+        float md = eval_value(G, fma3(its_t, d, o));
+        its_t += md * (10.f / (float)(10 + i));
+        refining = (md <= 0.f) || (md > trace_eps);
+        ++i;
+        refining = refining && (i < P.refine_steps);
+    }
+    nref = i;
+    return its_t;
+}
+
+// A4: SDFBase.ray_intersect_non_diff (shapes.py:290-339)
+DSDF_HD void trace_plain(const GridView &G, const dsdf_params &P, V3 o, V3 d_in, float ray_maxt, TraceOut &out) {
+    float inv = 1.f / sqrtf(dot(d_in, d_in));
+    V3 d = d_in * inv;
+    float lo = -P.bbox_delta, hi = 1.f + P.bbox_delta;
+    BoxHit b = bbox_ray_intersect(lo, hi, o, d);
+    bool active = b.hit && (b.mint > 0.f || b.inside);
+    float maxt = fminf(b.maxt, ray_maxt);
+    float trace_eps = P.trace_eps * fmaxf(maxt, 1.f);
+    float its_t = INFINITY;
+    float t = b.inside ? 0.f : b.mint + 1e-5f;
+    int steps = 0;
+    while (active) {
+        float v = eval_value(G, fma3(t, d, o));
+        bool hit = v < trace_eps;
+        if (hit) its_t = t;
+        float cur = hit ? 0.f : fabsf(v);
+        t += cur;
+        active = (t <= maxt) && !hit;
+        ++steps;
+    }
+    out.steps = steps;
+    out.its_t = P.refine_steps > 0 ? refine_hit(G, P, o, d, its_t, trace_eps, out.refine_steps) : its_t;
+    if (P.refine_steps <= 0) out.refine_steps = 0;
+    out.warp_t = 0.f; out.warp_weight = 0.f; out.weight_sum = 0.f;
+    out.warp_t_d = mk(0.f, 0.f, 0.f); out.warp_weight_d = mk(0.f, 0.f, 0.f);
+}
+
+// A2: SDFBase.ray_intersect (shapes.py:115-288) -- differentiable sphere tracing
+// with the weighted warp-t accumulation and its analytic direction derivative.
+DSDF_HD void trace_diff(const GridView &G, const dsdf_params &P, V3 o, V3 d_in, float ray_maxt, TraceOut &out) {
+    float invn = 1.f / sqrtf(dot(d_in, d_in));
+    V3 d = d_in * invn;                                              // :124
+    float lo = -P.bbox_delta, hi = 1.f + P.bbox_delta;
+    BoxHit b = bbox_ray_intersect(lo, hi, o, d);
+    bool hit_box = b.hit && (b.mint > 0.f || b.inside);              // :132
+    bool active = hit_box;
+    float maxt = fminf(b.maxt, ray_maxt);                            // :136
+    float trace_eps = P.trace_eps * fmaxf(maxt, 1.f);                // :137
+    float its_t = INFINITY;
+    float t = b.inside ? 0.f : b.mint + 1e-5f;                       // :141
+    float warp_t = 0.f, prev_sd = 0.f, wsum = 0.f, ews = 0.f;
+    V3 prev_gc = mk(0.f, 0.f, 0.f), mixed = mk(0.f, 0.f, 0.f), wdsum = mk(0.f, 0.f, 0.f), ews_d = mk(0.f, 0.f, 0.f);
+    int i = 0;
+    // entry-face derivative of t (:156-164)
+    V3 pb = fma3(t, d, o);
+    V3 n = closest_axis(mk(fminf(fabsf(lo - pb.x), fabsf(hi - pb.x)), fminf(fabsf(lo - pb.y), fabsf(hi - pb.y)),
+                           fminf(fabsf(lo - pb.z), fabsf(hi - pb.z))));
+    float ddn = dot(d, n);
+    V3 t_d = mk(0.f, 0.f, 0.f);
+    if (!b.inside && fabsf(ddn) > 0.f) t_d = n * (-t / ddn);
+
+    while (active) {
+        V3 x = fma3(t, d, o);
+        float v; V3 g; float H[6];
+        eval_cubic<2>(G, x, v, g, H);                                // :178
+        bool hit = v < trace_eps;                                    // :185
+        if (hit) its_t = t;
+        float sd = fabsf(v);
+        V3 w_d;
+        float w = eval_trace_weight(P, d, i, lo, hi, x, v, g, H, w_d);   // :188
+        float inv_den = 1.f / fminf(P.extra_thresh, sd);             // :198
+        float diff = prev_sd - sd;
+        ews += (diff >= 0.f) ? diff * inv_den : 0.f;
+        ews = fminf(ews, 1.f);                                       // :201
+        float cur = hit ? 0.f : sd;                                  // :203
+        float seg = 0.5f * (cur + prev_sd);
+        float winc = seg * w * ews;                                  // :205-207
+        wsum += winc;
+        warp_t += winc * t;
+        // convert_deriv(f) = t*f + dot(d,f)*t_d  (:126-127)
+        w_d = fma3(dot(d, w_d), t_d, t * w_d);
+        V3 gc = fma3(dot(d, g), t_d, t * g);
+        V3 seg_d = 0.5f * (gc + prev_gc);
+        V3 sd_d = drsign(v) * gc;                                    // :220-221
+        V3 ewd = (prev_gc - sd_d) * inv_den;
+        if (v < P.extra_thresh) ewd = ewd - (diff * inv_den * inv_den) * sd_d;
+        if (diff > 0.f) ews_d = ews_d + ewd;
+        if (ews >= 1.f || ews <= 0.f) ews_d = mk(0.f, 0.f, 0.f);    // :226
+        w_d = w * ews_d + ews * w_d;                                 // :227
+        w *= ews;
+        V3 winc_d = w * seg_d + seg * w_d;                           // :230
+        mixed = mixed + t * winc_d + (w * seg) * t_d;
+        t_d = t_d + gc;
+        wdsum = wdsum + winc_d;
+        ++i;
+        t += cur;
+        prev_sd = sd;
+        prev_gc = gc;
+        active = (t <= maxt) && !hit;                                // :238
+    }
+    out.steps = i;
+    out.weight_sum = wsum;
+    out.its_t = P.refine_steps > 0 ? refine_hit(G, P, o, d, its_t, trace_eps, out.refine_steps) : its_t;
+    if (P.refine_steps <= 0) out.refine_steps = 0;
+    float inv = 1.f / wsum;                                          // :259-261
+    warp_t *= inv;
+    V3 warp_t_d = (mixed - warp_t * wdsum) * inv;
+    float ww = fminf(fmaxf(wsum, 0.f), 1.f);                         // :271-272
+    V3 ww_d = (wsum > 0.f && wsum < 1.f) ? wdsum : mk(0.f, 0.f, 0.f);
+    bool invalid = (wsum < 1e-7f) || !hit_box;                       // :278-283
+    if (invalid) {
+        warp_t = INFINITY; warp_t_d = mk(0.f, 0.f, 0.f); ww = 0.f; ww_d = mk(0.f, 0.f, 0.f);
+    }
+    out.warp_t = warp_t; out.warp_t_d = warp_t_d; out.warp_weight = ww; out.warp_weight_d = ww_d;
+}
+
+// ---------------------------------------------------------------------------
+// Sensor (Mitsuba `perspective`) and film (C.3)
+// ---------------------------------------------------------------------------
+struct CamRay { V3 o, d, dl; float maxt; };
+
+DSDF_HD CamRay camera_ray(const dsdf_camera &c, const dsdf_params &P, float px, float py, int W, int H) {
+    float aspect = (float)W / (float)H;
+    float sx = px / (float)W, sy = py / (float)H;
+    V3 dl = mk((1.f - 2.f * sx) * c.tan_half_fov, (1.f - 2.f * sy) * c.tan_half_fov / aspect, 1.f);
+    dl = dl * (1.f / sqrtf(dot(dl, dl)));
+    CamRay r;
+    r.dl = dl;
+    r.d = mk(c.left[0] * dl.x + c.up[0] * dl.y + c.dir[0] * dl.z,
+             c.left[1] * dl.x + c.up[1] * dl.y + c.dir[1] * dl.z,
+             c.left[2] * dl.x + c.up[2] * dl.y + c.dir[2] * dl.z);
+    float near_t = P.near_clip / dl.z;
+    r.o = mk(c.origin[0], c.origin[1], c.origin[2]) + near_t * r.d;
+    r.maxt = P.far_clip / dl.z - near_t;
+    return r;
+}
+
+struct Reproj { float u, v; V3 ref; float dist; bool inside; };
+
+// `sensor.sample_direction(it)` for it.p = o + d (reparam.py:100-105): film position
+// (pixels) and whether the importance is non-zero.
+DSDF_HD Reproj reproject(const dsdf_camera &c, const dsdf_params &P, V3 p, int W, int H) {
+    V3 q = p - mk(c.origin[0], c.origin[1], c.origin[2]);
+    Reproj r;
+    r.ref = mk(c.left[0] * q.x + c.left[1] * q.y + c.left[2] * q.z,
+               c.up[0] * q.x + c.up[1] * q.y + c.up[2] * q.z,
+               c.dir[0] * q.x + c.dir[1] * q.y + c.dir[2] * q.z);
+    float aspect = (float)W / (float)H;
+    float cot = 1.f / c.tan_half_fov;
+    float sx = 0.5f - 0.5f * cot * r.ref.x / r.ref.z;
+    float sy = 0.5f - 0.5f * aspect * cot * r.ref.y / r.ref.z;
+    r.inside = r.ref.z >= P.near_clip && r.ref.z <= P.far_clip && sx >= 0.f && sx <= 1.f && sy >= 0.f && sy <= 1.f;
+    r.u = sx * (float)W; r.v = sy * (float)H;
+    r.dist = sqrtf(dot(r.ref, r.ref));
+    return r;
+}
+
+#define DSDF_BORDER 2
+#define DSDF_FILTER_RADIUS 2.0f
+#define DSDF_FILTER_ALPHA (-2.0f)            /* -1/(2*0.5^2) */
+#define DSDF_FILTER_BIAS 3.3546262790251185e-4f   /* exp(-2 * 2^2) */
+
+DSDF_HD float gauss_f(float x) { return fmaxf(0.f, expf(DSDF_FILTER_ALPHA * x * x) - DSDF_FILTER_BIAS); }
+DSDF_HD float gauss_df(float x) {
+    float e = expf(DSDF_FILTER_ALPHA * x * x);
+    return (e - DSDF_FILTER_BIAS) > 0.f ? 2.f * DSDF_FILTER_ALPHA * x * e : 0.f;
+}
+
+// ---------------------------------------------------------------------------
+// Mitsuba `independent` sampler: PCG32 seeded with sample_tea_32
+// ---------------------------------------------------------------------------
+DSDF_HD void sample_tea_32(uint32_t v0, uint32_t v1, uint32_t &o0, uint32_t &o1) {
+    uint32_t sum = 0;
+    for (int i = 0; i < 4; ++i) {
+        sum += 0x9e3779b9u;
+        v0 += ((v1 << 4) + 0xa341316cu) ^ (v1 + sum) ^ ((v1 >> 5) + 0xc8013ea4u);
+        v1 += ((v0 << 4) + 0xad90777du) ^ (v0 + sum) ^ ((v0 >> 5) + 0x7e95761eu);
+    }
+    o0 = v0; o1 = v1;
+}
+
+struct Pcg32 { uint64_t state, inc; };
+DSDF_HD uint32_t pcg32_next(Pcg32 &r) {
+    uint64_t old = r.state;
+    r.state = old * 0x5851f42d4c957f2dULL + r.inc;
+    uint32_t xs = (uint32_t)(((old >> 18u) ^ old) >> 27u);
+    uint32_t rot = (uint32_t)(old >> 59u);
+    return (xs >> rot) | (xs << ((~rot + 1u) & 31u));
+}
+DSDF_HD float pcg32_float(Pcg32 &r) {
+    union { uint32_t u; float f; } c;
+    c.u = (pcg32_next(r) >> 9) | 0x3f800000u;
+    return c.f - 1.f;
+}
+DSDF_HD void sampler_next_2d(uint32_t seed, uint32_t lane, float &r0, float &r1) {
+    uint32_t v0, v1;
+    sample_tea_32(seed, lane, v0, v1);
+    Pcg32 r;
+    r.state = 0; r.inc = ((uint64_t)v1 << 1u) | 1u;
+    pcg32_next(r);
+    r.state += (uint64_t)v0;
+    pcg32_next(r);
+    r0 = pcg32_float(r);
+    r1 = pcg32_float(r);
+}
+
+// ---------------------------------------------------------------------------
+// A8/A9: WarpField2D.weight / eval (warp.py:25-96), forward coefficients of the
+// linearised estimator: with v,g the SDF value/gradient at
+// x = o + warp_t d,   d(dir) = cdir * dv ,   div = a*v + b.g .
+// Returns false when the warp is inactive (w <= 0 or warp_t not finite).
+// ---------------------------------------------------------------------------
+struct WarpCoef { V3 cdir; float a; V3 b; float div; };
+
+DSDF_HD bool warp_coefficients(const GridView &G, const dsdf_params &P, V3 o, V3 d, const TraceOut &tr, WarpCoef &wc) {
+    float t = tr.warp_t;
+    if (!(fabsf(t) < INFINITY)) return false;                        // warp.py:52 (NaN fails too)
+    float lo = -P.bbox_delta, hi = 1.f + P.bbox_delta;
+    V3 x = fma3(t, d, o);
+    float v; V3 g; float H[6];
+    eval_cubic<2>(G, x, v, g, H);
+    float g2 = dot(g, g);
+    V3 n_ = g * (1.f / g2);                                          // normalize_sqr, math_util.py:13-17
+    // weight(), warp.py:25-39
+    float edge_eps = (P.weight_strategy == 6) ? P.edge_eps * t : P.edge_eps;
+    V3 bd_d;
+    float bd = bbox_distance_inside_d(x, lo, hi, bd_d);
+    bool use_eps = edge_eps <= bd;
+    V3 eps_dvec = use_eps ? mk(0.f, 0.f, 0.f) : bd_d;
+    float eps = fminf(edge_eps, bd);
+    float inv = 1.f / eps;
+    float sd = fabsf(v);
+    float fac = 1.f - sd * inv;
+    float w = fmaxf(fac, 0.f);
+    V3 w_d = mk(0.f, 0.f, 0.f);
+    float eps_d = 0.f;
+    if (fac >= 0.f) {
+        w_d = (-drsign(v) * inv) * g + (sd * inv * inv) * eps_dvec;
+        if (use_eps) eps_d = sd * inv * inv;
+    }
+    w_d = w_d + (eps_d * P.edge_eps) * d;                            // warp.py:70
+    w_d = tr.warp_weight * w_d + w * tr.warp_weight_d;               // warp.py:73
+    w *= tr.warp_weight;
+    if (!(w > 0.f)) return false;                                    // warp.py:91
+    // A = M P with P = I - d d^T, M = I + d (x) q, q = warp_t_d / t  (warp.py:86-87)
+    V3 q = tr.warp_t_d * (1.f / t);
+    V3 Pn = n_ - dot(d, n_) * d;                                     // P n'
+    V3 Pq = q - dot(d, q) * d;
+    V3 An = Pn + dot(Pq, n_) * d;                                    // A n' = P n' + d (Pq . n')
+    // tr(J_n H A), J_n = I/g2 - 2 g g^T / g2^2, A = P + d (Pq)^T:
+    // tr(J_n H P) + (Pq)^T J_n H d
+    float trH = H[0] + H[1] + H[2];
+    V3 Hd = symmul(H, d);
+    V3 Hg = symmul(H, g);
+    float dHd = dot(d, Hd), gHg = dot(g, Hg), gHd = dot(g, Hd);
+    float dg = dot(d, g);
+    // tr(J_n H) = trH/g2 - 2 gHg/g2^2 ; tr(J_n H d d^T) = d^T J_n H d = dHd/g2 - 2 dg*gHd/g2^2
+    float tr_JHP = (trH - dHd) / g2 - 2.f * (gHg - dg * gHd) / (g2 * g2);
+    // (Pq)^T J_n H d = Pq.Hd/g2 - 2 (Pq.g)(g.Hd)/g2^2
+    float pq_JHd = dot(Pq, Hd) / g2 - 2.f * dot(Pq, g) * gHd / (g2 * g2);
+    float tr_JHA = tr_JHP + pq_JHd;
+    // a = -(grad w)^T A n' - w tr(J_n H A) ;  (grad w)^T A n' = w_d.Pn + (w_d.d)(Pq.n')
+    float a = -(dot(w_d, Pn) + dot(w_d, d) * dot(Pq, n_)) - w * tr_JHA;
+    wc.a = a;
+    wc.b = (-w) * An;
+    float T = fmaxf(P.clamping_thresh, t);                           // warp.py:82
+    wc.cdir = (-w / T) * Pn;
+    wc.div = a * v + dot(wc.b, g);
+    return true;
+}
+
+}  // namespace dsdf

@@ -1,0 +1,88 @@
+"""ctypes binding of libdsdf.so (include/dsdf.h).
+
+The HIP library is the only compute path: if it is missing or fails to load this
+module raises -- there is no CPU or PyTorch fallback.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.normpath(os.path.join(_HERE, '..', '..', 'lib', 'libdsdf.so'))
+
+DSDF_SILHOUETTE = 0
+DSDF_SIMPLE_SHADING = 1
+DSDF_REPARAM = 1
+
+
+class DsdfCamera(C.Structure):
+    _fields_ = [('origin', C.c_float * 3), ('left', C.c_float * 3), ('up', C.c_float * 3),
+                ('dir', C.c_float * 3), ('tan_half_fov', C.c_float), ('pad', C.c_float * 3)]
+
+
+class DsdfParams(C.Structure):
+    _fields_ = [('trace_eps', C.c_float), ('extra_thresh', C.c_float), ('sil_weight_offset', C.c_float),
+                ('sil_weight_epsilon', C.c_float), ('bbox_delta', C.c_float), ('edge_eps', C.c_float),
+                ('clamping_thresh', C.c_float), ('near_clip', C.c_float), ('far_clip', C.c_float),
+                ('sdf_p', C.c_float * 3), ('weight_strategy', C.c_int), ('refine_steps', C.c_int),
+                ('reserved', C.c_int * 2)]
+
+
+class DsdfError(RuntimeError):
+    pass
+
+
+_lib = None
+
+# name -> (restype, argtypes); every symbol include/dsdf.h declares
+SYMBOLS = {
+    'dsdf_version': (C.c_int, []),
+    'dsdf_last_error': (C.c_char_p, []),
+    'dsdf_default_params': (None, [C.POINTER(DsdfParams)]),
+    'dsdf_padded_size': (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    'dsdf_pad_grid': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    'dsdf_eval_cubic': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(DsdfParams), C.c_void_p,
+                                  C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'dsdf_trace': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(DsdfParams), C.c_void_p, C.c_void_p,
+                             C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                             C.c_void_p, C.c_void_p, C.c_void_p]),
+    'dsdf_render_workspace_size': (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    'dsdf_render_forward': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(DsdfParams),
+                                      C.POINTER(DsdfCamera), C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                      C.POINTER(C.c_uint32), C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t,
+                                      C.c_void_p, C.c_void_p]),
+    'dsdf_render_backward': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(DsdfParams),
+                                       C.POINTER(DsdfCamera), C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                       C.POINTER(C.c_uint32), C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                       C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
+}
+
+
+def load():
+    """Loads libdsdf.so once; raises DsdfError if the HIP extension is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.isfile(LIB_PATH):
+        raise DsdfError(f"HIP extension not built: {LIB_PATH} is missing "
+                        f"(run `python -c 'import __graft_entry__ as g; g.build()'`). No CPU fallback exists.")
+    try:
+        lib = C.CDLL(LIB_PATH)
+    except OSError as e:
+        raise DsdfError(f"cannot load {LIB_PATH}: {e}") from e
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc != 0:
+        raise DsdfError(f"libdsdf error {rc}: {load().dsdf_last_error().decode()}")
+
+
+def default_params():
+    p = DsdfParams()
+    load().dsdf_default_params(C.byref(p))
+    return p

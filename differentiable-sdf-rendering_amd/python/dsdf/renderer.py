@@ -1,0 +1,222 @@
+"""Host-side operators over the C-ABI (include/dsdf.h) on torch HIP tensors.
+
+torch is used for device memory, streams and autograd plumbing only; every
+kernel on the path is in libdsdf.so.  `render()` plays the role of `mi.render`
+with the reference's `_RenderOp` semantics (python/shape_opt.py:78-80): the
+primal image comes from an (seed, spp) render without gradients, the backward
+from an independent (seed_grad, spp_grad) re-render
+(python/integrators/reparam.py:187-190).
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import DSDF_REPARAM, DSDF_SILHOUETTE, DSDF_SIMPLE_SHADING, DsdfCamera
+
+INTEGRATORS = {'sdf_silhouette_reparam': DSDF_SILHOUETTE, 'sdf_simple_shading_reparam': DSDF_SIMPLE_SHADING,
+               DSDF_SILHOUETTE: DSDF_SILHOUETTE, DSDF_SIMPLE_SHADING: DSDF_SIMPLE_SHADING}
+
+STAT_NAMES = ('lanes', 'bbox_lanes', 'steps', 'hits', 'refine_steps', 'warp_active', 'queue_len', 'reserved')
+
+_workspaces = {}
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def _require_dev(t, name, dtype=torch.float32):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise _lib.DsdfError(f"{name} must be a torch tensor on the HIP device (got {type(t).__name__}"
+                             f"{'' if not isinstance(t, torch.Tensor) else ' on ' + str(t.device)}); no CPU path exists")
+    if t.dtype != dtype:
+        raise _lib.DsdfError(f"{name} must be {dtype}, got {t.dtype}")
+    return t.contiguous()
+
+
+def _workspace(device, nbytes):
+    ws = _workspaces.get(device)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+        _workspaces[device] = ws
+    return ws
+
+
+class SdfGrid:
+    """Device-side SDF grid: `sdf.data` (Z,Y,X[,1]) plus the library's padded copy.
+    Mirrors what `Grid3d.__init__/update/parameters_changed` do with the Dr.Jit
+    texture (python/shapes.py:378-403, 473-479)."""
+
+    def __init__(self, data, params=None):
+        self.params = params if params is not None else _lib.default_params()
+        self.padded = None
+        self.update(data)
+
+    def update(self, data):
+        lib = _lib.load()
+        if data.dim() == 4:
+            if data.shape[3] != 1:
+                raise _lib.DsdfError("sdf.data must have one channel")
+            data = data[..., 0]
+        if data.dim() != 3:
+            raise _lib.DsdfError(f"sdf.data must be (Z,Y,X) or (Z,Y,X,1), got {tuple(data.shape)}")
+        data = _require_dev(data.detach(), 'sdf.data')
+        self.rz, self.ry, self.rx = (int(s) for s in data.shape)
+        n = lib.dsdf_padded_size(self.rx, self.ry, self.rz)
+        if self.padded is None or self.padded.numel() != n or self.padded.device != data.device:
+            self.padded = torch.empty(n, dtype=torch.float32, device=data.device)
+        with torch.cuda.device(data.device):
+            _lib.check(lib.dsdf_pad_grid(_ptr(data), self.rx, self.ry, self.rz, _ptr(self.padded), _stream()))
+        self.device = data.device
+        return self
+
+    @property
+    def shape(self):
+        return (self.rz, self.ry, self.rx)
+
+
+def eval_cubic(grid, points, order=2):
+    """A1. points (n,3) -> v (n,), g (n,3), H (n,6: xx,yy,zz,xy,xz,yz)."""
+    lib = _lib.load()
+    points = _require_dev(points, 'points')
+    n = points.shape[0]
+    dev = points.device
+    v = torch.empty(n, dtype=torch.float32, device=dev)
+    g = torch.empty(n, 3, dtype=torch.float32, device=dev) if order >= 1 else None
+    H = torch.empty(n, 6, dtype=torch.float32, device=dev) if order >= 2 else None
+    with torch.cuda.device(dev):
+        _lib.check(lib.dsdf_eval_cubic(_ptr(grid.padded), grid.rx, grid.ry, grid.rz, C.byref(grid.params), _ptr(points),
+                                       n, order, _ptr(v), _ptr(g), _ptr(H), _stream()))
+    return v, g, H
+
+
+def trace(grid, rays_o, rays_d, maxt, differentiable=True):
+    """A2/A4/A5: per-ray sphere tracing. Returns dict of per-ray outputs."""
+    lib = _lib.load()
+    rays_o = _require_dev(rays_o, 'rays_o'); rays_d = _require_dev(rays_d, 'rays_d'); maxt = _require_dev(maxt, 'maxt')
+    n = rays_o.shape[0]
+    dev = rays_o.device
+    f = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
+    out = dict(its_t=f(n), warp_t=f(n), warp_t_d=f(n, 3), warp_weight=f(n), warp_weight_d=f(n, 3),
+               steps=torch.empty(n, dtype=torch.int32, device=dev))
+    with torch.cuda.device(dev):
+        _lib.check(lib.dsdf_trace(_ptr(grid.padded), grid.rx, grid.ry, grid.rz, C.byref(grid.params), _ptr(rays_o),
+                                  _ptr(rays_d), _ptr(maxt), n, int(bool(differentiable)), _ptr(out['its_t']),
+                                  _ptr(out['warp_t']), _ptr(out['warp_t_d']), _ptr(out['warp_weight']),
+                                  _ptr(out['warp_weight_d']), _ptr(out['steps']), _stream()))
+    return out
+
+
+def _views(sensors):
+    sensors = list(sensors) if isinstance(sensors, (list, tuple)) else [sensors]
+    W, H = sensors[0].film_size()
+    for s in sensors:
+        if s.film_size() != (W, H):
+            raise _lib.DsdfError("all sensors of one call must share the film size")
+    cams = (DsdfCamera * len(sensors))(*[s.to_struct() for s in sensors])
+    return sensors, cams, W, H
+
+
+def _sampler_args(n_views, seeds, offsets, n_lanes):
+    if offsets is not None:
+        offsets = _require_dev(offsets, 'offsets')
+        if offsets.numel() != n_views * n_lanes * 2:
+            raise _lib.DsdfError(f"offsets must hold n_views*(W+4)*(H+4)*spp*2 = {n_views * n_lanes * 2} floats, "
+                                 f"got {offsets.numel()}")
+        return offsets, None
+    if seeds is None:
+        raise _lib.DsdfError("either seeds or offsets is required")
+    seeds = [seeds] * n_views if isinstance(seeds, int) else list(seeds)
+    if len(seeds) != n_views:
+        raise _lib.DsdfError("one seed per view is required")
+    return None, (C.c_uint32 * n_views)(*[int(s) & 0xffffffff for s in seeds])
+
+
+def render_forward(grid, sensors, spp, seeds=None, offsets=None, integrator=DSDF_SILHOUETTE, reparam=True, stats=None):
+    """`ReparamIntegrator.render` for a batch of views -> (n_views, H, W, 3)."""
+    lib = _lib.load()
+    sensors, cams, W, H = _views(sensors)
+    nv = len(sensors)
+    n_lanes = (W + 4) * (H + 4) * int(spp)
+    offsets, cseeds = _sampler_args(nv, seeds, offsets, n_lanes)
+    dev = grid.device
+    img = torch.empty(nv, H, W, 3, dtype=torch.float32, device=dev)
+    wsb = lib.dsdf_render_workspace_size(W, H, int(spp))
+    ws = _workspace(dev, wsb)
+    with torch.cuda.device(dev):
+        _lib.check(lib.dsdf_render_forward(_ptr(grid.padded), grid.rx, grid.ry, grid.rz, C.byref(grid.params), cams, nv,
+                                           W, H, int(spp), _ptr(offsets), cseeds, INTEGRATORS[integrator],
+                                           DSDF_REPARAM if reparam else 0, _ptr(img), _ptr(ws), wsb,
+                                           _ptr(stats), _stream()))
+    return img
+
+
+def render_backward(grid, sensors, spp, grad_image, grad_grid=None, seeds=None, offsets=None,
+                    integrator=DSDF_SILHOUETTE, reparam=True, stats=None, return_image=False):
+    """`ReparamIntegrator.render_backward`: accumulates dL/dsdf into grad_grid (Z,Y,X)."""
+    lib = _lib.load()
+    sensors, cams, W, H = _views(sensors)
+    nv = len(sensors)
+    n_lanes = (W + 4) * (H + 4) * int(spp)
+    offsets, cseeds = _sampler_args(nv, seeds, offsets, n_lanes)
+    dev = grid.device
+    grad_image = _require_dev(grad_image, 'grad_image')
+    if grad_image.numel() != nv * H * W * 3:
+        raise _lib.DsdfError(f"grad_image must be (n_views,H,W,3) = {(nv, H, W, 3)}, got {tuple(grad_image.shape)}")
+    if grad_grid is None:
+        grad_grid = torch.zeros(grid.rz, grid.ry, grid.rx, dtype=torch.float32, device=dev)
+    else:
+        if tuple(grad_grid.shape[:3]) != grid.shape or not grad_grid.is_contiguous():
+            raise _lib.DsdfError("grad_grid must be a contiguous (Z,Y,X) tensor matching the grid")
+        _require_dev(grad_grid, 'grad_grid')
+    img = torch.empty(nv, H, W, 3, dtype=torch.float32, device=dev) if return_image else None
+    wsb = lib.dsdf_render_workspace_size(W, H, int(spp))
+    ws = _workspace(dev, wsb)
+    with torch.cuda.device(dev):
+        _lib.check(lib.dsdf_render_backward(_ptr(grid.padded), grid.rx, grid.ry, grid.rz, C.byref(grid.params), cams, nv,
+                                            W, H, int(spp), _ptr(offsets), cseeds, INTEGRATORS[integrator],
+                                            DSDF_REPARAM if reparam else 0, _ptr(grad_image), _ptr(grad_grid),
+                                            _ptr(img), _ptr(ws), wsb, _ptr(stats), _stream()))
+    return (grad_grid, img) if return_image else grad_grid
+
+
+def new_stats(device):
+    return torch.zeros(8, dtype=torch.int64, device=device)
+
+
+def stats_dict(stats):
+    return dict(zip(STAT_NAMES, (int(x) for x in stats.cpu())))
+
+
+class _RenderOp(torch.autograd.Function):
+    """`mi.render`'s custom op: primal (seed, spp) without AD, backward via an
+    independent (seed_grad, spp_grad) gradient pass."""
+
+    @staticmethod
+    def forward(ctx, data, grid, sensors, spp, seed, spp_grad, seed_grad, integrator, reparam):
+        ctx.cfg = (grid, sensors, spp_grad, seed_grad, integrator, reparam)
+        ctx.data_shape = data.shape
+        n = len(sensors)
+        return render_forward(grid, sensors, spp, seeds=[seed + i for i in range(n)], integrator=integrator,
+                              reparam=reparam)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        grid, sensors, spp_grad, seed_grad, integrator, reparam = ctx.cfg
+        n = len(sensors)
+        g = render_backward(grid, sensors, spp_grad, grad_out.contiguous(), seeds=[seed_grad + i for i in range(n)],
+                            integrator=integrator, reparam=reparam)
+        return g.reshape(ctx.data_shape), None, None, None, None, None, None, None, None
+
+
+def render(data, grid, sensors, spp, seed=0, spp_grad=None, seed_grad=0, integrator=DSDF_SILHOUETTE, reparam=True):
+    """Differentiable render of `data` (the tensor behind `grid`) for one or more
+    sensors: returns (n_views,H,W,3) attached to `data`."""
+    sensors = list(sensors) if isinstance(sensors, (list, tuple)) else [sensors]
+    return _RenderOp.apply(data, grid, sensors, int(spp), int(seed), int(spp_grad or spp), int(seed_grad),
+                           integrator, reparam)

@@ -1,0 +1,157 @@
+/*
+ * dsdf.h -- C-ABI of the MI355X-native differentiable SDF renderer hot path.
+ *
+ * Drop-in boundary for the sphere-tracing primary-ray integrator + silhouette
+ * reparameterisation gradient estimator of rgl-epfl/differentiable-sdf-rendering.
+ * The reference has no FFI: the path sits behind Mitsuba's Python integrator
+ * plugin API and two duck-typed Python protocols.  Each entry point below names
+ * the reference interface it replaces (paths relative to the reference root).
+ *
+ * Conventions
+ *  - every pointer is caller-owned DEVICE memory (fp32 / int32, contiguous);
+ *    the library never allocates, frees or synchronises;
+ *  - `stream` is a hipStream_t passed as void* (NULL = default stream);
+ *  - SDF grids are (Z,Y,X) fp32, x fastest -- the layout of `sdf.data`
+ *    (python/shapes.py:387-388, 469-471);
+ *  - return value: 0 = ok, negative = dsdf_status; dsdf_last_error() gives text;
+ *  - re-entrant per stream; all work is enqueued on `stream`.
+ */
+#ifndef DSDF_H
+#define DSDF_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DSDF_VERSION 100
+
+enum dsdf_status {
+    DSDF_OK = 0,
+    DSDF_ERR_INVALID_ARG = -1,
+    DSDF_ERR_WORKSPACE = -2,
+    DSDF_ERR_LAUNCH = -3,
+    DSDF_ERR_NO_DEVICE = -4
+};
+
+/* python/integrators/sdf_silhouette_reparam.py:16-29 and
+ * python/integrators/sdf_simple_shading_reparam.py:16-26 (`sample()` bodies). */
+enum dsdf_integrator {
+    DSDF_SILHOUETTE = 0,
+    DSDF_SIMPLE_SHADING = 1
+};
+
+/* Flags for dsdf_render_*.  DSDF_REPARAM selects WarpField2D (python/warp.py:7-128);
+ * without it the DummyWarpField path is taken (python/warp.py:179-196). */
+enum dsdf_flags {
+    DSDF_REPARAM = 1
+};
+
+/* Perspective sensor as built by python/util.py:115-138 (`get_regular_cameras`):
+ * Mitsuba `perspective`, fov along x, look_at() frame.  16 floats. */
+typedef struct dsdf_camera {
+    float origin[3];
+    float left[3];   /* camera +x */
+    float up[3];     /* camera +y */
+    float dir[3];    /* camera +z (viewing direction) */
+    float tan_half_fov;
+    float pad[3];
+} dsdf_camera;
+
+/* Scalar constants of the path.  dsdf_default_params() fills
+ * the reference defaults; fields mirror python/shapes.py:28-39, python/warp.py:10-23,
+ * python/configs.py:21-30. */
+typedef struct dsdf_params {
+    float trace_eps;          /* shapes.py:31   1e-6 */
+    float extra_thresh;       /* shapes.py:35   0.05 */
+    float sil_weight_offset;  /* shapes.py:36   0.05 */
+    float sil_weight_epsilon; /* shapes.py:37   1e-6 */
+    float bbox_delta;         /* shapes.py:417  0.05 */
+    float edge_eps;           /* configs.py:21  0.01 */
+    float clamping_thresh;    /* configs.py:29  0.05 */
+    float near_clip;          /* Mitsuba perspective default 1e-2 */
+    float far_clip;           /* 1e4 */
+    float sdf_p[3];           /* `sdf.p` translation (shapes.py:389, 412) */
+    int   weight_strategy;    /* configs.py:30  6 -> eps = edge_eps * t (warp.py:41-45) */
+    int   refine_steps;       /* shapes.py:245-257  10 (0 disables refinement) */
+    int   reserved[2];
+} dsdf_params;
+
+int         dsdf_version(void);
+const char *dsdf_last_error(void);
+void        dsdf_default_params(dsdf_params *p);
+
+/* Number of floats of the library's internal padded copy of an (rz,ry,rx) grid
+ * (clamp-to-edge apron of 3 voxels per side, so the 4^3 B-spline footprint is
+ * always four contiguous 16-byte rows). */
+size_t dsdf_padded_size(int rx, int ry, int rz);
+
+/* Builds the padded copy.  Replaces `Texture3f.set_tensor` / `Grid3d.update`
+ * (python/shapes.py:388, 473-479): call whenever `sdf.data` changes. */
+int dsdf_pad_grid(const float *data, int rx, int ry, int rz, float *padded, void *stream);
+
+/* A1: `Grid3d.eval / eval_and_grad / eval_all` (python/shapes.py:420-450), i.e.
+ * Dr.Jit Texture3f.eval_cubic{,_grad,_hessian}.  points: n x 3 (x,y,z).
+ * order 0: v; 1: v,g (n x 3); 2: v,g,H (n x 6: xx,yy,zz,xy,xz,yz).  Unused
+ * outputs may be NULL.  Also serves `upsample_sdf` (python/variables.py:18-23). */
+int dsdf_eval_cubic(const float *padded, int rx, int ry, int rz, const dsdf_params *prm,
+                    const float *points, int64_t n, int order,
+                    float *v, float *g, float *H, void *stream);
+
+/* A2/A4/A5: `SDFBase.ray_intersect` (python/shapes.py:115-288; differentiable=1) or
+ * `ray_intersect_non_diff` (python/shapes.py:290-339; differentiable=0).
+ * rays_o/rays_d: n x 3, maxt: n.  Outputs (any may be NULL): its_t n, warp_t n,
+ * warp_t_d n x 3, warp_weight n, warp_weight_d n x 3, steps n (int32; AOV `i`,
+ * shapes.py:241).  its_t / warp_t = +inf on miss / invalid. */
+int dsdf_trace(const float *padded, int rx, int ry, int rz, const dsdf_params *prm,
+               const float *rays_o, const float *rays_d, const float *maxt, int64_t n,
+               int differentiable,
+               float *its_t, float *warp_t, float *warp_t_d,
+               float *warp_weight, float *warp_weight_d, int32_t *steps, void *stream);
+
+/* Workspace (bytes) needed by dsdf_render_forward / dsdf_render_backward for one
+ * view of width x height at spp samples (film block, per-lane records, queue). */
+size_t dsdf_render_workspace_size(int width, int height, int spp);
+
+/* `ReparamIntegrator.render` (python/integrators/reparam.py:120-185) for n_views
+ * sensors: ray generation (Mitsuba perspective sensor), sphere tracing,
+ * `sample()` of the selected integrator, re-projection, Gaussian-filter splat
+ * (`ImageBlock.put`, radius 2, sample_border) and `HDRFilm.develop`.
+ *   cams      : n_views dsdf_camera structs (HOST memory; copied into kernel args)
+ *   offsets   : n_views x (W+4)(H+4)*spp x 2 sub-pixel offsets in [0,1) in the
+ *               reference's lane order (reparam.py:140-155), or NULL to use the
+ *               built-in `independent` sampler (PCG32 seeded by sample_tea_32)
+ *               with seed = seeds[view]
+ *   seeds     : n_views uint32 (HOST memory; ignored when offsets != NULL)
+ *   image_out : n_views x H x W x 3
+ *   stats     : optional device int64[8] accumulators {lanes, bbox_lanes, steps,
+ *               hits, refine_steps, warp_active, queue_len, 0} (atomically added)
+ */
+int dsdf_render_forward(const float *padded, int rx, int ry, int rz, const dsdf_params *prm,
+                        const dsdf_camera *cams, int n_views, int width, int height, int spp,
+                        const float *offsets, const uint32_t *seeds,
+                        int integrator, int flags,
+                        float *image_out, void *workspace, size_t workspace_bytes,
+                        int64_t *stats, void *stream);
+
+/* `ReparamIntegrator.render_backward` (python/integrators/reparam.py:187-190):
+ * re-renders each view at `spp` with the reparameterisation attached and
+ * back-propagates grad_image (n_views x H x W x 3) into
+ * grad_grid (rz,ry,rx), ACCUMULATING (like dr.grad(params[key])).
+ * image_out (optional) receives the gradient-pass image.  Same sampler rules
+ * as dsdf_render_forward (the reference uses seed_grad / spp_grad here,
+ * python/shape_opt.py:78-80). */
+int dsdf_render_backward(const float *padded, int rx, int ry, int rz, const dsdf_params *prm,
+                         const dsdf_camera *cams, int n_views, int width, int height, int spp,
+                         const float *offsets, const uint32_t *seeds,
+                         int integrator, int flags,
+                         const float *grad_image, float *grad_grid, float *image_out,
+                         void *workspace, size_t workspace_bytes,
+                         int64_t *stats, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DSDF_H */

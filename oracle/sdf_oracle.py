@@ -648,26 +648,35 @@ def render(sdf, cam, W, H, spp, offsets, integrator=SILHOUETTE, reparam=True,
         d_att = d
         div = torch.ones(N, dtype=dt)
         if reparam:
-            fin = torch.isfinite(tr['warp_t'])
-            tw = torch.where(fin, tr['warp_t'], torch.ones_like(tr['warp_t']))   # sanitised; masked below
-            x = o + tw[:, None] * d
-            # (non-finite warp_t lanes are evaluated at a finite stand-in and masked
-            #  by `fin`, exactly the effect of `active &= dr.isfinite(t)`, warp.py:52)
-            wdir2, dv2, wact2 = warp_eval(sdf, x, d, tw, tr['warp_t_d'], tr['warp_weight'], tr['warp_weight_d'], fin)
-            d_att = wdir2                                                # warp.py:114
-            div = replace_grad(torch.ones(N, dtype=dt), dv2)             # warp.py:115
-            aux['warp_active'] += int(wact2.sum())
+            # warp.py:52, 91: lanes with non-finite warp_t or zero weight are masked
+            # (div = 0, dir = ray_d, no gradient).  They are skipped here instead of
+            # evaluated-then-masked so that 0 * NaN products of masked lanes (which
+            # Dr.Jit would also generate and the reference scrubs afterwards,
+            # variables.py:193-199) cannot poison the gradient.
+            sel = (torch.isfinite(tr['warp_t']) & (tr['warp_weight'] > 0)).nonzero()[:, 0]
+            if sel.numel() > 0:
+                tw = tr['warp_t'][sel]
+                x = o[sel] + tw[:, None] * d[sel]
+                wdir, dv, wact = warp_eval(sdf, x, d[sel], tw, tr['warp_t_d'][sel], tr['warp_weight'][sel],
+                                           tr['warp_weight_d'][sel], torch.ones_like(tw, dtype=torch.bool))
+                keep = wact.nonzero()[:, 0]
+                sel = sel[keep]
+                d_att = d.index_put((sel,), wdir[keep])                  # warp.py:114
+                div = div.index_put((sel,), replace_grad(torch.ones_like(dv[keep]), dv[keep]))   # warp.py:115
+                aux['warp_active'] += int(keep.numel())
         if integrator == SILHOUETTE:                                     # sdf_silhouette_reparam.py:20-22
             val = hit.to(dt) * div
         else:                                                            # sdf_simple_shading_reparam.py:20-22
-            ts = torch.where(hit, its_t, torch.ones_like(its_t))
-            _, _, n = compute_surface_interaction(sdf, o, d_att, ts, hit)
-            sh = torch.clamp(dot(n, light), min=0.0)
-            val = torch.where(hit, sh, torch.zeros_like(sh)) * div
+            hsel = hit.nonzero()[:, 0]                                    # (masked lanes skipped, see above)
+            sh = torch.zeros(N, dtype=dt)
+            if hsel.numel() > 0:
+                _, _, n = compute_surface_interaction(sdf, o[hsel], d_att[hsel], its_t[hsel], None)
+                sh = sh.index_put((hsel,), torch.clamp(dot(n, light), min=0.0))
+            val = sh * div
         rgb = val[:, None].expand(-1, 3)
         # re-projection, reparam.py:99-105
         uv, rw = cam.sample_direction(o + d_att, W, H)
-        rwn = torch.where(rw > 0, rw / rw.detach(), torch.ones_like(rw))
+        rwn = torch.where(rw > 0, rw / torch.where(rw > 0, rw.detach(), torch.ones_like(rw)), torch.ones_like(rw))
         rwn = replace_grad(torch.ones_like(rwn), rwn)
         rgb = rwn[:, None] * rgb
         wch = replace_grad(torch.ones(N, dtype=dt), div * rwn)           # reparam.py:115
@@ -688,6 +697,8 @@ def render_backward(sdf, cam, W, H, spp, offsets, grad_in, integrator=SILHOUETTE
     leaf = data.detach().clone().requires_grad_(True)
     s2 = Grid3d(leaf, sdf.p)
     img = render(s2, cam, W, H, spp, offsets, integrator, reparam)
+    if not img.requires_grad:
+        return torch.zeros_like(leaf)
     (img * grad_in).sum().backward()
     return leaf.grad if leaf.grad is not None else torch.zeros_like(leaf)
 

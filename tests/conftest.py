@@ -1,0 +1,96 @@
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, 'oracle'), os.path.join(ROOT, 'differentiable-sdf-rendering_amd', 'python')):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope='session')
+def built():
+    import __graft_entry__ as g
+    g.build_lib()
+    g.build_harness()
+    g.build_oracle()
+    return g
+
+
+class HostHarness:
+    """ctypes view of the TEST-ONLY host build of the kernel arithmetic."""
+
+    def __init__(self, path):
+        import dsdf
+        self.lib = C.CDLL(path)
+        self.params = dsdf.default_params()
+
+    @staticmethod
+    def _p(a):
+        return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+    def eval_cubic(self, grid, pts, order=2):
+        grid = np.ascontiguousarray(grid, np.float32); pts = np.ascontiguousarray(pts, np.float32)
+        n = pts.shape[0]
+        v = np.zeros(n, np.float32); g = np.zeros((n, 3), np.float32); H = np.zeros((n, 6), np.float32)
+        rz, ry, rx = grid.shape
+        self.lib.hh_eval_cubic(self._p(grid), rx, ry, rz, C.byref(self.params), self._p(pts), C.c_long(n), order,
+                               self._p(v), self._p(g), self._p(H))
+        return v, g, H
+
+    def trace(self, grid, o, d, maxt, diff=True):
+        grid = np.ascontiguousarray(grid, np.float32)
+        o = np.ascontiguousarray(o, np.float32); d = np.ascontiguousarray(d, np.float32)
+        maxt = np.ascontiguousarray(maxt, np.float32)
+        n = o.shape[0]
+        out = dict(its_t=np.zeros(n, np.float32), warp_t=np.zeros(n, np.float32), warp_t_d=np.zeros((n, 3), np.float32),
+                   warp_weight=np.zeros(n, np.float32), warp_weight_d=np.zeros((n, 3), np.float32),
+                   steps=np.zeros(n, np.int32))
+        rz, ry, rx = grid.shape
+        self.lib.hh_trace(self._p(grid), rx, ry, rz, C.byref(self.params), self._p(o), self._p(d), self._p(maxt),
+                          C.c_long(n), int(diff), self._p(out['its_t']), self._p(out['warp_t']), self._p(out['warp_t_d']),
+                          self._p(out['warp_weight']), self._p(out['warp_weight_d']), self._p(out['steps']))
+        return out
+
+    def render_forward(self, grid, cam, W, H, spp, offsets, integrator, reparam=True, diff=False, seed=0):
+        grid = np.ascontiguousarray(grid, np.float32)
+        offsets = None if offsets is None else np.ascontiguousarray(offsets, np.float32)
+        img = np.zeros((H, W, 3), np.float32)
+        rz, ry, rx = grid.shape
+        self.lib.hh_render_forward(self._p(grid), rx, ry, rz, C.byref(self.params), self._p(cam), W, H, spp,
+                                   self._p(offsets), C.c_uint(seed), integrator, int(reparam), int(diff), self._p(img))
+        return img
+
+    def render_backward(self, grid, cam, W, H, spp, offsets, grad_image, integrator, reparam=True, seed=0):
+        grid = np.ascontiguousarray(grid, np.float32)
+        offsets = None if offsets is None else np.ascontiguousarray(offsets, np.float32)
+        gi = np.ascontiguousarray(grad_image, np.float32)
+        gg = np.zeros(grid.shape, np.float32)
+        img = np.zeros((H, W, 3), np.float32)
+        rz, ry, rx = grid.shape
+        self.lib.hh_render_backward(self._p(grid), rx, ry, rz, C.byref(self.params), self._p(cam), W, H, spp,
+                                    self._p(offsets), C.c_uint(seed), integrator, int(reparam), self._p(gi),
+                                    self._p(gg), self._p(img))
+        return gg, img
+
+    def sampler(self, seed, n):
+        out = np.zeros((n, 2), np.float32)
+        self.lib.hh_sampler(C.c_uint(seed), C.c_long(n), self._p(out))
+        return out
+
+
+@pytest.fixture(scope='session')
+def harness(built):
+    return HostHarness(built.build_harness())
+
+
+def rel_l2(a, b):
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300))

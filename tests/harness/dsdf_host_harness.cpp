@@ -1,0 +1,138 @@
+// TEST-ONLY host build of the kernel arithmetic (csrc/dsdf_math.h, dsdf_lane.h).
+//
+// Lets the CPU test-suite (`pytest -m "not gpu"`) check the hand-derived adjoint
+// and the tracing arithmetic that the HIP kernels execute against the oracle
+// without a GPU.  It is NOT a fallback: the product (dsdf/_lib.py) only ever loads
+// libdsdf.so (HIP) and raises if that is missing.  Serial, unoptimised.
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+#include "../../differentiable-sdf-rendering_amd/csrc/dsdf_lane.h"
+
+using namespace dsdf;
+
+struct PlainAdd { void operator()(float *p, float v) const { *p += v; } };
+
+static std::vector<float> pad(const float *data, int rx, int ry, int rz) {
+    int sx = rx + 6, sy = ry + 6, sz = rz + 6;
+    std::vector<float> out((size_t)sx * sy * sz);
+    for (int z = 0; z < sz; ++z)
+        for (int y = 0; y < sy; ++y)
+            for (int x = 0; x < sx; ++x) {
+                int cx = iclamp(x - 3, 0, rx - 1), cy = iclamp(y - 3, 0, ry - 1), cz = iclamp(z - 3, 0, rz - 1);
+                out[((size_t)z * sy + y) * sx + x] = data[((size_t)cz * ry + cy) * rx + cx];
+            }
+    return out;
+}
+
+extern "C" {
+
+void hh_eval_cubic(const float *data, int rx, int ry, int rz, const dsdf_params *prm, const float *pts, long n,
+                   int order, float *v, float *g, float *H) {
+    std::vector<float> p = pad(data, rx, ry, rz);
+    GridView G = make_view(p.data(), rx, ry, rz, *prm);
+    for (long i = 0; i < n; ++i) {
+        V3 x = mk(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]);
+        float vv; V3 gg; float HH[6];
+        if (order == 0) eval_cubic<0>(G, x, vv, gg, HH);
+        else if (order == 1) eval_cubic<1>(G, x, vv, gg, HH);
+        else eval_cubic<2>(G, x, vv, gg, HH);
+        v[i] = vv;
+        if (order >= 1 && g) { g[3 * i] = gg.x; g[3 * i + 1] = gg.y; g[3 * i + 2] = gg.z; }
+        if (order >= 2 && H) for (int k = 0; k < 6; ++k) H[6 * i + k] = HH[k];
+    }
+}
+
+void hh_trace(const float *data, int rx, int ry, int rz, const dsdf_params *prm, const float *ro, const float *rd,
+              const float *maxt, long n, int diff, float *its_t, float *warp_t, float *warp_t_d, float *ww,
+              float *ww_d, int *steps) {
+    std::vector<float> p = pad(data, rx, ry, rz);
+    GridView G = make_view(p.data(), rx, ry, rz, *prm);
+    for (long i = 0; i < n; ++i) {
+        TraceOut t;
+        V3 o = mk(ro[3 * i], ro[3 * i + 1], ro[3 * i + 2]), d = mk(rd[3 * i], rd[3 * i + 1], rd[3 * i + 2]);
+        if (diff) trace_diff(G, *prm, o, d, maxt[i], t); else trace_plain(G, *prm, o, d, maxt[i], t);
+        its_t[i] = t.its_t; warp_t[i] = t.warp_t; ww[i] = t.warp_weight; steps[i] = t.steps;
+        warp_t_d[3 * i] = t.warp_t_d.x; warp_t_d[3 * i + 1] = t.warp_t_d.y; warp_t_d[3 * i + 2] = t.warp_t_d.z;
+        ww_d[3 * i] = t.warp_weight_d.x; ww_d[3 * i + 1] = t.warp_weight_d.y; ww_d[3 * i + 2] = t.warp_weight_d.z;
+    }
+}
+
+static ViewArgs view_args(const dsdf_camera *cam, int W, int H, int spp, const float *offsets, unsigned seed,
+                          int integrator, int flags) {
+    ViewArgs A;
+    A.cam = *cam; A.W = W; A.H = H; A.Wb = W + 2 * DSDF_BORDER; A.Hb = H + 2 * DSDF_BORDER; A.spp = spp;
+    A.integrator = integrator; A.flags = flags; A.seed = seed; A.offsets = offsets;
+    return A;
+}
+
+static void develop(const std::vector<float> &block, int W, int H, float *image) {
+    int Wb = W + 2 * DSDF_BORDER;
+    for (int y = 0; y < H; ++y)
+        for (int x = 0; x < W; ++x) {
+            const float *b = &block[2 * ((size_t)(y + DSDF_BORDER) * Wb + x + DSDF_BORDER)];
+            float w = b[1] == 0.f ? 1.f : b[1];
+            float v = b[0] / w;
+            float *o = image + 3 * ((size_t)y * W + x);
+            o[0] = v; o[1] = v; o[2] = v;
+        }
+}
+
+// diff=0: primal pass (trace_plain); diff=1: the gradient pass' forward sweep.
+void hh_render_forward(const float *data, int rx, int ry, int rz, const dsdf_params *prm, const dsdf_camera *cam,
+                       int W, int H, int spp, const float *offsets, unsigned seed, int integrator, int flags,
+                       int diff, float *image) {
+    std::vector<float> p = pad(data, rx, ry, rz);
+    GridView G = make_view(p.data(), rx, ry, rz, *prm);
+    ViewArgs A = view_args(cam, W, H, spp, offsets, seed, integrator, flags);
+    std::vector<float> block((size_t)2 * A.Wb * A.Hb, 0.f);
+    long n = (long)A.Wb * A.Hb * spp;
+    for (long lane = 0; lane < n; ++lane) {
+        Lane L = lane_setup(A, *prm, (uint32_t)lane);
+        TraceOut t;
+        if (diff) trace_diff(G, *prm, L.ray.o, L.ray.d, L.ray.maxt, t);
+        else trace_plain(G, *prm, L.ray.o, L.ray.d, L.ray.maxt, t);
+        float val = shade_value(G, A, L, t.its_t);
+        Reproj rp = reproject(A.cam, *prm, L.ray.o + L.ray.d, W, H);
+        splat_lane(block.data(), A.Wb, A.Hb, rp.u, rp.v, val, PlainAdd());
+    }
+    develop(block, W, H, image);
+}
+
+void hh_render_backward(const float *data, int rx, int ry, int rz, const dsdf_params *prm, const dsdf_camera *cam,
+                        int W, int H, int spp, const float *offsets, unsigned seed, int integrator, int flags,
+                        const float *grad_image, float *grad_grid, float *image) {
+    std::vector<float> p = pad(data, rx, ry, rz);
+    GridView G = make_view(p.data(), rx, ry, rz, *prm);
+    ViewArgs A = view_args(cam, W, H, spp, offsets, seed, integrator, flags);
+    std::vector<float> block((size_t)2 * A.Wb * A.Hb, 0.f), badj((size_t)2 * A.Wb * A.Hb, 0.f);
+    long n = (long)A.Wb * A.Hb * spp;
+    std::vector<TraceOut> tr(n);
+    for (long lane = 0; lane < n; ++lane) {
+        Lane L = lane_setup(A, *prm, (uint32_t)lane);
+        trace_diff(G, *prm, L.ray.o, L.ray.d, L.ray.maxt, tr[lane]);
+        float val = shade_value(G, A, L, tr[lane].its_t);
+        Reproj rp = reproject(A.cam, *prm, L.ray.o + L.ray.d, W, H);
+        splat_lane(block.data(), A.Wb, A.Hb, rp.u, rp.v, val, PlainAdd());
+    }
+    if (image) develop(block, W, H, image);
+    for (int y = 0; y < H; ++y)
+        for (int x = 0; x < W; ++x) {
+            size_t q = (size_t)(y + DSDF_BORDER) * A.Wb + x + DSDF_BORDER;
+            const float *gi = grad_image + 3 * ((size_t)y * W + x);
+            float gs = gi[0] + gi[1] + gi[2];
+            float w = block[2 * q + 1], s = block[2 * q];
+            if (w == 0.f) { badj[2 * q] = gs; badj[2 * q + 1] = 0.f; }
+            else { badj[2 * q] = gs / w; badj[2 * q + 1] = -gs * s / (w * w); }
+        }
+    for (long lane = 0; lane < n; ++lane) {
+        Lane L = lane_setup(A, *prm, (uint32_t)lane);
+        lane_backward(G, *prm, A, L, tr[lane], badj.data(), grad_grid, PlainAdd());
+    }
+}
+
+void hh_sampler(unsigned seed, long n, float *out) {
+    for (long i = 0; i < n; ++i) sampler_next_2d(seed, (uint32_t)i, out[2 * i], out[2 * i + 1]);
+}
+
+}  // extern "C"

@@ -1,0 +1,82 @@
+"""The C-ABI library loads and exports every symbol include/dsdf.h declares; argument
+validation that happens before any device work; the product path fails loudly
+without its extension.  No compute calls (runs without a GPU)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_symbols():
+    txt = open(os.path.join(ROOT, 'include', 'dsdf.h')).read()
+    txt = re.sub(r'/\*.*?\*/', '', txt, flags=re.S)
+    return sorted(set(re.findall(r'\b(dsdf_[a-z_0-9]+)\s*\(', txt)))
+
+
+def test_every_header_symbol_exported(built):
+    import dsdf
+    lib = dsdf.load()
+    syms = header_symbols()
+    assert len(syms) >= 10
+    for s in syms:
+        assert hasattr(lib, s), f"{s} declared in include/dsdf.h but not exported"
+    assert set(syms) == set(dsdf._lib.SYMBOLS), "ctypes prototypes out of sync with the header"
+    assert lib.dsdf_version() == 100
+
+
+def test_default_params_and_sizes(built):
+    import dsdf
+    lib = dsdf.load()
+    p = dsdf.default_params()
+    assert abs(p.trace_eps - 1e-6) < 1e-12 and abs(p.edge_eps - 0.01) < 1e-9 and p.weight_strategy == 6
+    assert p.refine_steps == 10 and abs(p.clamping_thresh - 0.05) < 1e-9
+    assert C.sizeof(dsdf.DsdfParams) == 64 and C.sizeof(dsdf.DsdfCamera) == 64
+    assert lib.dsdf_padded_size(256, 256, 256) == 262 ** 3
+    assert lib.dsdf_padded_size(4, 5, 6) == 10 * 11 * 12
+    ws = lib.dsdf_render_workspace_size(512, 512, 64)
+    assert ws >= 516 * 516 * 64 * 40 and lib.dsdf_render_workspace_size(0, 4, 4) == 0
+
+
+def test_argument_validation_before_device_work(built):
+    import dsdf
+    lib = dsdf.load()
+    p = dsdf.default_params()
+    assert lib.dsdf_pad_grid(None, 4, 4, 4, None, None) == -1
+    assert b'bad argument' in lib.dsdf_last_error()
+    cam = (dsdf.DsdfCamera * 1)()
+    one = C.c_void_p(16)     # never dereferenced: validation fails first
+    rc = lib.dsdf_render_forward(one, 4, 4, 4, C.byref(p), cam, 1, 8, 8, 4, None, None, 7, 1, one, one, 1 << 30, None, None)
+    assert rc == -1 and b'integrator' in lib.dsdf_last_error()
+    rc = lib.dsdf_render_forward(one, 4, 4, 4, C.byref(p), cam, 1, 8, 8, 4, None, None, 0, 1, one, one, 16, None, None)
+    assert rc == -2 and b'workspace' in lib.dsdf_last_error()
+    rc = lib.dsdf_render_forward(one, 4, 4, 4, C.byref(p), cam, 1, 40000, 40000, 4, None, None, 0, 1, one, one, 1 << 62, None, None)
+    assert rc == -1 and b'wavefront' in lib.dsdf_last_error()       # reparam.py:48-50
+
+
+def test_product_refuses_cpu_tensors(built):
+    import torch
+    import dsdf
+    with pytest.raises(dsdf.DsdfError, match='no CPU path'):
+        dsdf.SdfGrid(torch.zeros(4, 4, 4))
+
+
+def test_missing_extension_fails_loudly(built, monkeypatch):
+    import dsdf
+    from dsdf import _lib
+    monkeypatch.setattr(_lib, '_lib', None)
+    monkeypatch.setattr(_lib, 'LIB_PATH', '/nonexistent/libdsdf.so')
+    with pytest.raises(dsdf.DsdfError, match='No CPU fallback'):
+        _lib.load()
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, 'differentiable-sdf-rendering_amd')
+    for d, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(('.py', '.hip', '.h', '.cpp')):
+                src = open(os.path.join(d, f)).read()
+                assert 'sdf_oracle' not in src and 'oracle/' not in src, os.path.join(d, f)
+                assert 'host_harness' not in src, os.path.join(d, f)

@@ -1,0 +1,101 @@
+"""Kernel arithmetic (csrc/dsdf_math.h, dsdf_lane.h) compiled for the host
+(tests/harness, TEST-ONLY) against the oracle on identical inputs.  This is what
+lets the hand-derived adjoint be validated without a GPU; the GPU parity tests
+(test_gpu_parity.py) repeat the same comparisons through the C-ABI.
+
+Tolerances: forward images 1e-4 relative L2 (north_star).  Gradients: the fp64
+oracle and ANY fp32 evaluation of the estimator (including the oracle itself run
+in fp32, see test_fp32_noise_floor) differ by ~1e-3 relative L2 on these tiny
+cases because the warp-field weights are 1/denom^3 with denom down to 1e-6; the
+bound used is 3e-3 and the fp32-oracle floor is asserted alongside."""
+import numpy as np
+import pytest
+import torch
+
+import sdf_oracle as O
+from cases import make_case, oracle_backward, oracle_forward
+from conftest import rel_l2
+
+FWD_TOL = 1e-4
+GRAD_TOL = 3e-3
+
+
+def cam_params(case):
+    return O.Camera(case['origin']).params()
+
+
+def test_eval_cubic_host(harness):
+    grid = O.blob_grid(24, n=5, seed=4)
+    pts = (torch.rand(4000, 3, dtype=torch.float64) * 1.1 - 0.05).float()
+    v, g, H = harness.eval_cubic(grid.float().numpy(), pts.numpy(), 2)
+    vo, go, Ho = O.eval_cubic(grid, pts.double(), 2)
+    assert rel_l2(v, vo) < 1e-6
+    assert rel_l2(g, go) < 1e-5
+    Ho6 = torch.stack([Ho[:, 0, 0], Ho[:, 1, 1], Ho[:, 2, 2], Ho[:, 0, 1], Ho[:, 0, 2], Ho[:, 1, 2]], -1)
+    assert rel_l2(H, Ho6) < 1e-5
+
+
+def test_trace_host(harness):
+    case = make_case('blob32')
+    cam = O.Camera(case['origin'])
+    pos = torch.rand(3000, 2, dtype=torch.float64) * torch.tensor([case['W'], case['H']], dtype=torch.float64)
+    o, d, maxt = cam.sample_ray(pos, case['W'], case['H'])
+    o32, d32, m32 = o.float(), d.float(), maxt.float()
+    ref = O.ray_intersect(O.Grid3d(case['grid']), o32.double(), d32.double(), m32.double())
+    out = harness.trace(case['grid'].float().numpy(), o32.numpy(), d32.numpy(), m32.numpy(), diff=True)
+    fin = torch.isfinite(ref['its_t']).numpy()
+    assert np.array_equal(np.isfinite(out['its_t']), fin)
+    assert rel_l2(out['its_t'][fin], ref['its_t'].numpy()[fin]) < 1e-5
+    wf = torch.isfinite(ref['warp_t']).numpy()
+    assert (np.isfinite(out['warp_t']) == wf).mean() > 0.999
+    both = wf & np.isfinite(out['warp_t'])
+    assert rel_l2(out['warp_t'][both], ref['warp_t'].numpy()[both]) < 1e-4
+    assert rel_l2(out['warp_weight'][both], ref['warp_weight'].numpy()[both]) < 1e-3
+    same = out['steps'] == ref['steps'].numpy()
+    assert same.mean() > 0.99
+    plain = harness.trace(case['grid'].float().numpy(), o32.numpy(), d32.numpy(), m32.numpy(), diff=False)
+    assert np.array_equal(np.isfinite(plain['its_t']), np.isfinite(out['its_t']))
+    assert rel_l2(plain['its_t'][fin], out['its_t'][fin]) < 1e-6
+
+
+def test_sampler_host_matches_oracle(harness):
+    a = harness.sampler(12345, 5000)
+    b = O.independent_sampler_2d(12345, 5000)
+    assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize('name', ['sphere16', 'blob32', 'blob48_rect'])
+@pytest.mark.parametrize('integ', [O.SILHOUETTE, O.SIMPLE_SHADING])
+def test_render_forward_host(harness, name, integ):
+    case = make_case(name)
+    ref, aux = oracle_forward(case, integ)
+    for diff in (False, True):
+        img = harness.render_forward(case['grid'].float().numpy(), cam_params(case), case['W'], case['H'], case['spp'],
+                                     case['offsets'].numpy(), integ, diff=diff)
+        assert rel_l2(img, ref.numpy()) < FWD_TOL
+
+
+@pytest.mark.parametrize('name', ['sphere16', 'blob32', 'blob32_spp64', 'blob48_rect'])
+@pytest.mark.parametrize('integ', [O.SILHOUETTE, O.SIMPLE_SHADING])
+@pytest.mark.parametrize('reparam', [True, False])
+def test_render_backward_host(harness, name, integ, reparam):
+    case = make_case(name)
+    gref = oracle_backward(case, integ, reparam).numpy()
+    gg, img = harness.render_backward(case['grid'].float().numpy(), cam_params(case), case['W'], case['H'], case['spp'],
+                                      case['offsets'].numpy(), case['grad_image'].numpy(), integ, reparam=reparam)
+    if not reparam and integ == O.SILHOUETTE:
+        assert np.abs(gg).max() == 0 and np.abs(gref).max() == 0      # no shading, no warp -> no gradient
+        return
+    assert np.isfinite(gg).all()
+    assert rel_l2(gg, gref) < GRAD_TOL
+
+
+def test_fp32_noise_floor():
+    """The oracle itself, run in fp32, sits ~1e-3 from its fp64 result on the gradient."""
+    case = make_case('blob32')
+    g64 = oracle_backward(case, O.SILHOUETTE).numpy()
+    cam32 = O.Camera(case['origin'], dtype=torch.float32)
+    g32 = O.render_backward(O.Grid3d(case['grid'].float()), cam32, case['W'], case['H'], case['spp'], case['offsets'],
+                            case['grad_image'], O.SILHOUETTE).numpy()
+    e = rel_l2(g32, g64)
+    assert 1e-5 < e < GRAD_TOL
