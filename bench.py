@@ -1,0 +1,199 @@
+#!/usr/bin/env python3
+"""bench.py -- differentiable renders/s of the hot path on MI355X.
+
+One "step" = one differentiable render in the reference's sense
+(python/shape_opt.py:77-83 per view): for each of `--views` sensors a primal
+render at spp_primal (no AD) and a gradient pass at spp_grad that accumulates
+dL/dsdf, on a 256^3 SDF at 512^2 (BASELINE.json configs[2], the configuration the
+metric is quoted on; it fits one GPU).  Default spp = the reference's 256 / 64
+(python/configs.py:16,19).  Inputs are synthetic, seeded and resident in HBM
+before the timed region.
+
+Multi-GPU (launched by torch.distributed.run, one rank per GPU): weak scaling --
+every rank renders its own `--views` sensors of a 12*N-sensor ring (a larger view
+batch per optimisation step), then the per-voxel gradient grid is summed with one
+RCCL all-reduce (the path's only exchange step).  value = N * views-batches / time.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, 'differentiable-sdf-rendering_amd', 'python'))
+
+import torch
+
+
+def synth_grid(res, device, n=32, seed=0):
+    """Seeded union of spheres/tori clipped by the box SDF (SURVEY 8d synthetic inputs;
+    same recipe as variables.py:161-166, 185-187 for the box clip).  Built on the device."""
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    lin = torch.linspace(0, 1, res, device=device)
+    z, y, x = torch.meshgrid(lin, lin, lin, indexing='ij')
+    sd = torch.full((res, res, res), 1e9, device=device)
+    for k in range(n):
+        c = rng.uniform(0.3, 0.7, 3)
+        if k % 2 == 0:
+            r = rng.uniform(0.05, 0.12)
+            sd = torch.minimum(sd, torch.sqrt((x - c[0]) ** 2 + (y - c[1]) ** 2 + (z - c[2]) ** 2) - r)
+        else:
+            R, r = rng.uniform(0.08, 0.16), rng.uniform(0.015, 0.035)
+            q = [x - c[0], y - c[1], z - c[2]]
+            ax = k % 3
+            o = [a for a in range(3) if a != ax]
+            ring = torch.sqrt(q[o[0]] ** 2 + q[o[1]] ** 2) - R
+            sd = torch.minimum(sd, torch.sqrt(ring ** 2 + q[ax] ** 2) - r)
+    lin2 = torch.linspace(-0.5, 0.5, res, device=device)
+    z, y, x = torch.meshgrid(lin2, lin2, lin2, indexing='ij')
+    q = torch.stack([x.abs(), y.abs(), z.abs()], -1) - 0.49
+    box = torch.linalg.norm(q.clamp(min=0), dim=-1) + q.max(-1).values.clamp(max=0) - 0.01
+    return torch.maximum(sd, box).contiguous()
+
+
+def cpu_baseline(args, res_sample=48, spp_p=8, spp_g=2):
+    """Oracle ('port': torch-CPU restatement) timed on the host cores on a bounded
+    sample of the same workload: same 256^3 grid recipe, one sensor of the ring, a
+    48x48 film at 8/2 spp; scaled linearly in lanes to the full job."""
+    sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+    import sdf_oracle as O
+    g = synth_grid(args.res, 'cpu').double()
+    cam = O.Camera(O.regular_camera_origins(args.views)[0])
+    W = H = res_sample
+    torch.manual_seed(0)
+    op = torch.rand((W + 4) * (H + 4) * spp_p, 2, dtype=torch.float64)
+    og = torch.rand((W + 4) * (H + 4) * spp_g, 2, dtype=torch.float64)
+    gi = torch.randn(H, W, 3, dtype=torch.float64)
+    t0 = time.time()
+    with torch.no_grad():
+        O.render(O.Grid3d(g), cam, W, H, spp_p, op, O.SILHOUETTE)
+    t1 = time.time()
+    O.render_backward(O.Grid3d(g), cam, W, H, spp_g, og, gi, O.SILHOUETTE)
+    t2 = time.time()
+    Wb = args.img + 4
+    full_p, full_g = Wb * Wb * args.spp_primal, Wb * Wb * args.spp_grad
+    samp_p, samp_g = (W + 4) * (H + 4) * spp_p, (W + 4) * (H + 4) * spp_g
+    t_view = (t1 - t0) * full_p / samp_p + (t2 - t1) * full_g / samp_g
+    return {"value": 1.0 / (t_view * args.views), "unit": "renders/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"oracle (torch-CPU fp64), 1 of {args.views} sensors, {W}x{H} film, spp {spp_p}/{spp_g}, "
+                      f"{args.res}^3 grid; {t2 - t0:.1f}s measured, scaled linearly in lanes"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=3)
+    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--res', type=int, default=256)
+    ap.add_argument('--img', type=int, default=512)
+    ap.add_argument('--views', type=int, default=12)
+    ap.add_argument('--spp-primal', type=int, default=256)
+    ap.add_argument('--spp-grad', type=int, default=64)
+    ap.add_argument('--integrator', default='sdf_silhouette_reparam')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', 0))
+    local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    import dsdf
+    dsdf.load()
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group('nccl', device_id=dev)
+
+    data = synth_grid(args.res, dev)
+    grid = dsdf.SdfGrid(data)
+    target = dsdf.SdfGrid(synth_grid(args.res, dev, seed=1))
+    sensors = dsdf.get_regular_cameras(args.views * world, resx=args.img, resy=args.img)[rank * args.views:(rank + 1) * args.views]
+    grad = torch.zeros_like(data)
+    # target images (outside the timed region) -> L1 image gradient sign(img - target)/(H*W*3)
+    tgt = torch.cat([dsdf.render_forward(target, s, 64, seeds=[1000 + i]) for i, s in enumerate(sensors)])
+    scale = 1.0 / (args.img * args.img * 3)
+
+    ev = lambda: torch.cuda.Event(enable_timing=True)
+    prim_ms, grad_ms = [], []
+
+    def step(it, timed):
+        grad.zero_()
+        for i, s in enumerate(sensors):
+            seed = (it * args.views + i) * 2 + 17 * rank
+            e0, e1, e2 = ev(), ev(), ev()
+            e0.record()
+            img = dsdf.render_forward(grid, s, args.spp_primal, seeds=[seed], integrator=args.integrator)
+            e1.record()
+            gi = torch.sign(img - tgt[i:i + 1]) * scale
+            dsdf.render_backward(grid, s, args.spp_grad, gi, grad_grid=grad, seeds=[seed + 1], integrator=args.integrator)
+            e2.record()
+            if timed:
+                prim_ms.append((e0, e1)); grad_ms.append((e1, e2))
+        if dist is not None:
+            dist.all_reduce(grad)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for w in range(args.warmup):
+        step(w, False)
+    barrier()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(args.warmup + k, True)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t)
+
+    # per-launch statistics for the algorithmic byte count (untimed, one view)
+    st_p, st_g = dsdf.new_stats(dev), dsdf.new_stats(dev)
+    dsdf.render_forward(grid, sensors[0], args.spp_primal, seeds=[1], integrator=args.integrator, stats=st_p)
+    dsdf.render_backward(grid, sensors[0], args.spp_grad, torch.ones(1, args.img, args.img, 3, device=dev) * scale,
+                         grad_grid=torch.zeros_like(data), seeds=[2], integrator=args.integrator, stats=st_g)
+    sp, sg = dsdf.stats_dict(st_p), dsdf.stats_dict(st_g)
+    prim = [a.elapsed_time(b) for a, b in prim_ms]
+    gradt = [a.elapsed_time(b) for a, b in grad_ms]
+    prim_avg = sum(prim) / len(prim)
+    # DESIGN.md "Algorithmic bytes": 64 fp32 taps per cubic evaluation (trace steps + refinement),
+    # 16 px x 2 ch x 8 B film read-modify-write per lane, one compulsory read of the grid.
+    evals = sp['steps'] + sp['refine_steps']
+    alg_bytes = 256.0 * evals + 16 * 2 * 8.0 * sp['lanes'] + 4.0 * args.res ** 3
+    achieved = alg_bytes / (prim_avg * 1e-3) / 1e9
+
+    if rank == 0:
+        out = {
+            "metric": "diff-renders/sec (fwd+bwd) 256^3 SDF, 512^2, 12 views",
+            "value": world * args.steps / elapsed, "unit": "renders/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"no-tex-12-hq sizes: {args.res}^3 SDF, {args.views} views x {args.img}^2, "
+                                   f"{args.integrator}, spp primal/grad {args.spp_primal}/{args.spp_grad} "
+                                   f"(reference semantics, configs.py:16,19)",
+                       "views_per_gpu": args.views, "spp_primal": args.spp_primal, "spp_grad": args.spp_grad,
+                       "mean_steps_per_bbox_lane": sp['steps'] / max(sp['bbox_lanes'], 1),
+                       "hit_fraction": sp['hits'] / max(sp['lanes'], 1),
+                       "bbox_fraction": sp['bbox_lanes'] / max(sp['lanes'], 1),
+                       "backward_queue_fraction": sg['queue_len'] / max(sg['lanes'], 1),
+                       "primal_ms_per_view": prim_avg, "grad_ms_per_view": sum(gradt) / len(gradt)},
+            "roofline": {"bound": "hbm", "kernel": "k_render_pass<primal>", "achieved": achieved, "peak": 8000.0,
+                         "unit": "GB/s", "frac": achieved / 8000.0, "traffic": None,
+                         "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": prim_avg},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -174,7 +174,7 @@ __global__ __launch_bounds__(DSDF_BLOCK) void k_render_pass(GridView G, dsdf_par
     bool need = false;
     if (DIFF) {
         bool hit = tr.its_t < INFINITY;
-        bool warp_cand = (A.flags & DSDF_REPARAM) && (fabsf(tr.warp_t) < INFINITY) && (tr.warp_weight > 0.f);
+        bool warp_cand = (A.flags & DSDF_REPARAM) && warp_weight_positive(G, P, L.ray.o, L.ray.d, tr);
         need = valid && (warp_cand || (hit && A.integrator == DSDF_SIMPLE_SHADING));
         // wavefront compaction: ballot + mbcnt prefix + one atomic per wave
         uint64_t m = __ballot(need);

@@ -500,6 +500,21 @@ DSDF_HD void sampler_next_2d(uint32_t seed, uint32_t lane, float &r0, float &r1)
 // x = o + warp_t d,   d(dir) = cdir * dv ,   div = a*v + b.g .
 // Returns false when the warp is inactive (w <= 0 or warp_t not finite).
 // ---------------------------------------------------------------------------
+// Cheap exact test of "boundary weight w > 0" (warp.py:25-39, 71-74, 91) with a
+// value-only lookup; used to keep samples with a vanishing warp out of the backward queue.
+DSDF_HD bool warp_weight_positive(const GridView &G, const dsdf_params &P, V3 o, V3 d, const TraceOut &tr) {
+    float t = tr.warp_t;
+    if (!(fabsf(t) < INFINITY) || !(tr.warp_weight > 0.f)) return false;
+    V3 x = fma3(t, d, o);
+    float v = eval_value(G, x);
+    float edge_eps = (P.weight_strategy == 6) ? P.edge_eps * t : P.edge_eps;
+    V3 bd_d;
+    float bd = bbox_distance_inside_d(x, -P.bbox_delta, 1.f + P.bbox_delta, bd_d);
+    float eps = fminf(edge_eps, bd);
+    float fac = 1.f - fabsf(v) * (1.f / eps);
+    return fmaxf(fac, 0.f) * tr.warp_weight > 0.f;
+}
+
 struct WarpCoef { V3 cdir; float a; V3 b; float div; };
 
 DSDF_HD bool warp_coefficients(const GridView &G, const dsdf_params &P, V3 o, V3 d, const TraceOut &tr, WarpCoef &wc) {

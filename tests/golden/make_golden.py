@@ -1,0 +1,32 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/*.npz from the fp64 oracle (oracle/sdf_oracle.py).
+
+The reference itself ships no golden vectors and cannot be run here (Mitsuba /
+Dr.Jit absent), so these fixtures pin the ORACLE (and through it the HIP path)
+against silent regressions; they are not outputs of the reference.
+Run:  python tests/golden/make_golden.py
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+for p in (os.path.join(ROOT, 'oracle'), os.path.join(ROOT, 'tests')):
+    sys.path.insert(0, p)
+
+import sdf_oracle as O
+from cases import make_case, oracle_backward, oracle_forward
+
+for name in ('sphere16', 'blob32'):
+    case = make_case(name)
+    out = {}
+    for integ, tag in ((O.SILHOUETTE, 'sil'), (O.SIMPLE_SHADING, 'shade')):
+        img, aux = oracle_forward(case, integ)
+        out[f'img_{tag}'] = img.numpy().astype(np.float32)
+        out[f'grad_{tag}'] = oracle_backward(case, integ).numpy().astype(np.float32)
+        out[f'steps_{tag}'] = np.int64(aux['steps'])
+        out[f'hits_{tag}'] = np.int64(aux['hits'])
+    np.savez_compressed(os.path.join(HERE, f'{name}.npz'), **out)
+    print(name, {k: (v.shape if hasattr(v, 'shape') else v) for k, v in out.items()})

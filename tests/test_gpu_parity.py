@@ -1,0 +1,187 @@
+"""GPU parity: the HIP path (through the C-ABI / ctypes shim) against the oracle on
+identical seeded inputs, plus size-independent properties at larger sizes.
+Tolerances: forward 1e-4 relative L2 (north_star); gradient 3e-3 on the tiny
+oracle-sized cases (fp32 noise floor of the estimator, see test_kernel_math_host.py)."""
+import numpy as np
+import pytest
+import torch
+
+import sdf_oracle as O
+from cases import make_case, oracle_backward, oracle_forward
+from conftest import rel_l2
+
+pytestmark = pytest.mark.gpu
+
+FWD_TOL = 1e-4
+GRAD_TOL = 3e-3
+
+
+@pytest.fixture(scope='module')
+def dsdf(built):
+    import dsdf as m
+    m.load()
+    assert torch.cuda.is_available()
+    return m
+
+
+def dev_grid(dsdf, case):
+    return dsdf.SdfGrid(case['grid'].float().cuda())
+
+
+def sensor(dsdf, case):
+    return dsdf.get_regular_cameras(case['ncam'], resx=case['W'], resy=case['H'])[case['icam']]
+
+
+def test_eval_cubic_gpu(dsdf):
+    grid = O.blob_grid(24, n=5, seed=4)
+    pts = (torch.rand(20000, 3, dtype=torch.float64) * 1.1 - 0.05).float()
+    g = dsdf.SdfGrid(grid.float().cuda())
+    v, gr, H = dsdf.eval_cubic(g, pts.cuda(), 2)
+    vo, go, Ho = O.eval_cubic(grid, pts.double(), 2)
+    Ho6 = torch.stack([Ho[:, 0, 0], Ho[:, 1, 1], Ho[:, 2, 2], Ho[:, 0, 1], Ho[:, 0, 2], Ho[:, 1, 2]], -1)
+    assert rel_l2(v.cpu(), vo) < 1e-6 and rel_l2(gr.cpu(), go) < 1e-5 and rel_l2(H.cpu(), Ho6) < 1e-5
+    v0, _, _ = dsdf.eval_cubic(g, pts.cuda(), 0)
+    assert rel_l2(v0.cpu(), vo) < 1e-6
+
+
+def test_trace_gpu(dsdf):
+    case = make_case('blob32')
+    cam = O.Camera(case['origin'])
+    pos = torch.rand(5000, 2, dtype=torch.float64) * torch.tensor([case['W'], case['H']], dtype=torch.float64)
+    o, d, maxt = cam.sample_ray(pos, case['W'], case['H'])
+    o32, d32, m32 = o.float(), d.float(), maxt.float()
+    ref = O.ray_intersect(O.Grid3d(case['grid']), o32.double(), d32.double(), m32.double())
+    out = dsdf.trace(dev_grid(dsdf, case), o32.cuda(), d32.cuda(), m32.cuda(), True)
+    out = {k: v.cpu().numpy() for k, v in out.items()}
+    fin = torch.isfinite(ref['its_t']).numpy()
+    assert np.array_equal(np.isfinite(out['its_t']), fin)
+    assert rel_l2(out['its_t'][fin], ref['its_t'].numpy()[fin]) < 1e-5
+    both = torch.isfinite(ref['warp_t']).numpy() & np.isfinite(out['warp_t'])
+    assert both.sum() > 100
+    assert rel_l2(out['warp_t'][both], ref['warp_t'].numpy()[both]) < 1e-4
+    assert (out['steps'] == ref['steps'].numpy()).mean() > 0.99
+    plain = dsdf.trace(dev_grid(dsdf, case), o32.cuda(), d32.cuda(), m32.cuda(), False)['its_t'].cpu().numpy()
+    assert np.array_equal(np.isfinite(plain), fin) and rel_l2(plain[fin], out['its_t'][fin]) < 1e-6
+
+
+@pytest.mark.parametrize('name', ['sphere16', 'blob32', 'blob32_spp64', 'blob48_rect'])
+@pytest.mark.parametrize('integ', [O.SILHOUETTE, O.SIMPLE_SHADING])
+def test_render_forward_gpu(dsdf, name, integ):
+    case = make_case(name)
+    ref, aux = oracle_forward(case, integ)
+    stats = dsdf.new_stats('cuda')
+    img = dsdf.render_forward(dev_grid(dsdf, case), sensor(dsdf, case), case['spp'], offsets=case['offsets'].cuda(),
+                              integrator=integ, stats=stats)[0]
+    assert rel_l2(img.cpu(), ref) < FWD_TOL
+    st = dsdf.stats_dict(stats)
+    assert st['lanes'] == aux['lanes'] and st['hits'] == aux['hits']
+    assert abs(st['steps'] - aux['steps']) <= 0.01 * aux['steps']
+
+
+@pytest.mark.parametrize('name', ['sphere16', 'blob32', 'blob32_spp64', 'blob48_rect'])
+@pytest.mark.parametrize('integ', [O.SILHOUETTE, O.SIMPLE_SHADING])
+@pytest.mark.parametrize('reparam', [True, False])
+def test_render_backward_gpu(dsdf, name, integ, reparam):
+    case = make_case(name)
+    gref = oracle_backward(case, integ, reparam).numpy()
+    gg, img = dsdf.render_backward(dev_grid(dsdf, case), sensor(dsdf, case), case['spp'], case['grad_image'].cuda()[None],
+                                   offsets=case['offsets'].cuda(), integrator=integ, reparam=reparam, return_image=True)
+    ref_img, _ = oracle_forward(case, integ)
+    assert rel_l2(img[0].cpu(), ref_img) < FWD_TOL         # gradient-pass image == primal image on the same samples (F8)
+    gg = gg.cpu().numpy()
+    if not reparam and integ == O.SILHOUETTE:
+        assert np.abs(gg).max() == 0
+        return
+    assert np.isfinite(gg).all()
+    assert rel_l2(gg, gref) < GRAD_TOL
+
+
+def test_backward_accumulates(dsdf):
+    case = make_case('blob32')
+    grid, sen = dev_grid(dsdf, case), sensor(dsdf, case)
+    kw = dict(offsets=case['offsets'].cuda(), integrator=O.SILHOUETTE)
+    g1 = dsdf.render_backward(grid, sen, case['spp'], case['grad_image'].cuda()[None], **kw)
+    g2 = dsdf.render_backward(grid, sen, case['spp'], case['grad_image'].cuda()[None], grad_grid=g1.clone(), **kw)
+    assert rel_l2(g2.cpu(), 2 * g1.cpu()) < 1e-5
+    # linearity in grad_image (size-independent property)
+    g3 = dsdf.render_backward(grid, sen, case['spp'], -3.0 * case['grad_image'].cuda()[None], **kw)
+    assert rel_l2(g3.cpu(), -3.0 * g1.cpu()) < 1e-5
+
+
+def test_builtin_sampler_matches_explicit_offsets(dsdf):
+    """In-kernel `independent` sampler (PCG32 + sample_tea_32) == oracle's numpy restatement."""
+    case = make_case('blob32')
+    n = (case['W'] + 4) * (case['H'] + 4) * case['spp']
+    offs = torch.tensor(O.independent_sampler_2d(77, n))
+    grid, sen = dev_grid(dsdf, case), sensor(dsdf, case)
+    a = dsdf.render_forward(grid, sen, case['spp'], seeds=[77], integrator=O.SIMPLE_SHADING)
+    b = dsdf.render_forward(grid, sen, case['spp'], offsets=offs.cuda(), integrator=O.SIMPLE_SHADING)
+    assert rel_l2(a.cpu(), b.cpu()) < 1e-6
+
+
+def test_multi_view_batch_equals_single_views(dsdf):
+    case = make_case('blob48_rect')
+    sens = dsdf.get_regular_cameras(12, resx=case['W'], resy=case['H'])[:3]
+    grid = dev_grid(dsdf, case)
+    batch = dsdf.render_forward(grid, sens, 4, seeds=[5, 6, 7])
+    for i, s in enumerate(sens):
+        one = dsdf.render_forward(grid, s, 4, seeds=[5 + i])
+        assert rel_l2(batch[i].cpu(), one[0].cpu()) < 1e-6
+    gi = torch.randn(3, case['H'], case['W'], 3).cuda()
+    gb = dsdf.render_backward(grid, sens, 4, gi, seeds=[9, 10, 11])
+    gs = sum(dsdf.render_backward(grid, s, 4, gi[i:i + 1].contiguous(), seeds=[9 + i]) for i, s in enumerate(sens))
+    assert rel_l2(gb.cpu(), gs.cpu()) < 1e-5
+
+
+def test_autograd_render_op(dsdf):
+    """`mi.render` semantics: primal from (seed, spp), gradient from (seed_grad, spp_grad)."""
+    case = make_case('blob32')
+    data = case['grid'].float().cuda().requires_grad_(True)
+    grid = dsdf.SdfGrid(data)
+    sen = sensor(dsdf, case)
+    img = dsdf.render(data, grid, [sen], spp=16, seed=3, spp_grad=8, seed_grad=11)
+    target = torch.zeros_like(img)
+    loss = (img - target).abs().mean()
+    loss.backward()
+    assert data.grad is not None and torch.isfinite(data.grad).all() and data.grad.abs().sum() > 0
+    gi = torch.sign(img.detach()) / img.numel()
+    ref = dsdf.render_backward(grid, sen, 8, gi, seeds=[11])
+    assert rel_l2(data.grad.cpu(), ref.cpu()) < 1e-5
+
+
+def test_primal_invariance_large(dsdf):
+    """Size-independent property at a bench-like size: reparam on/off gives the same image (F8),
+    wave-uniform splat (spp=64) == per-lane splat path on the same samples."""
+    R, W, H = 128, 96, 96
+    data = O.blob_grid(R, n=16, seed=5).float().cuda()
+    grid = dsdf.SdfGrid(data)
+    sen = dsdf.get_regular_cameras(12, resx=W, resy=H)[3]
+    a = dsdf.render_forward(grid, sen, 64, seeds=[1], reparam=True)
+    b = dsdf.render_forward(grid, sen, 64, seeds=[1], reparam=False)
+    assert rel_l2(a.cpu(), b.cpu()) < 1e-6
+    gi = torch.randn(1, H, W, 3).cuda()
+    _, img_g = dsdf.render_backward(grid, sen, 64, gi, seeds=[1], return_image=True)
+    assert rel_l2(img_g.cpu(), a.cpu()) < 1e-5
+    assert 0.02 < float(a.mean()) < 0.9
+
+
+def test_gradient_descends_loss(dsdf):
+    """End-to-end sanity at GPU-only size: a few gradient steps on a sphere SDF towards a
+    bigger sphere reduce the image loss (the optimisation the reference runs)."""
+    R, W, H = 64, 64, 64
+    target_grid = dsdf.SdfGrid(O.sphere_grid(R, radius=0.36).float().cuda())
+    data = O.sphere_grid(R, radius=0.3).float().cuda().requires_grad_(True)
+    grid = dsdf.SdfGrid(data)
+    sens = dsdf.get_regular_cameras(4, resx=W, resy=H)
+    target = dsdf.render_forward(target_grid, sens, 64, seeds=[100, 101, 102, 103])
+    losses = []
+    for it in range(6):
+        grid.update(data)
+        img = dsdf.render(data, grid, sens, spp=64, seed=10 * it, spp_grad=16, seed_grad=10 * it + 5)
+        loss = (img - target).abs().mean()
+        data.grad = None
+        loss.backward()
+        with torch.no_grad():
+            data -= 0.01 * torch.sign(data.grad)
+        losses.append(float(loss))
+    assert losses[-1] < 0.7 * losses[0], losses
