@@ -91,6 +91,83 @@ __device__ __forceinline__ int wave_sum_i32(int v) {
     return v;
 }
 
+__device__ __forceinline__ int wave_min_i32(int v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v = min(v, __shfl_xor(v, m));
+    return v;
+}
+__device__ __forceinline__ int wave_max_i32(int v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v = max(v, __shfl_xor(v, m));
+    return v;
+}
+// LDS operations of one wave execute in program order; these fences only stop the
+// compiler from moving LDS accesses across the phases of the wave-private brick.
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// LDS-aggregated 64-tap scatter for one wave.  The samples of a wave come from a few
+// neighbouring pixels, so their 4^3 footprints overlap heavily: accumulate them in a
+// wave-private LDS brick spanning the bounding box of all taps (ds_add_f32), then
+// flush only the non-zero voxels with one global atomic each.  Falls back to direct
+// global atomics when the bounding box does not fit the brick.
+#define DSDF_BRICK_CAP 4096
+__device__ __forceinline__ void wave_scatter(const GridView &G, float *__restrict__ grad, const ScatterReq &rq,
+                                             float *brick, int lid) {
+    const bool on = rq.on;
+    if (!__ballot(on)) return;
+    CubicSetup s = cubic_setup(G, on ? rq.x : mk(0.f, 0.f, 0.f));
+    const int big = 1 << 30;
+    int minx = wave_min_i32(on ? iclamp(s.ix, 0, G.rx - 1) : big), maxx = wave_max_i32(on ? iclamp(s.ix + 3, 0, G.rx - 1) : -big);
+    int miny = wave_min_i32(on ? iclamp(s.iy, 0, G.ry - 1) : big), maxy = wave_max_i32(on ? iclamp(s.iy + 3, 0, G.ry - 1) : -big);
+    int minz = wave_min_i32(on ? iclamp(s.iz, 0, G.rz - 1) : big), maxz = wave_max_i32(on ? iclamp(s.iz + 3, 0, G.rz - 1) : -big);
+    int ex = maxx - minx + 1, ey = maxy - miny + 1, ez = maxz - minz + 1;
+    bool fits = ex <= 64 && ey <= 64 && ez <= 64 && ex * ey * ez <= DSDF_BRICK_CAP;
+    if (!fits) {
+        if (on) scatter_cubic(G, grad, rq.x, rq.cv, rq.cg, AtomicAdd());
+        return;
+    }
+    const int vol = ex * ey * ez;
+    for (int e = lid; e < vol; e += 64) brick[e] = 0.f;
+    wave_lds_sync();
+    if (on) {
+        float wx[4], wy[4], wz[4], dwx[4], dwy[4], dwz[4];
+        bspline_w(s.ax, wx); bspline_w(s.ay, wy); bspline_w(s.az, wz);
+        bspline_dw(s.ax, dwx); bspline_dw(s.ay, dwy); bspline_dw(s.az, dwz);
+        float gx = rq.cg.x * (float)G.rx, gy = rq.cg.y * (float)G.ry, gz = rq.cg.z * (float)G.rz;
+        int xo[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) xo[i] = iclamp(s.ix + i, 0, G.rx - 1) - minx;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            int zo = iclamp(s.iz + k, 0, G.rz - 1) - minz;
+            float azv = wz[k], azd = dwz[k] * gz;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                int yo = iclamp(s.iy + j, 0, G.ry - 1) - miny;
+                float *row = brick + (zo * ey + yo) * ex;
+                float c0 = azv * wy[j] * rq.cv + azd * wy[j] + azv * dwy[j] * gy;
+                float c1 = azv * wy[j] * gx;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) atomicAdd(row + xo[i], fmaf(c0, wx[i], c1 * dwx[i]));
+            }
+        }
+    }
+    wave_lds_sync();
+    for (int e = lid; e < vol; e += 64) {
+        float v = brick[e];
+        if (v != 0.f) {
+            int x = e % ex, t = e / ex;
+            int y = t % ey, z = t / ey;
+            atomicAdd(grad + ((size_t)(minz + z) * G.ry + (miny + y)) * G.rx + (minx + x), v);
+        }
+    }
+    wave_lds_sync();
+}
+
 // Transposed butterfly reduction: every lane brings 64 values, lane l leaves with
 // the wave-wide sum of slot l.  63 cross-lane exchanges instead of 64 x 6.
 template <int HALF>
@@ -249,10 +326,15 @@ __global__ void k_develop_adjoint(const float *__restrict__ block, const float *
 __global__ __launch_bounds__(DSDF_BLOCK) void k_backward(GridView G, dsdf_params P, ViewArgs A, Queue q,
                                                          const float *__restrict__ block_adj,
                                                          float *__restrict__ grad_grid, unsigned long long *stats) {
+    __shared__ float bricks[DSDF_BLOCK / 64][DSDF_BRICK_CAP];
     uint32_t count = *q.count;
     if (count > q.cap) count = q.cap;
     uint32_t idx = blockIdx.x * DSDF_BLOCK + threadIdx.x;
+    if ((blockIdx.x * DSDF_BLOCK) >= count) return;      // whole block past the end of the queue
+    const int lid = lane_id();
     bool did = false;
+    ScatterReq req[2];
+    req[0].on = false; req[1].on = false;
     if (idx < count) {
         uint32_t lane = q.lane[idx];
         const float *r = q.rec + idx;
@@ -264,11 +346,14 @@ __global__ __launch_bounds__(DSDF_BLOCK) void k_backward(GridView G, dsdf_params
         tr.warp_weight_d = mk(r[6 * c], r[7 * c], r[8 * c]);
         tr.steps = 0; tr.refine_steps = 0; tr.weight_sum = 0.f;
         Lane L = lane_setup(A, P, lane);
-        did = lane_backward(G, P, A, L, tr, block_adj, grad_grid, AtomicAdd());
+        did = lane_backward(G, P, A, L, tr, block_adj, req);
     }
+    float *brick = bricks[threadIdx.x / 64];
+    wave_scatter(G, grad_grid, req[0], brick, lid);
+    if (A.integrator != DSDF_SILHOUETTE) wave_scatter(G, grad_grid, req[1], brick, lid);
     if (stats) {
         int s = wave_sum_i32(did ? 1 : 0);
-        if (lane_id() == 0 && s) atomicAdd(stats + 5, (unsigned long long)s);
+        if (lid == 0 && s) atomicAdd(stats + 5, (unsigned long long)s);
     }
 }
 

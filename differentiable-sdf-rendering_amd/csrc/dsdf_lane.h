@@ -83,11 +83,17 @@ DSDF_HD void splat_lane(float *block, int Wb, int Hb, float u, float v, float va
     }
 }
 
+// One 64-tap scatter into dL/dsdf: grad[tap] += cv * W_tap + cg . (res * dW_tap) at point x.
+struct ScatterReq { bool on; V3 x; float cv; V3 cg; };
+
 // Adjoint of one gradient-pass sample.  `tr` holds the (detached) trace outputs,
-// block_adj the adjoint of the 2-channel film block.  Accumulates into grad_grid.
-template <class Adder>
+// block_adj the adjoint of the 2-channel film block.  Produces up to two scatter
+// requests: req[0] at the warp point x = o + warp_t d, req[1] at the hit point
+// (shading integrators only).  The caller performs them (scatter_cubic on the host,
+// the LDS-aggregated wave scatter on the device).
 DSDF_HD bool lane_backward(const GridView &G, const dsdf_params &P, const ViewArgs &A, const Lane &L,
-                           const TraceOut &tr, const float *block_adj, float *grad_grid, Adder add) {
+                           const TraceOut &tr, const float *block_adj, ScatterReq req[2]) {
+    req[0].on = false; req[1].on = false;
     const V3 o = L.ray.o, d = L.ray.d;
     bool hit = tr.its_t < INFINITY;
     // --- film adjoint gather (ImageBlock::put is linear in the values and
@@ -167,7 +173,7 @@ DSDF_HD bool lane_backward(const GridView &G, const dsdf_params &P, const ViewAr
         float t_bar = dot(p_bar, d);
         float v0_bar = t_bar / c;
         dir_bar = dir_bar + tr.its_t * p_bar + (v0_bar * tr.its_t) * ghit;
-        scatter_cubic(G, grad_grid, phit, v0_bar, G_bar, add);
+        req[1].on = true; req[1].x = phit; req[1].cv = v0_bar; req[1].cg = G_bar;
         did = true;
     }
     // --- warp channel
@@ -176,7 +182,7 @@ DSDF_HD bool lane_backward(const GridView &G, const dsdf_params &P, const ViewAr
         if (warp_coefficients(G, P, o, d, tr, wc)) {
             float vw_bar = dot(wc.cdir, dir_bar) + wc.a * div_bar;
             V3 gw_bar = div_bar * wc.b;
-            scatter_cubic(G, grad_grid, fma3(tr.warp_t, d, o), vw_bar, gw_bar, add);
+            req[0].on = true; req[0].x = fma3(tr.warp_t, d, o); req[0].cv = vw_bar; req[0].cg = gw_bar;
             did = true;
         }
     }

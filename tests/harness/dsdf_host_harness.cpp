@@ -127,7 +127,10 @@ void hh_render_backward(const float *data, int rx, int ry, int rz, const dsdf_pa
         }
     for (long lane = 0; lane < n; ++lane) {
         Lane L = lane_setup(A, *prm, (uint32_t)lane);
-        lane_backward(G, *prm, A, L, tr[lane], badj.data(), grad_grid, PlainAdd());
+        ScatterReq req[2];
+        lane_backward(G, *prm, A, L, tr[lane], badj.data(), req);
+        for (int r = 0; r < 2; ++r)
+            if (req[r].on) scatter_cubic(G, grad_grid, req[r].x, req[r].cv, req[r].cg, PlainAdd());
     }
 }
 
