@@ -24,6 +24,7 @@
 using namespace dsdf;
 
 #define DSDF_BLOCK 256
+#define DSDF_TSTRIDE 68   /* 64 + 4: rows 16-byte aligned, ds_read_b128 conflict-free across lanes */
 
 struct AtomicAdd {
     __device__ __forceinline__ void operator()(float *p, float v) const { atomicAdd(p, v); }
@@ -190,11 +191,14 @@ __device__ __forceinline__ float wave_transpose_reduce(float (&v)[64], int lane)
     return v[0];
 }
 
-// Queue of samples that need the backward sweep (SoA, stride = cap).
+// Queue of samples that need the backward sweep.  Every render-pass block owns the slot
+// range [block*DSDF_BLOCK, (block+1)*DSDF_BLOCK) and compacts its samples to the front of
+// it (block-level ballot/mbcnt prefix), so queue order stays pixel order: a backward block
+// sees the samples of a few neighbouring pixels and its LDS brick stays small.
 struct Queue {
-    uint32_t *count;
+    uint32_t *count;  // per render-pass block
     uint32_t *lane;
-    float *rec;       // 9 rows: its_t, warp_t, wtd.xyz, ww, wwd.xyz
+    float *rec;       // 9 rows (SoA, stride = cap): its_t, warp_t, wtd.xyz, ww, wwd.xyz
     uint32_t cap;
 };
 
@@ -224,25 +228,43 @@ __global__ __launch_bounds__(DSDF_BLOCK) void k_render_pass(GridView G, dsdf_par
             fx[i] = gauss_f((float)(L.px - 2 + i) - pfx);
             fy[i] = gauss_f((float)(L.py - 2 + i) - pfy);
         }
-        float v[64];
+        // Wave-wide sum of the 25 window weights (x value, x 1) through a wave-private LDS
+        // transpose: lane l writes column l, lane k < 25 sums row k (16 ds_read_b128).
+        __shared__ float tbuf[DSDF_BLOCK / 64][25 * DSDF_TSTRIDE];
+        float *T = tbuf[threadIdx.x >> 6];
+        float f[25];
 #pragma unroll
         for (int j = 0; j < 5; ++j)
 #pragma unroll
-            for (int i = 0; i < 5; ++i) {
-                float f = fx[i] * fy[j];
-                v[j * 5 + i] = f * val;
-                v[25 + j * 5 + i] = f;
-            }
+            for (int i = 0; i < 5; ++i) f[j * 5 + i] = fx[i] * fy[j];
+        const int j5 = lid / 5, i5 = lid - 5 * j5;
+        const int qx = L.px - 2 + i5, qy = L.py - 2 + j5;
+        const bool own = lid < 25 && qx >= 0 && qx < A.Wb && qy >= 0 && qy < A.Hb;
+        float *dst = block + 2 * ((size_t)(own ? qy : 0) * A.Wb + (own ? qx : 0));
+        const bool any_val = __ballot(val != 0.f) != 0;     // pixels nobody hits skip the value channel
 #pragma unroll
-        for (int k = 50; k < 64; ++k) v[k] = 0.f;
-        float total = wave_transpose_reduce(v, lid);
-        if (lid < 50) {
-            int ch = lid >= 25 ? 1 : 0;
-            int s = lid - 25 * ch;
-            int j = s / 5, i = s - 5 * j;
-            int qx = L.px - 2 + i, qy = L.py - 2 + j;
-            if (qx >= 0 && qx < A.Wb && qy >= 0 && qy < A.Hb && total != 0.f)
-                atomicAdd(block + 2 * ((size_t)qy * A.Wb + qx) + ch, total);
+        for (int ch = 0; ch < 2; ++ch) {
+            if (ch == 0 && !any_val) continue;
+#pragma unroll
+            for (int k = 0; k < 25; ++k) T[k * DSDF_TSTRIDE + lid] = ch == 0 ? f[k] * val : f[k];
+            wave_lds_sync();
+            float total = 0.f;
+            if (lid < 25) {
+                const float4 *row = reinterpret_cast<const float4 *>(T + lid * DSDF_TSTRIDE);
+                float4 a0 = row[0], a1 = row[1], a2 = row[2], a3 = row[3];
+#pragma unroll
+                for (int r = 4; r < 16; r += 4) {
+                    float4 b0 = row[r], b1 = row[r + 1], b2 = row[r + 2], b3 = row[r + 3];
+                    a0.x += b0.x; a0.y += b0.y; a0.z += b0.z; a0.w += b0.w;
+                    a1.x += b1.x; a1.y += b1.y; a1.z += b1.z; a1.w += b1.w;
+                    a2.x += b2.x; a2.y += b2.y; a2.z += b2.z; a2.w += b2.w;
+                    a3.x += b3.x; a3.y += b3.y; a3.z += b3.z; a3.w += b3.w;
+                }
+                total = ((a0.x + a0.y) + (a0.z + a0.w)) + ((a1.x + a1.y) + (a1.z + a1.w)) +
+                        (((a2.x + a2.y) + (a2.z + a2.w)) + ((a3.x + a3.y) + (a3.z + a3.w)));
+            }
+            wave_lds_sync();
+            if (own && total != 0.f) atomicAdd(dst + (ch == 0 ? 0 : 1), total);
         }
     } else if (valid) {
         splat_lane(block, A.Wb, A.Hb, rp.u, rp.v, val, AtomicAdd());
@@ -253,25 +275,29 @@ __global__ __launch_bounds__(DSDF_BLOCK) void k_render_pass(GridView G, dsdf_par
         bool hit = tr.its_t < INFINITY;
         bool warp_cand = (A.flags & DSDF_REPARAM) && warp_weight_positive(G, P, L.ray.o, L.ray.d, tr);
         need = valid && (warp_cand || (hit && A.integrator == DSDF_SIMPLE_SHADING));
-        // wavefront compaction: ballot + mbcnt prefix + one atomic per wave
+        // block-level compaction: per-wave ballot + mbcnt prefix, wave totals through LDS
+        __shared__ uint32_t wave_cnt[DSDF_BLOCK / 64];
         uint64_t m = __ballot(need);
-        if (m) {
-            uint32_t base = 0;
-            int leader = __ffsll((unsigned long long)m) - 1;
-            if (lid == leader) base = atomicAdd(q.count, (uint32_t)__popcll(m));
-            base = __shfl(base, leader);
-            if (need) {
-                uint32_t idx = base + mask_prefix(m);
-                if (idx < q.cap) {
-                    q.lane[idx] = lane;
-                    float *r = q.rec + idx;
-                    size_t c = q.cap;
-                    r[0] = tr.its_t; r[c] = tr.warp_t;
-                    r[2 * c] = tr.warp_t_d.x; r[3 * c] = tr.warp_t_d.y; r[4 * c] = tr.warp_t_d.z;
-                    r[5 * c] = tr.warp_weight;
-                    r[6 * c] = tr.warp_weight_d.x; r[7 * c] = tr.warp_weight_d.y; r[8 * c] = tr.warp_weight_d.z;
-                }
-            }
+        const int w = threadIdx.x >> 6;
+        if (lid == 0) wave_cnt[w] = (uint32_t)__popcll(m);
+        __syncthreads();
+        uint32_t base = 0, total = 0;
+#pragma unroll
+        for (int i = 0; i < DSDF_BLOCK / 64; ++i) {
+            uint32_t c = wave_cnt[i];
+            if (i < w) base += c;
+            total += c;
+        }
+        if (threadIdx.x == 0) q.count[blockIdx.x] = total;
+        if (need) {
+            uint32_t idx = blockIdx.x * DSDF_BLOCK + base + mask_prefix(m);
+            q.lane[idx] = lane;
+            float *r = q.rec + idx;
+            size_t c = q.cap;
+            r[0] = tr.its_t; r[c] = tr.warp_t;
+            r[2 * c] = tr.warp_t_d.x; r[3 * c] = tr.warp_t_d.y; r[4 * c] = tr.warp_t_d.z;
+            r[5 * c] = tr.warp_weight;
+            r[6 * c] = tr.warp_weight_d.x; r[7 * c] = tr.warp_weight_d.y; r[8 * c] = tr.warp_weight_d.z;
         }
     }
     if (stats) {
@@ -327,15 +353,14 @@ __global__ __launch_bounds__(DSDF_BLOCK) void k_backward(GridView G, dsdf_params
                                                          const float *__restrict__ block_adj,
                                                          float *__restrict__ grad_grid, unsigned long long *stats) {
     __shared__ float bricks[DSDF_BLOCK / 64][DSDF_BRICK_CAP];
-    uint32_t count = *q.count;
-    if (count > q.cap) count = q.cap;
-    uint32_t idx = blockIdx.x * DSDF_BLOCK + threadIdx.x;
-    if ((blockIdx.x * DSDF_BLOCK) >= count) return;      // whole block past the end of the queue
+    const uint32_t count = q.count[blockIdx.x];          // samples queued by render-pass block blockIdx.x
+    if ((threadIdx.x & ~63u) >= count) return;           // whole wave past the end of this block's slots
+    const uint32_t idx = blockIdx.x * DSDF_BLOCK + threadIdx.x;
     const int lid = lane_id();
     bool did = false;
     ScatterReq req[2];
     req[0].on = false; req[1].on = false;
-    if (idx < count) {
+    if (threadIdx.x < count) {
         uint32_t lane = q.lane[idx];
         const float *r = q.rec + idx;
         size_t c = q.cap;
@@ -392,10 +417,12 @@ static Workspace carve(void *base, int W, int H, int spp) {
     char *p = (char *)base;
     ws.block = (float *)(p + off); off += align_up(Wb * Hb * 2 * sizeof(float), 256);
     ws.block_adj = (float *)(p + off); off += align_up(Wb * Hb * 2 * sizeof(float), 256);
-    ws.count = (uint32_t *)(p + off); off += 256;
-    ws.qlane = (uint32_t *)(p + off); off += align_up(nl * sizeof(uint32_t), 256);
-    ws.qrec = (float *)(p + off); off += align_up(nl * 9 * sizeof(float), 256);
-    ws.cap = (uint32_t)nl;
+    size_t nblk = (nl + DSDF_BLOCK - 1) / DSDF_BLOCK;
+    size_t cap = nblk * DSDF_BLOCK;
+    ws.count = (uint32_t *)(p + off); off += align_up(nblk * sizeof(uint32_t), 256);
+    ws.qlane = (uint32_t *)(p + off); off += align_up(cap * sizeof(uint32_t), 256);
+    ws.qrec = (float *)(p + off); off += align_up(cap * 9 * sizeof(float), 256);
+    ws.cap = (uint32_t)cap;
     ws.bytes = off;
     return ws;
 }
@@ -523,8 +550,7 @@ int dsdf_render_backward(const float *padded, int rx, int ry, int rz, const dsdf
     for (int v = 0; v < n_views; ++v) {
         ViewArgs A = make_view_args(cams[v], width, height, spp, offsets ? offsets + (size_t)v * nl * 2 : nullptr,
                                     seeds ? seeds[v] : 0u, integrator, flags);
-        if (hipMemsetAsync(ws.block, 0, Wb * Hb * 2 * sizeof(float), st) != hipSuccess ||
-            hipMemsetAsync(ws.count, 0, 256, st) != hipSuccess)
+        if (hipMemsetAsync(ws.block, 0, Wb * Hb * 2 * sizeof(float), st) != hipSuccess)
             return fail(DSDF_ERR_LAUNCH, "hipMemsetAsync(workspace) failed");
         hipLaunchKernelGGL(k_render_pass<true>, dim3(nblk), dim3(DSDF_BLOCK), 0, st, G, *prm, A, ws.block, q,
                            (unsigned long long *)stats, nl, (spp % 64 == 0) ? 1 : 0);

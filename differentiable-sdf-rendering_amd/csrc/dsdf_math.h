@@ -100,13 +100,22 @@ DSDF_HD CubicSetup cubic_setup(const GridView &G, V3 x) {
     return s;
 }
 
-DSDF_HD void load_row4(const float *p, float r[4]) {
+// 2-wide float vector: arithmetic on it maps to the packed-fp32 VALU ops of CDNA
+// (v_pk_mul_f32 / v_pk_fma_f32: two fp32 FMAs per lane per instruction).
+typedef float v2f __attribute__((vector_size(8)));
+DSDF_HD v2f mk2(float a, float b) { v2f r = {a, b}; return r; }
+DSDF_HD v2f splat2(float a) { v2f r = {a, a}; return r; }
+
+// One 16-byte row of four x-consecutive taps (4-byte aligned address) as two pairs.
+DSDF_HD void load_row4(const float *base, uint32_t byte_off, v2f &lo, v2f &hi) {
 #if defined(__HIP_DEVICE_COMPILE__)
     typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
-    f4u t = *reinterpret_cast<const f4u *>(p);
-    r[0] = t.x; r[1] = t.y; r[2] = t.z; r[3] = t.w;
+    // uniform 64-bit base + 32-bit lane offset -> SGPR-base/VGPR-offset global load
+    f4u t = *reinterpret_cast<const f4u *>(reinterpret_cast<const char *>(base) + byte_off);
+    lo = mk2(t.x, t.y); hi = mk2(t.z, t.w);
 #else
-    r[0] = p[0]; r[1] = p[1]; r[2] = p[2]; r[3] = p[3];
+    const float *q = reinterpret_cast<const float *>(reinterpret_cast<const char *>(base) + byte_off);
+    lo = mk2(q[0], q[1]); hi = mk2(q[2], q[3]);
 #endif
 }
 
@@ -119,57 +128,80 @@ DSDF_HD void eval_cubic(const GridView &G, V3 x, float &v, V3 &g, float H[6]) {
     int bx = iclamp(s.ix, -DSDF_APRON, G.rx - 1) + DSDF_APRON;
     int by = iclamp(s.iy, -DSDF_APRON, G.ry - 1) + DSDF_APRON;
     int bz = iclamp(s.iz, -DSDF_APRON, G.rz - 1) + DSDF_APRON;
-    const float *base = G.p + (size_t)bz * G.sxy + (size_t)by * G.sx + bx;
-    float wx[4], wy[4], wz[4], dwx[4], dwy[4], dwz[4], ddwx[4], ddwy[4], ddwz[4];
+    const uint32_t base = 4u * ((uint32_t)bz * (uint32_t)G.sxy + (uint32_t)by * (uint32_t)G.sx + (uint32_t)bx);
+    const uint32_t sx4 = 4u * (uint32_t)G.sx, sxy4 = 4u * (uint32_t)G.sxy;
+    float wx[4], wy[4], wz[4];
     bspline_w(s.ax, wx); bspline_w(s.ay, wy); bspline_w(s.az, wz);
-    if (ORDER >= 1) { bspline_dw(s.ax, dwx); bspline_dw(s.ay, dwy); bspline_dw(s.az, dwz); }
-    if (ORDER >= 2) { bspline_ddw(s.ax, ddwx); bspline_ddw(s.ay, ddwy); bspline_ddw(s.az, ddwz); }
-    float av = 0.f, agx = 0.f, agy = 0.f, agz = 0.f;
-    float axx = 0.f, ayy = 0.f, azz = 0.f, axy = 0.f, axz = 0.f, ayz = 0.f;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        float y00 = 0.f, y01 = 0.f, y02 = 0.f, y10 = 0.f, y11 = 0.f, y20 = 0.f;  // y{dy}{dx}
+    if (ORDER == 0) {
+        // value only: fold wy into the x-weights, two packed FMAs per row
+        v2f Wlo[4], Whi[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            float r[4];
-            load_row4(base + k * G.sxy + j * G.sx, r);
-            float s0 = wx[0] * r[0] + wx[1] * r[1] + wx[2] * r[2] + wx[3] * r[3];
-            y00 = fmaf(wy[j], s0, y00);
-            if (ORDER >= 1) {
-                float s1 = dwx[0] * r[0] + dwx[1] * r[1] + dwx[2] * r[2] + dwx[3] * r[3];
-                y01 = fmaf(wy[j], s1, y01);
-                y10 = fmaf(dwy[j], s0, y10);
-                if (ORDER >= 2) {
-                    float s2 = ddwx[0] * r[0] + ddwx[1] * r[1] + ddwx[2] * r[2] + ddwx[3] * r[3];
-                    y02 = fmaf(wy[j], s2, y02);
-                    y11 = fmaf(dwy[j], s1, y11);
-                    y20 = fmaf(ddwy[j], s0, y20);
-                }
+            Wlo[j] = splat2(wy[j]) * mk2(wx[0], wx[1]);
+            Whi[j] = splat2(wy[j]) * mk2(wx[2], wx[3]);
+        }
+        float av = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            v2f acc = mk2(0.f, 0.f);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                v2f lo, hi;
+                load_row4(G.p, base + (uint32_t)k * sxy4 + (uint32_t)j * sx4, lo, hi);
+                acc = Wlo[j] * lo + acc;
+                acc = Whi[j] * hi + acc;
+            }
+            av = fmaf(wz[k], acc[0] + acc[1], av);
+        }
+        v = av;
+        return;
+    }
+    float dwx[4], dwy[4], dwz[4], ddwx[4], ddwy[4], ddwz[4];
+    bspline_dw(s.ax, dwx); bspline_dw(s.ay, dwy); bspline_dw(s.az, dwz);
+    if (ORDER >= 2) { bspline_ddw(s.ax, ddwx); bspline_ddw(s.ay, ddwy); bspline_ddw(s.az, ddwz); }
+    v2f wxd[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) wxd[i] = mk2(wx[i], dwx[i]);
+    // packed accumulators: A=(v,gx) B=(gy,hxy) C=(gz,hxz)
+    v2f A = mk2(0.f, 0.f), B = mk2(0.f, 0.f), C = mk2(0.f, 0.f);
+    float axx = 0.f, ayy = 0.f, azz = 0.f, ayz = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        v2f y0 = mk2(0.f, 0.f), y1 = mk2(0.f, 0.f);   // (y00,y01), (y10,y11)
+        float y02 = 0.f, y20 = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            v2f lo, hi;
+            load_row4(G.p, base + (uint32_t)k * sxy4 + (uint32_t)j * sx4, lo, hi);
+            v2f s01 = wxd[0] * splat2(lo[0]);
+            s01 = wxd[1] * splat2(lo[1]) + s01;
+            s01 = wxd[2] * splat2(hi[0]) + s01;
+            s01 = wxd[3] * splat2(hi[1]) + s01;
+            y0 = splat2(wy[j]) * s01 + y0;
+            y1 = splat2(dwy[j]) * s01 + y1;
+            if (ORDER >= 2) {
+                float s2 = ddwx[0] * lo[0];
+                s2 = fmaf(ddwx[1], lo[1], s2); s2 = fmaf(ddwx[2], hi[0], s2); s2 = fmaf(ddwx[3], hi[1], s2);
+                y02 = fmaf(wy[j], s2, y02);
+                y20 = fmaf(ddwy[j], s01[0], y20);
             }
         }
-        av = fmaf(wz[k], y00, av);
-        if (ORDER >= 1) {
-            agx = fmaf(wz[k], y01, agx);
-            agy = fmaf(wz[k], y10, agy);
-            agz = fmaf(dwz[k], y00, agz);
-            if (ORDER >= 2) {
-                axx = fmaf(wz[k], y02, axx);
-                ayy = fmaf(wz[k], y20, ayy);
-                azz = fmaf(ddwz[k], y00, azz);
-                axy = fmaf(wz[k], y11, axy);
-                axz = fmaf(dwz[k], y01, axz);
-                ayz = fmaf(dwz[k], y10, ayz);
-            }
+        A = splat2(wz[k]) * y0 + A;
+        B = splat2(wz[k]) * y1 + B;
+        C = splat2(dwz[k]) * y0 + C;
+        if (ORDER >= 2) {
+            ayz = fmaf(dwz[k], y1[0], ayz);
+            axx = fmaf(wz[k], y02, axx);
+            ayy = fmaf(wz[k], y20, ayy);
+            azz = fmaf(ddwz[k], y0[0], azz);
         }
     }
-    v = av;
-    if (ORDER >= 1) {
-        float fx = (float)G.rx, fy = (float)G.ry, fz = (float)G.rz;
-        g = mk(agx * fx, agy * fy, agz * fz);
-        if (ORDER >= 2) {
-            H[0] = axx * fx * fx; H[1] = ayy * fy * fy; H[2] = azz * fz * fz;
-            H[3] = axy * fx * fy; H[4] = axz * fx * fz; H[5] = ayz * fy * fz;
-        }
+    v = A[0];
+    float fx = (float)G.rx, fy = (float)G.ry, fz = (float)G.rz;
+    g = mk(A[1] * fx, B[0] * fy, C[0] * fz);
+    if (ORDER >= 2) {
+        H[0] = axx * fx * fx; H[1] = ayy * fy * fy; H[2] = azz * fz * fz;
+        H[3] = B[1] * fx * fy; H[4] = C[1] * fx * fz; H[5] = ayz * fy * fz;
     }
 }
 
