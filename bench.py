@@ -100,6 +100,7 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
     import dsdf
+    from dsdf import parallel
     dsdf.load()
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
@@ -121,20 +122,21 @@ def main():
     prim_ms, grad_ms = [], []
 
     def step(it, timed):
+        # one launch traces all views of the batch (primal), one launch the gradient pass
         grad.zero_()
-        for i, s in enumerate(sensors):
-            seed = (it * args.views + i) * 2 + 17 * rank
-            e0, e1, e2 = ev(), ev(), ev()
-            e0.record()
-            img = dsdf.render_forward(grid, s, args.spp_primal, seeds=[seed], integrator=args.integrator)
-            e1.record()
-            gi = torch.sign(img - tgt[i:i + 1]) * scale
-            dsdf.render_backward(grid, s, args.spp_grad, gi, grad_grid=grad, seeds=[seed + 1], integrator=args.integrator)
-            e2.record()
-            if timed:
-                prim_ms.append((e0, e1)); grad_ms.append((e1, e2))
+        seeds = [(it * args.views + i) * 2 + 17 * rank for i in range(args.views)]
+        e0, e1, e2 = ev(), ev(), ev()
+        e0.record()
+        img = dsdf.render_forward(grid, sensors, args.spp_primal, seeds=seeds, integrator=args.integrator)
+        e1.record()
+        gi = torch.sign(img - tgt) * scale
+        dsdf.render_backward(grid, sensors, args.spp_grad, gi, grad_grid=grad, seeds=[s + 1 for s in seeds],
+                             integrator=args.integrator)
+        e2.record()
+        if timed:
+            prim_ms.append((e0, e1)); grad_ms.append((e1, e2))
         if dist is not None:
-            dist.all_reduce(grad)
+            parallel.all_reduce_gradients([grad])
 
     def barrier():
         if dist is not None:
@@ -154,17 +156,18 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t)
 
-    # per-launch statistics for the algorithmic byte count (untimed, one view)
+    # per-launch statistics for the algorithmic byte count (untimed; same launch shape as the timed ones)
     st_p, st_g = dsdf.new_stats(dev), dsdf.new_stats(dev)
-    dsdf.render_forward(grid, sensors[0], args.spp_primal, seeds=[1], integrator=args.integrator, stats=st_p)
-    dsdf.render_backward(grid, sensors[0], args.spp_grad, torch.ones(1, args.img, args.img, 3, device=dev) * scale,
-                         grad_grid=torch.zeros_like(data), seeds=[2], integrator=args.integrator, stats=st_g)
-    sp, sg = dsdf.stats_dict(st_p), dsdf.stats_dict(st_g)
+    dsdf.render_forward(grid, sensors, args.spp_primal, seeds=list(range(args.views)), integrator=args.integrator, stats=st_p)
+    dsdf.render_backward(grid, sensors, args.spp_grad, torch.ones(args.views, args.img, args.img, 3, device=dev) * scale,
+                         grad_grid=torch.zeros_like(data), seeds=list(range(50, 50 + args.views)), integrator=args.integrator,
+                         stats=st_g)
     prim = [a.elapsed_time(b) for a, b in prim_ms]
     gradt = [a.elapsed_time(b) for a, b in grad_ms]
     prim_avg = sum(prim) / len(prim)
     # DESIGN.md "Algorithmic bytes": 64 fp32 taps per cubic evaluation (trace steps + refinement),
     # 16 px x 2 ch x 8 B film read-modify-write per lane, one compulsory read of the grid.
+    # (one launch = all `views` sensors of this rank)
     evals = sp['steps'] + sp['refine_steps']
     alg_bytes = 256.0 * evals + 16 * 2 * 8.0 * sp['lanes'] + 4.0 * args.res ** 3
     achieved = alg_bytes / (prim_avg * 1e-3) / 1e9
@@ -183,7 +186,8 @@ def main():
                        "hit_fraction": sp['hits'] / max(sp['lanes'], 1),
                        "bbox_fraction": sp['bbox_lanes'] / max(sp['lanes'], 1),
                        "backward_queue_fraction": sg['queue_len'] / max(sg['lanes'], 1),
-                       "primal_ms_per_view": prim_avg, "grad_ms_per_view": sum(gradt) / len(gradt)},
+                       "primal_ms_per_launch": prim_avg, "grad_ms_per_launch": sum(gradt) / len(gradt),
+                       "views_per_launch": args.views},
             "roofline": {"bound": "hbm", "kernel": "k_render_pass<primal>", "achieved": achieved, "peak": 8000.0,
                          "unit": "GB/s", "frac": achieved / 8000.0, "traffic": None,
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": prim_avg},

@@ -24,6 +24,9 @@
 using namespace dsdf;
 
 #define DSDF_BLOCK 256
+#ifndef DSDF_EPI_VARIANT
+#define DSDF_EPI_VARIANT 1
+#endif
 #define DSDF_TSTRIDE 68   /* 64 + 4: rows 16-byte aligned, ds_read_b128 conflict-free across lanes */
 
 struct AtomicAdd {
@@ -199,15 +202,32 @@ struct Queue {
     uint32_t *count;  // per render-pass block
     uint32_t *lane;
     float *rec;       // 9 rows (SoA, stride = cap): its_t, warp_t, wtd.xyz, ww, wwd.xyz
-    uint32_t cap;
+    uint32_t cap;     // slots per view (= nblk * DSDF_BLOCK)
+    uint32_t nblk;    // render-pass blocks per view
 };
+
+// Views of one launch (grid.y = view): all sensors of a batch are traced by ONE kernel so
+// that the long tail of one view (a handful of grazing rays with hundreds of steps) overlaps
+// with the bulk of the others instead of idling the chip once per view.
+#define DSDF_MAX_BATCH 16
+struct ViewBatch { ViewArgs v[DSDF_MAX_BATCH]; };
+
+__device__ __forceinline__ Queue view_queue(Queue q, uint32_t view) {
+    q.count += (size_t)view * q.nblk;
+    q.lane += (size_t)view * q.cap;
+    q.rec += (size_t)view * q.cap * 9;
+    return q;
+}
 
 // ------------------------------------------------------------------ render pass
 template <bool DIFF>
-__global__ __launch_bounds__(DSDF_BLOCK) void k_render_pass(GridView G, dsdf_params P, ViewArgs A,
-                                                            float *__restrict__ block, Queue q,
+__global__ __launch_bounds__(DSDF_BLOCK) void k_render_pass(GridView G, dsdf_params P, ViewBatch VB,
+                                                            float *__restrict__ blocks, Queue qall,
                                                             unsigned long long *stats, uint32_t n_lanes,
                                                             int wave_uniform) {
+    const ViewArgs &A = VB.v[blockIdx.y];
+    float *__restrict__ block = blocks + (size_t)blockIdx.y * 2 * A.Wb * A.Hb;
+    const Queue q = view_queue(qall, blockIdx.y);
     uint32_t lane = blockIdx.x * DSDF_BLOCK + threadIdx.x;
     const bool valid = lane < n_lanes;
     if (!valid) lane = n_lanes - 1;   // keep the wave converged for the cross-lane code
@@ -228,6 +248,7 @@ __global__ __launch_bounds__(DSDF_BLOCK) void k_render_pass(GridView G, dsdf_par
             fx[i] = gauss_f((float)(L.px - 2 + i) - pfx);
             fy[i] = gauss_f((float)(L.py - 2 + i) - pfy);
         }
+#if DSDF_EPI_VARIANT == 1
         // Wave-wide sum of the 25 window weights (x value, x 1) through a wave-private LDS
         // transpose: lane l writes column l, lane k < 25 sums row k (16 ds_read_b128).
         __shared__ float tbuf[DSDF_BLOCK / 64][25 * DSDF_TSTRIDE];
@@ -266,6 +287,28 @@ __global__ __launch_bounds__(DSDF_BLOCK) void k_render_pass(GridView G, dsdf_par
             wave_lds_sync();
             if (own && total != 0.f) atomicAdd(dst + (ch == 0 ? 0 : 1), total);
         }
+#else
+        float v[64];
+#pragma unroll
+        for (int j = 0; j < 5; ++j)
+#pragma unroll
+            for (int i = 0; i < 5; ++i) {
+                float f = fx[i] * fy[j];
+                v[j * 5 + i] = f * val;
+                v[25 + j * 5 + i] = f;
+            }
+#pragma unroll
+        for (int k = 50; k < 64; ++k) v[k] = 0.f;
+        float total = wave_transpose_reduce(v, lid);
+        if (lid < 50) {
+            int ch = lid >= 25 ? 1 : 0;
+            int s = lid - 25 * ch;
+            int j = s / 5, i = s - 5 * j;
+            int qx = L.px - 2 + i, qy = L.py - 2 + j;
+            if (qx >= 0 && qx < A.Wb && qy >= 0 && qy < A.Hb && total != 0.f)
+                atomicAdd(block + 2 * ((size_t)qy * A.Wb + qx) + ch, total);
+        }
+#endif
     } else if (valid) {
         splat_lane(block, A.Wb, A.Hb, rp.u, rp.v, val, AtomicAdd());
     }
@@ -319,11 +362,13 @@ __global__ __launch_bounds__(DSDF_BLOCK) void k_render_pass(GridView G, dsdf_par
 }
 
 // HDRFilm.develop: crop the border, value / (weight == 0 ? 1 : weight), R=G=B.
-__global__ void k_develop(const float *__restrict__ block, int W, int H, float *__restrict__ image) {
+__global__ void k_develop(const float *__restrict__ blocks, int W, int H, float *__restrict__ images) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= W * H) return;
     int y = i / W, x = i - y * W;
-    int Wb = W + 2 * DSDF_BORDER;
+    int Wb = W + 2 * DSDF_BORDER, Hb = H + 2 * DSDF_BORDER;
+    const float *block = blocks + (size_t)blockIdx.y * 2 * Wb * Hb;
+    float *image = images + (size_t)blockIdx.y * 3 * W * H;
     float2 b = reinterpret_cast<const float2 *>(block)[(size_t)(y + DSDF_BORDER) * Wb + x + DSDF_BORDER];
     float w = b.y == 0.f ? 1.f : b.y;
     float v = b.x / w;
@@ -331,11 +376,14 @@ __global__ void k_develop(const float *__restrict__ block, int W, int H, float *
 }
 
 // Adjoint of develop: dL/d(value sum) = sum_c gI_c / w ; dL/d(weight sum) = -sum_c gI_c * s / w^2.
-__global__ void k_develop_adjoint(const float *__restrict__ block, const float *__restrict__ grad_image, int W, int H,
-                                  float *__restrict__ block_adj) {
+__global__ void k_develop_adjoint(const float *__restrict__ blocks, const float *__restrict__ grad_images, int W, int H,
+                                  float *__restrict__ block_adjs) {
     int Wb = W + 2 * DSDF_BORDER, Hb = H + 2 * DSDF_BORDER;
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= Wb * Hb) return;
+    const float *block = blocks + (size_t)blockIdx.y * 2 * Wb * Hb;
+    const float *grad_image = grad_images + (size_t)blockIdx.y * 3 * W * H;
+    float *block_adj = block_adjs + (size_t)blockIdx.y * 2 * Wb * Hb;
     int qy = i / Wb, qx = i - qy * Wb;
     int x = qx - DSDF_BORDER, y = qy - DSDF_BORDER;
     float2 out = make_float2(0.f, 0.f);
@@ -349,10 +397,13 @@ __global__ void k_develop_adjoint(const float *__restrict__ block, const float *
     reinterpret_cast<float2 *>(block_adj)[i] = out;
 }
 
-__global__ __launch_bounds__(DSDF_BLOCK) void k_backward(GridView G, dsdf_params P, ViewArgs A, Queue q,
-                                                         const float *__restrict__ block_adj,
+__global__ __launch_bounds__(DSDF_BLOCK) void k_backward(GridView G, dsdf_params P, ViewBatch VB, Queue qall,
+                                                         const float *__restrict__ block_adjs,
                                                          float *__restrict__ grad_grid, unsigned long long *stats) {
     __shared__ float bricks[DSDF_BLOCK / 64][DSDF_BRICK_CAP];
+    const ViewArgs &A = VB.v[blockIdx.y];
+    const float *__restrict__ block_adj = block_adjs + (size_t)blockIdx.y * 2 * A.Wb * A.Hb;
+    const Queue q = view_queue(qall, blockIdx.y);
     const uint32_t count = q.count[blockIdx.x];          // samples queued by render-pass block blockIdx.x
     if ((threadIdx.x & ~63u) >= count) return;           // whole wave past the end of this block's slots
     const uint32_t idx = blockIdx.x * DSDF_BLOCK + threadIdx.x;
@@ -405,26 +456,35 @@ struct Workspace {
     float *block, *block_adj;
     uint32_t *count, *qlane;
     float *qrec;
-    uint32_t cap;
+    uint32_t cap, nblk;
     size_t bytes;
 };
 
-static Workspace carve(void *base, int W, int H, int spp) {
+// Workspace for `nv` views processed by one launch.
+static Workspace carve(void *base, int W, int H, int spp, int nv) {
     Workspace ws;
     size_t Wb = W + 2 * DSDF_BORDER, Hb = H + 2 * DSDF_BORDER;
     size_t nl = Wb * Hb * (size_t)spp;
-    size_t off = 0;
-    char *p = (char *)base;
-    ws.block = (float *)(p + off); off += align_up(Wb * Hb * 2 * sizeof(float), 256);
-    ws.block_adj = (float *)(p + off); off += align_up(Wb * Hb * 2 * sizeof(float), 256);
     size_t nblk = (nl + DSDF_BLOCK - 1) / DSDF_BLOCK;
     size_t cap = nblk * DSDF_BLOCK;
-    ws.count = (uint32_t *)(p + off); off += align_up(nblk * sizeof(uint32_t), 256);
-    ws.qlane = (uint32_t *)(p + off); off += align_up(cap * sizeof(uint32_t), 256);
-    ws.qrec = (float *)(p + off); off += align_up(cap * 9 * sizeof(float), 256);
+    size_t off = 0;
+    char *p = (char *)base;
+    ws.block = (float *)(p + off); off += align_up(nv * Wb * Hb * 2 * sizeof(float), 256);
+    ws.block_adj = (float *)(p + off); off += align_up(nv * Wb * Hb * 2 * sizeof(float), 256);
+    ws.count = (uint32_t *)(p + off); off += align_up(nv * nblk * sizeof(uint32_t), 256);
+    ws.qlane = (uint32_t *)(p + off); off += align_up(nv * cap * sizeof(uint32_t), 256);
+    ws.qrec = (float *)(p + off); off += align_up(nv * cap * 9 * sizeof(float), 256);
     ws.cap = (uint32_t)cap;
+    ws.nblk = (uint32_t)nblk;
     ws.bytes = off;
     return ws;
+}
+
+// Largest number of views (<= DSDF_MAX_BATCH, <= n_views) one launch can take with this workspace.
+static int batch_size(int W, int H, int spp, int n_views, size_t workspace_bytes) {
+    int nv = n_views < DSDF_MAX_BATCH ? n_views : DSDF_MAX_BATCH;
+    while (nv > 1 && carve(nullptr, W, H, spp, nv).bytes > workspace_bytes) --nv;
+    return nv;
 }
 
 static ViewArgs make_view_args(const dsdf_camera &cam, int W, int H, int spp, const float *offsets, uint32_t seed,
@@ -446,7 +506,7 @@ static int check_render_args(const float *padded, int rx, int ry, int rz, const 
     size_t nl = (size_t)(W + 2 * DSDF_BORDER) * (H + 2 * DSDF_BORDER) * (size_t)spp;
     // reparam.py:48-50 wavefront-size limit
     if (nl > 0x40000000ull) return fail(DSDF_ERR_INVALID_ARG, "wavefront size exceeds 0x40000000 lanes");
-    if (workspace_bytes < dsdf_render_workspace_size(W, H, spp)) return fail(DSDF_ERR_WORKSPACE, "workspace too small");
+    if (workspace_bytes < dsdf_render_workspace_size(W, H, spp, 1)) return fail(DSDF_ERR_WORKSPACE, "workspace too small");
     return DSDF_OK;
 }
 
@@ -496,9 +556,9 @@ int dsdf_trace(const float *padded, int rx, int ry, int rz, const dsdf_params *p
     return check_launch("k_trace");
 }
 
-size_t dsdf_render_workspace_size(int width, int height, int spp) {
-    if (width < 1 || height < 1 || spp < 1) return 0;
-    return carve(nullptr, width, height, spp).bytes;
+size_t dsdf_render_workspace_size(int width, int height, int spp, int n_views) {
+    if (width < 1 || height < 1 || spp < 1 || n_views < 1) return 0;
+    return carve(nullptr, width, height, spp, n_views < DSDF_MAX_BATCH ? n_views : DSDF_MAX_BATCH).bytes;
 }
 
 int dsdf_render_forward(const float *padded, int rx, int ry, int rz, const dsdf_params *prm, const dsdf_camera *cams,
@@ -511,21 +571,25 @@ int dsdf_render_forward(const float *padded, int rx, int ry, int rz, const dsdf_
     if (!image_out) return fail(DSDF_ERR_INVALID_ARG, "dsdf_render_forward: image_out is null");
     if (!offsets && !seeds) return fail(DSDF_ERR_INVALID_ARG, "dsdf_render_forward: need offsets or seeds");
     hipStream_t st = (hipStream_t)stream;
-    Workspace ws = carve(workspace, width, height, spp);
+    const int nb = batch_size(width, height, spp, n_views, workspace_bytes);
+    Workspace ws = carve(workspace, width, height, spp, nb);
     GridView G = make_view(padded, rx, ry, rz, *prm);
     size_t Wb = width + 2 * DSDF_BORDER, Hb = height + 2 * DSDF_BORDER;
     uint32_t nl = (uint32_t)(Wb * Hb * spp);
-    Queue q; q.count = ws.count; q.lane = ws.qlane; q.rec = ws.qrec; q.cap = ws.cap;
-    for (int v = 0; v < n_views; ++v) {
-        ViewArgs A = make_view_args(cams[v], width, height, spp, offsets ? offsets + (size_t)v * nl * 2 : nullptr,
-                                    seeds ? seeds[v] : 0u, integrator, flags);
-        if (hipMemsetAsync(ws.block, 0, Wb * Hb * 2 * sizeof(float), st) != hipSuccess)
+    Queue q; q.count = ws.count; q.lane = ws.qlane; q.rec = ws.qrec; q.cap = ws.cap; q.nblk = ws.nblk;
+    for (int v0 = 0; v0 < n_views; v0 += nb) {
+        const int nv = (n_views - v0) < nb ? (n_views - v0) : nb;
+        ViewBatch VB;
+        for (int i = 0; i < nv; ++i)
+            VB.v[i] = make_view_args(cams[v0 + i], width, height, spp, offsets ? offsets + (size_t)(v0 + i) * nl * 2 : nullptr,
+                                     seeds ? seeds[v0 + i] : 0u, integrator, flags);
+        if (hipMemsetAsync(ws.block, 0, nv * Wb * Hb * 2 * sizeof(float), st) != hipSuccess)
             return fail(DSDF_ERR_LAUNCH, "hipMemsetAsync(block) failed");
-        hipLaunchKernelGGL(k_render_pass<false>, dim3((nl + DSDF_BLOCK - 1) / DSDF_BLOCK), dim3(DSDF_BLOCK), 0, st, G, *prm,
-                           A, ws.block, q, (unsigned long long *)stats, nl, (spp % 64 == 0) ? 1 : 0);
+        hipLaunchKernelGGL(k_render_pass<false>, dim3(ws.nblk, nv), dim3(DSDF_BLOCK), 0, st, G, *prm, VB, ws.block, q,
+                           (unsigned long long *)stats, nl, (spp % 64 == 0) ? 1 : 0);
         if ((rc = check_launch("k_render_pass<primal>"))) return rc;
-        hipLaunchKernelGGL(k_develop, dim3((width * height + 255) / 256), dim3(256), 0, st, ws.block, width, height,
-                           image_out + (size_t)v * width * height * 3);
+        hipLaunchKernelGGL(k_develop, dim3((width * height + 255) / 256, nv), dim3(256), 0, st, ws.block, width, height,
+                           image_out + (size_t)v0 * width * height * 3);
         if ((rc = check_launch("k_develop"))) return rc;
     }
     return DSDF_OK;
@@ -541,29 +605,32 @@ int dsdf_render_backward(const float *padded, int rx, int ry, int rz, const dsdf
     if (!grad_image || !grad_grid) return fail(DSDF_ERR_INVALID_ARG, "dsdf_render_backward: null gradient buffer");
     if (!offsets && !seeds) return fail(DSDF_ERR_INVALID_ARG, "dsdf_render_backward: need offsets or seeds");
     hipStream_t st = (hipStream_t)stream;
-    Workspace ws = carve(workspace, width, height, spp);
+    const int nb = batch_size(width, height, spp, n_views, workspace_bytes);
+    Workspace ws = carve(workspace, width, height, spp, nb);
     GridView G = make_view(padded, rx, ry, rz, *prm);
     size_t Wb = width + 2 * DSDF_BORDER, Hb = height + 2 * DSDF_BORDER;
     uint32_t nl = (uint32_t)(Wb * Hb * spp);
-    Queue q; q.count = ws.count; q.lane = ws.qlane; q.rec = ws.qrec; q.cap = ws.cap;
-    unsigned nblk = (nl + DSDF_BLOCK - 1) / DSDF_BLOCK;
-    for (int v = 0; v < n_views; ++v) {
-        ViewArgs A = make_view_args(cams[v], width, height, spp, offsets ? offsets + (size_t)v * nl * 2 : nullptr,
-                                    seeds ? seeds[v] : 0u, integrator, flags);
-        if (hipMemsetAsync(ws.block, 0, Wb * Hb * 2 * sizeof(float), st) != hipSuccess)
+    Queue q; q.count = ws.count; q.lane = ws.qlane; q.rec = ws.qrec; q.cap = ws.cap; q.nblk = ws.nblk;
+    for (int v0 = 0; v0 < n_views; v0 += nb) {
+        const int nv = (n_views - v0) < nb ? (n_views - v0) : nb;
+        ViewBatch VB;
+        for (int i = 0; i < nv; ++i)
+            VB.v[i] = make_view_args(cams[v0 + i], width, height, spp, offsets ? offsets + (size_t)(v0 + i) * nl * 2 : nullptr,
+                                     seeds ? seeds[v0 + i] : 0u, integrator, flags);
+        if (hipMemsetAsync(ws.block, 0, nv * Wb * Hb * 2 * sizeof(float), st) != hipSuccess)
             return fail(DSDF_ERR_LAUNCH, "hipMemsetAsync(workspace) failed");
-        hipLaunchKernelGGL(k_render_pass<true>, dim3(nblk), dim3(DSDF_BLOCK), 0, st, G, *prm, A, ws.block, q,
+        hipLaunchKernelGGL(k_render_pass<true>, dim3(ws.nblk, nv), dim3(DSDF_BLOCK), 0, st, G, *prm, VB, ws.block, q,
                            (unsigned long long *)stats, nl, (spp % 64 == 0) ? 1 : 0);
         if ((rc = check_launch("k_render_pass<grad>"))) return rc;
         if (image_out) {
-            hipLaunchKernelGGL(k_develop, dim3((width * height + 255) / 256), dim3(256), 0, st, ws.block, width, height,
-                               image_out + (size_t)v * width * height * 3);
+            hipLaunchKernelGGL(k_develop, dim3((width * height + 255) / 256, nv), dim3(256), 0, st, ws.block, width, height,
+                               image_out + (size_t)v0 * width * height * 3);
             if ((rc = check_launch("k_develop"))) return rc;
         }
-        hipLaunchKernelGGL(k_develop_adjoint, dim3((unsigned)((Wb * Hb + 255) / 256)), dim3(256), 0, st, ws.block,
-                           grad_image + (size_t)v * width * height * 3, width, height, ws.block_adj);
+        hipLaunchKernelGGL(k_develop_adjoint, dim3((unsigned)((Wb * Hb + 255) / 256), nv), dim3(256), 0, st, ws.block,
+                           grad_image + (size_t)v0 * width * height * 3, width, height, ws.block_adj);
         if ((rc = check_launch("k_develop_adjoint"))) return rc;
-        hipLaunchKernelGGL(k_backward, dim3(nblk), dim3(DSDF_BLOCK), 0, st, G, *prm, A, q, ws.block_adj, grad_grid,
+        hipLaunchKernelGGL(k_backward, dim3(ws.nblk, nv), dim3(DSDF_BLOCK), 0, st, G, *prm, VB, q, ws.block_adj, grad_grid,
                            (unsigned long long *)stats);
         if ((rc = check_launch("k_backward"))) return rc;
     }

@@ -42,6 +42,9 @@ DSDF_HD V3 symmul(const float H[6], V3 a) {
 // per axis reproduce per-tap clamp-to-edge exactly (Dr.Jit wrap mode Clamp).
 // ---------------------------------------------------------------------------
 #define DSDF_APRON 3
+#ifndef DSDF_EVAL0_VARIANT
+#define DSDF_EVAL0_VARIANT 2
+#endif
 struct GridView {
     const float *p;
     int rx, ry, rz;
@@ -133,6 +136,7 @@ DSDF_HD void eval_cubic(const GridView &G, V3 x, float &v, V3 &g, float H[6]) {
     float wx[4], wy[4], wz[4];
     bspline_w(s.ax, wx); bspline_w(s.ay, wy); bspline_w(s.az, wz);
     if (ORDER == 0) {
+#if DSDF_EVAL0_VARIANT == 2
         // value only: fold wy into the x-weights, two packed FMAs per row
         v2f Wlo[4], Whi[4];
 #pragma unroll
@@ -154,6 +158,25 @@ DSDF_HD void eval_cubic(const GridView &G, V3 x, float &v, V3 &g, float H[6]) {
             av = fmaf(wz[k], acc[0] + acc[1], av);
         }
         v = av;
+#else
+        // value only, scalar FMA chains (v_fma_f32 issues at full rate on the SIMD-32 VALU;
+        // packed fp32 does not raise the FLOP rate on gfx950)
+        float av = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float y = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                v2f lo, hi;
+                load_row4(G.p, base + (uint32_t)k * sxy4 + (uint32_t)j * sx4, lo, hi);
+                float s0 = wx[0] * lo[0];
+                s0 = fmaf(wx[1], lo[1], s0); s0 = fmaf(wx[2], hi[0], s0); s0 = fmaf(wx[3], hi[1], s0);
+                y = fmaf(wy[j], s0, y);
+            }
+            av = fmaf(wz[k], y, av);
+        }
+        v = av;
+#endif
         return;
     }
     float dwx[4], dwy[4], dwz[4], ddwx[4], ddwy[4], ddwz[4];

@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.normpath(os.path.join(_HERE, '..', '..', 'lib', 'libdsdf.so'))
+# DSDF_LIB_PATH lets kernel A/B experiments point at another build of the SAME HIP library
+LIB_PATH = os.environ.get('DSDF_LIB_PATH') or os.path.normpath(os.path.join(_HERE, '..', '..', 'lib', 'libdsdf.so'))
 
 DSDF_SILHOUETTE = 0
 DSDF_SIMPLE_SHADING = 1
@@ -45,7 +46,7 @@ SYMBOLS = {
     'dsdf_trace': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(DsdfParams), C.c_void_p, C.c_void_p,
                              C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                              C.c_void_p, C.c_void_p, C.c_void_p]),
-    'dsdf_render_workspace_size': (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    'dsdf_render_workspace_size': (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
     'dsdf_render_forward': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(DsdfParams),
                                       C.POINTER(DsdfCamera), C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                       C.POINTER(C.c_uint32), C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t,

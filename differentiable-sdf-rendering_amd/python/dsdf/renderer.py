@@ -21,6 +21,10 @@ STAT_NAMES = ('lanes', 'bbox_lanes', 'steps', 'hits', 'refine_steps', 'warp_acti
 
 _workspaces = {}
 
+# Views traced by one kernel launch (bounded by the workspace: the backward queue holds
+# 40 B per gradient-pass sample and view; 288 GB of HBM makes 16 views x 512^2 x 64 spp = 11 GB cheap).
+MAX_VIEWS_PER_LAUNCH = 16
+
 
 def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
@@ -146,7 +150,7 @@ def render_forward(grid, sensors, spp, seeds=None, offsets=None, integrator=DSDF
     offsets, cseeds = _sampler_args(nv, seeds, offsets, n_lanes)
     dev = grid.device
     img = torch.empty(nv, H, W, 3, dtype=torch.float32, device=dev)
-    wsb = lib.dsdf_render_workspace_size(W, H, int(spp))
+    wsb = lib.dsdf_render_workspace_size(W, H, int(spp), min(nv, MAX_VIEWS_PER_LAUNCH))
     ws = _workspace(dev, wsb)
     with torch.cuda.device(dev):
         _lib.check(lib.dsdf_render_forward(_ptr(grid.padded), grid.rx, grid.ry, grid.rz, C.byref(grid.params), cams, nv,
@@ -175,7 +179,7 @@ def render_backward(grid, sensors, spp, grad_image, grad_grid=None, seeds=None, 
             raise _lib.DsdfError("grad_grid must be a contiguous (Z,Y,X) tensor matching the grid")
         _require_dev(grad_grid, 'grad_grid')
     img = torch.empty(nv, H, W, 3, dtype=torch.float32, device=dev) if return_image else None
-    wsb = lib.dsdf_render_workspace_size(W, H, int(spp))
+    wsb = lib.dsdf_render_workspace_size(W, H, int(spp), min(nv, MAX_VIEWS_PER_LAUNCH))
     ws = _workspace(dev, wsb)
     with torch.cuda.device(dev):
         _lib.check(lib.dsdf_render_backward(_ptr(grid.padded), grid.rx, grid.ry, grid.rz, C.byref(grid.params), cams, nv,

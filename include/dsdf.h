@@ -111,9 +111,12 @@ int dsdf_trace(const float *padded, int rx, int ry, int rz, const dsdf_params *p
                float *its_t, float *warp_t, float *warp_t_d,
                float *warp_weight, float *warp_weight_d, int32_t *steps, void *stream);
 
-/* Workspace (bytes) needed by dsdf_render_forward / dsdf_render_backward for one
- * view of width x height at spp samples (film block, per-lane records, queue). */
-size_t dsdf_render_workspace_size(int width, int height, int spp);
+/* Workspace (bytes) for dsdf_render_forward / dsdf_render_backward to process
+ * `n_views` sensors of width x height at spp samples in ONE launch (film blocks,
+ * per-sample backward queue).  The render calls batch as many views per launch as
+ * the workspace they are given allows (at most 16); a workspace sized for one view
+ * is always sufficient, larger ones overlap the ray-tracing tails of the views. */
+size_t dsdf_render_workspace_size(int width, int height, int spp, int n_views);
 
 /* `ReparamIntegrator.render` (python/integrators/reparam.py:120-185) for n_views
  * sensors: ray generation (Mitsuba perspective sensor), sphere tracing,

@@ -36,8 +36,10 @@ def test_default_params_and_sizes(built):
     assert C.sizeof(dsdf.DsdfParams) == 64 and C.sizeof(dsdf.DsdfCamera) == 64
     assert lib.dsdf_padded_size(256, 256, 256) == 262 ** 3
     assert lib.dsdf_padded_size(4, 5, 6) == 10 * 11 * 12
-    ws = lib.dsdf_render_workspace_size(512, 512, 64)
-    assert ws >= 516 * 516 * 64 * 40 and lib.dsdf_render_workspace_size(0, 4, 4) == 0
+    ws = lib.dsdf_render_workspace_size(512, 512, 64, 1)
+    assert ws >= 516 * 516 * 64 * 40 and lib.dsdf_render_workspace_size(0, 4, 4, 1) == 0
+    assert lib.dsdf_render_workspace_size(512, 512, 64, 4) >= 4 * 516 * 516 * 64 * 40
+    assert lib.dsdf_render_workspace_size(64, 64, 4, 100) == lib.dsdf_render_workspace_size(64, 64, 4, 16)
 
 
 def test_argument_validation_before_device_work(built):
