@@ -162,6 +162,7 @@ def main():
     dsdf.render_backward(grid, sensors, args.spp_grad, torch.ones(args.views, args.img, args.img, 3, device=dev) * scale,
                          grad_grid=torch.zeros_like(data), seeds=list(range(50, 50 + args.views)), integrator=args.integrator,
                          stats=st_g)
+    sp, sg = dsdf.stats_dict(st_p), dsdf.stats_dict(st_g)
     prim = [a.elapsed_time(b) for a, b in prim_ms]
     gradt = [a.elapsed_time(b) for a, b in grad_ms]
     prim_avg = sum(prim) / len(prim)

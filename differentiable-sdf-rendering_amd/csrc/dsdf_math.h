@@ -29,6 +29,15 @@ DSDF_HD V3 operator*(V3 a, V3 b) { return mk(a.x * b.x, a.y * b.y, a.z * b.z); }
 DSDF_HD float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 DSDF_HD V3 fma3(float s, V3 a, V3 b) { return mk(fmaf(s, a.x, b.x), fmaf(s, a.y, b.y), fmaf(s, a.z, b.z)); }
 DSDF_HD float drsign(float x) { return x >= 0.f ? 1.f : -1.f; }   // dr.sign: sign(0)=+1
+// 1/x: the hardware reciprocal (v_rcp_f32, 1 ulp) on the device instead of the ~10-instruction
+// IEEE division sequence; Dr.Jit's dr.rcp is the same approximate-reciprocal-plus-refinement class.
+DSDF_HD float rcpf(float x) {
+#if defined(__HIP_DEVICE_COMPILE__) && DSDF_FAST_RCP
+    return __builtin_amdgcn_rcpf(x);
+#else
+    return 1.f / x;
+#endif
+}
 // symmetric 3x3 (xx,yy,zz,xy,xz,yz) times vector
 DSDF_HD V3 symmul(const float H[6], V3 a) {
     return mk(H[0] * a.x + H[3] * a.y + H[4] * a.z,
@@ -42,8 +51,8 @@ DSDF_HD V3 symmul(const float H[6], V3 a) {
 // per axis reproduce per-tap clamp-to-edge exactly (Dr.Jit wrap mode Clamp).
 // ---------------------------------------------------------------------------
 #define DSDF_APRON 3
-#ifndef DSDF_EVAL0_VARIANT
-#define DSDF_EVAL0_VARIANT 2
+#ifndef DSDF_FAST_RCP
+#define DSDF_FAST_RCP 1
 #endif
 struct GridView {
     const float *p;
@@ -103,64 +112,58 @@ DSDF_HD CubicSetup cubic_setup(const GridView &G, V3 x) {
     return s;
 }
 
-// 2-wide float vector: arithmetic on it maps to the packed-fp32 VALU ops of CDNA
-// (v_pk_mul_f32 / v_pk_fma_f32: two fp32 FMAs per lane per instruction).
+// 2-wide float vector (packed-fp32 VALU ops; v_pk_fma_f32 issues at half rate on the
+// SIMD-32 VALU, so it saves instruction slots, not FLOP time).
 typedef float v2f __attribute__((vector_size(8)));
 DSDF_HD v2f mk2(float a, float b) { v2f r = {a, b}; return r; }
 DSDF_HD v2f splat2(float a) { v2f r = {a, a}; return r; }
 
-// One 16-byte row of four x-consecutive taps (4-byte aligned address) as two pairs.
-DSDF_HD void load_row4(const float *base, uint32_t byte_off, v2f &lo, v2f &hi) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
-    // uniform 64-bit base + 32-bit lane offset -> SGPR-base/VGPR-offset global load
-    f4u t = *reinterpret_cast<const f4u *>(reinterpret_cast<const char *>(base) + byte_off);
-    lo = mk2(t.x, t.y); hi = mk2(t.z, t.w);
-#else
-    const float *q = reinterpret_cast<const float *>(reinterpret_cast<const char *>(base) + byte_off);
-    lo = mk2(q[0], q[1]); hi = mk2(q[2], q[3]);
-#endif
-}
+// The B-spline cell of a lookup: byte offset of tap (0,0,0) in the padded grid (base
+// index clamped to [-3, r-1], see GridView) and the fractional offsets.
+struct CubicCell { uint32_t base; float ax, ay, az; };
 
-// A1: Grid3d.eval / eval_and_grad / eval_all (shapes.py:420-450).
-// ORDER 0: v; 1: v,g; 2: v,g,H (xx,yy,zz,xy,xz,yz).  Gradient scaled by res,
-// Hessian by res_i*res_j (Dr.Jit eval_cubic_grad / eval_cubic_hessian).
-template <int ORDER>
-DSDF_HD void eval_cubic(const GridView &G, V3 x, float &v, V3 &g, float H[6]) {
+DSDF_HD CubicCell cubic_cell(const GridView &G, V3 x) {
     CubicSetup s = cubic_setup(G, x);
     int bx = iclamp(s.ix, -DSDF_APRON, G.rx - 1) + DSDF_APRON;
     int by = iclamp(s.iy, -DSDF_APRON, G.ry - 1) + DSDF_APRON;
     int bz = iclamp(s.iz, -DSDF_APRON, G.rz - 1) + DSDF_APRON;
-    const uint32_t base = 4u * ((uint32_t)bz * (uint32_t)G.sxy + (uint32_t)by * (uint32_t)G.sx + (uint32_t)bx);
-    const uint32_t sx4 = 4u * (uint32_t)G.sx, sxy4 = 4u * (uint32_t)G.sxy;
-    float wx[4], wy[4], wz[4];
-    bspline_w(s.ax, wx); bspline_w(s.ay, wy); bspline_w(s.az, wz);
-    if (ORDER == 0) {
-#if DSDF_EVAL0_VARIANT == 2
-        // value only: fold wy into the x-weights, two packed FMAs per row
-        v2f Wlo[4], Whi[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            Wlo[j] = splat2(wy[j]) * mk2(wx[0], wx[1]);
-            Whi[j] = splat2(wy[j]) * mk2(wx[2], wx[3]);
-        }
-        float av = 0.f;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            v2f acc = mk2(0.f, 0.f);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                v2f lo, hi;
-                load_row4(G.p, base + (uint32_t)k * sxy4 + (uint32_t)j * sx4, lo, hi);
-                acc = Wlo[j] * lo + acc;
-                acc = Whi[j] * hi + acc;
-            }
-            av = fmaf(wz[k], acc[0] + acc[1], av);
-        }
-        v = av;
+    CubicCell c;
+    c.base = 4u * ((uint32_t)bz * (uint32_t)G.sxy + (uint32_t)by * (uint32_t)G.sx + (uint32_t)bx);
+    c.ax = s.ax; c.ay = s.ay; c.az = s.az;
+    return c;
+}
+
+// Row provider reading the 16 rows (k = z tap, j = y tap; four x-consecutive floats each)
+// of a cell straight from the padded grid: one 16-byte, 4-byte-aligned load per row with
+// a wave-uniform 64-bit base and a 32-bit lane offset.
+struct GlobalRows {
+    const float *p;
+    uint32_t base, sx4, sxy4;
+    DSDF_HD void get(int k, int j, v2f &lo, v2f &hi) const {
+        const char *q = reinterpret_cast<const char *>(p) + (base + (uint32_t)k * sxy4 + (uint32_t)j * sx4);
+#if defined(__HIP_DEVICE_COMPILE__)
+        typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+        f4u t = *reinterpret_cast<const f4u *>(q);
+        lo = mk2(t.x, t.y); hi = mk2(t.z, t.w);
 #else
-        // value only, scalar FMA chains (v_fma_f32 issues at full rate on the SIMD-32 VALU;
-        // packed fp32 does not raise the FLOP rate on gfx950)
+        const float *f = reinterpret_cast<const float *>(q);
+        lo = mk2(f[0], f[1]); hi = mk2(f[2], f[3]);
+#endif
+    }
+};
+DSDF_HD GlobalRows global_rows(const GridView &G, const CubicCell &c) {
+    GlobalRows r; r.p = G.p; r.base = c.base; r.sx4 = 4u * (uint32_t)G.sx; r.sxy4 = 4u * (uint32_t)G.sxy;
+    return r;
+}
+
+// A1: Grid3d.eval / eval_and_grad / eval_all (shapes.py:420-450) on the rows of one cell.
+// ORDER 0: v; 1: v,g; 2: v,g,H (xx,yy,zz,xy,xz,yz).  Gradient scaled by res,
+// Hessian by res_i*res_j (Dr.Jit eval_cubic_grad / eval_cubic_hessian).
+template <int ORDER, class Rows>
+DSDF_HD void eval_cubic_rows(const GridView &G, const CubicCell &c, const Rows &rows, float &v, V3 &g, float H[6]) {
+    float wx[4], wy[4], wz[4];
+    bspline_w(c.ax, wx); bspline_w(c.ay, wy); bspline_w(c.az, wz);
+    if (ORDER == 0) {
         float av = 0.f;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -168,7 +171,7 @@ DSDF_HD void eval_cubic(const GridView &G, V3 x, float &v, V3 &g, float H[6]) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 v2f lo, hi;
-                load_row4(G.p, base + (uint32_t)k * sxy4 + (uint32_t)j * sx4, lo, hi);
+                rows.get(k, j, lo, hi);
                 float s0 = wx[0] * lo[0];
                 s0 = fmaf(wx[1], lo[1], s0); s0 = fmaf(wx[2], hi[0], s0); s0 = fmaf(wx[3], hi[1], s0);
                 y = fmaf(wy[j], s0, y);
@@ -176,57 +179,76 @@ DSDF_HD void eval_cubic(const GridView &G, V3 x, float &v, V3 &g, float H[6]) {
             av = fmaf(wz[k], y, av);
         }
         v = av;
-#endif
         return;
     }
     float dwx[4], dwy[4], dwz[4], ddwx[4], ddwy[4], ddwz[4];
-    bspline_dw(s.ax, dwx); bspline_dw(s.ay, dwy); bspline_dw(s.az, dwz);
-    if (ORDER >= 2) { bspline_ddw(s.ax, ddwx); bspline_ddw(s.ay, ddwy); bspline_ddw(s.az, ddwz); }
-    v2f wxd[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) wxd[i] = mk2(wx[i], dwx[i]);
-    // packed accumulators: A=(v,gx) B=(gy,hxy) C=(gz,hxz)
-    v2f A = mk2(0.f, 0.f), B = mk2(0.f, 0.f), C = mk2(0.f, 0.f);
-    float axx = 0.f, ayy = 0.f, azz = 0.f, ayz = 0.f;
+    bspline_dw(c.ax, dwx); bspline_dw(c.ay, dwy); bspline_dw(c.az, dwz);
+    if (ORDER >= 2) { bspline_ddw(c.ax, ddwx); bspline_ddw(c.ay, ddwy); bspline_ddw(c.az, ddwz); }
+    // scalar FMA chains (full-rate v_fma_f32; no register-pair packing moves)
+    float av = 0.f, agx = 0.f, agy = 0.f, agz = 0.f;
+    float axx = 0.f, ayy = 0.f, azz = 0.f, axy = 0.f, axz = 0.f, ayz = 0.f;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        v2f y0 = mk2(0.f, 0.f), y1 = mk2(0.f, 0.f);   // (y00,y01), (y10,y11)
-        float y02 = 0.f, y20 = 0.f;
+        float y00 = 0.f, y01 = 0.f, y02 = 0.f, y10 = 0.f, y11 = 0.f, y20 = 0.f;  // y{dy}{dx}
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             v2f lo, hi;
-            load_row4(G.p, base + (uint32_t)k * sxy4 + (uint32_t)j * sx4, lo, hi);
-            v2f s01 = wxd[0] * splat2(lo[0]);
-            s01 = wxd[1] * splat2(lo[1]) + s01;
-            s01 = wxd[2] * splat2(hi[0]) + s01;
-            s01 = wxd[3] * splat2(hi[1]) + s01;
-            y0 = splat2(wy[j]) * s01 + y0;
-            y1 = splat2(dwy[j]) * s01 + y1;
+            rows.get(k, j, lo, hi);
+            float s0 = wx[0] * lo[0];
+            s0 = fmaf(wx[1], lo[1], s0); s0 = fmaf(wx[2], hi[0], s0); s0 = fmaf(wx[3], hi[1], s0);
+            float s1 = dwx[0] * lo[0];
+            s1 = fmaf(dwx[1], lo[1], s1); s1 = fmaf(dwx[2], hi[0], s1); s1 = fmaf(dwx[3], hi[1], s1);
+            y00 = fmaf(wy[j], s0, y00);
+            y01 = fmaf(wy[j], s1, y01);
+            y10 = fmaf(dwy[j], s0, y10);
             if (ORDER >= 2) {
                 float s2 = ddwx[0] * lo[0];
                 s2 = fmaf(ddwx[1], lo[1], s2); s2 = fmaf(ddwx[2], hi[0], s2); s2 = fmaf(ddwx[3], hi[1], s2);
                 y02 = fmaf(wy[j], s2, y02);
-                y20 = fmaf(ddwy[j], s01[0], y20);
+                y11 = fmaf(dwy[j], s1, y11);
+                y20 = fmaf(ddwy[j], s0, y20);
             }
         }
-        A = splat2(wz[k]) * y0 + A;
-        B = splat2(wz[k]) * y1 + B;
-        C = splat2(dwz[k]) * y0 + C;
+        av = fmaf(wz[k], y00, av);
+        agx = fmaf(wz[k], y01, agx);
+        agy = fmaf(wz[k], y10, agy);
+        agz = fmaf(dwz[k], y00, agz);
         if (ORDER >= 2) {
-            ayz = fmaf(dwz[k], y1[0], ayz);
             axx = fmaf(wz[k], y02, axx);
             ayy = fmaf(wz[k], y20, ayy);
-            azz = fmaf(ddwz[k], y0[0], azz);
+            azz = fmaf(ddwz[k], y00, azz);
+            axy = fmaf(wz[k], y11, axy);
+            axz = fmaf(dwz[k], y01, axz);
+            ayz = fmaf(dwz[k], y10, ayz);
         }
     }
-    v = A[0];
+    v = av;
     float fx = (float)G.rx, fy = (float)G.ry, fz = (float)G.rz;
-    g = mk(A[1] * fx, B[0] * fy, C[0] * fz);
+    g = mk(agx * fx, agy * fy, agz * fz);
     if (ORDER >= 2) {
         H[0] = axx * fx * fx; H[1] = ayy * fy * fy; H[2] = azz * fz * fz;
-        H[3] = B[1] * fx * fy; H[4] = C[1] * fx * fz; H[5] = ayz * fy * fz;
+        H[3] = axy * fx * fy; H[4] = axz * fx * fz; H[5] = ayz * fy * fz;
     }
 }
+
+template <int ORDER>
+DSDF_HD void eval_cubic(const GridView &G, V3 x, float &v, V3 &g, float H[6]) {
+    CubicCell c = cubic_cell(G, x);
+    eval_cubic_rows<ORDER>(G, c, global_rows(G, c), v, g, H);
+}
+
+// Fetch policy of the tracing loops.  DirectFetch: every lane reads its own rows (any ray
+// set; the host build).  The render kernels use a wave-cooperative cell cache instead
+// (dsdf_kernels.hip: WaveCellCache) with the same interface:
+//   any(b)            -> loop condition (wave-uniform on the device)
+//   eval<ORDER>(...)  -> lookup for the lanes with `active`; ALL lanes of the wave call it
+struct DirectFetch {
+    DSDF_HD bool any(bool b) const { return b; }
+    template <int ORDER>
+    DSDF_HD void eval(const GridView &G, V3 x, bool active, float &v, V3 &g, float H[6]) const {
+        if (active) eval_cubic<ORDER>(G, x, v, g, H);
+    }
+};
 
 DSDF_HD float eval_value(const GridView &G, V3 x) {
     float v; V3 g; float H[6];
@@ -314,17 +336,18 @@ DSDF_HD float eval_trace_weight(const dsdf_params &P, V3 d, int i, float lo, flo
                                 float v, V3 g, const float H[6], V3 &weight_d) {
     float n_dot_d = dot(g, d);
     float n_dot_n = dot(g, g);
-    float ratio = n_dot_d / n_dot_n;
+    float ratio = n_dot_d * rcpf(n_dot_n);
     float denom = P.sil_weight_epsilon + fabsf(v) + P.sil_weight_offset * n_dot_d * ratio;
-    float dist_w = 1.f / (denom * denom * denom);
+    float inv_denom = rcpf(denom);
+    float dist_w = inv_denom * inv_denom * inv_denom;
     V3 bd_d;
     float bd = bbox_distance_inside_d(x, lo, hi, bd_d);
     const float bbox_eps = 0.01f;
-    float bw = i > 0 ? fminf(bd, bbox_eps) / bbox_eps : 1.f;
+    float bw = i > 0 ? fminf(bd, bbox_eps) * (1.f / bbox_eps) : 1.f;
     V3 bw_d = (i > 0 && bd < bbox_eps) ? bd_d * (1.f / bbox_eps) : mk(0.f, 0.f, 0.f);
     V3 grad = (2.f * ratio) * (d - ratio * g);
     V3 denom_d = drsign(v) * g + P.sil_weight_offset * symmul(H, grad);
-    V3 dist_w_d = (-3.f * dist_w / denom) * denom_d;
+    V3 dist_w_d = (-3.f * dist_w * inv_denom) * denom_d;
     weight_d = dist_w * bw_d + bw * dist_w_d;
     return dist_w * bw;
 }
@@ -336,24 +359,28 @@ struct TraceOut {
 };
 
 // A5: refinement loop (shapes.py:245-257 / 323-334)
-DSDF_HD float refine_hit(const GridView &G, const dsdf_params &P, V3 o, V3 d, float its_t, float trace_eps, int &nref) {
-    nref = 0;
-    if (!(its_t < INFINITY)) return its_t;
-    bool refining = true;
+template <class Fetch>
+DSDF_HD float refine_hit(const GridView &G, const dsdf_params &P, V3 o, V3 d, float its_t, float trace_eps, int &nref,
+                         Fetch &F) {
+    bool refining = (its_t < INFINITY) && P.refine_steps > 0;
     int i = 0;
-    while (refining) {
-        float md = eval_value(G, fma3(its_t, d, o));
-        its_t += md * (10.f / (float)(10 + i));
-        refining = (md <= 0.f) || (md > trace_eps);
-        ++i;
-        refining = refining && (i < P.refine_steps);
+    while (F.any(refining)) {
+        float md = 0.f; V3 gd; float Hd[6];
+        F.template eval<0>(G, fma3(its_t, d, o), refining, md, gd, Hd);
+        if (refining) {
+            its_t += md * (10.f / (float)(10 + i));
+            refining = (md <= 0.f) || (md > trace_eps);
+            ++i;
+            refining = refining && (i < P.refine_steps);
+        }
     }
     nref = i;
     return its_t;
 }
 
 // A4: SDFBase.ray_intersect_non_diff (shapes.py:290-339)
-DSDF_HD void trace_plain(const GridView &G, const dsdf_params &P, V3 o, V3 d_in, float ray_maxt, TraceOut &out) {
+template <class Fetch>
+DSDF_HD void trace_plain(const GridView &G, const dsdf_params &P, V3 o, V3 d_in, float ray_maxt, TraceOut &out, Fetch &F) {
     float inv = 1.f / sqrtf(dot(d_in, d_in));
     V3 d = d_in * inv;
     float lo = -P.bbox_delta, hi = 1.f + P.bbox_delta;
@@ -364,25 +391,28 @@ DSDF_HD void trace_plain(const GridView &G, const dsdf_params &P, V3 o, V3 d_in,
     float its_t = INFINITY;
     float t = b.inside ? 0.f : b.mint + 1e-5f;
     int steps = 0;
-    while (active) {
-        float v = eval_value(G, fma3(t, d, o));
-        bool hit = v < trace_eps;
-        if (hit) its_t = t;
-        float cur = hit ? 0.f : fabsf(v);
-        t += cur;
-        active = (t <= maxt) && !hit;
-        ++steps;
+    while (F.any(active)) {
+        float v = 0.f; V3 gd; float Hd[6];
+        F.template eval<0>(G, fma3(t, d, o), active, v, gd, Hd);
+        if (active) {
+            bool hit = v < trace_eps;
+            if (hit) its_t = t;
+            float cur = hit ? 0.f : fabsf(v);
+            t += cur;
+            active = (t <= maxt) && !hit;
+            ++steps;
+        }
     }
     out.steps = steps;
-    out.its_t = P.refine_steps > 0 ? refine_hit(G, P, o, d, its_t, trace_eps, out.refine_steps) : its_t;
-    if (P.refine_steps <= 0) out.refine_steps = 0;
+    out.its_t = refine_hit(G, P, o, d, its_t, trace_eps, out.refine_steps, F);
     out.warp_t = 0.f; out.warp_weight = 0.f; out.weight_sum = 0.f;
     out.warp_t_d = mk(0.f, 0.f, 0.f); out.warp_weight_d = mk(0.f, 0.f, 0.f);
 }
 
 // A2: SDFBase.ray_intersect (shapes.py:115-288) -- differentiable sphere tracing
 // with the weighted warp-t accumulation and its analytic direction derivative.
-DSDF_HD void trace_diff(const GridView &G, const dsdf_params &P, V3 o, V3 d_in, float ray_maxt, TraceOut &out) {
+template <class Fetch>
+DSDF_HD void trace_diff(const GridView &G, const dsdf_params &P, V3 o, V3 d_in, float ray_maxt, TraceOut &out, Fetch &F) {
     float invn = 1.f / sqrtf(dot(d_in, d_in));
     V3 d = d_in * invn;                                              // :124
     float lo = -P.bbox_delta, hi = 1.f + P.bbox_delta;
@@ -404,49 +434,50 @@ DSDF_HD void trace_diff(const GridView &G, const dsdf_params &P, V3 o, V3 d_in, 
     V3 t_d = mk(0.f, 0.f, 0.f);
     if (!b.inside && fabsf(ddn) > 0.f) t_d = n * (-t / ddn);
 
-    while (active) {
+    while (F.any(active)) {
         V3 x = fma3(t, d, o);
-        float v; V3 g; float H[6];
-        eval_cubic<2>(G, x, v, g, H);                                // :178
-        bool hit = v < trace_eps;                                    // :185
-        if (hit) its_t = t;
-        float sd = fabsf(v);
-        V3 w_d;
-        float w = eval_trace_weight(P, d, i, lo, hi, x, v, g, H, w_d);   // :188
-        float inv_den = 1.f / fminf(P.extra_thresh, sd);             // :198
-        float diff = prev_sd - sd;
-        ews += (diff >= 0.f) ? diff * inv_den : 0.f;
-        ews = fminf(ews, 1.f);                                       // :201
-        float cur = hit ? 0.f : sd;                                  // :203
-        float seg = 0.5f * (cur + prev_sd);
-        float winc = seg * w * ews;                                  // :205-207
-        wsum += winc;
-        warp_t += winc * t;
-        // convert_deriv(f) = t*f + dot(d,f)*t_d  (:126-127)
-        w_d = fma3(dot(d, w_d), t_d, t * w_d);
-        V3 gc = fma3(dot(d, g), t_d, t * g);
-        V3 seg_d = 0.5f * (gc + prev_gc);
-        V3 sd_d = drsign(v) * gc;                                    // :220-221
-        V3 ewd = (prev_gc - sd_d) * inv_den;
-        if (v < P.extra_thresh) ewd = ewd - (diff * inv_den * inv_den) * sd_d;
-        if (diff > 0.f) ews_d = ews_d + ewd;
-        if (ews >= 1.f || ews <= 0.f) ews_d = mk(0.f, 0.f, 0.f);    // :226
-        w_d = w * ews_d + ews * w_d;                                 // :227
-        w *= ews;
-        V3 winc_d = w * seg_d + seg * w_d;                           // :230
-        mixed = mixed + t * winc_d + (w * seg) * t_d;
-        t_d = t_d + gc;
-        wdsum = wdsum + winc_d;
-        ++i;
-        t += cur;
-        prev_sd = sd;
-        prev_gc = gc;
-        active = (t <= maxt) && !hit;                                // :238
+        float v = 0.f; V3 g = mk(0.f, 0.f, 0.f); float H[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        F.template eval<2>(G, x, active, v, g, H);                   // :178
+        if (active) {
+            bool hit = v < trace_eps;                                // :185
+            if (hit) its_t = t;
+            float sd = fabsf(v);
+            V3 w_d;
+            float w = eval_trace_weight(P, d, i, lo, hi, x, v, g, H, w_d);   // :188
+            float inv_den = rcpf(fminf(P.extra_thresh, sd));         // :198
+            float diff = prev_sd - sd;
+            ews += (diff >= 0.f) ? diff * inv_den : 0.f;
+            ews = fminf(ews, 1.f);                                   // :201
+            float cur = hit ? 0.f : sd;                              // :203
+            float seg = 0.5f * (cur + prev_sd);
+            float winc = seg * w * ews;                              // :205-207
+            wsum += winc;
+            warp_t += winc * t;
+            // convert_deriv(f) = t*f + dot(d,f)*t_d  (:126-127)
+            w_d = fma3(dot(d, w_d), t_d, t * w_d);
+            V3 gc = fma3(dot(d, g), t_d, t * g);
+            V3 seg_d = 0.5f * (gc + prev_gc);
+            V3 sd_d = drsign(v) * gc;                                // :220-221
+            V3 ewd = (prev_gc - sd_d) * inv_den;
+            if (v < P.extra_thresh) ewd = ewd - (diff * inv_den * inv_den) * sd_d;
+            if (diff > 0.f) ews_d = ews_d + ewd;
+            if (ews >= 1.f || ews <= 0.f) ews_d = mk(0.f, 0.f, 0.f);    // :226
+            w_d = w * ews_d + ews * w_d;                             // :227
+            w *= ews;
+            V3 winc_d = w * seg_d + seg * w_d;                       // :230
+            mixed = mixed + t * winc_d + (w * seg) * t_d;
+            t_d = t_d + gc;
+            wdsum = wdsum + winc_d;
+            ++i;
+            t += cur;
+            prev_sd = sd;
+            prev_gc = gc;
+            active = (t <= maxt) && !hit;                            // :238
+        }
     }
     out.steps = i;
     out.weight_sum = wsum;
-    out.its_t = P.refine_steps > 0 ? refine_hit(G, P, o, d, its_t, trace_eps, out.refine_steps) : its_t;
-    if (P.refine_steps <= 0) out.refine_steps = 0;
+    out.its_t = refine_hit(G, P, o, d, its_t, trace_eps, out.refine_steps, F);
     float inv = 1.f / wsum;                                          // :259-261
     warp_t *= inv;
     V3 warp_t_d = (mixed - warp_t * wdsum) * inv;
@@ -457,6 +488,14 @@ DSDF_HD void trace_diff(const GridView &G, const dsdf_params &P, V3 o, V3 d_in, 
         warp_t = INFINITY; warp_t_d = mk(0.f, 0.f, 0.f); ww = 0.f; ww_d = mk(0.f, 0.f, 0.f);
     }
     out.warp_t = warp_t; out.warp_t_d = warp_t_d; out.warp_weight = ww; out.warp_weight_d = ww_d;
+}
+
+// per-lane (direct fetch) convenience forms
+DSDF_HD void trace_plain(const GridView &G, const dsdf_params &P, V3 o, V3 d, float maxt, TraceOut &out) {
+    DirectFetch F; trace_plain(G, P, o, d, maxt, out, F);
+}
+DSDF_HD void trace_diff(const GridView &G, const dsdf_params &P, V3 o, V3 d, float maxt, TraceOut &out) {
+    DirectFetch F; trace_diff(G, P, o, d, maxt, out, F);
 }
 
 // ---------------------------------------------------------------------------
