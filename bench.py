@@ -173,6 +173,19 @@ def main():
     alg_bytes = 256.0 * evals + 16 * 2 * 8.0 * sp['lanes'] + 4.0 * args.res ** 3
     achieved = alg_bytes / (prim_avg * 1e-3) / 1e9
 
+    # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process;
+    # the committed summary of the separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of THIS
+    # command (profiles/summarize.py) is used when it matches the launch shape, else null.
+    traffic = None
+    try:
+        tj = json.load(open(os.path.join(ROOT, 'profiles', 'r01_traffic.json')))
+        Wb = args.img + 4
+        key = f"k_render_pass<false, true> grid={Wb * Wb * args.spp_primal * args.views}"
+        if args.res == 256 and key in tj:
+            traffic = tj[key]['hbm_bytes_per_launch']
+    except (OSError, ValueError, KeyError):
+        pass
+
     if rank == 0:
         out = {
             "metric": "diff-renders/sec (fwd+bwd) 256^3 SDF, 512^2, 12 views",
@@ -190,7 +203,7 @@ def main():
                        "primal_ms_per_launch": prim_avg, "grad_ms_per_launch": sum(gradt) / len(gradt),
                        "views_per_launch": args.views},
             "roofline": {"bound": "hbm", "kernel": "k_render_pass<primal>", "achieved": achieved, "peak": 8000.0,
-                         "unit": "GB/s", "frac": achieved / 8000.0, "traffic": None,
+                         "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic,
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": prim_avg},
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -1,0 +1,61 @@
+#!/usr/bin/env python3
+"""Condenses rocprofv3 CSV output (gpurun_out/...) into the small summaries committed here.
+
+  python profiles/summarize.py <tag> <kernel_stats.csv> <kernel_trace.csv> [<fetch_counter.csv> <write_counter.csv>]
+
+Writes profiles/<tag>_kernel_stats.csv (top kernels of `rocprofv3 --kernel-trace --stats`),
+profiles/<tag>_dispatches.csv (per-dispatch durations of the library's kernels) and, when the
+two PMC passes are given, profiles/<tag>_traffic.json with HBM bytes per launch of every
+library kernel: (2 x FETCH_SIZE + WRITE_SIZE) x 1024 -- FETCH_SIZE reads half the bytes of
+wide coalesced streams on gfx950 (MI355X_MICROARCH.md, HBM section; calibrated here on
+k_pad_grid: 2 x 38170 KB ~ 64 MiB grid + apron reads, WRITE_SIZE 70253 KB = 262^3 x 4 B exactly).
+"""
+import collections
+import csv
+import json
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def short(name):
+    return name.split('(')[0].replace('void ', '').strip()
+
+
+def main():
+    tag, stats, trace = sys.argv[1:4]
+    rows = list(csv.DictReader(open(stats)))
+    with open(os.path.join(HERE, f'{tag}_kernel_stats.csv'), 'w') as f:
+        f.write('Name,Calls,TotalDurationNs,AverageNs,Percentage,MinNs,MaxNs\n')
+        for r in rows[:12]:
+            f.write(f"{short(r['Name'])[:70]},{r['Calls']},{r['TotalDurationNs']},{float(r['AverageNs']):.0f},"
+                    f"{r['Percentage']},{r['MinNs']},{r['MaxNs']}\n")
+    d = collections.defaultdict(list)
+    for r in csv.DictReader(open(trace)):
+        if short(r['Kernel_Name']).startswith('k_'):
+            key = f"{short(r['Kernel_Name'])} grid={r['Grid_Size_X']}x{r.get('Grid_Size_Y', '1')}"
+            d[key].append((int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e6)
+    with open(os.path.join(HERE, f'{tag}_dispatches.csv'), 'w') as f:
+        f.write('kernel,dispatches,median_ms,min_ms,max_ms\n')
+        for k, v in d.items():
+            s = sorted(v)
+            f.write(f"{k},{len(v)},{s[len(s) // 2]:.3f},{s[0]:.3f},{s[-1]:.3f}\n")
+    if len(sys.argv) >= 6:
+        out = {}
+        for col, path in (('FETCH_SIZE', sys.argv[4]), ('WRITE_SIZE', sys.argv[5])):
+            agg = collections.defaultdict(list)
+            for r in csv.DictReader(open(path)):
+                if r['Counter_Name'] == col and short(r['Kernel_Name']).startswith('k_'):
+                    agg[f"{short(r['Kernel_Name'])} grid={r['Grid_Size']}"].append(float(r['Counter_Value']))
+            for k, v in agg.items():
+                s = sorted(v)
+                out.setdefault(k, {})[col + '_KB'] = s[0]     # min over dispatches: excludes the bench's stats-enabled launch
+        for k, v in out.items():
+            if 'FETCH_SIZE_KB' in v and 'WRITE_SIZE_KB' in v:
+                v['hbm_bytes_per_launch'] = (2 * v['FETCH_SIZE_KB'] + v['WRITE_SIZE_KB']) * 1024
+        json.dump(out, open(os.path.join(HERE, f'{tag}_traffic.json'), 'w'), indent=1, sort_keys=True)
+
+
+if __name__ == '__main__':
+    main()
