@@ -54,32 +54,45 @@ def synth_grid(res, device, n=32, seed=0):
     return torch.maximum(sd, box).contiguous()
 
 
-def cpu_baseline(args, res_sample=48, spp_p=8, spp_g=2):
-    """Oracle ('port': torch-CPU restatement) timed on the host cores on a bounded
-    sample of the same workload: same 256^3 grid recipe, one sensor of the ring, a
-    48x48 film at 8/2 spp; scaled linearly in lanes to the full job."""
+def cpu_baseline(args, target_seconds=15.0):
+    """Oracle ('port': oracle/dsdf_oracle.c, plain C + OpenMP, fp32) timed on the host cores on a
+    bounded sample of the same workload: the same 256^3 grid, ONE sensor of the ring, the full
+    512^2 film, at reduced spp chosen so that the sample takes ~15 s (probe at 4/1 spp first);
+    scaled linearly in samples-per-pixel to the 256/64 spp, 12-view job."""
     sys.path.insert(0, os.path.join(ROOT, 'oracle'))
-    import sdf_oracle as O
-    g = synth_grid(args.res, 'cpu').double()
-    cam = O.Camera(O.regular_camera_origins(args.views)[0])
-    W = H = res_sample
-    torch.manual_seed(0)
-    op = torch.rand((W + 4) * (H + 4) * spp_p, 2, dtype=torch.float64)
-    og = torch.rand((W + 4) * (H + 4) * spp_g, 2, dtype=torch.float64)
-    gi = torch.randn(H, W, 3, dtype=torch.float64)
-    t0 = time.time()
-    with torch.no_grad():
-        O.render(O.Grid3d(g), cam, W, H, spp_p, op, O.SILHOUETTE)
-    t1 = time.time()
-    O.render_backward(O.Grid3d(g), cam, W, H, spp_g, og, gi, O.SILHOUETTE)
-    t2 = time.time()
-    Wb = args.img + 4
-    full_p, full_g = Wb * Wb * args.spp_primal, Wb * Wb * args.spp_grad
-    samp_p, samp_g = (W + 4) * (H + 4) * spp_p, (W + 4) * (H + 4) * spp_g
-    t_view = (t1 - t0) * full_p / samp_p + (t2 - t1) * full_g / samp_g
-    return {"value": 1.0 / (t_view * args.views), "unit": "renders/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"oracle (torch-CPU fp64), 1 of {args.views} sensors, {W}x{H} film, spp {spp_p}/{spp_g}, "
-                      f"{args.res}^3 grid; {t2 - t0:.1f}s measured, scaled linearly in lanes"}
+    import numpy as np
+    import c_oracle
+    lib = c_oracle.load()
+    g = synth_grid(args.res, 'cpu').numpy()
+    import dsdf
+    s = dsdf.get_regular_cameras(args.views, resx=args.img, resy=args.img)[0]
+    left, up, d = s.frame()
+    cam = np.concatenate([s.origin, left, up, d, [math.tan(math.radians(s.fov) * 0.5), 0, 0, 0]]).astype(np.float32)
+    W = H = args.img
+    rng = np.random.default_rng(0)
+    gi = (rng.standard_normal((H, W, 3)) / (H * W * 3)).astype(np.float32)
+    integ = 0 if 'silhouette' in args.integrator else 1
+
+    def run(spp_p, spp_g):
+        op = rng.random(((W + 4) * (H + 4) * spp_p, 2), dtype=np.float32)
+        og = rng.random(((W + 4) * (H + 4) * spp_g, 2), dtype=np.float32)
+        t0 = time.time()
+        c_oracle.render(lib, g, cam, W, H, spp_p, op, integ)
+        t1 = time.time()
+        c_oracle.render_backward(lib, g, cam, W, H, spp_g, og, gi, integ)
+        return t1 - t0, time.time() - t1
+
+    tp, tg = run(4, 1)
+    k = int(max(1, min(args.spp_grad, target_seconds / max(tp + tg, 1e-3))))
+    spp_g, spp_p = k, 4 * k
+    if k > 1:
+        tp, tg = run(spp_p, spp_g)
+    else:
+        spp_p, spp_g = 4, 1
+    t_view = tp * args.spp_primal / spp_p + tg * args.spp_grad / spp_g
+    return {"value": 1.0 / (t_view * args.views), "unit": "renders/s", "cores": lib.o_num_threads(), "kind": "port",
+            "sample": f"oracle/dsdf_oracle.c (C + OpenMP, fp32), 1 of {args.views} sensors, {W}x{H} film, spp {spp_p}/{spp_g}, "
+                      f"{args.res}^3 grid; {tp + tg:.1f}s measured, scaled linearly in spp and views"}
 
 
 def main():

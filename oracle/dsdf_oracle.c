@@ -1,0 +1,454 @@
+/*
+ * dsdf_oracle.c -- CPU ORACLE, TEST INFRASTRUCTURE ONLY (never linked by the product).
+ *
+ * Independent plain-C (C99 + OpenMP, fp32 like the reference's llvm_ad_rgb variant)
+ * restatement of the reference's hot path: tricubic B-spline SDF lookups, (differentiable)
+ * sphere tracing, WarpField2D, the silhouette / simple-shading integrators, Gaussian film
+ * splat + develop, and the backward pass.  Citations are file:line relative to the
+ * reference root.  Straightforward on purpose: per-tap index clamping, 64 scalar taps,
+ * no padding, no tiling.  It serves as (1) a second checker next to sdf_oracle.py (whose
+ * gradients come from autograd; here the adjoint is written out by hand and the two are
+ * compared in tests/test_c_oracle.py) and (2) the timed CPU baseline of bench.py
+ * (cpu_baseline.kind = "port").
+ *
+ * PARITY UNPINNED: see oracle/sdf_oracle.py -- the reference has no tests/golden vectors and
+ * Mitsuba / Dr.Jit cannot be run here; third-party conventions are restated from their
+ * published algorithms.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define TRACE_EPS 1e-6f       /* shapes.py:31 */
+#define EXTRA_THRESH 0.05f    /* shapes.py:35 */
+#define SIL_OFFSET 0.05f      /* shapes.py:36 */
+#define SIL_EPS 1e-6f         /* shapes.py:37 */
+#define BBOX_DELTA 0.05f      /* shapes.py:417 */
+#define EDGE_EPS 0.01f        /* configs.py:21 */
+#define CLAMP_THRESH 0.05f    /* configs.py:29 */
+#define NEAR_CLIP 1e-2f
+#define FAR_CLIP 1e4f
+#define BORDER 2
+#define FRADIUS 2.0f
+
+typedef struct { const float *d; int rx, ry, rz; } grid_t;
+typedef struct { float its_t, warp_t, wtd[3], ww, wwd[3]; int steps, refine; } trace_t;
+
+static float sgn(float x) { return x >= 0.f ? 1.f : -1.f; }          /* dr.sign */
+static float dot3(const float *a, const float *b) { return a[0]*b[0] + a[1]*b[1] + a[2]*b[2]; }
+static int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+/* ---- Dr.Jit Texture3f cubic B-spline (shapes.py:420-450) ---------------------------- */
+static void bsw(float a, float *w, float *dw, float *ddw) {
+    float a2 = a*a, a3 = a2*a;
+    w[0] = (-a3 + 3*a2 - 3*a + 1)/6.f; w[1] = (3*a3 - 6*a2 + 4)/6.f;
+    w[2] = (-3*a3 + 3*a2 + 3*a + 1)/6.f; w[3] = a3/6.f;
+    dw[0] = (-3*a2 + 6*a - 3)/6.f; dw[1] = (9*a2 - 12*a)/6.f; dw[2] = (-9*a2 + 6*a + 3)/6.f; dw[3] = 3*a2/6.f;
+    ddw[0] = 1 - a; ddw[1] = 3*a - 2; ddw[2] = 1 - 3*a; ddw[3] = a;
+}
+
+typedef struct { int ix[4], iy[4], iz[4]; float w[3][4], dw[3][4], ddw[3][4]; } taps_t;
+
+static void taps_setup(const grid_t *G, const float *p, taps_t *T) {
+    float res[3] = { (float)G->rx, (float)G->ry, (float)G->rz };
+    int base[3];
+    for (int a = 0; a < 3; ++a) {
+        float pf = p[a]*res[a] - 0.5f, fl = floorf(pf);
+        if (!(fl > -1e6f)) fl = -1e6f; if (!(fl < 1e6f)) fl = 1e6f;
+        base[a] = (int)fl - 1;
+        bsw(pf - floorf(pf), T->w[a], T->dw[a], T->ddw[a]);
+    }
+    for (int k = 0; k < 4; ++k) {
+        T->ix[k] = clampi(base[0] + k, 0, G->rx - 1);
+        T->iy[k] = clampi(base[1] + k, 0, G->ry - 1);
+        T->iz[k] = clampi(base[2] + k, 0, G->rz - 1);
+    }
+}
+
+/* order 0: v; 1: v,g; 2: v,g,H (xx,yy,zz,xy,xz,yz) */
+static void eval_cubic(const grid_t *G, const float *p, int order, float *v, float *g, float *H) {
+    taps_t T; taps_setup(G, p, &T);
+    float acc[10] = {0};
+    for (int k = 0; k < 4; ++k) for (int j = 0; j < 4; ++j) {
+        const float *row = G->d + ((size_t)T.iz[k]*G->ry + T.iy[j])*G->rx;
+        for (int i = 0; i < 4; ++i) {
+            float D = row[T.ix[i]];
+            float wx = T.w[0][i], wy = T.w[1][j], wz = T.w[2][k];
+            acc[0] += wz*wy*wx*D;
+            if (order >= 1) {
+                acc[1] += wz*wy*T.dw[0][i]*D; acc[2] += wz*T.dw[1][j]*wx*D; acc[3] += T.dw[2][k]*wy*wx*D;
+            }
+            if (order >= 2) {
+                acc[4] += wz*wy*T.ddw[0][i]*D; acc[5] += wz*T.ddw[1][j]*wx*D; acc[6] += T.ddw[2][k]*wy*wx*D;
+                acc[7] += wz*T.dw[1][j]*T.dw[0][i]*D; acc[8] += T.dw[2][k]*wy*T.dw[0][i]*D; acc[9] += T.dw[2][k]*T.dw[1][j]*wx*D;
+            }
+        }
+    }
+    float X = (float)G->rx, Y = (float)G->ry, Z = (float)G->rz;
+    *v = acc[0];
+    if (order >= 1) { g[0] = acc[1]*X; g[1] = acc[2]*Y; g[2] = acc[3]*Z; }
+    if (order >= 2) { H[0] = acc[4]*X*X; H[1] = acc[5]*Y*Y; H[2] = acc[6]*Z*Z; H[3] = acc[7]*X*Y; H[4] = acc[8]*X*Z; H[5] = acc[9]*Y*Z; }
+}
+
+/* adjoint of eval_cubic w.r.t. the grid: grad[tap] += cv*W + cg.(res*dW) */
+static void scatter_cubic(const grid_t *G, float *grad, const float *p, float cv, const float *cg) {
+    taps_t T; taps_setup(G, p, &T);
+    float X = (float)G->rx, Y = (float)G->ry, Z = (float)G->rz;
+    for (int k = 0; k < 4; ++k) for (int j = 0; j < 4; ++j) for (int i = 0; i < 4; ++i) {
+        float wx = T.w[0][i], wy = T.w[1][j], wz = T.w[2][k];
+        float c = cv*wz*wy*wx + cg[0]*X*wz*wy*T.dw[0][i] + cg[1]*Y*wz*T.dw[1][j]*wx + cg[2]*Z*T.dw[2][k]*wy*wx;
+        float *dst = grad + ((size_t)T.iz[k]*G->ry + T.iy[j])*G->rx + T.ix[i];
+#pragma omp atomic
+        *dst += c;
+    }
+}
+
+static void symmul(const float *H, const float *a, float *o) {
+    o[0] = H[0]*a[0] + H[3]*a[1] + H[4]*a[2];
+    o[1] = H[3]*a[0] + H[1]*a[1] + H[5]*a[2];
+    o[2] = H[4]*a[0] + H[5]*a[1] + H[2]*a[2];
+}
+
+/* ---- bbox helpers (math_util.py:31-41; Mitsuba BoundingBox3f) ------------------------ */
+static void closest_axis(const float *m, float *n) {
+    n[0] = (m[0] < m[1] && m[0] < m[2]) ? 1.f : 0.f;
+    n[1] = (m[1] < m[2] && m[1] < m[0]) ? 1.f : 0.f;
+    n[2] = (m[2] < m[0] && m[2] < m[1]) ? 1.f : 0.f;
+}
+
+static float bbox_dist_d(const float *x, float *dd) {
+    const float lo = -BBOX_DELTA, hi = 1.f + BBOX_DELTA;
+    float mlo = fminf(fminf(x[0]-lo, x[1]-lo), x[2]-lo), mhi = fminf(fminf(hi-x[0], hi-x[1]), hi-x[2]);
+    float dist = fmaxf(0.f, fminf(mlo, mhi));
+    float m[3], n[3], dmax[3], dmin[3];
+    for (int a = 0; a < 3; ++a) { dmax[a] = fabsf(hi - x[a]); dmin[a] = fabsf(lo - x[a]); m[a] = fminf(dmin[a], dmax[a]); }
+    closest_axis(m, n);
+    for (int a = 0; a < 3; ++a) dd[a] = dist > 0.f ? n[a]*sgn(dmax[a] - dmin[a]) : 0.f;
+    return dist;
+}
+
+/* ---- SDFBase.eval_trace_weight (shapes.py:68-113) ------------------------------------- */
+static float trace_weight(const float *d, int i, const float *x, float v, const float *g, const float *H, float *wd) {
+    float ndd = dot3(g, d), ndn = dot3(g, g), ratio = ndd/ndn;
+    float denom = SIL_EPS + fabsf(v) + SIL_OFFSET*ndd*ratio;
+    float dw = 1.f/(denom*denom*denom);
+    float bdd[3]; float bd = bbox_dist_d(x, bdd);
+    float bw = i > 0 ? fminf(bd, 0.01f)/0.01f : 1.f;
+    float gr[3], Hg[3];
+    for (int a = 0; a < 3; ++a) gr[a] = 2.f*ratio*(d[a] - ratio*g[a]);
+    symmul(H, gr, Hg);
+    for (int a = 0; a < 3; ++a) {
+        float bwd = (i > 0 && bd < 0.01f) ? bdd[a]/0.01f : 0.f;
+        float dend = sgn(v)*g[a] + SIL_OFFSET*Hg[a];
+        wd[a] = dw*bwd + bw*(-3.f*dw/denom)*dend;
+    }
+    return dw*bw;
+}
+
+/* ---- SDFBase.ray_intersect / ray_intersect_non_diff (shapes.py:115-339) ---------------- */
+static void trace(const grid_t *G, const float *o, const float *din, float ray_maxt, int diff, trace_t *out) {
+    const float lo = -BBOX_DELTA, hi = 1.f + BBOX_DELTA;
+    float inv = 1.f/sqrtf(dot3(din, din)), d[3] = { din[0]*inv, din[1]*inv, din[2]*inv };
+    float mint = -INFINITY, maxtb = INFINITY; int ok = 1, inside = 1;
+    for (int a = 0; a < 3; ++a) {
+        if (!(d[a] != 0.f || o[a] > lo || o[a] < hi)) ok = 0;
+        float r = 1.f/d[a], t1 = (lo - o[a])*r, t2 = (hi - o[a])*r;
+        mint = fmaxf(mint, fminf(t1, t2)); maxtb = fminf(maxtb, fmaxf(t1, t2));
+        if (!(o[a] >= lo && o[a] <= hi)) inside = 0;
+    }
+    int hit_box = ok && maxtb >= mint && (mint > 0.f || inside);
+    int active = hit_box;
+    float maxt = fminf(maxtb, ray_maxt), eps = TRACE_EPS*fmaxf(maxt, 1.f);
+    float its_t = INFINITY, t = inside ? 0.f : mint + 1e-5f;
+    float warp_t = 0, prev_sd = 0, wsum = 0, ews = 0;
+    float prev_gc[3] = {0}, mixed[3] = {0}, wdsum[3] = {0}, ews_d[3] = {0}, t_d[3] = {0};
+    int i = 0;
+    {   /* entry-face derivative of t, shapes.py:156-164 */
+        float pb[3], m[3], n[3];
+        for (int a = 0; a < 3; ++a) { pb[a] = o[a] + t*d[a]; m[a] = fminf(fabsf(lo - pb[a]), fabsf(hi - pb[a])); }
+        closest_axis(m, n);
+        float ddn = dot3(d, n);
+        if (!inside && fabsf(ddn) > 0.f) for (int a = 0; a < 3; ++a) t_d[a] = -n[a]/ddn*t;
+    }
+    while (active) {
+        float x[3] = { o[0] + t*d[0], o[1] + t*d[1], o[2] + t*d[2] }, v, g[3], H[6];
+        eval_cubic(G, x, diff ? 2 : 0, &v, g, H);
+        int hit = v < eps;
+        if (hit) its_t = t;
+        float sd = fabsf(v), cur = hit ? 0.f : sd;
+        if (diff) {
+            float wd[3], w = trace_weight(d, i, x, v, g, H, wd);
+            float inv_den = 1.f/fminf(EXTRA_THRESH, sd), dif = prev_sd - sd;
+            ews += dif >= 0.f ? dif*inv_den : 0.f;
+            ews = fminf(ews, 1.f);
+            float seg = 0.5f*(cur + prev_sd), winc = seg*w*ews;
+            wsum += winc; warp_t += winc*t;
+            float dwd = dot3(d, wd), dg = dot3(d, g), gc[3], wdc[3];
+            for (int a = 0; a < 3; ++a) { wdc[a] = t*wd[a] + dwd*t_d[a]; gc[a] = t*g[a] + dg*t_d[a]; }   /* convert_deriv */
+            for (int a = 0; a < 3; ++a) {
+                float sdd = sgn(v)*gc[a];
+                float ewd = (prev_gc[a] - sdd)*inv_den;
+                if (v < EXTRA_THRESH) ewd -= dif*inv_den*inv_den*sdd;
+                if (dif > 0.f) ews_d[a] += ewd;
+            }
+            if (ews >= 1.f || ews <= 0.f) ews_d[0] = ews_d[1] = ews_d[2] = 0.f;
+            float w2 = w*ews;
+            for (int a = 0; a < 3; ++a) {
+                float wda = w*ews_d[a] + wdc[a]*ews;
+                float segd = 0.5f*(gc[a] + prev_gc[a]);
+                float wincd = w2*segd + wda*seg;
+                mixed[a] += wincd*t + w2*seg*t_d[a];
+                wdsum[a] += wincd;
+            }
+            for (int a = 0; a < 3; ++a) { t_d[a] += gc[a]; prev_gc[a] = gc[a]; }
+            prev_sd = sd;
+        }
+        ++i; t += cur;
+        active = (t <= maxt) && !hit;
+    }
+    out->steps = i;
+    /* refinement, shapes.py:245-257 */
+    int ri = 0;
+    if (its_t < INFINITY) {
+        int refining = 1;
+        while (refining) {
+            float x[3] = { o[0] + its_t*d[0], o[1] + its_t*d[1], o[2] + its_t*d[2] }, md, g[3], H[6];
+            eval_cubic(G, x, 0, &md, g, H);
+            its_t += md*(10.f/(float)(10 + ri));
+            refining = (md <= 0.f) || (md > eps);
+            ++ri; refining = refining && ri < 10;
+        }
+    }
+    out->refine = ri; out->its_t = its_t;
+    if (diff) {
+        float iw = 1.f/wsum; warp_t *= iw;
+        for (int a = 0; a < 3; ++a) out->wtd[a] = (mixed[a] - warp_t*wdsum[a])*iw;
+        out->ww = fminf(fmaxf(wsum, 0.f), 1.f);
+        for (int a = 0; a < 3; ++a) out->wwd[a] = (wsum > 0.f && wsum < 1.f) ? wdsum[a] : 0.f;
+        if (wsum < 1e-7f || !hit_box) { warp_t = INFINITY; out->ww = 0.f; for (int a = 0; a < 3; ++a) out->wtd[a] = out->wwd[a] = 0.f; }
+        out->warp_t = warp_t;
+    } else { out->warp_t = 0; out->ww = 0; for (int a = 0; a < 3; ++a) out->wtd[a] = out->wwd[a] = 0.f; }
+}
+
+/* ---- sensor (Mitsuba perspective; cam = origin, left, up, dir, tan) -------------------- */
+typedef struct { float o[3], d[3], maxt; } ray_t;
+
+static void camera_ray(const float *cam, float px, float py, int W, int H, ray_t *r) {
+    float aspect = (float)W/(float)H, tn = cam[12];
+    float dl[3] = { (1.f - 2.f*px/(float)W)*tn, (1.f - 2.f*py/(float)H)*tn/aspect, 1.f };
+    float inv = 1.f/sqrtf(dot3(dl, dl)); dl[0] *= inv; dl[1] *= inv; dl[2] *= inv;
+    for (int a = 0; a < 3; ++a) r->d[a] = cam[3+a]*dl[0] + cam[6+a]*dl[1] + cam[9+a]*dl[2];
+    float nt = NEAR_CLIP/dl[2];
+    for (int a = 0; a < 3; ++a) r->o[a] = cam[a] + nt*r->d[a];
+    r->maxt = FAR_CLIP/dl[2] - nt;
+}
+
+/* sensor.sample_direction(o + d'): uv (pixels), ref point, inside flag */
+static int reproject(const float *cam, const float *p, int W, int H, float *uv, float *ref) {
+    float q[3] = { p[0]-cam[0], p[1]-cam[1], p[2]-cam[2] };
+    ref[0] = dot3(cam+3, q); ref[1] = dot3(cam+6, q); ref[2] = dot3(cam+9, q);
+    float aspect = (float)W/(float)H, cot = 1.f/cam[12];
+    float sx = 0.5f - 0.5f*cot*ref[0]/ref[2], sy = 0.5f - 0.5f*aspect*cot*ref[1]/ref[2];
+    uv[0] = sx*(float)W; uv[1] = sy*(float)H;
+    return ref[2] >= NEAR_CLIP && ref[2] <= FAR_CLIP && sx >= 0.f && sx <= 1.f && sy >= 0.f && sy <= 1.f;
+}
+
+static float gauss(float x) { return fmaxf(0.f, expf(-2.f*x*x) - expf(-8.f)); }
+static float dgauss(float x) { float e = expf(-2.f*x*x); return (e - expf(-8.f)) > 0.f ? -4.f*x*e : 0.f; }
+
+static void lane_ray(const float *cam, int W, int H, int spp, const float *offs, long lane, ray_t *r) {
+    int Wb = W + 2*BORDER;
+    long pix = lane/spp; int py = (int)(pix/Wb), px = (int)(pix - (long)py*Wb);
+    camera_ray(cam, (float)(px - BORDER) + offs[2*lane], (float)(py - BORDER) + offs[2*lane+1], W, H, r);
+}
+
+static float shade(const grid_t *G, const ray_t *r, float its_t, int integ, float *gh, float *Hh) {
+    if (!(its_t < INFINITY)) return 0.f;
+    if (integ == 0) return 1.f;
+    float p[3] = { r->o[0] + its_t*r->d[0], r->o[1] + its_t*r->d[1], r->o[2] + its_t*r->d[2] }, v;
+    eval_cubic(G, p, 2, &v, gh, Hh);
+    float l = 0.57735026918962576f;
+    return fmaxf((gh[0] + gh[1] + gh[2])*l/sqrtf(dot3(gh, gh)), 0.f);
+}
+
+static void splat(float *block, int Wb, int Hb, const float *uv, float val) {
+    float pfx = uv[0] + BORDER - 0.5f, pfy = uv[1] + BORDER - 0.5f;
+    int x0 = (int)ceilf(pfx - FRADIUS), y0 = (int)ceilf(pfy - FRADIUS);
+    for (int j = 0; j < 4; ++j) for (int i = 0; i < 4; ++i) {
+        int qx = x0 + i, qy = y0 + j;
+        if (qx < 0 || qx >= Wb || qy < 0 || qy >= Hb) continue;
+        float f = gauss((float)qx - pfx)*gauss((float)qy - pfy);
+        float *dst = block + 2*((size_t)qy*Wb + qx);
+#pragma omp atomic
+        dst[0] += f*val;
+#pragma omp atomic
+        dst[1] += f;
+    }
+}
+
+static void develop(const float *block, int W, int H, float *img) {
+    int Wb = W + 2*BORDER;
+    for (int y = 0; y < H; ++y) for (int x = 0; x < W; ++x) {
+        const float *b = block + 2*((size_t)(y + BORDER)*Wb + x + BORDER);
+        float v = b[0]/(b[1] == 0.f ? 1.f : b[1]);
+        img[3*((size_t)y*W + x)] = img[3*((size_t)y*W + x) + 1] = img[3*((size_t)y*W + x) + 2] = v;
+    }
+}
+
+/* ReparamIntegrator.render (reparam.py:120-185), primal: returns image, fills stats
+ * {lanes, bbox lanes, steps, hits, refine steps}. */
+void o_render(const float *grid, int rx, int ry, int rz, const float *cam, int W, int H, int spp,
+              const float *offsets, int integrator, float *image, long *stats) {
+    grid_t G = { grid, rx, ry, rz };
+    int Wb = W + 2*BORDER, Hb = H + 2*BORDER;
+    long n = (long)Wb*Hb*spp, s_steps = 0, s_hits = 0, s_ref = 0, s_box = 0;
+    float *block = (float *)calloc((size_t)2*Wb*Hb, sizeof(float));
+#pragma omp parallel for schedule(dynamic, 256) reduction(+:s_steps, s_hits, s_ref, s_box)
+    for (long lane = 0; lane < n; ++lane) {
+        ray_t r; trace_t t; float gh[3], Hh[6], uv[2], ref[3];
+        lane_ray(cam, W, H, spp, offsets, lane, &r);
+        trace(&G, r.o, r.d, r.maxt, 0, &t);
+        float val = shade(&G, &r, t.its_t, integrator, gh, Hh);
+        float p[3] = { r.o[0] + r.d[0], r.o[1] + r.d[1], r.o[2] + r.d[2] };
+        reproject(cam, p, W, H, uv, ref);
+        splat(block, Wb, Hb, uv, val);
+        s_steps += t.steps; s_hits += t.its_t < INFINITY; s_ref += t.refine; s_box += t.steps > 0;
+    }
+    develop(block, W, H, image);
+    if (stats) { stats[0] = n; stats[1] = s_box; stats[2] = s_steps; stats[3] = s_hits; stats[4] = s_ref; }
+    free(block);
+}
+
+/* ReparamIntegrator.render_backward (reparam.py:187-190): re-render with the
+ * reparameterisation attached, back-propagate grad_image into grad_grid (accumulating). */
+void o_render_backward(const float *grid, int rx, int ry, int rz, const float *cam, int W, int H, int spp,
+                       const float *offsets, int integrator, int reparam, const float *grad_image,
+                       float *grad_grid, float *image) {
+    grid_t G = { grid, rx, ry, rz };
+    int Wb = W + 2*BORDER, Hb = H + 2*BORDER;
+    long n = (long)Wb*Hb*spp;
+    float *block = (float *)calloc((size_t)2*Wb*Hb, sizeof(float));
+    float *badj = (float *)calloc((size_t)2*Wb*Hb, sizeof(float));
+    trace_t *tr = (trace_t *)malloc((size_t)n*sizeof(trace_t));
+#pragma omp parallel for schedule(dynamic, 256)
+    for (long lane = 0; lane < n; ++lane) {
+        ray_t r; float gh[3], Hh[6], uv[2], ref[3];
+        lane_ray(cam, W, H, spp, offsets, lane, &r);
+        trace(&G, r.o, r.d, r.maxt, 1, &tr[lane]);
+        float val = shade(&G, &r, tr[lane].its_t, integrator, gh, Hh);
+        float p[3] = { r.o[0] + r.d[0], r.o[1] + r.d[1], r.o[2] + r.d[2] };
+        reproject(cam, p, W, H, uv, ref);
+        splat(block, Wb, Hb, uv, val);
+    }
+    if (image) develop(block, W, H, image);
+    for (int y = 0; y < H; ++y) for (int x = 0; x < W; ++x) {              /* adjoint of develop */
+        size_t q = (size_t)(y + BORDER)*Wb + x + BORDER;
+        const float *gi = grad_image + 3*((size_t)y*W + x);
+        float gs = gi[0] + gi[1] + gi[2], w = block[2*q + 1], s = block[2*q];
+        badj[2*q] = w == 0.f ? gs : gs/w;
+        badj[2*q + 1] = w == 0.f ? 0.f : -gs*s/(w*w);
+    }
+#pragma omp parallel for schedule(dynamic, 256)
+    for (long lane = 0; lane < n; ++lane) {
+        const trace_t *t = &tr[lane];
+        int hit = t->its_t < INFINITY;
+        int warp_on = reparam && fabsf(t->warp_t) < INFINITY && t->ww > 0.f;
+        if (!warp_on && !(hit && integrator == 1)) continue;
+        ray_t r; float gh[3] = {0}, Hh[6] = {0}, uv[2], ref[3];
+        lane_ray(cam, W, H, spp, offsets, lane, &r);
+        const float *o = r.o, *d = r.d;
+        float val = shade(&G, &r, t->its_t, integrator, gh, Hh);
+        float p1[3] = { o[0] + d[0], o[1] + d[1], o[2] + d[2] };
+        int inside = reproject(cam, p1, W, H, uv, ref);
+        /* film adjoint gather */
+        float pfx = uv[0] + BORDER - 0.5f, pfy = uv[1] + BORDER - 0.5f;
+        int x0 = (int)ceilf(pfx - FRADIUS), y0 = (int)ceilf(pfy - FRADIUS);
+        float a_val = 0, a_w = 0, ub = 0, vb = 0;
+        for (int j = 0; j < 4; ++j) for (int i = 0; i < 4; ++i) {
+            int qx = x0 + i, qy = y0 + j;
+            if (qx < 0 || qx >= Wb || qy < 0 || qy >= Hb) continue;
+            float rx_ = (float)qx - pfx, ry_ = (float)qy - pfy, fx = gauss(rx_), fy = gauss(ry_);
+            const float *ba = badj + 2*((size_t)qy*Wb + qx);
+            a_val += fx*fy*ba[0]; a_w += fx*fy*ba[1];
+            float s = ba[0]*val + ba[1];
+            ub += s*(-dgauss(rx_)*fy); vb += s*(-fx*dgauss(ry_));
+        }
+        float div_bar = val*a_val + a_w, rw_bar = inside ? div_bar : 0.f;
+        /* adjoint of the warped direction through uv and log importance (reparam.py:99-105) */
+        float cot = 1.f/cam[12], iz = 1.f/ref[2], ku = -0.5f*(float)W*cot;
+        float dist2 = dot3(ref, ref);
+        float rb[3] = { ub*ku*iz + rw_bar*ref[0]/dist2, vb*ku*iz + rw_bar*ref[1]/dist2,
+                        -(ub*ku*ref[0] + vb*ku*ref[1])*iz*iz + rw_bar*(ref[2]/dist2 - 3.f*iz) };
+        float dir_bar[3];
+        for (int a = 0; a < 3; ++a) dir_bar[a] = cam[3+a]*rb[0] + cam[6+a]*rb[1] + cam[9+a]*rb[2];
+        /* shading channel, shapes.py:347-366 */
+        if (hit && integrator == 1) {
+            float g2 = dot3(gh, gh), gl = sqrtf(g2), l = 0.57735026918962576f, n[3] = { gh[0]/gl, gh[1]/gl, gh[2]/gl };
+            float ndl = (n[0] + n[1] + n[2])*l, s_bar = ndl > 0.f ? a_val : 0.f;
+            float Gb[3], pb[3];
+            for (int a = 0; a < 3; ++a) Gb[a] = s_bar/gl*(l - ndl*n[a]);
+            symmul(Hh, Gb, pb);
+            float c = -dot3(gh, d), v0 = dot3(pb, d)/c;
+            for (int a = 0; a < 3; ++a) dir_bar[a] += t->its_t*pb[a] + v0*t->its_t*gh[a];
+            float ph[3] = { o[0] + t->its_t*d[0], o[1] + t->its_t*d[1], o[2] + t->its_t*d[2] };
+            scatter_cubic(&G, grad_grid, ph, v0, Gb);
+        }
+        /* warp channel, warp.py:47-96 */
+        if (warp_on) {
+            float tt = t->warp_t, x[3] = { o[0] + tt*d[0], o[1] + tt*d[1], o[2] + tt*d[2] }, v, g[3], Hm[6];
+            eval_cubic(&G, x, 2, &v, g, Hm);
+            float g2 = dot3(g, g), n_[3] = { g[0]/g2, g[1]/g2, g[2]/g2 };
+            float bdd[3], bd = bbox_dist_d(x, bdd), ee = EDGE_EPS*tt;
+            int use_eps = ee <= bd;
+            float eps = fminf(ee, bd), ie = 1.f/eps, sd = fabsf(v), fac = 1.f - sd*ie, w = fmaxf(fac, 0.f);
+            float wd[3] = {0}, eps_d = 0.f;
+            if (fac >= 0.f) {
+                for (int a = 0; a < 3; ++a) wd[a] = -sgn(v)*g[a]*ie + sd*ie*ie*(use_eps ? 0.f : bdd[a]);
+                if (use_eps) eps_d = sd*ie*ie;
+            }
+            for (int a = 0; a < 3; ++a) wd[a] = t->ww*(wd[a] + eps_d*EDGE_EPS*d[a]) + w*t->wwd[a];
+            w *= t->ww;
+            if (w > 0.f) {
+                float q[3] = { t->wtd[0]/tt, t->wtd[1]/tt, t->wtd[2]/tt };
+                float dn = dot3(d, n_), dq = dot3(d, q), Pn[3], Pq[3], An[3], Hd[3], Hg[3];
+                for (int a = 0; a < 3; ++a) { Pn[a] = n_[a] - dn*d[a]; Pq[a] = q[a] - dq*d[a]; }
+                float pqn = dot3(Pq, n_);
+                for (int a = 0; a < 3; ++a) An[a] = Pn[a] + pqn*d[a];
+                symmul(Hm, d, Hd); symmul(Hm, g, Hg);
+                float trH = Hm[0] + Hm[1] + Hm[2], dHd = dot3(d, Hd), gHg = dot3(g, Hg), gHd = dot3(g, Hd), dg = dot3(d, g);
+                float trJHA = (trH - dHd)/g2 - 2.f*(gHg - dg*gHd)/(g2*g2) + dot3(Pq, Hd)/g2 - 2.f*dot3(Pq, g)*gHd/(g2*g2);
+                float a_ = -(dot3(wd, Pn) + dot3(wd, d)*pqn) - w*trJHA;
+                float T = fmaxf(CLAMP_THRESH, tt), vbar = a_*div_bar, gbar[3];
+                for (int a = 0; a < 3; ++a) { vbar += (-w/T)*Pn[a]*dir_bar[a]; gbar[a] = -w*An[a]*div_bar; }
+                scatter_cubic(&G, grad_grid, x, vbar, gbar);
+            }
+        }
+    }
+    free(block); free(badj); free(tr);
+}
+
+/* per-point / per-ray entry points for the cross-checks */
+void o_eval_cubic(const float *grid, int rx, int ry, int rz, const float *pts, long n, float *v, float *g, float *H) {
+    grid_t G = { grid, rx, ry, rz };
+    for (long i = 0; i < n; ++i) eval_cubic(&G, pts + 3*i, 2, v + i, g + 3*i, H + 6*i);
+}
+
+void o_trace(const float *grid, int rx, int ry, int rz, const float *ro, const float *rd, const float *maxt, long n,
+             int diff, float *its_t, float *warp_t, float *warp_t_d, float *ww, float *ww_d, int *steps) {
+    grid_t G = { grid, rx, ry, rz };
+    for (long i = 0; i < n; ++i) {
+        trace_t t; trace(&G, ro + 3*i, rd + 3*i, maxt[i], diff, &t);
+        its_t[i] = t.its_t; warp_t[i] = t.warp_t; ww[i] = t.ww; steps[i] = t.steps;
+        for (int a = 0; a < 3; ++a) { warp_t_d[3*i + a] = t.wtd[a]; ww_d[3*i + a] = t.wwd[a]; }
+    }
+}
+
+int o_num_threads(void) {
+#ifdef _OPENMP
+    extern int omp_get_max_threads(void);
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
