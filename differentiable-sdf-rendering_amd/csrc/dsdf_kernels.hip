@@ -28,6 +28,11 @@ using namespace dsdf;
 #define DSDF_EPI_VARIANT 1
 #endif
 #define DSDF_TSTRIDE 68   /* 64 + 4: rows 16-byte aligned, ds_read_b128 conflict-free across lanes */
+#define DSDF_TROWS 13     /* film transpose processes the 25 window slots in two chunks of <= 13 rows */
+#define DSDF_WAVE_LDS 1104 /* floats per wave: max(16 cache slots * 68 + 16 slot bases, 13 * 68) */
+#ifndef DSDF_PRIMAL_MINWAVES
+#define DSDF_PRIMAL_MINWAVES 8   /* latency-bound: 64 VGPRs (a 52-byte spill) for 8 waves/SIMD measured 48.5 vs 52.3 ms */
+#endif
 
 struct AtomicAdd {
     __device__ __forceinline__ void operator()(float *p, float v) const { atomicAdd(p, v); }
@@ -196,40 +201,42 @@ struct LdsRows {
 };
 
 struct WaveCellCache {
-    float *taps;   // wave-private LDS: DSDF_CACHE_SLOTS * DSDF_SLOT_STRIDE floats
+    float *taps;      // wave-private LDS: DSDF_CACHE_SLOTS * DSDF_SLOT_STRIDE floats, then DSDF_CACHE_SLOTS slot bases
     int lid;
     __device__ __forceinline__ bool any(bool b) const { return __ballot(b) != 0; }
 
     template <int ORDER>
     __device__ __forceinline__ void eval(const GridView &G, V3 x, bool active, float &v, V3 &g, float H[6]) {
         const CubicCell c = cubic_cell(G, active ? x : mk(0.f, 0.f, 0.f));
-        int slot = -1;
+        uint32_t *slot_base = reinterpret_cast<uint32_t *>(taps + DSDF_CACHE_SLOTS * DSDF_SLOT_STRIDE);
+        // 1. group the lanes by cell: leader = first unassigned active lane; every lane holding the
+        //    same cell key takes the slot (v_readlane + v_cmp + v_cndmask + scalar mask update per cell)
+        int slot = -1, n = 0;
         uint64_t todo = __ballot(active);
+        while (todo != 0 && n < DSDF_CACHE_SLOTS) {
+            const int leader = __builtin_ctzll(todo);
+            const uint32_t k = (uint32_t)__builtin_amdgcn_readlane((int)c.base, leader);
+            const bool same = c.base == k;
+            slot = same ? n : slot;
+            todo &= ~__ballot(same);
+            ++n;
+        }
+        if (slot >= 0) slot_base[slot] = c.base;        // all lanes of a slot write the same value
+        wave_lds_sync();
+        // 2. load every distinct cell once: lane (grp, r) fetches row r of slot 4*round + grp
         const int grp = lid >> 4, r = lid & 15;
         const uint32_t rowoff = (uint32_t)(r >> 2) * (4u * (uint32_t)G.sxy) + (uint32_t)(r & 3) * (4u * (uint32_t)G.sx);
-#pragma unroll
-        for (int round = 0; round < DSDF_CACHE_SLOTS / 4; ++round) {
-            if (todo == 0) break;
-            uint32_t myb = 0;
-            bool have = false;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                if (todo != 0) {
-                    const int leader = __ffsll((unsigned long long)todo) - 1;
-                    const uint32_t k = (uint32_t)__builtin_amdgcn_readlane((int)c.base, leader);
-                    const bool match = active && c.base == k;
-                    if (match) slot = round * 4 + q;
-                    if (grp == q) { myb = k; have = true; }
-                    todo &= ~__ballot(match);
-                }
-            }
-            if (have) {
+        for (int s0 = 0; s0 < n; s0 += 4) {
+            const int sl = s0 + grp;
+            if (sl < n) {
                 typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
-                f4u t = *reinterpret_cast<const f4u *>(reinterpret_cast<const char *>(G.p) + (myb + rowoff));
-                *reinterpret_cast<float4 *>(taps + (round * 4 + grp) * DSDF_SLOT_STRIDE + r * 4) = make_float4(t.x, t.y, t.z, t.w);
+                const uint32_t b = slot_base[sl];
+                f4u t = *reinterpret_cast<const f4u *>(reinterpret_cast<const char *>(G.p) + (b + rowoff));
+                *reinterpret_cast<float4 *>(taps + sl * DSDF_SLOT_STRIDE + r * 4) = make_float4(t.x, t.y, t.z, t.w);
             }
         }
         wave_lds_sync();
+        // 3. every lane evaluates from its slot (lanes beyond 16 distinct cells read global memory)
         if (active) {
             if (slot >= 0) {
                 LdsRows R; R.slot = taps + slot * DSDF_SLOT_STRIDE;
@@ -297,7 +304,7 @@ __device__ __forceinline__ Queue view_queue(Queue q, uint32_t view) {
 #define DSDF_DIFF_MINWAVES 1
 #endif
 template <bool DIFF, bool CACHE>
-__global__ __launch_bounds__(DSDF_BLOCK, DIFF ? DSDF_DIFF_MINWAVES : 1) void k_render_pass(GridView G, dsdf_params P, ViewBatch VB,
+__global__ __launch_bounds__(DSDF_BLOCK, DIFF ? DSDF_DIFF_MINWAVES : DSDF_PRIMAL_MINWAVES) void k_render_pass(GridView G, dsdf_params P, ViewBatch VB,
                                                             float *__restrict__ blocks, Queue qall,
                                                             unsigned long long *stats, uint32_t n_lanes,
                                                             int wave_uniform) {
@@ -310,7 +317,7 @@ __global__ __launch_bounds__(DSDF_BLOCK, DIFF ? DSDF_DIFF_MINWAVES : 1) void k_r
     const int lid = lane_id();
     Lane L = lane_setup(A, P, lane);
     // wave-private LDS scratch: cell cache during tracing, film transpose afterwards
-    __shared__ __attribute__((aligned(16))) float wave_lds[DSDF_BLOCK / 64][25 * DSDF_TSTRIDE];
+    __shared__ __attribute__((aligned(16))) float wave_lds[DSDF_BLOCK / 64][DSDF_WAVE_LDS];
     TraceOut tr;
     if (CACHE) {
         WaveCellCache F; F.taps = wave_lds[threadIdx.x >> 6]; F.lid = lid;
@@ -341,34 +348,39 @@ __global__ __launch_bounds__(DSDF_BLOCK, DIFF ? DSDF_DIFF_MINWAVES : 1) void k_r
         for (int j = 0; j < 5; ++j)
 #pragma unroll
             for (int i = 0; i < 5; ++i) f[j * 5 + i] = fx[i] * fy[j];
-        const int j5 = lid / 5, i5 = lid - 5 * j5;
-        const int qx = L.px - 2 + i5, qy = L.py - 2 + j5;
-        const bool own = lid < 25 && qx >= 0 && qx < A.Wb && qy >= 0 && qy < A.Hb;
-        float *dst = block + 2 * ((size_t)(own ? qy : 0) * A.Wb + (own ? qx : 0));
         const bool any_val = __ballot(val != 0.f) != 0;     // pixels nobody hits skip the value channel
 #pragma unroll
         for (int ch = 0; ch < 2; ++ch) {
             if (ch == 0 && !any_val) continue;
 #pragma unroll
-            for (int k = 0; k < 25; ++k) T[k * DSDF_TSTRIDE + lid] = ch == 0 ? f[k] * val : f[k];
-            wave_lds_sync();
-            float total = 0.f;
-            if (lid < 25) {
-                const float4 *row = reinterpret_cast<const float4 *>(T + lid * DSDF_TSTRIDE);
-                float4 a0 = row[0], a1 = row[1], a2 = row[2], a3 = row[3];
+            for (int k0 = 0; k0 < 25; k0 += DSDF_TROWS) {
+                const int nk = (25 - k0) < DSDF_TROWS ? (25 - k0) : DSDF_TROWS;
 #pragma unroll
-                for (int r = 4; r < 16; r += 4) {
-                    float4 b0 = row[r], b1 = row[r + 1], b2 = row[r + 2], b3 = row[r + 3];
-                    a0.x += b0.x; a0.y += b0.y; a0.z += b0.z; a0.w += b0.w;
-                    a1.x += b1.x; a1.y += b1.y; a1.z += b1.z; a1.w += b1.w;
-                    a2.x += b2.x; a2.y += b2.y; a2.z += b2.z; a2.w += b2.w;
-                    a3.x += b3.x; a3.y += b3.y; a3.z += b3.z; a3.w += b3.w;
+                for (int k = 0; k < DSDF_TROWS; ++k)
+                    if (k < nk) T[k * DSDF_TSTRIDE + lid] = ch == 0 ? f[k0 + k] * val : f[k0 + k];
+                wave_lds_sync();
+                float total = 0.f;
+                const int slot = k0 + lid;                   // window slot summed by this lane
+                const int j5 = slot / 5, i5 = slot - 5 * j5;
+                const int qx = L.px - 2 + i5, qy = L.py - 2 + j5;
+                const bool own = lid < nk && qx >= 0 && qx < A.Wb && qy >= 0 && qy < A.Hb;
+                if (lid < nk) {
+                    const float4 *row = reinterpret_cast<const float4 *>(T + lid * DSDF_TSTRIDE);
+                    float4 a0 = row[0], a1 = row[1], a2 = row[2], a3 = row[3];
+#pragma unroll
+                    for (int r = 4; r < 16; r += 4) {
+                        float4 b0 = row[r], b1 = row[r + 1], b2 = row[r + 2], b3 = row[r + 3];
+                        a0.x += b0.x; a0.y += b0.y; a0.z += b0.z; a0.w += b0.w;
+                        a1.x += b1.x; a1.y += b1.y; a1.z += b1.z; a1.w += b1.w;
+                        a2.x += b2.x; a2.y += b2.y; a2.z += b2.z; a2.w += b2.w;
+                        a3.x += b3.x; a3.y += b3.y; a3.z += b3.z; a3.w += b3.w;
+                    }
+                    total = ((a0.x + a0.y) + (a0.z + a0.w)) + ((a1.x + a1.y) + (a1.z + a1.w)) +
+                            (((a2.x + a2.y) + (a2.z + a2.w)) + ((a3.x + a3.y) + (a3.z + a3.w)));
                 }
-                total = ((a0.x + a0.y) + (a0.z + a0.w)) + ((a1.x + a1.y) + (a1.z + a1.w)) +
-                        (((a2.x + a2.y) + (a2.z + a2.w)) + ((a3.x + a3.y) + (a3.z + a3.w)));
+                wave_lds_sync();
+                if (own && total != 0.f) atomicAdd(block + 2 * ((size_t)qy * A.Wb + qx) + ch, total);
             }
-            wave_lds_sync();
-            if (own && total != 0.f) atomicAdd(dst + (ch == 0 ? 0 : 1), total);
         }
 #else
         float v[64];

@@ -71,12 +71,13 @@ DSDF_HD GridView make_view(const float *padded, int rx, int ry, int rz, const ds
 
 // Uniform cubic B-spline basis (taps i-1..i+2) and derivatives; Dr.Jit texture.h.
 DSDF_HD void bspline_w(float a, float w[4]) {
-    float a2 = a * a, a3 = a2 * a;
+    // (1-a)^3/6, (3a^3-6a^2+4)/6, (-3a^3+3a^2+3a+1)/6, a^3/6 in Horner form
     const float s = 1.f / 6.f;
-    w[0] = s * (-a3 + 3.f * a2 - 3.f * a + 1.f);
-    w[1] = s * (3.f * a3 - 6.f * a2 + 4.f);
-    w[2] = s * (-3.f * a3 + 3.f * a2 + 3.f * a + 1.f);
-    w[3] = s * a3;
+    float b = 1.f - a;
+    w[0] = s * b * b * b;
+    w[3] = s * a * a * a;
+    w[1] = fmaf(a * a, fmaf(0.5f, a, -1.f), 4.f * s);
+    w[2] = fmaf(b * b, fmaf(0.5f, b, -1.f), 4.f * s);
 }
 DSDF_HD void bspline_dw(float a, float w[4]) {
     float a2 = a * a;
@@ -544,9 +545,17 @@ DSDF_HD Reproj reproject(const dsdf_camera &c, const dsdf_params &P, V3 p, int W
 #define DSDF_FILTER_ALPHA (-2.0f)            /* -1/(2*0.5^2) */
 #define DSDF_FILTER_BIAS 3.3546262790251185e-4f   /* exp(-2 * 2^2) */
 
-DSDF_HD float gauss_f(float x) { return fmaxf(0.f, expf(DSDF_FILTER_ALPHA * x * x) - DSDF_FILTER_BIAS); }
+// exp(alpha x^2): v_exp_f32 (2^x, 1 ulp) on the device instead of the range-reduced expf sequence
+DSDF_HD float gauss_exp(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_exp2f((DSDF_FILTER_ALPHA * 1.4426950408889634f) * x * x);
+#else
+    return expf(DSDF_FILTER_ALPHA * x * x);
+#endif
+}
+DSDF_HD float gauss_f(float x) { return fmaxf(0.f, gauss_exp(x) - DSDF_FILTER_BIAS); }
 DSDF_HD float gauss_df(float x) {
-    float e = expf(DSDF_FILTER_ALPHA * x * x);
+    float e = gauss_exp(x);
     return (e - DSDF_FILTER_BIAS) > 0.f ? 2.f * DSDF_FILTER_ALPHA * x * e : 0.f;
 }
 
