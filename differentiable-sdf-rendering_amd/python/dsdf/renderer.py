@@ -189,6 +189,21 @@ def render_backward(grid, sensors, spp, grad_image, grad_grid=None, seeds=None, 
     return (grad_grid, img) if return_image else grad_grid
 
 
+def redistance(phi):
+    """`redistancing.redistance`: signed distance field with the zero level set of phi (Z,Y,X[,1])."""
+    lib = _lib.load()
+    shape = phi.shape
+    p3 = phi[..., 0] if phi.dim() == 4 else phi
+    p3 = _require_dev(p3.detach(), 'phi')
+    rz, ry, rx = (int(s) for s in p3.shape)
+    out = torch.empty_like(p3)
+    wsb = lib.dsdf_redistance_workspace_size(rx, ry, rz)
+    ws = torch.empty(int(wsb), dtype=torch.uint8, device=p3.device)
+    with torch.cuda.device(p3.device):
+        _lib.check(lib.dsdf_redistance(_ptr(p3), rx, ry, rz, _ptr(out), _ptr(ws), wsb, _stream()))
+    return out.reshape(shape)
+
+
 def new_stats(device):
     return torch.zeros(8, dtype=torch.int64, device=device)
 

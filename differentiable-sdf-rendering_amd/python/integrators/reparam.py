@@ -1,0 +1,169 @@
+"""`ReparamIntegrator` (python/integrators/reparam.py:10-277) over the HIP library, plus the
+tiny plugin registry and `render` op that stand in for `mi.register_integrator` / `mi.render`.
+
+A `Scene` here is just what the hot path needs from a Mitsuba scene: the sensors and the
+integrator that owns the SDF.
+"""
+import torch
+
+import dsdf
+from constants import SDF_DEFAULT_KEY, SDF_DEFAULT_KEY_P
+from shapes import Grid3d
+from warp import DummyWarpField
+
+_REGISTRY = {}
+
+
+def register_integrator(name, factory):
+    """mi.register_integrator(name, lambda props: Cls(props))."""
+    _REGISTRY[name] = factory
+
+
+def create_integrator(name, props=None):
+    if name not in _REGISTRY:
+        raise ValueError(f"unknown integrator plugin '{name}' (registered: {sorted(_REGISTRY)})")
+    return _REGISTRY[name](props or {})
+
+
+class Scene:
+    def __init__(self, sensors, integrator):
+        self._sensors = list(sensors)
+        self._integrator = integrator
+
+    def sensors(self):
+        return self._sensors
+
+    def integrator(self):
+        return self._integrator
+
+
+class SceneParameters(dict):
+    """What mi.traverse(scene) returns for this path: key -> tensor, with keep()/update()."""
+
+    def __init__(self, scene):
+        super().__init__()
+        self._scene = scene
+        scene.integrator().traverse(self)
+
+    def put_parameter(self, name, value, flags=None):
+        self['SamplingIntegrator.' + name] = value
+
+    def keep(self, keys):
+        for k in [k for k in self if k not in keys]:
+            del self[k]
+
+    def update(self, values=None):
+        if values is not None:
+            for k, v in dict(values).items():
+                if k in self:
+                    self[k] = v
+        integ = self._scene.integrator()
+        if SDF_DEFAULT_KEY in self:
+            integ.sdf.set_data(self[SDF_DEFAULT_KEY])
+        integ.parameters_changed(list(self))
+
+
+def traverse(scene):
+    return SceneParameters(scene)
+
+
+class ReparamIntegrator:
+    """Base class: owns `sdf` (Grid3d) and `warp_field`; subclasses pick the `sample()` body."""
+    integrator_id = None
+
+    def __init__(self, props=None):
+        props = props or {}
+        self.max_depth = props.get('max_depth', 4)
+        if props.get('weight_by_spp', False):
+            raise AssertionError("Not supported")                       # python/integrators/reparam.py:16
+        if props.get('antithetic_sampling', False) or props.get('use_aovs', False):
+            raise NotImplementedError("antithetic_sampling / use_aovs are outside the supported path")
+        fn = props.get('sdf_filename', '')
+        self.sdf = Grid3d(fn) if fn else props.get('sdf', None)
+        self.warp_field = None
+
+    # -- helpers -------------------------------------------------------------------------
+    def _sensors(self, scene, sensor):
+        if isinstance(sensor, int):
+            return [scene.sensors()[sensor]]
+        return list(sensor) if isinstance(sensor, (list, tuple)) else [sensor]
+
+    def _configured(self):
+        if self.sdf is None:
+            raise ValueError("integrator has no SDF (sdf_filename / props['sdf'])")
+        wf = self.warp_field if self.warp_field is not None else DummyWarpField(self.sdf)
+        wf.apply(self.sdf.grid.params)
+        return wf.reparameterize
+
+    # -- plugin API ----------------------------------------------------------------------
+    def render(self, scene, sensor=0, seed=0, spp=0, develop=True, evaluate=True, mode=None):
+        """python/integrators/reparam.py:120-185 -> image(s) (n,H,W,3) (a single sensor gives (H,W,3))."""
+        if not develop:
+            raise Exception("Must use develop=True for this AD integrator")
+        sens = self._sensors(scene, sensor)
+        reparam = self._configured()
+        img = dsdf.render_forward(self.sdf.grid, sens, spp or 4, seeds=[seed + i for i in range(len(sens))],
+                                  integrator=self.integrator_id, reparam=reparam)
+        return img[0] if len(sens) == 1 and not isinstance(sensor, (list, tuple)) else img
+
+    def render_backward(self, scene, params, grad_in, sensor=0, seed=0, spp=0):
+        """python/integrators/reparam.py:187-190: accumulates into params[key].grad."""
+        sens = self._sensors(scene, sensor)
+        reparam = self._configured()
+        data = params[SDF_DEFAULT_KEY]
+        g = dsdf.render_backward(self.sdf.grid, sens, spp or 4, grad_in.reshape(len(sens), *grad_in.shape[-3:]).contiguous(),
+                                 seeds=[seed + i for i in range(len(sens))], integrator=self.integrator_id, reparam=reparam)
+        g = g.reshape(data.shape)
+        data.grad = g if data.grad is None else data.grad + g
+
+    def render_forward(self, scene, params, sensor=0, seed=0, spp=0):
+        raise NotImplementedError("forward-mode gradients (render_forward) are outside the supported path")
+
+    def traverse(self, cb):
+        if self.sdf is not None:
+            self.sdf.traverse(cb)
+
+    def parameters_changed(self, keys=None):
+        if self.sdf is not None:
+            self.sdf.parameters_changed(keys)
+
+    def aov_names(self):
+        return []
+
+
+class _RenderOp(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, data, scene, sensors, seed, spp, seed_grad, spp_grad):
+        integ = scene.integrator()
+        ctx.args = (scene, sensors, seed_grad, spp_grad, data.shape)
+        integ.sdf.set_data(data.detach())
+        integ._configured()
+        return dsdf.render_forward(integ.sdf.grid, sensors, spp, seeds=[seed + i for i in range(len(sensors))],
+                                   integrator=integ.integrator_id, reparam=integ._configured())
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        scene, sensors, seed_grad, spp_grad, shape = ctx.args
+        integ = scene.integrator()
+        g = dsdf.render_backward(integ.sdf.grid, sensors, spp_grad, grad_out.contiguous(),
+                                 seeds=[seed_grad + i for i in range(len(sensors))], integrator=integ.integrator_id,
+                                 reparam=integ._configured())
+        return g.reshape(shape), None, None, None, None, None, None
+
+
+def render(scene, params=None, sensor=0, seed=0, spp=4, seed_grad=0, spp_grad=None, integrator=None):
+    """`mi.render(scene, params, sensor, seed, spp, seed_grad, spp_grad)` (python/shape_opt.py:78-80):
+    primal image from (seed, spp) without AD; if `params` holds a tensor that requires grad the
+    result is attached to it and its backward runs an independent (seed_grad, spp_grad) gradient pass."""
+    integ = scene.integrator()
+    single = not isinstance(sensor, (list, tuple))
+    sens = integ._sensors(scene, sensor)
+    data = params[SDF_DEFAULT_KEY] if params is not None and SDF_DEFAULT_KEY in params else None
+    if data is not None and data.requires_grad and torch.is_grad_enabled():
+        img = _RenderOp.apply(data, scene, sens, int(seed), int(spp), int(seed_grad), int(spp_grad or spp))
+    else:
+        with torch.no_grad():
+            if data is not None:
+                integ.sdf.set_data(data.detach())
+            img = integ.render(scene, sens, seed=seed, spp=spp)
+    return img[0] if single else img

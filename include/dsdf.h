@@ -154,6 +154,14 @@ int dsdf_render_backward(const float *padded, int rx, int ry, int rz, const dsdf
                          void *workspace, size_t workspace_bytes,
                          int64_t *stats, void *stream);
 
+/* `redistancing.redistance(phi)` (python/redistancing.py:4-13 -> fastsweep.redistance, an
+ * un-vendored native dependency): re-initialises phi (rz,ry,rx) to a signed distance field
+ * with the same zero level set, grid spacing 1/res on the unit cube.  Spec: frozen sub-voxel
+ * interface band + Godunov upwind Eikonal fixed point (oracle/dsdf_oracle.c:o_redistance). */
+size_t dsdf_redistance_workspace_size(int rx, int ry, int rz);
+int dsdf_redistance(const float *phi, int rx, int ry, int rz, float *out,
+                    void *workspace, size_t workspace_bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

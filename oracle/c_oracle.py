@@ -42,3 +42,11 @@ def render_backward(lib, grid, cam16, W, H, spp, offsets, grad_image, integrator
     lib.o_render_backward(_p(grid), rx, ry, rz, _p(cam16), W, H, spp, _p(offsets), integrator, int(reparam), _p(gi),
                           _p(gg), _p(img))
     return gg, img
+
+
+def redistance(lib, phi):
+    phi = np.ascontiguousarray(phi, np.float32)
+    out = np.zeros_like(phi)
+    rz, ry, rx = phi.shape
+    lib.o_redistance(_p(phi), rx, ry, rz, _p(out))
+    return out
