@@ -585,12 +585,36 @@ __global__ void k_redist_init(const float *__restrict__ phi, int rx, int ry, int
     frozen[i] = any ? 1 : 0;
 }
 
+// `tmap` holds three rotating per-tile "changed" maps: launch i reads map (i-1), writes map i and
+// clears map (i+1); a tile is relaxed only if it or one of its 6 neighbours changed in launch i-1,
+// so work follows the moving front instead of sweeping the whole grid every launch.
 __global__ __launch_bounds__(512) void k_redist_iter(float *__restrict__ u, const unsigned char *__restrict__ frozen,
-                                                     int rx, int ry, int rz, unsigned int *flags, int iter) {
+                                                     int rx, int ry, int rz, unsigned int *flags,
+                                                     unsigned char *__restrict__ tmap, int iter) {
     if (iter > 0 && flags[(iter + 2) % 3] == 0) return;       // previous launch changed nothing: converged
-    if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) flags[(iter + 1) % 3] = 0;
     const int T = DSDF_RD_TILE, S = T + 2;
+    const int ntx = gridDim.x, nty = gridDim.y, ntz = gridDim.z;
+    const size_t ntiles = (size_t)ntx * nty * ntz;
+    const size_t tid = ((size_t)blockIdx.z * nty + blockIdx.y) * ntx + blockIdx.x;
+    unsigned char *prev = tmap + (size_t)((iter + 2) % 3) * ntiles, *cur_map = tmap + (size_t)(iter % 3) * ntiles,
+                  *next = tmap + (size_t)((iter + 1) % 3) * ntiles;
+    if (threadIdx.x == 0) {
+        next[tid] = 0;
+        if (tid == 0) flags[(iter + 1) % 3] = 0;
+    }
+    if (iter > 0) {
+        bool act = prev[tid];
+        if (blockIdx.x > 0) act = act || prev[tid - 1];
+        if ((int)blockIdx.x < ntx - 1) act = act || prev[tid + 1];
+        if (blockIdx.y > 0) act = act || prev[tid - ntx];
+        if ((int)blockIdx.y < nty - 1) act = act || prev[tid + ntx];
+        if (blockIdx.z > 0) act = act || prev[tid - (size_t)ntx * nty];
+        if ((int)blockIdx.z < ntz - 1) act = act || prev[tid + (size_t)ntx * nty];
+        if (!act) return;                                     // block-uniform
+    }
     __shared__ float tile[S * S * S];
+    __shared__ int tile_changed;
+    if (threadIdx.x == 0) tile_changed = 0;
     const int x0 = blockIdx.x * T, y0 = blockIdx.y * T, z0 = blockIdx.z * T;
     for (int e = threadIdx.x; e < S * S * S; e += 512) {
         int lx = e % S, ly = (e / S) % S, lz = e / (S * S);
@@ -618,7 +642,9 @@ __global__ __launch_bounds__(512) void k_redist_iter(float *__restrict__ u, cons
         if (un < cur) { cur = un; tile[c] = un; }
         __syncthreads();
     }
-    if (cur < start) { u[gi] = cur; flags[iter % 3] = 1; }
+    if (cur < start) { u[gi] = cur; tile_changed = 1; }
+    __syncthreads();
+    if (threadIdx.x == 0 && tile_changed) { cur_map[tid] = 1; flags[iter % 3] = 1; }
 }
 
 __global__ void k_redist_finish(const float *__restrict__ phi, const float *__restrict__ u, size_t n, float *__restrict__ out) {
@@ -842,7 +868,9 @@ int dsdf_render_backward(const float *padded, int rx, int ry, int rz, const dsdf
 size_t dsdf_redistance_workspace_size(int rx, int ry, int rz) {
     if (rx < 1 || ry < 1 || rz < 1) return 0;
     size_t n = (size_t)rx * ry * rz;
-    return align_up(n * sizeof(float), 256) + align_up(n, 256) + 256;
+    size_t ntiles = (size_t)((rx + DSDF_RD_TILE - 1) / DSDF_RD_TILE) * ((ry + DSDF_RD_TILE - 1) / DSDF_RD_TILE) *
+                    ((rz + DSDF_RD_TILE - 1) / DSDF_RD_TILE);
+    return align_up(n * sizeof(float), 256) + align_up(n, 256) + 256 + align_up(3 * ntiles, 256);
 }
 
 int dsdf_redistance(const float *phi, int rx, int ry, int rz, float *out, void *workspace, size_t workspace_bytes,
@@ -854,15 +882,18 @@ int dsdf_redistance(const float *phi, int rx, int ry, int rz, float *out, void *
     char *p = (char *)workspace;
     float *u = (float *)p; p += align_up(n * sizeof(float), 256);
     unsigned char *frozen = (unsigned char *)p; p += align_up(n, 256);
-    unsigned int *flags = (unsigned int *)p;
+    unsigned int *flags = (unsigned int *)p; p += 256;
+    unsigned char *tmap = (unsigned char *)p;
+    dim3 tiles((rx + DSDF_RD_TILE - 1) / DSDF_RD_TILE, (ry + DSDF_RD_TILE - 1) / DSDF_RD_TILE, (rz + DSDF_RD_TILE - 1) / DSDF_RD_TILE);
     int rc;
+    if (hipMemsetAsync(tmap, 0, 3 * (size_t)tiles.x * tiles.y * tiles.z, st) != hipSuccess)
+        return fail(DSDF_ERR_LAUNCH, "hipMemsetAsync(tile map) failed");
     hipLaunchKernelGGL(k_redist_init, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, phi, rx, ry, rz, u, frozen, flags);
     if ((rc = check_launch("k_redist_init"))) return rc;
-    dim3 tiles((rx + DSDF_RD_TILE - 1) / DSDF_RD_TILE, (ry + DSDF_RD_TILE - 1) / DSDF_RD_TILE, (rz + DSDF_RD_TILE - 1) / DSDF_RD_TILE);
     // information crosses at least one tile per launch; 2x margin, converged launches return at once
     int max_iter = 2 * (int)(tiles.x + tiles.y + tiles.z) + 8;
     for (int it = 0; it < max_iter; ++it) {
-        hipLaunchKernelGGL(k_redist_iter, tiles, dim3(512), 0, st, u, frozen, rx, ry, rz, flags, it);
+        hipLaunchKernelGGL(k_redist_iter, tiles, dim3(512), 0, st, u, frozen, rx, ry, rz, flags, tmap, it);
         if ((rc = check_launch("k_redist_iter"))) return rc;
     }
     hipLaunchKernelGGL(k_redist_finish, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, phi, u, n, out);
