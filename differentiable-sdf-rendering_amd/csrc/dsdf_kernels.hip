@@ -755,9 +755,9 @@ int dsdf_pad_grid(const float *data, int rx, int ry, int rz, float *padded, void
 
 int dsdf_eval_cubic(const float *padded, int rx, int ry, int rz, const dsdf_params *prm, const float *points,
                     int64_t n, int order, float *v, float *g, float *H, void *stream) {
+    if (n == 0) return DSDF_OK;                     // empty input: nothing to do (pointers may be null)
     if (!padded || !prm || !points || n < 0 || order < 0 || order > 2)
         return fail(DSDF_ERR_INVALID_ARG, "dsdf_eval_cubic: bad argument");
-    if (n == 0) return DSDF_OK;
     GridView G = make_view(padded, rx, ry, rz, *prm);
     hipLaunchKernelGGL(k_eval_cubic, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, G, points, n,
                        order, v, g, H);
@@ -767,8 +767,8 @@ int dsdf_eval_cubic(const float *padded, int rx, int ry, int rz, const dsdf_para
 int dsdf_trace(const float *padded, int rx, int ry, int rz, const dsdf_params *prm, const float *rays_o,
                const float *rays_d, const float *maxt, int64_t n, int differentiable, float *its_t, float *warp_t,
                float *warp_t_d, float *warp_weight, float *warp_weight_d, int32_t *steps, void *stream) {
+    if (n == 0) return DSDF_OK;                     // empty input: nothing to do (pointers may be null)
     if (!padded || !prm || !rays_o || !rays_d || !maxt || n < 0) return fail(DSDF_ERR_INVALID_ARG, "dsdf_trace: bad argument");
-    if (n == 0) return DSDF_OK;
     GridView G = make_view(padded, rx, ry, rz, *prm);
     hipLaunchKernelGGL(k_trace, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, G, *prm, rays_o,
                        rays_d, maxt, n, differentiable, its_t, warp_t, warp_t_d, warp_weight, warp_weight_d, steps);

@@ -213,3 +213,72 @@ def test_gradient_vs_finite_differences_gpu(dsdf, integ):
     eps = 2e-3
     fd = (L(eps) - L(-eps)) / (2 * eps)
     assert abs(ad - fd) < 0.05 * abs(fd) + 0.5, (ad, fd)
+
+
+def test_non_cubic_grid_and_rect_film(dsdf):
+    """Ragged shapes: rx != ry != rz grid, W != H film, spp not a power of two."""
+    torch.manual_seed(7)
+    lin = [torch.linspace(0, 1, n, dtype=torch.float64) for n in (20, 28, 36)]        # (Z,Y,X)
+    z, y, x = torch.meshgrid(*lin, indexing='ij')
+    grid = (torch.sqrt((x - 0.5) ** 2 + (y - 0.45) ** 2 + (z - 0.55) ** 2) - 0.28).float().double()
+    W, H, spp = 20, 12, 3
+    offs = torch.rand((W + 4) * (H + 4) * spp, 2)
+    gi = torch.randn(H, W, 3)
+    origin = O.regular_camera_origins(5)[2]
+    sen = dsdf.Sensor(origin, resx=W, resy=H)
+    g = dsdf.SdfGrid(grid.float().cuda())
+    assert g.shape == (20, 28, 36)
+    for integ in (O.SILHOUETTE, O.SIMPLE_SHADING):
+        ref = O.render(O.Grid3d(grid), O.Camera(origin), W, H, spp, offs.double(), integ)
+        img = dsdf.render_forward(g, sen, spp, offsets=offs.cuda(), integrator=integ)[0]
+        assert rel_l2(img.cpu(), ref) < FWD_TOL
+        gref = O.render_backward(O.Grid3d(grid), O.Camera(origin), W, H, spp, offs.double(), gi.double(), integ)
+        gg = dsdf.render_backward(g, sen, spp, gi.cuda()[None], offsets=offs.cuda(), integrator=integ)
+        assert gg.shape == (20, 28, 36) and rel_l2(gg.cpu(), gref) < GRAD_TOL
+
+
+def test_empty_and_degenerate_inputs(dsdf):
+    g = dsdf.SdfGrid(torch.full((16, 16, 16), 0.5, device='cuda'))           # no surface anywhere
+    sen = dsdf.get_regular_cameras(2, resx=16, resy=16)
+    img = dsdf.render_forward(g, sen, 64, seeds=[1, 2])
+    assert float(img.abs().max()) == 0.0
+    gg = dsdf.render_backward(g, sen, 64, torch.ones(2, 16, 16, 3, device='cuda'), seeds=[3, 4], integrator=O.SIMPLE_SHADING)
+    assert float(gg.abs().max()) == 0.0 and torch.isfinite(gg).all()
+    inside = dsdf.SdfGrid(torch.full((16, 16, 16), -0.5, device='cuda'))     # solid block: every bbox ray hits at entry
+    img = dsdf.render_forward(inside, sen[0], 64, seeds=[5])
+    assert abs(float(img.max()) - 1.0) < 1e-5 and torch.isfinite(img).all()      # value and weight sums differ by fp32 rounding
+    # zero rays / zero points are no-ops
+    e = torch.empty(0, 3, device='cuda')
+    out = dsdf.trace(g, e, e, torch.empty(0, device='cuda'))
+    assert out['its_t'].numel() == 0
+    v, gr, H = dsdf.eval_cubic(g, e, 2)
+    assert v.numel() == 0 and H.shape == (0, 6)
+    # a ray that misses the bounding box / points far outside the grid (clamped texture)
+    o = torch.tensor([[3.0, 3.0, 3.0]], device='cuda'); d = torch.tensor([[1.0, 0.0, 0.0]], device='cuda')
+    t = dsdf.trace(g, o, d, torch.full((1,), 1e4, device='cuda'))
+    assert torch.isinf(t['its_t']).all() and torch.isinf(t['warp_t']).all() and float(t['warp_weight']) == 0.0
+    far = dsdf.eval_cubic(g, torch.tensor([[-5.0, 7.0, 0.5]], device='cuda'), 1)
+    assert abs(float(far[0]) - 0.5) < 1e-6 and float(far[1].abs().max()) == 0.0
+    with pytest.raises(dsdf.DsdfError):                                       # reparam.py:48-50 wavefront limit
+        dsdf.render_forward(g, dsdf.Sensor([2.5, 1, 0.5], resx=4096, resy=4096), 128, seeds=[0])
+    with pytest.raises(dsdf.DsdfError):
+        dsdf.render_forward(g, sen, 4, seeds=[1])                             # one seed for two views
+
+
+def test_large_spp_not_multiple_of_64(dsdf):
+    """Per-lane splat path (spp % 64 != 0) against the wave-uniform path on the same samples."""
+    R, W, H, spp = 64, 40, 40, 96
+    data = O.blob_grid(R, n=10, seed=2).float().cuda()
+    g = dsdf.SdfGrid(data)
+    sen = dsdf.get_regular_cameras(4, resx=W, resy=H)[1]
+    n = (W + 4) * (H + 4)
+    offs = torch.rand(n * spp, 2, device='cuda')
+    a = dsdf.render_forward(g, sen, spp, offsets=offs)                        # 96 spp: per-lane path
+    # the same samples re-ordered as 192 spp (multiple of 64) by duplicating each sample: identical image
+    offs2 = offs.reshape(n, spp, 2).repeat_interleave(2, dim=1).reshape(-1, 2).contiguous()
+    b = dsdf.render_forward(g, sen, 2 * spp, offsets=offs2)                   # 192 spp: wave-uniform + cell cache
+    assert rel_l2(a.cpu(), b.cpu()) < 1e-5
+    gi = torch.randn(1, H, W, 3, device='cuda')
+    ga = dsdf.render_backward(g, sen, spp, gi, offsets=offs)
+    gb = dsdf.render_backward(g, sen, 2 * spp, gi, offsets=offs2)
+    assert rel_l2(ga.cpu(), gb.cpu()) < 1e-4
