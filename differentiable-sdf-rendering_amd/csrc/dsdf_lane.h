@@ -49,7 +49,7 @@ DSDF_HD float shade_value(const GridView &G, const ViewArgs &A, const Lane &L, f
     // simple shading: n = normalize(grad sdf(o + t d)) ; max(n.l, 0)
     float v; V3 g; float H[6];
     eval_cubic<1>(G, fma3(its_t, L.ray.d, L.ray.o), v, g, H);
-    V3 n = g * (1.f / sqrtf(dot(g, g)));
+    V3 n = g * rsqf(dot(g, g));
     return fmaxf(dot(n, light_dir()), 0.f);
 }
 

@@ -16,6 +16,11 @@
 #define DSDF_HD inline
 #endif
 
+// 1 = hardware v_rcp_f32 / v_rsq_f32 (1 ulp) instead of IEEE division sequences in device code
+#ifndef DSDF_FAST_RCP
+#define DSDF_FAST_RCP 1
+#endif
+
 namespace dsdf {
 
 struct V3 { float x, y, z; };
@@ -31,6 +36,13 @@ DSDF_HD V3 fma3(float s, V3 a, V3 b) { return mk(fmaf(s, a.x, b.x), fmaf(s, a.y,
 DSDF_HD float drsign(float x) { return x >= 0.f ? 1.f : -1.f; }   // dr.sign: sign(0)=+1
 // 1/x: the hardware reciprocal (v_rcp_f32, 1 ulp) on the device instead of the ~10-instruction
 // IEEE division sequence; Dr.Jit's dr.rcp is the same approximate-reciprocal-plus-refinement class.
+DSDF_HD float rsqf(float x) {                 // 1/sqrt(x): v_rsq_f32 (1 ulp) on the device
+#if defined(__HIP_DEVICE_COMPILE__) && DSDF_FAST_RCP
+    return __builtin_amdgcn_rsqf(x);
+#else
+    return 1.f / sqrtf(x);
+#endif
+}
 DSDF_HD float rcpf(float x) {
 #if defined(__HIP_DEVICE_COMPILE__) && DSDF_FAST_RCP
     return __builtin_amdgcn_rcpf(x);
@@ -51,9 +63,6 @@ DSDF_HD V3 symmul(const float H[6], V3 a) {
 // per axis reproduce per-tap clamp-to-edge exactly (Dr.Jit wrap mode Clamp).
 // ---------------------------------------------------------------------------
 #define DSDF_APRON 3
-#ifndef DSDF_FAST_RCP
-#define DSDF_FAST_RCP 1
-#endif
 struct GridView {
     const float *p;
     int rx, ry, rz;
@@ -319,7 +328,7 @@ DSDF_HD BoxHit bbox_ray_intersect(float lo, float hi, V3 o, V3 d) {
     BoxHit b;
     bool ok = (d.x != 0.f || o.x > lo || o.x < hi) && (d.y != 0.f || o.y > lo || o.y < hi) &&
               (d.z != 0.f || o.z > lo || o.z < hi);
-    float rx = 1.f / d.x, ry = 1.f / d.y, rz = 1.f / d.z;
+    float rx = rcpf(d.x), ry = rcpf(d.y), rz = rcpf(d.z);
     float t1x = (lo - o.x) * rx, t2x = (hi - o.x) * rx;
     float t1y = (lo - o.y) * ry, t2y = (hi - o.y) * ry;
     float t1z = (lo - o.z) * rz, t2z = (hi - o.z) * rz;
@@ -382,7 +391,7 @@ DSDF_HD float refine_hit(const GridView &G, const dsdf_params &P, V3 o, V3 d, fl
 // A4: SDFBase.ray_intersect_non_diff (shapes.py:290-339)
 template <class Fetch>
 DSDF_HD void trace_plain(const GridView &G, const dsdf_params &P, V3 o, V3 d_in, float ray_maxt, TraceOut &out, Fetch &F) {
-    float inv = 1.f / sqrtf(dot(d_in, d_in));
+    float inv = rsqf(dot(d_in, d_in));
     V3 d = d_in * inv;
     float lo = -P.bbox_delta, hi = 1.f + P.bbox_delta;
     BoxHit b = bbox_ray_intersect(lo, hi, o, d);
@@ -414,7 +423,7 @@ DSDF_HD void trace_plain(const GridView &G, const dsdf_params &P, V3 o, V3 d_in,
 // with the weighted warp-t accumulation and its analytic direction derivative.
 template <class Fetch>
 DSDF_HD void trace_diff(const GridView &G, const dsdf_params &P, V3 o, V3 d_in, float ray_maxt, TraceOut &out, Fetch &F) {
-    float invn = 1.f / sqrtf(dot(d_in, d_in));
+    float invn = rsqf(dot(d_in, d_in));
     V3 d = d_in * invn;                                              // :124
     float lo = -P.bbox_delta, hi = 1.f + P.bbox_delta;
     BoxHit b = bbox_ray_intersect(lo, hi, o, d);
@@ -505,18 +514,20 @@ DSDF_HD void trace_diff(const GridView &G, const dsdf_params &P, V3 o, V3 d, flo
 struct CamRay { V3 o, d, dl; float maxt; };
 
 DSDF_HD CamRay camera_ray(const dsdf_camera &c, const dsdf_params &P, float px, float py, int W, int H) {
-    float aspect = (float)W / (float)H;
-    float sx = px / (float)W, sy = py / (float)H;
-    V3 dl = mk((1.f - 2.f * sx) * c.tan_half_fov, (1.f - 2.f * sy) * c.tan_half_fov / aspect, 1.f);
-    dl = dl * (1.f / sqrtf(dot(dl, dl)));
+    // (W, H are wave-uniform: their reciprocals are scalar work)
+    float inv_w = 1.f / (float)W, inv_h = 1.f / (float)H;
+    float sx = px * inv_w, sy = py * inv_h;
+    V3 dl = mk((1.f - 2.f * sx) * c.tan_half_fov, (1.f - 2.f * sy) * c.tan_half_fov * ((float)H * inv_w), 1.f);
+    dl = dl * rsqf(dot(dl, dl));
     CamRay r;
     r.dl = dl;
     r.d = mk(c.left[0] * dl.x + c.up[0] * dl.y + c.dir[0] * dl.z,
              c.left[1] * dl.x + c.up[1] * dl.y + c.dir[1] * dl.z,
              c.left[2] * dl.x + c.up[2] * dl.y + c.dir[2] * dl.z);
-    float near_t = P.near_clip / dl.z;
+    float inv_z = rcpf(dl.z);
+    float near_t = P.near_clip * inv_z;
     r.o = mk(c.origin[0], c.origin[1], c.origin[2]) + near_t * r.d;
-    r.maxt = P.far_clip / dl.z - near_t;
+    r.maxt = P.far_clip * inv_z - near_t;
     return r;
 }
 
@@ -532,8 +543,9 @@ DSDF_HD Reproj reproject(const dsdf_camera &c, const dsdf_params &P, V3 p, int W
                c.dir[0] * q.x + c.dir[1] * q.y + c.dir[2] * q.z);
     float aspect = (float)W / (float)H;
     float cot = 1.f / c.tan_half_fov;
-    float sx = 0.5f - 0.5f * cot * r.ref.x / r.ref.z;
-    float sy = 0.5f - 0.5f * aspect * cot * r.ref.y / r.ref.z;
+    float inv_z = rcpf(r.ref.z);
+    float sx = 0.5f - 0.5f * cot * r.ref.x * inv_z;
+    float sy = 0.5f - 0.5f * aspect * cot * r.ref.y * inv_z;
     r.inside = r.ref.z >= P.near_clip && r.ref.z <= P.far_clip && sx >= 0.f && sx <= 1.f && sy >= 0.f && sy <= 1.f;
     r.u = sx * (float)W; r.v = sy * (float)H;
     r.dist = sqrtf(dot(r.ref, r.ref));
