@@ -123,7 +123,7 @@ __device__ __forceinline__ void wave_lds_sync() {
 // wave-private LDS brick spanning the bounding box of all taps (ds_add_f32), then
 // flush only the non-zero voxels with one global atomic each.  Falls back to direct
 // global atomics when the bounding box does not fit the brick.
-#define DSDF_BRICK_CAP 4096
+#define DSDF_BRICK_CAP 2048   /* floats per wave-private brick (8 KB): ~20 single-wave blocks per CU */
 __device__ __forceinline__ void wave_scatter(const GridView &G, float *__restrict__ grad, const ScatterReq &rq,
                                              float *brick, int lid) {
     const bool on = rq.on;
@@ -140,9 +140,16 @@ __device__ __forceinline__ void wave_scatter(const GridView &G, float *__restric
         return;
     }
     const int vol = ex * ey * ez;
-    for (int e = lid; e < vol; e += 64) brick[e] = 0.f;
+    // Privatisation: the samples of a wave mostly share one cell, i.e. their ds_add_f32 hit the
+    // same addresses and serialise.  K copies of the brick (copy = lane mod K) cut the conflict
+    // degree K-fold; the flush sums the copies.
+    int K = 1;
+    while (K < 8 && 2 * K * vol <= DSDF_BRICK_CAP) K *= 2;
+    const int tot = K * vol;
+    for (int e = lid; e < tot; e += 64) brick[e] = 0.f;
     wave_lds_sync();
     if (on) {
+        float *mine = brick + (lid & (K - 1)) * vol;
         float wx[4], wy[4], wz[4], dwx[4], dwy[4], dwz[4];
         bspline_w(s.ax, wx); bspline_w(s.ay, wy); bspline_w(s.az, wz);
         bspline_dw(s.ax, dwx); bspline_dw(s.ay, dwy); bspline_dw(s.az, dwz);
@@ -157,7 +164,7 @@ __device__ __forceinline__ void wave_scatter(const GridView &G, float *__restric
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 int yo = iclamp(s.iy + j, 0, G.ry - 1) - miny;
-                float *row = brick + (zo * ey + yo) * ex;
+                float *row = mine + (zo * ey + yo) * ex;
                 float c0 = azv * wy[j] * rq.cv + azd * wy[j] + azv * dwy[j] * gy;
                 float c1 = azv * wy[j] * gx;
 #pragma unroll
@@ -168,6 +175,7 @@ __device__ __forceinline__ void wave_scatter(const GridView &G, float *__restric
     wave_lds_sync();
     for (int e = lid; e < vol; e += 64) {
         float v = brick[e];
+        for (int c = 1; c < K; ++c) v += brick[c * vol + e];
         if (v != 0.f) {
             int x = e % ex, t = e / ex;
             int y = t % ey, z = t / ey;
@@ -446,12 +454,15 @@ __global__ __launch_bounds__(DSDF_BLOCK, DIFF ? DSDF_DIFF_MINWAVES : DSDF_PRIMAL
         int s_val = wave_sum_i32(valid ? 1 : 0);
         int s_need = wave_sum_i32(need ? 1 : 0);
         if (lid == 0) {
-            atomicAdd(stats + 0, (unsigned long long)s_val);
-            atomicAdd(stats + 1, (unsigned long long)s_bbox);
-            atomicAdd(stats + 2, (unsigned long long)s_steps);
-            atomicAdd(stats + 3, (unsigned long long)s_hit);
-            atomicAdd(stats + 4, (unsigned long long)s_ref);
-            atomicAdd(stats + 6, (unsigned long long)s_need);
+            // 64 interleaved copies of the counters (summed by the caller): spreads the atomics
+            // of ~10^7 waves over 64 addresses instead of serialising them on one
+            unsigned long long *st = stats + (size_t)(blockIdx.x & 63u) * 8;
+            atomicAdd(st + 0, (unsigned long long)s_val);
+            atomicAdd(st + 1, (unsigned long long)s_bbox);
+            atomicAdd(st + 2, (unsigned long long)s_steps);
+            atomicAdd(st + 3, (unsigned long long)s_hit);
+            atomicAdd(st + 4, (unsigned long long)s_ref);
+            atomicAdd(st + 6, (unsigned long long)s_need);
         }
     }
 }
@@ -492,21 +503,25 @@ __global__ void k_develop_adjoint(const float *__restrict__ blocks, const float 
     reinterpret_cast<float2 *>(block_adj)[i] = out;
 }
 
-__global__ __launch_bounds__(DSDF_BLOCK) void k_backward(GridView G, dsdf_params P, ViewBatch VB, Queue qall,
-                                                         const float *__restrict__ block_adjs,
-                                                         float *__restrict__ grad_grid, unsigned long long *stats) {
-    __shared__ float bricks[DSDF_BLOCK / 64][DSDF_BRICK_CAP];
+// One 64-lane block per quarter of a render-pass block's slot range: blocks whose quarter is empty
+// exit at once and hold no LDS, so the CU keeps ~20 working waves resident.
+__global__ __launch_bounds__(64) void k_backward(GridView G, dsdf_params P, ViewBatch VB, Queue qall,
+                                                 const float *__restrict__ block_adjs,
+                                                 float *__restrict__ grad_grid, unsigned long long *stats) {
+    __shared__ float brick[DSDF_BRICK_CAP];
     const ViewArgs &A = VB.v[blockIdx.y];
     const float *__restrict__ block_adj = block_adjs + (size_t)blockIdx.y * 2 * A.Wb * A.Hb;
     const Queue q = view_queue(qall, blockIdx.y);
-    const uint32_t count = q.count[blockIdx.x];          // samples queued by render-pass block blockIdx.x
-    if ((threadIdx.x & ~63u) >= count) return;           // whole wave past the end of this block's slots
-    const uint32_t idx = blockIdx.x * DSDF_BLOCK + threadIdx.x;
+    const uint32_t fwd_block = blockIdx.x / (DSDF_BLOCK / 64), quarter = blockIdx.x % (DSDF_BLOCK / 64);
+    const uint32_t count = q.count[fwd_block];             // samples queued by that render-pass block
+    if (quarter * 64 >= count) return;
+    const uint32_t slot = quarter * 64 + threadIdx.x;
+    const uint32_t idx = fwd_block * DSDF_BLOCK + slot;
     const int lid = lane_id();
     bool did = false;
     ScatterReq req[2];
     req[0].on = false; req[1].on = false;
-    if (threadIdx.x < count) {
+    if (slot < count) {
         uint32_t lane = q.lane[idx];
         const float *r = q.rec + idx;
         size_t c = q.cap;
@@ -519,12 +534,11 @@ __global__ __launch_bounds__(DSDF_BLOCK) void k_backward(GridView G, dsdf_params
         Lane L = lane_setup(A, P, lane);
         did = lane_backward(G, P, A, L, tr, block_adj, req);
     }
-    float *brick = bricks[threadIdx.x / 64];
     wave_scatter(G, grad_grid, req[0], brick, lid);
     if (A.integrator != DSDF_SILHOUETTE) wave_scatter(G, grad_grid, req[1], brick, lid);
     if (stats) {
         int s = wave_sum_i32(did ? 1 : 0);
-        if (lid == 0 && s) atomicAdd(stats + 5, (unsigned long long)s);
+        if (lid == 0 && s) atomicAdd(stats + (size_t)(blockIdx.x & 63u) * 8 + 5, (unsigned long long)s);
     }
 }
 
@@ -857,7 +871,7 @@ int dsdf_render_backward(const float *padded, int rx, int ry, int rz, const dsdf
         hipLaunchKernelGGL(k_develop_adjoint, dim3((unsigned)((Wb * Hb + 255) / 256), nv), dim3(256), 0, st, ws.block,
                            grad_image + (size_t)v0 * width * height * 3, width, height, ws.block_adj);
         if ((rc = check_launch("k_develop_adjoint"))) return rc;
-        hipLaunchKernelGGL(k_backward, dim3(ws.nblk, nv), dim3(DSDF_BLOCK), 0, st, G, *prm, VB, q, ws.block_adj, grad_grid,
+        hipLaunchKernelGGL(k_backward, dim3(ws.nblk * (DSDF_BLOCK / 64), nv), dim3(64), 0, st, G, *prm, VB, q, ws.block_adj, grad_grid,
                            (unsigned long long *)stats);
         if ((rc = check_launch("k_backward"))) return rc;
     }

@@ -205,11 +205,11 @@ def redistance(phi):
 
 
 def new_stats(device):
-    return torch.zeros(8, dtype=torch.int64, device=device)
+    return torch.zeros(64, 8, dtype=torch.int64, device=device)
 
 
 def stats_dict(stats):
-    return dict(zip(STAT_NAMES, (int(x) for x in stats.cpu())))
+    return dict(zip(STAT_NAMES, (int(x) for x in stats.sum(0).cpu())))
 
 
 class _RenderOp(torch.autograd.Function):

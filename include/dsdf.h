@@ -129,8 +129,9 @@ size_t dsdf_render_workspace_size(int width, int height, int spp, int n_views);
  *               with seed = seeds[view]
  *   seeds     : n_views uint32 (HOST memory; ignored when offsets != NULL)
  *   image_out : n_views x H x W x 3
- *   stats     : optional device int64[8] accumulators {lanes, bbox_lanes, steps,
- *               hits, refine_steps, warp_active, queue_len, 0} (atomically added)
+ *   stats     : optional device int64[64][8] accumulators -- 64 interleaved copies (to
+ *               spread the atomics; sum over the first axis) of {lanes, bbox_lanes,
+ *               steps, hits, refine_steps, warp_active, queue_len, 0}
  */
 int dsdf_render_forward(const float *padded, int rx, int ry, int rz, const dsdf_params *prm,
                         const dsdf_camera *cams, int n_views, int width, int height, int spp,
