@@ -24,9 +24,6 @@
 using namespace dsdf;
 
 #define DSDF_BLOCK 256
-#ifndef DSDF_EPI_VARIANT
-#define DSDF_EPI_VARIANT 1
-#endif
 #define DSDF_TSTRIDE 68   /* 64 + 4: rows 16-byte aligned, ds_read_b128 conflict-free across lanes */
 #define DSDF_TROWS 13     /* film transpose processes the 25 window slots in two chunks of <= 13 rows */
 #define DSDF_WAVE_LDS 1104 /* floats per wave: max(16 cache slots * 68 + 16 slot bases, 13 * 68) */
@@ -257,28 +254,6 @@ struct WaveCellCache {
     }
 };
 
-// Transposed butterfly reduction: every lane brings 64 values, lane l leaves with
-// the wave-wide sum of slot l.  63 cross-lane exchanges instead of 64 x 6.
-template <int HALF>
-__device__ __forceinline__ void wave_transpose_step(float (&v)[64], int lane) {
-    const bool upper = (lane & HALF) != 0;
-#pragma unroll
-    for (int k = 0; k < HALF; ++k) {
-        float send = upper ? v[k] : v[k + HALF];
-        float keep = upper ? v[k + HALF] : v[k];
-        v[k] = keep + __shfl_xor(send, HALF);
-    }
-}
-__device__ __forceinline__ float wave_transpose_reduce(float (&v)[64], int lane) {
-    wave_transpose_step<32>(v, lane);
-    wave_transpose_step<16>(v, lane);
-    wave_transpose_step<8>(v, lane);
-    wave_transpose_step<4>(v, lane);
-    wave_transpose_step<2>(v, lane);
-    wave_transpose_step<1>(v, lane);
-    return v[0];
-}
-
 // Queue of samples that need the backward sweep.  Every render-pass block owns the slot
 // range [block*DSDF_BLOCK, (block+1)*DSDF_BLOCK) and compacts its samples to the front of
 // it (block-level ballot/mbcnt prefix), so queue order stays pixel order: a backward block
@@ -286,7 +261,7 @@ __device__ __forceinline__ float wave_transpose_reduce(float (&v)[64], int lane)
 struct Queue {
     uint32_t *count;  // per render-pass block
     uint32_t *lane;
-    float *rec;       // 9 rows (SoA, stride = cap): its_t, warp_t, wtd.xyz, ww, wwd.xyz
+    float *rec;       // 9 rows (SoA, stride = cap), indexed by sample: its_t, warp_t, wtd.xyz, ww, wwd.xyz
     uint32_t cap;     // slots per view (= nblk * DSDF_BLOCK)
     uint32_t nblk;    // render-pass blocks per view
 };
@@ -302,6 +277,60 @@ __device__ __forceinline__ Queue view_queue(Queue q, uint32_t view) {
     q.lane += (size_t)view * q.cap;
     q.rec += (size_t)view * q.cap * 9;
     return q;
+}
+
+// Film splat of one wave whose 64 samples belong to ONE pixel (px,py): their contributions fall into
+// the 5x5 block-pixel window around it; the 25 (+25 weight) partial sums are reduced across the wave
+// through a wave-private LDS transpose (lane l writes column l, lane k sums row k with 16 conflict-free
+// ds_read_b128; two chunks of <= 13 rows) and leave as one atomic per window pixel and channel.
+__device__ __forceinline__ void film_splat_wave(float *__restrict__ block, const ViewArgs &A, int px, int py,
+                                                float u, float v, float val, float *T, int lid) {
+    float pfx = u + (DSDF_BORDER - 0.5f), pfy = v + (DSDF_BORDER - 0.5f);
+    float fx[5], fy[5];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        fx[i] = gauss_f((float)(px - 2 + i) - pfx);
+        fy[i] = gauss_f((float)(py - 2 + i) - pfy);
+    }
+    float f[25];
+#pragma unroll
+    for (int j = 0; j < 5; ++j)
+#pragma unroll
+        for (int i = 0; i < 5; ++i) f[j * 5 + i] = fx[i] * fy[j];
+    const bool any_val = __ballot(val != 0.f) != 0;     // pixels nobody hits skip the value channel
+#pragma unroll
+    for (int ch = 0; ch < 2; ++ch) {
+        if (ch == 0 && !any_val) continue;
+#pragma unroll
+        for (int k0 = 0; k0 < 25; k0 += DSDF_TROWS) {
+            const int nk = (25 - k0) < DSDF_TROWS ? (25 - k0) : DSDF_TROWS;
+#pragma unroll
+            for (int k = 0; k < DSDF_TROWS; ++k)
+                if (k < nk) T[k * DSDF_TSTRIDE + lid] = ch == 0 ? f[k0 + k] * val : f[k0 + k];
+            wave_lds_sync();
+            float total = 0.f;
+            const int slot = k0 + lid;                   // window slot summed by this lane
+            const int j5 = slot / 5, i5 = slot - 5 * j5;
+            const int qx = px - 2 + i5, qy = py - 2 + j5;
+            const bool own = lid < nk && qx >= 0 && qx < A.Wb && qy >= 0 && qy < A.Hb;
+            if (lid < nk) {
+                const float4 *row = reinterpret_cast<const float4 *>(T + lid * DSDF_TSTRIDE);
+                float4 a0 = row[0], a1 = row[1], a2 = row[2], a3 = row[3];
+#pragma unroll
+                for (int r = 4; r < 16; r += 4) {
+                    float4 b0 = row[r], b1 = row[r + 1], b2 = row[r + 2], b3 = row[r + 3];
+                    a0.x += b0.x; a0.y += b0.y; a0.z += b0.z; a0.w += b0.w;
+                    a1.x += b1.x; a1.y += b1.y; a1.z += b1.z; a1.w += b1.w;
+                    a2.x += b2.x; a2.y += b2.y; a2.z += b2.z; a2.w += b2.w;
+                    a3.x += b3.x; a3.y += b3.y; a3.z += b3.z; a3.w += b3.w;
+                }
+                total = ((a0.x + a0.y) + (a0.z + a0.w)) + ((a1.x + a1.y) + (a1.z + a1.w)) +
+                        (((a2.x + a2.y) + (a2.z + a2.w)) + ((a3.x + a3.y) + (a3.z + a3.w)));
+            }
+            wave_lds_sync();
+            if (own && total != 0.f) atomicAdd(block + 2 * ((size_t)qy * A.Wb + qx) + ch, total);
+        }
+    }
 }
 
 // ------------------------------------------------------------------ render pass
@@ -339,79 +368,7 @@ __global__ __launch_bounds__(DSDF_BLOCK, DIFF ? DSDF_DIFF_MINWAVES : DSDF_PRIMAL
     Reproj rp = reproject(A.cam, P, L.ray.o + L.ray.d, A.W, A.H);
 
     if (wave_uniform) {
-        // all 64 lanes share (px,py): reduce the 5x5 window x {value, weight}
-        float pfx = rp.u + (DSDF_BORDER - 0.5f), pfy = rp.v + (DSDF_BORDER - 0.5f);
-        float fx[5], fy[5];
-#pragma unroll
-        for (int i = 0; i < 5; ++i) {
-            fx[i] = gauss_f((float)(L.px - 2 + i) - pfx);
-            fy[i] = gauss_f((float)(L.py - 2 + i) - pfy);
-        }
-#if DSDF_EPI_VARIANT == 1
-        // Wave-wide sum of the 25 window weights (x value, x 1) through a wave-private LDS
-        // transpose: lane l writes column l, lane k < 25 sums row k (16 ds_read_b128).
-        float *T = wave_lds[threadIdx.x >> 6];
-        float f[25];
-#pragma unroll
-        for (int j = 0; j < 5; ++j)
-#pragma unroll
-            for (int i = 0; i < 5; ++i) f[j * 5 + i] = fx[i] * fy[j];
-        const bool any_val = __ballot(val != 0.f) != 0;     // pixels nobody hits skip the value channel
-#pragma unroll
-        for (int ch = 0; ch < 2; ++ch) {
-            if (ch == 0 && !any_val) continue;
-#pragma unroll
-            for (int k0 = 0; k0 < 25; k0 += DSDF_TROWS) {
-                const int nk = (25 - k0) < DSDF_TROWS ? (25 - k0) : DSDF_TROWS;
-#pragma unroll
-                for (int k = 0; k < DSDF_TROWS; ++k)
-                    if (k < nk) T[k * DSDF_TSTRIDE + lid] = ch == 0 ? f[k0 + k] * val : f[k0 + k];
-                wave_lds_sync();
-                float total = 0.f;
-                const int slot = k0 + lid;                   // window slot summed by this lane
-                const int j5 = slot / 5, i5 = slot - 5 * j5;
-                const int qx = L.px - 2 + i5, qy = L.py - 2 + j5;
-                const bool own = lid < nk && qx >= 0 && qx < A.Wb && qy >= 0 && qy < A.Hb;
-                if (lid < nk) {
-                    const float4 *row = reinterpret_cast<const float4 *>(T + lid * DSDF_TSTRIDE);
-                    float4 a0 = row[0], a1 = row[1], a2 = row[2], a3 = row[3];
-#pragma unroll
-                    for (int r = 4; r < 16; r += 4) {
-                        float4 b0 = row[r], b1 = row[r + 1], b2 = row[r + 2], b3 = row[r + 3];
-                        a0.x += b0.x; a0.y += b0.y; a0.z += b0.z; a0.w += b0.w;
-                        a1.x += b1.x; a1.y += b1.y; a1.z += b1.z; a1.w += b1.w;
-                        a2.x += b2.x; a2.y += b2.y; a2.z += b2.z; a2.w += b2.w;
-                        a3.x += b3.x; a3.y += b3.y; a3.z += b3.z; a3.w += b3.w;
-                    }
-                    total = ((a0.x + a0.y) + (a0.z + a0.w)) + ((a1.x + a1.y) + (a1.z + a1.w)) +
-                            (((a2.x + a2.y) + (a2.z + a2.w)) + ((a3.x + a3.y) + (a3.z + a3.w)));
-                }
-                wave_lds_sync();
-                if (own && total != 0.f) atomicAdd(block + 2 * ((size_t)qy * A.Wb + qx) + ch, total);
-            }
-        }
-#else
-        float v[64];
-#pragma unroll
-        for (int j = 0; j < 5; ++j)
-#pragma unroll
-            for (int i = 0; i < 5; ++i) {
-                float f = fx[i] * fy[j];
-                v[j * 5 + i] = f * val;
-                v[25 + j * 5 + i] = f;
-            }
-#pragma unroll
-        for (int k = 50; k < 64; ++k) v[k] = 0.f;
-        float total = wave_transpose_reduce(v, lid);
-        if (lid < 50) {
-            int ch = lid >= 25 ? 1 : 0;
-            int s = lid - 25 * ch;
-            int j = s / 5, i = s - 5 * j;
-            int qx = L.px - 2 + i, qy = L.py - 2 + j;
-            if (qx >= 0 && qx < A.Wb && qy >= 0 && qy < A.Hb && total != 0.f)
-                atomicAdd(block + 2 * ((size_t)qy * A.Wb + qx) + ch, total);
-        }
-#endif
+        film_splat_wave(block, A, L.px, L.py, rp.u, rp.v, val, wave_lds[threadIdx.x >> 6], lid);
     } else if (valid) {
         splat_lane(block, A.Wb, A.Hb, rp.u, rp.v, val, AtomicAdd());
     }
@@ -438,7 +395,7 @@ __global__ __launch_bounds__(DSDF_BLOCK, DIFF ? DSDF_DIFF_MINWAVES : DSDF_PRIMAL
         if (need) {
             uint32_t idx = blockIdx.x * DSDF_BLOCK + base + mask_prefix(m);
             q.lane[idx] = lane;
-            float *r = q.rec + idx;
+            float *r = q.rec + lane;                       // records are dense by sample index
             size_t c = q.cap;
             r[0] = tr.its_t; r[c] = tr.warp_t;
             r[2 * c] = tr.warp_t_d.x; r[3 * c] = tr.warp_t_d.y; r[4 * c] = tr.warp_t_d.z;
@@ -523,7 +480,7 @@ __global__ __launch_bounds__(64) void k_backward(GridView G, dsdf_params P, View
     req[0].on = false; req[1].on = false;
     if (slot < count) {
         uint32_t lane = q.lane[idx];
-        const float *r = q.rec + idx;
+        const float *r = q.rec + lane;
         size_t c = q.cap;
         TraceOut tr;
         tr.its_t = r[0]; tr.warp_t = r[c];

@@ -99,3 +99,4 @@ def test_fp32_noise_floor():
                             case['grad_image'], O.SILHOUETTE).numpy()
     e = rel_l2(g32, g64)
     assert 1e-5 < e < GRAD_TOL
+
