@@ -118,7 +118,8 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     dist = None
-    if world > 1:
+    # (BENCH_FORCE_DIST=1 exercises the RCCL path with a single rank, e.g. under `torchrun --nproc-per-node 1`)
+    if world > 1 or os.environ.get('BENCH_FORCE_DIST') == '1':
         import torch.distributed as dist
         dist.init_process_group('nccl', device_id=dev)
 

@@ -460,8 +460,8 @@ __global__ void k_develop_adjoint(const float *__restrict__ blocks, const float 
     reinterpret_cast<float2 *>(block_adj)[i] = out;
 }
 
-// One 64-lane block per quarter of a render-pass block's slot range: blocks whose quarter is empty
-// exit at once and hold no LDS, so the CU keeps ~20 working waves resident.
+// One single-wave block per render-pass block: it walks that block's queued samples 64 at a time
+// (usually one round: ~12 % of 256 samples), holds one 8 KB brick, so a CU keeps ~20 working waves.
 __global__ __launch_bounds__(64) void k_backward(GridView G, dsdf_params P, ViewBatch VB, Queue qall,
                                                  const float *__restrict__ block_adjs,
                                                  float *__restrict__ grad_grid, unsigned long long *stats) {
@@ -469,32 +469,31 @@ __global__ __launch_bounds__(64) void k_backward(GridView G, dsdf_params P, View
     const ViewArgs &A = VB.v[blockIdx.y];
     const float *__restrict__ block_adj = block_adjs + (size_t)blockIdx.y * 2 * A.Wb * A.Hb;
     const Queue q = view_queue(qall, blockIdx.y);
-    const uint32_t fwd_block = blockIdx.x / (DSDF_BLOCK / 64), quarter = blockIdx.x % (DSDF_BLOCK / 64);
-    const uint32_t count = q.count[fwd_block];             // samples queued by that render-pass block
-    if (quarter * 64 >= count) return;
-    const uint32_t slot = quarter * 64 + threadIdx.x;
-    const uint32_t idx = fwd_block * DSDF_BLOCK + slot;
+    const uint32_t count = q.count[blockIdx.x];            // samples queued by render-pass block blockIdx.x
     const int lid = lane_id();
-    bool did = false;
-    ScatterReq req[2];
-    req[0].on = false; req[1].on = false;
-    if (slot < count) {
-        uint32_t lane = q.lane[idx];
-        const float *r = q.rec + lane;
-        size_t c = q.cap;
-        TraceOut tr;
-        tr.its_t = r[0]; tr.warp_t = r[c];
-        tr.warp_t_d = mk(r[2 * c], r[3 * c], r[4 * c]);
-        tr.warp_weight = r[5 * c];
-        tr.warp_weight_d = mk(r[6 * c], r[7 * c], r[8 * c]);
-        tr.steps = 0; tr.refine_steps = 0; tr.weight_sum = 0.f;
-        Lane L = lane_setup(A, P, lane);
-        did = lane_backward(G, P, A, L, tr, block_adj, req);
+    int n_did = 0;
+    for (uint32_t s0 = 0; s0 < count; s0 += 64) {
+        const uint32_t slot = s0 + threadIdx.x;
+        ScatterReq req[2];
+        req[0].on = false; req[1].on = false;
+        if (slot < count) {
+            const uint32_t lane = q.lane[blockIdx.x * DSDF_BLOCK + slot];
+            const float *r = q.rec + lane;
+            const size_t c = q.cap;
+            TraceOut tr;
+            tr.its_t = r[0]; tr.warp_t = r[c];
+            tr.warp_t_d = mk(r[2 * c], r[3 * c], r[4 * c]);
+            tr.warp_weight = r[5 * c];
+            tr.warp_weight_d = mk(r[6 * c], r[7 * c], r[8 * c]);
+            tr.steps = 0; tr.refine_steps = 0; tr.weight_sum = 0.f;
+            Lane L = lane_setup(A, P, lane);
+            n_did += lane_backward(G, P, A, L, tr, block_adj, req) ? 1 : 0;
+        }
+        wave_scatter(G, grad_grid, req[0], brick, lid);
+        if (A.integrator != DSDF_SILHOUETTE) wave_scatter(G, grad_grid, req[1], brick, lid);
     }
-    wave_scatter(G, grad_grid, req[0], brick, lid);
-    if (A.integrator != DSDF_SILHOUETTE) wave_scatter(G, grad_grid, req[1], brick, lid);
-    if (stats) {
-        int s = wave_sum_i32(did ? 1 : 0);
+    if (stats && count) {
+        int s = wave_sum_i32(n_did);
         if (lid == 0 && s) atomicAdd(stats + (size_t)(blockIdx.x & 63u) * 8 + 5, (unsigned long long)s);
     }
 }
@@ -828,7 +827,7 @@ int dsdf_render_backward(const float *padded, int rx, int ry, int rz, const dsdf
         hipLaunchKernelGGL(k_develop_adjoint, dim3((unsigned)((Wb * Hb + 255) / 256), nv), dim3(256), 0, st, ws.block,
                            grad_image + (size_t)v0 * width * height * 3, width, height, ws.block_adj);
         if ((rc = check_launch("k_develop_adjoint"))) return rc;
-        hipLaunchKernelGGL(k_backward, dim3(ws.nblk * (DSDF_BLOCK / 64), nv), dim3(64), 0, st, G, *prm, VB, q, ws.block_adj, grad_grid,
+        hipLaunchKernelGGL(k_backward, dim3(ws.nblk, nv), dim3(64), 0, st, G, *prm, VB, q, ws.block_adj, grad_grid,
                            (unsigned long long *)stats);
         if ((rc = check_launch("k_backward"))) return rc;
     }
@@ -861,8 +860,9 @@ int dsdf_redistance(const float *phi, int rx, int ry, int rz, float *out, void *
         return fail(DSDF_ERR_LAUNCH, "hipMemsetAsync(tile map) failed");
     hipLaunchKernelGGL(k_redist_init, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, phi, rx, ry, rz, u, frozen, flags);
     if ((rc = check_launch("k_redist_init"))) return rc;
-    // information crosses at least one tile per launch; 2x margin, converged launches return at once
-    int max_iter = 2 * (int)(tiles.x + tiles.y + tiles.z) + 8;
+    // information crosses at least one tile per launch (Manhattan tile distance <= sum of the tile
+    // counts); 25 % margin, converged launches return at once
+    int max_iter = (int)(tiles.x + tiles.y + tiles.z) + (int)(tiles.x + tiles.y + tiles.z) / 4 + 8;
     for (int it = 0; it < max_iter; ++it) {
         hipLaunchKernelGGL(k_redist_iter, tiles, dim3(512), 0, st, u, frozen, rx, ry, rz, flags, tmap, it);
         if ((rc = check_launch("k_redist_iter"))) return rc;

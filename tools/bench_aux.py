@@ -41,4 +41,37 @@ for name, sp, sg, integ in (('sil_256_64', 256, 64, 0), ('shade_256_64', 256, 64
     p = timed(lambda: dsdf.render_forward(grid, sens, sp, seeds=list(range(12)), integrator=integ), 3)
     b = timed(lambda: dsdf.render_backward(grid, sens, sg, gi, grad_grid=gg, seeds=list(range(12)), integrator=integ), 3)
     out[name] = {'primal_ms': p, 'grad_ms': b, 'renders_per_s': 1e3 / (p + b)}
+# one optimisation iteration of a `no-tex-12-hqq`-shaped state at its final resolution (256^3, 512^2, 6 of 12 views)
+sys.path.insert(0, os.path.join(ROOT, 'differentiable-sdf-rendering_amd', 'python'))
+import losses, regularizations, redistancing
+from shapes import Grid3d
+from integrators.reparam import Scene, create_integrator, render, traverse
+from constants import SDF_DEFAULT_KEY
+from variables import Adam
+integ = create_integrator('sdf_silhouette_reparam', {'sdf': Grid3d(data.clone())})
+import configs
+integ.warp_field = configs.get_config('warp').get_warpfield(integ.sdf)
+scene = Scene(sens, integ)
+params = traverse(scene); params.keep([SDF_DEFAULT_KEY])
+opt = Adam(lr=0.005, params=params)
+params.update(opt)
+refs = dsdf.render_forward(dsdf.SdfGrid(synth_grid(256, dev, seed=1)), sens, 64, seeds=list(range(12)))
+
+
+def iteration(i=[0]):
+    idx = [(j * 2 + i[0] % 2) % 12 for j in range(6)]
+    img = render(scene, params, [sens[k] for k in idx], seed=i[0], spp=256, seed_grad=i[0] + 13, spp_grad=64)
+    loss = sum(losses.multiscale_l1(img[j], refs[k]) / 6 for j, k in enumerate(idx))
+    loss.backward()
+    (1e-5 * regularizations.eval_discrete_laplacian_reg(opt[SDF_DEFAULT_KEY])).backward()
+    g = opt[SDF_DEFAULT_KEY].grad
+    opt[SDF_DEFAULT_KEY].grad = torch.nan_to_num(g).clamp_(-0.1, 0.1)
+    opt.step()
+    with torch.no_grad():
+        opt[SDF_DEFAULT_KEY] = redistancing.redistance(opt[SDF_DEFAULT_KEY].detach().contiguous())
+    params.update(opt)
+    i[0] += 1
+
+
+out['optimize_iteration_256cubed_6views_512sq_ms'] = timed(iteration, 4)
 print(json.dumps(out, indent=1))
