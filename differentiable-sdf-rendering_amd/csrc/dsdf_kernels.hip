@@ -333,6 +333,68 @@ __device__ __forceinline__ void film_splat_wave(float *__restrict__ block, const
     }
 }
 
+// ------------------------------------------------------------------ empty-space proof
+// Cubic B-spline weights are >= 0 and sum to 1, so every lookup is bounded below by the minimum of its
+// 64 taps.  `coarse[b]` = min of the grid over coarse block b (8^3 voxels) dilated by one block in every
+// direction; if it exceeds a threshold for every block the CENTRE ray of a film pixel passes through, no
+// point visited by ANY sample ray of that pixel (they deviate by less than the dilation margin, checked on
+// the host) can have an SDF value below the threshold.  Such pixels skip tracing with EXACTLY the result
+// tracing would give: primal -- every sample misses (threshold = trace_eps); gradient pass -- misses AND a
+// zero boundary weight, because w > 0 needs |sdf(x_warp)| < edge_eps * t (threshold = edge_eps * t_exit).
+__global__ void k_coarse_min(const float *__restrict__ data, int rx, int ry, int rz, float *__restrict__ c0, int cx, int cy, int cz) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= cx * cy * cz) return;
+    int bx = i % cx, by = (i / cx) % cy, bz = i / (cx * cy);
+    float m = INFINITY;
+    for (int z = bz * DSDF_COARSE; z < min(rz, (bz + 1) * DSDF_COARSE); ++z)
+        for (int y = by * DSDF_COARSE; y < min(ry, (by + 1) * DSDF_COARSE); ++y)
+            for (int x = bx * DSDF_COARSE; x < min(rx, (bx + 1) * DSDF_COARSE); ++x)
+                m = fminf(m, data[((size_t)z * ry + y) * rx + x]);
+    c0[i] = m;
+}
+
+__global__ void k_coarse_dilate(const float *__restrict__ c0, float *__restrict__ c, int cx, int cy, int cz) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= cx * cy * cz) return;
+    int bx = i % cx, by = (i / cx) % cy, bz = i / (cx * cy);
+    float m = INFINITY;
+    for (int z = max(bz - 1, 0); z <= min(bz + 1, cz - 1); ++z)
+        for (int y = max(by - 1, 0); y <= min(by + 1, cy - 1); ++y)
+            for (int x = max(bx - 1, 0); x <= min(bx + 1, cx - 1); ++x)
+                m = fminf(m, c0[(z * cy + y) * cx + x]);
+    c[i] = m;
+}
+
+// flags[view][Hb*Wb]: bit 0 = primal pass may skip the pixel, bit 1 = gradient pass may skip it.
+__global__ void k_pixel_skip(GridView G, dsdf_params P, ViewBatch VB, unsigned char *__restrict__ flags, float step) {
+    const ViewArgs &A = VB.v[blockIdx.y];
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= A.Wb * A.Hb) return;
+    int py = i / A.Wb, px = i - py * A.Wb;
+    CamRay r = camera_ray(A.cam, P, (float)(px - DSDF_BORDER) + 0.5f, (float)(py - DSDF_BORDER) + 0.5f, A.W, A.H);
+    V3 d = r.d * rsqf(dot(r.d, r.d));
+    // a slightly larger box than the traced one: sample rays may enter where the centre ray does not
+    const float grow = 0.02f;
+    BoxHit b = bbox_ray_intersect(-P.bbox_delta - grow, 1.f + P.bbox_delta + grow, r.o, d);
+    unsigned char f = 0;
+    if (b.hit && b.maxt > 0.f) {
+        float t0 = fmaxf(b.mint, 0.f), t1 = b.maxt;
+        float m = INFINITY;
+        for (float t = t0; t < t1 + step; t += step) {
+            V3 x = fma3(fminf(t, t1), d, r.o);
+            int bx = iclamp((int)floorf((x.x - G.tx) * (float)G.rx) / DSDF_COARSE, 0, G.cx - 1);
+            int by = iclamp((int)floorf((x.y - G.ty) * (float)G.ry) / DSDF_COARSE, 0, G.cy - 1);
+            int bz = iclamp((int)floorf((x.z - G.tz) * (float)G.rz) / DSDF_COARSE, 0, G.cz - 1);
+            m = fminf(m, G.coarse[(bz * G.cy + by) * G.cx + bx]);
+        }
+        float thr_p = 2.f * P.trace_eps * fmaxf(t1, 1.f) + 1e-5f;
+        float thr_g = (P.weight_strategy == 6 ? P.edge_eps * (t1 + 0.1f) : P.edge_eps) * 1.05f + 1e-4f;
+        if (m > thr_p) f |= 1;
+        if (m > fmaxf(thr_p, thr_g)) f |= 2;
+    }
+    flags[(size_t)blockIdx.y * A.Wb * A.Hb + i] = f;
+}
+
 // ------------------------------------------------------------------ render pass
 #ifndef DSDF_DIFF_CACHE
 #define DSDF_DIFF_CACHE 0   /* the gradient pass is VALU-bound: per-lane fetch measured faster */
@@ -344,7 +406,7 @@ template <bool DIFF, bool CACHE>
 __global__ __launch_bounds__(DSDF_BLOCK, DIFF ? DSDF_DIFF_MINWAVES : DSDF_PRIMAL_MINWAVES) void k_render_pass(GridView G, dsdf_params P, ViewBatch VB,
                                                             float *__restrict__ blocks, Queue qall,
                                                             unsigned long long *stats, uint32_t n_lanes,
-                                                            int wave_uniform) {
+                                                            int wave_uniform, const unsigned char *__restrict__ skip) {
     const ViewArgs &A = VB.v[blockIdx.y];
     float *__restrict__ block = blocks + (size_t)blockIdx.y * 2 * A.Wb * A.Hb;
     const Queue q = view_queue(qall, blockIdx.y);
@@ -356,13 +418,24 @@ __global__ __launch_bounds__(DSDF_BLOCK, DIFF ? DSDF_DIFF_MINWAVES : DSDF_PRIMAL
     // wave-private LDS scratch: cell cache during tracing, film transpose afterwards
     __shared__ __attribute__((aligned(16))) float wave_lds[DSDF_BLOCK / 64][DSDF_WAVE_LDS];
     TraceOut tr;
+    // empty-space proof for this pixel (wave-uniform when the wave sits in one pixel): the result of
+    // tracing is known -- a miss with no warp -- so the loop is skipped
+    bool skip_trace = false;
+    if (skip) skip_trace = (skip[(size_t)blockIdx.y * A.Wb * A.Hb + (size_t)L.py * A.Wb + L.px] & (DIFF ? 2 : 1)) != 0;
     if (CACHE) {
-        WaveCellCache F; F.taps = wave_lds[threadIdx.x >> 6]; F.lid = lid;
-        if (DIFF) trace_diff(G, P, L.ray.o, L.ray.d, L.ray.maxt, tr, F);
-        else trace_plain(G, P, L.ray.o, L.ray.d, L.ray.maxt, tr, F);
-    } else {
+        if (!skip_trace) {                                  // wave-uniform branch (CACHE implies one pixel per wave)
+            WaveCellCache F; F.taps = wave_lds[threadIdx.x >> 6]; F.lid = lid;
+            if (DIFF) trace_diff(G, P, L.ray.o, L.ray.d, L.ray.maxt, tr, F);
+            else trace_plain(G, P, L.ray.o, L.ray.d, L.ray.maxt, tr, F);
+        }
+    } else if (!skip_trace) {
         if (DIFF) trace_diff(G, P, L.ray.o, L.ray.d, L.ray.maxt, tr);
         else trace_plain(G, P, L.ray.o, L.ray.d, L.ray.maxt, tr);
+    }
+    if (skip_trace) {
+        tr.its_t = INFINITY; tr.warp_t = INFINITY; tr.warp_weight = 0.f; tr.weight_sum = 0.f;
+        tr.warp_t_d = mk(0.f, 0.f, 0.f); tr.warp_weight_d = mk(0.f, 0.f, 0.f);
+        tr.steps = 0; tr.refine_steps = 0;
     }
     float val = shade_value(G, A, L, tr.its_t);
     Reproj rp = reproject(A.cam, P, L.ray.o + L.ray.d, A.W, A.H);
@@ -645,6 +718,7 @@ struct Workspace {
     float *block, *block_adj;
     uint32_t *count, *qlane;
     float *qrec;
+    unsigned char *skip;
     uint32_t cap, nblk;
     size_t bytes;
 };
@@ -663,6 +737,7 @@ static Workspace carve(void *base, int W, int H, int spp, int nv) {
     ws.count = (uint32_t *)(p + off); off += align_up(nv * nblk * sizeof(uint32_t), 256);
     ws.qlane = (uint32_t *)(p + off); off += align_up(nv * cap * sizeof(uint32_t), 256);
     ws.qrec = (float *)(p + off); off += align_up(nv * cap * 9 * sizeof(float), 256);
+    ws.skip = (unsigned char *)(p + off); off += align_up(nv * Wb * Hb, 256);
     ws.cap = (uint32_t)cap;
     ws.nblk = (uint32_t)nblk;
     ws.bytes = off;
@@ -682,6 +757,35 @@ static ViewArgs make_view_args(const dsdf_camera &cam, int W, int H, int spp, co
     A.cam = cam; A.W = W; A.H = H; A.Wb = W + 2 * DSDF_BORDER; A.Hb = H + 2 * DSDF_BORDER; A.spp = spp;
     A.integrator = integrator; A.flags = flags; A.seed = seed; A.offsets = offsets;
     return A;
+}
+
+static size_t padded_floats(int rx, int ry, int rz) {
+    return (size_t)(rx + 2 * DSDF_APRON) * (ry + 2 * DSDF_APRON) * (rz + 2 * DSDF_APRON);
+}
+
+// GridView over the library's grid buffer: [padded grid | block minima | dilated block minima]
+static GridView device_view(const float *padded, int rx, int ry, int rz, const dsdf_params &prm) {
+    GridView G = make_view(padded, rx, ry, rz, prm);
+    G.coarse = padded + padded_floats(rx, ry, rz) + (size_t)G.cx * G.cy * G.cz;
+    return G;
+}
+
+// March step (world units) of the per-pixel empty-space proof, or 0 when the sample rays of a pixel may
+// stray further from the pixel's centre ray than the dilation margin of the coarse min-grid covers:
+// lateral deviation <= t_far * (0.7072 px * pixel size); lookup support 2.5 voxels; half a step.
+static float skip_step(const dsdf_camera *cams, int nv, int W, int rx, int ry, int rz) {
+    int rmax = rx > ry ? (rx > rz ? rx : rz) : (ry > rz ? ry : rz);
+    float worst = 0.f;
+    for (int i = 0; i < nv; ++i) {
+        float dx = cams[i].origin[0] - 0.5f, dy = cams[i].origin[1] - 0.5f, dz = cams[i].origin[2] - 0.5f;
+        float t_far = sqrtf(dx * dx + dy * dy + dz * dz) + 1.0f;
+        float rho = t_far * 0.7072f * (2.f * cams[i].tan_half_fov / (float)W) * (float)rmax;
+        worst = rho > worst ? rho : worst;
+    }
+    float step_vox = 2.f * ((float)DSDF_COARSE - 2.5f - worst);
+    if (step_vox < 1.f) return 0.f;
+    if (step_vox > (float)DSDF_COARSE) step_vox = (float)DSDF_COARSE;
+    return step_vox / (float)rmax;
 }
 
 static int check_render_args(const float *padded, int rx, int ry, int rz, const dsdf_params *prm,
@@ -712,15 +816,24 @@ void dsdf_default_params(dsdf_params *p) {
 }
 
 size_t dsdf_padded_size(int rx, int ry, int rz) {
-    return (size_t)(rx + 2 * DSDF_APRON) * (ry + 2 * DSDF_APRON) * (rz + 2 * DSDF_APRON);
+    size_t nc = (size_t)((rx + DSDF_COARSE - 1) / DSDF_COARSE) * ((ry + DSDF_COARSE - 1) / DSDF_COARSE) * ((rz + DSDF_COARSE - 1) / DSDF_COARSE);
+    return padded_floats(rx, ry, rz) + 2 * nc;
 }
 
 int dsdf_pad_grid(const float *data, int rx, int ry, int rz, float *padded, void *stream) {
     if (!data || !padded || rx < 1 || ry < 1 || rz < 1) return fail(DSDF_ERR_INVALID_ARG, "dsdf_pad_grid: bad argument");
-    size_t n = dsdf_padded_size(rx, ry, rz);
+    size_t n = padded_floats(rx, ry, rz);
     int grid = (int)((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192);
     hipLaunchKernelGGL(k_pad_grid, dim3(grid), dim3(256), 0, (hipStream_t)stream, data, rx, ry, rz, padded);
-    return check_launch("k_pad_grid");
+    int rc = check_launch("k_pad_grid");
+    if (rc) return rc;
+    // conservative min-grid for the empty-space proof
+    int cx = (rx + DSDF_COARSE - 1) / DSDF_COARSE, cy = (ry + DSDF_COARSE - 1) / DSDF_COARSE, cz = (rz + DSDF_COARSE - 1) / DSDF_COARSE;
+    int nc = cx * cy * cz;
+    float *c0 = padded + n, *c1 = c0 + nc;
+    hipLaunchKernelGGL(k_coarse_min, dim3((nc + 63) / 64), dim3(64), 0, (hipStream_t)stream, data, rx, ry, rz, c0, cx, cy, cz);
+    hipLaunchKernelGGL(k_coarse_dilate, dim3((nc + 63) / 64), dim3(64), 0, (hipStream_t)stream, c0, c1, cx, cy, cz);
+    return check_launch("k_coarse_min/dilate");
 }
 
 int dsdf_eval_cubic(const float *padded, int rx, int ry, int rz, const dsdf_params *prm, const float *points,
@@ -762,7 +875,7 @@ int dsdf_render_forward(const float *padded, int rx, int ry, int rz, const dsdf_
     hipStream_t st = (hipStream_t)stream;
     const int nb = batch_size(width, height, spp, n_views, workspace_bytes);
     Workspace ws = carve(workspace, width, height, spp, nb);
-    GridView G = make_view(padded, rx, ry, rz, *prm);
+    GridView G = device_view(padded, rx, ry, rz, *prm);
     size_t Wb = width + 2 * DSDF_BORDER, Hb = height + 2 * DSDF_BORDER;
     uint32_t nl = (uint32_t)(Wb * Hb * spp);
     Queue q; q.count = ws.count; q.lane = ws.qlane; q.rec = ws.qrec; q.cap = ws.cap; q.nblk = ws.nblk;
@@ -774,12 +887,19 @@ int dsdf_render_forward(const float *padded, int rx, int ry, int rz, const dsdf_
                                      seeds ? seeds[v0 + i] : 0u, integrator, flags);
         if (hipMemsetAsync(ws.block, 0, nv * Wb * Hb * 2 * sizeof(float), st) != hipSuccess)
             return fail(DSDF_ERR_LAUNCH, "hipMemsetAsync(block) failed");
+        const float step = (flags & DSDF_NO_SKIP) ? 0.f : skip_step(cams + v0, nv, width, rx, ry, rz);
+        const unsigned char *skip = nullptr;
+        if (step > 0.f) {
+            hipLaunchKernelGGL(k_pixel_skip, dim3((unsigned)((Wb * Hb + 255) / 256), nv), dim3(256), 0, st, G, *prm, VB, ws.skip, step);
+            if ((rc = check_launch("k_pixel_skip"))) return rc;
+            skip = ws.skip;
+        }
         if (spp % 64 == 0)
             hipLaunchKernelGGL((k_render_pass<false, true>), dim3(ws.nblk, nv), dim3(DSDF_BLOCK), 0, st, G, *prm, VB, ws.block, q,
-                               (unsigned long long *)stats, nl, 1);
+                               (unsigned long long *)stats, nl, 1, skip);
         else
             hipLaunchKernelGGL((k_render_pass<false, false>), dim3(ws.nblk, nv), dim3(DSDF_BLOCK), 0, st, G, *prm, VB, ws.block, q,
-                               (unsigned long long *)stats, nl, 0);
+                               (unsigned long long *)stats, nl, 0, skip);
         if ((rc = check_launch("k_render_pass<primal>"))) return rc;
         hipLaunchKernelGGL(k_develop, dim3((width * height + 255) / 256, nv), dim3(256), 0, st, ws.block, width, height,
                            image_out + (size_t)v0 * width * height * 3);
@@ -800,7 +920,7 @@ int dsdf_render_backward(const float *padded, int rx, int ry, int rz, const dsdf
     hipStream_t st = (hipStream_t)stream;
     const int nb = batch_size(width, height, spp, n_views, workspace_bytes);
     Workspace ws = carve(workspace, width, height, spp, nb);
-    GridView G = make_view(padded, rx, ry, rz, *prm);
+    GridView G = device_view(padded, rx, ry, rz, *prm);
     size_t Wb = width + 2 * DSDF_BORDER, Hb = height + 2 * DSDF_BORDER;
     uint32_t nl = (uint32_t)(Wb * Hb * spp);
     Queue q; q.count = ws.count; q.lane = ws.qlane; q.rec = ws.qrec; q.cap = ws.cap; q.nblk = ws.nblk;
@@ -812,12 +932,19 @@ int dsdf_render_backward(const float *padded, int rx, int ry, int rz, const dsdf
                                      seeds ? seeds[v0 + i] : 0u, integrator, flags);
         if (hipMemsetAsync(ws.block, 0, nv * Wb * Hb * 2 * sizeof(float), st) != hipSuccess)
             return fail(DSDF_ERR_LAUNCH, "hipMemsetAsync(workspace) failed");
+        const float step = (flags & DSDF_NO_SKIP) ? 0.f : skip_step(cams + v0, nv, width, rx, ry, rz);
+        const unsigned char *skip = nullptr;
+        if (step > 0.f) {
+            hipLaunchKernelGGL(k_pixel_skip, dim3((unsigned)((Wb * Hb + 255) / 256), nv), dim3(256), 0, st, G, *prm, VB, ws.skip, step);
+            if ((rc = check_launch("k_pixel_skip"))) return rc;
+            skip = ws.skip;
+        }
         if (spp % 64 == 0)
             hipLaunchKernelGGL((k_render_pass<true, DSDF_DIFF_CACHE != 0>), dim3(ws.nblk, nv), dim3(DSDF_BLOCK), 0, st, G, *prm, VB, ws.block, q,
-                               (unsigned long long *)stats, nl, 1);
+                               (unsigned long long *)stats, nl, 1, skip);
         else
             hipLaunchKernelGGL((k_render_pass<true, false>), dim3(ws.nblk, nv), dim3(DSDF_BLOCK), 0, st, G, *prm, VB, ws.block, q,
-                               (unsigned long long *)stats, nl, 0);
+                               (unsigned long long *)stats, nl, 0, skip);
         if ((rc = check_launch("k_render_pass<grad>"))) return rc;
         if (image_out) {
             hipLaunchKernelGGL(k_develop, dim3((width * height + 255) / 256, nv), dim3(256), 0, st, ws.block, width, height,

@@ -63,11 +63,14 @@ DSDF_HD V3 symmul(const float H[6], V3 a) {
 // per axis reproduce per-tap clamp-to-edge exactly (Dr.Jit wrap mode Clamp).
 // ---------------------------------------------------------------------------
 #define DSDF_APRON 3
+#define DSDF_COARSE 8          /* fine voxels per coarse block of the conservative min-grid */
 struct GridView {
     const float *p;
     int rx, ry, rz;
     int sx, sxy;
     float tx, ty, tz;   // sdf.p translation
+    const float *coarse;   // (cz,cy,cx) dilated block minima (device only; nullptr = absent)
+    int cx, cy, cz;
 };
 
 DSDF_HD GridView make_view(const float *padded, int rx, int ry, int rz, const dsdf_params &prm) {
@@ -75,6 +78,8 @@ DSDF_HD GridView make_view(const float *padded, int rx, int ry, int rz, const ds
     g.p = padded; g.rx = rx; g.ry = ry; g.rz = rz;
     g.sx = rx + 2 * DSDF_APRON; g.sxy = g.sx * (ry + 2 * DSDF_APRON);
     g.tx = prm.sdf_p[0]; g.ty = prm.sdf_p[1]; g.tz = prm.sdf_p[2];
+    g.cx = (rx + DSDF_COARSE - 1) / DSDF_COARSE; g.cy = (ry + DSDF_COARSE - 1) / DSDF_COARSE; g.cz = (rz + DSDF_COARSE - 1) / DSDF_COARSE;
+    g.coarse = nullptr;
     return g;
 }
 

@@ -13,6 +13,7 @@ LIB_PATH = os.environ.get('DSDF_LIB_PATH') or os.path.normpath(os.path.join(_HER
 DSDF_SILHOUETTE = 0
 DSDF_SIMPLE_SHADING = 1
 DSDF_REPARAM = 1
+DSDF_NO_SKIP = 2
 
 
 class DsdfCamera(C.Structure):

@@ -12,7 +12,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import DSDF_REPARAM, DSDF_SILHOUETTE, DSDF_SIMPLE_SHADING, DsdfCamera
+from ._lib import DSDF_NO_SKIP, DSDF_REPARAM, DSDF_SILHOUETTE, DSDF_SIMPLE_SHADING, DsdfCamera
 
 INTEGRATORS = {'sdf_silhouette_reparam': DSDF_SILHOUETTE, 'sdf_simple_shading_reparam': DSDF_SIMPLE_SHADING,
                DSDF_SILHOUETTE: DSDF_SILHOUETTE, DSDF_SIMPLE_SHADING: DSDF_SIMPLE_SHADING}
@@ -141,7 +141,8 @@ def _sampler_args(n_views, seeds, offsets, n_lanes):
     return None, (C.c_uint32 * n_views)(*[int(s) & 0xffffffff for s in seeds])
 
 
-def render_forward(grid, sensors, spp, seeds=None, offsets=None, integrator=DSDF_SILHOUETTE, reparam=True, stats=None):
+def render_forward(grid, sensors, spp, seeds=None, offsets=None, integrator=DSDF_SILHOUETTE, reparam=True, stats=None,
+                   empty_space_skip=True):
     """`ReparamIntegrator.render` for a batch of views -> (n_views, H, W, 3)."""
     lib = _lib.load()
     sensors, cams, W, H = _views(sensors)
@@ -155,13 +156,13 @@ def render_forward(grid, sensors, spp, seeds=None, offsets=None, integrator=DSDF
     with torch.cuda.device(dev):
         _lib.check(lib.dsdf_render_forward(_ptr(grid.padded), grid.rx, grid.ry, grid.rz, C.byref(grid.params), cams, nv,
                                            W, H, int(spp), _ptr(offsets), cseeds, INTEGRATORS[integrator],
-                                           DSDF_REPARAM if reparam else 0, _ptr(img), _ptr(ws), wsb,
-                                           _ptr(stats), _stream()))
+                                           (DSDF_REPARAM if reparam else 0) | (0 if empty_space_skip else DSDF_NO_SKIP),
+                                           _ptr(img), _ptr(ws), wsb, _ptr(stats), _stream()))
     return img
 
 
 def render_backward(grid, sensors, spp, grad_image, grad_grid=None, seeds=None, offsets=None,
-                    integrator=DSDF_SILHOUETTE, reparam=True, stats=None, return_image=False):
+                    integrator=DSDF_SILHOUETTE, reparam=True, stats=None, return_image=False, empty_space_skip=True):
     """`ReparamIntegrator.render_backward`: accumulates dL/dsdf into grad_grid (Z,Y,X)."""
     lib = _lib.load()
     sensors, cams, W, H = _views(sensors)
@@ -184,7 +185,8 @@ def render_backward(grid, sensors, spp, grad_image, grad_grid=None, seeds=None, 
     with torch.cuda.device(dev):
         _lib.check(lib.dsdf_render_backward(_ptr(grid.padded), grid.rx, grid.ry, grid.rz, C.byref(grid.params), cams, nv,
                                             W, H, int(spp), _ptr(offsets), cseeds, INTEGRATORS[integrator],
-                                            DSDF_REPARAM if reparam else 0, _ptr(grad_image), _ptr(grad_grid),
+                                            (DSDF_REPARAM if reparam else 0) | (0 if empty_space_skip else DSDF_NO_SKIP),
+                                            _ptr(grad_image), _ptr(grad_grid),
                                             _ptr(img), _ptr(ws), wsb, _ptr(stats), _stream()))
     return (grad_grid, img) if return_image else grad_grid
 

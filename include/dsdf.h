@@ -46,7 +46,8 @@ enum dsdf_integrator {
 /* Flags for dsdf_render_*.  DSDF_REPARAM selects WarpField2D (python/warp.py:7-128);
  * without it the DummyWarpField path is taken (python/warp.py:179-196). */
 enum dsdf_flags {
-    DSDF_REPARAM = 1
+    DSDF_REPARAM = 1,
+    DSDF_NO_SKIP = 2   /* disable the exact per-pixel empty-space proof (A/B and testing) */
 };
 
 /* Perspective sensor as built by python/util.py:115-138 (`get_regular_cameras`):
@@ -83,9 +84,10 @@ int         dsdf_version(void);
 const char *dsdf_last_error(void);
 void        dsdf_default_params(dsdf_params *p);
 
-/* Number of floats of the library's internal padded copy of an (rz,ry,rx) grid
- * (clamp-to-edge apron of 3 voxels per side, so the 4^3 B-spline footprint is
- * always four contiguous 16-byte rows). */
+/* Number of floats of the library's internal grid buffer for an (rz,ry,rx) grid:
+ * the padded copy (clamp-to-edge apron of 3 voxels per side, so the 4^3 B-spline
+ * footprint is always four contiguous 16-byte rows) followed by a coarse min-grid
+ * (8^3-voxel block minima and their 3x3x3 dilation) used to prove pixels empty. */
 size_t dsdf_padded_size(int rx, int ry, int rz);
 
 /* Builds the padded copy.  Replaces `Texture3f.set_tensor` / `Grid3d.update`

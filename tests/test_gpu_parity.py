@@ -69,10 +69,14 @@ def test_trace_gpu(dsdf):
 def test_render_forward_gpu(dsdf, name, integ):
     case = make_case(name)
     ref, aux = oracle_forward(case, integ)
-    stats = dsdf.new_stats('cuda')
     img = dsdf.render_forward(dev_grid(dsdf, case), sensor(dsdf, case), case['spp'], offsets=case['offsets'].cuda(),
-                              integrator=integ, stats=stats)[0]
+                              integrator=integ)[0]
     assert rel_l2(img.cpu(), ref) < FWD_TOL
+    # step statistics are compared with the empty-space proof off (it skips provably missing rays)
+    stats = dsdf.new_stats('cuda')
+    img2 = dsdf.render_forward(dev_grid(dsdf, case), sensor(dsdf, case), case['spp'], offsets=case['offsets'].cuda(),
+                               integrator=integ, stats=stats, empty_space_skip=False)[0]
+    assert rel_l2(img2.cpu(), ref) < FWD_TOL
     st = dsdf.stats_dict(stats)
     assert st['lanes'] == aux['lanes'] and st['hits'] == aux['hits']
     assert abs(st['steps'] - aux['steps']) <= 0.01 * aux['steps']
@@ -282,3 +286,31 @@ def test_large_spp_not_multiple_of_64(dsdf):
     ga = dsdf.render_backward(g, sen, spp, gi, offsets=offs)
     gb = dsdf.render_backward(g, sen, 2 * spp, gi, offsets=offs2)
     assert rel_l2(ga.cpu(), gb.cpu()) < 1e-4
+
+
+@pytest.mark.parametrize('integ', [O.SILHOUETTE, O.SIMPLE_SHADING])
+def test_empty_space_skip_is_exact(dsdf, integ):
+    """The per-pixel empty-space proof (coarse dilated min-grid) must not change any result: images and
+    gradients with and without it agree to atomic-ordering noise, while far fewer steps are traced."""
+    R, W, H, spp = 128, 128, 128, 64
+    data = O.blob_grid(R, n=16, seed=5).float().cuda()
+    grid = dsdf.SdfGrid(data)
+    sens = dsdf.get_regular_cameras(6, resx=W, resy=H)[:3]
+    seeds = [3, 4, 5]
+    sa, sb = dsdf.new_stats('cuda'), dsdf.new_stats('cuda')
+    a = dsdf.render_forward(grid, sens, spp, seeds=seeds, integrator=integ, stats=sa)
+    b = dsdf.render_forward(grid, sens, spp, seeds=seeds, integrator=integ, stats=sb, empty_space_skip=False)
+    assert rel_l2(a.cpu(), b.cpu()) < 1e-6
+    da, db = dsdf.stats_dict(sa), dsdf.stats_dict(sb)
+    assert da['hits'] == db['hits'] and da['lanes'] == db['lanes']
+    assert da['steps'] < 0.8 * db['steps']                     # a good part of the image is provably empty
+    gi = torch.randn(3, H, W, 3, device='cuda')
+    ga, ia = dsdf.render_backward(grid, sens, spp, gi, seeds=seeds, integrator=integ, return_image=True)
+    gb, ib = dsdf.render_backward(grid, sens, spp, gi, seeds=seeds, integrator=integ, return_image=True, empty_space_skip=False)
+    assert rel_l2(ia.cpu(), ib.cpu()) < 1e-6
+    assert rel_l2(ga.cpu(), gb.cpu()) < 1e-5
+    # low-resolution film on a fine grid: the pixel footprint exceeds the dilation margin -> proof disabled, same result
+    lo = dsdf.get_regular_cameras(6, resx=12, resy=12)[0]
+    c = dsdf.render_forward(grid, lo, spp, seeds=[1], integrator=integ)
+    d = dsdf.render_forward(grid, lo, spp, seeds=[1], integrator=integ, empty_space_skip=False)
+    assert rel_l2(c.cpu(), d.cpu()) < 1e-6
