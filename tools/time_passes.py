@@ -1,5 +1,8 @@
+"""Times the two launches of the bench workload (12 views, 256^3, 512^2): used for A/B runs of kernel variants
+(set DSDF_LIB_PATH to another build of libdsdf.so)."""
 import os, sys, time, torch
-sys.path.insert(0, 'differentiable-sdf-rendering_amd/python'); sys.path.insert(0, '.')
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, 'differentiable-sdf-rendering_amd', 'python')); sys.path.insert(0, ROOT)
 import dsdf
 from bench import synth_grid
 dev = torch.device('cuda')
