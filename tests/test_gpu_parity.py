@@ -314,3 +314,29 @@ def test_empty_space_skip_is_exact(dsdf, integ):
     c = dsdf.render_forward(grid, lo, spp, seeds=[1], integrator=integ)
     d = dsdf.render_forward(grid, lo, spp, seeds=[1], integrator=integ, empty_space_skip=False)
     assert rel_l2(c.cpu(), d.cpu()) < 1e-6
+
+
+def test_maximum_grid_size_512(dsdf):
+    """BASELINE.json's largest grid (512^3 = 537 MB padded): indexing stays in range, and the image
+    of an analytic sphere agrees with the same sphere sampled at 128^3 (the half-voxel convention shifts
+    the surface by 1/(2R), so the agreement is within the edge pixels)."""
+    sens = dsdf.get_regular_cameras(4, resx=96, resy=96)[:2]
+    imgs = {}
+    for R in (128, 512):
+        lin = torch.linspace(0, 1, R, device='cuda')
+        z, y, x = torch.meshgrid(lin, lin, lin, indexing='ij')
+        data = (torch.sqrt((x - 0.5) ** 2 + (y - 0.5) ** 2 + (z - 0.5) ** 2) - 0.3).contiguous()
+        del x, y, z
+        g = dsdf.SdfGrid(data)
+        imgs[R] = dsdf.render_forward(g, sens, 64, seeds=[1, 2], integrator=O.SIMPLE_SHADING)
+        if R == 512:
+            gi = torch.ones(2, 96, 96, 3, device='cuda') / (96 * 96)
+            grad = dsdf.render_backward(g, sens, 64, gi, seeds=[3, 4])
+            assert grad.shape == (512, 512, 512) and torch.isfinite(grad).all() and float(grad.abs().sum()) > 0
+            # growing the sphere (sdf -> sdf - eps) brightens the silhouette: dL/dsdf sums to a negative number
+            assert float(grad.sum()) < 0
+            del grad
+        del g, data
+        torch.cuda.empty_cache()
+    assert rel_l2(imgs[512].cpu(), imgs[128].cpu()) < 0.05
+    assert 0.05 < float(imgs[512].mean()) < 0.5

@@ -41,6 +41,16 @@ for name, sp, sg, integ in (('sil_256_64', 256, 64, 0), ('shade_256_64', 256, 64
     p = timed(lambda: dsdf.render_forward(grid, sens, sp, seeds=list(range(12)), integrator=integ), 3)
     b = timed(lambda: dsdf.render_backward(grid, sens, sg, gi, grad_grid=gg, seeds=list(range(12)), integrator=integ), 3)
     out[name] = {'primal_ms': p, 'grad_ms': b, 'renders_per_s': 1e3 / (p + b)}
+# BASELINE.json C4 grid size on one GPU (512^3, 12 views x 512^2, 256/64 spp)
+big = synth_grid(512, dev)
+gbig = dsdf.SdfGrid(big)
+ggb = torch.zeros_like(big)
+p = timed(lambda: dsdf.render_forward(gbig, sens, 256, seeds=list(range(12))), 2)
+b = timed(lambda: dsdf.render_backward(gbig, sens, 64, gi, grad_grid=ggb, seeds=list(range(12))), 2)
+out['sil_256_64_grid512'] = {'primal_ms': p, 'grad_ms': b, 'renders_per_s': 1e3 / (p + b)}
+del big, gbig, ggb
+torch.cuda.empty_cache()
+
 # one optimisation iteration of a `no-tex-12-hqq`-shaped state at its final resolution (256^3, 512^2, 6 of 12 views)
 sys.path.insert(0, os.path.join(ROOT, 'differentiable-sdf-rendering_amd', 'python'))
 import losses, regularizations, redistancing
