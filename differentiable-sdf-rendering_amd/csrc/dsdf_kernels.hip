@@ -795,6 +795,15 @@ static float skip_step(const dsdf_camera *cams, int nv, int W, int rx, int ry, i
     return step_vox / (float)rmax;
 }
 
+// Parameters of a render pass.  The silhouette integrator consumes only the hit FLAG of a sample
+// (sdf_silhouette_reparam.py:20-22), never the hit distance, and the refinement loop
+// (shapes.py:245-257) cannot turn a hit into a miss: skipping it leaves every output unchanged.
+static dsdf_params pass_params(const dsdf_params &prm, int integrator) {
+    dsdf_params p = prm;
+    if (integrator == DSDF_SILHOUETTE) p.refine_steps = 0;
+    return p;
+}
+
 static int check_render_args(const float *padded, int rx, int ry, int rz, const dsdf_params *prm,
                              const dsdf_camera *cams, int n_views, int W, int H, int spp, int integrator,
                              void *workspace, size_t workspace_bytes) {
@@ -880,6 +889,7 @@ int dsdf_render_forward(const float *padded, int rx, int ry, int rz, const dsdf_
     if (!image_out) return fail(DSDF_ERR_INVALID_ARG, "dsdf_render_forward: image_out is null");
     if (!offsets && !seeds) return fail(DSDF_ERR_INVALID_ARG, "dsdf_render_forward: need offsets or seeds");
     hipStream_t st = (hipStream_t)stream;
+    const dsdf_params pp = pass_params(*prm, integrator);
     const int nb = batch_size(width, height, spp, n_views, workspace_bytes);
     Workspace ws = carve(workspace, width, height, spp, nb);
     GridView G = device_view(padded, rx, ry, rz, *prm);
@@ -897,15 +907,15 @@ int dsdf_render_forward(const float *padded, int rx, int ry, int rz, const dsdf_
         const float step = (flags & DSDF_NO_SKIP) ? 0.f : skip_step(cams + v0, nv, width, rx, ry, rz);
         const unsigned char *skip = nullptr;
         if (step > 0.f) {
-            hipLaunchKernelGGL(k_pixel_skip, dim3((unsigned)((Wb * Hb + 255) / 256), nv), dim3(256), 0, st, G, *prm, VB, ws.skip, step);
+            hipLaunchKernelGGL(k_pixel_skip, dim3((unsigned)((Wb * Hb + 255) / 256), nv), dim3(256), 0, st, G, pp, VB, ws.skip, step);
             if ((rc = check_launch("k_pixel_skip"))) return rc;
             skip = ws.skip;
         }
         if (spp % 64 == 0)
-            hipLaunchKernelGGL((k_render_pass<false, true>), dim3(ws.nblk, nv), dim3(DSDF_BLOCK), 0, st, G, *prm, VB, ws.block, q,
+            hipLaunchKernelGGL((k_render_pass<false, true>), dim3(ws.nblk, nv), dim3(DSDF_BLOCK), 0, st, G, pp, VB, ws.block, q,
                                (unsigned long long *)stats, nl, 1, skip);
         else
-            hipLaunchKernelGGL((k_render_pass<false, false>), dim3(ws.nblk, nv), dim3(DSDF_BLOCK), 0, st, G, *prm, VB, ws.block, q,
+            hipLaunchKernelGGL((k_render_pass<false, false>), dim3(ws.nblk, nv), dim3(DSDF_BLOCK), 0, st, G, pp, VB, ws.block, q,
                                (unsigned long long *)stats, nl, 0, skip);
         if ((rc = check_launch("k_render_pass<primal>"))) return rc;
         hipLaunchKernelGGL(k_develop, dim3((width * height + 255) / 256, nv), dim3(256), 0, st, ws.block, width, height,
@@ -925,6 +935,7 @@ int dsdf_render_backward(const float *padded, int rx, int ry, int rz, const dsdf
     if (!grad_image || !grad_grid) return fail(DSDF_ERR_INVALID_ARG, "dsdf_render_backward: null gradient buffer");
     if (!offsets && !seeds) return fail(DSDF_ERR_INVALID_ARG, "dsdf_render_backward: need offsets or seeds");
     hipStream_t st = (hipStream_t)stream;
+    const dsdf_params pp = pass_params(*prm, integrator);
     const int nb = batch_size(width, height, spp, n_views, workspace_bytes);
     Workspace ws = carve(workspace, width, height, spp, nb);
     GridView G = device_view(padded, rx, ry, rz, *prm);
@@ -942,15 +953,15 @@ int dsdf_render_backward(const float *padded, int rx, int ry, int rz, const dsdf
         const float step = (flags & DSDF_NO_SKIP) ? 0.f : skip_step(cams + v0, nv, width, rx, ry, rz);
         const unsigned char *skip = nullptr;
         if (step > 0.f) {
-            hipLaunchKernelGGL(k_pixel_skip, dim3((unsigned)((Wb * Hb + 255) / 256), nv), dim3(256), 0, st, G, *prm, VB, ws.skip, step);
+            hipLaunchKernelGGL(k_pixel_skip, dim3((unsigned)((Wb * Hb + 255) / 256), nv), dim3(256), 0, st, G, pp, VB, ws.skip, step);
             if ((rc = check_launch("k_pixel_skip"))) return rc;
             skip = ws.skip;
         }
         if (spp % 64 == 0)
-            hipLaunchKernelGGL((k_render_pass<true, DSDF_DIFF_CACHE != 0>), dim3(ws.nblk, nv), dim3(DSDF_BLOCK), 0, st, G, *prm, VB, ws.block, q,
+            hipLaunchKernelGGL((k_render_pass<true, DSDF_DIFF_CACHE != 0>), dim3(ws.nblk, nv), dim3(DSDF_BLOCK), 0, st, G, pp, VB, ws.block, q,
                                (unsigned long long *)stats, nl, 1, skip);
         else
-            hipLaunchKernelGGL((k_render_pass<true, false>), dim3(ws.nblk, nv), dim3(DSDF_BLOCK), 0, st, G, *prm, VB, ws.block, q,
+            hipLaunchKernelGGL((k_render_pass<true, false>), dim3(ws.nblk, nv), dim3(DSDF_BLOCK), 0, st, G, pp, VB, ws.block, q,
                                (unsigned long long *)stats, nl, 0, skip);
         if ((rc = check_launch("k_render_pass<grad>"))) return rc;
         if (image_out) {
@@ -961,7 +972,7 @@ int dsdf_render_backward(const float *padded, int rx, int ry, int rz, const dsdf
         hipLaunchKernelGGL(k_develop_adjoint, dim3((unsigned)((Wb * Hb + 255) / 256), nv), dim3(256), 0, st, ws.block,
                            grad_image + (size_t)v0 * width * height * 3, width, height, ws.block_adj);
         if ((rc = check_launch("k_develop_adjoint"))) return rc;
-        hipLaunchKernelGGL(k_backward, dim3(ws.nblk, nv), dim3(64), 0, st, G, *prm, VB, q, ws.block_adj, grad_grid,
+        hipLaunchKernelGGL(k_backward, dim3(ws.nblk, nv), dim3(64), 0, st, G, pp, VB, q, ws.block_adj, grad_grid,
                            (unsigned long long *)stats);
         if ((rc = check_launch("k_backward"))) return rc;
     }
