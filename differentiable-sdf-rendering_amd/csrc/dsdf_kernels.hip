@@ -4,8 +4,9 @@
 //   k_pad_grid          clamp-to-edge padded copy of sdf.data (Texture3f.set_tensor)
 //   k_eval_cubic        A1  tricubic B-spline value/gradient/Hessian at points
 //   k_trace             A2/A4/A5 per-ray sphere tracing (standalone entry)
-//   k_coarse_min/dilate conservative min-grid of the SDF (8^3-voxel blocks, dilated)
+//   k_coarse_min/dilate conservative min-grids of the SDF (8^3- and 4^3-voxel blocks, dilated)
 //   k_pixel_skip        exact per-pixel empty-space proof against that grid
+//   k_skip_dilate       pixels whose samples cannot reach any output (not generated at all)
 //   k_render_pass<DIFF,CACHE> ray-gen + trace + shade + Gaussian splat; DIFF adds the
 //                       warp-t accumulators and emits a compacted backward queue;
 //                       CACHE = wave-cooperative LDS cache of the B-spline cells
@@ -96,6 +97,12 @@ __device__ __forceinline__ uint32_t mask_prefix(uint64_t m) {
 }
 
 __device__ __forceinline__ int wave_sum_i32(int v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+    return v;
+}
+
+__device__ __forceinline__ float wave_sum_f32(float v) {
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
     return v;
@@ -339,20 +346,22 @@ __device__ __forceinline__ void film_splat_wave(float *__restrict__ block, const
 
 // ------------------------------------------------------------------ empty-space proof
 // Cubic B-spline weights are >= 0 and sum to 1, so every lookup is bounded below by the minimum of its
-// 64 taps.  `coarse[b]` = min of the grid over coarse block b (8^3 voxels) dilated by one block in every
+// 64 taps.  `coarse[b]` = min of the grid over coarse block b (8^3 or 4^3 voxels: the finest level whose margin
+// covers the pixel footprint is used) dilated by one block in every
 // direction; if it exceeds a threshold for every block the CENTRE ray of a film pixel passes through, no
 // point visited by ANY sample ray of that pixel (they deviate by less than the dilation margin, checked on
 // the host) can have an SDF value below the threshold.  Such pixels skip tracing with EXACTLY the result
 // tracing would give: primal -- every sample misses (threshold = trace_eps); gradient pass -- misses AND a
 // zero boundary weight, because w > 0 needs |sdf(x_warp)| < edge_eps * t (threshold = edge_eps * t_exit).
-__global__ void k_coarse_min(const float *__restrict__ data, int rx, int ry, int rz, float *__restrict__ c0, int cx, int cy, int cz) {
+__global__ void k_coarse_min(const float *__restrict__ data, int rx, int ry, int rz, float *__restrict__ c0, int cx, int cy, int cz,
+                             int C) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= cx * cy * cz) return;
     int bx = i % cx, by = (i / cx) % cy, bz = i / (cx * cy);
     float m = INFINITY;
-    for (int z = bz * DSDF_COARSE; z < min(rz, (bz + 1) * DSDF_COARSE); ++z)
-        for (int y = by * DSDF_COARSE; y < min(ry, (by + 1) * DSDF_COARSE); ++y)
-            for (int x = bx * DSDF_COARSE; x < min(rx, (bx + 1) * DSDF_COARSE); ++x)
+    for (int z = bz * C; z < min(rz, (bz + 1) * C); ++z)
+        for (int y = by * C; y < min(ry, (by + 1) * C); ++y)
+            for (int x = bx * C; x < min(rx, (bx + 1) * C); ++x)
                 m = fminf(m, data[((size_t)z * ry + y) * rx + x]);
     c0[i] = m;
 }
@@ -386,9 +395,9 @@ __global__ void k_pixel_skip(GridView G, dsdf_params P, ViewBatch VB, unsigned c
         float m = INFINITY;
         for (float t = t0; t < t1 + step; t += step) {
             V3 x = fma3(fminf(t, t1), d, r.o);
-            int bx = iclamp((int)floorf((x.x - G.tx) * (float)G.rx) / DSDF_COARSE, 0, G.cx - 1);
-            int by = iclamp((int)floorf((x.y - G.ty) * (float)G.ry) / DSDF_COARSE, 0, G.cy - 1);
-            int bz = iclamp((int)floorf((x.z - G.tz) * (float)G.rz) / DSDF_COARSE, 0, G.cz - 1);
+            int bx = iclamp((int)floorf((x.x - G.tx) * (float)G.rx) >> G.cshift, 0, G.cx - 1);
+            int by = iclamp((int)floorf((x.y - G.ty) * (float)G.ry) >> G.cshift, 0, G.cy - 1);
+            int bz = iclamp((int)floorf((x.z - G.tz) * (float)G.rz) >> G.cshift, 0, G.cz - 1);
             m = fminf(m, G.coarse[(bz * G.cy + by) * G.cx + bx]);
         }
         float thr_p = 2.f * P.trace_eps * fmaxf(t1, 1.f) + 1e-5f;
@@ -397,6 +406,25 @@ __global__ void k_pixel_skip(GridView G, dsdf_params P, ViewBatch VB, unsigned c
         if (m > fmaxf(thr_p, thr_g)) f |= 2;
     }
     flags[(size_t)blockIdx.y * A.Wb * A.Hb + i] = f;
+}
+
+// Bits 2/3: every film pixel within +-4 of this one carries bit 0 / bit 1.  A sample only splats into
+// pixels within +-2 of its own, and a film pixel's weight sum only matters if a value lands on it or a
+// backward lane reads its adjoint -- both need a pixel within +-2 of it that is NOT proven empty.  So the
+// samples of a pixel with bit 2 (3) set cannot influence any output of the primal (gradient) pass and are
+// not generated at all.  (In place: writers only add bits 2/3, readers only look at bits 0/1.)
+#define DSDF_FAR_RADIUS 4
+__global__ void k_skip_dilate(ViewBatch VB, unsigned char *__restrict__ flags) {
+    const ViewArgs &A = VB.v[blockIdx.y];
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= A.Wb * A.Hb) return;
+    unsigned char *f = flags + (size_t)blockIdx.y * A.Wb * A.Hb;
+    int py = i / A.Wb, px = i - py * A.Wb;
+    unsigned m = 3u;
+    for (int y = max(py - DSDF_FAR_RADIUS, 0); y <= min(py + DSDF_FAR_RADIUS, A.Hb - 1); ++y)
+        for (int x = max(px - DSDF_FAR_RADIUS, 0); x <= min(px + DSDF_FAR_RADIUS, A.Wb - 1); ++x)
+            m &= f[y * A.Wb + x];
+    f[i] = (unsigned char)((f[i] & 3u) | (m << 2));
 }
 
 // ------------------------------------------------------------------ render pass
@@ -421,42 +449,57 @@ __global__ __launch_bounds__(DSDF_BLOCK, DIFF ? DSDF_DIFF_MINWAVES : DSDF_PRIMAL
     const bool valid = lane < n_lanes;
     if (!valid) lane = n_lanes - 1;   // keep the wave converged for the cross-lane code
     const int lid = lane_id();
-    Lane L = lane_setup(A, P, lane);
     // wave-private LDS scratch: cell cache during tracing, film transpose afterwards
     __shared__ __attribute__((aligned(16))) float wave_lds[DSDF_BLOCK / 64][DSDF_WAVE_LDS];
     TraceOut tr;
-    // empty-space proof for this pixel (wave-uniform when the wave sits in one pixel): the result of
-    // tracing is known -- a miss with no warp -- so the loop is skipped
-    bool skip_trace = false;
-    if (skip) skip_trace = (skip[(size_t)blockIdx.y * A.Wb * A.Hb + (size_t)L.py * A.Wb + L.px] & (DIFF ? 2 : 1)) != 0;
-    if (CACHE) {
-        if (!skip_trace) {                                  // wave-uniform branch (CACHE implies one pixel per wave)
-            WaveCellCache F; F.taps = wave_lds[threadIdx.x >> 6]; F.lid = lid;
-            if (DIFF) trace_diff(G, P, L.ray.o, L.ray.d, L.ray.maxt, tr, F);
-            else trace_plain(G, P, L.ray.o, L.ray.d, L.ray.maxt, tr, F);
+    tr.its_t = INFINITY; tr.warp_t = INFINITY; tr.warp_weight = 0.f; tr.weight_sum = 0.f;
+    tr.warp_t_d = mk(0.f, 0.f, 0.f); tr.warp_weight_d = mk(0.f, 0.f, 0.f);
+    tr.steps = 0; tr.refine_steps = 0;
+    // empty-space proof for this pixel (wave-uniform when the wave sits in one pixel).  skip_trace: the
+    // result of tracing is known -- a miss with no warp -- so the loop is skipped; far: nothing this
+    // sample does can reach an output (k_skip_dilate), so it is not generated.
+    bool skip_trace = false, far = false;
+    if (skip) {
+        int px, py;
+        lane_pixel(A, lane, px, py);
+        unsigned f = skip[(size_t)blockIdx.y * A.Wb * A.Hb + (size_t)py * A.Wb + px];
+        skip_trace = (f & (DIFF ? 2u : 1u)) != 0;
+#ifndef DSDF_NO_FAR
+        far = (f & (DIFF ? 8u : 4u)) != 0;
+#endif
+    }
+    Lane L;
+    if (!far) {                                             // wave-uniform when CACHE / wave_uniform
+        L = lane_setup(A, P, lane);
+        if (CACHE) {
+            if (!skip_trace) {                              // wave-uniform branch (CACHE implies one pixel per wave)
+                WaveCellCache F; F.taps = wave_lds[threadIdx.x >> 6]; F.lid = lid;
+                if (DIFF) trace_diff(G, P, L.ray.o, L.ray.d, L.ray.maxt, tr, F);
+                else trace_plain(G, P, L.ray.o, L.ray.d, L.ray.maxt, tr, F);
+            }
+        } else if (!skip_trace) {
+            if (DIFF) trace_diff(G, P, L.ray.o, L.ray.d, L.ray.maxt, tr);
+            else trace_plain(G, P, L.ray.o, L.ray.d, L.ray.maxt, tr);
         }
-    } else if (!skip_trace) {
-        if (DIFF) trace_diff(G, P, L.ray.o, L.ray.d, L.ray.maxt, tr);
-        else trace_plain(G, P, L.ray.o, L.ray.d, L.ray.maxt, tr);
-    }
-    if (skip_trace) {
-        tr.its_t = INFINITY; tr.warp_t = INFINITY; tr.warp_weight = 0.f; tr.weight_sum = 0.f;
-        tr.warp_t_d = mk(0.f, 0.f, 0.f); tr.warp_weight_d = mk(0.f, 0.f, 0.f);
-        tr.steps = 0; tr.refine_steps = 0;
-    }
-    float val = shade_value(G, A, L, tr.its_t);
-    Reproj rp = reproject(A.cam, P, L.ray.o + L.ray.d, A.W, A.H);
+        if (skip_trace) {
+            tr.its_t = INFINITY; tr.warp_t = INFINITY; tr.warp_weight = 0.f; tr.weight_sum = 0.f;
+            tr.warp_t_d = mk(0.f, 0.f, 0.f); tr.warp_weight_d = mk(0.f, 0.f, 0.f);
+            tr.steps = 0; tr.refine_steps = 0;
+        }
+        float val = shade_value(G, A, L, tr.its_t);
+        Reproj rp = reproject(A.cam, P, L.ray.o + L.ray.d, A.W, A.H);
 
-    if (wave_uniform) {
-        film_splat_wave(block, A, L.px, L.py, rp.u, rp.v, val, wave_lds[threadIdx.x >> 6], lid);
-    } else if (valid) {
-        splat_lane(block, A.Wb, A.Hb, rp.u, rp.v, val, AtomicAdd());
+        if (wave_uniform) {
+            film_splat_wave(block, A, L.px, L.py, rp.u, rp.v, val, wave_lds[threadIdx.x >> 6], lid);
+        } else if (valid) {
+            splat_lane(block, A.Wb, A.Hb, rp.u, rp.v, val, AtomicAdd());
+        }
     }
 
     bool need = false;
     if (DIFF) {
         bool hit = tr.its_t < INFINITY;
-        bool warp_cand = (A.flags & DSDF_REPARAM) && warp_weight_positive(G, P, L.ray.o, L.ray.d, tr);
+        bool warp_cand = !far && (A.flags & DSDF_REPARAM) && warp_weight_positive(G, P, L.ray.o, L.ray.d, tr);
         need = valid && (warp_cand || (hit && A.integrator == DSDF_SIMPLE_SHADING));
         // block-level compaction: per-wave ballot + mbcnt prefix, wave totals through LDS
         __shared__ uint32_t wave_cnt[DSDF_BLOCK / 64];
@@ -544,7 +587,8 @@ __global__ void k_develop_adjoint(const float *__restrict__ blocks, const float 
 // (usually one round: ~12 % of 256 samples), holds one 8 KB brick, so a CU keeps ~20 working waves.
 __global__ __launch_bounds__(64) void k_backward(GridView G, dsdf_params P, ViewBatch VB, Queue qall,
                                                  const float *__restrict__ block_adjs,
-                                                 float *__restrict__ grad_grid, unsigned long long *stats) {
+                                                 float *__restrict__ grad_grid, float *__restrict__ grad_p,
+                                                 unsigned long long *stats) {
     __shared__ float brick[DSDF_BRICK_CAP];
     const ViewArgs &A = VB.v[blockIdx.y];
     const float *__restrict__ block_adj = block_adjs + (size_t)blockIdx.y * 2 * A.Wb * A.Hb;
@@ -552,6 +596,7 @@ __global__ __launch_bounds__(64) void k_backward(GridView G, dsdf_params P, View
     const uint32_t count = q.count[blockIdx.x];            // samples queued by render-pass block blockIdx.x
     const int lid = lane_id();
     int n_did = 0;
+    V3 p_bar = mk(0.f, 0.f, 0.f);                          // dL/d(sdf.p) of this block's samples
     for (uint32_t s0 = 0; s0 < count; s0 += 64) {
         const uint32_t slot = s0 + threadIdx.x;
         ScatterReq req[2];
@@ -571,6 +616,14 @@ __global__ __launch_bounds__(64) void k_backward(GridView G, dsdf_params P, View
         }
         wave_scatter(G, grad_grid, req[0], brick, lid);
         if (A.integrator != DSDF_SILHOUETTE) wave_scatter(G, grad_grid, req[1], brick, lid);
+        if (grad_p) {
+            if (req[0].on) p_bar = p_bar + req[0].p_bar;
+            if (req[1].on) p_bar = p_bar + req[1].p_bar;
+        }
+    }
+    if (grad_p && count) {
+        float sx = wave_sum_f32(p_bar.x), sy = wave_sum_f32(p_bar.y), sz = wave_sum_f32(p_bar.z);
+        if (lid == 0) { atomicAdd(grad_p, sx); atomicAdd(grad_p + 1, sy); atomicAdd(grad_p + 2, sz); }
     }
     if (stats && count) {
         int s = wave_sum_i32(n_did);
@@ -770,17 +823,32 @@ static size_t padded_floats(int rx, int ry, int rz) {
     return (size_t)(rx + 2 * DSDF_APRON) * (ry + 2 * DSDF_APRON) * (rz + 2 * DSDF_APRON);
 }
 
-// GridView over the library's grid buffer: [padded grid | block minima | dilated block minima]
-static GridView device_view(const float *padded, int rx, int ry, int rz, const dsdf_params &prm) {
+// Blocks per axis / cells of coarse level `level` (block edge 8 >> level voxels).
+static void coarse_dims(int rx, int ry, int rz, int level, int &cx, int &cy, int &cz) {
+    const int C = 1 << DSDF_COARSE_SHIFT(level);
+    cx = (rx + C - 1) / C; cy = (ry + C - 1) / C; cz = (rz + C - 1) / C;
+}
+static size_t coarse_cells(int rx, int ry, int rz, int level) {
+    int cx, cy, cz;
+    coarse_dims(rx, ry, rz, level, cx, cy, cz);
+    return (size_t)cx * cy * cz;
+}
+
+// GridView over the library's grid buffer: [padded grid | per level: block minima, dilated block minima]
+static GridView device_view(const float *padded, int rx, int ry, int rz, const dsdf_params &prm, int level = 0) {
     GridView G = make_view(padded, rx, ry, rz, prm);
-    G.coarse = padded + padded_floats(rx, ry, rz) + (size_t)G.cx * G.cy * G.cz;
+    const float *c = padded + padded_floats(rx, ry, rz);
+    for (int l = 0; l < level; ++l) c += 2 * coarse_cells(rx, ry, rz, l);
+    coarse_dims(rx, ry, rz, level, G.cx, G.cy, G.cz);
+    G.cshift = DSDF_COARSE_SHIFT(level);
+    G.coarse = c + coarse_cells(rx, ry, rz, level);
     return G;
 }
 
-// March step (world units) of the per-pixel empty-space proof, or 0 when the sample rays of a pixel may
-// stray further from the pixel's centre ray than the dilation margin of the coarse min-grid covers:
-// lateral deviation <= t_far * (0.7072 px * pixel size); lookup support 2.5 voxels; half a step.
-static float skip_step(const dsdf_camera *cams, int nv, int W, int rx, int ry, int rz) {
+// March step (world units) of the per-pixel empty-space proof on coarse level `level`, or 0 when the
+// sample rays of a pixel may stray further from the pixel's centre ray than the dilation margin (one
+// block) covers: lateral deviation <= t_far * (0.7072 px * pixel size); lookup support 2.5 voxels; half a step.
+static float skip_step(const dsdf_camera *cams, int nv, int W, int rx, int ry, int rz, int level) {
     int rmax = rx > ry ? (rx > rz ? rx : rz) : (ry > rz ? ry : rz);
     float worst = 0.f;
     for (int i = 0; i < nv; ++i) {
@@ -789,10 +857,21 @@ static float skip_step(const dsdf_camera *cams, int nv, int W, int rx, int ry, i
         float rho = t_far * 0.7072f * (2.f * cams[i].tan_half_fov / (float)W) * (float)rmax;
         worst = rho > worst ? rho : worst;
     }
-    float step_vox = 2.f * ((float)DSDF_COARSE - 2.5f - worst);
+    const float C = (float)(1 << DSDF_COARSE_SHIFT(level));
+    float step_vox = 2.f * (C - 2.5f - worst);
     if (step_vox < 1.f) return 0.f;
-    if (step_vox > (float)DSDF_COARSE) step_vox = (float)DSDF_COARSE;
+    if (step_vox > C) step_vox = C;
     return step_vox / (float)rmax;
+}
+
+// Finest coarse level whose dilation margin covers this view batch (-1: none, trace every pixel).
+static int skip_level(const dsdf_camera *cams, int nv, int W, int rx, int ry, int rz, float &step) {
+    for (int level = DSDF_COARSE_LEVELS - 1; level >= 0; --level) {
+        step = skip_step(cams, nv, W, rx, ry, rz, level);
+        if (step > 0.f) return level;
+    }
+    step = 0.f;
+    return -1;
 }
 
 // Parameters of a render pass.  The silhouette integrator consumes only the hit FLAG of a sample
@@ -832,8 +911,9 @@ void dsdf_default_params(dsdf_params *p) {
 }
 
 size_t dsdf_padded_size(int rx, int ry, int rz) {
-    size_t nc = (size_t)((rx + DSDF_COARSE - 1) / DSDF_COARSE) * ((ry + DSDF_COARSE - 1) / DSDF_COARSE) * ((rz + DSDF_COARSE - 1) / DSDF_COARSE);
-    return padded_floats(rx, ry, rz) + 2 * nc;
+    size_t n = padded_floats(rx, ry, rz);
+    for (int l = 0; l < DSDF_COARSE_LEVELS; ++l) n += 2 * coarse_cells(rx, ry, rz, l);
+    return n;
 }
 
 int dsdf_pad_grid(const float *data, int rx, int ry, int rz, float *padded, void *stream) {
@@ -843,12 +923,18 @@ int dsdf_pad_grid(const float *data, int rx, int ry, int rz, float *padded, void
     hipLaunchKernelGGL(k_pad_grid, dim3(grid), dim3(256), 0, (hipStream_t)stream, data, rx, ry, rz, padded);
     int rc = check_launch("k_pad_grid");
     if (rc) return rc;
-    // conservative min-grid for the empty-space proof
-    int cx = (rx + DSDF_COARSE - 1) / DSDF_COARSE, cy = (ry + DSDF_COARSE - 1) / DSDF_COARSE, cz = (rz + DSDF_COARSE - 1) / DSDF_COARSE;
-    int nc = cx * cy * cz;
-    float *c0 = padded + n, *c1 = c0 + nc;
-    hipLaunchKernelGGL(k_coarse_min, dim3((nc + 63) / 64), dim3(64), 0, (hipStream_t)stream, data, rx, ry, rz, c0, cx, cy, cz);
-    hipLaunchKernelGGL(k_coarse_dilate, dim3((nc + 63) / 64), dim3(64), 0, (hipStream_t)stream, c0, c1, cx, cy, cz);
+    // conservative min-grids for the empty-space proof
+    float *c0 = padded + n;
+    for (int l = 0; l < DSDF_COARSE_LEVELS; ++l) {
+        int cx, cy, cz;
+        coarse_dims(rx, ry, rz, l, cx, cy, cz);
+        int nc = cx * cy * cz;
+        float *c1 = c0 + nc;
+        hipLaunchKernelGGL(k_coarse_min, dim3((nc + 63) / 64), dim3(64), 0, (hipStream_t)stream, data, rx, ry, rz, c0, cx, cy, cz,
+                           1 << DSDF_COARSE_SHIFT(l));
+        hipLaunchKernelGGL(k_coarse_dilate, dim3((nc + 63) / 64), dim3(64), 0, (hipStream_t)stream, c0, c1, cx, cy, cz);
+        c0 = c1 + nc;
+    }
     return check_launch("k_coarse_min/dilate");
 }
 
@@ -904,11 +990,15 @@ int dsdf_render_forward(const float *padded, int rx, int ry, int rz, const dsdf_
                                      seeds ? seeds[v0 + i] : 0u, integrator, flags);
         if (hipMemsetAsync(ws.block, 0, nv * Wb * Hb * 2 * sizeof(float), st) != hipSuccess)
             return fail(DSDF_ERR_LAUNCH, "hipMemsetAsync(block) failed");
-        const float step = (flags & DSDF_NO_SKIP) ? 0.f : skip_step(cams + v0, nv, width, rx, ry, rz);
+        float step = 0.f;
+        const int level = (flags & DSDF_NO_SKIP) ? -1 : skip_level(cams + v0, nv, width, rx, ry, rz, step);
         const unsigned char *skip = nullptr;
-        if (step > 0.f) {
-            hipLaunchKernelGGL(k_pixel_skip, dim3((unsigned)((Wb * Hb + 255) / 256), nv), dim3(256), 0, st, G, pp, VB, ws.skip, step);
+        if (level >= 0) {
+            hipLaunchKernelGGL(k_pixel_skip, dim3((unsigned)((Wb * Hb + 255) / 256), nv), dim3(256), 0, st,
+                               device_view(padded, rx, ry, rz, *prm, level), pp, VB, ws.skip, step);
             if ((rc = check_launch("k_pixel_skip"))) return rc;
+            hipLaunchKernelGGL(k_skip_dilate, dim3((unsigned)((Wb * Hb + 255) / 256), nv), dim3(256), 0, st, VB, ws.skip);
+            if ((rc = check_launch("k_skip_dilate"))) return rc;
             skip = ws.skip;
         }
         if (spp % 64 == 0)
@@ -927,8 +1017,8 @@ int dsdf_render_forward(const float *padded, int rx, int ry, int rz, const dsdf_
 
 int dsdf_render_backward(const float *padded, int rx, int ry, int rz, const dsdf_params *prm, const dsdf_camera *cams,
                          int n_views, int width, int height, int spp, const float *offsets, const uint32_t *seeds,
-                         int integrator, int flags, const float *grad_image, float *grad_grid, float *image_out,
-                         void *workspace, size_t workspace_bytes, int64_t *stats, void *stream) {
+                         int integrator, int flags, const float *grad_image, float *grad_grid, float *grad_p,
+                         float *image_out, void *workspace, size_t workspace_bytes, int64_t *stats, void *stream) {
     int rc = check_render_args(padded, rx, ry, rz, prm, cams, n_views, width, height, spp, integrator, workspace,
                                workspace_bytes);
     if (rc) return rc;
@@ -950,11 +1040,15 @@ int dsdf_render_backward(const float *padded, int rx, int ry, int rz, const dsdf
                                      seeds ? seeds[v0 + i] : 0u, integrator, flags);
         if (hipMemsetAsync(ws.block, 0, nv * Wb * Hb * 2 * sizeof(float), st) != hipSuccess)
             return fail(DSDF_ERR_LAUNCH, "hipMemsetAsync(workspace) failed");
-        const float step = (flags & DSDF_NO_SKIP) ? 0.f : skip_step(cams + v0, nv, width, rx, ry, rz);
+        float step = 0.f;
+        const int level = (flags & DSDF_NO_SKIP) ? -1 : skip_level(cams + v0, nv, width, rx, ry, rz, step);
         const unsigned char *skip = nullptr;
-        if (step > 0.f) {
-            hipLaunchKernelGGL(k_pixel_skip, dim3((unsigned)((Wb * Hb + 255) / 256), nv), dim3(256), 0, st, G, pp, VB, ws.skip, step);
+        if (level >= 0) {
+            hipLaunchKernelGGL(k_pixel_skip, dim3((unsigned)((Wb * Hb + 255) / 256), nv), dim3(256), 0, st,
+                               device_view(padded, rx, ry, rz, *prm, level), pp, VB, ws.skip, step);
             if ((rc = check_launch("k_pixel_skip"))) return rc;
+            hipLaunchKernelGGL(k_skip_dilate, dim3((unsigned)((Wb * Hb + 255) / 256), nv), dim3(256), 0, st, VB, ws.skip);
+            if ((rc = check_launch("k_skip_dilate"))) return rc;
             skip = ws.skip;
         }
         if (spp % 64 == 0)
@@ -973,7 +1067,7 @@ int dsdf_render_backward(const float *padded, int rx, int ry, int rz, const dsdf
                            grad_image + (size_t)v0 * width * height * 3, width, height, ws.block_adj);
         if ((rc = check_launch("k_develop_adjoint"))) return rc;
         hipLaunchKernelGGL(k_backward, dim3(ws.nblk, nv), dim3(64), 0, st, G, pp, VB, q, ws.block_adj, grad_grid,
-                           (unsigned long long *)stats);
+                           grad_p, (unsigned long long *)stats);
         if ((rc = check_launch("k_backward"))) return rc;
     }
     return DSDF_OK;

@@ -24,12 +24,16 @@ struct Lane {
     CamRay ray;
 };
 
+DSDF_HD void lane_pixel(const ViewArgs &A, uint32_t lane, int &px, int &py) {
+    uint32_t pix = lane / (uint32_t)A.spp;
+    py = (int)(pix / (uint32_t)A.Wb);
+    px = (int)(pix - (uint32_t)py * (uint32_t)A.Wb);
+}
+
 // lane -> pixel, jitter, camera ray (reparam.py:140-171, 90-95)
 DSDF_HD Lane lane_setup(const ViewArgs &A, const dsdf_params &P, uint32_t lane) {
     Lane L;
-    uint32_t pix = lane / (uint32_t)A.spp;
-    L.py = (int)(pix / (uint32_t)A.Wb);
-    L.px = (int)(pix - (uint32_t)L.py * (uint32_t)A.Wb);
+    lane_pixel(A, lane, L.px, L.py);
     float r0, r1;
     if (A.offsets) { r0 = A.offsets[2 * (size_t)lane]; r1 = A.offsets[2 * (size_t)lane + 1]; }
     else sampler_next_2d(A.seed, lane, r0, r1);
@@ -84,7 +88,9 @@ DSDF_HD void splat_lane(float *block, int Wb, int Hb, float u, float v, float va
 }
 
 // One 64-tap scatter into dL/dsdf: grad[tap] += cv * W_tap + cg . (res * dW_tap) at point x.
-struct ScatterReq { bool on; V3 x; float cv; V3 cg; };
+// p_bar: the same site's contribution to dL/d(sdf.p) -- the grid is looked up at x - p, so
+// dv = -g.dp and dg = -H dp:  p_bar = -(cv * g + H cg).
+struct ScatterReq { bool on; V3 x; float cv; V3 cg; V3 p_bar; };
 
 // Adjoint of one gradient-pass sample.  `tr` holds the (detached) trace outputs,
 // block_adj the adjoint of the 2-channel film block.  Produces up to two scatter
@@ -174,6 +180,7 @@ DSDF_HD bool lane_backward(const GridView &G, const dsdf_params &P, const ViewAr
         float v0_bar = t_bar / c;
         dir_bar = dir_bar + tr.its_t * p_bar + (v0_bar * tr.its_t) * ghit;
         req[1].on = true; req[1].x = phit; req[1].cv = v0_bar; req[1].cg = G_bar;
+        req[1].p_bar = -(v0_bar * ghit + symmul(Hhit, G_bar));
         did = true;
     }
     // --- warp channel
@@ -183,6 +190,7 @@ DSDF_HD bool lane_backward(const GridView &G, const dsdf_params &P, const ViewAr
             float vw_bar = dot(wc.cdir, dir_bar) + wc.a * div_bar;
             V3 gw_bar = div_bar * wc.b;
             req[0].on = true; req[0].x = fma3(tr.warp_t, d, o); req[0].cv = vw_bar; req[0].cg = gw_bar;
+            req[0].p_bar = -(vw_bar * wc.g + symmul(wc.H, gw_bar));
             did = true;
         }
     }

@@ -63,14 +63,15 @@ DSDF_HD V3 symmul(const float H[6], V3 a) {
 // per axis reproduce per-tap clamp-to-edge exactly (Dr.Jit wrap mode Clamp).
 // ---------------------------------------------------------------------------
 #define DSDF_APRON 3
-#define DSDF_COARSE 8          /* fine voxels per coarse block of the conservative min-grid */
+#define DSDF_COARSE_LEVELS 2   /* conservative min-grids over blocks of 8^3 (level 0) and 4^3 (level 1) voxels */
+#define DSDF_COARSE_SHIFT(level) (3 - (level))
 struct GridView {
     const float *p;
     int rx, ry, rz;
     int sx, sxy;
     float tx, ty, tz;   // sdf.p translation
-    const float *coarse;   // (cz,cy,cx) dilated block minima (device only; nullptr = absent)
-    int cx, cy, cz;
+    const float *coarse;   // (cz,cy,cx) dilated block minima of ONE level (device only; nullptr = absent)
+    int cx, cy, cz, cshift;   // blocks per axis, log2(voxels per block)
 };
 
 DSDF_HD GridView make_view(const float *padded, int rx, int ry, int rz, const dsdf_params &prm) {
@@ -78,7 +79,7 @@ DSDF_HD GridView make_view(const float *padded, int rx, int ry, int rz, const ds
     g.p = padded; g.rx = rx; g.ry = ry; g.rz = rz;
     g.sx = rx + 2 * DSDF_APRON; g.sxy = g.sx * (ry + 2 * DSDF_APRON);
     g.tx = prm.sdf_p[0]; g.ty = prm.sdf_p[1]; g.tz = prm.sdf_p[2];
-    g.cx = (rx + DSDF_COARSE - 1) / DSDF_COARSE; g.cy = (ry + DSDF_COARSE - 1) / DSDF_COARSE; g.cz = (rz + DSDF_COARSE - 1) / DSDF_COARSE;
+    g.cx = g.cy = g.cz = 0; g.cshift = 0;
     g.coarse = nullptr;
     return g;
 }
@@ -199,9 +200,9 @@ DSDF_HD void eval_cubic_rows(const GridView &G, const CubicCell &c, const Rows &
     float dwx[4], dwy[4], dwz[4], ddwx[4], ddwy[4], ddwz[4];
     bspline_dw(c.ax, dwx); bspline_dw(c.ay, dwy); bspline_dw(c.az, dwz);
     if (ORDER >= 2) { bspline_ddw(c.ax, ddwx); bspline_ddw(c.ay, ddwy); bspline_ddw(c.az, ddwz); }
-    // scalar FMA chains (full-rate v_fma_f32; no register-pair packing moves)
     float av = 0.f, agx = 0.f, agy = 0.f, agz = 0.f;
     float axx = 0.f, ayy = 0.f, azz = 0.f, axy = 0.f, axz = 0.f, ayz = 0.f;
+    // scalar FMA chains (v_pk_fma_f32 issues at half rate on gfx950: packed variants measured no faster / slower)
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         float y00 = 0.f, y01 = 0.f, y02 = 0.f, y10 = 0.f, y11 = 0.f, y20 = 0.f;  // y{dy}{dx}
@@ -635,7 +636,7 @@ DSDF_HD bool warp_weight_positive(const GridView &G, const dsdf_params &P, V3 o,
     return fmaxf(fac, 0.f) * tr.warp_weight > 0.f;
 }
 
-struct WarpCoef { V3 cdir; float a; V3 b; float div; };
+struct WarpCoef { V3 cdir; float a; V3 b; float div; V3 g; float H[6]; };   // g, H: SDF gradient / Hessian at x_warp
 
 DSDF_HD bool warp_coefficients(const GridView &G, const dsdf_params &P, V3 o, V3 d, const TraceOut &tr, WarpCoef &wc) {
     float t = tr.warp_t;
@@ -691,6 +692,8 @@ DSDF_HD bool warp_coefficients(const GridView &G, const dsdf_params &P, V3 o, V3
     float T = fmaxf(P.clamping_thresh, t);                           // warp.py:82
     wc.cdir = (-w / T) * Pn;
     wc.div = a * v + dot(wc.b, g);
+    wc.g = g;
+    for (int k = 0; k < 6; ++k) wc.H[k] = H[k];
     return true;
 }
 

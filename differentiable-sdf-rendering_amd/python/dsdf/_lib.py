@@ -57,7 +57,7 @@ SYMBOLS = {
     'dsdf_render_backward': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(DsdfParams),
                                        C.POINTER(DsdfCamera), C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                        C.POINTER(C.c_uint32), C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
-                                       C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
+                                       C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
 }
 
 

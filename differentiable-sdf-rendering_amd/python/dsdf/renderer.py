@@ -79,6 +79,12 @@ class SdfGrid:
         self.device = data.device
         return self
 
+    def set_translation(self, p):
+        """`sdf.p` (python/shapes.py:389, 412): lookups happen at x - p."""
+        px, py, pz = (float(v) for v in (p.detach().cpu().tolist() if isinstance(p, torch.Tensor) else p))
+        self.params.sdf_p[0], self.params.sdf_p[1], self.params.sdf_p[2] = px, py, pz
+        return self
+
     @property
     def shape(self):
         return (self.rz, self.ry, self.rx)
@@ -162,8 +168,10 @@ def render_forward(grid, sensors, spp, seeds=None, offsets=None, integrator=DSDF
 
 
 def render_backward(grid, sensors, spp, grad_image, grad_grid=None, seeds=None, offsets=None,
-                    integrator=DSDF_SILHOUETTE, reparam=True, stats=None, return_image=False, empty_space_skip=True):
-    """`ReparamIntegrator.render_backward`: accumulates dL/dsdf into grad_grid (Z,Y,X)."""
+                    integrator=DSDF_SILHOUETTE, reparam=True, stats=None, return_image=False, empty_space_skip=True,
+                    grad_p=None):
+    """`ReparamIntegrator.render_backward`: accumulates dL/dsdf into grad_grid (Z,Y,X) and, if given,
+    dL/d(sdf.p) into grad_p (3 floats on the device; `sdf.p`, python/shapes.py:471)."""
     lib = _lib.load()
     sensors, cams, W, H = _views(sensors)
     nv = len(sensors)
@@ -179,6 +187,10 @@ def render_backward(grid, sensors, spp, grad_image, grad_grid=None, seeds=None, 
         if tuple(grad_grid.shape[:3]) != grid.shape or not grad_grid.is_contiguous():
             raise _lib.DsdfError("grad_grid must be a contiguous (Z,Y,X) tensor matching the grid")
         _require_dev(grad_grid, 'grad_grid')
+    if grad_p is not None:
+        if grad_p.numel() != 3 or grad_p.dtype != torch.float32 or not grad_p.is_contiguous():
+            raise _lib.DsdfError("grad_p must be a contiguous float32 tensor of 3 elements")
+        _require_dev(grad_p, 'grad_p')
     img = torch.empty(nv, H, W, 3, dtype=torch.float32, device=dev) if return_image else None
     wsb = lib.dsdf_render_workspace_size(W, H, int(spp), min(nv, MAX_VIEWS_PER_LAUNCH))
     ws = _workspace(dev, wsb)
@@ -186,7 +198,7 @@ def render_backward(grid, sensors, spp, grad_image, grad_grid=None, seeds=None, 
         _lib.check(lib.dsdf_render_backward(_ptr(grid.padded), grid.rx, grid.ry, grid.rz, C.byref(grid.params), cams, nv,
                                             W, H, int(spp), _ptr(offsets), cseeds, INTEGRATORS[integrator],
                                             (DSDF_REPARAM if reparam else 0) | (0 if empty_space_skip else DSDF_NO_SKIP),
-                                            _ptr(grad_image), _ptr(grad_grid),
+                                            _ptr(grad_image), _ptr(grad_grid), _ptr(grad_p),
                                             _ptr(img), _ptr(ws), wsb, _ptr(stats), _stream()))
     return (grad_grid, img) if return_image else grad_grid
 
@@ -219,9 +231,12 @@ class _RenderOp(torch.autograd.Function):
     independent (seed_grad, spp_grad) gradient pass."""
 
     @staticmethod
-    def forward(ctx, data, grid, sensors, spp, seed, spp_grad, seed_grad, integrator, reparam):
+    def forward(ctx, data, grid, sensors, spp, seed, spp_grad, seed_grad, integrator, reparam, p=None):
         ctx.cfg = (grid, sensors, spp_grad, seed_grad, integrator, reparam)
         ctx.data_shape = data.shape
+        ctx.p_meta = None if p is None else (p.shape, p.dtype, p.device)
+        if p is not None:
+            grid.set_translation(p)
         n = len(sensors)
         return render_forward(grid, sensors, spp, seeds=[seed + i for i in range(n)], integrator=integrator,
                               reparam=reparam)
@@ -230,14 +245,22 @@ class _RenderOp(torch.autograd.Function):
     def backward(ctx, grad_out):
         grid, sensors, spp_grad, seed_grad, integrator, reparam = ctx.cfg
         n = len(sensors)
+        want_p = ctx.p_meta is not None and ctx.needs_input_grad[9]
+        gp = torch.zeros(3, dtype=torch.float32, device=grid.device) if want_p else None
         g = render_backward(grid, sensors, spp_grad, grad_out.contiguous(), seeds=[seed_grad + i for i in range(n)],
-                            integrator=integrator, reparam=reparam)
-        return g.reshape(ctx.data_shape), None, None, None, None, None, None, None, None
+                            integrator=integrator, reparam=reparam, grad_p=gp)
+        if want_p:
+            shape, dtype, dev = ctx.p_meta
+            gp = gp.to(device=dev, dtype=dtype).reshape(shape)
+        return (g.reshape(ctx.data_shape) if ctx.needs_input_grad[0] else None, None, None, None, None, None, None,
+                None, None, gp)
 
 
-def render(data, grid, sensors, spp, seed=0, spp_grad=None, seed_grad=0, integrator=DSDF_SILHOUETTE, reparam=True):
+def render(data, grid, sensors, spp, seed=0, spp_grad=None, seed_grad=0, integrator=DSDF_SILHOUETTE, reparam=True,
+           p=None):
     """Differentiable render of `data` (the tensor behind `grid`) for one or more
-    sensors: returns (n_views,H,W,3) attached to `data`."""
+    sensors: returns (n_views,H,W,3) attached to `data` and, if given, to the
+    translation `p` (3,) (`SamplingIntegrator.sdf.p`)."""
     sensors = list(sensors) if isinstance(sensors, (list, tuple)) else [sensors]
     return _RenderOp.apply(data, grid, sensors, int(spp), int(seed), int(spp_grad or spp), int(seed_grad),
-                           integrator, reparam)
+                           integrator, reparam, p)

@@ -60,6 +60,8 @@ class SceneParameters(dict):
         integ = self._scene.integrator()
         if SDF_DEFAULT_KEY in self:
             integ.sdf.set_data(self[SDF_DEFAULT_KEY])
+        if SDF_DEFAULT_KEY_P in self:
+            integ.sdf.p = self[SDF_DEFAULT_KEY_P]
         integ.parameters_changed(list(self))
 
 
@@ -93,6 +95,7 @@ class ReparamIntegrator:
             raise ValueError("integrator has no SDF (sdf_filename / props['sdf'])")
         wf = self.warp_field if self.warp_field is not None else DummyWarpField(self.sdf)
         wf.apply(self.sdf.grid.params)
+        self.sdf.grid.set_translation(self.sdf.p)
         return wf.reparameterize
 
     # -- plugin API ----------------------------------------------------------------------
@@ -111,10 +114,17 @@ class ReparamIntegrator:
         sens = self._sensors(scene, sensor)
         reparam = self._configured()
         data = params[SDF_DEFAULT_KEY]
+        pt = params[SDF_DEFAULT_KEY_P] if SDF_DEFAULT_KEY_P in params else None
+        want_p = isinstance(pt, torch.Tensor) and pt.requires_grad
+        gp = torch.zeros(3, dtype=torch.float32, device=self.sdf.grid.device) if want_p else None
         g = dsdf.render_backward(self.sdf.grid, sens, spp or 4, grad_in.reshape(len(sens), *grad_in.shape[-3:]).contiguous(),
-                                 seeds=[seed + i for i in range(len(sens))], integrator=self.integrator_id, reparam=reparam)
+                                 seeds=[seed + i for i in range(len(sens))], integrator=self.integrator_id, reparam=reparam,
+                                 grad_p=gp)
         g = g.reshape(data.shape)
         data.grad = g if data.grad is None else data.grad + g
+        if want_p:
+            gp = gp.to(device=pt.device, dtype=pt.dtype).reshape(pt.shape)
+            pt.grad = gp if pt.grad is None else pt.grad + gp
 
     def render_forward(self, scene, params, sensor=0, seed=0, spp=0):
         raise NotImplementedError("forward-mode gradients (render_forward) are outside the supported path")

@@ -86,8 +86,8 @@ void        dsdf_default_params(dsdf_params *p);
 
 /* Number of floats of the library's internal grid buffer for an (rz,ry,rx) grid:
  * the padded copy (clamp-to-edge apron of 3 voxels per side, so the 4^3 B-spline
- * footprint is always four contiguous 16-byte rows) followed by a coarse min-grid
- * (8^3-voxel block minima and their 3x3x3 dilation) used to prove pixels empty. */
+ * footprint is always four contiguous 16-byte rows) followed by two coarse min-grids
+ * (8^3- and 4^3-voxel block minima and their 3x3x3 dilations) used to prove pixels empty. */
 size_t dsdf_padded_size(int rx, int ry, int rz);
 
 /* Builds the padded copy.  Replaces `Texture3f.set_tensor` / `Grid3d.update`
@@ -146,6 +146,8 @@ int dsdf_render_forward(const float *padded, int rx, int ry, int rz, const dsdf_
  * re-renders each view at `spp` with the reparameterisation attached and
  * back-propagates grad_image (n_views x H x W x 3) into
  * grad_grid (rz,ry,rx), ACCUMULATING (like dr.grad(params[key])).
+ * grad_p (optional, 3 device floats) accumulates dL/d(sdf.p), the gradient with
+ * respect to the grid translation `SamplingIntegrator.sdf.p` (python/shapes.py:471).
  * image_out (optional) receives the gradient-pass image.  Same sampler rules
  * as dsdf_render_forward (the reference uses seed_grad / spp_grad here,
  * python/shape_opt.py:78-80). */
@@ -153,7 +155,7 @@ int dsdf_render_backward(const float *padded, int rx, int ry, int rz, const dsdf
                          const dsdf_camera *cams, int n_views, int width, int height, int spp,
                          const float *offsets, const uint32_t *seeds,
                          int integrator, int flags,
-                         const float *grad_image, float *grad_grid, float *image_out,
+                         const float *grad_image, float *grad_grid, float *grad_p, float *image_out,
                          void *workspace, size_t workspace_bytes,
                          int64_t *stats, void *stream);
 

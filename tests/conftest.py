@@ -74,10 +74,11 @@ class HostHarness:
         gi = np.ascontiguousarray(grad_image, np.float32)
         gg = np.zeros(grid.shape, np.float32)
         img = np.zeros((H, W, 3), np.float32)
+        self.last_grad_p = np.zeros(3, np.float32)
         rz, ry, rx = grid.shape
         self.lib.hh_render_backward(self._p(grid), rx, ry, rz, C.byref(self.params), self._p(cam), W, H, spp,
                                     self._p(offsets), C.c_uint(seed), integrator, int(reparam), self._p(gi),
-                                    self._p(gg), self._p(img))
+                                    self._p(gg), self._p(img), self._p(self.last_grad_p))
         return gg, img
 
     def sampler(self, seed, n):

@@ -101,7 +101,7 @@ void hh_render_forward(const float *data, int rx, int ry, int rz, const dsdf_par
 
 void hh_render_backward(const float *data, int rx, int ry, int rz, const dsdf_params *prm, const dsdf_camera *cam,
                         int W, int H, int spp, const float *offsets, unsigned seed, int integrator, int flags,
-                        const float *grad_image, float *grad_grid, float *image) {
+                        const float *grad_image, float *grad_grid, float *image, float *grad_p) {
     std::vector<float> p = pad(data, rx, ry, rz);
     GridView G = make_view(p.data(), rx, ry, rz, *prm);
     ViewArgs A = view_args(cam, W, H, spp, offsets, seed, integrator, flags);
@@ -130,7 +130,10 @@ void hh_render_backward(const float *data, int rx, int ry, int rz, const dsdf_pa
         ScatterReq req[2];
         lane_backward(G, *prm, A, L, tr[lane], badj.data(), req);
         for (int r = 0; r < 2; ++r)
-            if (req[r].on) scatter_cubic(G, grad_grid, req[r].x, req[r].cv, req[r].cg, PlainAdd());
+            if (req[r].on) {
+                scatter_cubic(G, grad_grid, req[r].x, req[r].cv, req[r].cg, PlainAdd());
+                if (grad_p) { grad_p[0] += req[r].p_bar.x; grad_p[1] += req[r].p_bar.y; grad_p[2] += req[r].p_bar.z; }
+            }
     }
 }
 

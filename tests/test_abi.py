@@ -34,8 +34,8 @@ def test_default_params_and_sizes(built):
     assert abs(p.trace_eps - 1e-6) < 1e-12 and abs(p.edge_eps - 0.01) < 1e-9 and p.weight_strategy == 6
     assert p.refine_steps == 10 and abs(p.clamping_thresh - 0.05) < 1e-9
     assert C.sizeof(dsdf.DsdfParams) == 64 and C.sizeof(dsdf.DsdfCamera) == 64
-    assert lib.dsdf_padded_size(256, 256, 256) == 262 ** 3 + 2 * 32 ** 3          # padded copy + coarse min-grids
-    assert lib.dsdf_padded_size(4, 5, 6) == 10 * 11 * 12 + 2
+    assert lib.dsdf_padded_size(256, 256, 256) == 262 ** 3 + 2 * 32 ** 3 + 2 * 64 ** 3   # padded copy + coarse min-grids
+    assert lib.dsdf_padded_size(4, 5, 6) == 10 * 11 * 12 + 2 + 2 * (1 * 2 * 2)
     ws = lib.dsdf_render_workspace_size(512, 512, 64, 1)
     assert ws >= 516 * 516 * 64 * 40 and lib.dsdf_render_workspace_size(0, 4, 4, 1) == 0
     assert lib.dsdf_render_workspace_size(512, 512, 64, 4) >= 4 * 516 * 516 * 64 * 40

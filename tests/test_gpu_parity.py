@@ -289,10 +289,11 @@ def test_large_spp_not_multiple_of_64(dsdf):
 
 
 @pytest.mark.parametrize('integ', [O.SILHOUETTE, O.SIMPLE_SHADING])
-def test_empty_space_skip_is_exact(dsdf, integ):
+@pytest.mark.parametrize('R,W', [(128, 128), (64, 160)])      # pixel footprint selects the 8^3 / the 4^3 min-grid
+def test_empty_space_skip_is_exact(dsdf, integ, R, W):
     """The per-pixel empty-space proof (coarse dilated min-grid) must not change any result: images and
     gradients with and without it agree to atomic-ordering noise, while far fewer steps are traced."""
-    R, W, H, spp = 128, 128, 128, 64
+    H, spp = W, 64
     data = O.blob_grid(R, n=16, seed=5).float().cuda()
     grid = dsdf.SdfGrid(data)
     sens = dsdf.get_regular_cameras(6, resx=W, resy=H)[:3]
@@ -340,3 +341,63 @@ def test_maximum_grid_size_512(dsdf):
         torch.cuda.empty_cache()
     assert rel_l2(imgs[512].cpu(), imgs[128].cpu()) < 0.05
     assert 0.05 < float(imgs[512].mean()) < 0.5
+
+
+@pytest.mark.parametrize('integ', [O.SILHOUETTE, O.SIMPLE_SHADING])
+def test_translation_parity_gpu(dsdf, integ):
+    """`SamplingIntegrator.sdf.p` (python/shapes.py:389, 412, 471): image and both gradients with a
+    non-zero grid translation against the oracle's autograd."""
+    case = make_case('blob32')
+    shift = [0.03, -0.02, 0.015]
+    cam = O.Camera(case['origin'])
+    data = case['grid'].clone().requires_grad_(True)
+    p = torch.tensor(shift, dtype=torch.float64, requires_grad=True)
+    ref = O.render(O.Grid3d(data, p), cam, case['W'], case['H'], case['spp'], case['offsets'].double(), integ)
+    (ref * case['grad_image'].double()).sum().backward()
+    grid = dev_grid(dsdf, case).set_translation(shift)
+    img = dsdf.render_forward(grid, sensor(dsdf, case), case['spp'], offsets=case['offsets'].cuda(), integrator=integ)[0]
+    assert rel_l2(img.cpu(), ref.detach()) < FWD_TOL
+    gp = torch.zeros(3, device='cuda')
+    gg = dsdf.render_backward(grid, sensor(dsdf, case), case['spp'], case['grad_image'].cuda()[None],
+                              offsets=case['offsets'].cuda(), integrator=integ, grad_p=gp)
+    assert rel_l2(gg.cpu(), data.grad) < GRAD_TOL
+    assert rel_l2(gp.cpu(), p.grad) < GRAD_TOL
+    # accumulation, like grad_grid
+    dsdf.render_backward(grid, sensor(dsdf, case), case['spp'], case['grad_image'].cuda()[None],
+                         offsets=case['offsets'].cuda(), integrator=integ, grad_p=gp)
+    assert rel_l2(gp.cpu(), 2 * p.grad) < GRAD_TOL
+
+
+@pytest.mark.parametrize('integ', [O.SILHOUETTE, O.SIMPLE_SHADING])
+def test_translation_gradient_vs_finite_differences_gpu(dsdf, integ):
+    """The reference's forward-gradient validation differentiates with respect to a translation
+    (figures/result_utils.py:126-161); here dL/d(sdf.p) from the autograd op against central
+    differences of the un-reparameterised render with common random numbers, 2048 spp, around a
+    non-zero translation (same sphere scene as the data-gradient check above)."""
+    R, W, H, spp = 64, 48, 48, 2048
+    p0 = [0.05, -0.04, 0.03]
+    data = O.sphere_grid(R, radius=0.3).float().cuda()
+    sens = dsdf.get_regular_cameras(3, resx=W, resy=H)
+    yy, xx = torch.meshgrid(torch.arange(H, device='cuda'), torch.arange(W, device='cuda'), indexing='ij')
+    G = torch.stack([xx / W, yy / H, (xx + yy) / (W + H)], -1).float()[None].repeat(3, 1, 1, 1).contiguous()
+    p = torch.tensor(p0, device='cuda', requires_grad=True)
+    grid = dsdf.SdfGrid(data)
+    img = dsdf.render(data, grid, sens, spp=4, seed=1, spp_grad=spp, seed_grad=11, integrator=integ, p=p)
+    (img * G).sum().backward()
+    assert p.grad is not None and p.grad.shape == (3,)
+
+    def L(shift):
+        g = dsdf.SdfGrid(data).set_translation(shift)
+        return float((dsdf.render_forward(g, sens, spp, seeds=[11, 12, 13], integrator=integ, reparam=False) * G).sum())
+    eps = 2e-3
+    fds = []
+    for a in range(3):
+        lo, hi = list(p0), list(p0)
+        lo[a] -= eps
+        hi[a] += eps
+        fds.append((L(hi) - L(lo)) / (2 * eps))
+    ad = [float(v) for v in p.grad]
+    scale = max(abs(v) for v in fds)
+    # 10 %: the shading term's interior gradient has a visible estimator bias at 64^3 / 48^2 (measured 9 % on one
+    # axis); the implementation itself is pinned to the oracle's autograd by test_translation_parity_gpu
+    assert all(abs(x - y) < 0.10 * scale + 1.0 for x, y in zip(ad, fds)), (ad, fds)

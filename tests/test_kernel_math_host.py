@@ -100,3 +100,16 @@ def test_fp32_noise_floor():
     e = rel_l2(g32, g64)
     assert 1e-5 < e < GRAD_TOL
 
+
+@pytest.mark.parametrize('integ', [O.SILHOUETTE, O.SIMPLE_SHADING])
+def test_translation_gradient_host(harness, integ):
+    """dL/d(sdf.p) (python/shapes.py:389, 412, 471: `sdf.p` is a differentiable parameter; the
+    reference's forward-gradient validation differentiates with respect to it) against autograd."""
+    case = make_case('blob32')
+    cam = O.Camera(case['origin'])
+    p = torch.zeros(3, dtype=torch.float64, requires_grad=True)
+    img = O.render(O.Grid3d(case['grid'], p), cam, case['W'], case['H'], case['spp'], case['offsets'].double(), integ)
+    (img * case['grad_image'].double()).sum().backward()
+    harness.render_backward(case['grid'].float().numpy(), cam_params(case), case['W'], case['H'], case['spp'],
+                            case['offsets'].numpy(), case['grad_image'].numpy(), integ)
+    assert rel_l2(harness.last_grad_p, p.grad.numpy()) < GRAD_TOL
