@@ -17,7 +17,19 @@ struct ViewArgs {
     int integrator, flags;
     uint32_t seed;
     const float *offsets;   // per-lane (r0,r1) or nullptr -> built-in sampler
+    const float *emitter_u; // sdf_direct_reparam: per-lane emitter sample or nullptr -> built-in sampler
 };
+
+// Scene-side inputs of sdf_direct_reparam (shared by all views of a call).
+struct ShadeArgs {
+    AlbedoView albedo;      // 'main-bsdf.reflectance.volume.data'
+    float env[3];           // radiance of the constant environment emitter
+    int hide_emitters;      // sdf_direct_reparam.py:12
+    float *grad_albedo;     // dL/d(albedo) accumulator (gradient pass) or nullptr
+};
+
+// Film block channels: value(s) + weight.  Silhouette / simple shading emit R=G=B -> one value channel.
+DSDF_HD int film_channels(int integrator) { return integrator == DSDF_DIRECT ? 4 : 2; }
 
 struct Lane {
     int px, py;             // block pixel (0..Wb-1, 0..Hb-1)
@@ -87,10 +99,96 @@ DSDF_HD void splat_lane(float *block, int Wb, int Hb, float u, float v, float va
     }
 }
 
+// Same for the 4-channel (r,g,b,weight) block of sdf_direct_reparam.
+template <class Adder>
+DSDF_HD void splat_lane_rgb(float *block, int Wb, int Hb, float u, float v, const float rgb[3], Adder add) {
+    float pfx = u + (DSDF_BORDER - 0.5f), pfy = v + (DSDF_BORDER - 0.5f);
+    int x0 = (int)ceilf(pfx - DSDF_FILTER_RADIUS), y0 = (int)ceilf(pfy - DSDF_FILTER_RADIUS);
+    float wx[4], wy[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        wx[i] = gauss_f((float)(x0 + i) - pfx);
+        wy[i] = gauss_f((float)(y0 + i) - pfy);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        int qy = y0 + j;
+        if (qy < 0 || qy >= Hb) continue;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int qx = x0 + i;
+            if (qx < 0 || qx >= Wb) continue;
+            float f = wx[i] * wy[j];
+            if (f == 0.f) continue;
+            float *dst = block + 4 * ((size_t)qy * Wb + qx);
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+                if (rgb[c] != 0.f) add(dst + c, f * rgb[c]);
+            add(dst + 3, f);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// sdf_direct_reparam.sample() (integrators/sdf_direct_reparam.py:16-75, use_mis = False): emitter sampling of a
+// constant environment through a (reparameterised) shadow ray, diffuse BSDF with a trilinear albedo volume.
+// The primary determinant multiplies in at the caller.  `trs` receives the shadow-ray trace (its_t = inf
+// <=> unoccluded); a sample is `lit` when it hit, faces the sampled direction and the shadow ray escapes.
+// ---------------------------------------------------------------------------
+struct DirectHit { bool lit; V3 p, g, n; ShadowRay sr; };
+
+DSDF_HD void emitter_sample(const ViewArgs &A, uint32_t lane, float &e0, float &e1) {
+    if (A.emitter_u) { e0 = A.emitter_u[2 * (size_t)lane]; e1 = A.emitter_u[2 * (size_t)lane + 1]; }
+    else sampler_emitter_2d(A.seed, lane, e0, e1);
+}
+
+// geometry of the hit and its shadow ray (no tracing); returns false when the BSDF is zero for the sampled
+// direction (diffuse::eval needs both cosines positive)
+DSDF_HD bool direct_setup(const GridView &G, const ViewArgs &A, const Lane &L, uint32_t lane, float its_t, DirectHit &h) {
+    h.lit = false;
+    h.p = fma3(its_t, L.ray.d, L.ray.o);
+    float v; float H[6];
+    eval_cubic<1>(G, h.p, v, h.g, H);
+    h.n = h.g * rsqf(dot(h.g, h.g));
+    float e0, e1;
+    emitter_sample(A, lane, e0, e1);
+    h.sr = spawn_shadow_ray(h.p, h.n, square_to_uniform_sphere(e0, e1));
+    return dot(h.n, h.sr.d) > 0.f && dot(h.n, -L.ray.d) > 0.f;
+}
+
+DSDF_HD void direct_radiance(const ShadeArgs &S, const DirectHit &h, float rgb[3]) {
+    float alb[3]; V3 ag[3];
+    eval_trilinear(S.albedo, h.p, alb, ag);
+    float k = 4.f * dot(h.n, h.sr.d);                                  // (cos / pi) * (4 pi): bsdf * emitter / pdf
+#pragma unroll
+    for (int c = 0; c < 3; ++c) rgb[c] = alb[c] * k * S.env[c];
+}
+
+// forward value of one sample; `diff` selects the differentiable shadow trace (gradient pass)
+DSDF_HD void direct_value(const GridView &G, const dsdf_params &P, const ViewArgs &A, const ShadeArgs &S, const Lane &L,
+                          uint32_t lane, float its_t, bool diff, TraceOut &trs, float rgb[3]) {
+    rgb[0] = rgb[1] = rgb[2] = 0.f;
+    trs.its_t = 0.f; trs.warp_t = INFINITY; trs.warp_weight = 0.f; trs.weight_sum = 0.f;
+    trs.warp_t_d = mk(0.f, 0.f, 0.f); trs.warp_weight_d = mk(0.f, 0.f, 0.f); trs.steps = 0; trs.refine_steps = 0;
+    if (!(its_t < INFINITY)) {
+        if (!S.hide_emitters) { rgb[0] = S.env[0]; rgb[1] = S.env[1]; rgb[2] = S.env[2]; }   // :25-26, 33
+        return;
+    }
+    DirectHit h;
+    if (!direct_setup(G, A, L, lane, its_t, h)) return;
+    dsdf_params Ps = P;
+    Ps.refine_steps = 0;                                               // ray_test consumes only isfinite(its_t)
+    if (diff) trace_diff(G, Ps, h.sr.o, h.sr.d, h.sr.maxt, trs);
+    else trace_plain(G, Ps, h.sr.o, h.sr.d, h.sr.maxt, trs);
+    if (trs.its_t < INFINITY) return;                                  // occluded
+    direct_radiance(S, h, rgb);
+}
+
 // One 64-tap scatter into dL/dsdf: grad[tap] += cv * W_tap + cg . (res * dW_tap) at point x.
 // p_bar: the same site's contribution to dL/d(sdf.p) -- the grid is looked up at x - p, so
 // dv = -g.dp and dg = -H dp:  p_bar = -(cv * g + H cg).
 struct ScatterReq { bool on; V3 x; float cv; V3 cg; V3 p_bar; };
+struct AlbedoReq { bool on; V3 x; float a_bar[3]; };     // 8-tap x 3-channel scatter into dL/d(albedo)
 
 // Adjoint of one gradient-pass sample.  `tr` holds the (detached) trace outputs,
 // block_adj the adjoint of the 2-channel film block.  Produces up to two scatter
@@ -184,6 +282,131 @@ DSDF_HD bool lane_backward(const GridView &G, const dsdf_params &P, const ViewAr
         did = true;
     }
     // --- warp channel
+    if (A.flags & DSDF_REPARAM) {
+        WarpCoef wc;
+        if (warp_coefficients(G, P, o, d, tr, wc)) {
+            float vw_bar = dot(wc.cdir, dir_bar) + wc.a * div_bar;
+            V3 gw_bar = div_bar * wc.b;
+            req[0].on = true; req[0].x = fma3(tr.warp_t, d, o); req[0].cv = vw_bar; req[0].cg = gw_bar;
+            req[0].p_bar = -(vw_bar * wc.g + symmul(wc.H, gw_bar));
+            did = true;
+        }
+    }
+    return did;
+}
+
+// Adjoint of one gradient-pass sample of sdf_direct_reparam.  tr / trs: (detached) primary and shadow trace
+// outputs; block_adj: adjoint of the 4-channel film block.  Scatter requests: req[0] primary warp point,
+// req[1] hit point (t and the normal), req[2] shadow-ray warp point, areq the albedo volume.
+// With rgb_c = a_c(p) * 4 cos_o * env_c * det * det_e (values det = det_e = 1), cos_o = n . d_s':
+//   a_c-bar = A_c * 4 cos_o env_c,   cos-bar = sum_c A_c a_c 4 env_c,   n-bar = cos-bar d_s,   d_s'-bar = cos-bar n,
+//   div_s-bar = sum_c A_c rgb_c,     p-bar = sum_c a_c-bar grad a_c + H_p G-bar + (v_s-bar g_s + H_s g_s-bar)
+// (the last term because the shadow ray starts at the attached hit point: its lookups move with p), then
+// t-bar = p-bar . d, v0-bar = t-bar / (G . -d), d'-bar += t (p-bar + v0-bar G) as for simple shading.
+DSDF_HD bool lane_backward_direct(const GridView &G, const dsdf_params &P, const ViewArgs &A, const ShadeArgs &S,
+                                  const Lane &L, uint32_t lane, const TraceOut &tr, const TraceOut &trs,
+                                  const float *block_adj, ScatterReq req[3], AlbedoReq &areq) {
+    req[0].on = false; req[1].on = false; req[2].on = false; areq.on = false;
+    const V3 o = L.ray.o, d = L.ray.d;
+    const bool hit = tr.its_t < INFINITY;
+    Reproj rp = reproject(A.cam, P, o + d, A.W, A.H);
+    float pfx = rp.u + (DSDF_BORDER - 0.5f), pfy = rp.v + (DSDF_BORDER - 0.5f);
+    int x0 = (int)ceilf(pfx - DSDF_FILTER_RADIUS), y0 = (int)ceilf(pfy - DSDF_FILTER_RADIUS);
+    float rgb[3] = {0.f, 0.f, 0.f};
+    DirectHit h;
+    bool lit = false;
+    float alb[3] = {0.f, 0.f, 0.f}; V3 ag[3]; float cos_o = 0.f;
+    if (!hit) {
+        if (!S.hide_emitters) { rgb[0] = S.env[0]; rgb[1] = S.env[1]; rgb[2] = S.env[2]; }
+    } else {
+        lit = direct_setup(G, A, L, lane, tr.its_t, h) && !(trs.its_t < INFINITY);
+        if (lit) {
+            eval_trilinear(S.albedo, h.p, alb, ag);
+            cos_o = dot(h.n, h.sr.d);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) rgb[c] = alb[c] * 4.f * cos_o * S.env[c];
+        }
+    }
+    float a_c[3] = {0.f, 0.f, 0.f}, a_w = 0.f, u_bar = 0.f, v_bar = 0.f;
+    float wx[4], wy[4], dwx[4], dwy[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        float rx = (float)(x0 + i) - pfx, ry = (float)(y0 + i) - pfy;
+        wx[i] = gauss_f(rx); dwx[i] = gauss_df(rx);
+        wy[i] = gauss_f(ry); dwy[i] = gauss_df(ry);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        int qy = y0 + j;
+        if (qy < 0 || qy >= A.Hb) continue;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int qx = x0 + i;
+            if (qx < 0 || qx >= A.Wb) continue;
+            const float *ba = block_adj + 4 * ((size_t)qy * A.Wb + qx);
+            float f = wx[i] * wy[j];
+            float s = ba[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { a_c[c] = fmaf(f, ba[c], a_c[c]); s = fmaf(ba[c], rgb[c], s); }
+            a_w = fmaf(f, ba[3], a_w);
+            u_bar = fmaf(s, -dwx[i] * wy[j], u_bar);
+            v_bar = fmaf(s, -wx[i] * dwy[j], v_bar);
+        }
+    }
+    const float rgb_dot = rgb[0] * a_c[0] + rgb[1] * a_c[1] + rgb[2] * a_c[2];
+    float div_bar = rgb_dot + a_w;
+    float rw_bar = rp.inside ? div_bar : 0.f;
+    V3 dir_bar = mk(0.f, 0.f, 0.f);
+    {
+        float cot = 1.f / A.cam.tan_half_fov;
+        float iz = 1.f / rp.ref.z;
+        float ku = -0.5f * (float)A.W * cot, kv = ku;
+        V3 ref_bar = mk(u_bar * ku * iz, v_bar * kv * iz,
+                        -(u_bar * ku * rp.ref.x + v_bar * kv * rp.ref.y) * iz * iz);
+        float id2 = 1.f / (rp.dist * rp.dist);
+        ref_bar = ref_bar + rw_bar * mk(rp.ref.x * id2, rp.ref.y * id2, rp.ref.z * id2 - 3.f * iz);
+        dir_bar = mk(A.cam.left[0] * ref_bar.x + A.cam.up[0] * ref_bar.y + A.cam.dir[0] * ref_bar.z,
+                     A.cam.left[1] * ref_bar.x + A.cam.up[1] * ref_bar.y + A.cam.dir[1] * ref_bar.z,
+                     A.cam.left[2] * ref_bar.x + A.cam.up[2] * ref_bar.y + A.cam.dir[2] * ref_bar.z);
+    }
+    bool did = false;
+    if (lit) {
+        float vhit; V3 ghit; float Hhit[6];
+        eval_cubic<2>(G, h.p, vhit, ghit, Hhit);
+        const float gl = sqrtf(dot(ghit, ghit));
+        const V3 n = ghit * (1.f / gl);
+        V3 p_bar = mk(0.f, 0.f, 0.f);
+        float cos_bar = 0.f;
+        areq.on = true; areq.x = h.p;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float k = 4.f * S.env[c] * a_c[c];
+            areq.a_bar[c] = k * cos_o;
+            p_bar = fma3(k * cos_o, ag[c], p_bar);
+            cos_bar = fmaf(k, alb[c], cos_bar);
+        }
+        const V3 n_bar = cos_bar * h.sr.d, sd_bar = cos_bar * n;
+        const V3 G_bar = (n_bar - dot(n, n_bar) * n) * (1.f / gl);
+        if (A.flags & DSDF_REPARAM) {
+            WarpCoef ws;
+            if (warp_coefficients(G, P, h.sr.o, h.sr.d, trs, ws)) {
+                float vs_bar = dot(ws.cdir, sd_bar) + ws.a * rgb_dot;          // det_e multiplies the rgb channels only
+                V3 gs_bar = rgb_dot * ws.b;
+                V3 xs_bar = vs_bar * ws.g + symmul(ws.H, gs_bar);
+                req[2].on = true; req[2].x = fma3(trs.warp_t, h.sr.d, h.sr.o); req[2].cv = vs_bar; req[2].cg = gs_bar;
+                req[2].p_bar = -xs_bar;
+                p_bar = p_bar + xs_bar;
+            }
+        }
+        p_bar = p_bar + symmul(Hhit, G_bar);
+        const float cden = dot(ghit, -d);
+        const float t_bar = dot(p_bar, d);
+        const float v0_bar = t_bar / cden;
+        dir_bar = dir_bar + tr.its_t * p_bar + (v0_bar * tr.its_t) * ghit;
+        req[1].on = true; req[1].x = h.p; req[1].cv = v0_bar; req[1].cg = G_bar;
+        req[1].p_bar = -(v0_bar * ghit + symmul(Hhit, G_bar));
+        did = true;
+    }
     if (A.flags & DSDF_REPARAM) {
         WarpCoef wc;
         if (warp_coefficients(G, P, o, d, tr, wc)) {

@@ -614,6 +614,108 @@ DSDF_HD void sampler_next_2d(uint32_t seed, uint32_t lane, float &r0, float &r1)
     r0 = pcg32_float(r);
     r1 = pcg32_float(r);
 }
+// The `next_2d()` of sdf_direct_reparam's emitter sampling (sdf_direct_reparam.py:40): the lane's stream
+// has produced the film position (2 floats, reparam.py:147) and the wavelength sample (1, reparam.py:90).
+DSDF_HD void sampler_emitter_2d(uint32_t seed, uint32_t lane, float &e0, float &e1) {
+    uint32_t v0, v1;
+    sample_tea_32(seed, lane, v0, v1);
+    Pcg32 r;
+    r.state = 0; r.inc = ((uint64_t)v1 << 1u) | 1u;
+    pcg32_next(r);
+    r.state += (uint64_t)v0;
+    pcg32_next(r);
+    pcg32_next(r); pcg32_next(r); pcg32_next(r);
+    e0 = pcg32_float(r);
+    e1 = pcg32_float(r);
+}
+
+// ---------------------------------------------------------------------------
+// sdf_direct_reparam (integrators/sdf_direct_reparam.py:16-75) building blocks.  The BSDF and the emitter
+// come from scene files the reference does not ship; this repo fixes them as Mitsuba `diffuse` over a
+// trilinear reflectance volume on the unit cube and a `constant` environment emitter (oracle/sdf_oracle.py).
+// ---------------------------------------------------------------------------
+#define DSDF_RAY_EPSILON 8.94069671630859375e-05f      /* mitsuba math::RayEpsilon<float> */
+#define DSDF_SHADOW_EPSILON (10.f * DSDF_RAY_EPSILON)
+#define DSDF_ENV_DIST 4.0f                               /* constant emitter: ds.p = it.p + d * 2 * bsphere.radius */
+
+struct AlbedoView { const float *data; int rx, ry, rz; };      // (Z,Y,X,3) fp32, texel centres (i+0.5)/res, clamp
+
+struct TrilinearCell { int i0[3]; float a[3]; };
+DSDF_HD TrilinearCell trilinear_cell(const AlbedoView &A, V3 p) {
+    TrilinearCell c;
+    float pf[3] = {p.x * (float)A.rx - 0.5f, p.y * (float)A.ry - 0.5f, p.z * (float)A.rz - 0.5f};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        float f = floorf(pf[k]);
+        c.i0[k] = (int)f;
+        c.a[k] = pf[k] - f;
+    }
+    return c;
+}
+// value (3 channels) and spatial gradient per channel (d a_c / d p, scaled by res)
+DSDF_HD void eval_trilinear(const AlbedoView &A, V3 p, float val[3], V3 grad[3]) {
+    TrilinearCell c = trilinear_cell(A, p);
+    val[0] = val[1] = val[2] = 0.f;
+    grad[0] = grad[1] = grad[2] = mk(0.f, 0.f, 0.f);
+#pragma unroll
+    for (int dz = 0; dz < 2; ++dz)
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 2; ++dx) {
+                int ix = iclamp(c.i0[0] + dx, 0, A.rx - 1), iy = iclamp(c.i0[1] + dy, 0, A.ry - 1), iz = iclamp(c.i0[2] + dz, 0, A.rz - 1);
+                float wx = dx ? c.a[0] : 1.f - c.a[0], wy = dy ? c.a[1] : 1.f - c.a[1], wz = dz ? c.a[2] : 1.f - c.a[2];
+                float sx = dx ? 1.f : -1.f, sy = dy ? 1.f : -1.f, sz = dz ? 1.f : -1.f;
+                const float *t = A.data + 3 * (((size_t)iz * A.ry + iy) * A.rx + ix);
+                float w = wx * wy * wz;
+                V3 dw = mk(sx * wy * wz * (float)A.rx, wx * sy * wz * (float)A.ry, wx * wy * sz * (float)A.rz);
+#pragma unroll
+                for (int ch = 0; ch < 3; ++ch) {
+                    val[ch] = fmaf(w, t[ch], val[ch]);
+                    grad[ch] = fma3(t[ch], dw, grad[ch]);
+                }
+            }
+}
+template <class Adder>
+DSDF_HD void scatter_trilinear(const AlbedoView &A, float *grad_albedo, V3 p, const float a_bar[3], Adder add) {
+    TrilinearCell c = trilinear_cell(A, p);
+#pragma unroll
+    for (int dz = 0; dz < 2; ++dz)
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 2; ++dx) {
+                int ix = iclamp(c.i0[0] + dx, 0, A.rx - 1), iy = iclamp(c.i0[1] + dy, 0, A.ry - 1), iz = iclamp(c.i0[2] + dz, 0, A.rz - 1);
+                float w = (dx ? c.a[0] : 1.f - c.a[0]) * (dy ? c.a[1] : 1.f - c.a[1]) * (dz ? c.a[2] : 1.f - c.a[2]);
+                float *t = grad_albedo + 3 * (((size_t)iz * A.ry + iy) * A.rx + ix);
+#pragma unroll
+                for (int ch = 0; ch < 3; ++ch)
+                    if (a_bar[ch] != 0.f) add(t + ch, w * a_bar[ch]);
+            }
+}
+
+DSDF_HD V3 square_to_uniform_sphere(float u0, float u1) {           // mitsuba warp.h
+    float z = 1.f - 2.f * u1;
+    float r = sqrtf(fmaxf(1.f - z * z, 0.f));
+    float phi = 6.283185307179586f * u0;
+    return mk(r * cosf(phi), r * sinf(phi), z);
+}
+
+// SurfaceInteraction3f::spawn_ray_to + offset_p (mitsuba interaction.h) towards p + wdir * DSDF_ENV_DIST:
+// the origin leaves the surface along the normal by (1 + max|p|) * RayEpsilon (sign of n . dir).
+struct ShadowRay { V3 o, d; float maxt; };
+DSDF_HD ShadowRay spawn_shadow_ray(V3 p, V3 n, V3 wdir) {
+    V3 target = fma3(DSDF_ENV_DIST, wdir, p);
+    float mag = (1.f + fmaxf(fabsf(p.x), fmaxf(fabsf(p.y), fabsf(p.z)))) * DSDF_RAY_EPSILON;
+    if (dot(n, target - p) < 0.f) mag = -mag;
+    ShadowRay r;
+    r.o = fma3(mag, n, p);
+    V3 dv = target - r.o;
+    float dist = sqrtf(dot(dv, dv));
+    r.d = dv * (1.f / dist);
+    r.maxt = dist * (1.f - DSDF_SHADOW_EPSILON);
+    return r;
+}
 
 // ---------------------------------------------------------------------------
 // A8/A9: WarpField2D.weight / eval (warp.py:25-96), forward coefficients of the

@@ -40,7 +40,8 @@ enum dsdf_status {
  * python/integrators/sdf_simple_shading_reparam.py:16-26 (`sample()` bodies). */
 enum dsdf_integrator {
     DSDF_SILHOUETTE = 0,
-    DSDF_SIMPLE_SHADING = 1
+    DSDF_SIMPLE_SHADING = 1,
+    DSDF_DIRECT = 2          /* sdf_direct_reparam (emitter sampling, use_mis = False); needs a dsdf_shading */
 };
 
 /* Flags for dsdf_render_*.  DSDF_REPARAM selects WarpField2D (python/warp.py:7-128);

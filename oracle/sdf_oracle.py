@@ -50,6 +50,16 @@ BORDER = 2                  # rfilter border_size = ceil(radius - 0.5)
 
 SILHOUETTE = 0              # integrators/sdf_silhouette_reparam.py
 SIMPLE_SHADING = 1          # integrators/sdf_simple_shading_reparam.py
+DIRECT = 2                  # integrators/sdf_direct_reparam.py (emitter sampling only, use_mis=False: reparam.py:17)
+
+# sdf_direct_reparam needs a BSDF and an emitter from the scene description; the reference's scene files are
+# not part of the repository, so the two plugins are fixed HERE as this repo's spec:
+#   BSDF    = Mitsuba `diffuse` whose reflectance is a trilinear `gridvolume` over the unit cube
+#             (the optimised key 'main-bsdf.reflectance.volume.data', opt_configs.py:286)
+#   emitter = Mitsuba `constant` environment emitter of radiance ENV_RADIANCE
+RAY_EPSILON = 8.94069671630859375e-05     # mitsuba math::RayEpsilon<float> = 1500 * 2^-24
+SHADOW_EPSILON = 10 * RAY_EPSILON         # math::ShadowEpsilon
+ENV_DIST = 4.0              # constant emitter: ds.p = it.p + d * 2 * bsphere.radius (radius 2 = the sensor ring, util.py:84)
 
 
 def replace_grad(a, b):
@@ -462,6 +472,100 @@ def compute_surface_interaction(sdf, o, d, t, valid):                 # shapes.p
 
 
 # --------------------------------------------------------------------------
+# sdf_direct_reparam.py:16-75: diffuse BSDF over a trilinear albedo volume, constant environment emitter
+# --------------------------------------------------------------------------
+def eval_trilinear(vol, p):
+    """Dr.Jit Texture3f.eval with linear filtering, clamp wrap (Mitsuba `gridvolume`, 'trilinear'):
+    vol (Z,Y,X,C), texel centres at (i+0.5)/res.  Differentiable w.r.t. vol and p."""
+    rz, ry, rx, C = vol.shape
+    res = torch.tensor([rx, ry, rz], dtype=p.dtype)
+    pf = p * res - 0.5
+    i0 = torch.floor(pf.detach())
+    a = pf - i0
+    i0 = i0.to(torch.int64)
+    out = torch.zeros(p.shape[0], C, dtype=p.dtype)
+    for dz in (0, 1):
+        for dy in (0, 1):
+            for dx in (0, 1):
+                ix = (i0[:, 0] + dx).clamp(0, rx - 1)
+                iy = (i0[:, 1] + dy).clamp(0, ry - 1)
+                iz = (i0[:, 2] + dz).clamp(0, rz - 1)
+                w = (a[:, 0] if dx else 1 - a[:, 0]) * (a[:, 1] if dy else 1 - a[:, 1]) * (a[:, 2] if dz else 1 - a[:, 2])
+                out = out + w[:, None] * vol[iz, iy, ix]
+    return out
+
+
+def square_to_uniform_sphere(u):                         # mitsuba warp.h
+    z = 1.0 - 2.0 * u[:, 1]
+    r = torch.sqrt(torch.clamp(1.0 - z * z, min=0.0))
+    phi = 2.0 * math.pi * u[:, 0]
+    return torch.stack([r * torch.cos(phi), r * torch.sin(phi), z], -1)
+
+
+def spawn_ray_to(p, n, target):
+    """SurfaceInteraction3f::spawn_ray_to / offset_p (mitsuba interaction.h): the origin is pushed off the
+    surface along the (detached) normal by (1 + max|p|) * RayEpsilon towards the target; attached to p only."""
+    mag = (1.0 + p.detach().abs().max(dim=-1).values) * RAY_EPSILON
+    sgn = torch.where(dot(n.detach(), target - p.detach()) >= 0, torch.ones_like(mag), -torch.ones_like(mag))
+    o = p + (mag * sgn)[:, None] * n.detach()
+    dv = target - o
+    dist = torch.linalg.norm(dv, dim=-1)
+    return o, dv / dist[:, None], dist * (1.0 - SHADOW_EPSILON)
+
+
+def warped_ray(sdf, o, d, maxt, reparam):
+    """WarpField2D.ray_intersect (warp.py:99-117) for a batch of rays whose origin may be attached:
+    trace under suspend_grad, then eval the warp at ray(warp_t).  -> (its_t, d_attached, det)."""
+    tr = ray_intersect(sdf, o.detach(), d.detach(), maxt)
+    N = o.shape[0]
+    d_att = d
+    det = torch.ones(N, dtype=o.dtype)
+    if reparam:
+        sel = (torch.isfinite(tr['warp_t']) & (tr['warp_weight'] > 0)).nonzero()[:, 0]
+        if sel.numel() > 0:
+            tw = tr['warp_t'][sel]
+            x = o[sel] + tw[:, None] * d[sel].detach()
+            wdir, dv, wact = warp_eval(sdf, x, d[sel].detach(), tw, tr['warp_t_d'][sel], tr['warp_weight'][sel],
+                                       tr['warp_weight_d'][sel], torch.ones_like(tw, dtype=torch.bool))
+            keep = wact.nonzero()[:, 0]
+            sel = sel[keep]
+            d_att = d.index_put((sel,), wdir[keep])
+            det = det.index_put((sel,), replace_grad(torch.ones_like(dv[keep]), dv[keep]))
+    return tr['its_t'], d_att, det
+
+
+def direct_radiance(sdf, albedo, o, d_att, its_t, emitter_u, reparam, env=1.0, hide_emitters=False):
+    """sdf_direct_reparam.py:29-75 for the hit lanes + the environment term of the others (without the
+    primary determinant, which the caller multiplies in).  -> rgb (N,3)."""
+    N = o.shape[0]
+    dt = o.dtype
+    hit = torch.isfinite(its_t)
+    rgb = torch.zeros(N, 3, dtype=dt)
+    if not hide_emitters:                                   # :25-26, 33: escaping rays see the environment
+        rgb = rgb + (~hit).to(dt)[:, None] * env
+    hsel = hit.nonzero()[:, 0]
+    if hsel.numel() == 0:
+        return rgb
+    oh, dh = o[hsel], d_att[hsel]
+    _, p, n = compute_surface_interaction(sdf, oh, dh, its_t[hsel], None)
+    wdir = square_to_uniform_sphere(emitter_u[hsel].to(dt))           # :40 constant emitter, pdf = 1/(4 pi)
+    so, sd, smaxt = spawn_ray_to(p, n, p.detach() + wdir * ENV_DIST)   # :51 (ds.p from the detached si)
+    sd = sd.detach()                                                    # :53
+    cos_i = dot(n, -dh).detach()
+    front = (dot(n, sd).detach() > 0) & (cos_i > 0)                     # diffuse::eval: both cosines positive
+    fsel = front.nonzero()[:, 0]
+    if fsel.numel() == 0:
+        return rgb
+    s_t, sd_att, det_e = warped_ray(sdf, so[fsel], sd[fsel], smaxt[fsel], reparam)   # :54 ray_test
+    vis = (~torch.isfinite(s_t)).to(dt)
+    cos_o = dot(n[fsel], sd_att)                                        # wo = si.to_local(shadow_ray.d)
+    a = eval_trilinear(albedo, p[fsel])                               # reflectance volume lives on the unit cube
+    bsdf = a * (cos_o / math.pi)[:, None]
+    contrib = bsdf * (env * 4.0 * math.pi) * (vis * det_e)[:, None]     # emitter_val / ds.pdf ; * det_e (:84)
+    return rgb.index_put((hsel[fsel],), contrib)
+
+
+# --------------------------------------------------------------------------
 # A18/A19: cameras (util.py:84-138) + Mitsuba perspective sensor restatement
 # --------------------------------------------------------------------------
 def regular_camera_origins(n, angle_shift=0.0, radius=2.0, height_scale=1.0):
@@ -554,10 +658,11 @@ def _pcg32_step(state, inc):
     return state, out
 
 
-def independent_sampler_2d(seed, n):
-    """First `next_2d()` of Mitsuba's independent sampler for lanes 0..n-1:
+def independent_sampler(seed, n, k=2):
+    """First k floats of Mitsuba's independent sampler for lanes 0..n-1:
     PCG32(initstate=v0, initseq=v1) with (v0,v1)=sample_tea_32(seed, lane);
-    next_float32 = (u32 >> 9 | 0x3f800000) - 1."""
+    next_float32 = (u32 >> 9 | 0x3f800000) - 1.  Draw order of a lane (reparam.py:140-171, 82-97,
+    sdf_direct_reparam.py:40): next_2d = film position, next_1d = wavelength sample, next_2d = emitter sample."""
     idx = np.arange(n, dtype=np.uint32)
     v0, v1 = sample_tea_32(np.full(n, seed, np.uint32), idx)
     with np.errstate(over='ignore'):
@@ -567,11 +672,21 @@ def independent_sampler_2d(seed, n):
         state = state + v0.astype(np.uint64)
         state, _ = _pcg32_step(state, inc)
     out = []
-    for _ in range(2):
+    for _ in range(k):
         state, u = _pcg32_step(state, inc)
         f = ((u >> np.uint32(9)) | np.uint32(0x3f800000)).view(np.float32) - np.float32(1.0)
         out.append(f)
     return np.stack(out, -1)
+
+
+def independent_sampler_2d(seed, n):
+    """First `next_2d()` (the film position sample) of every lane."""
+    return independent_sampler(seed, n, 2)
+
+
+def independent_sampler_emitter_2d(seed, n):
+    """The `next_2d()` consumed by sdf_direct_reparam's emitter sampling: floats 3 and 4 of the lane's stream."""
+    return independent_sampler(seed, n, 5)[:, 3:5]
 
 
 # --------------------------------------------------------------------------
@@ -627,7 +742,7 @@ def lane_positions(W, H, spp, offsets):
 
 
 def render(sdf, cam, W, H, spp, offsets, integrator=SILHOUETTE, reparam=True,
-           return_aux=False, chunk=1 << 17):
+           return_aux=False, chunk=1 << 17, albedo=None, emitter_u=None, env=1.0, hide_emitters=False):
     """One view.  offsets: (Wb*Hb*spp, 2) in [0,1) (the sampler's next_2d per
     lane).  Returns image (H,W,3), differentiable w.r.t. sdf.data / sdf.p when
     they require grad.  `reparam=False` gives the DummyWarpField path
@@ -664,7 +779,9 @@ def render(sdf, cam, W, H, spp, offsets, integrator=SILHOUETTE, reparam=True,
                 d_att = d.index_put((sel,), wdir[keep])                  # warp.py:114
                 div = div.index_put((sel,), replace_grad(torch.ones_like(dv[keep]), dv[keep]))   # warp.py:115
                 aux['warp_active'] += int(keep.numel())
-        if integrator == SILHOUETTE:                                     # sdf_silhouette_reparam.py:20-22
+        if integrator == DIRECT:                                         # sdf_direct_reparam.py:16-111
+            rgb = direct_radiance(sdf, albedo, o, d_att, its_t, emitter_u[s:s + chunk], reparam, env, hide_emitters) * div[:, None]
+        elif integrator == SILHOUETTE:                                   # sdf_silhouette_reparam.py:20-22
             val = hit.to(dt) * div
         else:                                                            # sdf_simple_shading_reparam.py:20-22
             hsel = hit.nonzero()[:, 0]                                    # (masked lanes skipped, see above)
@@ -673,7 +790,8 @@ def render(sdf, cam, W, H, spp, offsets, integrator=SILHOUETTE, reparam=True,
                 _, _, n = compute_surface_interaction(sdf, o[hsel], d_att[hsel], its_t[hsel], None)
                 sh = sh.index_put((hsel,), torch.clamp(dot(n, light), min=0.0))
             val = sh * div
-        rgb = val[:, None].expand(-1, 3)
+        if integrator != DIRECT:
+            rgb = val[:, None].expand(-1, 3)
         # re-projection, reparam.py:99-105
         uv, rw = cam.sample_direction(o + d_att, W, H)
         rwn = torch.where(rw > 0, rw / torch.where(rw > 0, rw.detach(), torch.ones_like(rw)), torch.ones_like(rw))

@@ -33,3 +33,28 @@ def oracle_backward(case, integrator, reparam=True):
     cam = O.Camera(case['origin'])
     return O.render_backward(O.Grid3d(case['grid']), cam, case['W'], case['H'], case['spp'], case['offsets'].double(),
                              case['grad_image'].double(), integrator, reparam)
+
+
+def direct_inputs(case, ares=(6, 5, 4), seed=11):
+    """Extra inputs of sdf_direct_reparam for a case: albedo volume (Z,Y,X,3) fp32 in [0.2, 0.8], per-lane
+    emitter samples (n,2) fp32, environment radiance."""
+    gen = torch.Generator().manual_seed(seed)
+    n = case['offsets'].shape[0]
+    albedo = torch.rand(*ares, 3, generator=gen, dtype=torch.float32) * 0.6 + 0.2
+    emitter_u = torch.rand(n, 2, generator=gen, dtype=torch.float32)
+    return dict(albedo=albedo, emitter_u=emitter_u, env=(1.0, 0.9, 0.8))
+
+
+def oracle_direct(case, extra, reparam=True, hide_emitters=False, grads=False, p=None):
+    """Oracle image of sdf_direct_reparam; with grads=True also (dL/d data, dL/d albedo[, dL/d p]) for
+    L = sum(image * grad_image)."""
+    cam = O.Camera(case['origin'])
+    data = case['grid'].clone().requires_grad_(grads)
+    alb = extra['albedo'].double().clone().requires_grad_(grads)
+    env = torch.tensor(extra['env'], dtype=torch.float64)
+    img = O.render(O.Grid3d(data, p), cam, case['W'], case['H'], case['spp'], case['offsets'].double(), O.DIRECT, reparam,
+                   albedo=alb, emitter_u=extra['emitter_u'].double(), env=env, hide_emitters=hide_emitters)
+    if not grads:
+        return img
+    (img * case['grad_image'].double()).sum().backward()
+    return img.detach(), data.grad, alb.grad

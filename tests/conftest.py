@@ -81,6 +81,46 @@ class HostHarness:
                                     self._p(gg), self._p(img), self._p(self.last_grad_p))
         return gg, img
 
+    def render_direct_forward(self, grid, cam, W, H, spp, offsets, emitter_u, albedo, env=(1.0, 1.0, 1.0), hide_emitters=False,
+                              reparam=True, diff=False, seed=0):
+        grid = np.ascontiguousarray(grid, np.float32)
+        offsets = None if offsets is None else np.ascontiguousarray(offsets, np.float32)
+        emitter_u = None if emitter_u is None else np.ascontiguousarray(emitter_u, np.float32)
+        albedo = np.ascontiguousarray(albedo, np.float32)
+        env = np.asarray(env, np.float32)
+        img = np.zeros((H, W, 3), np.float32)
+        rz, ry, rx = grid.shape
+        az, ay, ax = albedo.shape[:3]
+        self.lib.hh_render_direct_forward(self._p(grid), rx, ry, rz, C.byref(self.params), self._p(cam), W, H, spp,
+                                          self._p(offsets), self._p(emitter_u), C.c_uint(seed), int(reparam), int(diff),
+                                          self._p(albedo), ax, ay, az, self._p(env), int(hide_emitters), self._p(img))
+        return img
+
+    def render_direct_backward(self, grid, cam, W, H, spp, offsets, emitter_u, albedo, grad_image, env=(1.0, 1.0, 1.0),
+                               hide_emitters=False, reparam=True, seed=0):
+        grid = np.ascontiguousarray(grid, np.float32)
+        offsets = None if offsets is None else np.ascontiguousarray(offsets, np.float32)
+        emitter_u = None if emitter_u is None else np.ascontiguousarray(emitter_u, np.float32)
+        albedo = np.ascontiguousarray(albedo, np.float32)
+        env = np.asarray(env, np.float32)
+        gi = np.ascontiguousarray(grad_image, np.float32)
+        gg = np.zeros(grid.shape, np.float32)
+        ga = np.zeros(albedo.shape, np.float32)
+        gp = np.zeros(3, np.float32)
+        img = np.zeros((H, W, 3), np.float32)
+        rz, ry, rx = grid.shape
+        az, ay, ax = albedo.shape[:3]
+        self.lib.hh_render_direct_backward(self._p(grid), rx, ry, rz, C.byref(self.params), self._p(cam), W, H, spp,
+                                           self._p(offsets), self._p(emitter_u), C.c_uint(seed), int(reparam),
+                                           self._p(albedo), ax, ay, az, self._p(env), int(hide_emitters), self._p(gi),
+                                           self._p(gg), self._p(ga), self._p(gp), self._p(img))
+        return gg, ga, gp, img
+
+    def sampler_emitter(self, seed, n):
+        out = np.zeros((n, 2), np.float32)
+        self.lib.hh_sampler_emitter(C.c_uint(seed), C.c_long(n), self._p(out))
+        return out
+
     def sampler(self, seed, n):
         out = np.zeros((n, 2), np.float32)
         self.lib.hh_sampler(C.c_uint(seed), C.c_long(n), self._p(out))

@@ -62,7 +62,7 @@ static ViewArgs view_args(const dsdf_camera *cam, int W, int H, int spp, const f
                           int integrator, int flags) {
     ViewArgs A;
     A.cam = *cam; A.W = W; A.H = H; A.Wb = W + 2 * DSDF_BORDER; A.Hb = H + 2 * DSDF_BORDER; A.spp = spp;
-    A.integrator = integrator; A.flags = flags; A.seed = seed; A.offsets = offsets;
+    A.integrator = integrator; A.flags = flags; A.seed = seed; A.offsets = offsets; A.emitter_u = nullptr;
     return A;
 }
 
@@ -139,6 +139,100 @@ void hh_render_backward(const float *data, int rx, int ry, int rz, const dsdf_pa
 
 void hh_sampler(unsigned seed, long n, float *out) {
     for (long i = 0; i < n; ++i) sampler_next_2d(seed, (uint32_t)i, out[2 * i], out[2 * i + 1]);
+}
+
+// ---- sdf_direct_reparam (4-channel film block) -----------------------------------------------
+static ShadeArgs shade_args(const float *albedo, int ax, int ay, int az, const float *env, int hide, float *grad_albedo) {
+    ShadeArgs S;
+    S.albedo.data = albedo; S.albedo.rx = ax; S.albedo.ry = ay; S.albedo.rz = az;
+    S.env[0] = env[0]; S.env[1] = env[1]; S.env[2] = env[2];
+    S.hide_emitters = hide; S.grad_albedo = grad_albedo;
+    return S;
+}
+
+static void develop_rgb(const std::vector<float> &block, int W, int H, float *image) {
+    int Wb = W + 2 * DSDF_BORDER;
+    for (int y = 0; y < H; ++y)
+        for (int x = 0; x < W; ++x) {
+            const float *b = &block[4 * ((size_t)(y + DSDF_BORDER) * Wb + x + DSDF_BORDER)];
+            float w = b[3] == 0.f ? 1.f : b[3];
+            float *o = image + 3 * ((size_t)y * W + x);
+            o[0] = b[0] / w; o[1] = b[1] / w; o[2] = b[2] / w;
+        }
+}
+
+// diff=0: primal pass; diff=1: forward sweep of the gradient pass (differentiable traces)
+void hh_render_direct_forward(const float *data, int rx, int ry, int rz, const dsdf_params *prm, const dsdf_camera *cam,
+                              int W, int H, int spp, const float *offsets, const float *emitter_u, unsigned seed, int flags,
+                              int diff, const float *albedo, int ax, int ay, int az, const float *env, int hide, float *image) {
+    std::vector<float> p = pad(data, rx, ry, rz);
+    GridView G = make_view(p.data(), rx, ry, rz, *prm);
+    ViewArgs A = view_args(cam, W, H, spp, offsets, seed, DSDF_DIRECT, flags);
+    A.emitter_u = emitter_u;
+    ShadeArgs S = shade_args(albedo, ax, ay, az, env, hide, nullptr);
+    std::vector<float> block((size_t)4 * A.Wb * A.Hb, 0.f);
+    long n = (long)A.Wb * A.Hb * spp;
+    for (long lane = 0; lane < n; ++lane) {
+        Lane L = lane_setup(A, *prm, (uint32_t)lane);
+        TraceOut t, ts;
+        if (diff) trace_diff(G, *prm, L.ray.o, L.ray.d, L.ray.maxt, t);
+        else trace_plain(G, *prm, L.ray.o, L.ray.d, L.ray.maxt, t);
+        float rgb[3];
+        direct_value(G, *prm, A, S, L, (uint32_t)lane, t.its_t, diff != 0, ts, rgb);
+        Reproj rp = reproject(A.cam, *prm, L.ray.o + L.ray.d, W, H);
+        splat_lane_rgb(block.data(), A.Wb, A.Hb, rp.u, rp.v, rgb, PlainAdd());
+    }
+    develop_rgb(block, W, H, image);
+}
+
+void hh_render_direct_backward(const float *data, int rx, int ry, int rz, const dsdf_params *prm, const dsdf_camera *cam,
+                               int W, int H, int spp, const float *offsets, const float *emitter_u, unsigned seed, int flags,
+                               const float *albedo, int ax, int ay, int az, const float *env, int hide,
+                               const float *grad_image, float *grad_grid, float *grad_albedo, float *grad_p, float *image) {
+    std::vector<float> p = pad(data, rx, ry, rz);
+    GridView G = make_view(p.data(), rx, ry, rz, *prm);
+    ViewArgs A = view_args(cam, W, H, spp, offsets, seed, DSDF_DIRECT, flags);
+    A.emitter_u = emitter_u;
+    ShadeArgs S = shade_args(albedo, ax, ay, az, env, hide, grad_albedo);
+    std::vector<float> block((size_t)4 * A.Wb * A.Hb, 0.f), badj((size_t)4 * A.Wb * A.Hb, 0.f);
+    long n = (long)A.Wb * A.Hb * spp;
+    std::vector<TraceOut> tr(n), trs(n);
+    for (long lane = 0; lane < n; ++lane) {
+        Lane L = lane_setup(A, *prm, (uint32_t)lane);
+        trace_diff(G, *prm, L.ray.o, L.ray.d, L.ray.maxt, tr[lane]);
+        float rgb[3];
+        direct_value(G, *prm, A, S, L, (uint32_t)lane, tr[lane].its_t, true, trs[lane], rgb);
+        Reproj rp = reproject(A.cam, *prm, L.ray.o + L.ray.d, W, H);
+        splat_lane_rgb(block.data(), A.Wb, A.Hb, rp.u, rp.v, rgb, PlainAdd());
+    }
+    if (image) develop_rgb(block, W, H, image);
+    for (int y = 0; y < H; ++y)
+        for (int x = 0; x < W; ++x) {
+            size_t q = (size_t)(y + DSDF_BORDER) * A.Wb + x + DSDF_BORDER;
+            const float *gi = grad_image + 3 * ((size_t)y * W + x);
+            float w = block[4 * q + 3];
+            if (w == 0.f) { for (int c = 0; c < 3; ++c) badj[4 * q + c] = gi[c]; badj[4 * q + 3] = 0.f; }
+            else {
+                float acc = 0.f;
+                for (int c = 0; c < 3; ++c) { badj[4 * q + c] = gi[c] / w; acc += gi[c] * block[4 * q + c]; }
+                badj[4 * q + 3] = -acc / (w * w);
+            }
+        }
+    for (long lane = 0; lane < n; ++lane) {
+        Lane L = lane_setup(A, *prm, (uint32_t)lane);
+        ScatterReq req[3]; AlbedoReq areq;
+        lane_backward_direct(G, *prm, A, S, L, (uint32_t)lane, tr[lane], trs[lane], badj.data(), req, areq);
+        for (int r = 0; r < 3; ++r)
+            if (req[r].on) {
+                scatter_cubic(G, grad_grid, req[r].x, req[r].cv, req[r].cg, PlainAdd());
+                if (grad_p) { grad_p[0] += req[r].p_bar.x; grad_p[1] += req[r].p_bar.y; grad_p[2] += req[r].p_bar.z; }
+            }
+        if (areq.on && grad_albedo) scatter_trilinear(S.albedo, grad_albedo, areq.x, areq.a_bar, PlainAdd());
+    }
+}
+
+void hh_sampler_emitter(unsigned seed, long n, float *out) {
+    for (long i = 0; i < n; ++i) sampler_emitter_2d(seed, (uint32_t)i, out[2 * i], out[2 * i + 1]);
 }
 
 }  // extern "C"
