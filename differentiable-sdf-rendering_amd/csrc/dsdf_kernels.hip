@@ -272,7 +272,9 @@ struct WaveCellCache {
 struct Queue {
     uint32_t *count;  // per render-pass block
     uint32_t *lane;
-    float *rec;       // 9 rows (SoA, stride = cap), indexed by sample: its_t, warp_t, wtd.xyz, ww, wwd.xyz
+    float *rec;       // `rows` rows (SoA, stride = cap), indexed by sample: its_t, warp_t, wtd.xyz, ww, wwd.xyz
+                      // of the primary ray (9) and, for sdf_direct_reparam, of the shadow ray (18)
+    uint32_t rows;
     uint32_t cap;     // slots per view (= nblk * DSDF_BLOCK)
     uint32_t nblk;    // render-pass blocks per view
 };
@@ -286,16 +288,31 @@ struct ViewBatch { ViewArgs v[DSDF_MAX_BATCH]; };
 __device__ __forceinline__ Queue view_queue(Queue q, uint32_t view) {
     q.count += (size_t)view * q.nblk;
     q.lane += (size_t)view * q.cap;
-    q.rec += (size_t)view * q.cap * 9;
+    q.rec += (size_t)view * q.cap * q.rows;
     return q;
+}
+
+__device__ __forceinline__ void store_record(float *r, size_t c, const TraceOut &tr) {
+    r[0] = tr.its_t; r[c] = tr.warp_t;
+    r[2 * c] = tr.warp_t_d.x; r[3 * c] = tr.warp_t_d.y; r[4 * c] = tr.warp_t_d.z;
+    r[5 * c] = tr.warp_weight;
+    r[6 * c] = tr.warp_weight_d.x; r[7 * c] = tr.warp_weight_d.y; r[8 * c] = tr.warp_weight_d.z;
+}
+__device__ __forceinline__ void load_record(const float *r, size_t c, TraceOut &tr) {
+    tr.its_t = r[0]; tr.warp_t = r[c];
+    tr.warp_t_d = mk(r[2 * c], r[3 * c], r[4 * c]);
+    tr.warp_weight = r[5 * c];
+    tr.warp_weight_d = mk(r[6 * c], r[7 * c], r[8 * c]);
+    tr.steps = 0; tr.refine_steps = 0; tr.weight_sum = 0.f;
 }
 
 // Film splat of one wave whose 64 samples belong to ONE pixel (px,py): their contributions fall into
 // the 5x5 block-pixel window around it; the 25 (+25 weight) partial sums are reduced across the wave
 // through a wave-private LDS transpose (lane l writes column l, lane k sums row k with 16 conflict-free
 // ds_read_b128; two chunks of <= 13 rows) and leave as one atomic per window pixel and channel.
+template <int NCH>     // block channels: NCH - 1 value channels + weight
 __device__ __forceinline__ void film_splat_wave(float *__restrict__ block, const ViewArgs &A, int px, int py,
-                                                float u, float v, float val, float *T, int lid) {
+                                                float u, float v, const float *vals, float *T, int lid) {
     float pfx = u + (DSDF_BORDER - 0.5f), pfy = v + (DSDF_BORDER - 0.5f);
     float fx[5], fy[5];
 #pragma unroll
@@ -308,16 +325,16 @@ __device__ __forceinline__ void film_splat_wave(float *__restrict__ block, const
     for (int j = 0; j < 5; ++j)
 #pragma unroll
         for (int i = 0; i < 5; ++i) f[j * 5 + i] = fx[i] * fy[j];
-    const bool any_val = __ballot(val != 0.f) != 0;     // pixels nobody hits skip the value channel
 #pragma unroll
-    for (int ch = 0; ch < 2; ++ch) {
-        if (ch == 0 && !any_val) continue;
+    for (int ch = 0; ch < NCH; ++ch) {
+        const float val = ch < NCH - 1 ? vals[ch] : 1.f;
+        if (ch < NCH - 1 && __ballot(val != 0.f) == 0) continue;     // pixels nobody hits skip the value channel
 #pragma unroll
         for (int k0 = 0; k0 < 25; k0 += DSDF_TROWS) {
             const int nk = (25 - k0) < DSDF_TROWS ? (25 - k0) : DSDF_TROWS;
 #pragma unroll
             for (int k = 0; k < DSDF_TROWS; ++k)
-                if (k < nk) T[k * DSDF_TSTRIDE + lid] = ch == 0 ? f[k0 + k] * val : f[k0 + k];
+                if (k < nk) T[k * DSDF_TSTRIDE + lid] = f[k0 + k] * val;
             wave_lds_sync();
             float total = 0.f;
             const int slot = k0 + lid;                   // window slot summed by this lane
@@ -339,7 +356,7 @@ __device__ __forceinline__ void film_splat_wave(float *__restrict__ block, const
                         (((a2.x + a2.y) + (a2.z + a2.w)) + ((a3.x + a3.y) + (a3.z + a3.w)));
             }
             wave_lds_sync();
-            if (own && total != 0.f) atomicAdd(block + 2 * ((size_t)qy * A.Wb + qx) + ch, total);
+            if (own && total != 0.f) atomicAdd(block + NCH * ((size_t)qy * A.Wb + qx) + ch, total);
         }
     }
 }
@@ -434,13 +451,17 @@ __global__ void k_skip_dilate(ViewBatch VB, unsigned char *__restrict__ flags) {
 #ifndef DSDF_DIFF_MINWAVES
 #define DSDF_DIFF_MINWAVES 1
 #endif
-template <bool DIFF, bool CACHE>
-__global__ __launch_bounds__(DSDF_BLOCK, DIFF ? DSDF_DIFF_MINWAVES : DSDF_PRIMAL_MINWAVES) void k_render_pass(GridView G, dsdf_params P, ViewBatch VB,
+// DIRECT = sdf_direct_reparam: a second (shadow) ray per hit sample, rgb film block (4 channels), own instantiation so
+// that the one-channel integrators keep their register budget.
+template <bool DIFF, bool CACHE, bool DIRECT>
+__global__ __launch_bounds__(DSDF_BLOCK, DIRECT ? 1 : (DIFF ? DSDF_DIFF_MINWAVES : DSDF_PRIMAL_MINWAVES)) void k_render_pass(GridView G, dsdf_params P, ViewBatch VB,
                                                             float *__restrict__ blocks, Queue qall,
                                                             unsigned long long *stats, uint32_t n_lanes,
-                                                            int wave_uniform, const unsigned char *__restrict__ skip) {
+                                                            int wave_uniform, const unsigned char *__restrict__ skip,
+                                                            ShadeArgs S) {
     const ViewArgs &A = VB.v[blockIdx.y];
-    float *__restrict__ block = blocks + (size_t)blockIdx.y * 2 * A.Wb * A.Hb;
+    constexpr int NCH = DIRECT ? 4 : 2;
+    float *__restrict__ block = blocks + (size_t)blockIdx.y * NCH * A.Wb * A.Hb;
     const Queue q = view_queue(qall, blockIdx.y);
     // (blocks are issued round-robin over the 8 XCDs; giving each XCD a contiguous eighth of the film for L2
     //  locality was measured 1.7x SLOWER: film regions differ wildly in cost and the static split unbalances)
@@ -467,7 +488,10 @@ __global__ __launch_bounds__(DSDF_BLOCK, DIFF ? DSDF_DIFF_MINWAVES : DSDF_PRIMAL
 #ifndef DSDF_NO_FAR
         far = (f & (DIFF ? 8u : 4u)) != 0;
 #endif
+        if (DIRECT && !S.hide_emitters) far = false;        // the background is the environment, not zero
     }
+    TraceOut trs;                                           // shadow ray (DIRECT)
+    bool lit = false;
     Lane L;
     if (!far) {                                             // wave-uniform when CACHE / wave_uniform
         L = lane_setup(A, P, lane);
@@ -486,13 +510,16 @@ __global__ __launch_bounds__(DSDF_BLOCK, DIFF ? DSDF_DIFF_MINWAVES : DSDF_PRIMAL
             tr.warp_t_d = mk(0.f, 0.f, 0.f); tr.warp_weight_d = mk(0.f, 0.f, 0.f);
             tr.steps = 0; tr.refine_steps = 0;
         }
-        float val = shade_value(G, A, L, tr.its_t);
         Reproj rp = reproject(A.cam, P, L.ray.o + L.ray.d, A.W, A.H);
-
-        if (wave_uniform) {
-            film_splat_wave(block, A, L.px, L.py, rp.u, rp.v, val, wave_lds[threadIdx.x >> 6], lid);
-        } else if (valid) {
-            splat_lane(block, A.Wb, A.Hb, rp.u, rp.v, val, AtomicAdd());
+        if (DIRECT) {
+            float rgb[3];
+            lit = direct_value(G, P, A, S, L, lane, tr.its_t, DIFF, trs, rgb);
+            if (wave_uniform) film_splat_wave<4>(block, A, L.px, L.py, rp.u, rp.v, rgb, wave_lds[threadIdx.x >> 6], lid);
+            else if (valid) splat_lane_rgb(block, A.Wb, A.Hb, rp.u, rp.v, rgb, AtomicAdd());
+        } else {
+            float val = shade_value(G, A, L, tr.its_t);
+            if (wave_uniform) film_splat_wave<2>(block, A, L.px, L.py, rp.u, rp.v, &val, wave_lds[threadIdx.x >> 6], lid);
+            else if (valid) splat_lane(block, A.Wb, A.Hb, rp.u, rp.v, val, AtomicAdd());
         }
     }
 
@@ -500,7 +527,7 @@ __global__ __launch_bounds__(DSDF_BLOCK, DIFF ? DSDF_DIFF_MINWAVES : DSDF_PRIMAL
     if (DIFF) {
         bool hit = tr.its_t < INFINITY;
         bool warp_cand = !far && (A.flags & DSDF_REPARAM) && warp_weight_positive(G, P, L.ray.o, L.ray.d, tr);
-        need = valid && (warp_cand || (hit && A.integrator == DSDF_SIMPLE_SHADING));
+        need = valid && (warp_cand || (DIRECT ? lit : (hit && A.integrator == DSDF_SIMPLE_SHADING)));
         // block-level compaction: per-wave ballot + mbcnt prefix, wave totals through LDS
         __shared__ uint32_t wave_cnt[DSDF_BLOCK / 64];
         uint64_t m = __ballot(need);
@@ -518,12 +545,8 @@ __global__ __launch_bounds__(DSDF_BLOCK, DIFF ? DSDF_DIFF_MINWAVES : DSDF_PRIMAL
         if (need) {
             uint32_t idx = bid * DSDF_BLOCK + base + mask_prefix(m);
             q.lane[idx] = lane;
-            float *r = q.rec + lane;                       // records are dense by sample index
-            size_t c = q.cap;
-            r[0] = tr.its_t; r[c] = tr.warp_t;
-            r[2 * c] = tr.warp_t_d.x; r[3 * c] = tr.warp_t_d.y; r[4 * c] = tr.warp_t_d.z;
-            r[5 * c] = tr.warp_weight;
-            r[6 * c] = tr.warp_weight_d.x; r[7 * c] = tr.warp_weight_d.y; r[8 * c] = tr.warp_weight_d.z;
+            store_record(q.rec + lane, q.cap, tr);          // records are dense by sample index
+            if (DIRECT) store_record(q.rec + lane + 9 * (size_t)q.cap, q.cap, trs);
         }
     }
     if (stats) {
@@ -583,15 +606,53 @@ __global__ void k_develop_adjoint(const float *__restrict__ blocks, const float 
     reinterpret_cast<float2 *>(block_adj)[i] = out;
 }
 
+// The same two kernels for the 4-channel (r,g,b,weight) block of sdf_direct_reparam.
+__global__ void k_develop_rgb(const float *__restrict__ blocks, int W, int H, float *__restrict__ images) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= W * H) return;
+    int y = i / W, x = i - y * W;
+    int Wb = W + 2 * DSDF_BORDER, Hb = H + 2 * DSDF_BORDER;
+    const float *block = blocks + (size_t)blockIdx.y * 4 * Wb * Hb;
+    float *image = images + (size_t)blockIdx.y * 3 * W * H;
+    float4 b = reinterpret_cast<const float4 *>(block)[(size_t)(y + DSDF_BORDER) * Wb + x + DSDF_BORDER];
+    float iw = 1.f / (b.w == 0.f ? 1.f : b.w);
+    image[3 * (size_t)i] = b.x * iw; image[3 * (size_t)i + 1] = b.y * iw; image[3 * (size_t)i + 2] = b.z * iw;
+}
+
+__global__ void k_develop_adjoint_rgb(const float *__restrict__ blocks, const float *__restrict__ grad_images, int W, int H,
+                                      float *__restrict__ block_adjs) {
+    int Wb = W + 2 * DSDF_BORDER, Hb = H + 2 * DSDF_BORDER;
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= Wb * Hb) return;
+    const float *block = blocks + (size_t)blockIdx.y * 4 * Wb * Hb;
+    const float *grad_image = grad_images + (size_t)blockIdx.y * 3 * W * H;
+    float *block_adj = block_adjs + (size_t)blockIdx.y * 4 * Wb * Hb;
+    int qy = i / Wb, qx = i - qy * Wb;
+    int x = qx - DSDF_BORDER, y = qy - DSDF_BORDER;
+    float4 out = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (x >= 0 && x < W && y >= 0 && y < H) {
+        const float *gi = grad_image + 3 * ((size_t)y * W + x);
+        float4 b = reinterpret_cast<const float4 *>(block)[i];
+        if (b.w == 0.f) out = make_float4(gi[0], gi[1], gi[2], 0.f);
+        else {
+            float iw = 1.f / b.w;
+            out = make_float4(gi[0] * iw, gi[1] * iw, gi[2] * iw, -(gi[0] * b.x + gi[1] * b.y + gi[2] * b.z) * iw * iw);
+        }
+    }
+    reinterpret_cast<float4 *>(block_adj)[i] = out;
+}
+
 // One single-wave block per render-pass block: it walks that block's queued samples 64 at a time
 // (usually one round: ~12 % of 256 samples), holds one 8 KB brick, so a CU keeps ~20 working waves.
+template <bool DIRECT>
 __global__ __launch_bounds__(64) void k_backward(GridView G, dsdf_params P, ViewBatch VB, Queue qall,
                                                  const float *__restrict__ block_adjs,
                                                  float *__restrict__ grad_grid, float *__restrict__ grad_p,
-                                                 unsigned long long *stats) {
+                                                 unsigned long long *stats, ShadeArgs S) {
     __shared__ float brick[DSDF_BRICK_CAP];
     const ViewArgs &A = VB.v[blockIdx.y];
-    const float *__restrict__ block_adj = block_adjs + (size_t)blockIdx.y * 2 * A.Wb * A.Hb;
+    constexpr int NCH = DIRECT ? 4 : 2;
+    const float *__restrict__ block_adj = block_adjs + (size_t)blockIdx.y * NCH * A.Wb * A.Hb;
     const Queue q = view_queue(qall, blockIdx.y);
     const uint32_t count = q.count[blockIdx.x];            // samples queued by render-pass block blockIdx.x
     const int lid = lane_id();
@@ -599,26 +660,31 @@ __global__ __launch_bounds__(64) void k_backward(GridView G, dsdf_params P, View
     V3 p_bar = mk(0.f, 0.f, 0.f);                          // dL/d(sdf.p) of this block's samples
     for (uint32_t s0 = 0; s0 < count; s0 += 64) {
         const uint32_t slot = s0 + threadIdx.x;
-        ScatterReq req[2];
-        req[0].on = false; req[1].on = false;
+        ScatterReq req[3];
+        req[0].on = false; req[1].on = false; req[2].on = false;
         if (slot < count) {
             const uint32_t lane = q.lane[blockIdx.x * DSDF_BLOCK + slot];
-            const float *r = q.rec + lane;
-            const size_t c = q.cap;
             TraceOut tr;
-            tr.its_t = r[0]; tr.warp_t = r[c];
-            tr.warp_t_d = mk(r[2 * c], r[3 * c], r[4 * c]);
-            tr.warp_weight = r[5 * c];
-            tr.warp_weight_d = mk(r[6 * c], r[7 * c], r[8 * c]);
-            tr.steps = 0; tr.refine_steps = 0; tr.weight_sum = 0.f;
+            load_record(q.rec + lane, q.cap, tr);
             Lane L = lane_setup(A, P, lane);
-            n_did += lane_backward(G, P, A, L, tr, block_adj, req) ? 1 : 0;
+            if (DIRECT) {
+                TraceOut trs;
+                load_record(q.rec + lane + 9 * (size_t)q.cap, q.cap, trs);
+                AlbedoReq areq;
+                n_did += lane_backward_direct(G, P, A, S, L, lane, tr, trs, block_adj, req, areq) ? 1 : 0;
+                // the albedo volume is small and its adjoint 24 floats per lit sample: plain atomics
+                if (areq.on && S.grad_albedo) scatter_trilinear(S.albedo, S.grad_albedo, areq.x, areq.a_bar, AtomicAdd());
+            } else {
+                n_did += lane_backward(G, P, A, L, tr, block_adj, req) ? 1 : 0;
+            }
         }
         wave_scatter(G, grad_grid, req[0], brick, lid);
         if (A.integrator != DSDF_SILHOUETTE) wave_scatter(G, grad_grid, req[1], brick, lid);
+        if (DIRECT) wave_scatter(G, grad_grid, req[2], brick, lid);
         if (grad_p) {
             if (req[0].on) p_bar = p_bar + req[0].p_bar;
             if (req[1].on) p_bar = p_bar + req[1].p_bar;
+            if (DIRECT && req[2].on) p_bar = p_bar + req[2].p_bar;
         }
     }
     if (grad_p && count) {
@@ -783,20 +849,21 @@ struct Workspace {
     size_t bytes;
 };
 
-// Workspace for `nv` views processed by one launch.
-static Workspace carve(void *base, int W, int H, int spp, int nv) {
+// Workspace for `nv` views processed by one launch (film channels and queue-record rows depend on the integrator).
+static Workspace carve(void *base, int W, int H, int spp, int nv, int integrator) {
     Workspace ws;
+    const size_t nch = (size_t)film_channels(integrator), rows = integrator == DSDF_DIRECT ? 18 : 9;
     size_t Wb = W + 2 * DSDF_BORDER, Hb = H + 2 * DSDF_BORDER;
     size_t nl = Wb * Hb * (size_t)spp;
     size_t nblk = (nl + DSDF_BLOCK - 1) / DSDF_BLOCK;
     size_t cap = nblk * DSDF_BLOCK;
     size_t off = 0;
     char *p = (char *)base;
-    ws.block = (float *)(p + off); off += align_up(nv * Wb * Hb * 2 * sizeof(float), 256);
-    ws.block_adj = (float *)(p + off); off += align_up(nv * Wb * Hb * 2 * sizeof(float), 256);
+    ws.block = (float *)(p + off); off += align_up(nv * Wb * Hb * nch * sizeof(float), 256);
+    ws.block_adj = (float *)(p + off); off += align_up(nv * Wb * Hb * nch * sizeof(float), 256);
     ws.count = (uint32_t *)(p + off); off += align_up(nv * nblk * sizeof(uint32_t), 256);
     ws.qlane = (uint32_t *)(p + off); off += align_up(nv * cap * sizeof(uint32_t), 256);
-    ws.qrec = (float *)(p + off); off += align_up(nv * cap * 9 * sizeof(float), 256);
+    ws.qrec = (float *)(p + off); off += align_up(nv * cap * rows * sizeof(float), 256);
     ws.skip = (unsigned char *)(p + off); off += align_up(nv * Wb * Hb, 256);
     ws.cap = (uint32_t)cap;
     ws.nblk = (uint32_t)nblk;
@@ -805,18 +872,30 @@ static Workspace carve(void *base, int W, int H, int spp, int nv) {
 }
 
 // Largest number of views (<= DSDF_MAX_BATCH, <= n_views) one launch can take with this workspace.
-static int batch_size(int W, int H, int spp, int n_views, size_t workspace_bytes) {
+static int batch_size(int W, int H, int spp, int n_views, int integrator, size_t workspace_bytes) {
     int nv = n_views < DSDF_MAX_BATCH ? n_views : DSDF_MAX_BATCH;
-    while (nv > 1 && carve(nullptr, W, H, spp, nv).bytes > workspace_bytes) --nv;
+    while (nv > 1 && carve(nullptr, W, H, spp, nv, integrator).bytes > workspace_bytes) --nv;
     return nv;
 }
 
 static ViewArgs make_view_args(const dsdf_camera &cam, int W, int H, int spp, const float *offsets, uint32_t seed,
-                               int integrator, int flags) {
+                               int integrator, int flags, const float *emitter_u = nullptr) {
     ViewArgs A;
     A.cam = cam; A.W = W; A.H = H; A.Wb = W + 2 * DSDF_BORDER; A.Hb = H + 2 * DSDF_BORDER; A.spp = spp;
-    A.integrator = integrator; A.flags = flags; A.seed = seed; A.offsets = offsets;
+    A.integrator = integrator; A.flags = flags; A.seed = seed; A.offsets = offsets; A.emitter_u = emitter_u;
     return A;
+}
+
+static ShadeArgs make_shade_args(const dsdf_shading *sh, bool with_grad) {
+    ShadeArgs S;
+    memset(&S, 0, sizeof(S));
+    if (sh) {
+        S.albedo.data = sh->albedo; S.albedo.rx = sh->ax; S.albedo.ry = sh->ay; S.albedo.rz = sh->az;
+        S.env[0] = sh->env_radiance[0]; S.env[1] = sh->env_radiance[1]; S.env[2] = sh->env_radiance[2];
+        S.hide_emitters = sh->hide_emitters;
+        S.grad_albedo = with_grad ? sh->grad_albedo : nullptr;
+    }
+    return S;
 }
 
 static size_t padded_floats(int rx, int ry, int rz) {
@@ -885,16 +964,18 @@ static dsdf_params pass_params(const dsdf_params &prm, int integrator) {
 
 static int check_render_args(const float *padded, int rx, int ry, int rz, const dsdf_params *prm,
                              const dsdf_camera *cams, int n_views, int W, int H, int spp, int integrator,
-                             void *workspace, size_t workspace_bytes) {
+                             const dsdf_shading *shading, void *workspace, size_t workspace_bytes) {
     if (!padded || !prm || !cams || !workspace) return fail(DSDF_ERR_INVALID_ARG, "null pointer argument");
     if (rx < 1 || ry < 1 || rz < 1 || n_views < 1 || W < 1 || H < 1 || spp < 1)
         return fail(DSDF_ERR_INVALID_ARG, "non-positive size argument");
-    if (integrator != DSDF_SILHOUETTE && integrator != DSDF_SIMPLE_SHADING)
+    if (integrator != DSDF_SILHOUETTE && integrator != DSDF_SIMPLE_SHADING && integrator != DSDF_DIRECT)
         return fail(DSDF_ERR_INVALID_ARG, "unknown integrator id");
+    if (integrator == DSDF_DIRECT && (!shading || !shading->albedo || shading->ax < 1 || shading->ay < 1 || shading->az < 1))
+        return fail(DSDF_ERR_INVALID_ARG, "sdf_direct_reparam needs a dsdf_shading with an albedo volume");
     size_t nl = (size_t)(W + 2 * DSDF_BORDER) * (H + 2 * DSDF_BORDER) * (size_t)spp;
     // reparam.py:48-50 wavefront-size limit
     if (nl > 0x40000000ull) return fail(DSDF_ERR_INVALID_ARG, "wavefront size exceeds 0x40000000 lanes");
-    if (workspace_bytes < dsdf_render_workspace_size(W, H, spp, 1)) return fail(DSDF_ERR_WORKSPACE, "workspace too small");
+    if (workspace_bytes < dsdf_render_workspace_size(W, H, spp, 1, integrator)) return fail(DSDF_ERR_WORKSPACE, "workspace too small");
     return DSDF_OK;
 }
 
@@ -960,35 +1041,39 @@ int dsdf_trace(const float *padded, int rx, int ry, int rz, const dsdf_params *p
     return check_launch("k_trace");
 }
 
-size_t dsdf_render_workspace_size(int width, int height, int spp, int n_views) {
+size_t dsdf_render_workspace_size(int width, int height, int spp, int n_views, int integrator) {
     if (width < 1 || height < 1 || spp < 1 || n_views < 1) return 0;
-    return carve(nullptr, width, height, spp, n_views < DSDF_MAX_BATCH ? n_views : DSDF_MAX_BATCH).bytes;
+    return carve(nullptr, width, height, spp, n_views < DSDF_MAX_BATCH ? n_views : DSDF_MAX_BATCH, integrator).bytes;
 }
 
 int dsdf_render_forward(const float *padded, int rx, int ry, int rz, const dsdf_params *prm, const dsdf_camera *cams,
                         int n_views, int width, int height, int spp, const float *offsets, const uint32_t *seeds,
-                        int integrator, int flags, float *image_out, void *workspace, size_t workspace_bytes,
-                        int64_t *stats, void *stream) {
-    int rc = check_render_args(padded, rx, ry, rz, prm, cams, n_views, width, height, spp, integrator, workspace,
+                        int integrator, int flags, const dsdf_shading *shading, float *image_out, void *workspace,
+                        size_t workspace_bytes, int64_t *stats, void *stream) {
+    int rc = check_render_args(padded, rx, ry, rz, prm, cams, n_views, width, height, spp, integrator, shading, workspace,
                                workspace_bytes);
     if (rc) return rc;
     if (!image_out) return fail(DSDF_ERR_INVALID_ARG, "dsdf_render_forward: image_out is null");
     if (!offsets && !seeds) return fail(DSDF_ERR_INVALID_ARG, "dsdf_render_forward: need offsets or seeds");
     hipStream_t st = (hipStream_t)stream;
     const dsdf_params pp = pass_params(*prm, integrator);
-    const int nb = batch_size(width, height, spp, n_views, workspace_bytes);
-    Workspace ws = carve(workspace, width, height, spp, nb);
+    const int nb = batch_size(width, height, spp, n_views, integrator, workspace_bytes);
+    Workspace ws = carve(workspace, width, height, spp, nb, integrator);
+    const bool direct = integrator == DSDF_DIRECT;
+    const size_t nch = (size_t)film_channels(integrator);
+    const float *emitter_u = direct ? shading->emitter_samples : nullptr;
     GridView G = device_view(padded, rx, ry, rz, *prm);
     size_t Wb = width + 2 * DSDF_BORDER, Hb = height + 2 * DSDF_BORDER;
     uint32_t nl = (uint32_t)(Wb * Hb * spp);
-    Queue q; q.count = ws.count; q.lane = ws.qlane; q.rec = ws.qrec; q.cap = ws.cap; q.nblk = ws.nblk;
+    Queue q; q.count = ws.count; q.lane = ws.qlane; q.rec = ws.qrec; q.rows = direct ? 18u : 9u; q.cap = ws.cap; q.nblk = ws.nblk;
     for (int v0 = 0; v0 < n_views; v0 += nb) {
         const int nv = (n_views - v0) < nb ? (n_views - v0) : nb;
         ViewBatch VB;
         for (int i = 0; i < nv; ++i)
             VB.v[i] = make_view_args(cams[v0 + i], width, height, spp, offsets ? offsets + (size_t)(v0 + i) * nl * 2 : nullptr,
-                                     seeds ? seeds[v0 + i] : 0u, integrator, flags);
-        if (hipMemsetAsync(ws.block, 0, nv * Wb * Hb * 2 * sizeof(float), st) != hipSuccess)
+                                     seeds ? seeds[v0 + i] : 0u, integrator, flags,
+                                     emitter_u ? emitter_u + (size_t)(v0 + i) * nl * 2 : nullptr);
+        if (hipMemsetAsync(ws.block, 0, nv * Wb * Hb * nch * sizeof(float), st) != hipSuccess)
             return fail(DSDF_ERR_LAUNCH, "hipMemsetAsync(block) failed");
         float step = 0.f;
         const int level = (flags & DSDF_NO_SKIP) ? -1 : skip_level(cams + v0, nv, width, rx, ry, rz, step);
@@ -1001,15 +1086,23 @@ int dsdf_render_forward(const float *padded, int rx, int ry, int rz, const dsdf_
             if ((rc = check_launch("k_skip_dilate"))) return rc;
             skip = ws.skip;
         }
-        if (spp % 64 == 0)
-            hipLaunchKernelGGL((k_render_pass<false, true>), dim3(ws.nblk, nv), dim3(DSDF_BLOCK), 0, st, G, pp, VB, ws.block, q,
-                               (unsigned long long *)stats, nl, 1, skip);
-        else
-            hipLaunchKernelGGL((k_render_pass<false, false>), dim3(ws.nblk, nv), dim3(DSDF_BLOCK), 0, st, G, pp, VB, ws.block, q,
-                               (unsigned long long *)stats, nl, 0, skip);
+        const ShadeArgs S = make_shade_args(shading, false);
+        const dim3 grid(ws.nblk, nv), blk(DSDF_BLOCK);
+        unsigned long long *st64 = (unsigned long long *)stats;
+        if (direct) {
+            if (spp % 64 == 0) hipLaunchKernelGGL((k_render_pass<false, true, true>), grid, blk, 0, st, G, pp, VB, ws.block, q, st64, nl, 1, skip, S);
+            else hipLaunchKernelGGL((k_render_pass<false, false, true>), grid, blk, 0, st, G, pp, VB, ws.block, q, st64, nl, 0, skip, S);
+        } else {
+            if (spp % 64 == 0) hipLaunchKernelGGL((k_render_pass<false, true, false>), grid, blk, 0, st, G, pp, VB, ws.block, q, st64, nl, 1, skip, S);
+            else hipLaunchKernelGGL((k_render_pass<false, false, false>), grid, blk, 0, st, G, pp, VB, ws.block, q, st64, nl, 0, skip, S);
+        }
         if ((rc = check_launch("k_render_pass<primal>"))) return rc;
-        hipLaunchKernelGGL(k_develop, dim3((width * height + 255) / 256, nv), dim3(256), 0, st, ws.block, width, height,
-                           image_out + (size_t)v0 * width * height * 3);
+        if (direct)
+            hipLaunchKernelGGL(k_develop_rgb, dim3((width * height + 255) / 256, nv), dim3(256), 0, st, ws.block, width, height,
+                               image_out + (size_t)v0 * width * height * 3);
+        else
+            hipLaunchKernelGGL(k_develop, dim3((width * height + 255) / 256, nv), dim3(256), 0, st, ws.block, width, height,
+                               image_out + (size_t)v0 * width * height * 3);
         if ((rc = check_launch("k_develop"))) return rc;
     }
     return DSDF_OK;
@@ -1017,28 +1110,33 @@ int dsdf_render_forward(const float *padded, int rx, int ry, int rz, const dsdf_
 
 int dsdf_render_backward(const float *padded, int rx, int ry, int rz, const dsdf_params *prm, const dsdf_camera *cams,
                          int n_views, int width, int height, int spp, const float *offsets, const uint32_t *seeds,
-                         int integrator, int flags, const float *grad_image, float *grad_grid, float *grad_p,
-                         float *image_out, void *workspace, size_t workspace_bytes, int64_t *stats, void *stream) {
-    int rc = check_render_args(padded, rx, ry, rz, prm, cams, n_views, width, height, spp, integrator, workspace,
+                         int integrator, int flags, const dsdf_shading *shading, const float *grad_image, float *grad_grid,
+                         float *grad_p, float *image_out, void *workspace, size_t workspace_bytes, int64_t *stats,
+                         void *stream) {
+    int rc = check_render_args(padded, rx, ry, rz, prm, cams, n_views, width, height, spp, integrator, shading, workspace,
                                workspace_bytes);
     if (rc) return rc;
     if (!grad_image || !grad_grid) return fail(DSDF_ERR_INVALID_ARG, "dsdf_render_backward: null gradient buffer");
     if (!offsets && !seeds) return fail(DSDF_ERR_INVALID_ARG, "dsdf_render_backward: need offsets or seeds");
     hipStream_t st = (hipStream_t)stream;
     const dsdf_params pp = pass_params(*prm, integrator);
-    const int nb = batch_size(width, height, spp, n_views, workspace_bytes);
-    Workspace ws = carve(workspace, width, height, spp, nb);
+    const int nb = batch_size(width, height, spp, n_views, integrator, workspace_bytes);
+    Workspace ws = carve(workspace, width, height, spp, nb, integrator);
+    const bool direct = integrator == DSDF_DIRECT;
+    const size_t nch = (size_t)film_channels(integrator);
+    const float *emitter_u = direct ? shading->emitter_samples : nullptr;
     GridView G = device_view(padded, rx, ry, rz, *prm);
     size_t Wb = width + 2 * DSDF_BORDER, Hb = height + 2 * DSDF_BORDER;
     uint32_t nl = (uint32_t)(Wb * Hb * spp);
-    Queue q; q.count = ws.count; q.lane = ws.qlane; q.rec = ws.qrec; q.cap = ws.cap; q.nblk = ws.nblk;
+    Queue q; q.count = ws.count; q.lane = ws.qlane; q.rec = ws.qrec; q.rows = direct ? 18u : 9u; q.cap = ws.cap; q.nblk = ws.nblk;
     for (int v0 = 0; v0 < n_views; v0 += nb) {
         const int nv = (n_views - v0) < nb ? (n_views - v0) : nb;
         ViewBatch VB;
         for (int i = 0; i < nv; ++i)
             VB.v[i] = make_view_args(cams[v0 + i], width, height, spp, offsets ? offsets + (size_t)(v0 + i) * nl * 2 : nullptr,
-                                     seeds ? seeds[v0 + i] : 0u, integrator, flags);
-        if (hipMemsetAsync(ws.block, 0, nv * Wb * Hb * 2 * sizeof(float), st) != hipSuccess)
+                                     seeds ? seeds[v0 + i] : 0u, integrator, flags,
+                                     emitter_u ? emitter_u + (size_t)(v0 + i) * nl * 2 : nullptr);
+        if (hipMemsetAsync(ws.block, 0, nv * Wb * Hb * nch * sizeof(float), st) != hipSuccess)
             return fail(DSDF_ERR_LAUNCH, "hipMemsetAsync(workspace) failed");
         float step = 0.f;
         const int level = (flags & DSDF_NO_SKIP) ? -1 : skip_level(cams + v0, nv, width, rx, ry, rz, step);
@@ -1051,23 +1149,30 @@ int dsdf_render_backward(const float *padded, int rx, int ry, int rz, const dsdf
             if ((rc = check_launch("k_skip_dilate"))) return rc;
             skip = ws.skip;
         }
-        if (spp % 64 == 0)
-            hipLaunchKernelGGL((k_render_pass<true, DSDF_DIFF_CACHE != 0>), dim3(ws.nblk, nv), dim3(DSDF_BLOCK), 0, st, G, pp, VB, ws.block, q,
-                               (unsigned long long *)stats, nl, 1, skip);
-        else
-            hipLaunchKernelGGL((k_render_pass<true, false>), dim3(ws.nblk, nv), dim3(DSDF_BLOCK), 0, st, G, pp, VB, ws.block, q,
-                               (unsigned long long *)stats, nl, 0, skip);
+        const ShadeArgs S = make_shade_args(shading, true);
+        const dim3 grid(ws.nblk, nv), blk(DSDF_BLOCK);
+        unsigned long long *st64 = (unsigned long long *)stats;
+        if (direct) {
+            if (spp % 64 == 0) hipLaunchKernelGGL((k_render_pass<true, false, true>), grid, blk, 0, st, G, pp, VB, ws.block, q, st64, nl, 1, skip, S);
+            else hipLaunchKernelGGL((k_render_pass<true, false, true>), grid, blk, 0, st, G, pp, VB, ws.block, q, st64, nl, 0, skip, S);
+        } else {
+            if (spp % 64 == 0) hipLaunchKernelGGL((k_render_pass<true, DSDF_DIFF_CACHE != 0, false>), grid, blk, 0, st, G, pp, VB, ws.block, q, st64, nl, 1, skip, S);
+            else hipLaunchKernelGGL((k_render_pass<true, false, false>), grid, blk, 0, st, G, pp, VB, ws.block, q, st64, nl, 0, skip, S);
+        }
         if ((rc = check_launch("k_render_pass<grad>"))) return rc;
+        const dim3 dev_grid((width * height + 255) / 256, nv), adj_grid((unsigned)((Wb * Hb + 255) / 256), nv);
         if (image_out) {
-            hipLaunchKernelGGL(k_develop, dim3((width * height + 255) / 256, nv), dim3(256), 0, st, ws.block, width, height,
-                               image_out + (size_t)v0 * width * height * 3);
+            float *img = image_out + (size_t)v0 * width * height * 3;
+            if (direct) hipLaunchKernelGGL(k_develop_rgb, dev_grid, dim3(256), 0, st, ws.block, width, height, img);
+            else hipLaunchKernelGGL(k_develop, dev_grid, dim3(256), 0, st, ws.block, width, height, img);
             if ((rc = check_launch("k_develop"))) return rc;
         }
-        hipLaunchKernelGGL(k_develop_adjoint, dim3((unsigned)((Wb * Hb + 255) / 256), nv), dim3(256), 0, st, ws.block,
-                           grad_image + (size_t)v0 * width * height * 3, width, height, ws.block_adj);
+        const float *gi = grad_image + (size_t)v0 * width * height * 3;
+        if (direct) hipLaunchKernelGGL(k_develop_adjoint_rgb, adj_grid, dim3(256), 0, st, ws.block, gi, width, height, ws.block_adj);
+        else hipLaunchKernelGGL(k_develop_adjoint, adj_grid, dim3(256), 0, st, ws.block, gi, width, height, ws.block_adj);
         if ((rc = check_launch("k_develop_adjoint"))) return rc;
-        hipLaunchKernelGGL(k_backward, dim3(ws.nblk, nv), dim3(64), 0, st, G, pp, VB, q, ws.block_adj, grad_grid,
-                           grad_p, (unsigned long long *)stats);
+        if (direct) hipLaunchKernelGGL(k_backward<true>, grid, dim3(64), 0, st, G, pp, VB, q, ws.block_adj, grad_grid, grad_p, st64, S);
+        else hipLaunchKernelGGL(k_backward<false>, grid, dim3(64), 0, st, G, pp, VB, q, ws.block_adj, grad_grid, grad_p, st64, S);
         if ((rc = check_launch("k_backward"))) return rc;
     }
     return DSDF_OK;

@@ -165,23 +165,24 @@ DSDF_HD void direct_radiance(const ShadeArgs &S, const DirectHit &h, float rgb[3
 }
 
 // forward value of one sample; `diff` selects the differentiable shadow trace (gradient pass)
-DSDF_HD void direct_value(const GridView &G, const dsdf_params &P, const ViewArgs &A, const ShadeArgs &S, const Lane &L,
+DSDF_HD bool direct_value(const GridView &G, const dsdf_params &P, const ViewArgs &A, const ShadeArgs &S, const Lane &L,
                           uint32_t lane, float its_t, bool diff, TraceOut &trs, float rgb[3]) {
     rgb[0] = rgb[1] = rgb[2] = 0.f;
     trs.its_t = 0.f; trs.warp_t = INFINITY; trs.warp_weight = 0.f; trs.weight_sum = 0.f;
     trs.warp_t_d = mk(0.f, 0.f, 0.f); trs.warp_weight_d = mk(0.f, 0.f, 0.f); trs.steps = 0; trs.refine_steps = 0;
     if (!(its_t < INFINITY)) {
         if (!S.hide_emitters) { rgb[0] = S.env[0]; rgb[1] = S.env[1]; rgb[2] = S.env[2]; }   // :25-26, 33
-        return;
+        return false;
     }
     DirectHit h;
-    if (!direct_setup(G, A, L, lane, its_t, h)) return;
+    if (!direct_setup(G, A, L, lane, its_t, h)) return false;
     dsdf_params Ps = P;
     Ps.refine_steps = 0;                                               // ray_test consumes only isfinite(its_t)
     if (diff) trace_diff(G, Ps, h.sr.o, h.sr.d, h.sr.maxt, trs);
     else trace_plain(G, Ps, h.sr.o, h.sr.d, h.sr.maxt, trs);
-    if (trs.its_t < INFINITY) return;                                  // occluded
+    if (trs.its_t < INFINITY) return false;                            // occluded
     direct_radiance(S, h, rgb);
+    return true;
 }
 
 // One 64-tap scatter into dL/dsdf: grad[tap] += cv * W_tap + cg . (res * dW_tap) at point x.

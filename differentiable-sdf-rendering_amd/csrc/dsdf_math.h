@@ -632,7 +632,7 @@ DSDF_HD void sampler_emitter_2d(uint32_t seed, uint32_t lane, float &e0, float &
 // ---------------------------------------------------------------------------
 // sdf_direct_reparam (integrators/sdf_direct_reparam.py:16-75) building blocks.  The BSDF and the emitter
 // come from scene files the reference does not ship; this repo fixes them as Mitsuba `diffuse` over a
-// trilinear reflectance volume on the unit cube and a `constant` environment emitter (oracle/sdf_oracle.py).
+// trilinear reflectance volume on the unit cube and a `constant` environment emitter.
 // ---------------------------------------------------------------------------
 #define DSDF_RAY_EPSILON 8.94069671630859375e-05f      /* mitsuba math::RayEpsilon<float> */
 #define DSDF_SHADOW_EPSILON (10.f * DSDF_RAY_EPSILON)

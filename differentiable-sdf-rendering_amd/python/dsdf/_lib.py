@@ -12,6 +12,7 @@ LIB_PATH = os.environ.get('DSDF_LIB_PATH') or os.path.normpath(os.path.join(_HER
 
 DSDF_SILHOUETTE = 0
 DSDF_SIMPLE_SHADING = 1
+DSDF_DIRECT = 2
 DSDF_REPARAM = 1
 DSDF_NO_SKIP = 2
 
@@ -27,6 +28,12 @@ class DsdfParams(C.Structure):
                 ('clamping_thresh', C.c_float), ('near_clip', C.c_float), ('far_clip', C.c_float),
                 ('sdf_p', C.c_float * 3), ('weight_strategy', C.c_int), ('refine_steps', C.c_int),
                 ('reserved', C.c_int * 2)]
+
+
+class DsdfShading(C.Structure):
+    _fields_ = [('albedo', C.c_void_p), ('ax', C.c_int), ('ay', C.c_int), ('az', C.c_int),
+                ('env_radiance', C.c_float * 3), ('hide_emitters', C.c_int), ('emitter_samples', C.c_void_p),
+                ('grad_albedo', C.c_void_p)]
 
 
 class DsdfError(RuntimeError):
@@ -47,17 +54,17 @@ SYMBOLS = {
     'dsdf_trace': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(DsdfParams), C.c_void_p, C.c_void_p,
                              C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                              C.c_void_p, C.c_void_p, C.c_void_p]),
-    'dsdf_render_workspace_size': (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    'dsdf_render_workspace_size': (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     'dsdf_render_forward': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(DsdfParams),
                                       C.POINTER(DsdfCamera), C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
-                                      C.POINTER(C.c_uint32), C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t,
-                                      C.c_void_p, C.c_void_p]),
+                                      C.POINTER(C.c_uint32), C.c_int, C.c_int, C.POINTER(DsdfShading), C.c_void_p, C.c_void_p,
+                                      C.c_size_t, C.c_void_p, C.c_void_p]),
     'dsdf_redistance_workspace_size': (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     'dsdf_redistance': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     'dsdf_render_backward': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(DsdfParams),
                                        C.POINTER(DsdfCamera), C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
-                                       C.POINTER(C.c_uint32), C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
-                                       C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
+                                       C.POINTER(C.c_uint32), C.c_int, C.c_int, C.POINTER(DsdfShading), C.c_void_p, C.c_void_p,
+                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
 }
 
 

@@ -12,10 +12,12 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import DSDF_NO_SKIP, DSDF_REPARAM, DSDF_SILHOUETTE, DSDF_SIMPLE_SHADING, DsdfCamera
+from ._lib import (DSDF_DIRECT, DSDF_NO_SKIP, DSDF_REPARAM, DSDF_SILHOUETTE, DSDF_SIMPLE_SHADING, DsdfCamera,
+                   DsdfShading)
 
 INTEGRATORS = {'sdf_silhouette_reparam': DSDF_SILHOUETTE, 'sdf_simple_shading_reparam': DSDF_SIMPLE_SHADING,
-               DSDF_SILHOUETTE: DSDF_SILHOUETTE, DSDF_SIMPLE_SHADING: DSDF_SIMPLE_SHADING}
+               'sdf_direct_reparam': DSDF_DIRECT,
+               DSDF_SILHOUETTE: DSDF_SILHOUETTE, DSDF_SIMPLE_SHADING: DSDF_SIMPLE_SHADING, DSDF_DIRECT: DSDF_DIRECT}
 
 STAT_NAMES = ('lanes', 'bbox_lanes', 'steps', 'hits', 'refine_steps', 'warp_active', 'queue_len', 'reserved')
 
@@ -90,6 +92,50 @@ class SdfGrid:
         return (self.rz, self.ry, self.rx)
 
 
+class Shading:
+    """Scene-side inputs of `sdf_direct_reparam` (python/integrators/sdf_direct_reparam.py): the diffuse
+    BSDF's reflectance volume `albedo` (Z,Y,X,3) -- 'main-bsdf.reflectance.volume.data',
+    python/opt_configs.py:286 -- and a constant environment emitter (include/dsdf.h: dsdf_shading)."""
+
+    def __init__(self, albedo, env_radiance=(1.0, 1.0, 1.0), hide_emitters=False):
+        self.albedo = albedo
+        self.env_radiance = (float(env_radiance),) * 3 if isinstance(env_radiance, (int, float)) else tuple(env_radiance)
+        self.hide_emitters = bool(hide_emitters)
+
+    def to_struct(self, n_views, n_lanes, emitter_samples=None, grad_albedo=None):
+        a = self.albedo.detach()
+        if a.dim() != 4 or a.shape[3] != 3:
+            raise _lib.DsdfError(f"albedo must be (Z,Y,X,3), got {tuple(a.shape)}")
+        a = _require_dev(a, 'albedo')
+        st = DsdfShading()
+        st.albedo = a.data_ptr()
+        st.az, st.ay, st.ax = (int(v) for v in a.shape[:3])
+        st.env_radiance[0], st.env_radiance[1], st.env_radiance[2] = self.env_radiance
+        st.hide_emitters = int(self.hide_emitters)
+        keep = [a]
+        if emitter_samples is not None:
+            emitter_samples = _require_dev(emitter_samples, 'emitter_samples')
+            if emitter_samples.numel() != n_views * n_lanes * 2:
+                raise _lib.DsdfError(f"emitter_samples must hold n_views*(W+4)*(H+4)*spp*2 = {n_views * n_lanes * 2} floats")
+            st.emitter_samples = emitter_samples.data_ptr()
+            keep.append(emitter_samples)
+        if grad_albedo is not None:
+            if tuple(grad_albedo.shape) != tuple(a.shape) or not grad_albedo.is_contiguous():
+                raise _lib.DsdfError("grad_albedo must be a contiguous tensor shaped like albedo")
+            _require_dev(grad_albedo, 'grad_albedo')
+            st.grad_albedo = grad_albedo.data_ptr()
+        return st, keep
+
+
+def _shading_arg(integrator, shading, n_views, n_lanes, emitter_samples=None, grad_albedo=None):
+    if INTEGRATORS[integrator] != DSDF_DIRECT:
+        return None, None
+    if shading is None:
+        raise _lib.DsdfError("sdf_direct_reparam needs shading=dsdf.Shading(albedo, ...)")
+    st, keep = shading.to_struct(n_views, n_lanes, emitter_samples, grad_albedo)
+    return C.byref(st), (st, keep)
+
+
 def eval_cubic(grid, points, order=2):
     """A1. points (n,3) -> v (n,), g (n,3), H (n,6: xx,yy,zz,xy,xz,yz)."""
     lib = _lib.load()
@@ -148,8 +194,9 @@ def _sampler_args(n_views, seeds, offsets, n_lanes):
 
 
 def render_forward(grid, sensors, spp, seeds=None, offsets=None, integrator=DSDF_SILHOUETTE, reparam=True, stats=None,
-                   empty_space_skip=True):
-    """`ReparamIntegrator.render` for a batch of views -> (n_views, H, W, 3)."""
+                   empty_space_skip=True, shading=None, emitter_samples=None):
+    """`ReparamIntegrator.render` for a batch of views -> (n_views, H, W, 3).  `shading` (dsdf.Shading) and the
+    optional per-lane `emitter_samples` belong to sdf_direct_reparam."""
     lib = _lib.load()
     sensors, cams, W, H = _views(sensors)
     nv = len(sensors)
@@ -157,21 +204,23 @@ def render_forward(grid, sensors, spp, seeds=None, offsets=None, integrator=DSDF
     offsets, cseeds = _sampler_args(nv, seeds, offsets, n_lanes)
     dev = grid.device
     img = torch.empty(nv, H, W, 3, dtype=torch.float32, device=dev)
-    wsb = lib.dsdf_render_workspace_size(W, H, int(spp), min(nv, MAX_VIEWS_PER_LAUNCH))
+    wsb = lib.dsdf_render_workspace_size(W, H, int(spp), min(nv, MAX_VIEWS_PER_LAUNCH), INTEGRATORS[integrator])
     ws = _workspace(dev, wsb)
+    sh, _keep = _shading_arg(integrator, shading, nv, n_lanes, emitter_samples)
     with torch.cuda.device(dev):
         _lib.check(lib.dsdf_render_forward(_ptr(grid.padded), grid.rx, grid.ry, grid.rz, C.byref(grid.params), cams, nv,
                                            W, H, int(spp), _ptr(offsets), cseeds, INTEGRATORS[integrator],
                                            (DSDF_REPARAM if reparam else 0) | (0 if empty_space_skip else DSDF_NO_SKIP),
-                                           _ptr(img), _ptr(ws), wsb, _ptr(stats), _stream()))
+                                           sh, _ptr(img), _ptr(ws), wsb, _ptr(stats), _stream()))
     return img
 
 
 def render_backward(grid, sensors, spp, grad_image, grad_grid=None, seeds=None, offsets=None,
                     integrator=DSDF_SILHOUETTE, reparam=True, stats=None, return_image=False, empty_space_skip=True,
-                    grad_p=None):
+                    grad_p=None, shading=None, emitter_samples=None, grad_albedo=None):
     """`ReparamIntegrator.render_backward`: accumulates dL/dsdf into grad_grid (Z,Y,X) and, if given,
-    dL/d(sdf.p) into grad_p (3 floats on the device; `sdf.p`, python/shapes.py:471)."""
+    dL/d(sdf.p) into grad_p (3 floats on the device; `sdf.p`, python/shapes.py:471) and, for
+    sdf_direct_reparam, dL/d(albedo) into grad_albedo (shaped like shading.albedo)."""
     lib = _lib.load()
     sensors, cams, W, H = _views(sensors)
     nv = len(sensors)
@@ -192,13 +241,14 @@ def render_backward(grid, sensors, spp, grad_image, grad_grid=None, seeds=None, 
             raise _lib.DsdfError("grad_p must be a contiguous float32 tensor of 3 elements")
         _require_dev(grad_p, 'grad_p')
     img = torch.empty(nv, H, W, 3, dtype=torch.float32, device=dev) if return_image else None
-    wsb = lib.dsdf_render_workspace_size(W, H, int(spp), min(nv, MAX_VIEWS_PER_LAUNCH))
+    wsb = lib.dsdf_render_workspace_size(W, H, int(spp), min(nv, MAX_VIEWS_PER_LAUNCH), INTEGRATORS[integrator])
     ws = _workspace(dev, wsb)
+    sh, _keep = _shading_arg(integrator, shading, nv, n_lanes, emitter_samples, grad_albedo)
     with torch.cuda.device(dev):
         _lib.check(lib.dsdf_render_backward(_ptr(grid.padded), grid.rx, grid.ry, grid.rz, C.byref(grid.params), cams, nv,
                                             W, H, int(spp), _ptr(offsets), cseeds, INTEGRATORS[integrator],
                                             (DSDF_REPARAM if reparam else 0) | (0 if empty_space_skip else DSDF_NO_SKIP),
-                                            _ptr(grad_image), _ptr(grad_grid), _ptr(grad_p),
+                                            sh, _ptr(grad_image), _ptr(grad_grid), _ptr(grad_p),
                                             _ptr(img), _ptr(ws), wsb, _ptr(stats), _stream()))
     return (grad_grid, img) if return_image else grad_grid
 
@@ -231,15 +281,19 @@ class _RenderOp(torch.autograd.Function):
     independent (seed_grad, spp_grad) gradient pass."""
 
     @staticmethod
-    def forward(ctx, data, grid, sensors, spp, seed, spp_grad, seed_grad, integrator, reparam, p=None):
+    def forward(ctx, data, grid, sensors, spp, seed, spp_grad, seed_grad, integrator, reparam, p=None, albedo=None,
+                shading=None):
+        if albedo is not None:
+            shading = Shading(albedo, shading.env_radiance, shading.hide_emitters)
         ctx.cfg = (grid, sensors, spp_grad, seed_grad, integrator, reparam)
+        ctx.shading = shading
         ctx.data_shape = data.shape
         ctx.p_meta = None if p is None else (p.shape, p.dtype, p.device)
         if p is not None:
             grid.set_translation(p)
         n = len(sensors)
         return render_forward(grid, sensors, spp, seeds=[seed + i for i in range(n)], integrator=integrator,
-                              reparam=reparam)
+                              reparam=reparam, shading=shading)
 
     @staticmethod
     def backward(ctx, grad_out):
@@ -247,20 +301,24 @@ class _RenderOp(torch.autograd.Function):
         n = len(sensors)
         want_p = ctx.p_meta is not None and ctx.needs_input_grad[9]
         gp = torch.zeros(3, dtype=torch.float32, device=grid.device) if want_p else None
+        sh = ctx.shading
+        want_a = sh is not None and ctx.needs_input_grad[10]
+        ga = torch.zeros_like(sh.albedo, dtype=torch.float32).contiguous() if want_a else None
         g = render_backward(grid, sensors, spp_grad, grad_out.contiguous(), seeds=[seed_grad + i for i in range(n)],
-                            integrator=integrator, reparam=reparam, grad_p=gp)
+                            integrator=integrator, reparam=reparam, grad_p=gp, shading=sh, grad_albedo=ga)
         if want_p:
             shape, dtype, dev = ctx.p_meta
             gp = gp.to(device=dev, dtype=dtype).reshape(shape)
         return (g.reshape(ctx.data_shape) if ctx.needs_input_grad[0] else None, None, None, None, None, None, None,
-                None, None, gp)
+                None, None, gp, ga, None)
 
 
 def render(data, grid, sensors, spp, seed=0, spp_grad=None, seed_grad=0, integrator=DSDF_SILHOUETTE, reparam=True,
-           p=None):
+           p=None, shading=None):
     """Differentiable render of `data` (the tensor behind `grid`) for one or more
     sensors: returns (n_views,H,W,3) attached to `data` and, if given, to the
     translation `p` (3,) (`SamplingIntegrator.sdf.p`)."""
     sensors = list(sensors) if isinstance(sensors, (list, tuple)) else [sensors]
+    albedo = shading.albedo if shading is not None else None      # attached when it requires grad (sdf_direct_reparam)
     return _RenderOp.apply(data, grid, sensors, int(spp), int(seed), int(spp_grad or spp), int(seed_grad),
-                           integrator, reparam, p)
+                           integrator, reparam, p, albedo, shading)

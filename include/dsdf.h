@@ -81,6 +81,20 @@ typedef struct dsdf_params {
     int   reserved[2];
 } dsdf_params;
 
+/* Scene-side inputs of sdf_direct_reparam (python/integrators/sdf_direct_reparam.py:16-75, emitter
+ * sampling only).  The reference takes BSDF and emitter from scene files it does not ship; this library
+ * fixes them as Mitsuba `diffuse` over a trilinear reflectance volume on the unit cube
+ * ('main-bsdf.reflectance.volume.data', python/opt_configs.py:286) and a `constant` environment emitter. */
+typedef struct dsdf_shading {
+    const float *albedo;          /* device, (az,ay,ax,3) fp32 */
+    int   ax, ay, az;
+    float env_radiance[3];
+    int   hide_emitters;          /* sdf_direct_reparam.py:12: escaping primary rays see black instead of the environment */
+    const float *emitter_samples; /* device, n_views x (W+4)(H+4)*spp x 2 in [0,1): the lane's emitter `next_2d()`
+                                     (sdf_direct_reparam.py:40), or NULL for the built-in sampler */
+    float *grad_albedo;           /* device, (az,ay,ax,3): dL/d(albedo) accumulator of dsdf_render_backward, or NULL */
+} dsdf_shading;
+
 int         dsdf_version(void);
 const char *dsdf_last_error(void);
 void        dsdf_default_params(dsdf_params *p);
@@ -116,10 +130,10 @@ int dsdf_trace(const float *padded, int rx, int ry, int rz, const dsdf_params *p
 
 /* Workspace (bytes) for dsdf_render_forward / dsdf_render_backward to process
  * `n_views` sensors of width x height at spp samples in ONE launch (film blocks,
- * per-sample backward queue).  The render calls batch as many views per launch as
+ * per-sample backward queue) with the given integrator (DSDF_DIRECT needs about twice as much).  The render calls batch as many views per launch as
  * the workspace they are given allows (at most 16); a workspace sized for one view
  * is always sufficient, larger ones overlap the ray-tracing tails of the views. */
-size_t dsdf_render_workspace_size(int width, int height, int spp, int n_views);
+size_t dsdf_render_workspace_size(int width, int height, int spp, int n_views, int integrator);
 
 /* `ReparamIntegrator.render` (python/integrators/reparam.py:120-185) for n_views
  * sensors: ray generation (Mitsuba perspective sensor), sphere tracing,
@@ -139,7 +153,7 @@ size_t dsdf_render_workspace_size(int width, int height, int spp, int n_views);
 int dsdf_render_forward(const float *padded, int rx, int ry, int rz, const dsdf_params *prm,
                         const dsdf_camera *cams, int n_views, int width, int height, int spp,
                         const float *offsets, const uint32_t *seeds,
-                        int integrator, int flags,
+                        int integrator, int flags, const dsdf_shading *shading /* DSDF_DIRECT only, else NULL */,
                         float *image_out, void *workspace, size_t workspace_bytes,
                         int64_t *stats, void *stream);
 
@@ -155,7 +169,7 @@ int dsdf_render_forward(const float *padded, int rx, int ry, int rz, const dsdf_
 int dsdf_render_backward(const float *padded, int rx, int ry, int rz, const dsdf_params *prm,
                          const dsdf_camera *cams, int n_views, int width, int height, int spp,
                          const float *offsets, const uint32_t *seeds,
-                         int integrator, int flags,
+                         int integrator, int flags, const dsdf_shading *shading /* DSDF_DIRECT only, else NULL */,
                          const float *grad_image, float *grad_grid, float *grad_p, float *image_out,
                          void *workspace, size_t workspace_bytes,
                          int64_t *stats, void *stream);

@@ -36,10 +36,11 @@ def test_default_params_and_sizes(built):
     assert C.sizeof(dsdf.DsdfParams) == 64 and C.sizeof(dsdf.DsdfCamera) == 64
     assert lib.dsdf_padded_size(256, 256, 256) == 262 ** 3 + 2 * 32 ** 3 + 2 * 64 ** 3   # padded copy + coarse min-grids
     assert lib.dsdf_padded_size(4, 5, 6) == 10 * 11 * 12 + 2 + 2 * (1 * 2 * 2)
-    ws = lib.dsdf_render_workspace_size(512, 512, 64, 1)
-    assert ws >= 516 * 516 * 64 * 40 and lib.dsdf_render_workspace_size(0, 4, 4, 1) == 0
-    assert lib.dsdf_render_workspace_size(512, 512, 64, 4) >= 4 * 516 * 516 * 64 * 40
-    assert lib.dsdf_render_workspace_size(64, 64, 4, 100) == lib.dsdf_render_workspace_size(64, 64, 4, 16)
+    ws = lib.dsdf_render_workspace_size(512, 512, 64, 1, 0)
+    assert ws >= 516 * 516 * 64 * 40 and lib.dsdf_render_workspace_size(0, 4, 4, 1, 0) == 0
+    assert lib.dsdf_render_workspace_size(512, 512, 64, 4, 0) >= 4 * 516 * 516 * 64 * 40
+    assert lib.dsdf_render_workspace_size(64, 64, 4, 100, 0) == lib.dsdf_render_workspace_size(64, 64, 4, 16, 0)
+    assert lib.dsdf_render_workspace_size(512, 512, 64, 1, 2) >= 516 * 516 * 64 * 76      # sdf_direct_reparam: 18-row records
 
 
 def test_argument_validation_before_device_work(built):
@@ -50,12 +51,14 @@ def test_argument_validation_before_device_work(built):
     assert b'bad argument' in lib.dsdf_last_error()
     cam = (dsdf.DsdfCamera * 1)()
     one = C.c_void_p(16)     # never dereferenced: validation fails first
-    rc = lib.dsdf_render_forward(one, 4, 4, 4, C.byref(p), cam, 1, 8, 8, 4, None, None, 7, 1, one, one, 1 << 30, None, None)
+    rc = lib.dsdf_render_forward(one, 4, 4, 4, C.byref(p), cam, 1, 8, 8, 4, None, None, 7, 1, None, one, one, 1 << 30, None, None)
     assert rc == -1 and b'integrator' in lib.dsdf_last_error()
-    rc = lib.dsdf_render_forward(one, 4, 4, 4, C.byref(p), cam, 1, 8, 8, 4, None, None, 0, 1, one, one, 16, None, None)
+    rc = lib.dsdf_render_forward(one, 4, 4, 4, C.byref(p), cam, 1, 8, 8, 4, None, None, 0, 1, None, one, one, 16, None, None)
     assert rc == -2 and b'workspace' in lib.dsdf_last_error()
-    rc = lib.dsdf_render_forward(one, 4, 4, 4, C.byref(p), cam, 1, 40000, 40000, 4, None, None, 0, 1, one, one, 1 << 62, None, None)
+    rc = lib.dsdf_render_forward(one, 4, 4, 4, C.byref(p), cam, 1, 40000, 40000, 4, None, None, 0, 1, None, one, one, 1 << 62, None, None)
     assert rc == -1 and b'wavefront' in lib.dsdf_last_error()       # reparam.py:48-50
+    rc = lib.dsdf_render_forward(one, 4, 4, 4, C.byref(p), cam, 1, 8, 8, 4, None, None, 2, 1, None, one, one, 1 << 30, None, None)
+    assert rc == -1 and b'dsdf_shading' in lib.dsdf_last_error()     # sdf_direct_reparam without its scene inputs
 
 
 def test_product_refuses_cpu_tensors(built):

@@ -1,0 +1,139 @@
+"""GPU parity of sdf_direct_reparam (integrators/sdf_direct_reparam.py:16-75, emitter sampling) through the
+C-ABI against the oracle, plus properties at GPU-only sample counts.  BSDF / emitter: this repo's spec
+(include/dsdf.h: dsdf_shading).  Tolerances as in test_gpu_parity.py."""
+import numpy as np
+import pytest
+import torch
+
+import sdf_oracle as O
+from cases import direct_inputs, make_case, oracle_direct
+from conftest import rel_l2
+
+pytestmark = pytest.mark.gpu
+
+FWD_TOL = 1e-4
+GRAD_TOL = 3e-3
+
+
+@pytest.fixture(scope='module')
+def dsdf(built):
+    import dsdf as m
+    m.load()
+    assert torch.cuda.is_available()
+    return m
+
+
+def setup(dsdf, case, ex, hide=False):
+    grid = dsdf.SdfGrid(case['grid'].float().cuda())
+    sen = dsdf.get_regular_cameras(case['ncam'], resx=case['W'], resy=case['H'])[case['icam']]
+    sh = dsdf.Shading(ex['albedo'].cuda(), ex['env'], hide_emitters=hide)
+    return grid, sen, sh
+
+
+@pytest.mark.parametrize('name', ['sphere16', 'blob32', 'blob32_spp64', 'blob48_rect'])
+@pytest.mark.parametrize('hide', [False, True])
+def test_direct_forward_gpu(dsdf, name, hide):
+    case = make_case(name)
+    ex = direct_inputs(case)
+    ref = oracle_direct(case, ex, reparam=False, hide_emitters=hide)
+    grid, sen, sh = setup(dsdf, case, ex, hide)
+    for skip in (True, False):
+        img = dsdf.render_forward(grid, sen, case['spp'], offsets=case['offsets'].cuda(), integrator='sdf_direct_reparam',
+                                  shading=sh, emitter_samples=ex['emitter_u'].cuda(), empty_space_skip=skip)[0]
+        assert rel_l2(img.cpu(), ref) < FWD_TOL
+
+
+@pytest.mark.parametrize('name', ['sphere16', 'blob32', 'blob32_spp64', 'blob48_rect'])
+@pytest.mark.parametrize('reparam', [True, False])
+def test_direct_backward_gpu(dsdf, name, reparam):
+    case = make_case(name)
+    ex = direct_inputs(case)
+    img_ref, gd, ga = oracle_direct(case, ex, reparam=reparam, grads=True)
+    grid, sen, sh = setup(dsdf, case, ex)
+    galb = torch.zeros_like(sh.albedo)
+    gp = torch.zeros(3, device='cuda')
+    gg, img = dsdf.render_backward(grid, sen, case['spp'], case['grad_image'].cuda()[None], offsets=case['offsets'].cuda(),
+                                   integrator='sdf_direct_reparam', reparam=reparam, return_image=True, shading=sh,
+                                   emitter_samples=ex['emitter_u'].cuda(), grad_albedo=galb, grad_p=gp)
+    assert rel_l2(img[0].cpu(), img_ref) < FWD_TOL
+    assert torch.isfinite(gg).all() and torch.isfinite(galb).all()
+    assert rel_l2(galb.cpu(), ga) < GRAD_TOL
+    assert rel_l2(gg.cpu(), gd) < GRAD_TOL
+
+
+def test_direct_builtin_sampler_and_batch(dsdf):
+    """In-kernel sampler (film position = floats 0,1; emitter sample = floats 3,4 of the lane's PCG32 stream)
+    equals explicit samples; a batch of views equals the single views."""
+    case = make_case('blob48_rect')
+    ex = direct_inputs(case)
+    grid, _, sh = setup(dsdf, case, ex)
+    sens = dsdf.get_regular_cameras(12, resx=case['W'], resy=case['H'])[:3]
+    n = (case['W'] + 4) * (case['H'] + 4) * 4
+    offs = torch.cat([torch.tensor(O.independent_sampler_2d(5 + i, n)) for i in range(3)]).cuda()
+    emit = torch.cat([torch.tensor(O.independent_sampler_emitter_2d(5 + i, n)) for i in range(3)]).cuda()
+    a = dsdf.render_forward(grid, sens, 4, seeds=[5, 6, 7], integrator='sdf_direct_reparam', shading=sh)
+    b = dsdf.render_forward(grid, sens, 4, offsets=offs, integrator='sdf_direct_reparam', shading=sh, emitter_samples=emit)
+    assert rel_l2(a.cpu(), b.cpu()) < 1e-6
+    for i, s in enumerate(sens):
+        one = dsdf.render_forward(grid, s, 4, seeds=[5 + i], integrator='sdf_direct_reparam', shading=sh)
+        assert rel_l2(a[i].cpu(), one[0].cpu()) < 1e-6
+
+
+def test_direct_known_answer_and_autograd(dsdf):
+    """Convex object under a constant environment: radiance = albedo * L (GPU-only sample count); the
+    autograd op delivers gradients for sdf.data and the albedo volume."""
+    R, W, H = 64, 48, 48
+    data = O.sphere_grid(R, radius=0.3).float().cuda().requires_grad_(True)
+    grid = dsdf.SdfGrid(data)
+    alb = torch.zeros(4, 4, 4, 3, device='cuda')
+    alb[..., 0], alb[..., 1], alb[..., 2] = 0.8, 0.5, 0.2
+    alb.requires_grad_(True)
+    sh = dsdf.Shading(alb, 2.0, hide_emitters=True)
+    sens = dsdf.get_regular_cameras(4, resx=W, resy=H)[:2]
+    img = dsdf.render(data, grid, sens, spp=256, seed=3, spp_grad=64, seed_grad=9, integrator='sdf_direct_reparam', shading=sh)
+    sil = dsdf.render_forward(grid, sens, 256, seeds=[3, 4])
+    inside = sil[..., 0] > 0.999
+    mean = img.detach()[inside].mean(0).cpu()
+    assert torch.allclose(mean, 2.0 * torch.tensor([0.8, 0.5, 0.2]), rtol=0.02), mean
+    assert float(img.detach()[0, 0, 0].abs().max()) == 0.0
+    (img - 0.3).abs().mean().backward()
+    assert data.grad is not None and torch.isfinite(data.grad).all() and data.grad.abs().sum() > 0
+    assert alb.grad is not None and torch.isfinite(alb.grad).all() and alb.grad.abs().sum() > 0
+
+
+def test_direct_gradient_vs_finite_differences_gpu(dsdf):
+    """Reparameterised gradient against central differences of the un-reparameterised render with common
+    random numbers (figures/result_utils.py:126-161), 2048 spp: w.r.t. a grid perturbation, the
+    translation sdf.p and a uniform albedo scale."""
+    R, W, H, spp = 64, 48, 48, 2048
+    base = O.sphere_grid(R, radius=0.3).float().cuda()
+    lin = torch.linspace(0, 1, R, device='cuda')
+    z, y, x = torch.meshgrid(lin, lin, lin, indexing='ij')
+    r = torch.sqrt((x - 0.5) ** 2 + (y - 0.5) ** 2 + (z - 0.5) ** 2).clamp(min=1e-3)
+    direction = (-(x - 0.5) / r + 0.5).contiguous()
+    torch.manual_seed(1)
+    alb = (torch.rand(5, 5, 5, 3, device='cuda') * 0.6 + 0.2)
+    sens = dsdf.get_regular_cameras(3, resx=W, resy=H)
+    yy, xx = torch.meshgrid(torch.arange(H, device='cuda'), torch.arange(W, device='cuda'), indexing='ij')
+    G = torch.stack([xx / W, yy / H, (xx + yy) / (W + H)], -1).float()[None].repeat(3, 1, 1, 1).contiguous()
+    seeds = [11, 12, 13]
+    sh = dsdf.Shading(alb, (1.0, 0.9, 0.8), hide_emitters=False)
+    galb, gp = torch.zeros_like(alb), torch.zeros(3, device='cuda')
+    grad = dsdf.render_backward(dsdf.SdfGrid(base), sens, spp, G, seeds=seeds, integrator='sdf_direct_reparam', shading=sh,
+                                grad_albedo=galb, grad_p=gp)
+
+    def L(data=base, shift=(0.0, 0.0, 0.0), scale=1.0):
+        g = dsdf.SdfGrid(data).set_translation(shift)
+        s2 = dsdf.Shading(alb * scale, (1.0, 0.9, 0.8), hide_emitters=False)
+        return float((dsdf.render_forward(g, sens, spp, seeds=seeds, integrator='sdf_direct_reparam', reparam=False, shading=s2) * G).sum())
+    eps = 2e-3
+    fd = (L(base + eps * direction) - L(base - eps * direction)) / (2 * eps)
+    ad = float((grad * direction).sum())
+    assert abs(ad - fd) < 0.08 * abs(fd) + 1.0, (ad, fd)
+    fd_p = [(L(shift=[eps if a == k else 0.0 for k in range(3)]) - L(shift=[-eps if a == k else 0.0 for k in range(3)])) / (2 * eps)
+            for a in range(3)]
+    scale = max(abs(v) for v in fd_p)
+    assert all(abs(float(gp[a]) - fd_p[a]) < 0.10 * scale + 1.0 for a in range(3)), (gp.tolist(), fd_p)
+    fd_a = (L(scale=1.01) - L(scale=0.99)) / 0.02                      # the render is linear in the albedo
+    ad_a = float((galb * alb).sum())
+    assert abs(ad_a - fd_a) < 0.01 * abs(fd_a) + 1e-3, (ad_a, fd_a)
