@@ -48,6 +48,10 @@ class SceneParameters(dict):
     def put_parameter(self, name, value, flags=None):
         self['SamplingIntegrator.' + name] = value
 
+    def put_scene_parameter(self, key, value, flags=None):
+        """Parameters Mitsuba would publish under a scene object id (e.g. 'main-bsdf.reflectance.volume.data')."""
+        self[key] = value
+
     def keep(self, keys):
         for k in [k for k in self if k not in keys]:
             del self[k]
@@ -62,6 +66,7 @@ class SceneParameters(dict):
             integ.sdf.set_data(self[SDF_DEFAULT_KEY])
         if SDF_DEFAULT_KEY_P in self:
             integ.sdf.p = self[SDF_DEFAULT_KEY_P]
+        integ.scene_parameters_changed(self)
         integ.parameters_changed(list(self))
 
 
@@ -106,7 +111,7 @@ class ReparamIntegrator:
         sens = self._sensors(scene, sensor)
         reparam = self._configured()
         img = dsdf.render_forward(self.sdf.grid, sens, spp or 4, seeds=[seed + i for i in range(len(sens))],
-                                  integrator=self.integrator_id, reparam=reparam)
+                                  integrator=self.integrator_id, reparam=reparam, shading=self.shading())
         return img[0] if len(sens) == 1 and not isinstance(sensor, (list, tuple)) else img
 
     def render_backward(self, scene, params, grad_in, sensor=0, seed=0, spp=0):
@@ -117,11 +122,17 @@ class ReparamIntegrator:
         pt = params[SDF_DEFAULT_KEY_P] if SDF_DEFAULT_KEY_P in params else None
         want_p = isinstance(pt, torch.Tensor) and pt.requires_grad
         gp = torch.zeros(3, dtype=torch.float32, device=self.sdf.grid.device) if want_p else None
+        sh = self.shading()
+        at = sh.albedo if sh is not None else None
+        want_a = isinstance(at, torch.Tensor) and at.requires_grad
+        ga = torch.zeros_like(at.detach(), dtype=torch.float32).contiguous() if want_a else None
         g = dsdf.render_backward(self.sdf.grid, sens, spp or 4, grad_in.reshape(len(sens), *grad_in.shape[-3:]).contiguous(),
                                  seeds=[seed + i for i in range(len(sens))], integrator=self.integrator_id, reparam=reparam,
-                                 grad_p=gp)
+                                 grad_p=gp, shading=sh, grad_albedo=ga)
         g = g.reshape(data.shape)
         data.grad = g if data.grad is None else data.grad + g
+        if want_a:
+            at.grad = ga if at.grad is None else at.grad + ga
         if want_p:
             gp = gp.to(device=pt.device, dtype=pt.dtype).reshape(pt.shape)
             pt.grad = gp if pt.grad is None else pt.grad + gp
@@ -133,6 +144,13 @@ class ReparamIntegrator:
         if self.sdf is not None:
             self.sdf.traverse(cb)
 
+    def shading(self):
+        """Scene-side inputs of the integrator (dsdf.Shading) -- only sdf_direct_reparam has any."""
+        return None
+
+    def scene_parameters_changed(self, params):
+        return None
+
     def parameters_changed(self, keys=None):
         if self.sdf is not None:
             self.sdf.parameters_changed(keys)
@@ -143,22 +161,25 @@ class ReparamIntegrator:
 
 class _RenderOp(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, data, scene, sensors, seed, spp, seed_grad, spp_grad):
+    def forward(ctx, data, albedo, scene, sensors, seed, spp, seed_grad, spp_grad):
         integ = scene.integrator()
         ctx.args = (scene, sensors, seed_grad, spp_grad, data.shape)
         integ.sdf.set_data(data.detach())
-        integ._configured()
+        reparam = integ._configured()
         return dsdf.render_forward(integ.sdf.grid, sensors, spp, seeds=[seed + i for i in range(len(sensors))],
-                                   integrator=integ.integrator_id, reparam=integ._configured())
+                                   integrator=integ.integrator_id, reparam=reparam, shading=integ.shading())
 
     @staticmethod
     def backward(ctx, grad_out):
         scene, sensors, seed_grad, spp_grad, shape = ctx.args
         integ = scene.integrator()
+        sh = integ.shading()
+        want_a = sh is not None and ctx.needs_input_grad[1]
+        ga = torch.zeros_like(sh.albedo.detach(), dtype=torch.float32).contiguous() if want_a else None
         g = dsdf.render_backward(integ.sdf.grid, sensors, spp_grad, grad_out.contiguous(),
                                  seeds=[seed_grad + i for i in range(len(sensors))], integrator=integ.integrator_id,
-                                 reparam=integ._configured())
-        return g.reshape(shape), None, None, None, None, None, None
+                                 reparam=integ._configured(), shading=sh, grad_albedo=ga)
+        return g.reshape(shape) if ctx.needs_input_grad[0] else None, ga, None, None, None, None, None, None
 
 
 def render(scene, params=None, sensor=0, seed=0, spp=4, seed_grad=0, spp_grad=None, integrator=None):
@@ -169,8 +190,11 @@ def render(scene, params=None, sensor=0, seed=0, spp=4, seed_grad=0, spp_grad=No
     single = not isinstance(sensor, (list, tuple))
     sens = integ._sensors(scene, sensor)
     data = params[SDF_DEFAULT_KEY] if params is not None and SDF_DEFAULT_KEY in params else None
-    if data is not None and data.requires_grad and torch.is_grad_enabled():
-        img = _RenderOp.apply(data, scene, sens, int(seed), int(spp), int(seed_grad), int(spp_grad or spp))
+    sh = integ.shading()
+    albedo = sh.albedo if sh is not None else None
+    attached = (data is not None and data.requires_grad) or (isinstance(albedo, torch.Tensor) and albedo.requires_grad)
+    if data is not None and attached and torch.is_grad_enabled():
+        img = _RenderOp.apply(data, albedo, scene, sens, int(seed), int(spp), int(seed_grad), int(spp_grad or spp))
     else:
         with torch.no_grad():
             if data is not None:

@@ -17,7 +17,7 @@ from constants import OUTPUT_DIR, RENDER_DIR
 def render_reference_images(scene_config, config, ref_spp=1024, force=False, verbose=False, mts_args=None):
     """python/optimize.py:11-29."""
     from integrators.reparam import Scene, create_integrator, render
-    from scenes import load_target_sdf
+    from scenes import load_target_albedo, load_target_sdf
     from shapes import Grid3d
     from util import set_sensor_res, write_image
     folder = join(RENDER_DIR, scene_config.scene, scene_config.name, config.integrator, 'ref')
@@ -32,7 +32,10 @@ def render_reference_images(scene_config, config, ref_spp=1024, force=False, ver
             continue
         if scene is None:
             target = load_target_sdf(scene_config.scene, res=max(128, 2 * 64))
-            scene = Scene(scene_config.sensors, create_integrator(config.integrator, {'sdf': Grid3d(target)}))
+            props = {'sdf': Grid3d(target)}
+            if config.integrator == 'sdf_direct_reparam':
+                props['reflectance'] = load_target_albedo(scene_config.scene)
+            scene = Scene(scene_config.sensors, create_integrator(config.integrator, props))
         with torch.no_grad():
             # 64-sample waves: round the reference spp up to a multiple of 64
             img = render(scene, sensor=sensor, seed=idx + 41, spp=((ref_spp + 63) // 64) * 64)

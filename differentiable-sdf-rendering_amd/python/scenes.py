@@ -51,3 +51,17 @@ def load_target_sdf(scene_name, res=128, device='cuda'):
     seed = 0 if scene_name == 'blobs' else int(hashlib.sha1(scene_name.encode()).hexdigest()[:8], 16)
     print(f"[scenes] no assets for '{scene_name}' under {SCENE_DIR}; using a procedural stand-in (seed {seed})")
     return _blobs(res, seed, device)
+
+
+def load_target_albedo(scene_name, res=32, device='cuda'):
+    """Reflectance volume (Z,Y,X,3) of the target for `sdf_direct_reparam` references:
+    `scenes/<scene>/<scene>-albedo.vol` if present, else a smooth procedural colour field in [0.15, 0.9]."""
+    path = os.path.join(SCENE_DIR, scene_name, f'{scene_name}-albedo.vol')
+    if os.path.isfile(path):
+        return read_vol(path, device)
+    z, y, x = _axes(res, device)
+    ph = (int(hashlib.sha1(scene_name.encode()).hexdigest()[:4], 16) % 628) / 100.0
+    r = 0.525 + 0.375 * torch.sin(6.0 * x + ph)
+    g = 0.525 + 0.375 * torch.sin(5.0 * y + 2.0 * ph)
+    b = 0.525 + 0.375 * torch.sin(7.0 * z + 3.0 * ph)
+    return torch.stack([r, g, b], -1).contiguous()

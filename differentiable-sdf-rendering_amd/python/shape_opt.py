@@ -49,8 +49,10 @@ def optimize_shape(scene_config, mts_args, ref_image_paths, output_dir, config, 
     integ.warp_field = config.get_warpfield(sdf_object)
     params = traverse(sdf_scene)
     params.keep(scene_config.param_keys)
-    if len(scene_config.param_keys) > 1:
-        raise NotImplementedError("texture variables need sdf_direct_reparam with scene BSDFs (DESIGN.md section 9)")
+    missing = [k for k in scene_config.param_keys if k not in params]
+    if missing:
+        raise NotImplementedError(f"parameters {missing} are not published by integrator '{config.integrator}' "
+                                  f"(reflectance volumes need sdf_direct_reparam; base_color/roughness are unsupported)")
     opt = Adam(lr=config.learning_rate, params=params, mask_updates=config.mask_optimizer)
     n_iter = config.n_iter
     scene_config.initialize(opt, sdf_scene)

@@ -139,3 +139,57 @@ def test_optimize_cli_end_to_end(dsdf, tmp_path, monkeypatch):
     import util
     final = util.read_vol(str(out / 'params' / 'sdf-data-final.vol'))
     assert final.shape[0] == 8 and torch.isfinite(final).all()          # 32 / 2^2 (two upsample steps not reached in 40 its)
+
+
+def test_direct_integrator_plugin(dsdf):
+    """The `sdf_direct_reparam` plugin publishes the reflectance volume next to sdf.data and its render op
+    attaches both (python/opt_configs.py:286 optimises exactly these two keys)."""
+    import configs
+    import shapes
+    from constants import SDF_DEFAULT_KEY
+    from integrators.reparam import Scene, create_integrator, render, traverse
+    from integrators.sdf_direct_reparam import REFLECTANCE_KEY
+    data = O.blob_grid(32, n=6, seed=1).float().cuda()
+    alb = (torch.rand(8, 8, 8, 3, device='cuda') * 0.6 + 0.2)
+    sens = dsdf.get_regular_cameras(3, resx=24, resy=24)
+    integ = create_integrator('sdf_direct_reparam', {'sdf': shapes.Grid3d(data.clone()), 'reflectance': alb, 'hide_emitters': True})
+    scene = Scene(sens, integ)
+    integ.warp_field = configs.get_config('warp').get_warpfield(integ.sdf)
+    params = traverse(scene)
+    assert set(params) == {SDF_DEFAULT_KEY, 'SamplingIntegrator.sdf.p', REFLECTANCE_KEY}
+    sh = dsdf.Shading(alb, 1.0, hide_emitters=True)
+    img = integ.render(scene, sensor=1, seed=5, spp=64)
+    ref = dsdf.render_forward(dsdf.SdfGrid(data), sens[1], 64, seeds=[5], integrator='sdf_direct_reparam', shading=sh)[0]
+    assert rel_l2(img.cpu(), ref.cpu()) < 1e-6 and float((img[..., 0] - img[..., 2]).abs().max()) > 0
+    params.keep([SDF_DEFAULT_KEY, REFLECTANCE_KEY])
+    p = params[SDF_DEFAULT_KEY].clone().requires_grad_(True)
+    a = alb.clone().requires_grad_(True)
+    params[SDF_DEFAULT_KEY], params[REFLECTANCE_KEY] = p, a
+    params.update()
+    out = render(scene, params, sensor=[sens[0], sens[2]], seed=3, spp=64, seed_grad=9, spp_grad=64)
+    out.sum().backward()
+    ga = torch.zeros_like(alb)
+    gref = dsdf.render_backward(dsdf.SdfGrid(data), [sens[0], sens[2]], 64, torch.ones(2, 24, 24, 3, device='cuda'),
+                                seeds=[9, 10], integrator='sdf_direct_reparam', shading=sh, grad_albedo=ga)
+    assert rel_l2(p.grad[..., 0].cpu(), gref.cpu()) < 1e-5 and rel_l2(a.grad.cpu(), ga.cpu()) < 1e-5
+    with pytest.raises(NotImplementedError):
+        create_integrator('sdf_direct_reparam', {'use_mis': True})
+
+
+def test_optimize_cli_textured(dsdf, tmp_path, monkeypatch):
+    """`python optimize.py sphere --optconfig diffuse-6`: shape and reflectance volume optimised jointly with the
+    default integrator of the method configs (sdf_direct_reparam)."""
+    import optimize
+    monkeypatch.setattr(optimize, 'RENDER_DIR', str(tmp_path / 'renders'))
+    args = ['sphere', '--optconfig', 'diffuse-6', '--configs', 'warp', '--outputdir', str(tmp_path / 'out'), '--refspp', '128',
+            '--n_iter=40', '--spp=64', '--sdf_res=32', '--resx=48', '--resy=48']
+    optimize.main(args)
+    out = tmp_path / 'out' / 'sphere' / 'diffuse-6' / 'warp'
+    meta = json.load(open(out / 'metadata.json'))
+    lv = meta['loss_values']
+    assert len(lv) == 40 and np.mean(lv[-5:]) < 0.7 * np.mean(lv[:3]), lv
+    assert (out / 'params' / 'main-bsdf-reflectance-volume-data-final.vol').exists()
+    import util
+    refl = util.read_vol(str(out / 'params' / 'main-bsdf-reflectance-volume-data-final.vol'))
+    assert refl.shape[-1] == 3 and float(refl.min()) >= 1e-5 and float(refl.max()) <= 1.0
+    assert float(refl.std()) > 1e-3                                        # moved away from the uniform initial value

@@ -41,6 +41,17 @@ for name, sp, sg, integ in (('sil_256_64', 256, 64, 0), ('shade_256_64', 256, 64
     p = timed(lambda: dsdf.render_forward(grid, sens, sp, seeds=list(range(12)), integrator=integ), 3)
     b = timed(lambda: dsdf.render_backward(grid, sens, sg, gi, grad_grid=gg, seeds=list(range(12)), integrator=integ), 3)
     out[name] = {'primal_ms': p, 'grad_ms': b, 'renders_per_s': 1e3 / (p + b)}
+# BASELINE.json C5: sdf_direct_reparam with a 3-channel 256^3 albedo volume (12 views x 512^2, 256/64 spp)
+alb = torch.rand(256, 256, 256, 3, device=dev) * 0.6 + 0.2
+galb = torch.zeros_like(alb)
+for hide in (True, False):
+    sh = dsdf.Shading(alb, 1.0, hide_emitters=hide)
+    p = timed(lambda: dsdf.render_forward(grid, sens, 256, seeds=list(range(12)), integrator='sdf_direct_reparam', shading=sh), 2)
+    b = timed(lambda: dsdf.render_backward(grid, sens, 64, gi, grad_grid=gg, seeds=list(range(12)), integrator='sdf_direct_reparam',
+                                           shading=sh, grad_albedo=galb), 2)
+    out['direct_256_64' + ('_hide_emitters' if hide else '')] = {'primal_ms': p, 'grad_ms': b, 'renders_per_s': 1e3 / (p + b)}
+del alb, galb
+torch.cuda.empty_cache()
 # BASELINE.json C4 grid size on one GPU (512^3, 12 views x 512^2, 256/64 spp)
 big = synth_grid(512, dev)
 gbig = dsdf.SdfGrid(big)
