@@ -697,6 +697,39 @@ __global__ __launch_bounds__(64) void k_backward(GridView G, dsdf_params P, View
     }
 }
 
+// Forward mode (`render_forward`, integrators/reparam.py:192-196): the queued samples of the gradient pass push
+// the tangent of their film contribution into a tangent film block (the transpose of k_backward: gathers from
+// the tangent grid instead of scattering into the gradient grid).
+__global__ __launch_bounds__(64) void k_forward_tangent(GridView G, const float *__restrict__ tangent, V3 dp, dsdf_params P,
+                                                        ViewBatch VB, Queue qall, float *__restrict__ dblocks) {
+    const ViewArgs &A = VB.v[blockIdx.y];
+    float *__restrict__ dblock = dblocks + (size_t)blockIdx.y * 2 * A.Wb * A.Hb;
+    const Queue q = view_queue(qall, blockIdx.y);
+    const uint32_t count = q.count[blockIdx.x];
+    for (uint32_t slot = threadIdx.x; slot < count; slot += 64) {
+        const uint32_t lane = q.lane[blockIdx.x * DSDF_BLOCK + slot];
+        TraceOut tr;
+        load_record(q.rec + lane, q.cap, tr);
+        Lane L = lane_setup(A, P, lane);
+        SampleTangent st;
+        if (lane_forward_tangent(G, tangent, dp, P, A, L, tr, st)) splat_tangent(dblock, A.Wb, A.Hb, st, AtomicAdd());
+    }
+}
+
+// d(value / weight) = d value / weight - value d weight / weight^2, R=G=B.
+__global__ void k_develop_tangent(const float *__restrict__ blocks, const float *__restrict__ dblocks, int W, int H,
+                                  float *__restrict__ grad_images) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= W * H) return;
+    int y = i / W, x = i - y * W;
+    int Wb = W + 2 * DSDF_BORDER, Hb = H + 2 * DSDF_BORDER;
+    size_t qi = (size_t)blockIdx.y * Wb * Hb + (size_t)(y + DSDF_BORDER) * Wb + x + DSDF_BORDER;
+    float2 b = reinterpret_cast<const float2 *>(blocks)[qi], db = reinterpret_cast<const float2 *>(dblocks)[qi];
+    float g = b.y == 0.f ? db.x : db.x / b.y - b.x * db.y / (b.y * b.y);
+    float *o = grad_images + (size_t)blockIdx.y * 3 * W * H + 3 * (size_t)i;
+    o[0] = g; o[1] = g; o[2] = g;
+}
+
 // ------------------------------------------------------------------ redistancing
 // |grad u| = 1 with a frozen sub-voxel interface band (spec: include/dsdf.h, dsdf_redistance).
 // Block-iterative solver: a 512-thread block relaxes an 8^3 tile (+1 halo) in LDS for 8 inner
@@ -1178,6 +1211,66 @@ int dsdf_render_backward(const float *padded, int rx, int ry, int rz, const dsdf
     return DSDF_OK;
 }
 
+
+int dsdf_render_forward_grad(const float *padded, int rx, int ry, int rz, const dsdf_params *prm, const dsdf_camera *cams,
+                             int n_views, int width, int height, int spp, const float *offsets, const uint32_t *seeds,
+                             int integrator, int flags, const float *tangent_padded, const float *tangent_p,
+                             float *grad_image_out, float *image_out, void *workspace, size_t workspace_bytes, void *stream) {
+    int rc = check_render_args(padded, rx, ry, rz, prm, cams, n_views, width, height, spp, integrator, nullptr, workspace,
+                               workspace_bytes);
+    if (rc) return rc;
+    if (integrator == DSDF_DIRECT) return fail(DSDF_ERR_INVALID_ARG, "dsdf_render_forward_grad: sdf_direct_reparam is not supported");
+    if (!grad_image_out) return fail(DSDF_ERR_INVALID_ARG, "dsdf_render_forward_grad: grad_image_out is null");
+    if (!tangent_padded && !tangent_p) return fail(DSDF_ERR_INVALID_ARG, "dsdf_render_forward_grad: need a tangent");
+    if (!offsets && !seeds) return fail(DSDF_ERR_INVALID_ARG, "dsdf_render_forward_grad: need offsets or seeds");
+    hipStream_t st = (hipStream_t)stream;
+    const dsdf_params pp = pass_params(*prm, integrator);
+    const int nb = batch_size(width, height, spp, n_views, integrator, workspace_bytes);
+    Workspace ws = carve(workspace, width, height, spp, nb, integrator);
+    GridView G = device_view(padded, rx, ry, rz, *prm);
+    size_t Wb = width + 2 * DSDF_BORDER, Hb = height + 2 * DSDF_BORDER;
+    uint32_t nl = (uint32_t)(Wb * Hb * spp);
+    Queue q; q.count = ws.count; q.lane = ws.qlane; q.rec = ws.qrec; q.rows = 9u; q.cap = ws.cap; q.nblk = ws.nblk;
+    const V3 dp = tangent_p ? mk(tangent_p[0], tangent_p[1], tangent_p[2]) : mk(0.f, 0.f, 0.f);
+    const ShadeArgs S = make_shade_args(nullptr, false);
+    for (int v0 = 0; v0 < n_views; v0 += nb) {
+        const int nv = (n_views - v0) < nb ? (n_views - v0) : nb;
+        ViewBatch VB;
+        for (int i = 0; i < nv; ++i)
+            VB.v[i] = make_view_args(cams[v0 + i], width, height, spp, offsets ? offsets + (size_t)(v0 + i) * nl * 2 : nullptr,
+                                     seeds ? seeds[v0 + i] : 0u, integrator, flags);
+        // film block and its tangent (the adjoint block's storage) are adjacent in the workspace
+        if (hipMemsetAsync(ws.block, 0, nv * Wb * Hb * 2 * sizeof(float), st) != hipSuccess ||
+            hipMemsetAsync(ws.block_adj, 0, nv * Wb * Hb * 2 * sizeof(float), st) != hipSuccess)
+            return fail(DSDF_ERR_LAUNCH, "hipMemsetAsync(workspace) failed");
+        float step = 0.f;
+        const int level = (flags & DSDF_NO_SKIP) ? -1 : skip_level(cams + v0, nv, width, rx, ry, rz, step);
+        const unsigned char *skip = nullptr;
+        if (level >= 0) {
+            hipLaunchKernelGGL(k_pixel_skip, dim3((unsigned)((Wb * Hb + 255) / 256), nv), dim3(256), 0, st,
+                               device_view(padded, rx, ry, rz, *prm, level), pp, VB, ws.skip, step);
+            if ((rc = check_launch("k_pixel_skip"))) return rc;
+            hipLaunchKernelGGL(k_skip_dilate, dim3((unsigned)((Wb * Hb + 255) / 256), nv), dim3(256), 0, st, VB, ws.skip);
+            if ((rc = check_launch("k_skip_dilate"))) return rc;
+            skip = ws.skip;
+        }
+        const dim3 grid(ws.nblk, nv), blk(DSDF_BLOCK);
+        if (spp % 64 == 0) hipLaunchKernelGGL((k_render_pass<true, DSDF_DIFF_CACHE != 0, false>), grid, blk, 0, st, G, pp, VB, ws.block, q, (unsigned long long *)nullptr, nl, 1, skip, S);
+        else hipLaunchKernelGGL((k_render_pass<true, false, false>), grid, blk, 0, st, G, pp, VB, ws.block, q, (unsigned long long *)nullptr, nl, 0, skip, S);
+        if ((rc = check_launch("k_render_pass<grad>"))) return rc;
+        hipLaunchKernelGGL(k_forward_tangent, grid, dim3(64), 0, st, G, tangent_padded, dp, pp, VB, q, ws.block_adj);
+        if ((rc = check_launch("k_forward_tangent"))) return rc;
+        const dim3 dev_grid((width * height + 255) / 256, nv);
+        hipLaunchKernelGGL(k_develop_tangent, dev_grid, dim3(256), 0, st, ws.block, ws.block_adj, width, height,
+                           grad_image_out + (size_t)v0 * width * height * 3);
+        if ((rc = check_launch("k_develop_tangent"))) return rc;
+        if (image_out) {
+            hipLaunchKernelGGL(k_develop, dev_grid, dim3(256), 0, st, ws.block, width, height, image_out + (size_t)v0 * width * height * 3);
+            if ((rc = check_launch("k_develop"))) return rc;
+        }
+    }
+    return DSDF_OK;
+}
 
 size_t dsdf_redistance_workspace_size(int rx, int ry, int rz) {
     if (rx < 1 || ry < 1 || rz < 1) return 0;

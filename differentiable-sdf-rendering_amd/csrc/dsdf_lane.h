@@ -130,6 +130,109 @@ DSDF_HD void splat_lane_rgb(float *block, int Wb, int Hb, float u, float v, cons
 }
 
 // ---------------------------------------------------------------------------
+// Forward mode (`ReparamIntegrator.render_forward`, integrators/reparam.py:192-196; used by the reference's
+// gradient-image validation, figures/result_utils.py:126-161, with the tangent on `sdf.p`): the tangent of one
+// gradient-pass sample's film contribution for a tangent grid `T` (d sdf.data, may be absent) and a tangent
+// `dp` of the translation sdf.p.  Exactly the transpose of lane_backward: every attached quantity is linear in
+// the SDF value / gradient at the warp point and at the hit point,
+//   dv = T(x) - g . dp,   dg = grad T(x) - H dp   (the grid is looked up at x - p),
+// and  d dir = cdir dv_w,  d div = a dv_w + b . dg_w;  shading adds  dt = (dv_0 + t G . d dir) / (G . -d),
+// d p_hit = t d dir + d dt,  dG = dg_0 + H d p_hit,  d val = [n.l > 0] l . (I - n n^T) dG / |G|.
+// Outputs: tangents of the sample's value / weight channel entries and of its film position.
+// ---------------------------------------------------------------------------
+struct SampleTangent { float val, d_val, d_w, d_u, d_v, u, v; };
+
+DSDF_HD bool lane_forward_tangent(const GridView &G, const float *tangent, V3 dp, const dsdf_params &P, const ViewArgs &A,
+                                  const Lane &L, const TraceOut &tr, SampleTangent &out) {
+    const V3 o = L.ray.o, d = L.ray.d;
+    const bool hit = tr.its_t < INFINITY;
+    GridView T = G;
+    T.p = tangent;
+    Reproj rp = reproject(A.cam, P, o + d, A.W, A.H);
+    out.u = rp.u; out.v = rp.v;
+    out.val = 0.f; out.d_val = 0.f; out.d_w = 0.f; out.d_u = 0.f; out.d_v = 0.f;
+    V3 d_dir = mk(0.f, 0.f, 0.f);
+    float d_div = 0.f;
+    bool did = false;
+    if (A.flags & DSDF_REPARAM) {
+        WarpCoef wc;
+        if (warp_coefficients(G, P, o, d, tr, wc)) {
+            float tv = 0.f; V3 tg = mk(0.f, 0.f, 0.f); float tH[6];
+            if (tangent) eval_cubic<1>(T, fma3(tr.warp_t, d, o), tv, tg, tH);
+            const float dv = tv - dot(wc.g, dp);
+            const V3 dg = tg - symmul(wc.H, dp);
+            d_dir = dv * wc.cdir;
+            d_div = wc.a * dv + dot(wc.b, dg);
+            did = true;
+        }
+    }
+    if (hit) {
+        if (A.integrator == DSDF_SILHOUETTE) out.val = 1.f;
+        else {
+            const V3 phit = fma3(tr.its_t, d, o);
+            float vhit; V3 ghit; float Hhit[6];
+            eval_cubic<2>(G, phit, vhit, ghit, Hhit);
+            const float gl = sqrtf(dot(ghit, ghit));
+            const V3 n = ghit * (1.f / gl);
+            const V3 l = light_dir();
+            const float ndl = dot(n, l);
+            out.val = fmaxf(ndl, 0.f);
+            float tv = 0.f; V3 tg = mk(0.f, 0.f, 0.f); float tH[6];
+            if (tangent) eval_cubic<1>(T, phit, tv, tg, tH);
+            const float dv0 = tv - dot(ghit, dp) + tr.its_t * dot(ghit, d_dir);
+            const float dt = dv0 / dot(ghit, -d);
+            const V3 dpos = tr.its_t * d_dir + dt * d;
+            const V3 dG = tg - symmul(Hhit, dp) + symmul(Hhit, dpos);
+            if (ndl > 0.f) out.d_val = (dot(l, dG) - ndl * dot(n, dG)) / gl;
+            did = true;
+        }
+    }
+    // a_v = val * div * rw, a_w = div * rw (div, rw have value 1); film position through the attached direction
+    const V3 dref = mk(A.cam.left[0] * d_dir.x + A.cam.left[1] * d_dir.y + A.cam.left[2] * d_dir.z,
+                       A.cam.up[0] * d_dir.x + A.cam.up[1] * d_dir.y + A.cam.up[2] * d_dir.z,
+                       A.cam.dir[0] * d_dir.x + A.cam.dir[1] * d_dir.y + A.cam.dir[2] * d_dir.z);
+    const float iz = 1.f / rp.ref.z;
+    const float ku = -0.5f * (float)A.W / A.cam.tan_half_fov;
+    out.d_u = ku * iz * (dref.x - rp.ref.x * iz * dref.z);
+    out.d_v = ku * iz * (dref.y - rp.ref.y * iz * dref.z);
+    float d_rw = 0.f;
+    if (rp.inside) d_rw = dot(rp.ref, dref) / (rp.dist * rp.dist) - 3.f * iz * dref.z;
+    out.d_w = d_div + d_rw;
+    out.d_val = out.d_val + out.val * out.d_w;
+    return did;
+}
+
+// splat of a sample tangent into the tangent film block (value, weight): d(f a) = f da + a (f_u du + f_v dv)
+template <class Adder>
+DSDF_HD void splat_tangent(float *dblock, int Wb, int Hb, const SampleTangent &s, Adder add) {
+    float pfx = s.u + (DSDF_BORDER - 0.5f), pfy = s.v + (DSDF_BORDER - 0.5f);
+    int x0 = (int)ceilf(pfx - DSDF_FILTER_RADIUS), y0 = (int)ceilf(pfy - DSDF_FILTER_RADIUS);
+    float wx[4], wy[4], dwx[4], dwy[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        float rx = (float)(x0 + i) - pfx, ry = (float)(y0 + i) - pfy;
+        wx[i] = gauss_f(rx); dwx[i] = gauss_df(rx);
+        wy[i] = gauss_f(ry); dwy[i] = gauss_df(ry);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        int qy = y0 + j;
+        if (qy < 0 || qy >= Hb) continue;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int qx = x0 + i;
+            if (qx < 0 || qx >= Wb) continue;
+            float f = wx[i] * wy[j];
+            float dfp = -dwx[i] * wy[j] * s.d_u - wx[i] * dwy[j] * s.d_v;     // d f / d(u,v) . (du, dv)
+            float tv = f * s.d_val + s.val * dfp, tw = f * s.d_w + dfp;
+            float *dst = dblock + 2 * ((size_t)qy * Wb + qx);
+            if (tv != 0.f) add(dst, tv);
+            if (tw != 0.f) add(dst + 1, tw);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
 // sdf_direct_reparam.sample() (integrators/sdf_direct_reparam.py:16-75, use_mis = False): emitter sampling of a
 // constant environment through a (reparameterised) shadow ray, diffuse BSDF with a trilinear albedo volume.
 // The primary determinant multiplies in at the caller.  `trs` receives the shadow-ray trace (its_t = inf

@@ -253,6 +253,40 @@ def render_backward(grid, sensors, spp, grad_image, grad_grid=None, seeds=None, 
     return (grad_grid, img) if return_image else grad_grid
 
 
+def render_forward_grad(grid, sensors, spp, tangent_data=None, tangent_p=None, seeds=None, offsets=None,
+                        integrator=DSDF_SILHOUETTE, reparam=True, return_image=False, empty_space_skip=True):
+    """`ReparamIntegrator.render_forward` (python/integrators/reparam.py:192-196): forward-mode gradient image(s)
+    (n_views,H,W,3) for a tangent on sdf.data (tensor shaped like the grid) and / or on sdf.p (3 floats)."""
+    lib = _lib.load()
+    sensors, cams, W, H = _views(sensors)
+    nv = len(sensors)
+    n_lanes = (W + 4) * (H + 4) * int(spp)
+    offsets, cseeds = _sampler_args(nv, seeds, offsets, n_lanes)
+    dev = grid.device
+    tpad = None
+    if tangent_data is not None:
+        t = tangent_data[..., 0] if tangent_data.dim() == 4 else tangent_data
+        if tuple(t.shape) != grid.shape:
+            raise _lib.DsdfError(f"tangent_data must match the grid {grid.shape}, got {tuple(t.shape)}")
+        tpad = SdfGrid(t, grid.params).padded
+    tp = None
+    if tangent_p is not None:
+        vals = tangent_p.detach().cpu().tolist() if isinstance(tangent_p, torch.Tensor) else list(tangent_p)
+        tp = (C.c_float * 3)(*[float(v) for v in vals])
+    if tpad is None and tp is None:
+        raise _lib.DsdfError("render_forward_grad needs tangent_data and / or tangent_p")
+    out = torch.empty(nv, H, W, 3, dtype=torch.float32, device=dev)
+    img = torch.empty(nv, H, W, 3, dtype=torch.float32, device=dev) if return_image else None
+    wsb = lib.dsdf_render_workspace_size(W, H, int(spp), min(nv, MAX_VIEWS_PER_LAUNCH), INTEGRATORS[integrator])
+    ws = _workspace(dev, wsb)
+    with torch.cuda.device(dev):
+        _lib.check(lib.dsdf_render_forward_grad(_ptr(grid.padded), grid.rx, grid.ry, grid.rz, C.byref(grid.params), cams, nv,
+                                                W, H, int(spp), _ptr(offsets), cseeds, INTEGRATORS[integrator],
+                                                (DSDF_REPARAM if reparam else 0) | (0 if empty_space_skip else DSDF_NO_SKIP),
+                                                _ptr(tpad), tp, _ptr(out), _ptr(img), _ptr(ws), wsb, _stream()))
+    return (out, img) if return_image else out
+
+
 def redistance(phi):
     """`redistancing.redistance`: signed distance field with the zero level set of phi (Z,Y,X[,1])."""
     lib = _lib.load()

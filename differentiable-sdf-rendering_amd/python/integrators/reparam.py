@@ -138,7 +138,20 @@ class ReparamIntegrator:
             pt.grad = gp if pt.grad is None else pt.grad + gp
 
     def render_forward(self, scene, params, sensor=0, seed=0, spp=0):
-        raise NotImplementedError("forward-mode gradients (render_forward) are outside the supported path")
+        """python/integrators/reparam.py:192-196: forward-mode gradient image.  Dr.Jit seeds the tangent with
+        `dr.set_grad` / `dr.forward(param)`; here the tangent of a parameter is its `.grad` field (sdf.data: a tensor
+        of the same shape; sdf.p: 3 floats, e.g. (1,0,0) for `dr.forward(p.x)`, figures/result_utils.py:126-161)."""
+        sens = self._sensors(scene, sensor)
+        reparam = self._configured()
+        data = params[SDF_DEFAULT_KEY] if SDF_DEFAULT_KEY in params else None
+        pt = params[SDF_DEFAULT_KEY_P] if SDF_DEFAULT_KEY_P in params else None
+        td = data.grad if isinstance(data, torch.Tensor) and data.grad is not None else None
+        tp = pt.grad if isinstance(pt, torch.Tensor) and pt.grad is not None else None
+        if td is None and tp is None:
+            raise ValueError("render_forward: set the tangent of sdf.data and / or sdf.p through their .grad fields")
+        g = dsdf.render_forward_grad(self.sdf.grid, sens, spp or 4, tangent_data=td, tangent_p=tp,
+                                     seeds=[seed + i for i in range(len(sens))], integrator=self.integrator_id, reparam=reparam)
+        return g[0] if len(sens) == 1 and not isinstance(sensor, (list, tuple)) else g
 
     def traverse(self, cb):
         if self.sdf is not None:

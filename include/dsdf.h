@@ -174,6 +174,19 @@ int dsdf_render_backward(const float *padded, int rx, int ry, int rz, const dsdf
                          void *workspace, size_t workspace_bytes,
                          int64_t *stats, void *stream);
 
+/* `ReparamIntegrator.render_forward` (python/integrators/reparam.py:192-196): forward-mode gradient image
+ * d image / d theta (n_views x H x W x 3) of a gradient-pass render at `spp`, for the tangent
+ *   tangent_padded : d(sdf.data)/d theta as a padded grid buffer (dsdf_pad_grid of the tangent tensor), or NULL
+ *   tangent_p      : d(sdf.p)/d theta, 3 HOST floats, or NULL -- the reference's gradient-image validation
+ *                    differentiates with respect to one axis of sdf.p (figures/result_utils.py:126-161).
+ * Silhouette and simple-shading integrators.  image_out (optional) receives the gradient-pass image. */
+int dsdf_render_forward_grad(const float *padded, int rx, int ry, int rz, const dsdf_params *prm,
+                             const dsdf_camera *cams, int n_views, int width, int height, int spp,
+                             const float *offsets, const uint32_t *seeds, int integrator, int flags,
+                             const float *tangent_padded, const float *tangent_p,
+                             float *grad_image_out, float *image_out,
+                             void *workspace, size_t workspace_bytes, void *stream);
+
 /* `redistancing.redistance(phi)` (python/redistancing.py:4-13 -> fastsweep.redistance, an
  * un-vendored native dependency): re-initialises phi (rz,ry,rx) to a signed distance field
  * with the same zero level set, grid spacing 1/res on the unit cube.  Spec: frozen sub-voxel

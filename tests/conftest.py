@@ -81,6 +81,18 @@ class HostHarness:
                                     self._p(gg), self._p(img), self._p(self.last_grad_p))
         return gg, img
 
+    def render_forward_grad(self, grid, cam, W, H, spp, offsets, integrator, tangent=None, tangent_p=None, reparam=True, seed=0):
+        grid = np.ascontiguousarray(grid, np.float32)
+        offsets = None if offsets is None else np.ascontiguousarray(offsets, np.float32)
+        tangent = None if tangent is None else np.ascontiguousarray(tangent, np.float32)
+        tangent_p = None if tangent_p is None else np.ascontiguousarray(tangent_p, np.float32)
+        out = np.zeros((H, W, 3), np.float32)
+        rz, ry, rx = grid.shape
+        self.lib.hh_render_forward_grad(self._p(grid), rx, ry, rz, C.byref(self.params), self._p(cam), W, H, spp,
+                                        self._p(offsets), C.c_uint(seed), integrator, int(reparam), self._p(tangent),
+                                        self._p(tangent_p), self._p(out))
+        return out
+
     def render_direct_forward(self, grid, cam, W, H, spp, offsets, emitter_u, albedo, env=(1.0, 1.0, 1.0), hide_emitters=False,
                               reparam=True, diff=False, seed=0):
         grid = np.ascontiguousarray(grid, np.float32)

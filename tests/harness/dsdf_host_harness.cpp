@@ -141,6 +141,39 @@ void hh_sampler(unsigned seed, long n, float *out) {
     for (long i = 0; i < n; ++i) sampler_next_2d(seed, (uint32_t)i, out[2 * i], out[2 * i + 1]);
 }
 
+// Forward mode: d image for a tangent grid (may be null) and a tangent of sdf.p.
+void hh_render_forward_grad(const float *data, int rx, int ry, int rz, const dsdf_params *prm, const dsdf_camera *cam,
+                            int W, int H, int spp, const float *offsets, unsigned seed, int integrator, int flags,
+                            const float *tangent, const float *tangent_p, float *grad_image) {
+    std::vector<float> p = pad(data, rx, ry, rz);
+    std::vector<float> tp;
+    if (tangent) tp = pad(tangent, rx, ry, rz);
+    GridView G = make_view(p.data(), rx, ry, rz, *prm);
+    ViewArgs A = view_args(cam, W, H, spp, offsets, seed, integrator, flags);
+    V3 dp = tangent_p ? mk(tangent_p[0], tangent_p[1], tangent_p[2]) : mk(0.f, 0.f, 0.f);
+    std::vector<float> block((size_t)2 * A.Wb * A.Hb, 0.f), dblock((size_t)2 * A.Wb * A.Hb, 0.f);
+    long n = (long)A.Wb * A.Hb * spp;
+    for (long lane = 0; lane < n; ++lane) {
+        Lane L = lane_setup(A, *prm, (uint32_t)lane);
+        TraceOut t;
+        trace_diff(G, *prm, L.ray.o, L.ray.d, L.ray.maxt, t);
+        float val = shade_value(G, A, L, t.its_t);
+        Reproj rp = reproject(A.cam, *prm, L.ray.o + L.ray.d, W, H);
+        splat_lane(block.data(), A.Wb, A.Hb, rp.u, rp.v, val, PlainAdd());
+        SampleTangent st;
+        if (lane_forward_tangent(G, tangent ? tp.data() : nullptr, dp, *prm, A, L, t, st))
+            splat_tangent(dblock.data(), A.Wb, A.Hb, st, PlainAdd());
+    }
+    for (int y = 0; y < H; ++y)
+        for (int x = 0; x < W; ++x) {
+            size_t q = (size_t)(y + DSDF_BORDER) * A.Wb + x + DSDF_BORDER;
+            float s = block[2 * q], w = block[2 * q + 1], ds = dblock[2 * q], dw = dblock[2 * q + 1];
+            float g = w == 0.f ? ds : ds / w - s * dw / (w * w);
+            float *o = grad_image + 3 * ((size_t)y * W + x);
+            o[0] = g; o[1] = g; o[2] = g;
+        }
+}
+
 // ---- sdf_direct_reparam (4-channel film block) -----------------------------------------------
 static ShadeArgs shade_args(const float *albedo, int ax, int ay, int az, const float *env, int hide, float *grad_albedo) {
     ShadeArgs S;

@@ -401,3 +401,38 @@ def test_translation_gradient_vs_finite_differences_gpu(dsdf, integ):
     # 10 %: the shading term's interior gradient has a visible estimator bias at 64^3 / 48^2 (measured 9 % on one
     # axis); the implementation itself is pinned to the oracle's autograd by test_translation_parity_gpu
     assert all(abs(x - y) < 0.10 * scale + 1.0 for x, y in zip(ad, fds)), (ad, fds)
+
+
+@pytest.mark.parametrize('integ', [O.SILHOUETTE, O.SIMPLE_SHADING])
+def test_forward_mode_gpu(dsdf, integ):
+    """`render_forward` (integrators/reparam.py:192-196): (i) against forward-over-reverse autograd of the oracle for a
+    translation tangent (the reference's eval_forward_gradient, figures/result_utils.py:126-161), (ii) transpose
+    identity <J dtheta, G> == <dtheta, J^T G> with the GPU backward for tangents on sdf.data and sdf.p, several views."""
+    case = make_case('sphere16')
+    cam = O.Camera(case['origin'])
+    tp = torch.tensor([0.0, 1.0, 0.0], dtype=torch.float64)
+
+    def f(p):
+        return O.render(O.Grid3d(case['grid'], p), cam, case['W'], case['H'], case['spp'], case['offsets'].double(), integ)
+    _, ref = torch.autograd.functional.jvp(f, torch.zeros(3, dtype=torch.float64), tp)
+    out, img = dsdf.render_forward_grad(dev_grid(dsdf, case), sensor(dsdf, case), case['spp'], tangent_p=tp,
+                                        offsets=case['offsets'].cuda(), integrator=integ, return_image=True)
+    assert rel_l2(out[0].cpu(), ref) < GRAD_TOL
+    assert rel_l2(img[0].cpu(), oracle_forward(case, integ)[0]) < FWD_TOL
+
+    case = make_case('blob48_rect')
+    grid = dev_grid(dsdf, case)
+    sens = dsdf.get_regular_cameras(12, resx=case['W'], resy=case['H'])[3:6]
+    G = torch.randn(3, case['H'], case['W'], 3, device='cuda')
+    tdata = torch.randn(grid.shape, device='cuda')
+    tpv = torch.tensor([0.3, -0.7, 0.5])
+    gp = torch.zeros(3, device='cuda')
+    gg = dsdf.render_backward(grid, sens, 64, G, seeds=[4, 5, 6], integrator=integ, grad_p=gp)
+    jd = dsdf.render_forward_grad(grid, sens, 64, tangent_data=tdata, seeds=[4, 5, 6], integrator=integ)
+    jp = dsdf.render_forward_grad(grid, sens, 64, tangent_p=tpv, seeds=[4, 5, 6], integrator=integ)
+    lhs_d, rhs_d = float((jd.double() * G).sum()), float((gg.double() * tdata).sum())
+    lhs_p, rhs_p = float((jp.double() * G).sum()), float((gp.cpu().double() * tpv.double()).sum())
+    assert abs(lhs_d - rhs_d) < 2e-3 * max(abs(rhs_d), 1.0), (lhs_d, rhs_d)
+    assert abs(lhs_p - rhs_p) < 2e-3 * max(abs(rhs_p), 1.0), (lhs_p, rhs_p)
+    with pytest.raises(dsdf.DsdfError):
+        dsdf.render_forward_grad(grid, sens, 64, seeds=[4, 5, 6], integrator=integ)           # no tangent

@@ -113,3 +113,40 @@ def test_translation_gradient_host(harness, integ):
     harness.render_backward(case['grid'].float().numpy(), cam_params(case), case['W'], case['H'], case['spp'],
                             case['offsets'].numpy(), case['grad_image'].numpy(), integ)
     assert rel_l2(harness.last_grad_p, p.grad.numpy()) < GRAD_TOL
+
+
+@pytest.mark.parametrize('integ', [O.SILHOUETTE, O.SIMPLE_SHADING])
+def test_forward_mode_is_transpose_of_backward(harness, integ):
+    """`render_forward` (integrators/reparam.py:192-196): <J dtheta, G> == <dtheta, J^T G> for a tangent on
+    sdf.data and on sdf.p, J^T G being the (oracle-checked) backward."""
+    case = make_case('blob32')
+    g32 = case['grid'].float().numpy()
+    args = (g32, cam_params(case), case['W'], case['H'], case['spp'], case['offsets'].numpy())
+    gen = torch.Generator().manual_seed(5)
+    tdata = torch.randn(g32.shape, generator=gen).numpy().astype(np.float32)
+    tp = np.array([0.3, -0.7, 0.5], np.float32)
+    G = case['grad_image'].numpy()
+    gg, _ = harness.render_backward(*args, G, integ)
+    gp = harness.last_grad_p.copy()
+    jd = harness.render_forward_grad(*args, integ, tangent=tdata)
+    jp = harness.render_forward_grad(*args, integ, tangent_p=tp)
+    lhs_d, rhs_d = float((jd.astype(np.float64) * G).sum()), float((gg.astype(np.float64) * tdata).sum())
+    lhs_p, rhs_p = float((jp.astype(np.float64) * G).sum()), float((gp.astype(np.float64) * tp).sum())
+    assert abs(lhs_d - rhs_d) < 2e-3 * max(abs(rhs_d), 1.0), (lhs_d, rhs_d)
+    assert abs(lhs_p - rhs_p) < 2e-3 * max(abs(rhs_p), 1.0), (lhs_p, rhs_p)
+    assert np.abs(jd).max() > 0 and np.abs(jp).max() > 0
+
+
+def test_forward_mode_matches_oracle_jvp(harness):
+    """Gradient image w.r.t. a translation of the SDF (the reference's eval_forward_gradient,
+    figures/result_utils.py:126-161) against forward-over-reverse autograd of the oracle."""
+    case = make_case('sphere16')
+    cam = O.Camera(case['origin'])
+    tp = torch.tensor([1.0, 0.0, 0.0], dtype=torch.float64)
+
+    def f(p):
+        return O.render(O.Grid3d(case['grid'], p), cam, case['W'], case['H'], case['spp'], case['offsets'].double(), O.SIMPLE_SHADING)
+    _, ref = torch.autograd.functional.jvp(f, torch.zeros(3, dtype=torch.float64), tp)
+    out = harness.render_forward_grad(case['grid'].float().numpy(), cam_params(case), case['W'], case['H'], case['spp'],
+                                      case['offsets'].numpy(), O.SIMPLE_SHADING, tangent_p=tp.numpy())
+    assert rel_l2(out, ref) < GRAD_TOL
