@@ -44,6 +44,33 @@ def render_backward(lib, grid, cam16, W, H, spp, offsets, grad_image, integrator
     return gg, img
 
 
+def render_direct(lib, grid, cam16, W, H, spp, offsets, emitter_u, albedo, env=(1.0, 1.0, 1.0), hide_emitters=False):
+    grid = np.ascontiguousarray(grid, np.float32); offsets = np.ascontiguousarray(offsets, np.float32)
+    cam16 = np.ascontiguousarray(cam16, np.float32); emitter_u = np.ascontiguousarray(emitter_u, np.float32)
+    albedo = np.ascontiguousarray(albedo, np.float32); env = np.asarray(env, np.float32)
+    img = np.zeros((H, W, 3), np.float32)
+    rz, ry, rx = grid.shape
+    az, ay, ax = albedo.shape[:3]
+    lib.o_render_direct(_p(grid), rx, ry, rz, _p(cam16), W, H, spp, _p(offsets), _p(emitter_u), _p(albedo), ax, ay, az,
+                        _p(env), int(hide_emitters), _p(img))
+    return img
+
+
+def render_direct_backward(lib, grid, cam16, W, H, spp, offsets, emitter_u, albedo, grad_image, env=(1.0, 1.0, 1.0),
+                           hide_emitters=False, reparam=True):
+    grid = np.ascontiguousarray(grid, np.float32); offsets = np.ascontiguousarray(offsets, np.float32)
+    cam16 = np.ascontiguousarray(cam16, np.float32); emitter_u = np.ascontiguousarray(emitter_u, np.float32)
+    albedo = np.ascontiguousarray(albedo, np.float32); env = np.asarray(env, np.float32)
+    gi = np.ascontiguousarray(grad_image, np.float32)
+    gg = np.zeros(grid.shape, np.float32); ga = np.zeros(albedo.shape, np.float32)
+    img = np.zeros((H, W, 3), np.float32)
+    rz, ry, rx = grid.shape
+    az, ay, ax = albedo.shape[:3]
+    lib.o_render_direct_backward(_p(grid), rx, ry, rz, _p(cam16), W, H, spp, _p(offsets), _p(emitter_u), _p(albedo), ax, ay, az,
+                                 _p(env), int(hide_emitters), int(reparam), _p(gi), _p(gg), _p(ga), _p(img))
+    return gg, ga, img
+
+
 def redistance(lib, phi):
     phi = np.ascontiguousarray(phi, np.float32)
     out = np.zeros_like(phi)

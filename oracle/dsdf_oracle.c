@@ -3,7 +3,7 @@
  *
  * Independent plain-C (C99 + OpenMP, fp32 like the reference's llvm_ad_rgb variant)
  * restatement of the reference's hot path: tricubic B-spline SDF lookups, (differentiable)
- * sphere tracing, WarpField2D, the silhouette / simple-shading integrators, Gaussian film
+ * sphere tracing, WarpField2D, the silhouette / simple-shading / direct integrators, Gaussian film
  * splat + develop, and the backward pass.  Citations are file:line relative to the
  * reference root.  Straightforward on purpose: per-tap index clamping, 64 scalar taps,
  * no padding, no tiling.  It serves as (1) a second checker next to sdf_oracle.py (whose
@@ -426,6 +426,268 @@ void o_render_backward(const float *grid, int rx, int ry, int rz, const float *c
         }
     }
     free(block); free(badj); free(tr);
+}
+
+/* ======================================================================================
+ * sdf_direct_reparam (integrators/sdf_direct_reparam.py:16-75, emitter sampling only).  BSDF and emitter are this
+ * repository's spec (see sdf_oracle.py): Mitsuba `diffuse` over a trilinear reflectance volume on the unit cube,
+ * `constant` environment emitter.  Film block: 4 channels (r, g, b, weight).
+ * ====================================================================================== */
+#define RAY_EPSILON 8.94069671630859375e-05f
+#define SHADOW_EPSILON (10.f*RAY_EPSILON)
+#define ENV_DIST 4.0f
+
+typedef struct { const float *d; int rx, ry, rz; } vol3_t;     /* (Z,Y,X,3) */
+
+/* value a[3] and spatial gradient ag[ch][3] of the trilinear lookup; `taps` (8 x {index, weight}) for the adjoint */
+static void trilinear(const vol3_t *A, const float *p, float *a, float ag[3][3], size_t *tix, float *tw) {
+    float res[3] = { (float)A->rx, (float)A->ry, (float)A->rz }, fr[3]; int i0[3];
+    for (int k = 0; k < 3; ++k) { float pf = p[k]*res[k] - 0.5f, f = floorf(pf); i0[k] = (int)f; fr[k] = pf - f; }
+    for (int c = 0; c < 3; ++c) { a[c] = 0.f; ag[c][0] = ag[c][1] = ag[c][2] = 0.f; }
+    int n = 0;
+    for (int dz = 0; dz < 2; ++dz) for (int dy = 0; dy < 2; ++dy) for (int dx = 0; dx < 2; ++dx, ++n) {
+        int ix = clampi(i0[0] + dx, 0, A->rx - 1), iy = clampi(i0[1] + dy, 0, A->ry - 1), iz = clampi(i0[2] + dz, 0, A->rz - 1);
+        float wx = dx ? fr[0] : 1.f - fr[0], wy = dy ? fr[1] : 1.f - fr[1], wz = dz ? fr[2] : 1.f - fr[2];
+        float gx = (dx ? 1.f : -1.f)*res[0], gy = (dy ? 1.f : -1.f)*res[1], gz = (dz ? 1.f : -1.f)*res[2];
+        size_t ti = 3*(((size_t)iz*A->ry + iy)*A->rx + ix);
+        tix[n] = ti; tw[n] = wx*wy*wz;
+        for (int c = 0; c < 3; ++c) {
+            float t = A->d[ti + c];
+            a[c] += tw[n]*t;
+            ag[c][0] += t*gx*wy*wz; ag[c][1] += t*wx*gy*wz; ag[c][2] += t*wx*wy*gz;
+        }
+    }
+}
+
+typedef struct { int front; float p[3], g[3], H[6], n[3], so[3], sd[3], smaxt; } dhit_t;
+
+/* hit point, normal, emitter direction (uniform sphere, mitsuba warp.h), shadow ray (spawn_ray_to / offset_p) */
+static void direct_setup(const grid_t *G, const ray_t *r, float its_t, const float *u, dhit_t *h) {
+    float v;
+    for (int a = 0; a < 3; ++a) h->p[a] = r->o[a] + its_t*r->d[a];
+    eval_cubic(G, h->p, 2, &v, h->g, h->H);
+    float gl = sqrtf(dot3(h->g, h->g));
+    for (int a = 0; a < 3; ++a) h->n[a] = h->g[a]/gl;
+    float z = 1.f - 2.f*u[1], rr = sqrtf(fmaxf(1.f - z*z, 0.f)), phi = 6.283185307179586f*u[0];
+    float wd[3] = { rr*cosf(phi), rr*sinf(phi), z }, tgt[3], tp[3];
+    for (int a = 0; a < 3; ++a) { tgt[a] = h->p[a] + ENV_DIST*wd[a]; tp[a] = tgt[a] - h->p[a]; }
+    float mag = (1.f + fmaxf(fabsf(h->p[0]), fmaxf(fabsf(h->p[1]), fabsf(h->p[2]))))*RAY_EPSILON;
+    if (dot3(h->n, tp) < 0.f) mag = -mag;
+    float dv[3];
+    for (int a = 0; a < 3; ++a) { h->so[a] = h->p[a] + mag*h->n[a]; dv[a] = tgt[a] - h->so[a]; }
+    float dist = sqrtf(dot3(dv, dv));
+    for (int a = 0; a < 3; ++a) h->sd[a] = dv[a]/dist;
+    h->smaxt = dist*(1.f - SHADOW_EPSILON);
+    float md[3] = { -r->d[0], -r->d[1], -r->d[2] };
+    h->front = dot3(h->n, h->sd) > 0.f && dot3(h->n, md) > 0.f;          /* diffuse::eval: both cosines positive */
+}
+
+static void splat4(float *block, int Wb, int Hb, const float *uv, const float *rgb) {
+    float pfx = uv[0] + BORDER - 0.5f, pfy = uv[1] + BORDER - 0.5f;
+    int x0 = (int)ceilf(pfx - FRADIUS), y0 = (int)ceilf(pfy - FRADIUS);
+    for (int j = 0; j < 4; ++j) for (int i = 0; i < 4; ++i) {
+        int qx = x0 + i, qy = y0 + j;
+        if (qx < 0 || qx >= Wb || qy < 0 || qy >= Hb) continue;
+        float f = gauss((float)qx - pfx)*gauss((float)qy - pfy);
+        float *dst = block + 4*((size_t)qy*Wb + qx);
+        for (int c = 0; c < 3; ++c) {
+#pragma omp atomic
+            dst[c] += f*rgb[c];
+        }
+#pragma omp atomic
+        dst[3] += f;
+    }
+}
+
+static void develop4(const float *block, int W, int H, float *img) {
+    int Wb = W + 2*BORDER;
+    for (int y = 0; y < H; ++y) for (int x = 0; x < W; ++x) {
+        const float *b = block + 4*((size_t)(y + BORDER)*Wb + x + BORDER);
+        float w = b[3] == 0.f ? 1.f : b[3];
+        for (int c = 0; c < 3; ++c) img[3*((size_t)y*W + x) + c] = b[c]/w;
+    }
+}
+
+/* one sample's radiance; ts = shadow-ray trace (its_t = inf <=> unoccluded); returns 1 when lit */
+static int direct_sample(const grid_t *G, const vol3_t *A, const ray_t *r, float its_t, const float *u, const float *env,
+                         int hide, int diff, dhit_t *h, trace_t *ts, float *rgb, float *alb, float ag[3][3], size_t *tix, float *tw) {
+    rgb[0] = rgb[1] = rgb[2] = 0.f;
+    if (!(its_t < INFINITY)) { if (!hide) { rgb[0] = env[0]; rgb[1] = env[1]; rgb[2] = env[2]; } return 0; }
+    direct_setup(G, r, its_t, u, h);
+    if (!h->front) return 0;
+    trace(G, h->so, h->sd, h->smaxt, diff, ts);
+    if (ts->its_t < INFINITY) return 0;
+    trilinear(A, h->p, alb, ag, tix, tw);
+    float k = 4.f*dot3(h->n, h->sd);
+    for (int c = 0; c < 3; ++c) rgb[c] = alb[c]*k*env[c];
+    return 1;
+}
+
+void o_render_direct(const float *grid, int rx, int ry, int rz, const float *cam, int W, int H, int spp, const float *offsets,
+                     const float *emitter_u, const float *albedo, int ax, int ay, int az, const float *env, int hide,
+                     float *image) {
+    grid_t G = { grid, rx, ry, rz };
+    vol3_t A = { albedo, ax, ay, az };
+    int Wb = W + 2*BORDER, Hb = H + 2*BORDER;
+    long n = (long)Wb*Hb*spp;
+    float *block = (float *)calloc((size_t)4*Wb*Hb, sizeof(float));
+#pragma omp parallel for schedule(dynamic, 256)
+    for (long lane = 0; lane < n; ++lane) {
+        ray_t r; trace_t t, ts; dhit_t h; float rgb[3], alb[3], ag[3][3], tw[8], uv[2], ref[3]; size_t tix[8];
+        lane_ray(cam, W, H, spp, offsets, lane, &r);
+        trace(&G, r.o, r.d, r.maxt, 0, &t);
+        direct_sample(&G, &A, &r, t.its_t, emitter_u + 2*lane, env, hide, 0, &h, &ts, rgb, alb, ag, tix, tw);
+        float p[3] = { r.o[0] + r.d[0], r.o[1] + r.d[1], r.o[2] + r.d[2] };
+        reproject(cam, p, W, H, uv, ref);
+        splat4(block, Wb, Hb, uv, rgb);
+    }
+    develop4(block, W, H, image);
+    free(block);
+}
+
+/* coefficients of WarpField2D.eval (warp.py:47-96) at x = o + warp_t d: d dir = cdir dv, div = a v + b . g */
+typedef struct { float x[3], cdir[3], a, b[3], g[3], H[6]; } wcoef_t;
+static int warp_coef(const grid_t *G, const float *o, const float *d, const trace_t *t, wcoef_t *c) {
+    if (!(fabsf(t->warp_t) < INFINITY) || !(t->ww > 0.f)) return 0;
+    float tt = t->warp_t, v;
+    for (int a = 0; a < 3; ++a) c->x[a] = o[a] + tt*d[a];
+    eval_cubic(G, c->x, 2, &v, c->g, c->H);
+    const float *g = c->g, *Hm = c->H;
+    float g2 = dot3(g, g), n_[3] = { g[0]/g2, g[1]/g2, g[2]/g2 };
+    float bdd[3], bd = bbox_dist_d(c->x, bdd), ee = EDGE_EPS*tt;
+    int use_eps = ee <= bd;
+    float eps = fminf(ee, bd), ie = 1.f/eps, sd = fabsf(v), fac = 1.f - sd*ie, w = fmaxf(fac, 0.f);
+    float wd[3] = {0}, eps_d = 0.f;
+    if (fac >= 0.f) {
+        for (int a = 0; a < 3; ++a) wd[a] = -sgn(v)*g[a]*ie + sd*ie*ie*(use_eps ? 0.f : bdd[a]);
+        if (use_eps) eps_d = sd*ie*ie;
+    }
+    for (int a = 0; a < 3; ++a) wd[a] = t->ww*(wd[a] + eps_d*EDGE_EPS*d[a]) + w*t->wwd[a];
+    w *= t->ww;
+    if (!(w > 0.f)) return 0;
+    float q[3] = { t->wtd[0]/tt, t->wtd[1]/tt, t->wtd[2]/tt };
+    float dn = dot3(d, n_), dq = dot3(d, q), Pn[3], Pq[3], An[3], Hd[3], Hg[3];
+    for (int a = 0; a < 3; ++a) { Pn[a] = n_[a] - dn*d[a]; Pq[a] = q[a] - dq*d[a]; }
+    float pqn = dot3(Pq, n_);
+    for (int a = 0; a < 3; ++a) An[a] = Pn[a] + pqn*d[a];
+    symmul(Hm, d, Hd); symmul(Hm, g, Hg);
+    float trH = Hm[0] + Hm[1] + Hm[2], dHd = dot3(d, Hd), gHg = dot3(g, Hg), gHd = dot3(g, Hd), dg = dot3(d, g);
+    float trJHA = (trH - dHd)/g2 - 2.f*(gHg - dg*gHd)/(g2*g2) + dot3(Pq, Hd)/g2 - 2.f*dot3(Pq, g)*gHd/(g2*g2);
+    c->a = -(dot3(wd, Pn) + dot3(wd, d)*pqn) - w*trJHA;
+    float T = fmaxf(CLAMP_THRESH, tt);
+    for (int a = 0; a < 3; ++a) { c->cdir[a] = (-w/T)*Pn[a]; c->b[a] = -w*An[a]; }
+    return 1;
+}
+
+void o_render_direct_backward(const float *grid, int rx, int ry, int rz, const float *cam, int W, int H, int spp,
+                              const float *offsets, const float *emitter_u, const float *albedo, int ax, int ay, int az,
+                              const float *env, int hide, int reparam, const float *grad_image, float *grad_grid,
+                              float *grad_albedo, float *image) {
+    grid_t G = { grid, rx, ry, rz };
+    vol3_t A = { albedo, ax, ay, az };
+    int Wb = W + 2*BORDER, Hb = H + 2*BORDER;
+    long n = (long)Wb*Hb*spp;
+    float *block = (float *)calloc((size_t)4*Wb*Hb, sizeof(float));
+    float *badj = (float *)calloc((size_t)4*Wb*Hb, sizeof(float));
+    trace_t *tr = (trace_t *)malloc((size_t)n*sizeof(trace_t)), *trs = (trace_t *)malloc((size_t)n*sizeof(trace_t));
+    unsigned char *lit = (unsigned char *)calloc((size_t)n, 1);
+#pragma omp parallel for schedule(dynamic, 256)
+    for (long lane = 0; lane < n; ++lane) {
+        ray_t r; dhit_t h; float rgb[3], alb[3], ag[3][3], tw[8], uv[2], ref[3]; size_t tix[8];
+        lane_ray(cam, W, H, spp, offsets, lane, &r);
+        trace(&G, r.o, r.d, r.maxt, 1, &tr[lane]);
+        lit[lane] = (unsigned char)direct_sample(&G, &A, &r, tr[lane].its_t, emitter_u + 2*lane, env, hide, 1, &h, &trs[lane],
+                                                 rgb, alb, ag, tix, tw);
+        float p[3] = { r.o[0] + r.d[0], r.o[1] + r.d[1], r.o[2] + r.d[2] };
+        reproject(cam, p, W, H, uv, ref);
+        splat4(block, Wb, Hb, uv, rgb);
+    }
+    if (image) develop4(block, W, H, image);
+    for (int y = 0; y < H; ++y) for (int x = 0; x < W; ++x) {              /* adjoint of develop */
+        size_t q = (size_t)(y + BORDER)*Wb + x + BORDER;
+        const float *gi = grad_image + 3*((size_t)y*W + x);
+        float w = block[4*q + 3], acc = 0.f;
+        for (int c = 0; c < 3; ++c) { badj[4*q + c] = w == 0.f ? gi[c] : gi[c]/w; acc += gi[c]*block[4*q + c]; }
+        badj[4*q + 3] = w == 0.f ? 0.f : -acc/(w*w);
+    }
+#pragma omp parallel for schedule(dynamic, 256)
+    for (long lane = 0; lane < n; ++lane) {
+        const trace_t *t = &tr[lane], *ts = &trs[lane];
+        wcoef_t wc;
+        ray_t r;
+        lane_ray(cam, W, H, spp, offsets, lane, &r);
+        const float *o = r.o, *d = r.d;
+        int warp_on = reparam && warp_coef(&G, o, d, t, &wc);
+        if (!warp_on && !lit[lane]) continue;
+        int hit = t->its_t < INFINITY;
+        float rgb[3] = {0, 0, 0}, alb[3] = {0, 0, 0}, ag[3][3], tw[8], uv[2], ref[3], cos_o = 0.f; size_t tix[8];
+        dhit_t h;
+        if (!hit) { if (!hide) { rgb[0] = env[0]; rgb[1] = env[1]; rgb[2] = env[2]; } }
+        else if (lit[lane]) {
+            direct_setup(&G, &r, t->its_t, emitter_u + 2*lane, &h);
+            trilinear(&A, h.p, alb, ag, tix, tw);
+            cos_o = dot3(h.n, h.sd);
+            for (int c = 0; c < 3; ++c) rgb[c] = alb[c]*4.f*cos_o*env[c];
+        }
+        float p1[3] = { o[0] + d[0], o[1] + d[1], o[2] + d[2] };
+        int inside = reproject(cam, p1, W, H, uv, ref);
+        float pfx = uv[0] + BORDER - 0.5f, pfy = uv[1] + BORDER - 0.5f;
+        int x0 = (int)ceilf(pfx - FRADIUS), y0 = (int)ceilf(pfy - FRADIUS);
+        float ac[3] = {0, 0, 0}, a_w = 0, ub = 0, vb = 0;
+        for (int j = 0; j < 4; ++j) for (int i = 0; i < 4; ++i) {
+            int qx = x0 + i, qy = y0 + j;
+            if (qx < 0 || qx >= Wb || qy < 0 || qy >= Hb) continue;
+            float rx_ = (float)qx - pfx, ry_ = (float)qy - pfy, fx = gauss(rx_), fy = gauss(ry_);
+            const float *ba = badj + 4*((size_t)qy*Wb + qx);
+            float s = ba[3];
+            for (int c = 0; c < 3; ++c) { ac[c] += fx*fy*ba[c]; s += ba[c]*rgb[c]; }
+            a_w += fx*fy*ba[3];
+            ub += s*(-dgauss(rx_)*fy); vb += s*(-fx*dgauss(ry_));
+        }
+        float rgb_dot = rgb[0]*ac[0] + rgb[1]*ac[1] + rgb[2]*ac[2];
+        float div_bar = rgb_dot + a_w, rw_bar = inside ? div_bar : 0.f;
+        float cot = 1.f/cam[12], iz = 1.f/ref[2], ku = -0.5f*(float)W*cot, dist2 = dot3(ref, ref);
+        float rb[3] = { ub*ku*iz + rw_bar*ref[0]/dist2, vb*ku*iz + rw_bar*ref[1]/dist2,
+                        -(ub*ku*ref[0] + vb*ku*ref[1])*iz*iz + rw_bar*(ref[2]/dist2 - 3.f*iz) };
+        float dir_bar[3];
+        for (int a = 0; a < 3; ++a) dir_bar[a] = cam[3+a]*rb[0] + cam[6+a]*rb[1] + cam[9+a]*rb[2];
+        if (lit[lane]) {
+            /* albedo: a_c-bar = A_c 4 cos_o L_c ; cos-bar = sum_c A_c a_c 4 L_c */
+            float pbar[3] = {0, 0, 0}, cos_bar = 0.f;
+            for (int c = 0; c < 3; ++c) {
+                float k = 4.f*env[c]*ac[c], abar = k*cos_o;
+                for (int m = 0; m < 8; ++m) {
+#pragma omp atomic
+                    grad_albedo[tix[m] + c] += tw[m]*abar;
+                }
+                for (int a = 0; a < 3; ++a) pbar[a] += abar*ag[c][a];
+                cos_bar += k*alb[c];
+            }
+            float gl = sqrtf(dot3(h.g, h.g)), nbar[3], sdbar[3], Gb[3], nn = 0.f, HG[3];
+            for (int a = 0; a < 3; ++a) { nbar[a] = cos_bar*h.sd[a]; sdbar[a] = cos_bar*h.n[a]; nn += h.n[a]*nbar[a]; }
+            for (int a = 0; a < 3; ++a) Gb[a] = (nbar[a] - nn*h.n[a])/gl;
+            /* shadow-ray warp (warp.py:110-115 with the attached origin si.p): det_e multiplies the rgb channels only */
+            wcoef_t ws;
+            if (reparam && warp_coef(&G, h.so, h.sd, ts, &ws)) {
+                float vs = dot3(ws.cdir, sdbar) + ws.a*rgb_dot, gs[3], Hgs[3];
+                for (int a = 0; a < 3; ++a) gs[a] = rgb_dot*ws.b[a];
+                scatter_cubic(&G, grad_grid, ws.x, vs, gs);
+                symmul(ws.H, gs, Hgs);
+                for (int a = 0; a < 3; ++a) pbar[a] += vs*ws.g[a] + Hgs[a];
+            }
+            symmul(h.H, Gb, HG);
+            for (int a = 0; a < 3; ++a) pbar[a] += HG[a];
+            float c = -dot3(h.g, d), v0 = dot3(pbar, d)/c;
+            for (int a = 0; a < 3; ++a) dir_bar[a] += t->its_t*pbar[a] + v0*t->its_t*h.g[a];
+            scatter_cubic(&G, grad_grid, h.p, v0, Gb);
+        }
+        if (warp_on) {
+            float vbar = dot3(wc.cdir, dir_bar) + wc.a*div_bar, gbar[3];
+            for (int a = 0; a < 3; ++a) gbar[a] = div_bar*wc.b[a];
+            scatter_cubic(&G, grad_grid, wc.x, vbar, gbar);
+        }
+    }
+    free(block); free(badj); free(tr); free(trs); free(lit);
 }
 
 /* per-point / per-ray entry points for the cross-checks */
