@@ -1,0 +1,144 @@
+// dsdf_film.h -- film side of the render kernels (included by dsdf_kernels.hip): the wave-level Gaussian splat and
+// the develop kernels (HDRFilm.develop), their adjoints and tangents.
+#pragma once
+
+// Film splat of one wave whose 64 samples belong to ONE pixel (px,py): their contributions fall into
+// the 5x5 block-pixel window around it; the 25 (+25 weight) partial sums are reduced across the wave
+// through a wave-private LDS transpose (lane l writes column l, lane k sums row k with 16 conflict-free
+// ds_read_b128; two chunks of <= 13 rows) and leave as one atomic per window pixel and channel.
+template <int NCH>     // block channels: NCH - 1 value channels + weight
+__device__ __forceinline__ void film_splat_wave(float *__restrict__ block, const ViewArgs &A, int px, int py,
+                                                float u, float v, const float *vals, float *T, int lid) {
+    float pfx = u + (DSDF_BORDER - 0.5f), pfy = v + (DSDF_BORDER - 0.5f);
+    float fx[5], fy[5];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        fx[i] = gauss_f((float)(px - 2 + i) - pfx);
+        fy[i] = gauss_f((float)(py - 2 + i) - pfy);
+    }
+    float f[25];
+#pragma unroll
+    for (int j = 0; j < 5; ++j)
+#pragma unroll
+        for (int i = 0; i < 5; ++i) f[j * 5 + i] = fx[i] * fy[j];
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+        const float val = ch < NCH - 1 ? vals[ch] : 1.f;
+        if (ch < NCH - 1 && __ballot(val != 0.f) == 0) continue;     // pixels nobody hits skip the value channel
+#pragma unroll
+        for (int k0 = 0; k0 < 25; k0 += DSDF_TROWS) {
+            const int nk = (25 - k0) < DSDF_TROWS ? (25 - k0) : DSDF_TROWS;
+#pragma unroll
+            for (int k = 0; k < DSDF_TROWS; ++k)
+                if (k < nk) T[k * DSDF_TSTRIDE + lid] = f[k0 + k] * val;
+            wave_lds_sync();
+            float total = 0.f;
+            const int slot = k0 + lid;                   // window slot summed by this lane
+            const int j5 = slot / 5, i5 = slot - 5 * j5;
+            const int qx = px - 2 + i5, qy = py - 2 + j5;
+            const bool own = lid < nk && qx >= 0 && qx < A.Wb && qy >= 0 && qy < A.Hb;
+            if (lid < nk) {
+                const float4 *row = reinterpret_cast<const float4 *>(T + lid * DSDF_TSTRIDE);
+                float4 a0 = row[0], a1 = row[1], a2 = row[2], a3 = row[3];
+#pragma unroll
+                for (int r = 4; r < 16; r += 4) {
+                    float4 b0 = row[r], b1 = row[r + 1], b2 = row[r + 2], b3 = row[r + 3];
+                    a0.x += b0.x; a0.y += b0.y; a0.z += b0.z; a0.w += b0.w;
+                    a1.x += b1.x; a1.y += b1.y; a1.z += b1.z; a1.w += b1.w;
+                    a2.x += b2.x; a2.y += b2.y; a2.z += b2.z; a2.w += b2.w;
+                    a3.x += b3.x; a3.y += b3.y; a3.z += b3.z; a3.w += b3.w;
+                }
+                total = ((a0.x + a0.y) + (a0.z + a0.w)) + ((a1.x + a1.y) + (a1.z + a1.w)) +
+                        (((a2.x + a2.y) + (a2.z + a2.w)) + ((a3.x + a3.y) + (a3.z + a3.w)));
+            }
+            wave_lds_sync();
+            if (own && total != 0.f) atomicAdd(block + NCH * ((size_t)qy * A.Wb + qx) + ch, total);
+        }
+    }
+}
+
+// HDRFilm.develop: crop the border, value / (weight == 0 ? 1 : weight), R=G=B.
+__global__ void k_develop(const float *__restrict__ blocks, int W, int H, float *__restrict__ images) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= W * H) return;
+    int y = i / W, x = i - y * W;
+    int Wb = W + 2 * DSDF_BORDER, Hb = H + 2 * DSDF_BORDER;
+    const float *block = blocks + (size_t)blockIdx.y * 2 * Wb * Hb;
+    float *image = images + (size_t)blockIdx.y * 3 * W * H;
+    float2 b = reinterpret_cast<const float2 *>(block)[(size_t)(y + DSDF_BORDER) * Wb + x + DSDF_BORDER];
+    float w = b.y == 0.f ? 1.f : b.y;
+    float v = b.x / w;
+    image[3 * (size_t)i] = v; image[3 * (size_t)i + 1] = v; image[3 * (size_t)i + 2] = v;
+}
+
+// Adjoint of develop: dL/d(value sum) = sum_c gI_c / w ; dL/d(weight sum) = -sum_c gI_c * s / w^2.
+__global__ void k_develop_adjoint(const float *__restrict__ blocks, const float *__restrict__ grad_images, int W, int H,
+                                  float *__restrict__ block_adjs) {
+    int Wb = W + 2 * DSDF_BORDER, Hb = H + 2 * DSDF_BORDER;
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= Wb * Hb) return;
+    const float *block = blocks + (size_t)blockIdx.y * 2 * Wb * Hb;
+    const float *grad_image = grad_images + (size_t)blockIdx.y * 3 * W * H;
+    float *block_adj = block_adjs + (size_t)blockIdx.y * 2 * Wb * Hb;
+    int qy = i / Wb, qx = i - qy * Wb;
+    int x = qx - DSDF_BORDER, y = qy - DSDF_BORDER;
+    float2 out = make_float2(0.f, 0.f);
+    if (x >= 0 && x < W && y >= 0 && y < H) {
+        const float *gi = grad_image + 3 * ((size_t)y * W + x);
+        float gs = gi[0] + gi[1] + gi[2];
+        float2 b = reinterpret_cast<const float2 *>(block)[i];
+        if (b.y == 0.f) out = make_float2(gs, 0.f);
+        else out = make_float2(gs / b.y, -gs * b.x / (b.y * b.y));
+    }
+    reinterpret_cast<float2 *>(block_adj)[i] = out;
+}
+
+// The same two kernels for the 4-channel (r,g,b,weight) block of sdf_direct_reparam.
+__global__ void k_develop_rgb(const float *__restrict__ blocks, int W, int H, float *__restrict__ images) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= W * H) return;
+    int y = i / W, x = i - y * W;
+    int Wb = W + 2 * DSDF_BORDER, Hb = H + 2 * DSDF_BORDER;
+    const float *block = blocks + (size_t)blockIdx.y * 4 * Wb * Hb;
+    float *image = images + (size_t)blockIdx.y * 3 * W * H;
+    float4 b = reinterpret_cast<const float4 *>(block)[(size_t)(y + DSDF_BORDER) * Wb + x + DSDF_BORDER];
+    float iw = 1.f / (b.w == 0.f ? 1.f : b.w);
+    image[3 * (size_t)i] = b.x * iw; image[3 * (size_t)i + 1] = b.y * iw; image[3 * (size_t)i + 2] = b.z * iw;
+}
+
+__global__ void k_develop_adjoint_rgb(const float *__restrict__ blocks, const float *__restrict__ grad_images, int W, int H,
+                                      float *__restrict__ block_adjs) {
+    int Wb = W + 2 * DSDF_BORDER, Hb = H + 2 * DSDF_BORDER;
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= Wb * Hb) return;
+    const float *block = blocks + (size_t)blockIdx.y * 4 * Wb * Hb;
+    const float *grad_image = grad_images + (size_t)blockIdx.y * 3 * W * H;
+    float *block_adj = block_adjs + (size_t)blockIdx.y * 4 * Wb * Hb;
+    int qy = i / Wb, qx = i - qy * Wb;
+    int x = qx - DSDF_BORDER, y = qy - DSDF_BORDER;
+    float4 out = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (x >= 0 && x < W && y >= 0 && y < H) {
+        const float *gi = grad_image + 3 * ((size_t)y * W + x);
+        float4 b = reinterpret_cast<const float4 *>(block)[i];
+        if (b.w == 0.f) out = make_float4(gi[0], gi[1], gi[2], 0.f);
+        else {
+            float iw = 1.f / b.w;
+            out = make_float4(gi[0] * iw, gi[1] * iw, gi[2] * iw, -(gi[0] * b.x + gi[1] * b.y + gi[2] * b.z) * iw * iw);
+        }
+    }
+    reinterpret_cast<float4 *>(block_adj)[i] = out;
+}
+
+// d(value / weight) = d value / weight - value d weight / weight^2, R=G=B.
+__global__ void k_develop_tangent(const float *__restrict__ blocks, const float *__restrict__ dblocks, int W, int H,
+                                  float *__restrict__ grad_images) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= W * H) return;
+    int y = i / W, x = i - y * W;
+    int Wb = W + 2 * DSDF_BORDER, Hb = H + 2 * DSDF_BORDER;
+    size_t qi = (size_t)blockIdx.y * Wb * Hb + (size_t)(y + DSDF_BORDER) * Wb + x + DSDF_BORDER;
+    float2 b = reinterpret_cast<const float2 *>(blocks)[qi], db = reinterpret_cast<const float2 *>(dblocks)[qi];
+    float g = b.y == 0.f ? db.x : db.x / b.y - b.x * db.y / (b.y * b.y);
+    float *o = grad_images + (size_t)blockIdx.y * 3 * W * H + 3 * (size_t)i;
+    o[0] = g; o[1] = g; o[2] = g;
+}

@@ -1,4 +1,10 @@
-// dsdf_kernels.hip -- gfx950 (MI355X / CDNA4) kernels + C-ABI of the hot path.
+// dsdf_kernels.hip -- gfx950 (MI355X / CDNA4) kernels + C-ABI of the hot path.  One translation unit:
+//   dsdf_math.h, dsdf_lane.h   host/device arithmetic of one sample (also compiled by the host-side tests)
+//   dsdf_wave.h                wave-level device helpers: reductions, LDS brick scatter, wave cell cache
+//   dsdf_film.h                wave-level film splat, develop kernels (+ adjoint / tangent)
+//   dsdf_skip.h                exact empty-space proof (coarse min-grids, per-pixel flags)
+//   dsdf_redistance.h          Eikonal redistancing kernels + entry points
+//   this file                  render pass, backward / forward-tangent sweeps, workspace, C-ABI
 //
 // Kernel inventory (DESIGN.md has the roofline for each):
 //   k_pad_grid          clamp-to-edge padded copy of sdf.data (Texture3f.set_tensor)
@@ -86,184 +92,7 @@ __global__ void k_trace(GridView G, dsdf_params P, const float *__restrict__ ro,
     if (ww_d) { ww_d[3 * i] = t.warp_weight_d.x; ww_d[3 * i + 1] = t.warp_weight_d.y; ww_d[3 * i + 2] = t.warp_weight_d.z; }
 }
 
-// ------------------------------------------------------------------ wave helpers
-__device__ __forceinline__ int lane_id() {
-    return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-}
-
-// exclusive prefix count of set bits below this lane (v_mbcnt_lo/hi)
-__device__ __forceinline__ uint32_t mask_prefix(uint64_t m) {
-    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-}
-
-__device__ __forceinline__ int wave_sum_i32(int v) {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
-    return v;
-}
-
-__device__ __forceinline__ float wave_sum_f32(float v) {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
-    return v;
-}
-
-__device__ __forceinline__ int wave_min_i32(int v) {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v = min(v, __shfl_xor(v, m));
-    return v;
-}
-__device__ __forceinline__ int wave_max_i32(int v) {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v = max(v, __shfl_xor(v, m));
-    return v;
-}
-// LDS operations of one wave execute in program order; these fences only stop the
-// compiler from moving LDS accesses across the phases of the wave-private brick.
-__device__ __forceinline__ void wave_lds_sync() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
-// LDS-aggregated 64-tap scatter for one wave.  The samples of a wave come from a few
-// neighbouring pixels, so their 4^3 footprints overlap heavily: accumulate them in a
-// wave-private LDS brick spanning the bounding box of all taps (ds_add_f32), then
-// flush only the non-zero voxels with one global atomic each.  Falls back to direct
-// global atomics when the bounding box does not fit the brick.
-#define DSDF_BRICK_CAP 2048   /* floats per wave-private brick (8 KB): ~20 single-wave blocks per CU */
-__device__ __forceinline__ void wave_scatter(const GridView &G, float *__restrict__ grad, const ScatterReq &rq,
-                                             float *brick, int lid) {
-    const bool on = rq.on;
-    if (!__ballot(on)) return;
-    CubicSetup s = cubic_setup(G, on ? rq.x : mk(0.f, 0.f, 0.f));
-    const int big = 1 << 30;
-    int minx = wave_min_i32(on ? iclamp(s.ix, 0, G.rx - 1) : big), maxx = wave_max_i32(on ? iclamp(s.ix + 3, 0, G.rx - 1) : -big);
-    int miny = wave_min_i32(on ? iclamp(s.iy, 0, G.ry - 1) : big), maxy = wave_max_i32(on ? iclamp(s.iy + 3, 0, G.ry - 1) : -big);
-    int minz = wave_min_i32(on ? iclamp(s.iz, 0, G.rz - 1) : big), maxz = wave_max_i32(on ? iclamp(s.iz + 3, 0, G.rz - 1) : -big);
-    int ex = maxx - minx + 1, ey = maxy - miny + 1, ez = maxz - minz + 1;
-    bool fits = ex <= 64 && ey <= 64 && ez <= 64 && ex * ey * ez <= DSDF_BRICK_CAP;
-    if (!fits) {
-        if (on) scatter_cubic(G, grad, rq.x, rq.cv, rq.cg, AtomicAdd());
-        return;
-    }
-    const int vol = ex * ey * ez;
-    // Privatisation: the samples of a wave mostly share one cell, i.e. their ds_add_f32 hit the
-    // same addresses and serialise.  K copies of the brick (copy = lane mod K) cut the conflict
-    // degree K-fold; the flush sums the copies.
-    int K = 1;
-    while (K < 8 && 2 * K * vol <= DSDF_BRICK_CAP) K *= 2;
-    const int tot = K * vol;
-    for (int e = lid; e < tot; e += 64) brick[e] = 0.f;
-    wave_lds_sync();
-    if (on) {
-        float *mine = brick + (lid & (K - 1)) * vol;
-        float wx[4], wy[4], wz[4], dwx[4], dwy[4], dwz[4];
-        bspline_w(s.ax, wx); bspline_w(s.ay, wy); bspline_w(s.az, wz);
-        bspline_dw(s.ax, dwx); bspline_dw(s.ay, dwy); bspline_dw(s.az, dwz);
-        float gx = rq.cg.x * (float)G.rx, gy = rq.cg.y * (float)G.ry, gz = rq.cg.z * (float)G.rz;
-        int xo[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) xo[i] = iclamp(s.ix + i, 0, G.rx - 1) - minx;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            int zo = iclamp(s.iz + k, 0, G.rz - 1) - minz;
-            float azv = wz[k], azd = dwz[k] * gz;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                int yo = iclamp(s.iy + j, 0, G.ry - 1) - miny;
-                float *row = mine + (zo * ey + yo) * ex;
-                float c0 = azv * wy[j] * rq.cv + azd * wy[j] + azv * dwy[j] * gy;
-                float c1 = azv * wy[j] * gx;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) atomicAdd(row + xo[i], fmaf(c0, wx[i], c1 * dwx[i]));
-            }
-        }
-    }
-    wave_lds_sync();
-    for (int e = lid; e < vol; e += 64) {
-        float v = brick[e];
-        for (int c = 1; c < K; ++c) v += brick[c * vol + e];
-        if (v != 0.f) {
-            int x = e % ex, t = e / ex;
-            int y = t % ey, z = t / ey;
-            atomicAdd(grad + ((size_t)(minz + z) * G.ry + (miny + y)) * G.rx + (minx + x), v);
-        }
-    }
-    wave_lds_sync();
-}
-
-// ------------------------------------------------------------------ wave cell cache
-// The 64 lanes of a wave are samples of ONE pixel, so at every trace step they sit in a
-// handful of B-spline cells (measured: 5 distinct cells on average, <= 8 in 87 % and <= 16
-// in 95 % of the wave-steps at 256^3 / 512^2).  Reading 64 x 16 rows through the vector
-// memory path (64 B/clk/CU) bounds the naive loop; instead the wave
-//   1. groups its lanes by cell with a readlane/ballot loop (<= 16 groups = "slots"),
-//   2. loads each distinct cell ONCE: 16 lanes fetch the 16 rows of a slot, 4 slots per
-//      global_load_dwordx4 + ds_write_b128 round,
-//   3. lets every lane read its cell's rows with 16 conflict-free ds_read_b128
-//      (slot stride 68 floats: 16-byte aligned, consecutive slots 4 banks apart).
-// Lanes whose cell did not get a slot (> 16 distinct cells) read from global memory as
-// before.  Same arithmetic as the per-lane path, so results are bit-identical.
-#define DSDF_CACHE_SLOTS 16
-#define DSDF_SLOT_STRIDE 68
-
-struct LdsRows {
-    const float *slot;
-    __device__ __forceinline__ void get(int k, int j, v2f &lo, v2f &hi) const {
-        float4 t = *reinterpret_cast<const float4 *>(slot + (k * 4 + j) * 4);
-        lo = mk2(t.x, t.y); hi = mk2(t.z, t.w);
-    }
-};
-
-struct WaveCellCache {
-    float *taps;      // wave-private LDS: DSDF_CACHE_SLOTS * DSDF_SLOT_STRIDE floats, then DSDF_CACHE_SLOTS slot bases
-    int lid;
-    __device__ __forceinline__ bool any(bool b) const { return __ballot(b) != 0; }
-
-    template <int ORDER>
-    __device__ __forceinline__ void eval(const GridView &G, V3 x, bool active, float &v, V3 &g, float H[6]) {
-        const CubicCell c = cubic_cell(G, active ? x : mk(0.f, 0.f, 0.f));
-        uint32_t *slot_base = reinterpret_cast<uint32_t *>(taps + DSDF_CACHE_SLOTS * DSDF_SLOT_STRIDE);
-        // 1. group the lanes by cell: leader = first unassigned active lane; every lane holding the
-        //    same cell key takes the slot (v_readlane + v_cmp + v_cndmask + scalar mask update per cell)
-        int slot = -1, n = 0;
-        uint64_t todo = __ballot(active);
-        while (todo != 0 && n < DSDF_CACHE_SLOTS) {
-            const int leader = __builtin_ctzll(todo);
-            const uint32_t k = (uint32_t)__builtin_amdgcn_readlane((int)c.base, leader);
-            const bool same = c.base == k;
-            slot = same ? n : slot;
-            todo &= ~__ballot(same);
-            ++n;
-        }
-        if (slot >= 0) slot_base[slot] = c.base;        // all lanes of a slot write the same value
-        wave_lds_sync();
-        // 2. load every distinct cell once: lane (grp, r) fetches row r of slot 4*round + grp
-        const int grp = lid >> 4, r = lid & 15;
-        const uint32_t rowoff = (uint32_t)(r >> 2) * (4u * (uint32_t)G.sxy) + (uint32_t)(r & 3) * (4u * (uint32_t)G.sx);
-        for (int s0 = 0; s0 < n; s0 += 4) {
-            const int sl = s0 + grp;
-            if (sl < n) {
-                typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
-                const uint32_t b = slot_base[sl];
-                f4u t = *reinterpret_cast<const f4u *>(reinterpret_cast<const char *>(G.p) + (b + rowoff));
-                *reinterpret_cast<float4 *>(taps + sl * DSDF_SLOT_STRIDE + r * 4) = make_float4(t.x, t.y, t.z, t.w);
-            }
-        }
-        wave_lds_sync();
-        // 3. every lane evaluates from its slot (lanes beyond 16 distinct cells read global memory)
-        if (active) {
-            if (slot >= 0) {
-                LdsRows R; R.slot = taps + slot * DSDF_SLOT_STRIDE;
-                eval_cubic_rows<ORDER>(G, c, R, v, g, H);
-            } else {
-                eval_cubic_rows<ORDER>(G, c, global_rows(G, c), v, g, H);
-            }
-        }
-        wave_lds_sync();
-    }
-};
+#include "dsdf_wave.h"
 
 // Queue of samples that need the backward sweep.  Every render-pass block owns the slot
 // range [block*DSDF_BLOCK, (block+1)*DSDF_BLOCK) and compacts its samples to the front of
@@ -306,143 +135,8 @@ __device__ __forceinline__ void load_record(const float *r, size_t c, TraceOut &
     tr.steps = 0; tr.refine_steps = 0; tr.weight_sum = 0.f;
 }
 
-// Film splat of one wave whose 64 samples belong to ONE pixel (px,py): their contributions fall into
-// the 5x5 block-pixel window around it; the 25 (+25 weight) partial sums are reduced across the wave
-// through a wave-private LDS transpose (lane l writes column l, lane k sums row k with 16 conflict-free
-// ds_read_b128; two chunks of <= 13 rows) and leave as one atomic per window pixel and channel.
-template <int NCH>     // block channels: NCH - 1 value channels + weight
-__device__ __forceinline__ void film_splat_wave(float *__restrict__ block, const ViewArgs &A, int px, int py,
-                                                float u, float v, const float *vals, float *T, int lid) {
-    float pfx = u + (DSDF_BORDER - 0.5f), pfy = v + (DSDF_BORDER - 0.5f);
-    float fx[5], fy[5];
-#pragma unroll
-    for (int i = 0; i < 5; ++i) {
-        fx[i] = gauss_f((float)(px - 2 + i) - pfx);
-        fy[i] = gauss_f((float)(py - 2 + i) - pfy);
-    }
-    float f[25];
-#pragma unroll
-    for (int j = 0; j < 5; ++j)
-#pragma unroll
-        for (int i = 0; i < 5; ++i) f[j * 5 + i] = fx[i] * fy[j];
-#pragma unroll
-    for (int ch = 0; ch < NCH; ++ch) {
-        const float val = ch < NCH - 1 ? vals[ch] : 1.f;
-        if (ch < NCH - 1 && __ballot(val != 0.f) == 0) continue;     // pixels nobody hits skip the value channel
-#pragma unroll
-        for (int k0 = 0; k0 < 25; k0 += DSDF_TROWS) {
-            const int nk = (25 - k0) < DSDF_TROWS ? (25 - k0) : DSDF_TROWS;
-#pragma unroll
-            for (int k = 0; k < DSDF_TROWS; ++k)
-                if (k < nk) T[k * DSDF_TSTRIDE + lid] = f[k0 + k] * val;
-            wave_lds_sync();
-            float total = 0.f;
-            const int slot = k0 + lid;                   // window slot summed by this lane
-            const int j5 = slot / 5, i5 = slot - 5 * j5;
-            const int qx = px - 2 + i5, qy = py - 2 + j5;
-            const bool own = lid < nk && qx >= 0 && qx < A.Wb && qy >= 0 && qy < A.Hb;
-            if (lid < nk) {
-                const float4 *row = reinterpret_cast<const float4 *>(T + lid * DSDF_TSTRIDE);
-                float4 a0 = row[0], a1 = row[1], a2 = row[2], a3 = row[3];
-#pragma unroll
-                for (int r = 4; r < 16; r += 4) {
-                    float4 b0 = row[r], b1 = row[r + 1], b2 = row[r + 2], b3 = row[r + 3];
-                    a0.x += b0.x; a0.y += b0.y; a0.z += b0.z; a0.w += b0.w;
-                    a1.x += b1.x; a1.y += b1.y; a1.z += b1.z; a1.w += b1.w;
-                    a2.x += b2.x; a2.y += b2.y; a2.z += b2.z; a2.w += b2.w;
-                    a3.x += b3.x; a3.y += b3.y; a3.z += b3.z; a3.w += b3.w;
-                }
-                total = ((a0.x + a0.y) + (a0.z + a0.w)) + ((a1.x + a1.y) + (a1.z + a1.w)) +
-                        (((a2.x + a2.y) + (a2.z + a2.w)) + ((a3.x + a3.y) + (a3.z + a3.w)));
-            }
-            wave_lds_sync();
-            if (own && total != 0.f) atomicAdd(block + NCH * ((size_t)qy * A.Wb + qx) + ch, total);
-        }
-    }
-}
-
-// ------------------------------------------------------------------ empty-space proof
-// Cubic B-spline weights are >= 0 and sum to 1, so every lookup is bounded below by the minimum of its
-// 64 taps.  `coarse[b]` = min of the grid over coarse block b (8^3 or 4^3 voxels: the finest level whose margin
-// covers the pixel footprint is used) dilated by one block in every
-// direction; if it exceeds a threshold for every block the CENTRE ray of a film pixel passes through, no
-// point visited by ANY sample ray of that pixel (they deviate by less than the dilation margin, checked on
-// the host) can have an SDF value below the threshold.  Such pixels skip tracing with EXACTLY the result
-// tracing would give: primal -- every sample misses (threshold = trace_eps); gradient pass -- misses AND a
-// zero boundary weight, because w > 0 needs |sdf(x_warp)| < edge_eps * t (threshold = edge_eps * t_exit).
-__global__ void k_coarse_min(const float *__restrict__ data, int rx, int ry, int rz, float *__restrict__ c0, int cx, int cy, int cz,
-                             int C) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= cx * cy * cz) return;
-    int bx = i % cx, by = (i / cx) % cy, bz = i / (cx * cy);
-    float m = INFINITY;
-    for (int z = bz * C; z < min(rz, (bz + 1) * C); ++z)
-        for (int y = by * C; y < min(ry, (by + 1) * C); ++y)
-            for (int x = bx * C; x < min(rx, (bx + 1) * C); ++x)
-                m = fminf(m, data[((size_t)z * ry + y) * rx + x]);
-    c0[i] = m;
-}
-
-__global__ void k_coarse_dilate(const float *__restrict__ c0, float *__restrict__ c, int cx, int cy, int cz) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= cx * cy * cz) return;
-    int bx = i % cx, by = (i / cx) % cy, bz = i / (cx * cy);
-    float m = INFINITY;
-    for (int z = max(bz - 1, 0); z <= min(bz + 1, cz - 1); ++z)
-        for (int y = max(by - 1, 0); y <= min(by + 1, cy - 1); ++y)
-            for (int x = max(bx - 1, 0); x <= min(bx + 1, cx - 1); ++x)
-                m = fminf(m, c0[(z * cy + y) * cx + x]);
-    c[i] = m;
-}
-
-// flags[view][Hb*Wb]: bit 0 = primal pass may skip the pixel, bit 1 = gradient pass may skip it.
-__global__ void k_pixel_skip(GridView G, dsdf_params P, ViewBatch VB, unsigned char *__restrict__ flags, float step) {
-    const ViewArgs &A = VB.v[blockIdx.y];
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= A.Wb * A.Hb) return;
-    int py = i / A.Wb, px = i - py * A.Wb;
-    CamRay r = camera_ray(A.cam, P, (float)(px - DSDF_BORDER) + 0.5f, (float)(py - DSDF_BORDER) + 0.5f, A.W, A.H);
-    V3 d = r.d * rsqf(dot(r.d, r.d));
-    // a slightly larger box than the traced one: sample rays may enter where the centre ray does not
-    const float grow = 0.02f;
-    BoxHit b = bbox_ray_intersect(-P.bbox_delta - grow, 1.f + P.bbox_delta + grow, r.o, d);
-    unsigned char f = 0;
-    if (b.hit && b.maxt > 0.f) {
-        float t0 = fmaxf(b.mint, 0.f), t1 = b.maxt;
-        float m = INFINITY;
-        for (float t = t0; t < t1 + step; t += step) {
-            V3 x = fma3(fminf(t, t1), d, r.o);
-            int bx = iclamp((int)floorf((x.x - G.tx) * (float)G.rx) >> G.cshift, 0, G.cx - 1);
-            int by = iclamp((int)floorf((x.y - G.ty) * (float)G.ry) >> G.cshift, 0, G.cy - 1);
-            int bz = iclamp((int)floorf((x.z - G.tz) * (float)G.rz) >> G.cshift, 0, G.cz - 1);
-            m = fminf(m, G.coarse[(bz * G.cy + by) * G.cx + bx]);
-        }
-        float thr_p = 2.f * P.trace_eps * fmaxf(t1, 1.f) + 1e-5f;
-        float thr_g = (P.weight_strategy == 6 ? P.edge_eps * (t1 + 0.1f) : P.edge_eps) * 1.05f + 1e-4f;
-        if (m > thr_p) f |= 1;
-        if (m > fmaxf(thr_p, thr_g)) f |= 2;
-    }
-    flags[(size_t)blockIdx.y * A.Wb * A.Hb + i] = f;
-}
-
-// Bits 2/3: every film pixel within +-4 of this one carries bit 0 / bit 1.  A sample only splats into
-// pixels within +-2 of its own, and a film pixel's weight sum only matters if a value lands on it or a
-// backward lane reads its adjoint -- both need a pixel within +-2 of it that is NOT proven empty.  So the
-// samples of a pixel with bit 2 (3) set cannot influence any output of the primal (gradient) pass and are
-// not generated at all.  (In place: writers only add bits 2/3, readers only look at bits 0/1.)
-#define DSDF_FAR_RADIUS 4
-__global__ void k_skip_dilate(ViewBatch VB, unsigned char *__restrict__ flags) {
-    const ViewArgs &A = VB.v[blockIdx.y];
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= A.Wb * A.Hb) return;
-    unsigned char *f = flags + (size_t)blockIdx.y * A.Wb * A.Hb;
-    int py = i / A.Wb, px = i - py * A.Wb;
-    unsigned m = 3u;
-    for (int y = max(py - DSDF_FAR_RADIUS, 0); y <= min(py + DSDF_FAR_RADIUS, A.Hb - 1); ++y)
-        for (int x = max(px - DSDF_FAR_RADIUS, 0); x <= min(px + DSDF_FAR_RADIUS, A.Wb - 1); ++x)
-            m &= f[y * A.Wb + x];
-    f[i] = (unsigned char)((f[i] & 3u) | (m << 2));
-}
+#include "dsdf_film.h"
+#include "dsdf_skip.h"
 
 // ------------------------------------------------------------------ render pass
 #ifndef DSDF_DIFF_CACHE
@@ -570,78 +264,6 @@ __global__ __launch_bounds__(DSDF_BLOCK, DIRECT ? 1 : (DIFF ? DSDF_DIFF_MINWAVES
     }
 }
 
-// HDRFilm.develop: crop the border, value / (weight == 0 ? 1 : weight), R=G=B.
-__global__ void k_develop(const float *__restrict__ blocks, int W, int H, float *__restrict__ images) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= W * H) return;
-    int y = i / W, x = i - y * W;
-    int Wb = W + 2 * DSDF_BORDER, Hb = H + 2 * DSDF_BORDER;
-    const float *block = blocks + (size_t)blockIdx.y * 2 * Wb * Hb;
-    float *image = images + (size_t)blockIdx.y * 3 * W * H;
-    float2 b = reinterpret_cast<const float2 *>(block)[(size_t)(y + DSDF_BORDER) * Wb + x + DSDF_BORDER];
-    float w = b.y == 0.f ? 1.f : b.y;
-    float v = b.x / w;
-    image[3 * (size_t)i] = v; image[3 * (size_t)i + 1] = v; image[3 * (size_t)i + 2] = v;
-}
-
-// Adjoint of develop: dL/d(value sum) = sum_c gI_c / w ; dL/d(weight sum) = -sum_c gI_c * s / w^2.
-__global__ void k_develop_adjoint(const float *__restrict__ blocks, const float *__restrict__ grad_images, int W, int H,
-                                  float *__restrict__ block_adjs) {
-    int Wb = W + 2 * DSDF_BORDER, Hb = H + 2 * DSDF_BORDER;
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= Wb * Hb) return;
-    const float *block = blocks + (size_t)blockIdx.y * 2 * Wb * Hb;
-    const float *grad_image = grad_images + (size_t)blockIdx.y * 3 * W * H;
-    float *block_adj = block_adjs + (size_t)blockIdx.y * 2 * Wb * Hb;
-    int qy = i / Wb, qx = i - qy * Wb;
-    int x = qx - DSDF_BORDER, y = qy - DSDF_BORDER;
-    float2 out = make_float2(0.f, 0.f);
-    if (x >= 0 && x < W && y >= 0 && y < H) {
-        const float *gi = grad_image + 3 * ((size_t)y * W + x);
-        float gs = gi[0] + gi[1] + gi[2];
-        float2 b = reinterpret_cast<const float2 *>(block)[i];
-        if (b.y == 0.f) out = make_float2(gs, 0.f);
-        else out = make_float2(gs / b.y, -gs * b.x / (b.y * b.y));
-    }
-    reinterpret_cast<float2 *>(block_adj)[i] = out;
-}
-
-// The same two kernels for the 4-channel (r,g,b,weight) block of sdf_direct_reparam.
-__global__ void k_develop_rgb(const float *__restrict__ blocks, int W, int H, float *__restrict__ images) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= W * H) return;
-    int y = i / W, x = i - y * W;
-    int Wb = W + 2 * DSDF_BORDER, Hb = H + 2 * DSDF_BORDER;
-    const float *block = blocks + (size_t)blockIdx.y * 4 * Wb * Hb;
-    float *image = images + (size_t)blockIdx.y * 3 * W * H;
-    float4 b = reinterpret_cast<const float4 *>(block)[(size_t)(y + DSDF_BORDER) * Wb + x + DSDF_BORDER];
-    float iw = 1.f / (b.w == 0.f ? 1.f : b.w);
-    image[3 * (size_t)i] = b.x * iw; image[3 * (size_t)i + 1] = b.y * iw; image[3 * (size_t)i + 2] = b.z * iw;
-}
-
-__global__ void k_develop_adjoint_rgb(const float *__restrict__ blocks, const float *__restrict__ grad_images, int W, int H,
-                                      float *__restrict__ block_adjs) {
-    int Wb = W + 2 * DSDF_BORDER, Hb = H + 2 * DSDF_BORDER;
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= Wb * Hb) return;
-    const float *block = blocks + (size_t)blockIdx.y * 4 * Wb * Hb;
-    const float *grad_image = grad_images + (size_t)blockIdx.y * 3 * W * H;
-    float *block_adj = block_adjs + (size_t)blockIdx.y * 4 * Wb * Hb;
-    int qy = i / Wb, qx = i - qy * Wb;
-    int x = qx - DSDF_BORDER, y = qy - DSDF_BORDER;
-    float4 out = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (x >= 0 && x < W && y >= 0 && y < H) {
-        const float *gi = grad_image + 3 * ((size_t)y * W + x);
-        float4 b = reinterpret_cast<const float4 *>(block)[i];
-        if (b.w == 0.f) out = make_float4(gi[0], gi[1], gi[2], 0.f);
-        else {
-            float iw = 1.f / b.w;
-            out = make_float4(gi[0] * iw, gi[1] * iw, gi[2] * iw, -(gi[0] * b.x + gi[1] * b.y + gi[2] * b.z) * iw * iw);
-        }
-    }
-    reinterpret_cast<float4 *>(block_adj)[i] = out;
-}
-
 // One single-wave block per render-pass block: it walks that block's queued samples 64 at a time
 // (usually one round: ~12 % of 256 samples), holds one 8 KB brick, so a CU keeps ~20 working waves.
 template <bool DIRECT>
@@ -714,144 +336,6 @@ __global__ __launch_bounds__(64) void k_forward_tangent(GridView G, const float 
         SampleTangent st;
         if (lane_forward_tangent(G, tangent, dp, P, A, L, tr, st)) splat_tangent(dblock, A.Wb, A.Hb, st, AtomicAdd());
     }
-}
-
-// d(value / weight) = d value / weight - value d weight / weight^2, R=G=B.
-__global__ void k_develop_tangent(const float *__restrict__ blocks, const float *__restrict__ dblocks, int W, int H,
-                                  float *__restrict__ grad_images) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= W * H) return;
-    int y = i / W, x = i - y * W;
-    int Wb = W + 2 * DSDF_BORDER, Hb = H + 2 * DSDF_BORDER;
-    size_t qi = (size_t)blockIdx.y * Wb * Hb + (size_t)(y + DSDF_BORDER) * Wb + x + DSDF_BORDER;
-    float2 b = reinterpret_cast<const float2 *>(blocks)[qi], db = reinterpret_cast<const float2 *>(dblocks)[qi];
-    float g = b.y == 0.f ? db.x : db.x / b.y - b.x * db.y / (b.y * b.y);
-    float *o = grad_images + (size_t)blockIdx.y * 3 * W * H + 3 * (size_t)i;
-    o[0] = g; o[1] = g; o[2] = g;
-}
-
-// ------------------------------------------------------------------ redistancing
-// |grad u| = 1 with a frozen sub-voxel interface band (spec: include/dsdf.h, dsdf_redistance).
-// Block-iterative solver: a 512-thread block relaxes an 8^3 tile (+1 halo) in LDS for 8 inner
-// Jacobi passes per launch (Godunov upwind update, monotone => same fixed point as fast sweeping);
-// launches are chained without host synchronisation through three rotating "changed" flags:
-// launch i returns immediately once launch i-1 reported no change.
-#define DSDF_RD_BIG 1e10f
-#define DSDF_RD_TILE 8
-#define DSDF_RD_INNER 8
-
-__device__ __forceinline__ float eikonal_update(float a, float b, float c, float ha, float hb, float hc) {
-    // sort (value, spacing) ascending by value
-    if (a > b) { float t = a; a = b; b = t; t = ha; ha = hb; hb = t; }
-    if (b > c) { float t = b; b = c; c = t; t = hb; hb = hc; hc = t; }
-    if (a > b) { float t = a; a = b; b = t; t = ha; ha = hb; hb = t; }
-    float u = a + ha;
-    if (u <= b) return u;
-    float w0 = 1.f / (ha * ha), w1 = 1.f / (hb * hb);
-    {
-        float A = w0 + w1, B = -2.f * (w0 * a + w1 * b), C = w0 * a * a + w1 * b * b - 1.f;
-        u = (-B + sqrtf(fmaxf(B * B - 4.f * A * C, 0.f))) / (2.f * A);
-        if (u <= c) return u;
-    }
-    float w2 = 1.f / (hc * hc);
-    float A = w0 + w1 + w2, B = -2.f * (w0 * a + w1 * b + w2 * c), C = w0 * a * a + w1 * b * b + w2 * c * c - 1.f;
-    return (-B + sqrtf(fmaxf(B * B - 4.f * A * C, 0.f))) / (2.f * A);
-}
-
-__global__ void k_redist_init(const float *__restrict__ phi, int rx, int ry, int rz, float *__restrict__ u,
-                              unsigned char *__restrict__ frozen, unsigned int *flags) {
-    size_t n = (size_t)rx * ry * rz;
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i == 0) { flags[0] = 0; flags[1] = 0; flags[2] = 0; }
-    if (i >= n) return;
-    int x = (int)(i % rx); size_t r = i / rx; int y = (int)(r % ry), z = (int)(r / ry);
-    float p = phi[i];
-    if (p == 0.f) { u[i] = 0.f; frozen[i] = 1; return; }
-    const float h[3] = {1.f / rx, 1.f / ry, 1.f / rz};
-    const int c[3] = {x, y, z}, dims[3] = {rx, ry, rz};
-    const long strides[3] = {1, rx, (long)rx * ry};
-    float inv2 = 0.f; bool any = false;
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-        float d = DSDF_RD_BIG;
-#pragma unroll
-        for (int sgn = -1; sgn <= 1; sgn += 2) {
-            int cn = c[a] + sgn;
-            if (cn < 0 || cn >= dims[a]) continue;
-            float q = phi[(long)i + sgn * strides[a]];
-            if ((p > 0.f) != (q > 0.f)) d = fminf(d, h[a] * fabsf(p) / (fabsf(p) + fabsf(q)));
-        }
-        if (d < DSDF_RD_BIG) { inv2 += 1.f / (d * d); any = true; }
-    }
-    u[i] = any ? 1.f / sqrtf(inv2) : DSDF_RD_BIG;
-    frozen[i] = any ? 1 : 0;
-}
-
-// `tmap` holds three rotating per-tile "changed" maps: launch i reads map (i-1), writes map i and
-// clears map (i+1); a tile is relaxed only if it or one of its 6 neighbours changed in launch i-1,
-// so work follows the moving front instead of sweeping the whole grid every launch.
-__global__ __launch_bounds__(512) void k_redist_iter(float *__restrict__ u, const unsigned char *__restrict__ frozen,
-                                                     int rx, int ry, int rz, unsigned int *flags,
-                                                     unsigned char *__restrict__ tmap, int iter) {
-    if (iter > 0 && flags[(iter + 2) % 3] == 0) return;       // previous launch changed nothing: converged
-    const int T = DSDF_RD_TILE, S = T + 2;
-    const int ntx = gridDim.x, nty = gridDim.y, ntz = gridDim.z;
-    const size_t ntiles = (size_t)ntx * nty * ntz;
-    const size_t tid = ((size_t)blockIdx.z * nty + blockIdx.y) * ntx + blockIdx.x;
-    unsigned char *prev = tmap + (size_t)((iter + 2) % 3) * ntiles, *cur_map = tmap + (size_t)(iter % 3) * ntiles,
-                  *next = tmap + (size_t)((iter + 1) % 3) * ntiles;
-    if (threadIdx.x == 0) {
-        next[tid] = 0;
-        if (tid == 0) flags[(iter + 1) % 3] = 0;
-    }
-    if (iter > 0) {
-        bool act = prev[tid];
-        if (blockIdx.x > 0) act = act || prev[tid - 1];
-        if ((int)blockIdx.x < ntx - 1) act = act || prev[tid + 1];
-        if (blockIdx.y > 0) act = act || prev[tid - ntx];
-        if ((int)blockIdx.y < nty - 1) act = act || prev[tid + ntx];
-        if (blockIdx.z > 0) act = act || prev[tid - (size_t)ntx * nty];
-        if ((int)blockIdx.z < ntz - 1) act = act || prev[tid + (size_t)ntx * nty];
-        if (!act) return;                                     // block-uniform
-    }
-    __shared__ float tile[S * S * S];
-    __shared__ int tile_changed;
-    if (threadIdx.x == 0) tile_changed = 0;
-    const int x0 = blockIdx.x * T, y0 = blockIdx.y * T, z0 = blockIdx.z * T;
-    for (int e = threadIdx.x; e < S * S * S; e += 512) {
-        int lx = e % S, ly = (e / S) % S, lz = e / (S * S);
-        int gx = x0 + lx - 1, gy = y0 + ly - 1, gz = z0 + lz - 1;
-        bool in = gx >= 0 && gx < rx && gy >= 0 && gy < ry && gz >= 0 && gz < rz;
-        tile[e] = in ? u[((size_t)gz * ry + gy) * rx + gx] : DSDF_RD_BIG;
-    }
-    const int lx = threadIdx.x % T, ly = (threadIdx.x / T) % T, lz = threadIdx.x / (T * T);
-    const int gx = x0 + lx, gy = y0 + ly, gz = z0 + lz;
-    const bool in = gx < rx && gy < ry && gz < rz;
-    const size_t gi = ((size_t)gz * ry + gy) * rx + gx;
-    const bool fixed = !in || frozen[gi];
-    const int c = ((lz + 1) * S + (ly + 1)) * S + (lx + 1);
-    const float hx = 1.f / rx, hy = 1.f / ry, hz = 1.f / rz;
-    __syncthreads();
-    const float start = tile[c];
-    float cur = start;
-    for (int it = 0; it < DSDF_RD_INNER; ++it) {
-        float a = fminf(tile[c - 1], tile[c + 1]);
-        float b = fminf(tile[c - S], tile[c + S]);
-        float d = fminf(tile[c - S * S], tile[c + S * S]);
-        float un = cur;
-        if (!fixed && fminf(a, fminf(b, d)) < DSDF_RD_BIG) un = fminf(cur, eikonal_update(a, b, d, hx, hy, hz));
-        __syncthreads();
-        if (un < cur) { cur = un; tile[c] = un; }
-        __syncthreads();
-    }
-    if (cur < start) { u[gi] = cur; tile_changed = 1; }
-    __syncthreads();
-    if (threadIdx.x == 0 && tile_changed) { cur_map[tid] = 1; flags[iter % 3] = 1; }
-}
-
-__global__ void k_redist_finish(const float *__restrict__ phi, const float *__restrict__ u, size_t n, float *__restrict__ out) {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = phi[i] < 0.f ? -u[i] : u[i];
 }
 
 // ------------------------------------------------------------------ host side
@@ -930,62 +414,6 @@ static ShadeArgs make_shade_args(const dsdf_shading *sh, bool with_grad) {
     }
     return S;
 }
-
-static size_t padded_floats(int rx, int ry, int rz) {
-    return (size_t)(rx + 2 * DSDF_APRON) * (ry + 2 * DSDF_APRON) * (rz + 2 * DSDF_APRON);
-}
-
-// Blocks per axis / cells of coarse level `level` (block edge 8 >> level voxels).
-static void coarse_dims(int rx, int ry, int rz, int level, int &cx, int &cy, int &cz) {
-    const int C = 1 << DSDF_COARSE_SHIFT(level);
-    cx = (rx + C - 1) / C; cy = (ry + C - 1) / C; cz = (rz + C - 1) / C;
-}
-static size_t coarse_cells(int rx, int ry, int rz, int level) {
-    int cx, cy, cz;
-    coarse_dims(rx, ry, rz, level, cx, cy, cz);
-    return (size_t)cx * cy * cz;
-}
-
-// GridView over the library's grid buffer: [padded grid | per level: block minima, dilated block minima]
-static GridView device_view(const float *padded, int rx, int ry, int rz, const dsdf_params &prm, int level = 0) {
-    GridView G = make_view(padded, rx, ry, rz, prm);
-    const float *c = padded + padded_floats(rx, ry, rz);
-    for (int l = 0; l < level; ++l) c += 2 * coarse_cells(rx, ry, rz, l);
-    coarse_dims(rx, ry, rz, level, G.cx, G.cy, G.cz);
-    G.cshift = DSDF_COARSE_SHIFT(level);
-    G.coarse = c + coarse_cells(rx, ry, rz, level);
-    return G;
-}
-
-// March step (world units) of the per-pixel empty-space proof on coarse level `level`, or 0 when the
-// sample rays of a pixel may stray further from the pixel's centre ray than the dilation margin (one
-// block) covers: lateral deviation <= t_far * (0.7072 px * pixel size); lookup support 2.5 voxels; half a step.
-static float skip_step(const dsdf_camera *cams, int nv, int W, int rx, int ry, int rz, int level) {
-    int rmax = rx > ry ? (rx > rz ? rx : rz) : (ry > rz ? ry : rz);
-    float worst = 0.f;
-    for (int i = 0; i < nv; ++i) {
-        float dx = cams[i].origin[0] - 0.5f, dy = cams[i].origin[1] - 0.5f, dz = cams[i].origin[2] - 0.5f;
-        float t_far = sqrtf(dx * dx + dy * dy + dz * dz) + 1.0f;
-        float rho = t_far * 0.7072f * (2.f * cams[i].tan_half_fov / (float)W) * (float)rmax;
-        worst = rho > worst ? rho : worst;
-    }
-    const float C = (float)(1 << DSDF_COARSE_SHIFT(level));
-    float step_vox = 2.f * (C - 2.5f - worst);
-    if (step_vox < 1.f) return 0.f;
-    if (step_vox > C) step_vox = C;
-    return step_vox / (float)rmax;
-}
-
-// Finest coarse level whose dilation margin covers this view batch (-1: none, trace every pixel).
-static int skip_level(const dsdf_camera *cams, int nv, int W, int rx, int ry, int rz, float &step) {
-    for (int level = DSDF_COARSE_LEVELS - 1; level >= 0; --level) {
-        step = skip_step(cams, nv, W, rx, ry, rz, level);
-        if (step > 0.f) return level;
-    }
-    step = 0.f;
-    return -1;
-}
-
 // Parameters of a render pass.  The silhouette integrator consumes only the hit FLAG of a sample
 // (sdf_silhouette_reparam.py:20-22), never the hit distance, and the refinement loop
 // (shapes.py:245-257) cannot turn a hit into a miss: skipping it leaves every output unchanged.
@@ -1272,40 +700,6 @@ int dsdf_render_forward_grad(const float *padded, int rx, int ry, int rz, const 
     return DSDF_OK;
 }
 
-size_t dsdf_redistance_workspace_size(int rx, int ry, int rz) {
-    if (rx < 1 || ry < 1 || rz < 1) return 0;
-    size_t n = (size_t)rx * ry * rz;
-    size_t ntiles = (size_t)((rx + DSDF_RD_TILE - 1) / DSDF_RD_TILE) * ((ry + DSDF_RD_TILE - 1) / DSDF_RD_TILE) *
-                    ((rz + DSDF_RD_TILE - 1) / DSDF_RD_TILE);
-    return align_up(n * sizeof(float), 256) + align_up(n, 256) + 256 + align_up(3 * ntiles, 256);
-}
-
-int dsdf_redistance(const float *phi, int rx, int ry, int rz, float *out, void *workspace, size_t workspace_bytes,
-                    void *stream) {
-    if (!phi || !out || !workspace || rx < 1 || ry < 1 || rz < 1) return fail(DSDF_ERR_INVALID_ARG, "dsdf_redistance: bad argument");
-    if (workspace_bytes < dsdf_redistance_workspace_size(rx, ry, rz)) return fail(DSDF_ERR_WORKSPACE, "workspace too small");
-    hipStream_t st = (hipStream_t)stream;
-    size_t n = (size_t)rx * ry * rz;
-    char *p = (char *)workspace;
-    float *u = (float *)p; p += align_up(n * sizeof(float), 256);
-    unsigned char *frozen = (unsigned char *)p; p += align_up(n, 256);
-    unsigned int *flags = (unsigned int *)p; p += 256;
-    unsigned char *tmap = (unsigned char *)p;
-    dim3 tiles((rx + DSDF_RD_TILE - 1) / DSDF_RD_TILE, (ry + DSDF_RD_TILE - 1) / DSDF_RD_TILE, (rz + DSDF_RD_TILE - 1) / DSDF_RD_TILE);
-    int rc;
-    if (hipMemsetAsync(tmap, 0, 3 * (size_t)tiles.x * tiles.y * tiles.z, st) != hipSuccess)
-        return fail(DSDF_ERR_LAUNCH, "hipMemsetAsync(tile map) failed");
-    hipLaunchKernelGGL(k_redist_init, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, phi, rx, ry, rz, u, frozen, flags);
-    if ((rc = check_launch("k_redist_init"))) return rc;
-    // information crosses at least one tile per launch (Manhattan tile distance <= sum of the tile
-    // counts); 25 % margin, converged launches return at once
-    int max_iter = (int)(tiles.x + tiles.y + tiles.z) + (int)(tiles.x + tiles.y + tiles.z) / 4 + 8;
-    for (int it = 0; it < max_iter; ++it) {
-        hipLaunchKernelGGL(k_redist_iter, tiles, dim3(512), 0, st, u, frozen, rx, ry, rz, flags, tmap, it);
-        if ((rc = check_launch("k_redist_iter"))) return rc;
-    }
-    hipLaunchKernelGGL(k_redist_finish, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, phi, u, n, out);
-    return check_launch("k_redist_finish");
-}
-
 }  // extern "C"
+
+#include "dsdf_redistance.h"

@@ -1,0 +1,182 @@
+// dsdf_wave.h -- device-only wave-level building blocks of the render kernels (included by dsdf_kernels.hip):
+// cross-lane reductions, the LDS-aggregated 64-tap scatter and the wave cell cache.
+#pragma once
+
+// ------------------------------------------------------------------ wave helpers
+__device__ __forceinline__ int lane_id() {
+    return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+}
+
+// exclusive prefix count of set bits below this lane (v_mbcnt_lo/hi)
+__device__ __forceinline__ uint32_t mask_prefix(uint64_t m) {
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+
+__device__ __forceinline__ int wave_sum_i32(int v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+    return v;
+}
+
+__device__ __forceinline__ float wave_sum_f32(float v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+    return v;
+}
+
+__device__ __forceinline__ int wave_min_i32(int v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v = min(v, __shfl_xor(v, m));
+    return v;
+}
+__device__ __forceinline__ int wave_max_i32(int v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v = max(v, __shfl_xor(v, m));
+    return v;
+}
+// LDS operations of one wave execute in program order; these fences only stop the
+// compiler from moving LDS accesses across the phases of the wave-private brick.
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// LDS-aggregated 64-tap scatter for one wave.  The samples of a wave come from a few
+// neighbouring pixels, so their 4^3 footprints overlap heavily: accumulate them in a
+// wave-private LDS brick spanning the bounding box of all taps (ds_add_f32), then
+// flush only the non-zero voxels with one global atomic each.  Falls back to direct
+// global atomics when the bounding box does not fit the brick.
+#define DSDF_BRICK_CAP 2048   /* floats per wave-private brick (8 KB): ~20 single-wave blocks per CU */
+__device__ __forceinline__ void wave_scatter(const GridView &G, float *__restrict__ grad, const ScatterReq &rq,
+                                             float *brick, int lid) {
+    const bool on = rq.on;
+    if (!__ballot(on)) return;
+    CubicSetup s = cubic_setup(G, on ? rq.x : mk(0.f, 0.f, 0.f));
+    const int big = 1 << 30;
+    int minx = wave_min_i32(on ? iclamp(s.ix, 0, G.rx - 1) : big), maxx = wave_max_i32(on ? iclamp(s.ix + 3, 0, G.rx - 1) : -big);
+    int miny = wave_min_i32(on ? iclamp(s.iy, 0, G.ry - 1) : big), maxy = wave_max_i32(on ? iclamp(s.iy + 3, 0, G.ry - 1) : -big);
+    int minz = wave_min_i32(on ? iclamp(s.iz, 0, G.rz - 1) : big), maxz = wave_max_i32(on ? iclamp(s.iz + 3, 0, G.rz - 1) : -big);
+    int ex = maxx - minx + 1, ey = maxy - miny + 1, ez = maxz - minz + 1;
+    bool fits = ex <= 64 && ey <= 64 && ez <= 64 && ex * ey * ez <= DSDF_BRICK_CAP;
+    if (!fits) {
+        if (on) scatter_cubic(G, grad, rq.x, rq.cv, rq.cg, AtomicAdd());
+        return;
+    }
+    const int vol = ex * ey * ez;
+    // Privatisation: the samples of a wave mostly share one cell, i.e. their ds_add_f32 hit the
+    // same addresses and serialise.  K copies of the brick (copy = lane mod K) cut the conflict
+    // degree K-fold; the flush sums the copies.
+    int K = 1;
+    while (K < 8 && 2 * K * vol <= DSDF_BRICK_CAP) K *= 2;
+    const int tot = K * vol;
+    for (int e = lid; e < tot; e += 64) brick[e] = 0.f;
+    wave_lds_sync();
+    if (on) {
+        float *mine = brick + (lid & (K - 1)) * vol;
+        float wx[4], wy[4], wz[4], dwx[4], dwy[4], dwz[4];
+        bspline_w(s.ax, wx); bspline_w(s.ay, wy); bspline_w(s.az, wz);
+        bspline_dw(s.ax, dwx); bspline_dw(s.ay, dwy); bspline_dw(s.az, dwz);
+        float gx = rq.cg.x * (float)G.rx, gy = rq.cg.y * (float)G.ry, gz = rq.cg.z * (float)G.rz;
+        int xo[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) xo[i] = iclamp(s.ix + i, 0, G.rx - 1) - minx;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            int zo = iclamp(s.iz + k, 0, G.rz - 1) - minz;
+            float azv = wz[k], azd = dwz[k] * gz;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                int yo = iclamp(s.iy + j, 0, G.ry - 1) - miny;
+                float *row = mine + (zo * ey + yo) * ex;
+                float c0 = azv * wy[j] * rq.cv + azd * wy[j] + azv * dwy[j] * gy;
+                float c1 = azv * wy[j] * gx;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) atomicAdd(row + xo[i], fmaf(c0, wx[i], c1 * dwx[i]));
+            }
+        }
+    }
+    wave_lds_sync();
+    for (int e = lid; e < vol; e += 64) {
+        float v = brick[e];
+        for (int c = 1; c < K; ++c) v += brick[c * vol + e];
+        if (v != 0.f) {
+            int x = e % ex, t = e / ex;
+            int y = t % ey, z = t / ey;
+            atomicAdd(grad + ((size_t)(minz + z) * G.ry + (miny + y)) * G.rx + (minx + x), v);
+        }
+    }
+    wave_lds_sync();
+}
+
+// ------------------------------------------------------------------ wave cell cache
+// The 64 lanes of a wave are samples of ONE pixel, so at every trace step they sit in a
+// handful of B-spline cells (measured: 5 distinct cells on average, <= 8 in 87 % and <= 16
+// in 95 % of the wave-steps at 256^3 / 512^2).  Reading 64 x 16 rows through the vector
+// memory path (64 B/clk/CU) bounds the naive loop; instead the wave
+//   1. groups its lanes by cell with a readlane/ballot loop (<= 16 groups = "slots"),
+//   2. loads each distinct cell ONCE: 16 lanes fetch the 16 rows of a slot, 4 slots per
+//      global_load_dwordx4 + ds_write_b128 round,
+//   3. lets every lane read its cell's rows with 16 conflict-free ds_read_b128
+//      (slot stride 68 floats: 16-byte aligned, consecutive slots 4 banks apart).
+// Lanes whose cell did not get a slot (> 16 distinct cells) read from global memory as
+// before.  Same arithmetic as the per-lane path, so results are bit-identical.
+#define DSDF_CACHE_SLOTS 16
+#define DSDF_SLOT_STRIDE 68
+
+struct LdsRows {
+    const float *slot;
+    __device__ __forceinline__ void get(int k, int j, v2f &lo, v2f &hi) const {
+        float4 t = *reinterpret_cast<const float4 *>(slot + (k * 4 + j) * 4);
+        lo = mk2(t.x, t.y); hi = mk2(t.z, t.w);
+    }
+};
+
+struct WaveCellCache {
+    float *taps;      // wave-private LDS: DSDF_CACHE_SLOTS * DSDF_SLOT_STRIDE floats, then DSDF_CACHE_SLOTS slot bases
+    int lid;
+    __device__ __forceinline__ bool any(bool b) const { return __ballot(b) != 0; }
+
+    template <int ORDER>
+    __device__ __forceinline__ void eval(const GridView &G, V3 x, bool active, float &v, V3 &g, float H[6]) {
+        const CubicCell c = cubic_cell(G, active ? x : mk(0.f, 0.f, 0.f));
+        uint32_t *slot_base = reinterpret_cast<uint32_t *>(taps + DSDF_CACHE_SLOTS * DSDF_SLOT_STRIDE);
+        // 1. group the lanes by cell: leader = first unassigned active lane; every lane holding the
+        //    same cell key takes the slot (v_readlane + v_cmp + v_cndmask + scalar mask update per cell)
+        int slot = -1, n = 0;
+        uint64_t todo = __ballot(active);
+        while (todo != 0 && n < DSDF_CACHE_SLOTS) {
+            const int leader = __builtin_ctzll(todo);
+            const uint32_t k = (uint32_t)__builtin_amdgcn_readlane((int)c.base, leader);
+            const bool same = c.base == k;
+            slot = same ? n : slot;
+            todo &= ~__ballot(same);
+            ++n;
+        }
+        if (slot >= 0) slot_base[slot] = c.base;        // all lanes of a slot write the same value
+        wave_lds_sync();
+        // 2. load every distinct cell once: lane (grp, r) fetches row r of slot 4*round + grp
+        const int grp = lid >> 4, r = lid & 15;
+        const uint32_t rowoff = (uint32_t)(r >> 2) * (4u * (uint32_t)G.sxy) + (uint32_t)(r & 3) * (4u * (uint32_t)G.sx);
+        for (int s0 = 0; s0 < n; s0 += 4) {
+            const int sl = s0 + grp;
+            if (sl < n) {
+                typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+                const uint32_t b = slot_base[sl];
+                f4u t = *reinterpret_cast<const f4u *>(reinterpret_cast<const char *>(G.p) + (b + rowoff));
+                *reinterpret_cast<float4 *>(taps + sl * DSDF_SLOT_STRIDE + r * 4) = make_float4(t.x, t.y, t.z, t.w);
+            }
+        }
+        wave_lds_sync();
+        // 3. every lane evaluates from its slot (lanes beyond 16 distinct cells read global memory)
+        if (active) {
+            if (slot >= 0) {
+                LdsRows R; R.slot = taps + slot * DSDF_SLOT_STRIDE;
+                eval_cubic_rows<ORDER>(G, c, R, v, g, H);
+            } else {
+                eval_cubic_rows<ORDER>(G, c, global_rows(G, c), v, g, H);
+            }
+        }
+        wave_lds_sync();
+    }
+};
