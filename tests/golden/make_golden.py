@@ -17,7 +17,7 @@ for p in (os.path.join(ROOT, 'oracle'), os.path.join(ROOT, 'tests')):
     sys.path.insert(0, p)
 
 import sdf_oracle as O
-from cases import make_case, oracle_backward, oracle_forward
+from cases import direct_inputs, make_case, oracle_backward, oracle_forward, oracle_direct
 
 for name in ('sphere16', 'blob32'):
     case = make_case(name)
@@ -30,3 +30,14 @@ for name in ('sphere16', 'blob32'):
         out[f'hits_{tag}'] = np.int64(aux['hits'])
     np.savez_compressed(os.path.join(HERE, f'{name}.npz'), **out)
     print(name, {k: (v.shape if hasattr(v, 'shape') else v) for k, v in out.items()})
+
+# sdf_direct_reparam (BSDF / emitter: this repo's spec, oracle/sdf_oracle.py header)
+for name in ('sphere16', 'blob32'):
+    case = make_case(name)
+    ex = direct_inputs(case)
+    img, gd, ga = oracle_direct(case, ex, reparam=True, grads=True)
+    out = {'img': img.numpy().astype(np.float32), 'grad_data': gd.numpy().astype(np.float32),
+           'grad_albedo': ga.numpy().astype(np.float32),
+           'img_hidden': oracle_direct(case, ex, reparam=False, hide_emitters=True).numpy().astype(np.float32)}
+    np.savez_compressed(os.path.join(HERE, f'{name}_direct.npz'), **out)
+    print(name + '_direct', {k: v.shape for k, v in out.items()})
