@@ -281,8 +281,16 @@ DSDF_HD bool direct_value(const GridView &G, const dsdf_params &P, const ViewArg
     if (!direct_setup(G, A, L, lane, its_t, h)) return false;
     dsdf_params Ps = P;
     Ps.refine_steps = 0;                                               // ray_test consumes only isfinite(its_t)
+#ifdef DSDF_SHADOW_REUSE
+    {
+        ReuseFetch F;                                                  // shadow rays dwell in the cell they start in
+        if (diff) trace_diff(G, Ps, h.sr.o, h.sr.d, h.sr.maxt, trs, F);
+        else trace_plain(G, Ps, h.sr.o, h.sr.d, h.sr.maxt, trs, F);
+    }
+#else
     if (diff) trace_diff(G, Ps, h.sr.o, h.sr.d, h.sr.maxt, trs);
     else trace_plain(G, Ps, h.sr.o, h.sr.d, h.sr.maxt, trs);
+#endif
     if (trs.its_t < INFINITY) return false;                            // occluded
     direct_radiance(S, h, rgb);
     return true;

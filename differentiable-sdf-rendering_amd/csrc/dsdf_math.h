@@ -266,6 +266,47 @@ struct DirectFetch {
     }
 };
 
+// ReuseFetch: a lane keeps the 64 taps of the last cell it visited in registers and only gathers again when
+// its ray enters another cell.  Rays that leave a surface (shadow rays: Mitsuba's offset_p starts them 1e-4 away)
+// or converge onto one spend many consecutive steps inside one cell.  Same rows, same arithmetic: bit-identical
+// to DirectFetch (tests/test_kernel_math_host.py).  Opt-in on the device (DSDF_SHADOW_REUSE): it costs 64 VGPRs.
+struct RegRows {
+    const float *t;
+    DSDF_HD void get(int k, int j, v2f &lo, v2f &hi) const {
+        const float *r = t + (k * 4 + j) * 4;
+        lo = mk2(r[0], r[1]); hi = mk2(r[2], r[3]);
+    }
+};
+struct ReuseFetch {
+    uint32_t base;
+    bool valid;
+    float taps[64];
+    DSDF_HD ReuseFetch() : base(0u), valid(false) {}
+    DSDF_HD bool any(bool b) const { return b; }
+    template <int ORDER>
+    DSDF_HD void eval(const GridView &G, V3 x, bool active, float &v, V3 &g, float H[6]) {
+        if (!active) return;
+        const CubicCell c = cubic_cell(G, x);
+        if (!valid || c.base != base) {
+            const GlobalRows rows = global_rows(G, c);
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    v2f lo, hi;
+                    rows.get(k, j, lo, hi);
+                    float *r = taps + (k * 4 + j) * 4;
+                    r[0] = lo[0]; r[1] = lo[1]; r[2] = hi[0]; r[3] = hi[1];
+                }
+            base = c.base;
+            valid = true;
+        }
+        RegRows rr;
+        rr.t = taps;
+        eval_cubic_rows<ORDER>(G, c, rr, v, g, H);
+    }
+};
+
 DSDF_HD float eval_value(const GridView &G, V3 x) {
     float v; V3 g; float H[6];
     eval_cubic<0>(G, x, v, g, H);

@@ -51,7 +51,11 @@ void hh_trace(const float *data, int rx, int ry, int rz, const dsdf_params *prm,
     for (long i = 0; i < n; ++i) {
         TraceOut t;
         V3 o = mk(ro[3 * i], ro[3 * i + 1], ro[3 * i + 2]), d = mk(rd[3 * i], rd[3 * i + 1], rd[3 * i + 2]);
-        if (diff) trace_diff(G, *prm, o, d, maxt[i], t); else trace_plain(G, *prm, o, d, maxt[i], t);
+        if (diff >= 2) {                                  // 2 / 3: plain / differentiable trace through ReuseFetch
+            ReuseFetch F;
+            if (diff == 3) trace_diff(G, *prm, o, d, maxt[i], t, F); else trace_plain(G, *prm, o, d, maxt[i], t, F);
+        } else if (diff) trace_diff(G, *prm, o, d, maxt[i], t);
+        else trace_plain(G, *prm, o, d, maxt[i], t);
         its_t[i] = t.its_t; warp_t[i] = t.warp_t; ww[i] = t.warp_weight; steps[i] = t.steps;
         warp_t_d[3 * i] = t.warp_t_d.x; warp_t_d[3 * i + 1] = t.warp_t_d.y; warp_t_d[3 * i + 2] = t.warp_t_d.z;
         ww_d[3 * i] = t.warp_weight_d.x; ww_d[3 * i + 1] = t.warp_weight_d.y; ww_d[3 * i + 2] = t.warp_weight_d.z;

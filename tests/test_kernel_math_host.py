@@ -150,3 +150,28 @@ def test_forward_mode_matches_oracle_jvp(harness):
     out = harness.render_forward_grad(case['grid'].float().numpy(), cam_params(case), case['W'], case['H'], case['spp'],
                                       case['offsets'].numpy(), O.SIMPLE_SHADING, tangent_p=tp.numpy())
     assert rel_l2(out, ref) < GRAD_TOL
+
+
+def test_reuse_fetch_is_bit_identical(harness):
+    """ReuseFetch (taps of the last visited cell kept in registers) against the per-step gather, on rays that start
+    on the surface like shadow rays do: identical hit distances, warp quantities and step counts, bit for bit."""
+    case = make_case('blob32')
+    g = case['grid'].float().numpy()
+    cam = O.Camera(case['origin'])
+    torch.manual_seed(4)
+    pos = torch.rand(3000, 2, dtype=torch.float64) * torch.tensor([case['W'], case['H']], dtype=torch.float64)
+    o, d, maxt = cam.sample_ray(pos, case['W'], case['H'])
+    prim = harness.trace(g, o.float().numpy(), d.float().numpy(), maxt.float().numpy(), diff=0)
+    hit = np.isfinite(prim['its_t'])
+    # secondary rays leaving the hit points in random directions, origins 1e-4 off the surface
+    oh = (o.float().numpy() + prim['its_t'][:, None] * d.float().numpy())[hit]
+    dirs = torch.randn(oh.shape[0], 3).numpy().astype(np.float32)
+    dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
+    o2 = (oh + 1e-4 * dirs).astype(np.float32)
+    m2 = np.full(o2.shape[0], 3.9, np.float32)
+    for base_mode, reuse_mode in ((0, 2), (1, 3)):
+        a = harness.trace(g, o2, dirs, m2, diff=base_mode)
+        b = harness.trace(g, o2, dirs, m2, diff=reuse_mode)
+        for k in a:
+            assert np.array_equal(a[k], b[k], equal_nan=True), (base_mode, k)
+    assert hit.sum() > 50 and prim["steps"].max() > 10
