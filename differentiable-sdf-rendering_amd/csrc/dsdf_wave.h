@@ -135,6 +135,13 @@ struct LdsRows {
 struct WaveCellCache {
     float *taps;      // wave-private LDS: DSDF_CACHE_SLOTS * DSDF_SLOT_STRIDE floats, then DSDF_CACHE_SLOTS slot bases
     int lid;
+#ifdef DSDF_CACHE_REUSE
+    // Opt-in (not timed yet): near convergence the steps are a fraction of a voxel, so whole waves stay in the cells of
+    // the previous step; the slots filled then are still valid and phases 1-2 are skipped.  A lane that was inactive
+    // at the last fill holds an invalid key, i.e. it forces a refill before it may read a slot again.
+    uint32_t prev_base = 0xffffffffu;
+    int prev_slot = -1;
+#endif
     __device__ __forceinline__ bool any(bool b) const { return __ballot(b) != 0; }
 
     template <int ORDER>
@@ -143,7 +150,14 @@ struct WaveCellCache {
         uint32_t *slot_base = reinterpret_cast<uint32_t *>(taps + DSDF_CACHE_SLOTS * DSDF_SLOT_STRIDE);
         // 1. group the lanes by cell: leader = first unassigned active lane; every lane holding the
         //    same cell key takes the slot (v_readlane + v_cmp + v_cndmask + scalar mask update per cell)
+#ifdef DSDF_CACHE_REUSE
+        int slot = prev_slot, n = 0;
+        if (__ballot(active && c.base != prev_base) != 0) {
+        slot = -1;
+#else
         int slot = -1, n = 0;
+        {
+#endif
         uint64_t todo = __ballot(active);
         while (todo != 0 && n < DSDF_CACHE_SLOTS) {
             const int leader = __builtin_ctzll(todo);
@@ -168,6 +182,11 @@ struct WaveCellCache {
             }
         }
         wave_lds_sync();
+#ifdef DSDF_CACHE_REUSE
+        prev_slot = slot;
+        prev_base = active ? c.base : 0xffffffffu;
+#endif
+        }
         // 3. every lane evaluates from its slot (lanes beyond 16 distinct cells read global memory)
         if (active) {
             if (slot >= 0) {
