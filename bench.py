@@ -231,7 +231,10 @@ def main():
                        "views_per_launch": args.views},
             "roofline": {"bound": "hbm", "kernel": "k_render_pass<primal>", "achieved": achieved, "peak": 8000.0,
                          "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic,
-                         "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": prim_avg},
+                         "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": prim_avg,
+                         "note": "SURVEY 8(d) asks for algorithmic tap bytes / HBM peak AND measured HBM bytes: the taps are served "
+                                 "by L1/LDS (wave cell cache), so frac > 1 and traffic << algorithmic bytes; the kernel is "
+                                 "VALU-issue bound (DESIGN.md section 7)"},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args)
