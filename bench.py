@@ -133,7 +133,9 @@ def main():
     data = synth_grid(args.res, dev)
     grid = dsdf.SdfGrid(data)
     target = dsdf.SdfGrid(synth_grid(args.res, dev, seed=1))
-    sensors = dsdf.get_regular_cameras(args.views * world, resx=args.img, resy=args.img)[rank * args.views:(rank + 1) * args.views]
+    # weak scaling: a ring of views*world sensors, dealt round-robin so that every rank sees the whole ring (a contiguous arc
+    # per rank would give the ranks differently expensive views and the step waits for the slowest)
+    sensors = dsdf.get_regular_cameras(args.views * world, resx=args.img, resy=args.img)[rank::world]
     grad = torch.zeros_like(data)
     # BASELINE.json C5 (--integrator sdf_direct_reparam): a 3-channel albedo volume of the grid's resolution is optimised too
     shade, shade_g = {}, {}
