@@ -435,33 +435,48 @@ DSDF_HD float refine_hit(const GridView &G, const dsdf_params &P, V3 o, V3 d, fl
     return its_t;
 }
 
-// A4: SDFBase.ray_intersect_non_diff (shapes.py:290-339)
+// A4: SDFBase.ray_intersect_non_diff (shapes.py:290-339) as a resumable march (begin / step) -- a wave may hand the
+// few rays that outlive the others to a tail queue and a persistent wave resumes them (dsdf_tail.h) -- and as the
+// closed loop.
+struct PlainMarch { V3 o, d; float t, maxt, trace_eps, its_t; bool active; };
+
+DSDF_HD PlainMarch plain_march_begin(const dsdf_params &P, V3 o, V3 d_in, float ray_maxt) {
+    PlainMarch m;
+    float inv = rsqf(dot(d_in, d_in));
+    m.o = o;
+    m.d = d_in * inv;
+    float lo = -P.bbox_delta, hi = 1.f + P.bbox_delta;
+    BoxHit b = bbox_ray_intersect(lo, hi, o, m.d);
+    m.active = b.hit && (b.mint > 0.f || b.inside);
+    m.maxt = fminf(b.maxt, ray_maxt);
+    m.trace_eps = P.trace_eps * fmaxf(m.maxt, 1.f);
+    m.its_t = INFINITY;
+    m.t = b.inside ? 0.f : b.mint + 1e-5f;
+    return m;
+}
+// consumes the SDF value at o + t d of an active march
+DSDF_HD void plain_march_step(PlainMarch &m, float v) {
+    bool hit = v < m.trace_eps;
+    if (hit) m.its_t = m.t;
+    float cur = hit ? 0.f : fabsf(v);
+    m.t += cur;
+    m.active = (m.t <= m.maxt) && !hit;
+}
+
 template <class Fetch>
 DSDF_HD void trace_plain(const GridView &G, const dsdf_params &P, V3 o, V3 d_in, float ray_maxt, TraceOut &out, Fetch &F) {
-    float inv = rsqf(dot(d_in, d_in));
-    V3 d = d_in * inv;
-    float lo = -P.bbox_delta, hi = 1.f + P.bbox_delta;
-    BoxHit b = bbox_ray_intersect(lo, hi, o, d);
-    bool active = b.hit && (b.mint > 0.f || b.inside);
-    float maxt = fminf(b.maxt, ray_maxt);
-    float trace_eps = P.trace_eps * fmaxf(maxt, 1.f);
-    float its_t = INFINITY;
-    float t = b.inside ? 0.f : b.mint + 1e-5f;
+    PlainMarch m = plain_march_begin(P, o, d_in, ray_maxt);
     int steps = 0;
-    while (F.any(active)) {
+    while (F.any(m.active)) {
         float v = 0.f; V3 gd; float Hd[6];
-        F.template eval<0>(G, fma3(t, d, o), active, v, gd, Hd);
-        if (active) {
-            bool hit = v < trace_eps;
-            if (hit) its_t = t;
-            float cur = hit ? 0.f : fabsf(v);
-            t += cur;
-            active = (t <= maxt) && !hit;
+        F.template eval<0>(G, fma3(m.t, m.d, m.o), m.active, v, gd, Hd);
+        if (m.active) {
+            plain_march_step(m, v);
             ++steps;
         }
     }
     out.steps = steps;
-    out.its_t = refine_hit(G, P, o, d, its_t, trace_eps, out.refine_steps, F);
+    out.its_t = refine_hit(G, P, m.o, m.d, m.its_t, m.trace_eps, out.refine_steps, F);
     out.warp_t = 0.f; out.warp_weight = 0.f; out.weight_sum = 0.f;
     out.warp_t_d = mk(0.f, 0.f, 0.f); out.warp_weight_d = mk(0.f, 0.f, 0.f);
 }
