@@ -51,7 +51,8 @@ void hh_trace(const float *data, int rx, int ry, int rz, const dsdf_params *prm,
     for (long i = 0; i < n; ++i) {
         TraceOut t;
         V3 o = mk(ro[3 * i], ro[3 * i + 1], ro[3 * i + 2]), d = mk(rd[3 * i], rd[3 * i + 1], rd[3 * i + 2]);
-        if (diff >= 2) {                                  // 2 / 3: plain / differentiable trace through ReuseFetch
+        if (diff == 4) { DirectFetch F; trace_diff_marched(G, *prm, o, d, maxt[i], t, F); }      // resumable form of the differentiable march
+        else if (diff >= 2) {                             // 2 / 3: plain / differentiable trace through ReuseFetch
             ReuseFetch F;
             if (diff == 3) trace_diff(G, *prm, o, d, maxt[i], t, F); else trace_plain(G, *prm, o, d, maxt[i], t, F);
         } else if (diff) trace_diff(G, *prm, o, d, maxt[i], t);
