@@ -204,6 +204,13 @@ __global__ __launch_bounds__(DSDF_BLOCK, DIRECT ? 1 : (DIFF ? DSDF_DIFF_MINWAVES
                 else trace_plain(G, P, L.ray.o, L.ray.d, L.ray.maxt, tr, F);
             }
         } else if (!skip_trace) {
+#if DSDF_TAIL_HANDOFF > 0
+            if (DIFF && !DIRECT && tq.state && wave_uniform) {      // wave-uniform branch: the wave sits in one pixel
+                bool unfinished; float st[DSDF_TAIL_WORDS - 1];
+                trace_diff_handoff(G, P, L.ray.o, L.ray.d, L.ray.maxt, tr, unfinished, st);
+                tail_enqueue_diff(tq, blockIdx.y, blockIdx.x % DSDF_TAIL_SUBQ, valid && unfinished, lane, st);
+            } else
+#endif
             if (DIFF) trace_diff(G, P, L.ray.o, L.ray.d, L.ray.maxt, tr);
             else trace_plain(G, P, L.ray.o, L.ray.d, L.ray.maxt, tr);
         }
@@ -370,6 +377,8 @@ struct Workspace {
     uint32_t *count, *qlane;
     float *qrec;
     unsigned char *skip;
+    char *tail;            // tail hand-off of the gradient sweep (DSDF_TAIL_HANDOFF > 0)
+    size_t tail_bytes;
     uint32_t cap, nblk;
     size_t bytes;
 };
@@ -390,6 +399,15 @@ static Workspace carve(void *base, int W, int H, int spp, int nv, int integrator
     ws.qlane = (uint32_t *)(p + off); off += align_up(nv * cap * sizeof(uint32_t), 256);
     ws.qrec = (float *)(p + off); off += align_up(nv * cap * rows * sizeof(float), 256);
     ws.skip = (unsigned char *)(p + off); off += align_up(nv * Wb * Hb, 256);
+    ws.tail = nullptr; ws.tail_bytes = 0;
+#if DSDF_TAIL_HANDOFF > 0
+    {   // per view: DSDF_TAIL_SUBQ counters + sub-queues of march states (at most DSDF_TAIL_HANDOFF rays per wave)
+        const size_t cap_sub = (nblk + DSDF_TAIL_SUBQ - 1) / DSDF_TAIL_SUBQ * (DSDF_BLOCK / 64) * DSDF_TAIL_HANDOFF;
+        ws.tail_bytes = align_up((size_t)nv * DSDF_TAIL_SUBQ * 2 * sizeof(uint32_t), 256) +
+                        align_up((size_t)nv * DSDF_TAIL_SUBQ * cap_sub * DSDF_TAIL_WORDS * sizeof(float), 256);
+        ws.tail = p + off; off += ws.tail_bytes;
+    }
+#endif
     ws.cap = (uint32_t)cap;
     ws.nblk = (uint32_t)nblk;
     ws.bytes = off;
@@ -642,6 +660,16 @@ int dsdf_render_backward(const float *padded, int rx, int ry, int rz, const dsdf
         const ShadeArgs S = make_shade_args(shading, true);
         TailQueue tq;
         memset(&tq, 0, sizeof(tq));
+#if DSDF_TAIL_HANDOFF > 0
+        const bool handoff = !direct && !stats && spp % 64 == 0;
+        if (handoff) {
+            tq.cap_sub = (uint32_t)(((size_t)ws.nblk + DSDF_TAIL_SUBQ - 1) / DSDF_TAIL_SUBQ * (DSDF_BLOCK / 64) * DSDF_TAIL_HANDOFF);
+            tq.count = (uint32_t *)ws.tail;
+            tq.state = (float *)(ws.tail + align_up((size_t)nb * DSDF_TAIL_SUBQ * 2 * sizeof(uint32_t), 256));
+            if (hipMemsetAsync(tq.count, 0, (size_t)nv * DSDF_TAIL_SUBQ * 2 * sizeof(uint32_t), st) != hipSuccess)
+                return fail(DSDF_ERR_LAUNCH, "hipMemsetAsync(tail queue) failed");
+        }
+#endif
         const dim3 grid(ws.nblk, nv), blk(DSDF_BLOCK);
         unsigned long long *st64 = (unsigned long long *)stats;
         if (direct) {
@@ -652,6 +680,12 @@ int dsdf_render_backward(const float *padded, int rx, int ry, int rz, const dsdf
             else hipLaunchKernelGGL((k_render_pass<true, false, false>), grid, blk, 0, st, G, pp, VB, ws.block, q, st64, nl, 0, skip, S, tq);
         }
         if ((rc = check_launch("k_render_pass<grad>"))) return rc;
+#if DSDF_TAIL_HANDOFF > 0
+        if (handoff) {
+            hipLaunchKernelGGL(k_tail_trace_diff, dim3(DSDF_TAIL_SUBQ * DSDF_TAIL_BLOCKS_PER_SUBQ, nv), dim3(256), 0, st, G, pp, VB, ws.block, tq, q);
+            if ((rc = check_launch("k_tail_trace_diff"))) return rc;
+        }
+#endif
         const dim3 dev_grid((width * height + 255) / 256, nv), adj_grid((unsigned)((Wb * Hb + 255) / 256), nv);
         if (image_out) {
             float *img = image_out + (size_t)v0 * width * height * 3;
