@@ -137,6 +137,7 @@ __device__ __forceinline__ void load_record(const float *r, size_t c, TraceOut &
 
 #include "dsdf_film.h"
 #include "dsdf_skip.h"
+#include "dsdf_tail.h"
 
 // ------------------------------------------------------------------ render pass
 #ifndef DSDF_DIFF_CACHE
@@ -152,7 +153,7 @@ __global__ __launch_bounds__(DSDF_BLOCK, DIRECT ? 1 : (DIFF ? DSDF_DIFF_MINWAVES
                                                             float *__restrict__ blocks, Queue qall,
                                                             unsigned long long *stats, uint32_t n_lanes,
                                                             int wave_uniform, const unsigned char *__restrict__ skip,
-                                                            ShadeArgs S) {
+                                                            ShadeArgs S, TailQueue tq) {
     const ViewArgs &A = VB.v[blockIdx.y];
     constexpr int NCH = DIRECT ? 4 : 2;
     float *__restrict__ block = blocks + (size_t)blockIdx.y * NCH * A.Wb * A.Hb;
@@ -193,9 +194,23 @@ __global__ __launch_bounds__(DSDF_BLOCK, DIRECT ? 1 : (DIFF ? DSDF_DIFF_MINWAVES
             if (!skip_trace) {                              // wave-uniform branch (CACHE implies one pixel per wave)
                 WaveCellCache F; F.taps = wave_lds[threadIdx.x >> 6]; F.lid = lid;
                 if (DIFF) trace_diff(G, P, L.ray.o, L.ray.d, L.ray.maxt, tr, F);
+#if DSDF_TAIL_HANDOFF > 0
+                else if (!DIRECT && tq.entry) {
+                    bool unfinished; float resume_t;
+                    trace_plain_handoff(G, P, L.ray.o, L.ray.d, L.ray.maxt, tr, F, unfinished, resume_t);
+                    tail_enqueue(tq, blockIdx.y, blockIdx.x % DSDF_TAIL_SUBQ, valid && unfinished, lane, resume_t);
+                }
+#endif
                 else trace_plain(G, P, L.ray.o, L.ray.d, L.ray.maxt, tr, F);
             }
         } else if (!skip_trace) {
+#if DSDF_TAIL_HANDOFF > 0
+            if (DIFF && !DIRECT && tq.state && wave_uniform) {      // wave-uniform branch: the wave sits in one pixel
+                bool unfinished; float st[DSDF_TAIL_WORDS - 1];
+                trace_diff_handoff(G, P, L.ray.o, L.ray.d, L.ray.maxt, tr, unfinished, st);
+                tail_enqueue_diff(tq, blockIdx.y, blockIdx.x % DSDF_TAIL_SUBQ, valid && unfinished, lane, st);
+            } else
+#endif
             if (DIFF) trace_diff(G, P, L.ray.o, L.ray.d, L.ray.maxt, tr);
             else trace_plain(G, P, L.ray.o, L.ray.d, L.ray.maxt, tr);
         }
@@ -362,6 +377,8 @@ struct Workspace {
     uint32_t *count, *qlane;
     float *qrec;
     unsigned char *skip;
+    char *tail;            // tail hand-off of the gradient sweep (DSDF_TAIL_HANDOFF > 0)
+    size_t tail_bytes;
     uint32_t cap, nblk;
     size_t bytes;
 };
@@ -382,6 +399,15 @@ static Workspace carve(void *base, int W, int H, int spp, int nv, int integrator
     ws.qlane = (uint32_t *)(p + off); off += align_up(nv * cap * sizeof(uint32_t), 256);
     ws.qrec = (float *)(p + off); off += align_up(nv * cap * rows * sizeof(float), 256);
     ws.skip = (unsigned char *)(p + off); off += align_up(nv * Wb * Hb, 256);
+    ws.tail = nullptr; ws.tail_bytes = 0;
+#if DSDF_TAIL_HANDOFF > 0
+    {   // per view: DSDF_TAIL_SUBQ counters + sub-queues of march states (at most DSDF_TAIL_HANDOFF rays per wave)
+        const size_t cap_sub = (nblk + DSDF_TAIL_SUBQ - 1) / DSDF_TAIL_SUBQ * (DSDF_BLOCK / 64) * DSDF_TAIL_HANDOFF;
+        ws.tail_bytes = align_up((size_t)nv * DSDF_TAIL_SUBQ * 2 * sizeof(uint32_t), 256) +
+                        align_up((size_t)nv * DSDF_TAIL_SUBQ * cap_sub * DSDF_TAIL_WORDS * sizeof(float), 256);
+        ws.tail = p + off; off += ws.tail_bytes;
+    }
+#endif
     ws.cap = (uint32_t)cap;
     ws.nblk = (uint32_t)nblk;
     ws.bytes = off;
@@ -550,14 +576,35 @@ int dsdf_render_forward(const float *padded, int rx, int ry, int rz, const dsdf_
         const ShadeArgs S = make_shade_args(shading, false);
         const dim3 grid(ws.nblk, nv), blk(DSDF_BLOCK);
         unsigned long long *st64 = (unsigned long long *)stats;
+        TailQueue tq;
+        memset(&tq, 0, sizeof(tq));
+#if DSDF_TAIL_HANDOFF > 0
+        // tail hand-off (wave-uniform one-channel passes without statistics): the queue lives in the backward-queue
+        // records, which are idle in a primal call -- at most DSDF_TAIL_HANDOFF entries per wave
+        const bool handoff = !direct && !stats && spp % 64 == 0;
+        if (handoff) {
+            // a sub-queue serves the blocks with blockIdx.x % DSDF_TAIL_SUBQ == sub; every wave queues at most DSDF_TAIL_HANDOFF rays
+            tq.cap_sub = (uint32_t)(((size_t)ws.nblk + DSDF_TAIL_SUBQ - 1) / DSDF_TAIL_SUBQ * (DSDF_BLOCK / 64) * DSDF_TAIL_HANDOFF);
+            tq.count = (uint32_t *)ws.qrec;
+            tq.entry = (uint2 *)((char *)ws.qrec + align_up((size_t)nv * DSDF_TAIL_SUBQ * 2 * sizeof(uint32_t), 256));
+            if (hipMemsetAsync(tq.count, 0, (size_t)nv * DSDF_TAIL_SUBQ * 2 * sizeof(uint32_t), st) != hipSuccess)
+                return fail(DSDF_ERR_LAUNCH, "hipMemsetAsync(tail queue) failed");
+        }
+#endif
         if (direct) {
-            if (spp % 64 == 0) hipLaunchKernelGGL((k_render_pass<false, true, true>), grid, blk, 0, st, G, pp, VB, ws.block, q, st64, nl, 1, skip, S);
-            else hipLaunchKernelGGL((k_render_pass<false, false, true>), grid, blk, 0, st, G, pp, VB, ws.block, q, st64, nl, 0, skip, S);
+            if (spp % 64 == 0) hipLaunchKernelGGL((k_render_pass<false, true, true>), grid, blk, 0, st, G, pp, VB, ws.block, q, st64, nl, 1, skip, S, tq);
+            else hipLaunchKernelGGL((k_render_pass<false, false, true>), grid, blk, 0, st, G, pp, VB, ws.block, q, st64, nl, 0, skip, S, tq);
         } else {
-            if (spp % 64 == 0) hipLaunchKernelGGL((k_render_pass<false, true, false>), grid, blk, 0, st, G, pp, VB, ws.block, q, st64, nl, 1, skip, S);
-            else hipLaunchKernelGGL((k_render_pass<false, false, false>), grid, blk, 0, st, G, pp, VB, ws.block, q, st64, nl, 0, skip, S);
+            if (spp % 64 == 0) hipLaunchKernelGGL((k_render_pass<false, true, false>), grid, blk, 0, st, G, pp, VB, ws.block, q, st64, nl, 1, skip, S, tq);
+            else hipLaunchKernelGGL((k_render_pass<false, false, false>), grid, blk, 0, st, G, pp, VB, ws.block, q, st64, nl, 0, skip, S, tq);
         }
         if ((rc = check_launch("k_render_pass<primal>"))) return rc;
+#if DSDF_TAIL_HANDOFF > 0
+        if (handoff) {
+            hipLaunchKernelGGL(k_tail_trace, dim3(DSDF_TAIL_SUBQ * DSDF_TAIL_BLOCKS_PER_SUBQ, nv), dim3(256), 0, st, G, pp, VB, ws.block, tq);
+            if ((rc = check_launch("k_tail_trace"))) return rc;
+        }
+#endif
         if (direct)
             hipLaunchKernelGGL(k_develop_rgb, dim3((width * height + 255) / 256, nv), dim3(256), 0, st, ws.block, width, height,
                                image_out + (size_t)v0 * width * height * 3);
@@ -611,16 +658,34 @@ int dsdf_render_backward(const float *padded, int rx, int ry, int rz, const dsdf
             skip = ws.skip;
         }
         const ShadeArgs S = make_shade_args(shading, true);
+        TailQueue tq;
+        memset(&tq, 0, sizeof(tq));
+#if DSDF_TAIL_HANDOFF > 0
+        const bool handoff = !direct && !stats && spp % 64 == 0;
+        if (handoff) {
+            tq.cap_sub = (uint32_t)(((size_t)ws.nblk + DSDF_TAIL_SUBQ - 1) / DSDF_TAIL_SUBQ * (DSDF_BLOCK / 64) * DSDF_TAIL_HANDOFF);
+            tq.count = (uint32_t *)ws.tail;
+            tq.state = (float *)(ws.tail + align_up((size_t)nb * DSDF_TAIL_SUBQ * 2 * sizeof(uint32_t), 256));
+            if (hipMemsetAsync(tq.count, 0, (size_t)nv * DSDF_TAIL_SUBQ * 2 * sizeof(uint32_t), st) != hipSuccess)
+                return fail(DSDF_ERR_LAUNCH, "hipMemsetAsync(tail queue) failed");
+        }
+#endif
         const dim3 grid(ws.nblk, nv), blk(DSDF_BLOCK);
         unsigned long long *st64 = (unsigned long long *)stats;
         if (direct) {
-            if (spp % 64 == 0) hipLaunchKernelGGL((k_render_pass<true, false, true>), grid, blk, 0, st, G, pp, VB, ws.block, q, st64, nl, 1, skip, S);
-            else hipLaunchKernelGGL((k_render_pass<true, false, true>), grid, blk, 0, st, G, pp, VB, ws.block, q, st64, nl, 0, skip, S);
+            if (spp % 64 == 0) hipLaunchKernelGGL((k_render_pass<true, false, true>), grid, blk, 0, st, G, pp, VB, ws.block, q, st64, nl, 1, skip, S, tq);
+            else hipLaunchKernelGGL((k_render_pass<true, false, true>), grid, blk, 0, st, G, pp, VB, ws.block, q, st64, nl, 0, skip, S, tq);
         } else {
-            if (spp % 64 == 0) hipLaunchKernelGGL((k_render_pass<true, DSDF_DIFF_CACHE != 0, false>), grid, blk, 0, st, G, pp, VB, ws.block, q, st64, nl, 1, skip, S);
-            else hipLaunchKernelGGL((k_render_pass<true, false, false>), grid, blk, 0, st, G, pp, VB, ws.block, q, st64, nl, 0, skip, S);
+            if (spp % 64 == 0) hipLaunchKernelGGL((k_render_pass<true, DSDF_DIFF_CACHE != 0, false>), grid, blk, 0, st, G, pp, VB, ws.block, q, st64, nl, 1, skip, S, tq);
+            else hipLaunchKernelGGL((k_render_pass<true, false, false>), grid, blk, 0, st, G, pp, VB, ws.block, q, st64, nl, 0, skip, S, tq);
         }
         if ((rc = check_launch("k_render_pass<grad>"))) return rc;
+#if DSDF_TAIL_HANDOFF > 0
+        if (handoff) {
+            hipLaunchKernelGGL(k_tail_trace_diff, dim3(DSDF_TAIL_SUBQ * DSDF_TAIL_BLOCKS_PER_SUBQ, nv), dim3(256), 0, st, G, pp, VB, ws.block, tq, q);
+            if ((rc = check_launch("k_tail_trace_diff"))) return rc;
+        }
+#endif
         const dim3 dev_grid((width * height + 255) / 256, nv), adj_grid((unsigned)((Wb * Hb + 255) / 256), nv);
         if (image_out) {
             float *img = image_out + (size_t)v0 * width * height * 3;
@@ -661,6 +726,8 @@ int dsdf_render_forward_grad(const float *padded, int rx, int ry, int rz, const 
     Queue q; q.count = ws.count; q.lane = ws.qlane; q.rec = ws.qrec; q.rows = 9u; q.cap = ws.cap; q.nblk = ws.nblk;
     const V3 dp = tangent_p ? mk(tangent_p[0], tangent_p[1], tangent_p[2]) : mk(0.f, 0.f, 0.f);
     const ShadeArgs S = make_shade_args(nullptr, false);
+    TailQueue tq;
+    memset(&tq, 0, sizeof(tq));
     for (int v0 = 0; v0 < n_views; v0 += nb) {
         const int nv = (n_views - v0) < nb ? (n_views - v0) : nb;
         ViewBatch VB;
@@ -683,8 +750,8 @@ int dsdf_render_forward_grad(const float *padded, int rx, int ry, int rz, const 
             skip = ws.skip;
         }
         const dim3 grid(ws.nblk, nv), blk(DSDF_BLOCK);
-        if (spp % 64 == 0) hipLaunchKernelGGL((k_render_pass<true, DSDF_DIFF_CACHE != 0, false>), grid, blk, 0, st, G, pp, VB, ws.block, q, (unsigned long long *)nullptr, nl, 1, skip, S);
-        else hipLaunchKernelGGL((k_render_pass<true, false, false>), grid, blk, 0, st, G, pp, VB, ws.block, q, (unsigned long long *)nullptr, nl, 0, skip, S);
+        if (spp % 64 == 0) hipLaunchKernelGGL((k_render_pass<true, DSDF_DIFF_CACHE != 0, false>), grid, blk, 0, st, G, pp, VB, ws.block, q, (unsigned long long *)nullptr, nl, 1, skip, S, tq);
+        else hipLaunchKernelGGL((k_render_pass<true, false, false>), grid, blk, 0, st, G, pp, VB, ws.block, q, (unsigned long long *)nullptr, nl, 0, skip, S, tq);
         if ((rc = check_launch("k_render_pass<grad>"))) return rc;
         hipLaunchKernelGGL(k_forward_tangent, grid, dim3(64), 0, st, G, tangent_padded, dp, pp, VB, q, ws.block_adj);
         if ((rc = check_launch("k_forward_tangent"))) return rc;

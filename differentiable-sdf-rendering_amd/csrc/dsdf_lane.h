@@ -99,6 +99,26 @@ DSDF_HD void splat_lane(float *block, int Wb, int Hb, float u, float v, float va
     }
 }
 
+// Value channel only (the weight of the sample has been splatted already): tail rays, dsdf_tail.h.
+template <class Adder>
+DSDF_HD void splat_value_lane(float *block, int Wb, int Hb, float u, float v, float val, Adder add) {
+    float pfx = u + (DSDF_BORDER - 0.5f), pfy = v + (DSDF_BORDER - 0.5f);
+    int x0 = (int)ceilf(pfx - DSDF_FILTER_RADIUS), y0 = (int)ceilf(pfy - DSDF_FILTER_RADIUS);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        int qy = y0 + j;
+        if (qy < 0 || qy >= Hb) continue;
+        float wy = gauss_f((float)qy - pfy);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int qx = x0 + i;
+            if (qx < 0 || qx >= Wb) continue;
+            float f = gauss_f((float)qx - pfx) * wy;
+            if (f != 0.f) add(block + 2 * ((size_t)qy * Wb + qx), f * val);
+        }
+    }
+}
+
 // Same for the 4-channel (r,g,b,weight) block of sdf_direct_reparam.
 template <class Adder>
 DSDF_HD void splat_lane_rgb(float *block, int Wb, int Hb, float u, float v, const float rgb[3], Adder add) {

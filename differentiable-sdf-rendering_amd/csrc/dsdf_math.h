@@ -435,33 +435,48 @@ DSDF_HD float refine_hit(const GridView &G, const dsdf_params &P, V3 o, V3 d, fl
     return its_t;
 }
 
-// A4: SDFBase.ray_intersect_non_diff (shapes.py:290-339)
+// A4: SDFBase.ray_intersect_non_diff (shapes.py:290-339) as a resumable march (begin / step) -- a wave may hand the
+// few rays that outlive the others to a tail queue and a persistent wave resumes them (dsdf_tail.h) -- and as the
+// closed loop.
+struct PlainMarch { V3 o, d; float t, maxt, trace_eps, its_t; bool active; };
+
+DSDF_HD PlainMarch plain_march_begin(const dsdf_params &P, V3 o, V3 d_in, float ray_maxt) {
+    PlainMarch m;
+    float inv = rsqf(dot(d_in, d_in));
+    m.o = o;
+    m.d = d_in * inv;
+    float lo = -P.bbox_delta, hi = 1.f + P.bbox_delta;
+    BoxHit b = bbox_ray_intersect(lo, hi, o, m.d);
+    m.active = b.hit && (b.mint > 0.f || b.inside);
+    m.maxt = fminf(b.maxt, ray_maxt);
+    m.trace_eps = P.trace_eps * fmaxf(m.maxt, 1.f);
+    m.its_t = INFINITY;
+    m.t = b.inside ? 0.f : b.mint + 1e-5f;
+    return m;
+}
+// consumes the SDF value at o + t d of an active march
+DSDF_HD void plain_march_step(PlainMarch &m, float v) {
+    bool hit = v < m.trace_eps;
+    if (hit) m.its_t = m.t;
+    float cur = hit ? 0.f : fabsf(v);
+    m.t += cur;
+    m.active = (m.t <= m.maxt) && !hit;
+}
+
 template <class Fetch>
 DSDF_HD void trace_plain(const GridView &G, const dsdf_params &P, V3 o, V3 d_in, float ray_maxt, TraceOut &out, Fetch &F) {
-    float inv = rsqf(dot(d_in, d_in));
-    V3 d = d_in * inv;
-    float lo = -P.bbox_delta, hi = 1.f + P.bbox_delta;
-    BoxHit b = bbox_ray_intersect(lo, hi, o, d);
-    bool active = b.hit && (b.mint > 0.f || b.inside);
-    float maxt = fminf(b.maxt, ray_maxt);
-    float trace_eps = P.trace_eps * fmaxf(maxt, 1.f);
-    float its_t = INFINITY;
-    float t = b.inside ? 0.f : b.mint + 1e-5f;
+    PlainMarch m = plain_march_begin(P, o, d_in, ray_maxt);
     int steps = 0;
-    while (F.any(active)) {
+    while (F.any(m.active)) {
         float v = 0.f; V3 gd; float Hd[6];
-        F.template eval<0>(G, fma3(t, d, o), active, v, gd, Hd);
-        if (active) {
-            bool hit = v < trace_eps;
-            if (hit) its_t = t;
-            float cur = hit ? 0.f : fabsf(v);
-            t += cur;
-            active = (t <= maxt) && !hit;
+        F.template eval<0>(G, fma3(m.t, m.d, m.o), m.active, v, gd, Hd);
+        if (m.active) {
+            plain_march_step(m, v);
             ++steps;
         }
     }
     out.steps = steps;
-    out.its_t = refine_hit(G, P, o, d, its_t, trace_eps, out.refine_steps, F);
+    out.its_t = refine_hit(G, P, m.o, m.d, m.its_t, m.trace_eps, out.refine_steps, F);
     out.warp_t = 0.f; out.warp_weight = 0.f; out.weight_sum = 0.f;
     out.warp_t_d = mk(0.f, 0.f, 0.f); out.warp_weight_d = mk(0.f, 0.f, 0.f);
 }
@@ -545,6 +560,115 @@ DSDF_HD void trace_diff(const GridView &G, const dsdf_params &P, V3 o, V3 d_in, 
         warp_t = INFINITY; warp_t_d = mk(0.f, 0.f, 0.f); ww = 0.f; ww_d = mk(0.f, 0.f, 0.f);
     }
     out.warp_t = warp_t; out.warp_t_d = warp_t_d; out.warp_weight = ww; out.warp_weight_d = ww_d;
+}
+
+// The same march in resumable form (begin / step / finish): the state of a ray can be handed to another wave
+// (dsdf_tail.h).  Kept apart from the closed loop above, whose local-variable form allocates 158 VGPRs in the
+// gradient kernel where this one needs 203.
+struct DiffMarch {
+    V3 o, d;
+    float t, maxt, trace_eps, its_t;
+    float warp_t, prev_sd, wsum, ews;
+    V3 t_d, prev_gc, mixed, wdsum, ews_d;
+    int i;
+    bool active, hit_box;
+};
+
+DSDF_HD DiffMarch diff_march_begin(const dsdf_params &P, V3 o, V3 d_in, float ray_maxt) {
+    DiffMarch m;
+    float invn = rsqf(dot(d_in, d_in));
+    m.o = o;
+    m.d = d_in * invn;                                               // :124
+    float lo = -P.bbox_delta, hi = 1.f + P.bbox_delta;
+    BoxHit b = bbox_ray_intersect(lo, hi, o, m.d);
+    m.hit_box = b.hit && (b.mint > 0.f || b.inside);                 // :132
+    m.active = m.hit_box;
+    m.maxt = fminf(b.maxt, ray_maxt);                                // :136
+    m.trace_eps = P.trace_eps * fmaxf(m.maxt, 1.f);                  // :137
+    m.its_t = INFINITY;
+    m.t = b.inside ? 0.f : b.mint + 1e-5f;                           // :141
+    m.warp_t = 0.f; m.prev_sd = 0.f; m.wsum = 0.f; m.ews = 0.f;
+    m.prev_gc = mk(0.f, 0.f, 0.f); m.mixed = mk(0.f, 0.f, 0.f); m.wdsum = mk(0.f, 0.f, 0.f); m.ews_d = mk(0.f, 0.f, 0.f);
+    m.i = 0;
+    // entry-face derivative of t (:156-164)
+    V3 pb = fma3(m.t, m.d, o);
+    V3 n = closest_axis(mk(fminf(fabsf(lo - pb.x), fabsf(hi - pb.x)), fminf(fabsf(lo - pb.y), fabsf(hi - pb.y)),
+                           fminf(fabsf(lo - pb.z), fabsf(hi - pb.z))));
+    float ddn = dot(m.d, n);
+    m.t_d = mk(0.f, 0.f, 0.f);
+    if (!b.inside && fabsf(ddn) > 0.f) m.t_d = n * (-m.t / ddn);
+    return m;
+}
+
+// consumes value / gradient / Hessian of the SDF at x = o + t d of an active march
+DSDF_HD void diff_march_step(const dsdf_params &P, DiffMarch &m, V3 x, float v, V3 g, const float H[6]) {
+    const float lo = -P.bbox_delta, hi = 1.f + P.bbox_delta;
+    const V3 d = m.d;
+    const float t = m.t;
+    bool hit = v < m.trace_eps;                                      // :185
+    if (hit) m.its_t = t;
+    float sd = fabsf(v);
+    V3 w_d;
+    float w = eval_trace_weight(P, d, m.i, lo, hi, x, v, g, H, w_d); // :188
+    float inv_den = rcpf(fminf(P.extra_thresh, sd));                 // :198
+    float diff = m.prev_sd - sd;
+    m.ews += (diff >= 0.f) ? diff * inv_den : 0.f;
+    m.ews = fminf(m.ews, 1.f);                                       // :201
+    float cur = hit ? 0.f : sd;                                      // :203
+    float seg = 0.5f * (cur + m.prev_sd);
+    float winc = seg * w * m.ews;                                    // :205-207
+    m.wsum += winc;
+    m.warp_t += winc * t;
+    // convert_deriv(f) = t*f + dot(d,f)*t_d  (:126-127)
+    w_d = fma3(dot(d, w_d), m.t_d, t * w_d);
+    V3 gc = fma3(dot(d, g), m.t_d, t * g);
+    V3 seg_d = 0.5f * (gc + m.prev_gc);
+    V3 sd_d = drsign(v) * gc;                                        // :220-221
+    V3 ewd = (m.prev_gc - sd_d) * inv_den;
+    if (v < P.extra_thresh) ewd = ewd - (diff * inv_den * inv_den) * sd_d;
+    if (diff > 0.f) m.ews_d = m.ews_d + ewd;
+    if (m.ews >= 1.f || m.ews <= 0.f) m.ews_d = mk(0.f, 0.f, 0.f);   // :226
+    w_d = w * m.ews_d + m.ews * w_d;                                 // :227
+    w *= m.ews;
+    V3 winc_d = w * seg_d + seg * w_d;                               // :230
+    m.mixed = m.mixed + t * winc_d + (w * seg) * m.t_d;
+    m.t_d = m.t_d + gc;
+    m.wdsum = m.wdsum + winc_d;
+    ++m.i;
+    m.t += cur;
+    m.prev_sd = sd;
+    m.prev_gc = gc;
+    m.active = (m.t <= m.maxt) && !hit;                              // :238
+}
+
+// everything after the loop except the refinement of its_t (which needs a Fetch)
+DSDF_HD void diff_march_finish(const DiffMarch &m, TraceOut &out) {
+    out.steps = m.i;
+    out.weight_sum = m.wsum;
+    float inv = 1.f / m.wsum;                                        // :259-261
+    float warp_t = m.warp_t * inv;
+    V3 warp_t_d = (m.mixed - warp_t * m.wdsum) * inv;
+    float ww = fminf(fmaxf(m.wsum, 0.f), 1.f);                       // :271-272
+    V3 ww_d = (m.wsum > 0.f && m.wsum < 1.f) ? m.wdsum : mk(0.f, 0.f, 0.f);
+    bool invalid = (m.wsum < 1e-7f) || !m.hit_box;                   // :278-283
+    if (invalid) {
+        warp_t = INFINITY; warp_t_d = mk(0.f, 0.f, 0.f); ww = 0.f; ww_d = mk(0.f, 0.f, 0.f);
+    }
+    out.warp_t = warp_t; out.warp_t_d = warp_t_d; out.warp_weight = ww; out.warp_weight_d = ww_d;
+}
+
+// closed loop over the resumable form (the tail kernel's arithmetic; the host tests check it against trace_diff bit for bit)
+template <class Fetch>
+DSDF_HD void trace_diff_marched(const GridView &G, const dsdf_params &P, V3 o, V3 d_in, float ray_maxt, TraceOut &out, Fetch &F) {
+    DiffMarch m = diff_march_begin(P, o, d_in, ray_maxt);
+    while (F.any(m.active)) {
+        V3 x = fma3(m.t, m.d, m.o);
+        float v = 0.f; V3 g = mk(0.f, 0.f, 0.f); float H[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        F.template eval<2>(G, x, m.active, v, g, H);
+        if (m.active) diff_march_step(P, m, x, v, g, H);
+    }
+    out.its_t = refine_hit(G, P, m.o, m.d, m.its_t, m.trace_eps, out.refine_steps, F);
+    diff_march_finish(m, out);
 }
 
 // per-lane (direct fetch) convenience forms

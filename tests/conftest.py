@@ -59,6 +59,20 @@ class HostHarness:
                           self._p(out['warp_weight']), self._p(out['warp_weight_d']), self._p(out['steps']))
         return out
 
+    def trace_resumed(self, grid, o, d, maxt, split):
+        grid = np.ascontiguousarray(grid, np.float32)
+        o = np.ascontiguousarray(o, np.float32); d = np.ascontiguousarray(d, np.float32)
+        maxt = np.ascontiguousarray(maxt, np.float32)
+        n = o.shape[0]
+        out = dict(its_t=np.zeros(n, np.float32), warp_t=np.zeros(n, np.float32), warp_t_d=np.zeros((n, 3), np.float32),
+                   warp_weight=np.zeros(n, np.float32), warp_weight_d=np.zeros((n, 3), np.float32),
+                   steps=np.zeros(n, np.int32))
+        rz, ry, rx = grid.shape
+        self.lib.hh_trace_resumed(self._p(grid), rx, ry, rz, C.byref(self.params), self._p(o), self._p(d), self._p(maxt),
+                                  C.c_long(n), int(split), self._p(out['its_t']), self._p(out['warp_t']), self._p(out['warp_t_d']),
+                                  self._p(out['warp_weight']), self._p(out['warp_weight_d']), self._p(out['steps']))
+        return out
+
     def render_forward(self, grid, cam, W, H, spp, offsets, integrator, reparam=True, diff=False, seed=0):
         grid = np.ascontiguousarray(grid, np.float32)
         offsets = None if offsets is None else np.ascontiguousarray(offsets, np.float32)

@@ -51,7 +51,8 @@ void hh_trace(const float *data, int rx, int ry, int rz, const dsdf_params *prm,
     for (long i = 0; i < n; ++i) {
         TraceOut t;
         V3 o = mk(ro[3 * i], ro[3 * i + 1], ro[3 * i + 2]), d = mk(rd[3 * i], rd[3 * i + 1], rd[3 * i + 2]);
-        if (diff >= 2) {                                  // 2 / 3: plain / differentiable trace through ReuseFetch
+        if (diff == 4) { DirectFetch F; trace_diff_marched(G, *prm, o, d, maxt[i], t, F); }      // resumable form of the differentiable march
+        else if (diff >= 2) {                             // 2 / 3: plain / differentiable trace through ReuseFetch
             ReuseFetch F;
             if (diff == 3) trace_diff(G, *prm, o, d, maxt[i], t, F); else trace_plain(G, *prm, o, d, maxt[i], t, F);
         } else if (diff) trace_diff(G, *prm, o, d, maxt[i], t);
@@ -138,6 +139,45 @@ void hh_render_backward(const float *data, int rx, int ry, int rz, const dsdf_pa
                 scatter_cubic(G, grad_grid, req[r].x, req[r].cv, req[r].cg, PlainAdd());
                 if (grad_p) { grad_p[0] += req[r].p_bar.x; grad_p[1] += req[r].p_bar.y; grad_p[2] += req[r].p_bar.z; }
             }
+    }
+}
+
+// Tail hand-off (dsdf_tail.h): stop the differentiable march after `split` steps, export the state in the tail-queue
+// layout, rebuild the march from the camera-independent inputs + that state (what k_tail_trace_diff does) and finish.
+void hh_trace_resumed(const float *data, int rx, int ry, int rz, const dsdf_params *prm, const float *ro, const float *rd,
+                      const float *maxt, long n, int split, float *its_t, float *warp_t, float *warp_t_d, float *ww,
+                      float *ww_d, int *steps) {
+    std::vector<float> p = pad(data, rx, ry, rz);
+    GridView G = make_view(p.data(), rx, ry, rz, *prm);
+    for (long r = 0; r < n; ++r) {
+        V3 o = mk(ro[3 * r], ro[3 * r + 1], ro[3 * r + 2]), d = mk(rd[3 * r], rd[3 * r + 1], rd[3 * r + 2]);
+        DiffMarch m = diff_march_begin(*prm, o, d, maxt[r]);
+        auto step = [&](DiffMarch &mm) {
+            V3 x = fma3(mm.t, mm.d, mm.o);
+            float v; V3 g; float H[6];
+            eval_cubic<2>(G, x, v, g, H);
+            diff_march_step(*prm, mm, x, v, g, H);
+        };
+        for (int k = 0; k < split && m.active; ++k) step(m);
+        if (m.active) {
+            float e[21] = {m.t, m.warp_t, m.prev_sd, m.wsum, m.ews, m.t_d.x, m.t_d.y, m.t_d.z, m.prev_gc.x, m.prev_gc.y, m.prev_gc.z,
+                           m.mixed.x, m.mixed.y, m.mixed.z, m.wdsum.x, m.wdsum.y, m.wdsum.z, m.ews_d.x, m.ews_d.y, m.ews_d.z, 0.f};
+            int steps_so_far = m.i;
+            DiffMarch m2 = diff_march_begin(*prm, o, d, maxt[r]);
+            m2.t = e[0]; m2.warp_t = e[1]; m2.prev_sd = e[2]; m2.wsum = e[3]; m2.ews = e[4];
+            m2.t_d = mk(e[5], e[6], e[7]); m2.prev_gc = mk(e[8], e[9], e[10]); m2.mixed = mk(e[11], e[12], e[13]);
+            m2.wdsum = mk(e[14], e[15], e[16]); m2.ews_d = mk(e[17], e[18], e[19]);
+            m2.i = steps_so_far;
+            m = m2;
+            while (m.active) step(m);
+        }
+        TraceOut t;
+        DirectFetch F;
+        t.its_t = refine_hit(G, *prm, m.o, m.d, m.its_t, m.trace_eps, t.refine_steps, F);
+        diff_march_finish(m, t);
+        its_t[r] = t.its_t; warp_t[r] = t.warp_t; ww[r] = t.warp_weight; steps[r] = t.steps;
+        warp_t_d[3 * r] = t.warp_t_d.x; warp_t_d[3 * r + 1] = t.warp_t_d.y; warp_t_d[3 * r + 2] = t.warp_t_d.z;
+        ww_d[3 * r] = t.warp_weight_d.x; ww_d[3 * r + 1] = t.warp_weight_d.y; ww_d[3 * r + 2] = t.warp_weight_d.z;
     }
 }
 

@@ -175,3 +175,34 @@ def test_reuse_fetch_is_bit_identical(harness):
         for k in a:
             assert np.array_equal(a[k], b[k], equal_nan=True), (base_mode, k)
     assert hit.sum() > 50 and prim["steps"].max() > 10
+
+
+def test_resumable_diff_march_is_bit_identical(harness):
+    """DiffMarch (begin / step / finish), the form a tail wave resumes, against the closed loop of trace_diff."""
+    case = make_case('blob48_rect')
+    cam = O.Camera(case['origin'])
+    torch.manual_seed(2)
+    pos = torch.rand(6000, 2, dtype=torch.float64) * torch.tensor([case['W'], case['H']], dtype=torch.float64)
+    o, d, maxt = cam.sample_ray(pos, case['W'], case['H'])
+    g = case['grid'].float().numpy()
+    a = harness.trace(g, o.float().numpy(), d.float().numpy(), maxt.float().numpy(), diff=1)
+    b = harness.trace(g, o.float().numpy(), d.float().numpy(), maxt.float().numpy(), diff=4)
+    for k in a:
+        assert np.array_equal(a[k], b[k], equal_nan=True), k
+
+
+@pytest.mark.parametrize('split', [1, 3, 8, 20])
+def test_handed_off_march_resumes_bit_identically(harness, split):
+    """Tail hand-off: a differentiable march stopped after `split` steps, exported in the tail-queue layout and
+    resumed from a freshly begun march equals the uninterrupted one bit for bit (no piece of state is lost)."""
+    case = make_case('blob48_rect')
+    cam = O.Camera(case['origin'])
+    torch.manual_seed(6)
+    pos = torch.rand(5000, 2, dtype=torch.float64) * torch.tensor([case['W'], case['H']], dtype=torch.float64)
+    o, d, maxt = cam.sample_ray(pos, case['W'], case['H'])
+    g = case['grid'].float().numpy()
+    a = harness.trace(g, o.float().numpy(), d.float().numpy(), maxt.float().numpy(), diff=1)
+    b = harness.trace_resumed(g, o.float().numpy(), d.float().numpy(), maxt.float().numpy(), split)
+    for k in a:
+        assert np.array_equal(a[k], b[k], equal_nan=True), k
+    assert (a['steps'] > split).sum() > 100
