@@ -1,5 +1,5 @@
-"""ctypes view of oracle/_build/libdsdf_oracle.so (plain-C restatement).  TEST INFRASTRUCTURE
-ONLY: imported by tests/ and bench.py's cpu_baseline leg, never by the product."""
+"""ctypes view of oracle/_build/libdsdf_oracle{,64}.so (plain-C restatement, fp32 or fp64 build).  TEST
+INFRASTRUCTURE ONLY: imported by tests/ and bench.py's cpu_baseline leg, never by the product."""
 import ctypes as C
 import os
 import subprocess
@@ -8,15 +8,25 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB = os.path.join(HERE, '_build', 'libdsdf_oracle.so')
+LIB64 = os.path.join(HERE, '_build', 'libdsdf_oracle64.so')
 
 
-def load():
+def load(double=False):
+    """fp32 build (the reference's arithmetic type; the timed CPU baseline) or, with double=True, the fp64 build of
+    the same statements (checker at config sizes / yardstick of the fp32 noise floor)."""
+    path = LIB64 if double else LIB
     src = os.path.join(HERE, 'dsdf_oracle.c')
-    if not os.path.isfile(LIB) or os.path.getmtime(LIB) < os.path.getmtime(src):
+    if not os.path.isfile(path) or os.path.getmtime(path) < os.path.getmtime(src):
         subprocess.check_call(['make', '-C', HERE])
-    lib = C.CDLL(LIB)
+    lib = C.CDLL(path)
     lib.o_num_threads.restype = C.c_int
+    lib.o_real_bytes.restype = C.c_int
+    assert lib.o_real_bytes() == (8 if double else 4)
     return lib
+
+
+def _dt(lib):
+    return np.float64 if lib.o_real_bytes() == 8 else np.float32
 
 
 def _p(a):
@@ -24,9 +34,9 @@ def _p(a):
 
 
 def render(lib, grid, cam16, W, H, spp, offsets, integrator):
-    grid = np.ascontiguousarray(grid, np.float32); offsets = np.ascontiguousarray(offsets, np.float32)
-    cam16 = np.ascontiguousarray(cam16, np.float32)
-    img = np.zeros((H, W, 3), np.float32)
+    grid = np.ascontiguousarray(grid, _dt(lib)); offsets = np.ascontiguousarray(offsets, _dt(lib))
+    cam16 = np.ascontiguousarray(cam16, _dt(lib))
+    img = np.zeros((H, W, 3), _dt(lib))
     stats = np.zeros(8, np.int64)
     rz, ry, rx = grid.shape
     lib.o_render(_p(grid), rx, ry, rz, _p(cam16), W, H, spp, _p(offsets), integrator, _p(img), _p(stats))
@@ -34,10 +44,10 @@ def render(lib, grid, cam16, W, H, spp, offsets, integrator):
 
 
 def render_backward(lib, grid, cam16, W, H, spp, offsets, grad_image, integrator, reparam=True):
-    grid = np.ascontiguousarray(grid, np.float32); offsets = np.ascontiguousarray(offsets, np.float32)
-    cam16 = np.ascontiguousarray(cam16, np.float32); gi = np.ascontiguousarray(grad_image, np.float32)
-    gg = np.zeros(grid.shape, np.float32)
-    img = np.zeros((H, W, 3), np.float32)
+    grid = np.ascontiguousarray(grid, _dt(lib)); offsets = np.ascontiguousarray(offsets, _dt(lib))
+    cam16 = np.ascontiguousarray(cam16, _dt(lib)); gi = np.ascontiguousarray(grad_image, _dt(lib))
+    gg = np.zeros(grid.shape, _dt(lib))
+    img = np.zeros((H, W, 3), _dt(lib))
     rz, ry, rx = grid.shape
     lib.o_render_backward(_p(grid), rx, ry, rz, _p(cam16), W, H, spp, _p(offsets), integrator, int(reparam), _p(gi),
                           _p(gg), _p(img))
@@ -45,10 +55,10 @@ def render_backward(lib, grid, cam16, W, H, spp, offsets, grad_image, integrator
 
 
 def render_direct(lib, grid, cam16, W, H, spp, offsets, emitter_u, albedo, env=(1.0, 1.0, 1.0), hide_emitters=False):
-    grid = np.ascontiguousarray(grid, np.float32); offsets = np.ascontiguousarray(offsets, np.float32)
-    cam16 = np.ascontiguousarray(cam16, np.float32); emitter_u = np.ascontiguousarray(emitter_u, np.float32)
-    albedo = np.ascontiguousarray(albedo, np.float32); env = np.asarray(env, np.float32)
-    img = np.zeros((H, W, 3), np.float32)
+    grid = np.ascontiguousarray(grid, _dt(lib)); offsets = np.ascontiguousarray(offsets, _dt(lib))
+    cam16 = np.ascontiguousarray(cam16, _dt(lib)); emitter_u = np.ascontiguousarray(emitter_u, _dt(lib))
+    albedo = np.ascontiguousarray(albedo, _dt(lib)); env = np.asarray(env, _dt(lib))
+    img = np.zeros((H, W, 3), _dt(lib))
     rz, ry, rx = grid.shape
     az, ay, ax = albedo.shape[:3]
     lib.o_render_direct(_p(grid), rx, ry, rz, _p(cam16), W, H, spp, _p(offsets), _p(emitter_u), _p(albedo), ax, ay, az,
@@ -58,12 +68,12 @@ def render_direct(lib, grid, cam16, W, H, spp, offsets, emitter_u, albedo, env=(
 
 def render_direct_backward(lib, grid, cam16, W, H, spp, offsets, emitter_u, albedo, grad_image, env=(1.0, 1.0, 1.0),
                            hide_emitters=False, reparam=True):
-    grid = np.ascontiguousarray(grid, np.float32); offsets = np.ascontiguousarray(offsets, np.float32)
-    cam16 = np.ascontiguousarray(cam16, np.float32); emitter_u = np.ascontiguousarray(emitter_u, np.float32)
-    albedo = np.ascontiguousarray(albedo, np.float32); env = np.asarray(env, np.float32)
-    gi = np.ascontiguousarray(grad_image, np.float32)
-    gg = np.zeros(grid.shape, np.float32); ga = np.zeros(albedo.shape, np.float32)
-    img = np.zeros((H, W, 3), np.float32)
+    grid = np.ascontiguousarray(grid, _dt(lib)); offsets = np.ascontiguousarray(offsets, _dt(lib))
+    cam16 = np.ascontiguousarray(cam16, _dt(lib)); emitter_u = np.ascontiguousarray(emitter_u, _dt(lib))
+    albedo = np.ascontiguousarray(albedo, _dt(lib)); env = np.asarray(env, _dt(lib))
+    gi = np.ascontiguousarray(grad_image, _dt(lib))
+    gg = np.zeros(grid.shape, _dt(lib)); ga = np.zeros(albedo.shape, _dt(lib))
+    img = np.zeros((H, W, 3), _dt(lib))
     rz, ry, rx = grid.shape
     az, ay, ax = albedo.shape[:3]
     lib.o_render_direct_backward(_p(grid), rx, ry, rz, _p(cam16), W, H, spp, _p(offsets), _p(emitter_u), _p(albedo), ax, ay, az,
@@ -72,8 +82,36 @@ def render_direct_backward(lib, grid, cam16, W, H, spp, offsets, emitter_u, albe
 
 
 def redistance(lib, phi):
-    phi = np.ascontiguousarray(phi, np.float32)
+    phi = np.ascontiguousarray(phi, _dt(lib))
     out = np.zeros_like(phi)
     rz, ry, rx = phi.shape
     lib.o_redistance(_p(phi), rx, ry, rz, _p(out))
     return out
+
+
+def eval_cubic(lib, grid, pts):
+    grid = np.ascontiguousarray(grid, _dt(lib)); pts = np.ascontiguousarray(pts, _dt(lib))
+    n = pts.shape[0]
+    v = np.zeros(n, _dt(lib)); g = np.zeros((n, 3), _dt(lib)); H = np.zeros((n, 6), _dt(lib))
+    rz, ry, rx = grid.shape
+    lib.o_eval_cubic(_p(grid), rx, ry, rz, _p(pts), C.c_long(n), _p(v), _p(g), _p(H))
+    return v, g, H
+
+
+def trace(lib, grid, o, d, maxt, diff=True):
+    dt = _dt(lib)
+    grid = np.ascontiguousarray(grid, dt); o = np.ascontiguousarray(o, dt); d = np.ascontiguousarray(d, dt)
+    maxt = np.ascontiguousarray(maxt, dt)
+    n = o.shape[0]
+    out = dict(its_t=np.zeros(n, dt), warp_t=np.zeros(n, dt), warp_t_d=np.zeros((n, 3), dt), warp_weight=np.zeros(n, dt),
+               warp_weight_d=np.zeros((n, 3), dt), steps=np.zeros(n, np.int32))
+    rz, ry, rx = grid.shape
+    lib.o_trace(_p(grid), rx, ry, rz, _p(o), _p(d), _p(maxt), C.c_long(n), int(diff), _p(out['its_t']), _p(out['warp_t']),
+                _p(out['warp_t_d']), _p(out['warp_weight']), _p(out['warp_weight_d']), _p(out['steps']))
+    return out
+
+
+def cam16(origin, left, up, direction, fov_deg):
+    """The 16-float camera record of the C oracle: origin, left, up, dir, tan(fov/2), 3 pads."""
+    import math
+    return np.concatenate([origin, left, up, direction, [math.tan(math.radians(fov_deg) * 0.5), 0, 0, 0]]).astype(np.float64)

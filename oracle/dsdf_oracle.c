@@ -1,7 +1,7 @@
 /*
  * dsdf_oracle.c -- CPU ORACLE, TEST INFRASTRUCTURE ONLY (never linked by the product).
  *
- * Independent plain-C (C99 + OpenMP, fp32 like the reference's llvm_ad_rgb variant)
+ * Independent plain-C (C99 + OpenMP; `real` = fp32 like the reference's llvm_ad_rgb variant, or fp64 with -DO_DOUBLE)
  * restatement of the reference's hot path: tricubic B-spline SDF lookups, (differentiable)
  * sphere tracing, WarpField2D, the silhouette / simple-shading / direct integrators, Gaussian film
  * splat + develop, and the backward pass.  Citations are file:line relative to the
@@ -20,6 +20,26 @@
 #include <stdlib.h>
 #include <string.h>
 
+/* Arithmetic type of the whole restatement.  Default: fp32, like the reference's llvm_ad_rgb variant (and the
+ * timed CPU baseline).  -DO_DOUBLE builds the SAME statements in fp64 (libdsdf_oracle64.so): the high-precision
+ * checker used at BASELINE.json config sizes, where the torch oracle is too slow, and the yardstick for the
+ * fp32 noise floor of the gradient estimator (fp32 build vs fp64 build on identical inputs).  Every exported
+ * pointer argument is an array of `real`.  (Constants keep their fp32 values in both builds.) */
+#ifdef O_DOUBLE
+typedef double real;
+#define fminf fmin
+#define fmaxf fmax
+#define fabsf fabs
+#define sqrtf sqrt
+#define floorf floor
+#define ceilf ceil
+#define expf exp
+#define cosf cos
+#define sinf sin
+#else
+typedef float real;
+#endif
+
 #define TRACE_EPS 1e-6f       /* shapes.py:31 */
 #define EXTRA_THRESH 0.05f    /* shapes.py:35 */
 #define SIL_OFFSET 0.05f      /* shapes.py:36 */
@@ -32,30 +52,31 @@
 #define BORDER 2
 #define FRADIUS 2.0f
 
-typedef struct { const float *d; int rx, ry, rz; } grid_t;
-typedef struct { float its_t, warp_t, wtd[3], ww, wwd[3]; int steps, refine; } trace_t;
+typedef struct { const real *d; int rx, ry, rz; } grid_t;
+typedef struct { real its_t, warp_t, wtd[3], ww, wwd[3]; int steps, refine; } trace_t;
 
-static float sgn(float x) { return x >= 0.f ? 1.f : -1.f; }          /* dr.sign */
-static float dot3(const float *a, const float *b) { return a[0]*b[0] + a[1]*b[1] + a[2]*b[2]; }
+static real sgn(real x) { return x >= 0.f ? 1.f : -1.f; }          /* dr.sign */
+static real dot3(const real *a, const real *b) { return a[0]*b[0] + a[1]*b[1] + a[2]*b[2]; }
 static int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
 /* ---- Dr.Jit Texture3f cubic B-spline (shapes.py:420-450) ---------------------------- */
-static void bsw(float a, float *w, float *dw, float *ddw) {
-    float a2 = a*a, a3 = a2*a;
+static void bsw(real a, real *w, real *dw, real *ddw) {
+    real a2 = a*a, a3 = a2*a;
     w[0] = (-a3 + 3*a2 - 3*a + 1)/6.f; w[1] = (3*a3 - 6*a2 + 4)/6.f;
     w[2] = (-3*a3 + 3*a2 + 3*a + 1)/6.f; w[3] = a3/6.f;
     dw[0] = (-3*a2 + 6*a - 3)/6.f; dw[1] = (9*a2 - 12*a)/6.f; dw[2] = (-9*a2 + 6*a + 3)/6.f; dw[3] = 3*a2/6.f;
     ddw[0] = 1 - a; ddw[1] = 3*a - 2; ddw[2] = 1 - 3*a; ddw[3] = a;
 }
 
-typedef struct { int ix[4], iy[4], iz[4]; float w[3][4], dw[3][4], ddw[3][4]; } taps_t;
+typedef struct { int ix[4], iy[4], iz[4]; real w[3][4], dw[3][4], ddw[3][4]; } taps_t;
 
-static void taps_setup(const grid_t *G, const float *p, taps_t *T) {
-    float res[3] = { (float)G->rx, (float)G->ry, (float)G->rz };
+static void taps_setup(const grid_t *G, const real *p, taps_t *T) {
+    real res[3] = { (real)G->rx, (real)G->ry, (real)G->rz };
     int base[3];
     for (int a = 0; a < 3; ++a) {
-        float pf = p[a]*res[a] - 0.5f, fl = floorf(pf);
-        if (!(fl > -1e6f)) fl = -1e6f; if (!(fl < 1e6f)) fl = 1e6f;
+        real pf = p[a]*res[a] - 0.5f, fl = floorf(pf);
+        if (!(fl > -1e6f)) fl = -1e6f;
+        if (!(fl < 1e6f)) fl = 1e6f;
         base[a] = (int)fl - 1;
         bsw(pf - floorf(pf), T->w[a], T->dw[a], T->ddw[a]);
     }
@@ -67,14 +88,14 @@ static void taps_setup(const grid_t *G, const float *p, taps_t *T) {
 }
 
 /* order 0: v; 1: v,g; 2: v,g,H (xx,yy,zz,xy,xz,yz) */
-static void eval_cubic(const grid_t *G, const float *p, int order, float *v, float *g, float *H) {
+static void eval_cubic(const grid_t *G, const real *p, int order, real *v, real *g, real *H) {
     taps_t T; taps_setup(G, p, &T);
-    float acc[10] = {0};
+    real acc[10] = {0};
     for (int k = 0; k < 4; ++k) for (int j = 0; j < 4; ++j) {
-        const float *row = G->d + ((size_t)T.iz[k]*G->ry + T.iy[j])*G->rx;
+        const real *row = G->d + ((size_t)T.iz[k]*G->ry + T.iy[j])*G->rx;
         for (int i = 0; i < 4; ++i) {
-            float D = row[T.ix[i]];
-            float wx = T.w[0][i], wy = T.w[1][j], wz = T.w[2][k];
+            real D = row[T.ix[i]];
+            real wx = T.w[0][i], wy = T.w[1][j], wz = T.w[2][k];
             acc[0] += wz*wy*wx*D;
             if (order >= 1) {
                 acc[1] += wz*wy*T.dw[0][i]*D; acc[2] += wz*T.dw[1][j]*wx*D; acc[3] += T.dw[2][k]*wy*wx*D;
@@ -85,43 +106,43 @@ static void eval_cubic(const grid_t *G, const float *p, int order, float *v, flo
             }
         }
     }
-    float X = (float)G->rx, Y = (float)G->ry, Z = (float)G->rz;
+    real X = (real)G->rx, Y = (real)G->ry, Z = (real)G->rz;
     *v = acc[0];
     if (order >= 1) { g[0] = acc[1]*X; g[1] = acc[2]*Y; g[2] = acc[3]*Z; }
     if (order >= 2) { H[0] = acc[4]*X*X; H[1] = acc[5]*Y*Y; H[2] = acc[6]*Z*Z; H[3] = acc[7]*X*Y; H[4] = acc[8]*X*Z; H[5] = acc[9]*Y*Z; }
 }
 
 /* adjoint of eval_cubic w.r.t. the grid: grad[tap] += cv*W + cg.(res*dW) */
-static void scatter_cubic(const grid_t *G, float *grad, const float *p, float cv, const float *cg) {
+static void scatter_cubic(const grid_t *G, real *grad, const real *p, real cv, const real *cg) {
     taps_t T; taps_setup(G, p, &T);
-    float X = (float)G->rx, Y = (float)G->ry, Z = (float)G->rz;
+    real X = (real)G->rx, Y = (real)G->ry, Z = (real)G->rz;
     for (int k = 0; k < 4; ++k) for (int j = 0; j < 4; ++j) for (int i = 0; i < 4; ++i) {
-        float wx = T.w[0][i], wy = T.w[1][j], wz = T.w[2][k];
-        float c = cv*wz*wy*wx + cg[0]*X*wz*wy*T.dw[0][i] + cg[1]*Y*wz*T.dw[1][j]*wx + cg[2]*Z*T.dw[2][k]*wy*wx;
-        float *dst = grad + ((size_t)T.iz[k]*G->ry + T.iy[j])*G->rx + T.ix[i];
+        real wx = T.w[0][i], wy = T.w[1][j], wz = T.w[2][k];
+        real c = cv*wz*wy*wx + cg[0]*X*wz*wy*T.dw[0][i] + cg[1]*Y*wz*T.dw[1][j]*wx + cg[2]*Z*T.dw[2][k]*wy*wx;
+        real *dst = grad + ((size_t)T.iz[k]*G->ry + T.iy[j])*G->rx + T.ix[i];
 #pragma omp atomic
         *dst += c;
     }
 }
 
-static void symmul(const float *H, const float *a, float *o) {
+static void symmul(const real *H, const real *a, real *o) {
     o[0] = H[0]*a[0] + H[3]*a[1] + H[4]*a[2];
     o[1] = H[3]*a[0] + H[1]*a[1] + H[5]*a[2];
     o[2] = H[4]*a[0] + H[5]*a[1] + H[2]*a[2];
 }
 
 /* ---- bbox helpers (math_util.py:31-41; Mitsuba BoundingBox3f) ------------------------ */
-static void closest_axis(const float *m, float *n) {
+static void closest_axis(const real *m, real *n) {
     n[0] = (m[0] < m[1] && m[0] < m[2]) ? 1.f : 0.f;
     n[1] = (m[1] < m[2] && m[1] < m[0]) ? 1.f : 0.f;
     n[2] = (m[2] < m[0] && m[2] < m[1]) ? 1.f : 0.f;
 }
 
-static float bbox_dist_d(const float *x, float *dd) {
-    const float lo = -BBOX_DELTA, hi = 1.f + BBOX_DELTA;
-    float mlo = fminf(fminf(x[0]-lo, x[1]-lo), x[2]-lo), mhi = fminf(fminf(hi-x[0], hi-x[1]), hi-x[2]);
-    float dist = fmaxf(0.f, fminf(mlo, mhi));
-    float m[3], n[3], dmax[3], dmin[3];
+static real bbox_dist_d(const real *x, real *dd) {
+    const real lo = -BBOX_DELTA, hi = 1.f + BBOX_DELTA;
+    real mlo = fminf(fminf(x[0]-lo, x[1]-lo), x[2]-lo), mhi = fminf(fminf(hi-x[0], hi-x[1]), hi-x[2]);
+    real dist = fmaxf(0.f, fminf(mlo, mhi));
+    real m[3], n[3], dmax[3], dmin[3];
     for (int a = 0; a < 3; ++a) { dmax[a] = fabsf(hi - x[a]); dmin[a] = fabsf(lo - x[a]); m[a] = fminf(dmin[a], dmax[a]); }
     closest_axis(m, n);
     for (int a = 0; a < 3; ++a) dd[a] = dist > 0.f ? n[a]*sgn(dmax[a] - dmin[a]) : 0.f;
@@ -129,75 +150,75 @@ static float bbox_dist_d(const float *x, float *dd) {
 }
 
 /* ---- SDFBase.eval_trace_weight (shapes.py:68-113) ------------------------------------- */
-static float trace_weight(const float *d, int i, const float *x, float v, const float *g, const float *H, float *wd) {
-    float ndd = dot3(g, d), ndn = dot3(g, g), ratio = ndd/ndn;
-    float denom = SIL_EPS + fabsf(v) + SIL_OFFSET*ndd*ratio;
-    float dw = 1.f/(denom*denom*denom);
-    float bdd[3]; float bd = bbox_dist_d(x, bdd);
-    float bw = i > 0 ? fminf(bd, 0.01f)/0.01f : 1.f;
-    float gr[3], Hg[3];
+static real trace_weight(const real *d, int i, const real *x, real v, const real *g, const real *H, real *wd) {
+    real ndd = dot3(g, d), ndn = dot3(g, g), ratio = ndd/ndn;
+    real denom = SIL_EPS + fabsf(v) + SIL_OFFSET*ndd*ratio;
+    real dw = 1.f/(denom*denom*denom);
+    real bdd[3]; real bd = bbox_dist_d(x, bdd);
+    real bw = i > 0 ? fminf(bd, 0.01f)/0.01f : 1.f;
+    real gr[3], Hg[3];
     for (int a = 0; a < 3; ++a) gr[a] = 2.f*ratio*(d[a] - ratio*g[a]);
     symmul(H, gr, Hg);
     for (int a = 0; a < 3; ++a) {
-        float bwd = (i > 0 && bd < 0.01f) ? bdd[a]/0.01f : 0.f;
-        float dend = sgn(v)*g[a] + SIL_OFFSET*Hg[a];
+        real bwd = (i > 0 && bd < 0.01f) ? bdd[a]/0.01f : 0.f;
+        real dend = sgn(v)*g[a] + SIL_OFFSET*Hg[a];
         wd[a] = dw*bwd + bw*(-3.f*dw/denom)*dend;
     }
     return dw*bw;
 }
 
 /* ---- SDFBase.ray_intersect / ray_intersect_non_diff (shapes.py:115-339) ---------------- */
-static void trace(const grid_t *G, const float *o, const float *din, float ray_maxt, int diff, trace_t *out) {
-    const float lo = -BBOX_DELTA, hi = 1.f + BBOX_DELTA;
-    float inv = 1.f/sqrtf(dot3(din, din)), d[3] = { din[0]*inv, din[1]*inv, din[2]*inv };
-    float mint = -INFINITY, maxtb = INFINITY; int ok = 1, inside = 1;
+static void trace(const grid_t *G, const real *o, const real *din, real ray_maxt, int diff, trace_t *out) {
+    const real lo = -BBOX_DELTA, hi = 1.f + BBOX_DELTA;
+    real inv = 1.f/sqrtf(dot3(din, din)), d[3] = { din[0]*inv, din[1]*inv, din[2]*inv };
+    real mint = -INFINITY, maxtb = INFINITY; int ok = 1, inside = 1;
     for (int a = 0; a < 3; ++a) {
         if (!(d[a] != 0.f || o[a] > lo || o[a] < hi)) ok = 0;
-        float r = 1.f/d[a], t1 = (lo - o[a])*r, t2 = (hi - o[a])*r;
+        real r = 1.f/d[a], t1 = (lo - o[a])*r, t2 = (hi - o[a])*r;
         mint = fmaxf(mint, fminf(t1, t2)); maxtb = fminf(maxtb, fmaxf(t1, t2));
         if (!(o[a] >= lo && o[a] <= hi)) inside = 0;
     }
     int hit_box = ok && maxtb >= mint && (mint > 0.f || inside);
     int active = hit_box;
-    float maxt = fminf(maxtb, ray_maxt), eps = TRACE_EPS*fmaxf(maxt, 1.f);
-    float its_t = INFINITY, t = inside ? 0.f : mint + 1e-5f;
-    float warp_t = 0, prev_sd = 0, wsum = 0, ews = 0;
-    float prev_gc[3] = {0}, mixed[3] = {0}, wdsum[3] = {0}, ews_d[3] = {0}, t_d[3] = {0};
+    real maxt = fminf(maxtb, ray_maxt), eps = TRACE_EPS*fmaxf(maxt, 1.f);
+    real its_t = INFINITY, t = inside ? 0.f : mint + 1e-5f;
+    real warp_t = 0, prev_sd = 0, wsum = 0, ews = 0;
+    real prev_gc[3] = {0}, mixed[3] = {0}, wdsum[3] = {0}, ews_d[3] = {0}, t_d[3] = {0};
     int i = 0;
     {   /* entry-face derivative of t, shapes.py:156-164 */
-        float pb[3], m[3], n[3];
+        real pb[3], m[3], n[3];
         for (int a = 0; a < 3; ++a) { pb[a] = o[a] + t*d[a]; m[a] = fminf(fabsf(lo - pb[a]), fabsf(hi - pb[a])); }
         closest_axis(m, n);
-        float ddn = dot3(d, n);
+        real ddn = dot3(d, n);
         if (!inside && fabsf(ddn) > 0.f) for (int a = 0; a < 3; ++a) t_d[a] = -n[a]/ddn*t;
     }
     while (active) {
-        float x[3] = { o[0] + t*d[0], o[1] + t*d[1], o[2] + t*d[2] }, v, g[3], H[6];
+        real x[3] = { o[0] + t*d[0], o[1] + t*d[1], o[2] + t*d[2] }, v, g[3], H[6];
         eval_cubic(G, x, diff ? 2 : 0, &v, g, H);
         int hit = v < eps;
         if (hit) its_t = t;
-        float sd = fabsf(v), cur = hit ? 0.f : sd;
+        real sd = fabsf(v), cur = hit ? 0.f : sd;
         if (diff) {
-            float wd[3], w = trace_weight(d, i, x, v, g, H, wd);
-            float inv_den = 1.f/fminf(EXTRA_THRESH, sd), dif = prev_sd - sd;
+            real wd[3], w = trace_weight(d, i, x, v, g, H, wd);
+            real inv_den = 1.f/fminf(EXTRA_THRESH, sd), dif = prev_sd - sd;
             ews += dif >= 0.f ? dif*inv_den : 0.f;
             ews = fminf(ews, 1.f);
-            float seg = 0.5f*(cur + prev_sd), winc = seg*w*ews;
+            real seg = 0.5f*(cur + prev_sd), winc = seg*w*ews;
             wsum += winc; warp_t += winc*t;
-            float dwd = dot3(d, wd), dg = dot3(d, g), gc[3], wdc[3];
+            real dwd = dot3(d, wd), dg = dot3(d, g), gc[3], wdc[3];
             for (int a = 0; a < 3; ++a) { wdc[a] = t*wd[a] + dwd*t_d[a]; gc[a] = t*g[a] + dg*t_d[a]; }   /* convert_deriv */
             for (int a = 0; a < 3; ++a) {
-                float sdd = sgn(v)*gc[a];
-                float ewd = (prev_gc[a] - sdd)*inv_den;
+                real sdd = sgn(v)*gc[a];
+                real ewd = (prev_gc[a] - sdd)*inv_den;
                 if (v < EXTRA_THRESH) ewd -= dif*inv_den*inv_den*sdd;
                 if (dif > 0.f) ews_d[a] += ewd;
             }
             if (ews >= 1.f || ews <= 0.f) ews_d[0] = ews_d[1] = ews_d[2] = 0.f;
-            float w2 = w*ews;
+            real w2 = w*ews;
             for (int a = 0; a < 3; ++a) {
-                float wda = w*ews_d[a] + wdc[a]*ews;
-                float segd = 0.5f*(gc[a] + prev_gc[a]);
-                float wincd = w2*segd + wda*seg;
+                real wda = w*ews_d[a] + wdc[a]*ews;
+                real segd = 0.5f*(gc[a] + prev_gc[a]);
+                real wincd = w2*segd + wda*seg;
                 mixed[a] += wincd*t + w2*seg*t_d[a];
                 wdsum[a] += wincd;
             }
@@ -213,16 +234,16 @@ static void trace(const grid_t *G, const float *o, const float *din, float ray_m
     if (its_t < INFINITY) {
         int refining = 1;
         while (refining) {
-            float x[3] = { o[0] + its_t*d[0], o[1] + its_t*d[1], o[2] + its_t*d[2] }, md, g[3], H[6];
+            real x[3] = { o[0] + its_t*d[0], o[1] + its_t*d[1], o[2] + its_t*d[2] }, md, g[3], H[6];
             eval_cubic(G, x, 0, &md, g, H);
-            its_t += md*(10.f/(float)(10 + ri));
+            its_t += md*(10.f/(real)(10 + ri));
             refining = (md <= 0.f) || (md > eps);
             ++ri; refining = refining && ri < 10;
         }
     }
     out->refine = ri; out->its_t = its_t;
     if (diff) {
-        float iw = 1.f/wsum; warp_t *= iw;
+        real iw = 1.f/wsum; warp_t *= iw;
         for (int a = 0; a < 3; ++a) out->wtd[a] = (mixed[a] - warp_t*wdsum[a])*iw;
         out->ww = fminf(fmaxf(wsum, 0.f), 1.f);
         for (int a = 0; a < 3; ++a) out->wwd[a] = (wsum > 0.f && wsum < 1.f) ? wdsum[a] : 0.f;
@@ -232,54 +253,54 @@ static void trace(const grid_t *G, const float *o, const float *din, float ray_m
 }
 
 /* ---- sensor (Mitsuba perspective; cam = origin, left, up, dir, tan) -------------------- */
-typedef struct { float o[3], d[3], maxt; } ray_t;
+typedef struct { real o[3], d[3], maxt; } ray_t;
 
-static void camera_ray(const float *cam, float px, float py, int W, int H, ray_t *r) {
-    float aspect = (float)W/(float)H, tn = cam[12];
-    float dl[3] = { (1.f - 2.f*px/(float)W)*tn, (1.f - 2.f*py/(float)H)*tn/aspect, 1.f };
-    float inv = 1.f/sqrtf(dot3(dl, dl)); dl[0] *= inv; dl[1] *= inv; dl[2] *= inv;
+static void camera_ray(const real *cam, real px, real py, int W, int H, ray_t *r) {
+    real aspect = (real)W/(real)H, tn = cam[12];
+    real dl[3] = { (1.f - 2.f*px/(real)W)*tn, (1.f - 2.f*py/(real)H)*tn/aspect, 1.f };
+    real inv = 1.f/sqrtf(dot3(dl, dl)); dl[0] *= inv; dl[1] *= inv; dl[2] *= inv;
     for (int a = 0; a < 3; ++a) r->d[a] = cam[3+a]*dl[0] + cam[6+a]*dl[1] + cam[9+a]*dl[2];
-    float nt = NEAR_CLIP/dl[2];
+    real nt = NEAR_CLIP/dl[2];
     for (int a = 0; a < 3; ++a) r->o[a] = cam[a] + nt*r->d[a];
     r->maxt = FAR_CLIP/dl[2] - nt;
 }
 
 /* sensor.sample_direction(o + d'): uv (pixels), ref point, inside flag */
-static int reproject(const float *cam, const float *p, int W, int H, float *uv, float *ref) {
-    float q[3] = { p[0]-cam[0], p[1]-cam[1], p[2]-cam[2] };
+static int reproject(const real *cam, const real *p, int W, int H, real *uv, real *ref) {
+    real q[3] = { p[0]-cam[0], p[1]-cam[1], p[2]-cam[2] };
     ref[0] = dot3(cam+3, q); ref[1] = dot3(cam+6, q); ref[2] = dot3(cam+9, q);
-    float aspect = (float)W/(float)H, cot = 1.f/cam[12];
-    float sx = 0.5f - 0.5f*cot*ref[0]/ref[2], sy = 0.5f - 0.5f*aspect*cot*ref[1]/ref[2];
-    uv[0] = sx*(float)W; uv[1] = sy*(float)H;
+    real aspect = (real)W/(real)H, cot = 1.f/cam[12];
+    real sx = 0.5f - 0.5f*cot*ref[0]/ref[2], sy = 0.5f - 0.5f*aspect*cot*ref[1]/ref[2];
+    uv[0] = sx*(real)W; uv[1] = sy*(real)H;
     return ref[2] >= NEAR_CLIP && ref[2] <= FAR_CLIP && sx >= 0.f && sx <= 1.f && sy >= 0.f && sy <= 1.f;
 }
 
-static float gauss(float x) { return fmaxf(0.f, expf(-2.f*x*x) - expf(-8.f)); }
-static float dgauss(float x) { float e = expf(-2.f*x*x); return (e - expf(-8.f)) > 0.f ? -4.f*x*e : 0.f; }
+static real gauss(real x) { return fmaxf(0.f, expf(-2.f*x*x) - expf(-8.f)); }
+static real dgauss(real x) { real e = expf(-2.f*x*x); return (e - expf(-8.f)) > 0.f ? -4.f*x*e : 0.f; }
 
-static void lane_ray(const float *cam, int W, int H, int spp, const float *offs, long lane, ray_t *r) {
+static void lane_ray(const real *cam, int W, int H, int spp, const real *offs, long lane, ray_t *r) {
     int Wb = W + 2*BORDER;
     long pix = lane/spp; int py = (int)(pix/Wb), px = (int)(pix - (long)py*Wb);
-    camera_ray(cam, (float)(px - BORDER) + offs[2*lane], (float)(py - BORDER) + offs[2*lane+1], W, H, r);
+    camera_ray(cam, (real)(px - BORDER) + offs[2*lane], (real)(py - BORDER) + offs[2*lane+1], W, H, r);
 }
 
-static float shade(const grid_t *G, const ray_t *r, float its_t, int integ, float *gh, float *Hh) {
+static real shade(const grid_t *G, const ray_t *r, real its_t, int integ, real *gh, real *Hh) {
     if (!(its_t < INFINITY)) return 0.f;
     if (integ == 0) return 1.f;
-    float p[3] = { r->o[0] + its_t*r->d[0], r->o[1] + its_t*r->d[1], r->o[2] + its_t*r->d[2] }, v;
+    real p[3] = { r->o[0] + its_t*r->d[0], r->o[1] + its_t*r->d[1], r->o[2] + its_t*r->d[2] }, v;
     eval_cubic(G, p, 2, &v, gh, Hh);
-    float l = 0.57735026918962576f;
+    real l = 0.57735026918962576f;
     return fmaxf((gh[0] + gh[1] + gh[2])*l/sqrtf(dot3(gh, gh)), 0.f);
 }
 
-static void splat(float *block, int Wb, int Hb, const float *uv, float val) {
-    float pfx = uv[0] + BORDER - 0.5f, pfy = uv[1] + BORDER - 0.5f;
+static void splat(real *block, int Wb, int Hb, const real *uv, real val) {
+    real pfx = uv[0] + BORDER - 0.5f, pfy = uv[1] + BORDER - 0.5f;
     int x0 = (int)ceilf(pfx - FRADIUS), y0 = (int)ceilf(pfy - FRADIUS);
     for (int j = 0; j < 4; ++j) for (int i = 0; i < 4; ++i) {
         int qx = x0 + i, qy = y0 + j;
         if (qx < 0 || qx >= Wb || qy < 0 || qy >= Hb) continue;
-        float f = gauss((float)qx - pfx)*gauss((float)qy - pfy);
-        float *dst = block + 2*((size_t)qy*Wb + qx);
+        real f = gauss((real)qx - pfx)*gauss((real)qy - pfy);
+        real *dst = block + 2*((size_t)qy*Wb + qx);
 #pragma omp atomic
         dst[0] += f*val;
 #pragma omp atomic
@@ -287,30 +308,30 @@ static void splat(float *block, int Wb, int Hb, const float *uv, float val) {
     }
 }
 
-static void develop(const float *block, int W, int H, float *img) {
+static void develop(const real *block, int W, int H, real *img) {
     int Wb = W + 2*BORDER;
     for (int y = 0; y < H; ++y) for (int x = 0; x < W; ++x) {
-        const float *b = block + 2*((size_t)(y + BORDER)*Wb + x + BORDER);
-        float v = b[0]/(b[1] == 0.f ? 1.f : b[1]);
+        const real *b = block + 2*((size_t)(y + BORDER)*Wb + x + BORDER);
+        real v = b[0]/(b[1] == 0.f ? 1.f : b[1]);
         img[3*((size_t)y*W + x)] = img[3*((size_t)y*W + x) + 1] = img[3*((size_t)y*W + x) + 2] = v;
     }
 }
 
 /* ReparamIntegrator.render (reparam.py:120-185), primal: returns image, fills stats
  * {lanes, bbox lanes, steps, hits, refine steps}. */
-void o_render(const float *grid, int rx, int ry, int rz, const float *cam, int W, int H, int spp,
-              const float *offsets, int integrator, float *image, long *stats) {
+void o_render(const real *grid, int rx, int ry, int rz, const real *cam, int W, int H, int spp,
+              const real *offsets, int integrator, real *image, long *stats) {
     grid_t G = { grid, rx, ry, rz };
     int Wb = W + 2*BORDER, Hb = H + 2*BORDER;
     long n = (long)Wb*Hb*spp, s_steps = 0, s_hits = 0, s_ref = 0, s_box = 0;
-    float *block = (float *)calloc((size_t)2*Wb*Hb, sizeof(float));
+    real *block = (real *)calloc((size_t)2*Wb*Hb, sizeof(real));
 #pragma omp parallel for schedule(dynamic, 256) reduction(+:s_steps, s_hits, s_ref, s_box)
     for (long lane = 0; lane < n; ++lane) {
-        ray_t r; trace_t t; float gh[3], Hh[6], uv[2], ref[3];
+        ray_t r; trace_t t; real gh[3], Hh[6], uv[2], ref[3];
         lane_ray(cam, W, H, spp, offsets, lane, &r);
         trace(&G, r.o, r.d, r.maxt, 0, &t);
-        float val = shade(&G, &r, t.its_t, integrator, gh, Hh);
-        float p[3] = { r.o[0] + r.d[0], r.o[1] + r.d[1], r.o[2] + r.d[2] };
+        real val = shade(&G, &r, t.its_t, integrator, gh, Hh);
+        real p[3] = { r.o[0] + r.d[0], r.o[1] + r.d[1], r.o[2] + r.d[2] };
         reproject(cam, p, W, H, uv, ref);
         splat(block, Wb, Hb, uv, val);
         s_steps += t.steps; s_hits += t.its_t < INFINITY; s_ref += t.refine; s_box += t.steps > 0;
@@ -322,30 +343,30 @@ void o_render(const float *grid, int rx, int ry, int rz, const float *cam, int W
 
 /* ReparamIntegrator.render_backward (reparam.py:187-190): re-render with the
  * reparameterisation attached, back-propagate grad_image into grad_grid (accumulating). */
-void o_render_backward(const float *grid, int rx, int ry, int rz, const float *cam, int W, int H, int spp,
-                       const float *offsets, int integrator, int reparam, const float *grad_image,
-                       float *grad_grid, float *image) {
+void o_render_backward(const real *grid, int rx, int ry, int rz, const real *cam, int W, int H, int spp,
+                       const real *offsets, int integrator, int reparam, const real *grad_image,
+                       real *grad_grid, real *image) {
     grid_t G = { grid, rx, ry, rz };
     int Wb = W + 2*BORDER, Hb = H + 2*BORDER;
     long n = (long)Wb*Hb*spp;
-    float *block = (float *)calloc((size_t)2*Wb*Hb, sizeof(float));
-    float *badj = (float *)calloc((size_t)2*Wb*Hb, sizeof(float));
+    real *block = (real *)calloc((size_t)2*Wb*Hb, sizeof(real));
+    real *badj = (real *)calloc((size_t)2*Wb*Hb, sizeof(real));
     trace_t *tr = (trace_t *)malloc((size_t)n*sizeof(trace_t));
 #pragma omp parallel for schedule(dynamic, 256)
     for (long lane = 0; lane < n; ++lane) {
-        ray_t r; float gh[3], Hh[6], uv[2], ref[3];
+        ray_t r; real gh[3], Hh[6], uv[2], ref[3];
         lane_ray(cam, W, H, spp, offsets, lane, &r);
         trace(&G, r.o, r.d, r.maxt, 1, &tr[lane]);
-        float val = shade(&G, &r, tr[lane].its_t, integrator, gh, Hh);
-        float p[3] = { r.o[0] + r.d[0], r.o[1] + r.d[1], r.o[2] + r.d[2] };
+        real val = shade(&G, &r, tr[lane].its_t, integrator, gh, Hh);
+        real p[3] = { r.o[0] + r.d[0], r.o[1] + r.d[1], r.o[2] + r.d[2] };
         reproject(cam, p, W, H, uv, ref);
         splat(block, Wb, Hb, uv, val);
     }
     if (image) develop(block, W, H, image);
     for (int y = 0; y < H; ++y) for (int x = 0; x < W; ++x) {              /* adjoint of develop */
         size_t q = (size_t)(y + BORDER)*Wb + x + BORDER;
-        const float *gi = grad_image + 3*((size_t)y*W + x);
-        float gs = gi[0] + gi[1] + gi[2], w = block[2*q + 1], s = block[2*q];
+        const real *gi = grad_image + 3*((size_t)y*W + x);
+        real gs = gi[0] + gi[1] + gi[2], w = block[2*q + 1], s = block[2*q];
         badj[2*q] = w == 0.f ? gs : gs/w;
         badj[2*q + 1] = w == 0.f ? 0.f : -gs*s/(w*w);
     }
@@ -355,54 +376,54 @@ void o_render_backward(const float *grid, int rx, int ry, int rz, const float *c
         int hit = t->its_t < INFINITY;
         int warp_on = reparam && fabsf(t->warp_t) < INFINITY && t->ww > 0.f;
         if (!warp_on && !(hit && integrator == 1)) continue;
-        ray_t r; float gh[3] = {0}, Hh[6] = {0}, uv[2], ref[3];
+        ray_t r; real gh[3] = {0}, Hh[6] = {0}, uv[2], ref[3];
         lane_ray(cam, W, H, spp, offsets, lane, &r);
-        const float *o = r.o, *d = r.d;
-        float val = shade(&G, &r, t->its_t, integrator, gh, Hh);
-        float p1[3] = { o[0] + d[0], o[1] + d[1], o[2] + d[2] };
+        const real *o = r.o, *d = r.d;
+        real val = shade(&G, &r, t->its_t, integrator, gh, Hh);
+        real p1[3] = { o[0] + d[0], o[1] + d[1], o[2] + d[2] };
         int inside = reproject(cam, p1, W, H, uv, ref);
         /* film adjoint gather */
-        float pfx = uv[0] + BORDER - 0.5f, pfy = uv[1] + BORDER - 0.5f;
+        real pfx = uv[0] + BORDER - 0.5f, pfy = uv[1] + BORDER - 0.5f;
         int x0 = (int)ceilf(pfx - FRADIUS), y0 = (int)ceilf(pfy - FRADIUS);
-        float a_val = 0, a_w = 0, ub = 0, vb = 0;
+        real a_val = 0, a_w = 0, ub = 0, vb = 0;
         for (int j = 0; j < 4; ++j) for (int i = 0; i < 4; ++i) {
             int qx = x0 + i, qy = y0 + j;
             if (qx < 0 || qx >= Wb || qy < 0 || qy >= Hb) continue;
-            float rx_ = (float)qx - pfx, ry_ = (float)qy - pfy, fx = gauss(rx_), fy = gauss(ry_);
-            const float *ba = badj + 2*((size_t)qy*Wb + qx);
+            real rx_ = (real)qx - pfx, ry_ = (real)qy - pfy, fx = gauss(rx_), fy = gauss(ry_);
+            const real *ba = badj + 2*((size_t)qy*Wb + qx);
             a_val += fx*fy*ba[0]; a_w += fx*fy*ba[1];
-            float s = ba[0]*val + ba[1];
+            real s = ba[0]*val + ba[1];
             ub += s*(-dgauss(rx_)*fy); vb += s*(-fx*dgauss(ry_));
         }
-        float div_bar = val*a_val + a_w, rw_bar = inside ? div_bar : 0.f;
+        real div_bar = val*a_val + a_w, rw_bar = inside ? div_bar : 0.f;
         /* adjoint of the warped direction through uv and log importance (reparam.py:99-105) */
-        float cot = 1.f/cam[12], iz = 1.f/ref[2], ku = -0.5f*(float)W*cot;
-        float dist2 = dot3(ref, ref);
-        float rb[3] = { ub*ku*iz + rw_bar*ref[0]/dist2, vb*ku*iz + rw_bar*ref[1]/dist2,
+        real cot = 1.f/cam[12], iz = 1.f/ref[2], ku = -0.5f*(real)W*cot;
+        real dist2 = dot3(ref, ref);
+        real rb[3] = { ub*ku*iz + rw_bar*ref[0]/dist2, vb*ku*iz + rw_bar*ref[1]/dist2,
                         -(ub*ku*ref[0] + vb*ku*ref[1])*iz*iz + rw_bar*(ref[2]/dist2 - 3.f*iz) };
-        float dir_bar[3];
+        real dir_bar[3];
         for (int a = 0; a < 3; ++a) dir_bar[a] = cam[3+a]*rb[0] + cam[6+a]*rb[1] + cam[9+a]*rb[2];
         /* shading channel, shapes.py:347-366 */
         if (hit && integrator == 1) {
-            float g2 = dot3(gh, gh), gl = sqrtf(g2), l = 0.57735026918962576f, n[3] = { gh[0]/gl, gh[1]/gl, gh[2]/gl };
-            float ndl = (n[0] + n[1] + n[2])*l, s_bar = ndl > 0.f ? a_val : 0.f;
-            float Gb[3], pb[3];
+            real g2 = dot3(gh, gh), gl = sqrtf(g2), l = 0.57735026918962576f, n[3] = { gh[0]/gl, gh[1]/gl, gh[2]/gl };
+            real ndl = (n[0] + n[1] + n[2])*l, s_bar = ndl > 0.f ? a_val : 0.f;
+            real Gb[3], pb[3];
             for (int a = 0; a < 3; ++a) Gb[a] = s_bar/gl*(l - ndl*n[a]);
             symmul(Hh, Gb, pb);
-            float c = -dot3(gh, d), v0 = dot3(pb, d)/c;
+            real c = -dot3(gh, d), v0 = dot3(pb, d)/c;
             for (int a = 0; a < 3; ++a) dir_bar[a] += t->its_t*pb[a] + v0*t->its_t*gh[a];
-            float ph[3] = { o[0] + t->its_t*d[0], o[1] + t->its_t*d[1], o[2] + t->its_t*d[2] };
+            real ph[3] = { o[0] + t->its_t*d[0], o[1] + t->its_t*d[1], o[2] + t->its_t*d[2] };
             scatter_cubic(&G, grad_grid, ph, v0, Gb);
         }
         /* warp channel, warp.py:47-96 */
         if (warp_on) {
-            float tt = t->warp_t, x[3] = { o[0] + tt*d[0], o[1] + tt*d[1], o[2] + tt*d[2] }, v, g[3], Hm[6];
+            real tt = t->warp_t, x[3] = { o[0] + tt*d[0], o[1] + tt*d[1], o[2] + tt*d[2] }, v, g[3], Hm[6];
             eval_cubic(&G, x, 2, &v, g, Hm);
-            float g2 = dot3(g, g), n_[3] = { g[0]/g2, g[1]/g2, g[2]/g2 };
-            float bdd[3], bd = bbox_dist_d(x, bdd), ee = EDGE_EPS*tt;
+            real g2 = dot3(g, g), n_[3] = { g[0]/g2, g[1]/g2, g[2]/g2 };
+            real bdd[3], bd = bbox_dist_d(x, bdd), ee = EDGE_EPS*tt;
             int use_eps = ee <= bd;
-            float eps = fminf(ee, bd), ie = 1.f/eps, sd = fabsf(v), fac = 1.f - sd*ie, w = fmaxf(fac, 0.f);
-            float wd[3] = {0}, eps_d = 0.f;
+            real eps = fminf(ee, bd), ie = 1.f/eps, sd = fabsf(v), fac = 1.f - sd*ie, w = fmaxf(fac, 0.f);
+            real wd[3] = {0}, eps_d = 0.f;
             if (fac >= 0.f) {
                 for (int a = 0; a < 3; ++a) wd[a] = -sgn(v)*g[a]*ie + sd*ie*ie*(use_eps ? 0.f : bdd[a]);
                 if (use_eps) eps_d = sd*ie*ie;
@@ -410,16 +431,16 @@ void o_render_backward(const float *grid, int rx, int ry, int rz, const float *c
             for (int a = 0; a < 3; ++a) wd[a] = t->ww*(wd[a] + eps_d*EDGE_EPS*d[a]) + w*t->wwd[a];
             w *= t->ww;
             if (w > 0.f) {
-                float q[3] = { t->wtd[0]/tt, t->wtd[1]/tt, t->wtd[2]/tt };
-                float dn = dot3(d, n_), dq = dot3(d, q), Pn[3], Pq[3], An[3], Hd[3], Hg[3];
+                real q[3] = { t->wtd[0]/tt, t->wtd[1]/tt, t->wtd[2]/tt };
+                real dn = dot3(d, n_), dq = dot3(d, q), Pn[3], Pq[3], An[3], Hd[3], Hg[3];
                 for (int a = 0; a < 3; ++a) { Pn[a] = n_[a] - dn*d[a]; Pq[a] = q[a] - dq*d[a]; }
-                float pqn = dot3(Pq, n_);
+                real pqn = dot3(Pq, n_);
                 for (int a = 0; a < 3; ++a) An[a] = Pn[a] + pqn*d[a];
                 symmul(Hm, d, Hd); symmul(Hm, g, Hg);
-                float trH = Hm[0] + Hm[1] + Hm[2], dHd = dot3(d, Hd), gHg = dot3(g, Hg), gHd = dot3(g, Hd), dg = dot3(d, g);
-                float trJHA = (trH - dHd)/g2 - 2.f*(gHg - dg*gHd)/(g2*g2) + dot3(Pq, Hd)/g2 - 2.f*dot3(Pq, g)*gHd/(g2*g2);
-                float a_ = -(dot3(wd, Pn) + dot3(wd, d)*pqn) - w*trJHA;
-                float T = fmaxf(CLAMP_THRESH, tt), vbar = a_*div_bar, gbar[3];
+                real trH = Hm[0] + Hm[1] + Hm[2], dHd = dot3(d, Hd), gHg = dot3(g, Hg), gHd = dot3(g, Hd), dg = dot3(d, g);
+                real trJHA = (trH - dHd)/g2 - 2.f*(gHg - dg*gHd)/(g2*g2) + dot3(Pq, Hd)/g2 - 2.f*dot3(Pq, g)*gHd/(g2*g2);
+                real a_ = -(dot3(wd, Pn) + dot3(wd, d)*pqn) - w*trJHA;
+                real T = fmaxf(CLAMP_THRESH, tt), vbar = a_*div_bar, gbar[3];
                 for (int a = 0; a < 3; ++a) { vbar += (-w/T)*Pn[a]*dir_bar[a]; gbar[a] = -w*An[a]*div_bar; }
                 scatter_cubic(&G, grad_grid, x, vbar, gbar);
             }
@@ -437,59 +458,59 @@ void o_render_backward(const float *grid, int rx, int ry, int rz, const float *c
 #define SHADOW_EPSILON (10.f*RAY_EPSILON)
 #define ENV_DIST 4.0f
 
-typedef struct { const float *d; int rx, ry, rz; } vol3_t;     /* (Z,Y,X,3) */
+typedef struct { const real *d; int rx, ry, rz; } vol3_t;     /* (Z,Y,X,3) */
 
 /* value a[3] and spatial gradient ag[ch][3] of the trilinear lookup; `taps` (8 x {index, weight}) for the adjoint */
-static void trilinear(const vol3_t *A, const float *p, float *a, float ag[3][3], size_t *tix, float *tw) {
-    float res[3] = { (float)A->rx, (float)A->ry, (float)A->rz }, fr[3]; int i0[3];
-    for (int k = 0; k < 3; ++k) { float pf = p[k]*res[k] - 0.5f, f = floorf(pf); i0[k] = (int)f; fr[k] = pf - f; }
+static void trilinear(const vol3_t *A, const real *p, real *a, real ag[3][3], size_t *tix, real *tw) {
+    real res[3] = { (real)A->rx, (real)A->ry, (real)A->rz }, fr[3]; int i0[3];
+    for (int k = 0; k < 3; ++k) { real pf = p[k]*res[k] - 0.5f, f = floorf(pf); i0[k] = (int)f; fr[k] = pf - f; }
     for (int c = 0; c < 3; ++c) { a[c] = 0.f; ag[c][0] = ag[c][1] = ag[c][2] = 0.f; }
     int n = 0;
     for (int dz = 0; dz < 2; ++dz) for (int dy = 0; dy < 2; ++dy) for (int dx = 0; dx < 2; ++dx, ++n) {
         int ix = clampi(i0[0] + dx, 0, A->rx - 1), iy = clampi(i0[1] + dy, 0, A->ry - 1), iz = clampi(i0[2] + dz, 0, A->rz - 1);
-        float wx = dx ? fr[0] : 1.f - fr[0], wy = dy ? fr[1] : 1.f - fr[1], wz = dz ? fr[2] : 1.f - fr[2];
-        float gx = (dx ? 1.f : -1.f)*res[0], gy = (dy ? 1.f : -1.f)*res[1], gz = (dz ? 1.f : -1.f)*res[2];
+        real wx = dx ? fr[0] : 1.f - fr[0], wy = dy ? fr[1] : 1.f - fr[1], wz = dz ? fr[2] : 1.f - fr[2];
+        real gx = (dx ? 1.f : -1.f)*res[0], gy = (dy ? 1.f : -1.f)*res[1], gz = (dz ? 1.f : -1.f)*res[2];
         size_t ti = 3*(((size_t)iz*A->ry + iy)*A->rx + ix);
         tix[n] = ti; tw[n] = wx*wy*wz;
         for (int c = 0; c < 3; ++c) {
-            float t = A->d[ti + c];
+            real t = A->d[ti + c];
             a[c] += tw[n]*t;
             ag[c][0] += t*gx*wy*wz; ag[c][1] += t*wx*gy*wz; ag[c][2] += t*wx*wy*gz;
         }
     }
 }
 
-typedef struct { int front; float p[3], g[3], H[6], n[3], so[3], sd[3], smaxt; } dhit_t;
+typedef struct { int front; real p[3], g[3], H[6], n[3], so[3], sd[3], smaxt; } dhit_t;
 
 /* hit point, normal, emitter direction (uniform sphere, mitsuba warp.h), shadow ray (spawn_ray_to / offset_p) */
-static void direct_setup(const grid_t *G, const ray_t *r, float its_t, const float *u, dhit_t *h) {
-    float v;
+static void direct_setup(const grid_t *G, const ray_t *r, real its_t, const real *u, dhit_t *h) {
+    real v;
     for (int a = 0; a < 3; ++a) h->p[a] = r->o[a] + its_t*r->d[a];
     eval_cubic(G, h->p, 2, &v, h->g, h->H);
-    float gl = sqrtf(dot3(h->g, h->g));
+    real gl = sqrtf(dot3(h->g, h->g));
     for (int a = 0; a < 3; ++a) h->n[a] = h->g[a]/gl;
-    float z = 1.f - 2.f*u[1], rr = sqrtf(fmaxf(1.f - z*z, 0.f)), phi = 6.283185307179586f*u[0];
-    float wd[3] = { rr*cosf(phi), rr*sinf(phi), z }, tgt[3], tp[3];
+    real z = 1.f - 2.f*u[1], rr = sqrtf(fmaxf(1.f - z*z, 0.f)), phi = 6.283185307179586f*u[0];
+    real wd[3] = { rr*cosf(phi), rr*sinf(phi), z }, tgt[3], tp[3];
     for (int a = 0; a < 3; ++a) { tgt[a] = h->p[a] + ENV_DIST*wd[a]; tp[a] = tgt[a] - h->p[a]; }
-    float mag = (1.f + fmaxf(fabsf(h->p[0]), fmaxf(fabsf(h->p[1]), fabsf(h->p[2]))))*RAY_EPSILON;
+    real mag = (1.f + fmaxf(fabsf(h->p[0]), fmaxf(fabsf(h->p[1]), fabsf(h->p[2]))))*RAY_EPSILON;
     if (dot3(h->n, tp) < 0.f) mag = -mag;
-    float dv[3];
+    real dv[3];
     for (int a = 0; a < 3; ++a) { h->so[a] = h->p[a] + mag*h->n[a]; dv[a] = tgt[a] - h->so[a]; }
-    float dist = sqrtf(dot3(dv, dv));
+    real dist = sqrtf(dot3(dv, dv));
     for (int a = 0; a < 3; ++a) h->sd[a] = dv[a]/dist;
     h->smaxt = dist*(1.f - SHADOW_EPSILON);
-    float md[3] = { -r->d[0], -r->d[1], -r->d[2] };
+    real md[3] = { -r->d[0], -r->d[1], -r->d[2] };
     h->front = dot3(h->n, h->sd) > 0.f && dot3(h->n, md) > 0.f;          /* diffuse::eval: both cosines positive */
 }
 
-static void splat4(float *block, int Wb, int Hb, const float *uv, const float *rgb) {
-    float pfx = uv[0] + BORDER - 0.5f, pfy = uv[1] + BORDER - 0.5f;
+static void splat4(real *block, int Wb, int Hb, const real *uv, const real *rgb) {
+    real pfx = uv[0] + BORDER - 0.5f, pfy = uv[1] + BORDER - 0.5f;
     int x0 = (int)ceilf(pfx - FRADIUS), y0 = (int)ceilf(pfy - FRADIUS);
     for (int j = 0; j < 4; ++j) for (int i = 0; i < 4; ++i) {
         int qx = x0 + i, qy = y0 + j;
         if (qx < 0 || qx >= Wb || qy < 0 || qy >= Hb) continue;
-        float f = gauss((float)qx - pfx)*gauss((float)qy - pfy);
-        float *dst = block + 4*((size_t)qy*Wb + qx);
+        real f = gauss((real)qx - pfx)*gauss((real)qy - pfy);
+        real *dst = block + 4*((size_t)qy*Wb + qx);
         for (int c = 0; c < 3; ++c) {
 #pragma omp atomic
             dst[c] += f*rgb[c];
@@ -499,18 +520,18 @@ static void splat4(float *block, int Wb, int Hb, const float *uv, const float *r
     }
 }
 
-static void develop4(const float *block, int W, int H, float *img) {
+static void develop4(const real *block, int W, int H, real *img) {
     int Wb = W + 2*BORDER;
     for (int y = 0; y < H; ++y) for (int x = 0; x < W; ++x) {
-        const float *b = block + 4*((size_t)(y + BORDER)*Wb + x + BORDER);
-        float w = b[3] == 0.f ? 1.f : b[3];
+        const real *b = block + 4*((size_t)(y + BORDER)*Wb + x + BORDER);
+        real w = b[3] == 0.f ? 1.f : b[3];
         for (int c = 0; c < 3; ++c) img[3*((size_t)y*W + x) + c] = b[c]/w;
     }
 }
 
 /* one sample's radiance; ts = shadow-ray trace (its_t = inf <=> unoccluded); returns 1 when lit */
-static int direct_sample(const grid_t *G, const vol3_t *A, const ray_t *r, float its_t, const float *u, const float *env,
-                         int hide, int diff, dhit_t *h, trace_t *ts, float *rgb, float *alb, float ag[3][3], size_t *tix, float *tw) {
+static int direct_sample(const grid_t *G, const vol3_t *A, const ray_t *r, real its_t, const real *u, const real *env,
+                         int hide, int diff, dhit_t *h, trace_t *ts, real *rgb, real *alb, real ag[3][3], size_t *tix, real *tw) {
     rgb[0] = rgb[1] = rgb[2] = 0.f;
     if (!(its_t < INFINITY)) { if (!hide) { rgb[0] = env[0]; rgb[1] = env[1]; rgb[2] = env[2]; } return 0; }
     direct_setup(G, r, its_t, u, h);
@@ -518,26 +539,26 @@ static int direct_sample(const grid_t *G, const vol3_t *A, const ray_t *r, float
     trace(G, h->so, h->sd, h->smaxt, diff, ts);
     if (ts->its_t < INFINITY) return 0;
     trilinear(A, h->p, alb, ag, tix, tw);
-    float k = 4.f*dot3(h->n, h->sd);
+    real k = 4.f*dot3(h->n, h->sd);
     for (int c = 0; c < 3; ++c) rgb[c] = alb[c]*k*env[c];
     return 1;
 }
 
-void o_render_direct(const float *grid, int rx, int ry, int rz, const float *cam, int W, int H, int spp, const float *offsets,
-                     const float *emitter_u, const float *albedo, int ax, int ay, int az, const float *env, int hide,
-                     float *image) {
+void o_render_direct(const real *grid, int rx, int ry, int rz, const real *cam, int W, int H, int spp, const real *offsets,
+                     const real *emitter_u, const real *albedo, int ax, int ay, int az, const real *env, int hide,
+                     real *image) {
     grid_t G = { grid, rx, ry, rz };
     vol3_t A = { albedo, ax, ay, az };
     int Wb = W + 2*BORDER, Hb = H + 2*BORDER;
     long n = (long)Wb*Hb*spp;
-    float *block = (float *)calloc((size_t)4*Wb*Hb, sizeof(float));
+    real *block = (real *)calloc((size_t)4*Wb*Hb, sizeof(real));
 #pragma omp parallel for schedule(dynamic, 256)
     for (long lane = 0; lane < n; ++lane) {
-        ray_t r; trace_t t, ts; dhit_t h; float rgb[3], alb[3], ag[3][3], tw[8], uv[2], ref[3]; size_t tix[8];
+        ray_t r; trace_t t, ts; dhit_t h; real rgb[3], alb[3], ag[3][3], tw[8], uv[2], ref[3]; size_t tix[8];
         lane_ray(cam, W, H, spp, offsets, lane, &r);
         trace(&G, r.o, r.d, r.maxt, 0, &t);
         direct_sample(&G, &A, &r, t.its_t, emitter_u + 2*lane, env, hide, 0, &h, &ts, rgb, alb, ag, tix, tw);
-        float p[3] = { r.o[0] + r.d[0], r.o[1] + r.d[1], r.o[2] + r.d[2] };
+        real p[3] = { r.o[0] + r.d[0], r.o[1] + r.d[1], r.o[2] + r.d[2] };
         reproject(cam, p, W, H, uv, ref);
         splat4(block, Wb, Hb, uv, rgb);
     }
@@ -546,18 +567,18 @@ void o_render_direct(const float *grid, int rx, int ry, int rz, const float *cam
 }
 
 /* coefficients of WarpField2D.eval (warp.py:47-96) at x = o + warp_t d: d dir = cdir dv, div = a v + b . g */
-typedef struct { float x[3], cdir[3], a, b[3], g[3], H[6]; } wcoef_t;
-static int warp_coef(const grid_t *G, const float *o, const float *d, const trace_t *t, wcoef_t *c) {
+typedef struct { real x[3], cdir[3], a, b[3], g[3], H[6]; } wcoef_t;
+static int warp_coef(const grid_t *G, const real *o, const real *d, const trace_t *t, wcoef_t *c) {
     if (!(fabsf(t->warp_t) < INFINITY) || !(t->ww > 0.f)) return 0;
-    float tt = t->warp_t, v;
+    real tt = t->warp_t, v;
     for (int a = 0; a < 3; ++a) c->x[a] = o[a] + tt*d[a];
     eval_cubic(G, c->x, 2, &v, c->g, c->H);
-    const float *g = c->g, *Hm = c->H;
-    float g2 = dot3(g, g), n_[3] = { g[0]/g2, g[1]/g2, g[2]/g2 };
-    float bdd[3], bd = bbox_dist_d(c->x, bdd), ee = EDGE_EPS*tt;
+    const real *g = c->g, *Hm = c->H;
+    real g2 = dot3(g, g), n_[3] = { g[0]/g2, g[1]/g2, g[2]/g2 };
+    real bdd[3], bd = bbox_dist_d(c->x, bdd), ee = EDGE_EPS*tt;
     int use_eps = ee <= bd;
-    float eps = fminf(ee, bd), ie = 1.f/eps, sd = fabsf(v), fac = 1.f - sd*ie, w = fmaxf(fac, 0.f);
-    float wd[3] = {0}, eps_d = 0.f;
+    real eps = fminf(ee, bd), ie = 1.f/eps, sd = fabsf(v), fac = 1.f - sd*ie, w = fmaxf(fac, 0.f);
+    real wd[3] = {0}, eps_d = 0.f;
     if (fac >= 0.f) {
         for (int a = 0; a < 3; ++a) wd[a] = -sgn(v)*g[a]*ie + sd*ie*ie*(use_eps ? 0.f : bdd[a]);
         if (use_eps) eps_d = sd*ie*ie;
@@ -565,48 +586,48 @@ static int warp_coef(const grid_t *G, const float *o, const float *d, const trac
     for (int a = 0; a < 3; ++a) wd[a] = t->ww*(wd[a] + eps_d*EDGE_EPS*d[a]) + w*t->wwd[a];
     w *= t->ww;
     if (!(w > 0.f)) return 0;
-    float q[3] = { t->wtd[0]/tt, t->wtd[1]/tt, t->wtd[2]/tt };
-    float dn = dot3(d, n_), dq = dot3(d, q), Pn[3], Pq[3], An[3], Hd[3], Hg[3];
+    real q[3] = { t->wtd[0]/tt, t->wtd[1]/tt, t->wtd[2]/tt };
+    real dn = dot3(d, n_), dq = dot3(d, q), Pn[3], Pq[3], An[3], Hd[3], Hg[3];
     for (int a = 0; a < 3; ++a) { Pn[a] = n_[a] - dn*d[a]; Pq[a] = q[a] - dq*d[a]; }
-    float pqn = dot3(Pq, n_);
+    real pqn = dot3(Pq, n_);
     for (int a = 0; a < 3; ++a) An[a] = Pn[a] + pqn*d[a];
     symmul(Hm, d, Hd); symmul(Hm, g, Hg);
-    float trH = Hm[0] + Hm[1] + Hm[2], dHd = dot3(d, Hd), gHg = dot3(g, Hg), gHd = dot3(g, Hd), dg = dot3(d, g);
-    float trJHA = (trH - dHd)/g2 - 2.f*(gHg - dg*gHd)/(g2*g2) + dot3(Pq, Hd)/g2 - 2.f*dot3(Pq, g)*gHd/(g2*g2);
+    real trH = Hm[0] + Hm[1] + Hm[2], dHd = dot3(d, Hd), gHg = dot3(g, Hg), gHd = dot3(g, Hd), dg = dot3(d, g);
+    real trJHA = (trH - dHd)/g2 - 2.f*(gHg - dg*gHd)/(g2*g2) + dot3(Pq, Hd)/g2 - 2.f*dot3(Pq, g)*gHd/(g2*g2);
     c->a = -(dot3(wd, Pn) + dot3(wd, d)*pqn) - w*trJHA;
-    float T = fmaxf(CLAMP_THRESH, tt);
+    real T = fmaxf(CLAMP_THRESH, tt);
     for (int a = 0; a < 3; ++a) { c->cdir[a] = (-w/T)*Pn[a]; c->b[a] = -w*An[a]; }
     return 1;
 }
 
-void o_render_direct_backward(const float *grid, int rx, int ry, int rz, const float *cam, int W, int H, int spp,
-                              const float *offsets, const float *emitter_u, const float *albedo, int ax, int ay, int az,
-                              const float *env, int hide, int reparam, const float *grad_image, float *grad_grid,
-                              float *grad_albedo, float *image) {
+void o_render_direct_backward(const real *grid, int rx, int ry, int rz, const real *cam, int W, int H, int spp,
+                              const real *offsets, const real *emitter_u, const real *albedo, int ax, int ay, int az,
+                              const real *env, int hide, int reparam, const real *grad_image, real *grad_grid,
+                              real *grad_albedo, real *image) {
     grid_t G = { grid, rx, ry, rz };
     vol3_t A = { albedo, ax, ay, az };
     int Wb = W + 2*BORDER, Hb = H + 2*BORDER;
     long n = (long)Wb*Hb*spp;
-    float *block = (float *)calloc((size_t)4*Wb*Hb, sizeof(float));
-    float *badj = (float *)calloc((size_t)4*Wb*Hb, sizeof(float));
+    real *block = (real *)calloc((size_t)4*Wb*Hb, sizeof(real));
+    real *badj = (real *)calloc((size_t)4*Wb*Hb, sizeof(real));
     trace_t *tr = (trace_t *)malloc((size_t)n*sizeof(trace_t)), *trs = (trace_t *)malloc((size_t)n*sizeof(trace_t));
     unsigned char *lit = (unsigned char *)calloc((size_t)n, 1);
 #pragma omp parallel for schedule(dynamic, 256)
     for (long lane = 0; lane < n; ++lane) {
-        ray_t r; dhit_t h; float rgb[3], alb[3], ag[3][3], tw[8], uv[2], ref[3]; size_t tix[8];
+        ray_t r; dhit_t h; real rgb[3], alb[3], ag[3][3], tw[8], uv[2], ref[3]; size_t tix[8];
         lane_ray(cam, W, H, spp, offsets, lane, &r);
         trace(&G, r.o, r.d, r.maxt, 1, &tr[lane]);
         lit[lane] = (unsigned char)direct_sample(&G, &A, &r, tr[lane].its_t, emitter_u + 2*lane, env, hide, 1, &h, &trs[lane],
                                                  rgb, alb, ag, tix, tw);
-        float p[3] = { r.o[0] + r.d[0], r.o[1] + r.d[1], r.o[2] + r.d[2] };
+        real p[3] = { r.o[0] + r.d[0], r.o[1] + r.d[1], r.o[2] + r.d[2] };
         reproject(cam, p, W, H, uv, ref);
         splat4(block, Wb, Hb, uv, rgb);
     }
     if (image) develop4(block, W, H, image);
     for (int y = 0; y < H; ++y) for (int x = 0; x < W; ++x) {              /* adjoint of develop */
         size_t q = (size_t)(y + BORDER)*Wb + x + BORDER;
-        const float *gi = grad_image + 3*((size_t)y*W + x);
-        float w = block[4*q + 3], acc = 0.f;
+        const real *gi = grad_image + 3*((size_t)y*W + x);
+        real w = block[4*q + 3], acc = 0.f;
         for (int c = 0; c < 3; ++c) { badj[4*q + c] = w == 0.f ? gi[c] : gi[c]/w; acc += gi[c]*block[4*q + c]; }
         badj[4*q + 3] = w == 0.f ? 0.f : -acc/(w*w);
     }
@@ -616,11 +637,11 @@ void o_render_direct_backward(const float *grid, int rx, int ry, int rz, const f
         wcoef_t wc;
         ray_t r;
         lane_ray(cam, W, H, spp, offsets, lane, &r);
-        const float *o = r.o, *d = r.d;
+        const real *o = r.o, *d = r.d;
         int warp_on = reparam && warp_coef(&G, o, d, t, &wc);
         if (!warp_on && !lit[lane]) continue;
         int hit = t->its_t < INFINITY;
-        float rgb[3] = {0, 0, 0}, alb[3] = {0, 0, 0}, ag[3][3], tw[8], uv[2], ref[3], cos_o = 0.f; size_t tix[8];
+        real rgb[3] = {0, 0, 0}, alb[3] = {0, 0, 0}, ag[3][3], tw[8], uv[2], ref[3], cos_o = 0.f; size_t tix[8];
         dhit_t h;
         if (!hit) { if (!hide) { rgb[0] = env[0]; rgb[1] = env[1]; rgb[2] = env[2]; } }
         else if (lit[lane]) {
@@ -629,33 +650,33 @@ void o_render_direct_backward(const float *grid, int rx, int ry, int rz, const f
             cos_o = dot3(h.n, h.sd);
             for (int c = 0; c < 3; ++c) rgb[c] = alb[c]*4.f*cos_o*env[c];
         }
-        float p1[3] = { o[0] + d[0], o[1] + d[1], o[2] + d[2] };
+        real p1[3] = { o[0] + d[0], o[1] + d[1], o[2] + d[2] };
         int inside = reproject(cam, p1, W, H, uv, ref);
-        float pfx = uv[0] + BORDER - 0.5f, pfy = uv[1] + BORDER - 0.5f;
+        real pfx = uv[0] + BORDER - 0.5f, pfy = uv[1] + BORDER - 0.5f;
         int x0 = (int)ceilf(pfx - FRADIUS), y0 = (int)ceilf(pfy - FRADIUS);
-        float ac[3] = {0, 0, 0}, a_w = 0, ub = 0, vb = 0;
+        real ac[3] = {0, 0, 0}, a_w = 0, ub = 0, vb = 0;
         for (int j = 0; j < 4; ++j) for (int i = 0; i < 4; ++i) {
             int qx = x0 + i, qy = y0 + j;
             if (qx < 0 || qx >= Wb || qy < 0 || qy >= Hb) continue;
-            float rx_ = (float)qx - pfx, ry_ = (float)qy - pfy, fx = gauss(rx_), fy = gauss(ry_);
-            const float *ba = badj + 4*((size_t)qy*Wb + qx);
-            float s = ba[3];
+            real rx_ = (real)qx - pfx, ry_ = (real)qy - pfy, fx = gauss(rx_), fy = gauss(ry_);
+            const real *ba = badj + 4*((size_t)qy*Wb + qx);
+            real s = ba[3];
             for (int c = 0; c < 3; ++c) { ac[c] += fx*fy*ba[c]; s += ba[c]*rgb[c]; }
             a_w += fx*fy*ba[3];
             ub += s*(-dgauss(rx_)*fy); vb += s*(-fx*dgauss(ry_));
         }
-        float rgb_dot = rgb[0]*ac[0] + rgb[1]*ac[1] + rgb[2]*ac[2];
-        float div_bar = rgb_dot + a_w, rw_bar = inside ? div_bar : 0.f;
-        float cot = 1.f/cam[12], iz = 1.f/ref[2], ku = -0.5f*(float)W*cot, dist2 = dot3(ref, ref);
-        float rb[3] = { ub*ku*iz + rw_bar*ref[0]/dist2, vb*ku*iz + rw_bar*ref[1]/dist2,
+        real rgb_dot = rgb[0]*ac[0] + rgb[1]*ac[1] + rgb[2]*ac[2];
+        real div_bar = rgb_dot + a_w, rw_bar = inside ? div_bar : 0.f;
+        real cot = 1.f/cam[12], iz = 1.f/ref[2], ku = -0.5f*(real)W*cot, dist2 = dot3(ref, ref);
+        real rb[3] = { ub*ku*iz + rw_bar*ref[0]/dist2, vb*ku*iz + rw_bar*ref[1]/dist2,
                         -(ub*ku*ref[0] + vb*ku*ref[1])*iz*iz + rw_bar*(ref[2]/dist2 - 3.f*iz) };
-        float dir_bar[3];
+        real dir_bar[3];
         for (int a = 0; a < 3; ++a) dir_bar[a] = cam[3+a]*rb[0] + cam[6+a]*rb[1] + cam[9+a]*rb[2];
         if (lit[lane]) {
             /* albedo: a_c-bar = A_c 4 cos_o L_c ; cos-bar = sum_c A_c a_c 4 L_c */
-            float pbar[3] = {0, 0, 0}, cos_bar = 0.f;
+            real pbar[3] = {0, 0, 0}, cos_bar = 0.f;
             for (int c = 0; c < 3; ++c) {
-                float k = 4.f*env[c]*ac[c], abar = k*cos_o;
+                real k = 4.f*env[c]*ac[c], abar = k*cos_o;
                 for (int m = 0; m < 8; ++m) {
 #pragma omp atomic
                     grad_albedo[tix[m] + c] += tw[m]*abar;
@@ -663,13 +684,13 @@ void o_render_direct_backward(const float *grid, int rx, int ry, int rz, const f
                 for (int a = 0; a < 3; ++a) pbar[a] += abar*ag[c][a];
                 cos_bar += k*alb[c];
             }
-            float gl = sqrtf(dot3(h.g, h.g)), nbar[3], sdbar[3], Gb[3], nn = 0.f, HG[3];
+            real gl = sqrtf(dot3(h.g, h.g)), nbar[3], sdbar[3], Gb[3], nn = 0.f, HG[3];
             for (int a = 0; a < 3; ++a) { nbar[a] = cos_bar*h.sd[a]; sdbar[a] = cos_bar*h.n[a]; nn += h.n[a]*nbar[a]; }
             for (int a = 0; a < 3; ++a) Gb[a] = (nbar[a] - nn*h.n[a])/gl;
             /* shadow-ray warp (warp.py:110-115 with the attached origin si.p): det_e multiplies the rgb channels only */
             wcoef_t ws;
             if (reparam && warp_coef(&G, h.so, h.sd, ts, &ws)) {
-                float vs = dot3(ws.cdir, sdbar) + ws.a*rgb_dot, gs[3], Hgs[3];
+                real vs = dot3(ws.cdir, sdbar) + ws.a*rgb_dot, gs[3], Hgs[3];
                 for (int a = 0; a < 3; ++a) gs[a] = rgb_dot*ws.b[a];
                 scatter_cubic(&G, grad_grid, ws.x, vs, gs);
                 symmul(ws.H, gs, Hgs);
@@ -677,12 +698,12 @@ void o_render_direct_backward(const float *grid, int rx, int ry, int rz, const f
             }
             symmul(h.H, Gb, HG);
             for (int a = 0; a < 3; ++a) pbar[a] += HG[a];
-            float c = -dot3(h.g, d), v0 = dot3(pbar, d)/c;
+            real c = -dot3(h.g, d), v0 = dot3(pbar, d)/c;
             for (int a = 0; a < 3; ++a) dir_bar[a] += t->its_t*pbar[a] + v0*t->its_t*h.g[a];
             scatter_cubic(&G, grad_grid, h.p, v0, Gb);
         }
         if (warp_on) {
-            float vbar = dot3(wc.cdir, dir_bar) + wc.a*div_bar, gbar[3];
+            real vbar = dot3(wc.cdir, dir_bar) + wc.a*div_bar, gbar[3];
             for (int a = 0; a < 3; ++a) gbar[a] = div_bar*wc.b[a];
             scatter_cubic(&G, grad_grid, wc.x, vbar, gbar);
         }
@@ -691,13 +712,13 @@ void o_render_direct_backward(const float *grid, int rx, int ry, int rz, const f
 }
 
 /* per-point / per-ray entry points for the cross-checks */
-void o_eval_cubic(const float *grid, int rx, int ry, int rz, const float *pts, long n, float *v, float *g, float *H) {
+void o_eval_cubic(const real *grid, int rx, int ry, int rz, const real *pts, long n, real *v, real *g, real *H) {
     grid_t G = { grid, rx, ry, rz };
     for (long i = 0; i < n; ++i) eval_cubic(&G, pts + 3*i, 2, v + i, g + 3*i, H + 6*i);
 }
 
-void o_trace(const float *grid, int rx, int ry, int rz, const float *ro, const float *rd, const float *maxt, long n,
-             int diff, float *its_t, float *warp_t, float *warp_t_d, float *ww, float *ww_d, int *steps) {
+void o_trace(const real *grid, int rx, int ry, int rz, const real *ro, const real *rd, const real *maxt, long n,
+             int diff, real *its_t, real *warp_t, real *warp_t_d, real *ww, real *ww_d, int *steps) {
     grid_t G = { grid, rx, ry, rz };
     for (long i = 0; i < n; ++i) {
         trace_t t; trace(&G, ro + 3*i, rd + 3*i, maxt[i], diff, &t);
@@ -705,6 +726,8 @@ void o_trace(const float *grid, int rx, int ry, int rz, const float *ro, const f
         for (int a = 0; a < 3; ++a) { warp_t_d[3*i + a] = t.wtd[a]; ww_d[3*i + a] = t.wwd[a]; }
     }
 }
+
+int o_real_bytes(void) { return (int)sizeof(real); }
 
 int o_num_threads(void) {
 #ifdef _OPENMP
@@ -726,48 +749,48 @@ int o_num_threads(void) {
  *      (Zhao 2005; 8 orderings, Gauss-Seidel) until the largest update is < 1e-7;
  *   3. result = sign(phi) * u.
  * ====================================================================================== */
-static float eikonal_update(float a, float b, float c, float ha, float hb, float hc) {
+static real eikonal_update(real a, real b, real c, real ha, real hb, real hc) {
     /* sort (value, spacing) ascending by value */
-    float v[3] = { a, b, c }, h[3] = { ha, hb, hc };
+    real v[3] = { a, b, c }, h[3] = { ha, hb, hc };
     for (int i = 0; i < 2; ++i) for (int j = 0; j < 2 - i; ++j)
-        if (v[j] > v[j+1]) { float t = v[j]; v[j] = v[j+1]; v[j+1] = t; t = h[j]; h[j] = h[j+1]; h[j+1] = t; }
-    float u = v[0] + h[0];
+        if (v[j] > v[j+1]) { real t = v[j]; v[j] = v[j+1]; v[j+1] = t; t = h[j]; h[j] = h[j+1]; h[j+1] = t; }
+    real u = v[0] + h[0];
     if (u <= v[1]) return u;
     {   /* two dimensions: ((u-v0)/h0)^2 + ((u-v1)/h1)^2 = 1 */
-        float w0 = 1.f/(h[0]*h[0]), w1 = 1.f/(h[1]*h[1]);
-        float A = w0 + w1, B = -2.f*(w0*v[0] + w1*v[1]), C = w0*v[0]*v[0] + w1*v[1]*v[1] - 1.f;
-        float disc = B*B - 4.f*A*C;
+        real w0 = 1.f/(h[0]*h[0]), w1 = 1.f/(h[1]*h[1]);
+        real A = w0 + w1, B = -2.f*(w0*v[0] + w1*v[1]), C = w0*v[0]*v[0] + w1*v[1]*v[1] - 1.f;
+        real disc = B*B - 4.f*A*C;
         u = (-B + sqrtf(fmaxf(disc, 0.f)))/(2.f*A);
         if (u <= v[2]) return u;
     }
     {
-        float w0 = 1.f/(h[0]*h[0]), w1 = 1.f/(h[1]*h[1]), w2 = 1.f/(h[2]*h[2]);
-        float A = w0 + w1 + w2, B = -2.f*(w0*v[0] + w1*v[1] + w2*v[2]);
-        float C = w0*v[0]*v[0] + w1*v[1]*v[1] + w2*v[2]*v[2] - 1.f;
-        float disc = B*B - 4.f*A*C;
+        real w0 = 1.f/(h[0]*h[0]), w1 = 1.f/(h[1]*h[1]), w2 = 1.f/(h[2]*h[2]);
+        real A = w0 + w1 + w2, B = -2.f*(w0*v[0] + w1*v[1] + w2*v[2]);
+        real C = w0*v[0]*v[0] + w1*v[1]*v[1] + w2*v[2]*v[2] - 1.f;
+        real disc = B*B - 4.f*A*C;
         return (-B + sqrtf(fmaxf(disc, 0.f)))/(2.f*A);
     }
 }
 
-void o_redistance(const float *phi, int rx, int ry, int rz, float *out) {
+void o_redistance(const real *phi, int rx, int ry, int rz, real *out) {
     size_t n = (size_t)rx*ry*rz;
-    float h[3] = { 1.f/rx, 1.f/ry, 1.f/rz };
-    const float BIG = 1e10f;
-    float *u = (float *)malloc(n*sizeof(float));
+    real h[3] = { 1.f/rx, 1.f/ry, 1.f/rz };
+    const real BIG = 1e10f;
+    real *u = (real *)malloc(n*sizeof(real));
     unsigned char *frozen = (unsigned char *)calloc(n, 1);
     int dims[3] = { rx, ry, rz };
     size_t strides[3] = { 1, (size_t)rx, (size_t)rx*ry };
     for (int z = 0; z < rz; ++z) for (int y = 0; y < ry; ++y) for (int x = 0; x < rx; ++x) {
         size_t i = ((size_t)z*ry + y)*rx + x;
         int c[3] = { x, y, z };
-        float p = phi[i], inv2 = 0.f; int any = 0;
+        real p = phi[i], inv2 = 0.f; int any = 0;
         if (p == 0.f) { u[i] = 0.f; frozen[i] = 1; continue; }
         for (int a = 0; a < 3; ++a) {
-            float d = BIG;
+            real d = BIG;
             for (int s = -1; s <= 1; s += 2) {
                 int cn = c[a] + s;
                 if (cn < 0 || cn >= dims[a]) continue;
-                float q = phi[i + s*(long)strides[a]];
+                real q = phi[i + s*(long)strides[a]];
                 if ((p > 0.f) != (q > 0.f)) d = fminf(d, h[a]*fabsf(p)/(fabsf(p) + fabsf(q)));
             }
             if (d < BIG) { inv2 += 1.f/(d*d); any = 1; }
@@ -775,7 +798,7 @@ void o_redistance(const float *phi, int rx, int ry, int rz, float *out) {
         if (any) { u[i] = 1.f/sqrtf(inv2); frozen[i] = 1; } else u[i] = BIG;
     }
     for (int round = 0; round < 64; ++round) {
-        float maxchg = 0.f;
+        real maxchg = 0.f;
         for (int sweep = 0; sweep < 8; ++sweep) {
             int sx = sweep & 1, sy = (sweep >> 1) & 1, sz = (sweep >> 2) & 1;
             for (int kz = 0; kz < rz; ++kz) { int z = sz ? rz - 1 - kz : kz;
@@ -783,11 +806,11 @@ void o_redistance(const float *phi, int rx, int ry, int rz, float *out) {
             for (int kx = 0; kx < rx; ++kx) { int x = sx ? rx - 1 - kx : kx;
                 size_t i = ((size_t)z*ry + y)*rx + x;
                 if (frozen[i]) continue;
-                float a = fminf(x > 0 ? u[i-1] : BIG, x < rx-1 ? u[i+1] : BIG);
-                float b = fminf(y > 0 ? u[i-rx] : BIG, y < ry-1 ? u[i+rx] : BIG);
-                float c = fminf(z > 0 ? u[i-(size_t)rx*ry] : BIG, z < rz-1 ? u[i+(size_t)rx*ry] : BIG);
+                real a = fminf(x > 0 ? u[i-1] : BIG, x < rx-1 ? u[i+1] : BIG);
+                real b = fminf(y > 0 ? u[i-rx] : BIG, y < ry-1 ? u[i+rx] : BIG);
+                real c = fminf(z > 0 ? u[i-(size_t)rx*ry] : BIG, z < rz-1 ? u[i+(size_t)rx*ry] : BIG);
                 if (fminf(a, fminf(b, c)) >= BIG) continue;
-                float un = eikonal_update(a, b, c, h[0], h[1], h[2]);
+                real un = eikonal_update(a, b, c, h[0], h[1], h[2]);
                 if (un < u[i]) { maxchg = fmaxf(maxchg, u[i] < BIG ? u[i] - un : 1.f); u[i] = un; }
             }}}
         }

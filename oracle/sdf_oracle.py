@@ -595,6 +595,23 @@ class Camera:
         self.tan = math.tan(math.radians(fov) * 0.5)
         self.dtype = dtype
 
+    @classmethod
+    def from_params(cls, cam16, dtype=torch.float64):
+        """The sensor DEFINED by a float32[16] record (what the C-ABI receives): the fp32-rounded origin / frame /
+        tan, held in `dtype`.  Parity runs use it so that oracle and HIP path see bit-identical inputs -- the
+        gradient estimator amplifies a 6e-8 relative input rounding to ~1e-4."""
+        c = np.asarray(cam16, np.float32).astype(np.float64)
+        self = cls.__new__(cls)
+        self.origin = torch.tensor(c[0:3], dtype=dtype)
+        self.R = torch.tensor(np.stack([c[3:6], c[6:9], c[9:12]], 1), dtype=dtype)
+        self.tan = float(c[12])
+        self.dtype = dtype
+        return self
+
+    def rounded(self):
+        """This sensor with its record rounded to fp32 (see from_params)."""
+        return Camera.from_params(self.params(), self.dtype)
+
     def params(self):
         """Flat float32[16]: origin(3) left(3) up(3) dir(3) tan, pad(3) -- the
         layout handed to the C-ABI (include/dsdf.h: dsdf_camera)."""

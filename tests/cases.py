@@ -19,18 +19,20 @@ def make_case(name):
     offsets = torch.rand((W + 4) * (H + 4) * spp, 2, generator=gen, dtype=torch.float32)
     grad_image = torch.randn(H, W, 3, generator=gen, dtype=torch.float32)
     origin = O.regular_camera_origins(ncam)[icam]
-    return dict(name=name, grid=gridfn(), ncam=ncam, icam=icam, origin=origin, W=W, H=H, spp=spp,
+    # the oracle's sensor is the one DEFINED by the fp32 record the C-ABI receives (bit-identical inputs on both sides)
+    cam = O.Camera(origin).rounded()
+    return dict(name=name, grid=gridfn(), ncam=ncam, icam=icam, origin=origin, cam=cam, W=W, H=H, spp=spp,
                 offsets=offsets, grad_image=grad_image)
 
 
 def oracle_forward(case, integrator, reparam=True):
-    cam = O.Camera(case['origin'])
+    cam = case['cam']
     return O.render(O.Grid3d(case['grid']), cam, case['W'], case['H'], case['spp'], case['offsets'].double(),
                     integrator, reparam, return_aux=True)
 
 
 def oracle_backward(case, integrator, reparam=True):
-    cam = O.Camera(case['origin'])
+    cam = case['cam']
     return O.render_backward(O.Grid3d(case['grid']), cam, case['W'], case['H'], case['spp'], case['offsets'].double(),
                              case['grad_image'].double(), integrator, reparam)
 
@@ -48,7 +50,7 @@ def direct_inputs(case, ares=(6, 5, 4), seed=11):
 def oracle_direct(case, extra, reparam=True, hide_emitters=False, grads=False, p=None):
     """Oracle image of sdf_direct_reparam; with grads=True also (dL/d data, dL/d albedo[, dL/d p]) for
     L = sum(image * grad_image)."""
-    cam = O.Camera(case['origin'])
+    cam = case['cam']
     data = case['grid'].clone().requires_grad_(grads)
     alb = extra['albedo'].double().clone().requires_grad_(grads)
     env = torch.tensor(extra['env'], dtype=torch.float64)

@@ -79,7 +79,7 @@ def test_direct_backward_host(harness, name, reparam):
 def test_direct_translation_gradient_host(harness):
     case = make_case('blob32')
     ex = direct_inputs(case)
-    cam = O.Camera(case['origin'])
+    cam = case['cam']
     p = torch.zeros(3, dtype=torch.float64, requires_grad=True)
     img = O.render(O.Grid3d(case['grid'], p), cam, case['W'], case['H'], case['spp'], case['offsets'].double(), O.DIRECT,
                    albedo=ex['albedo'].double(), emitter_u=ex['emitter_u'].double(), env=torch.tensor(ex['env'], dtype=torch.float64))

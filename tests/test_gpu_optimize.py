@@ -69,7 +69,7 @@ def test_grid3d_protocol_and_upsample(dsdf):
     z, y, x = torch.meshgrid(ax, ax, ax, indexing='ij')
     ref = O.eval_cubic(data.cpu().double(), torch.stack([x, y, z], -1).reshape(-1, 3), 0)[0].reshape(64, 64, 64)
     assert rel_l2(up[..., 0].cpu(), ref) < 1e-5
-    cam = O.Camera(O.regular_camera_origins(3)[1])
+    cam = O.Camera(O.regular_camera_origins(3)[1]).rounded()
     o, d, maxt = cam.sample_ray(torch.rand(500, 2, dtype=torch.float64) * 24, 24, 24)
     its, wt, wtd, ww, wwd = g.ray_intersect(o.float().cuda(), d.float().cuda(), maxt.float().cuda(), warp=object())
     its_nd = g.ray_intersect_non_diff(o.float().cuda(), d.float().cuda(), maxt.float().cuda())[0]

@@ -46,7 +46,7 @@ def test_eval_cubic_gpu(dsdf):
 
 def test_trace_gpu(dsdf):
     case = make_case('blob32')
-    cam = O.Camera(case['origin'])
+    cam = case['cam']
     pos = torch.rand(5000, 2, dtype=torch.float64) * torch.tensor([case['W'], case['H']], dtype=torch.float64)
     o, d, maxt = cam.sample_ray(pos, case['W'], case['H'])
     o32, d32, m32 = o.float(), d.float(), maxt.float()
@@ -233,10 +233,10 @@ def test_non_cubic_grid_and_rect_film(dsdf):
     g = dsdf.SdfGrid(grid.float().cuda())
     assert g.shape == (20, 28, 36)
     for integ in (O.SILHOUETTE, O.SIMPLE_SHADING):
-        ref = O.render(O.Grid3d(grid), O.Camera(origin), W, H, spp, offs.double(), integ)
+        ref = O.render(O.Grid3d(grid), O.Camera(origin).rounded(), W, H, spp, offs.double(), integ)
         img = dsdf.render_forward(g, sen, spp, offsets=offs.cuda(), integrator=integ)[0]
         assert rel_l2(img.cpu(), ref) < FWD_TOL
-        gref = O.render_backward(O.Grid3d(grid), O.Camera(origin), W, H, spp, offs.double(), gi.double(), integ)
+        gref = O.render_backward(O.Grid3d(grid), O.Camera(origin).rounded(), W, H, spp, offs.double(), gi.double(), integ)
         gg = dsdf.render_backward(g, sen, spp, gi.cuda()[None], offsets=offs.cuda(), integrator=integ)
         assert gg.shape == (20, 28, 36) and rel_l2(gg.cpu(), gref) < GRAD_TOL
 
@@ -349,7 +349,7 @@ def test_translation_parity_gpu(dsdf, integ):
     non-zero grid translation against the oracle's autograd."""
     case = make_case('blob32')
     shift = [0.03, -0.02, 0.015]
-    cam = O.Camera(case['origin'])
+    cam = case['cam']
     data = case['grid'].clone().requires_grad_(True)
     p = torch.tensor(shift, dtype=torch.float64, requires_grad=True)
     ref = O.render(O.Grid3d(data, p), cam, case['W'], case['H'], case['spp'], case['offsets'].double(), integ)
@@ -409,7 +409,7 @@ def test_forward_mode_gpu(dsdf, integ):
     translation tangent (the reference's eval_forward_gradient, figures/result_utils.py:126-161), (ii) transpose
     identity <J dtheta, G> == <dtheta, J^T G> with the GPU backward for tangents on sdf.data and sdf.p, several views."""
     case = make_case('sphere16')
-    cam = O.Camera(case['origin'])
+    cam = case['cam']
     tp = torch.tensor([0.0, 1.0, 0.0], dtype=torch.float64)
 
     def f(p):

@@ -37,7 +37,7 @@ def test_eval_cubic_host(harness):
 
 def test_trace_host(harness):
     case = make_case('blob32')
-    cam = O.Camera(case['origin'])
+    cam = case['cam']
     pos = torch.rand(3000, 2, dtype=torch.float64) * torch.tensor([case['W'], case['H']], dtype=torch.float64)
     o, d, maxt = cam.sample_ray(pos, case['W'], case['H'])
     o32, d32, m32 = o.float(), d.float(), maxt.float()
@@ -106,7 +106,7 @@ def test_translation_gradient_host(harness, integ):
     """dL/d(sdf.p) (python/shapes.py:389, 412, 471: `sdf.p` is a differentiable parameter; the
     reference's forward-gradient validation differentiates with respect to it) against autograd."""
     case = make_case('blob32')
-    cam = O.Camera(case['origin'])
+    cam = case['cam']
     p = torch.zeros(3, dtype=torch.float64, requires_grad=True)
     img = O.render(O.Grid3d(case['grid'], p), cam, case['W'], case['H'], case['spp'], case['offsets'].double(), integ)
     (img * case['grad_image'].double()).sum().backward()
@@ -141,7 +141,7 @@ def test_forward_mode_matches_oracle_jvp(harness):
     """Gradient image w.r.t. a translation of the SDF (the reference's eval_forward_gradient,
     figures/result_utils.py:126-161) against forward-over-reverse autograd of the oracle."""
     case = make_case('sphere16')
-    cam = O.Camera(case['origin'])
+    cam = case['cam']
     tp = torch.tensor([1.0, 0.0, 0.0], dtype=torch.float64)
 
     def f(p):
@@ -157,7 +157,7 @@ def test_reuse_fetch_is_bit_identical(harness):
     on the surface like shadow rays do: identical hit distances, warp quantities and step counts, bit for bit."""
     case = make_case('blob32')
     g = case['grid'].float().numpy()
-    cam = O.Camera(case['origin'])
+    cam = case['cam']
     torch.manual_seed(4)
     pos = torch.rand(3000, 2, dtype=torch.float64) * torch.tensor([case['W'], case['H']], dtype=torch.float64)
     o, d, maxt = cam.sample_ray(pos, case['W'], case['H'])
@@ -180,7 +180,7 @@ def test_reuse_fetch_is_bit_identical(harness):
 def test_resumable_diff_march_is_bit_identical(harness):
     """DiffMarch (begin / step / finish), the form a tail wave resumes, against the closed loop of trace_diff."""
     case = make_case('blob48_rect')
-    cam = O.Camera(case['origin'])
+    cam = case['cam']
     torch.manual_seed(2)
     pos = torch.rand(6000, 2, dtype=torch.float64) * torch.tensor([case['W'], case['H']], dtype=torch.float64)
     o, d, maxt = cam.sample_ray(pos, case['W'], case['H'])
@@ -196,7 +196,7 @@ def test_handed_off_march_resumes_bit_identically(harness, split):
     """Tail hand-off: a differentiable march stopped after `split` steps, exported in the tail-queue layout and
     resumed from a freshly begun march equals the uninterrupted one bit for bit (no piece of state is lost)."""
     case = make_case('blob48_rect')
-    cam = O.Camera(case['origin'])
+    cam = case['cam']
     torch.manual_seed(6)
     pos = torch.rand(5000, 2, dtype=torch.float64) * torch.tensor([case['W'], case['H']], dtype=torch.float64)
     o, d, maxt = cam.sample_ray(pos, case['W'], case['H'])
