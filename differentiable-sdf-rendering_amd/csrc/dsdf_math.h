@@ -16,7 +16,9 @@
 #define DSDF_HD inline
 #endif
 
-// 1 = hardware v_rcp_f32 / v_rsq_f32 (1 ulp) instead of IEEE division sequences in device code
+// 1 = hardware v_rcp_f32 / v_rsq_f32 / v_exp_f32 (1 ulp) instead of the IEEE division / expf sequences in device code.
+// -DDSDF_FAST_RCP=0 builds the precision A/B variant lib/variants/libdsdf_ieee.so (tools/precision_table.py): it
+// isolates what the approximations cost against the fp64 oracle (nothing measurable: DESIGN.md section 3).
 #ifndef DSDF_FAST_RCP
 #define DSDF_FAST_RCP 1
 #endif
@@ -730,7 +732,7 @@ DSDF_HD Reproj reproject(const dsdf_camera &c, const dsdf_params &P, V3 p, int W
 
 // exp(alpha x^2): v_exp_f32 (2^x, 1 ulp) on the device instead of the range-reduced expf sequence
 DSDF_HD float gauss_exp(float x) {
-#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__) && DSDF_FAST_RCP
     return __builtin_amdgcn_exp2f((DSDF_FILTER_ALPHA * 1.4426950408889634f) * x * x);
 #else
     return expf(DSDF_FILTER_ALPHA * x * x);

@@ -10,7 +10,8 @@ import sdf_oracle as O
 from conftest import rel_l2
 
 FWD_TOL = 1e-4
-GRAD_TOL = 3e-3
+GRAD_TOL = 3e-3   # degenerate set-ups (sensor inside the box / the object, grid partly outside): coarse sanity gate only;
+                  # the measured per-case gates live in test_kernel_math_host.py / tests/precision.py
 
 
 def run_case(harness, grid, origin, W, H, spp, integ, seed=0, target=(0.5, 0.5, 0.5), p=None, check_grad=True):

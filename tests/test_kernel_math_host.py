@@ -3,25 +3,25 @@
 lets the hand-derived adjoint be validated without a GPU; the GPU parity tests
 (test_gpu_parity.py) repeat the same comparisons through the C-ABI.
 
-Tolerances: forward images 1e-4 relative L2 (north_star).  Gradients: the fp64
-oracle and ANY fp32 evaluation of the estimator (including the oracle itself run
-in fp32, see test_fp32_noise_floor) differ by ~1e-3 relative L2 on these tiny
-cases because the warp-field weights are 1/denom^3 with denom down to 1e-6; the
-bound used is 3e-3 and the fp32-oracle floor is asserted alongside."""
+Tolerances: forward images 1e-4 relative L2 (north_star).  Gradients: per case
+max(2 x measured fp32 floor, 1e-4) against the fp64 oracle (tests/precision.py: the
+warp-field weights are 1/denom^3 with denom down to 1e-6, so ANY fp32 evaluation of
+the estimator -- the C restatement built in fp32, the torch oracle run in fp32 --
+sits 3e-5 ... 2e-3 from its fp64 result on these cases; test_fp32_noise_floor records it)."""
 import numpy as np
 import pytest
 import torch
 
 import sdf_oracle as O
 from cases import make_case, oracle_backward, oracle_forward
+import precision as P
 from conftest import rel_l2
 
 FWD_TOL = 1e-4
-GRAD_TOL = 3e-3
 
 
 def cam_params(case):
-    return O.Camera(case['origin']).params()
+    return case['cam'].params()
 
 
 def test_eval_cubic_host(harness):
@@ -87,18 +87,27 @@ def test_render_backward_host(harness, name, integ, reparam):
         assert np.abs(gg).max() == 0 and np.abs(gref).max() == 0      # no shading, no warp -> no gradient
         return
     assert np.isfinite(gg).all()
-    assert rel_l2(gg, gref) < GRAD_TOL
+    ok, msg = P.check_gradient('host-harness', case, integ, reparam, gg)
+    assert ok, msg
+    assert rel_l2(gref, P.reference_gradient(case, integ, reparam)['g64']) < 1e-6     # torch autograd == hand-written C adjoint (fp64)
 
 
 def test_fp32_noise_floor():
-    """The oracle itself, run in fp32, sits ~1e-3 from its fp64 result on the gradient."""
+    """Two independent fp32 evaluations of the reference algorithm (C restatement built in fp32, torch oracle run in
+    fp32) against the fp64 oracle, on bit-identical inputs: the floor every gradient gate in this suite is derived from.
+    Also: rounding the sensor record to fp32 alone (a 6e-8 relative input change) moves the fp64 gradient by ~1e-4."""
+    for name in ('sphere16', 'blob32', 'blob32_spp64', 'blob48_rect'):
+        case = make_case(name)
+        for integ in (O.SILHOUETTE, O.SIMPLE_SHADING):
+            r = P.reference_gradient(case, integ, True)
+            P.record('floor', case=name, integ=integ, floor_c=r['floor_c'], floor_torch=r['floor_torch'])
+            assert 1e-6 < r['floor_c'] < 5e-3 and 1e-6 < r['floor_torch'] < 5e-3, (name, integ, r['floor_c'], r['floor_torch'])
     case = make_case('blob32')
-    g64 = oracle_backward(case, O.SILHOUETTE).numpy()
-    cam32 = O.Camera(case['origin'], dtype=torch.float32)
-    g32 = O.render_backward(O.Grid3d(case['grid'].float()), cam32, case['W'], case['H'], case['spp'], case['offsets'],
-                            case['grad_image'], O.SILHOUETTE).numpy()
-    e = rel_l2(g32, g64)
-    assert 1e-5 < e < GRAD_TOL
+    exact_cam = O.Camera(case['origin'])                                   # un-rounded fp64 sensor
+    g_exact = O.render_backward(O.Grid3d(case['grid']), exact_cam, case['W'], case['H'], case['spp'], case['offsets'].double(),
+                                case['grad_image'].double(), O.SILHOUETTE).numpy()
+    e = rel_l2(g_exact, P.reference_gradient(case, O.SILHOUETTE, True)['g64'])
+    assert 1e-5 < e < 1e-3, e                                              # conditioning: ~1e-4 from a 6e-8 input change
 
 
 @pytest.mark.parametrize('integ', [O.SILHOUETTE, O.SIMPLE_SHADING])
@@ -106,13 +115,17 @@ def test_translation_gradient_host(harness, integ):
     """dL/d(sdf.p) (python/shapes.py:389, 412, 471: `sdf.p` is a differentiable parameter; the
     reference's forward-gradient validation differentiates with respect to it) against autograd."""
     case = make_case('blob32')
-    cam = case['cam']
-    p = torch.zeros(3, dtype=torch.float64, requires_grad=True)
-    img = O.render(O.Grid3d(case['grid'], p), cam, case['W'], case['H'], case['spp'], case['offsets'].double(), integ)
-    (img * case['grad_image'].double()).sum().backward()
+
+    def oracle(dt):
+        p = torch.zeros(3, dtype=dt, requires_grad=True)
+        img = O.render(O.Grid3d(case['grid'].to(dt), p), O.Camera.from_params(cam_params(case), dtype=dt), case['W'], case['H'],
+                       case['spp'], case['offsets'].to(dt), integ)
+        (img * case['grad_image'].to(dt)).sum().backward()
+        return (p.grad,)
+    (gp_ref,), (tol,) = P.torch_gate(oracle)
     harness.render_backward(case['grid'].float().numpy(), cam_params(case), case['W'], case['H'], case['spp'],
                             case['offsets'].numpy(), case['grad_image'].numpy(), integ)
-    assert rel_l2(harness.last_grad_p, p.grad.numpy()) < GRAD_TOL
+    assert rel_l2(harness.last_grad_p, gp_ref) < tol, (rel_l2(harness.last_grad_p, gp_ref), tol)
 
 
 @pytest.mark.parametrize('integ', [O.SILHOUETTE, O.SIMPLE_SHADING])
@@ -141,15 +154,18 @@ def test_forward_mode_matches_oracle_jvp(harness):
     """Gradient image w.r.t. a translation of the SDF (the reference's eval_forward_gradient,
     figures/result_utils.py:126-161) against forward-over-reverse autograd of the oracle."""
     case = make_case('sphere16')
-    cam = case['cam']
     tp = torch.tensor([1.0, 0.0, 0.0], dtype=torch.float64)
 
-    def f(p):
-        return O.render(O.Grid3d(case['grid'], p), cam, case['W'], case['H'], case['spp'], case['offsets'].double(), O.SIMPLE_SHADING)
-    _, ref = torch.autograd.functional.jvp(f, torch.zeros(3, dtype=torch.float64), tp)
+    def oracle(dt):
+        c = O.Camera.from_params(cam_params(case), dtype=dt)
+
+        def f(p):
+            return O.render(O.Grid3d(case['grid'].to(dt), p), c, case['W'], case['H'], case['spp'], case['offsets'].to(dt), O.SIMPLE_SHADING)
+        return (torch.autograd.functional.jvp(f, torch.zeros(3, dtype=dt), tp.to(dt))[1],)
+    (ref,), (tol,) = P.torch_gate(oracle)
     out = harness.render_forward_grad(case['grid'].float().numpy(), cam_params(case), case['W'], case['H'], case['spp'],
                                       case['offsets'].numpy(), O.SIMPLE_SHADING, tangent_p=tp.numpy())
-    assert rel_l2(out, ref) < GRAD_TOL
+    assert rel_l2(out, ref) < tol, (rel_l2(out, ref), tol)
 
 
 def test_reuse_fetch_is_bit_identical(harness):
