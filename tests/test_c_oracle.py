@@ -114,7 +114,7 @@ def test_c64_per_ray_outputs_match_torch_oracle():
     out = c_oracle.trace(P.clib(True), case['grid'].float().numpy(), o.numpy(), d.numpy(), maxt.numpy())
     assert np.array_equal(out['steps'], ref['steps'].numpy())
     # (the C build keeps fp32-VALUED constants -- 1e-6f vs 1e-6 -- which the 1/denom^3 weights amplify in the derivatives)
-    for k, tol in (('its_t', 1e-7), ('warp_t', 1e-7), ('warp_weight', 1e-6), ('warp_t_d', 2e-5), ('warp_weight_d', 2e-5)):
+    for k, tol in (('its_t', 1e-7), ('warp_t', 1e-7), ('warp_weight', 1e-5), ('warp_t_d', 2e-5), ('warp_weight_d', 2e-5)):
         a, b = out[k], ref[k].numpy()
         fin = np.isfinite(b)
         assert np.array_equal(np.isfinite(a), fin), k
