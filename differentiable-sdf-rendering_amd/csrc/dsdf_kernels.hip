@@ -92,6 +92,53 @@ __global__ void k_trace(GridView G, dsdf_params P, const float *__restrict__ ro,
     if (ww_d) { ww_d[3 * i] = t.warp_weight_d.x; ww_d[3 * i + 1] = t.warp_weight_d.y; ww_d[3 * i + 2] = t.warp_weight_d.z; }
 }
 
+// A9 per ray: WarpField2D.eval (warp.py:47-96) as the coefficients of its linearisation in the SDF value v and
+// gradient g at x = o + warp_t d:  d(dir) = cdir dv,  div = a v + b . g.
+__global__ void k_warp_eval(GridView G, dsdf_params P, const float *__restrict__ ro, const float *__restrict__ rd,
+                            const float *__restrict__ warp_t, const float *__restrict__ warp_t_d, const float *__restrict__ ww,
+                            const float *__restrict__ ww_d, int64_t n, int32_t *active, float *cdir, float *a, float *b, float *div) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    V3 o = mk(ro[3 * i], ro[3 * i + 1], ro[3 * i + 2]), d = mk(rd[3 * i], rd[3 * i + 1], rd[3 * i + 2]);
+    TraceOut tr;
+    tr.its_t = INFINITY; tr.warp_t = warp_t[i]; tr.warp_weight = ww[i]; tr.weight_sum = 0.f; tr.steps = 0; tr.refine_steps = 0;
+    tr.warp_t_d = mk(warp_t_d[3 * i], warp_t_d[3 * i + 1], warp_t_d[3 * i + 2]);
+    tr.warp_weight_d = mk(ww_d[3 * i], ww_d[3 * i + 1], ww_d[3 * i + 2]);
+    WarpCoef wc;
+    wc.cdir = mk(0.f, 0.f, 0.f); wc.a = 0.f; wc.b = mk(0.f, 0.f, 0.f); wc.div = 0.f;
+    const bool on = warp_coefficients(G, P, o, d, tr, wc);
+    if (!on) { wc.cdir = mk(0.f, 0.f, 0.f); wc.a = 0.f; wc.b = mk(0.f, 0.f, 0.f); wc.div = 0.f; }      // warp.py:91-93
+    if (active) active[i] = on ? 1 : 0;
+    if (cdir) { cdir[3 * i] = wc.cdir.x; cdir[3 * i + 1] = wc.cdir.y; cdir[3 * i + 2] = wc.cdir.z; }
+    if (a) a[i] = wc.a;
+    if (b) { b[3 * i] = wc.b.x; b[3 * i + 1] = wc.b.y; b[3 * i + 2] = wc.b.z; }
+    if (div) div[i] = wc.div;
+}
+
+// A6 per ray: SDFBase.compute_surface_interaction (shapes.py:347-366): p = o + t d, n = normalize(grad sdf(p)), and the
+// coefficient of the re-attached hit distance, t = replace_grad(t, v(p) / detach(g . -d)) -> dt/dv = 1 / (g . -d).
+__global__ void k_surface_interaction(GridView G, const float *__restrict__ ro, const float *__restrict__ rd,
+                                      const float *__restrict__ t, int64_t n, float *p, float *nrm, float *grad, float *t_coef) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    V3 o = mk(ro[3 * i], ro[3 * i + 1], ro[3 * i + 2]), d = mk(rd[3 * i], rd[3 * i + 1], rd[3 * i + 2]);
+    const float ti = t[i];
+    const bool valid = ti < INFINITY;
+    V3 x = mk(0.f, 0.f, 0.f), g = mk(0.f, 0.f, 0.f), nn = mk(0.f, 0.f, 0.f);
+    float c = 0.f;
+    if (valid) {
+        x = fma3(ti, d, o);
+        float v; float H[6];
+        eval_cubic<1>(G, x, v, g, H);
+        nn = g * (1.f / sqrtf(dot(g, g)));
+        c = 1.f / dot(g, -d);
+    }
+    if (p) { p[3 * i] = x.x; p[3 * i + 1] = x.y; p[3 * i + 2] = x.z; }
+    if (nrm) { nrm[3 * i] = nn.x; nrm[3 * i + 1] = nn.y; nrm[3 * i + 2] = nn.z; }
+    if (grad) { grad[3 * i] = g.x; grad[3 * i + 1] = g.y; grad[3 * i + 2] = g.z; }
+    if (t_coef) t_coef[i] = c;
+}
+
 #include "dsdf_wave.h"
 
 // Queue of samples that need the backward sweep.  Every render-pass block owns the slot
@@ -526,6 +573,29 @@ int dsdf_trace(const float *padded, int rx, int ry, int rz, const dsdf_params *p
     hipLaunchKernelGGL(k_trace, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, G, *prm, rays_o,
                        rays_d, maxt, n, differentiable, its_t, warp_t, warp_t_d, warp_weight, warp_weight_d, steps);
     return check_launch("k_trace");
+}
+
+int dsdf_warp_eval(const float *padded, int rx, int ry, int rz, const dsdf_params *prm, const float *rays_o,
+                   const float *rays_d, int64_t n, const float *warp_t, const float *warp_t_d, const float *warp_weight,
+                   const float *warp_weight_d, int32_t *active, float *cdir, float *a, float *b, float *div, void *stream) {
+    if (n == 0) return DSDF_OK;
+    if (!padded || !prm || !rays_o || !rays_d || !warp_t || !warp_t_d || !warp_weight || !warp_weight_d || n < 0)
+        return fail(DSDF_ERR_INVALID_ARG, "dsdf_warp_eval: bad argument");
+    GridView G = make_view(padded, rx, ry, rz, *prm);
+    hipLaunchKernelGGL(k_warp_eval, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, G, *prm, rays_o, rays_d,
+                       warp_t, warp_t_d, warp_weight, warp_weight_d, n, active, cdir, a, b, div);
+    return check_launch("k_warp_eval");
+}
+
+int dsdf_surface_interaction(const float *padded, int rx, int ry, int rz, const dsdf_params *prm, const float *rays_o,
+                             const float *rays_d, const float *t, int64_t n, float *p, float *normal, float *grad,
+                             float *t_coef, void *stream) {
+    if (n == 0) return DSDF_OK;
+    if (!padded || !prm || !rays_o || !rays_d || !t || n < 0) return fail(DSDF_ERR_INVALID_ARG, "dsdf_surface_interaction: bad argument");
+    GridView G = make_view(padded, rx, ry, rz, *prm);
+    hipLaunchKernelGGL(k_surface_interaction, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, G, rays_o,
+                       rays_d, t, n, p, normal, grad, t_coef);
+    return check_launch("k_surface_interaction");
 }
 
 size_t dsdf_render_workspace_size(int width, int height, int spp, int n_views, int integrator) {

@@ -168,6 +168,38 @@ def trace(grid, rays_o, rays_d, maxt, differentiable=True):
     return out
 
 
+def warp_eval(grid, rays_o, rays_d, trace_out):
+    """A9 per ray: `WarpField2D.eval` (python/warp.py:47-96) as its linearisation in (v, g) at x = o + warp_t d.
+    trace_out: the dict returned by trace(..., differentiable=True).  Returns dict(active, cdir, a, b, div)."""
+    lib = _lib.load()
+    rays_o = _require_dev(rays_o, 'rays_o'); rays_d = _require_dev(rays_d, 'rays_d')
+    n = rays_o.shape[0]
+    dev = rays_o.device
+    t = {k: _require_dev(trace_out[k], k) for k in ('warp_t', 'warp_t_d', 'warp_weight', 'warp_weight_d')}
+    f = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
+    out = dict(active=torch.empty(n, dtype=torch.int32, device=dev), cdir=f(n, 3), a=f(n), b=f(n, 3), div=f(n))
+    with torch.cuda.device(dev):
+        _lib.check(lib.dsdf_warp_eval(_ptr(grid.padded), grid.rx, grid.ry, grid.rz, C.byref(grid.params), _ptr(rays_o), _ptr(rays_d),
+                                      n, _ptr(t['warp_t']), _ptr(t['warp_t_d']), _ptr(t['warp_weight']), _ptr(t['warp_weight_d']),
+                                      _ptr(out['active']), _ptr(out['cdir']), _ptr(out['a']), _ptr(out['b']), _ptr(out['div']), _stream()))
+    return out
+
+
+def surface_interaction(grid, rays_o, rays_d, t):
+    """A6 per ray: `SDFBase.compute_surface_interaction` (python/shapes.py:347-366) -> dict(p, n, grad, t_coef)."""
+    lib = _lib.load()
+    rays_o = _require_dev(rays_o, 'rays_o'); rays_d = _require_dev(rays_d, 'rays_d'); t = _require_dev(t, 't')
+    n = rays_o.shape[0]
+    dev = rays_o.device
+    f = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
+    out = dict(p=f(n, 3), n=f(n, 3), grad=f(n, 3), t_coef=f(n))
+    with torch.cuda.device(dev):
+        _lib.check(lib.dsdf_surface_interaction(_ptr(grid.padded), grid.rx, grid.ry, grid.rz, C.byref(grid.params), _ptr(rays_o),
+                                                _ptr(rays_d), _ptr(t), n, _ptr(out['p']), _ptr(out['n']), _ptr(out['grad']),
+                                                _ptr(out['t_coef']), _stream()))
+    return out
+
+
 def _views(sensors):
     sensors = list(sensors) if isinstance(sensors, (list, tuple)) else [sensors]
     W, H = sensors[0].film_size()

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define DSDF_VERSION 100
+#define DSDF_VERSION 200
 
 enum dsdf_status {
     DSDF_OK = 0,
@@ -127,6 +127,27 @@ int dsdf_trace(const float *padded, int rx, int ry, int rz, const dsdf_params *p
                int differentiable,
                float *its_t, float *warp_t, float *warp_t_d,
                float *warp_weight, float *warp_weight_d, int32_t *steps, void *stream);
+
+/* A9 per ray: `WarpField2D.eval` (python/warp.py:47-96) at x = o + warp_t d for rays with NORMALISED directions and the
+ * outputs of dsdf_trace (differentiable = 1).  For primary rays x carries no parameter dependence (the trace runs under
+ * suspend_grad, warp.py:104-107), so the attached outputs of eval are linear in the SDF value v and gradient g at x; the
+ * entry point returns that linearisation (outputs may be NULL):
+ *   active n (int32) -- boundary weight w > 0 and warp_t finite (warp.py:52, 91); all other outputs are 0 where inactive
+ *   cdir n x 3       -- d(warped direction)/dv : -(w/T) (I - d d^T) g/|g|^2, T = max(clamping_thresh, warp_t) (warp.py:81-83)
+ *   a n, b n x 3     -- div = a v + b . g (warp.py:59, 77, 86-88; the value of `div` is replaced by 1 at warp.py:115)
+ *   div n            -- the value a v + b . g itself */
+int dsdf_warp_eval(const float *padded, int rx, int ry, int rz, const dsdf_params *prm,
+                   const float *rays_o, const float *rays_d, int64_t n,
+                   const float *warp_t, const float *warp_t_d, const float *warp_weight, const float *warp_weight_d,
+                   int32_t *active, float *cdir, float *a, float *b, float *div, void *stream);
+
+/* A6 per ray: `SDFBase.compute_surface_interaction` (python/shapes.py:347-366) for rays with normalised directions and
+ * hit distances t (+inf = miss: outputs 0).  p n x 3 = o + t d; normal n x 3 = normalize(grad sdf(p)); grad n x 3 = the
+ * un-normalised SDF gradient; t_coef n = dt/dv(p) = 1 / (grad . -d), the coefficient of
+ * `t = replace_grad(t, v / detach(dot(g, -d)))` (shapes.py:354-356).  Outputs may be NULL. */
+int dsdf_surface_interaction(const float *padded, int rx, int ry, int rz, const dsdf_params *prm,
+                             const float *rays_o, const float *rays_d, const float *t, int64_t n,
+                             float *p, float *normal, float *grad, float *t_coef, void *stream);
 
 /* Workspace (bytes) for dsdf_render_forward / dsdf_render_backward to process
  * `n_views` sensors of width x height at spp samples in ONE launch (film blocks,

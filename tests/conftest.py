@@ -73,6 +73,19 @@ class HostHarness:
                                   self._p(out['warp_weight']), self._p(out['warp_weight_d']), self._p(out['steps']))
         return out
 
+    def warp_eval(self, grid, o, d, tr):
+        grid = np.ascontiguousarray(grid, np.float32)
+        o = np.ascontiguousarray(o, np.float32); d = np.ascontiguousarray(d, np.float32)
+        n = o.shape[0]
+        t = {k: np.ascontiguousarray(tr[k], np.float32) for k in ('warp_t', 'warp_t_d', 'warp_weight', 'warp_weight_d')}
+        out = dict(active=np.zeros(n, np.int32), cdir=np.zeros((n, 3), np.float32), a=np.zeros(n, np.float32),
+                   b=np.zeros((n, 3), np.float32), div=np.zeros(n, np.float32))
+        rz, ry, rx = grid.shape
+        self.lib.hh_warp_eval(self._p(grid), rx, ry, rz, C.byref(self.params), self._p(o), self._p(d), C.c_long(n),
+                              self._p(t['warp_t']), self._p(t['warp_t_d']), self._p(t['warp_weight']), self._p(t['warp_weight_d']),
+                              self._p(out['active']), self._p(out['cdir']), self._p(out['a']), self._p(out['b']), self._p(out['div']))
+        return out
+
     def render_forward(self, grid, cam, W, H, spp, offsets, integrator, reparam=True, diff=False, seed=0):
         grid = np.ascontiguousarray(grid, np.float32)
         offsets = None if offsets is None else np.ascontiguousarray(offsets, np.float32)

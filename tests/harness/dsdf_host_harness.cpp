@@ -63,6 +63,27 @@ void hh_trace(const float *data, int rx, int ry, int rz, const dsdf_params *prm,
     }
 }
 
+// per-ray WarpField2D.eval coefficients (same statements as k_warp_eval of the HIP library)
+void hh_warp_eval(const float *data, int rx, int ry, int rz, const dsdf_params *prm, const float *ro, const float *rd, long n,
+                  const float *warp_t, const float *warp_t_d, const float *ww, const float *ww_d, int *active, float *cdir,
+                  float *a, float *b, float *div) {
+    std::vector<float> p = pad(data, rx, ry, rz);
+    GridView G = make_view(p.data(), rx, ry, rz, *prm);
+    for (long i = 0; i < n; ++i) {
+        V3 o = mk(ro[3 * i], ro[3 * i + 1], ro[3 * i + 2]), d = mk(rd[3 * i], rd[3 * i + 1], rd[3 * i + 2]);
+        TraceOut tr;
+        tr.its_t = INFINITY; tr.warp_t = warp_t[i]; tr.warp_weight = ww[i]; tr.weight_sum = 0.f; tr.steps = 0; tr.refine_steps = 0;
+        tr.warp_t_d = mk(warp_t_d[3 * i], warp_t_d[3 * i + 1], warp_t_d[3 * i + 2]);
+        tr.warp_weight_d = mk(ww_d[3 * i], ww_d[3 * i + 1], ww_d[3 * i + 2]);
+        WarpCoef wc;
+        bool on = warp_coefficients(G, *prm, o, d, tr, wc);
+        if (!on) { wc.cdir = mk(0.f, 0.f, 0.f); wc.a = 0.f; wc.b = mk(0.f, 0.f, 0.f); wc.div = 0.f; }
+        active[i] = on ? 1 : 0;
+        cdir[3 * i] = wc.cdir.x; cdir[3 * i + 1] = wc.cdir.y; cdir[3 * i + 2] = wc.cdir.z;
+        a[i] = wc.a; b[3 * i] = wc.b.x; b[3 * i + 1] = wc.b.y; b[3 * i + 2] = wc.b.z; div[i] = wc.div;
+    }
+}
+
 static ViewArgs view_args(const dsdf_camera *cam, int W, int H, int spp, const float *offsets, unsigned seed,
                           int integrator, int flags) {
     ViewArgs A;

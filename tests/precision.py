@@ -135,6 +135,79 @@ def reference_direct(case, ex, reparam=True):
     return _cache[key]
 
 
+class _LeafSdf:
+    """An SDF whose value / gradient at the query points are autograd LEAVES (their numbers come from the real grid):
+    differentiating WarpField2D.eval with respect to them yields exactly the per-ray coefficients cdir, a, b."""
+
+    def __init__(self, sdf, x):
+        v, _, g, _, H = sdf.eval_all(x)
+        self.v = v.detach().clone().requires_grad_(True)
+        self.g = g.detach().clone().requires_grad_(True)
+        self.H = H.detach()
+        self._bbox = sdf.bbox()
+
+    def bbox(self):
+        return self._bbox
+
+    def eval_all(self, x):
+        return self.v, self.v.detach(), self.g, self.g.detach(), self.H
+
+
+def oracle_warp_coefficients(case, o, d, tr, dtype=torch.float64):
+    """python/warp.py:47-96 through oracle/sdf_oracle.py:warp_eval with autograd: per-ray active flag, cdir = d(dir)/dv,
+    a = d(div)/dv, b = d(div)/dg and the value of div.  o, d: (n,3) tensors; tr: dict of per-ray trace outputs (tensors)."""
+    o = o.to(dtype); d = d.to(dtype)
+    t = tr['warp_t'].to(dtype)
+    fin = torch.isfinite(t)
+    tt = torch.where(fin, t, torch.ones_like(t))
+    x = o + tt[:, None] * d
+    sdf = O.Grid3d(case['grid'].float().to(dtype))
+    leaf = _LeafSdf(sdf, x)
+    wdir, div, active = O.warp_eval(leaf, x, d, tt, tr['warp_t_d'].to(dtype), tr['warp_weight'].to(dtype),
+                                    tr['warp_weight_d'].to(dtype), fin)
+    a, b = torch.autograd.grad(div.sum(), (leaf.v, leaf.g), retain_graph=True, allow_unused=True)
+    cols = []
+    for k in range(3):
+        (c,) = torch.autograd.grad(wdir[:, k].sum(), (leaf.v,), retain_graph=True, allow_unused=True)
+        cols.append(torch.zeros_like(leaf.v) if c is None else c)
+    z = lambda q, like: torch.zeros_like(like) if q is None else q
+    return dict(active=active.numpy(), cdir=torch.stack(cols, -1).numpy(), a=z(a, leaf.v).numpy(), b=z(b, leaf.g).numpy(),
+                div=div.detach().numpy())
+
+
+def silhouette_rays(case, n=6000, seed=7):
+    """Camera rays of a case, fp32-rounded, with the fp64 oracle's per-ray trace outputs (SDFBase.ray_intersect)."""
+    gen = torch.Generator().manual_seed(seed)
+    pos = torch.rand(n, 2, dtype=torch.float64, generator=gen) * torch.tensor([case['W'], case['H']], dtype=torch.float64)
+    o, d, maxt = case['cam'].sample_ray(pos, case['W'], case['H'])
+    o32, d32, m32 = o.float(), d.float(), maxt.float()
+    tr = O.ray_intersect(O.Grid3d(case['grid'].float().double()), o32.double(), d32.double(), m32.double())
+    return o32, d32, m32, tr
+
+
+def check_warp_coefficients(tag, case, o32, d32, tr32, out):
+    """Per-ray A9 outputs (dict of numpy arrays: active, cdir, a, b, div) against the oracle's autograd linearisation of
+    WarpField2D.eval; gates = max(2 x the torch oracle's own fp32-vs-fp64 difference, 1e-4) per output."""
+    ref = oracle_warp_coefficients(case, o32, d32, tr32)
+    r32 = oracle_warp_coefficients(case, o32, d32, tr32, dtype=torch.float32)
+    act = np.asarray(out['active']) != 0
+    assert (act != ref['active']).mean() < 2e-3, (act.sum(), ref['active'].sum())
+    m = act & ref['active'] & r32['active']
+    assert m.sum() > 100, m.sum()
+    msgs = []
+    for k in ('cdir', 'a', 'b', 'div'):
+        e, f = rel_l2(np.asarray(out[k])[m], ref[k][m]), rel_l2(r32[k][m], ref[k][m])
+        tol = max(FLOOR_FACTOR * f, NORTH_STAR)
+        record('warp_eval', tag=tag, case=case['name'], output=k, err=e, floor=f, tol=tol, rays=int(m.sum()))
+        msgs.append((k, e, tol))
+    bad = [x for x in msgs if not x[1] <= x[2]]
+    assert not bad, msgs
+    off = ~act
+    for k in ('cdir', 'a', 'b', 'div'):
+        assert np.abs(np.asarray(out[k])[off]).max(initial=0.0) == 0.0          # inactive lanes report zeros (warp.py:91-93)
+    return msgs
+
+
 def torch_gate(fn):
     """For special configurations (translated grid, non-cubic grid, forward mode ...) whose reference comes from the torch
     oracle: fn(dtype) -> tuple of arrays; returns (fp64 references, per-output gates max(2 x fp32-vs-fp64, 1e-4))."""

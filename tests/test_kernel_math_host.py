@@ -168,6 +168,16 @@ def test_forward_mode_matches_oracle_jvp(harness):
     assert rel_l2(out, ref) < tol, (rel_l2(out, ref), tol)
 
 
+def test_warp_eval_host(harness):
+    """A9 per ray: cdir, a, b, div of `warp_coefficients` (the statements k_warp_eval / k_backward execute) against the
+    oracle's autograd linearisation of WarpField2D.eval (python/warp.py:47-96)."""
+    case = make_case('blob32')
+    o32, d32, m32, tr = P.silhouette_rays(case)
+    tr32 = {k: v.float() for k, v in tr.items() if k != 'steps'}
+    out = harness.warp_eval(case['grid'].float().numpy(), o32.numpy(), d32.numpy(), {k: v.numpy() for k, v in tr32.items()})
+    P.check_warp_coefficients('host-harness', case, o32, d32, tr32, out)
+
+
 def test_reuse_fetch_is_bit_identical(harness):
     """ReuseFetch (taps of the last visited cell kept in registers) against the per-step gather, on rays that start
     on the surface like shadow rays do: identical hit distances, warp quantities and step counts, bit for bit."""
