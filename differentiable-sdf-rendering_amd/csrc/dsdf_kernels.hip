@@ -270,11 +270,12 @@ __global__ __launch_bounds__(DSDF_BLOCK, DIRECT ? 1 : (DIFF ? DSDF_DIFF_MINWAVES
         if (DIRECT) {
             float rgb[3];
             lit = direct_value(G, P, A, S, L, lane, tr.its_t, DIFF, trs, rgb);
-            if (wave_uniform) film_splat_wave<4>(block, A, L.px, L.py, rp.u, rp.v, rgb, wave_lds[threadIdx.x >> 6], lid);
+            // (wave_uniform: n_lanes % 64 == 0, so `valid` is wave-uniform too; the tail waves past n_lanes must not splat)
+            if (wave_uniform) { if (valid) film_splat_wave<4>(block, A, L.px, L.py, rp.u, rp.v, rgb, wave_lds[threadIdx.x >> 6], lid); }
             else if (valid) splat_lane_rgb(block, A.Wb, A.Hb, rp.u, rp.v, rgb, AtomicAdd());
         } else {
             float val = shade_value(G, A, L, tr.its_t);
-            if (wave_uniform) film_splat_wave<2>(block, A, L.px, L.py, rp.u, rp.v, &val, wave_lds[threadIdx.x >> 6], lid);
+            if (wave_uniform) { if (valid) film_splat_wave<2>(block, A, L.px, L.py, rp.u, rp.v, &val, wave_lds[threadIdx.x >> 6], lid); }
             else if (valid) splat_lane(block, A.Wb, A.Hb, rp.u, rp.v, val, AtomicAdd());
         }
     }

@@ -155,6 +155,26 @@ def test_render_backward_gpu(dsdf, name, integ, reparam):
     assert rel_l2(gref, P.reference_gradient(case, integ, reparam)['g64']) < 1e-6     # both fp64 oracles agree
 
 
+def test_odd_film_tail_waves_do_not_splat(dsdf):
+    """Film 33x33 at spp 64: (W+4)(H+4) = 1369 pixel-waves, not a multiple of the 4 waves of a block -- the three tail
+    waves past the last sample are clamped to it for the cross-lane code and must not splat.  Proof off, so
+    that nothing else hides them; compared with the oracle, last pixel included."""
+    W = H = 33
+    gen = torch.Generator().manual_seed(9)
+    offs = torch.rand((W + 4) * (H + 4) * 64, 2, generator=gen)
+    grid64 = O.blob_grid(32, n=6, seed=1)
+    origin = O.regular_camera_origins(3)[1]
+    cam = O.Camera(origin).rounded()
+    import c_oracle
+    ref, _ = c_oracle.render(P.clib(True), grid64.float().numpy(), cam.params(), W, H, 64, offs.numpy(), O.SIMPLE_SHADING)
+    sen = dsdf.Sensor(origin, resx=W, resy=H)
+    for skip in (False, True):
+        img = dsdf.render_forward(dsdf.SdfGrid(grid64.float().cuda()), sen, 64, offsets=offs.cuda(), integrator=O.SIMPLE_SHADING,
+                                  empty_space_skip=skip)[0].cpu().numpy()
+        assert rel_l2(img, ref) < FWD_TOL
+        assert np.abs(img[-2:, -2:] - ref[-2:, -2:]).max() < 1e-5
+
+
 def test_backward_accumulates(dsdf):
     case = make_case('blob32')
     grid, sen = dev_grid(dsdf, case), sensor(dsdf, case)
