@@ -1,18 +1,30 @@
 #!/usr/bin/env python3
 """bench.py -- differentiable renders/s of the hot path on MI355X.
 
-One "step" = one differentiable render in the reference's sense
-(python/shape_opt.py:77-83 per view): for each of `--views` sensors a primal
-render at spp_primal (no AD) and a gradient pass at spp_grad that accumulates
-dL/dsdf, on a 256^3 SDF at 512^2 (BASELINE.json configs[2], the configuration the
-metric is quoted on; it fits one GPU).  Default spp = the reference's 256 / 64
-(python/configs.py:16,19).  Inputs are synthetic, seeded and resident in HBM
-before the timed region.
+One "step" = one differentiable render in the reference's sense (python/shape_opt.py:77-83 per view): for each of the
+12 sensors a primal render at spp_primal (no AD) and a gradient pass at spp_grad that accumulates dL/dsdf, on a 256^3
+SDF at 512^2 (BASELINE.json configs[2], the configuration the metric is quoted on; it fits one GPU).  Default spp = the
+reference's 256 / 64 (python/configs.py:16,19).  Inputs are synthetic, seeded and resident in HBM before the timed region.
 
-Multi-GPU (launched by torch.distributed.run, one rank per GPU): weak scaling --
-every rank renders its own `--views` sensors of a 12*N-sensor ring (a larger view
-batch per optimisation step), then the per-voxel gradient grid is summed with one
-RCCL all-reduce (the path's only exchange step).  value = N * views-batches / time.
+Multi-GPU (launched by torch.distributed.run, one rank per GPU).  Default `--scaling strong`: the metric's 12 views are
+partitioned over the ranks (dsdf.parallel.view_shard; with more ranks than a divisor of 12 the shards differ by one view),
+every rank renders its views, then the per-voxel gradient grid is summed with ONE RCCL all-reduce (the path's only
+exchange step); value = steps / time means the same at every N.  `--scaling weak` (12 views PER rank, a 12*N ring) is
+kept under a different metric string.
+
+The JSON line carries, besides the contract's fields:
+  roofline     -- VALU-issue roofline of the dominant kernel (the primal k_render_pass): the path is not HBM-bound (taps
+                  are LDS/L1-resident: measured HBM traffic is ~1 % of the algorithmic tap bytes), it issues vector ALU
+                  instructions.  achieved = wave-level VALU instructions per launch / launch time; peak = 1024 SIMDs x
+                  2.4 GHz / 2 clk per wave64 instruction (MI355X_MICROARCH.md: SIMD-32, `v_fma_f32` 2 cyc).  The
+                  instruction count is LIVE: lock-step wave iterations counted by the kernel itself (stats[7]) x the
+                  per-iteration VALU instruction counts of the shipped ISA, calibrated against SQ_INSTS_VALU of the
+                  committed PMC pass (profiles/, tag in `calibration`).  The HBM-equivalent algorithmic-bytes figure of
+                  SURVEY 8(d) is kept as a secondary field (`hbm_equivalent`); `traffic` is null here (PMC counters cannot
+                  be read in-process; the measured bytes live in profiles/).
+  low_spp      -- the same step at 4/1 spp (the sampling rate at which north_star's >= 50 renders/s target and its 60 %
+                  roofline coincide), timed in the same process after the headline region.
+  cpu_baseline -- oracle/dsdf_oracle.c (fp32 build) on the host cores, bounded sample (rank 0, N = 1 only).
 """
 import argparse
 import json
@@ -25,6 +37,14 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, 'differentiable-sdf-rendering_amd', 'python'))
 
 import torch
+
+# VALU instructions per lock-step wave iteration / per wave, from the ISA of the shipped kernels
+# (hipcc -S, instruction histogram of the loop bodies; cross-checked against SQ_INSTS_VALU: profiles/r02_sq.json)
+VALU_MODEL = {
+    'calibration': 'profiles/r02_sq.json',
+    'primal': {'per_wave_step': 262.0, 'per_traced_wave': 520.0, 'per_wave': 40.0},
+}
+VALU_PEAK = 1024 * 2.4e9 / 2.0        # wave64 VALU instructions / s: 256 CUs x 4 SIMD-32, 2 clk per instruction
 
 
 def synth_grid(res, device, n=32, seed=0):
@@ -55,7 +75,7 @@ def synth_grid(res, device, n=32, seed=0):
 
 
 def cpu_baseline(args, target_seconds=15.0):
-    """Oracle ('port': oracle/dsdf_oracle.c, plain C + OpenMP, fp32) timed on the host cores on a
+    """Oracle ('port': oracle/dsdf_oracle.c, plain C + OpenMP, fp32 build) timed on the host cores on a
     bounded sample of the same workload: the same 256^3 grid, ONE sensor of the ring, the full
     512^2 film, at reduced spp chosen so that the sample takes ~15 s (probe at 4/1 spp first);
     scaled linearly in samples-per-pixel to the 256/64 spp, 12-view job."""
@@ -105,15 +125,17 @@ def cpu_baseline(args, target_seconds=15.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=3)
-    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--res', type=int, default=256)
     ap.add_argument('--img', type=int, default=512)
     ap.add_argument('--views', type=int, default=12)
     ap.add_argument('--spp-primal', type=int, default=256)
     ap.add_argument('--spp-grad', type=int, default=64)
     ap.add_argument('--integrator', default='sdf_silhouette_reparam')
+    ap.add_argument('--scaling', choices=('strong', 'weak'), default='strong')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-low-spp', action='store_true')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', 0))
@@ -133,9 +155,17 @@ def main():
     data = synth_grid(args.res, dev)
     grid = dsdf.SdfGrid(data)
     target = dsdf.SdfGrid(synth_grid(args.res, dev, seed=1))
-    # weak scaling: a ring of views*world sensors, dealt round-robin so that every rank sees the whole ring (a contiguous arc
-    # per rank would give the ranks differently expensive views and the step waits for the slowest)
-    sensors = dsdf.get_regular_cameras(args.views * world, resx=args.img, resy=args.img)[rank::world]
+    if args.scaling == 'strong':
+        # the metric's 12 views, partitioned: every rank renders its shard of the SAME ring (round-robin, so that all
+        # ranks see equally expensive views); the job is the same at every N
+        ring = dsdf.get_regular_cameras(args.views, resx=args.img, resy=args.img)
+        mine = parallel.strided_view_shard(list(range(args.views)), rank, world)
+    else:
+        # weak scaling: a ring of views*world sensors, `views` per rank
+        ring = dsdf.get_regular_cameras(args.views * world, resx=args.img, resy=args.img)
+        mine = list(range(args.views * world))[rank::world]
+    sensors = [ring[i] for i in mine]
+    nv = len(sensors)
     grad = torch.zeros_like(data)
     # BASELINE.json C5 (--integrator sdf_direct_reparam): a 3-channel albedo volume of the grid's resolution is optimised too
     shade, shade_g = {}, {}
@@ -144,100 +174,117 @@ def main():
         shade = {'shading': dsdf.Shading(albedo, 1.0, hide_emitters=False)}
         shade_g = dict(shade, grad_albedo=torch.zeros_like(albedo))
     # target images (outside the timed region) -> L1 image gradient sign(img - target)/(H*W*3)
-    tgt = torch.cat([dsdf.render_forward(target, s, 64, seeds=[1000 + i]) for i, s in enumerate(sensors)])
+    tgt = torch.cat([dsdf.render_forward(target, s, 64, seeds=[1000 + i]) for i, s in zip(mine, sensors)]) if nv else None
     scale = 1.0 / (args.img * args.img * 3)
 
     ev = lambda: torch.cuda.Event(enable_timing=True)
-    prim_ms, grad_ms = [], []
 
-    def step(it, timed):
-        # one launch traces all views of the batch (primal), one launch the gradient pass
-        grad.zero_()
-        seeds = [(it * args.views + i) * 2 + 17 * rank for i in range(args.views)]
-        e0, e1, e2 = ev(), ev(), ev()
-        e0.record()
-        img = dsdf.render_forward(grid, sensors, args.spp_primal, seeds=seeds, integrator=args.integrator, **shade)
-        e1.record()
-        gi = torch.sign(img - tgt) * scale
-        dsdf.render_backward(grid, sensors, args.spp_grad, gi, grad_grid=grad, seeds=[s + 1 for s in seeds],
-                             integrator=args.integrator, **shade_g)
-        e2.record()
-        if timed:
-            prim_ms.append((e0, e1)); grad_ms.append((e1, e2))
-        if dist is not None:
-            parallel.all_reduce_gradients([grad] + ([shade_g['grad_albedo']] if shade_g else []))
+    def make_step(spp_p, spp_g, prim_ms, grad_ms):
+        def step(it, timed):
+            # one launch traces all views of this rank's shard (primal), one launch the gradient pass
+            grad.zero_()
+            if nv:
+                seeds = [(it * args.views + i) * 2 for i in mine]
+                e0, e1, e2 = ev(), ev(), ev()
+                e0.record()
+                img = dsdf.render_forward(grid, sensors, spp_p, seeds=seeds, integrator=args.integrator, **shade)
+                e1.record()
+                gi = torch.sign(img - tgt) * scale
+                dsdf.render_backward(grid, sensors, spp_g, gi, grad_grid=grad, seeds=[s + 1 for s in seeds],
+                                     integrator=args.integrator, **shade_g)
+                e2.record()
+                if timed:
+                    prim_ms.append((e0, e1)); grad_ms.append((e1, e2))
+            if dist is not None:
+                parallel.all_reduce_gradients([grad] + ([shade_g['grad_albedo']] if shade_g else []))
+        return step
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for w in range(args.warmup):
-        step(w, False)
-    barrier()
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        step(args.warmup + k, True)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t)
+    def timed_run(step, warmup, steps):
+        for w in range(warmup):
+            step(w, False)
+        barrier()
+        t0 = time.perf_counter()
+        for k in range(steps):
+            step(warmup + k, True)
+        barrier()
+        elapsed = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t)
+        return elapsed
 
-    # per-launch statistics for the algorithmic byte count (untimed; same launch shape as the timed ones)
-    st_p, st_g = dsdf.new_stats(dev), dsdf.new_stats(dev)
-    dsdf.render_forward(grid, sensors, args.spp_primal, seeds=list(range(args.views)), integrator=args.integrator, stats=st_p, **shade)
-    dsdf.render_backward(grid, sensors, args.spp_grad, torch.ones(args.views, args.img, args.img, 3, device=dev) * scale,
-                         grad_grid=torch.zeros_like(data), seeds=list(range(50, 50 + args.views)), integrator=args.integrator, **shade_g,
-                         stats=st_g)
-    sp, sg = dsdf.stats_dict(st_p), dsdf.stats_dict(st_g)
-    prim = [a.elapsed_time(b) for a, b in prim_ms]
-    gradt = [a.elapsed_time(b) for a, b in grad_ms]
-    prim_avg = sum(prim) / len(prim)
-    # DESIGN.md "Algorithmic bytes": 64 fp32 taps per cubic evaluation (trace steps + refinement),
-    # 16 px x 2 ch x 8 B film read-modify-write per lane, one compulsory read of the grid.
-    # (one launch = all `views` sensors of this rank)
-    evals = sp['steps'] + sp['refine_steps']
-    alg_bytes = 256.0 * evals + 16 * 2 * 8.0 * sp['lanes'] + 4.0 * args.res ** 3
-    achieved = alg_bytes / (prim_avg * 1e-3) / 1e9
+    prim_ms, grad_ms = [], []
+    elapsed = timed_run(make_step(args.spp_primal, args.spp_grad, prim_ms, grad_ms), args.warmup, args.steps)
 
-    # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process;
-    # the committed summary of the separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of THIS
-    # command (profiles/summarize.py) is used when it matches the launch shape, else null.
-    traffic = None
-    try:
-        tj = json.load(open(os.path.join(ROOT, 'profiles', 'r01_traffic.json')))
-        Wb = args.img + 4
-        key = f"k_render_pass<false, true> grid={Wb * Wb * args.spp_primal * args.views}"
-        if args.res == 256 and key in tj:
-            traffic = tj[key]['hbm_bytes_per_launch']
-    except (OSError, ValueError, KeyError):
-        pass
+    low = None
+    if not args.no_low_spp:
+        lp, lg = [], []
+        lsteps = max(args.steps, 20)
+        lel = timed_run(make_step(4, 1, lp, lg), 2, lsteps)
+        low = {"value": lsteps / lel if args.scaling == 'strong' else world * lsteps / lel, "unit": "renders/s", "steps": lsteps,
+               "ms_per_step": 1e3 * lel / lsteps,
+               "config": {"workload": f"{args.res}^3 SDF, {args.views} views x {args.img}^2, {args.integrator}, spp primal/grad 4/1 "
+                                      f"(north_star's >= 50 renders/s point, SURVEY F10)"},
+               "primal_ms_per_launch": sum(a.elapsed_time(b) for a, b in lp) / max(len(lp), 1),
+               "grad_ms_per_launch": sum(a.elapsed_time(b) for a, b in lg) / max(len(lg), 1)}
+
+    # per-launch statistics (untimed; same launch shape as the timed ones)
+    out_cfg, roof = {}, None
+    if nv:
+        st_p, st_g = dsdf.new_stats(dev), dsdf.new_stats(dev)
+        dsdf.render_forward(grid, sensors, args.spp_primal, seeds=list(range(nv)), integrator=args.integrator, stats=st_p, **shade)
+        dsdf.render_backward(grid, sensors, args.spp_grad, torch.ones(nv, args.img, args.img, 3, device=dev) * scale,
+                             grad_grid=torch.zeros_like(data), seeds=list(range(50, 50 + nv)), integrator=args.integrator, **shade_g,
+                             stats=st_g)
+        sp, sg = dsdf.stats_dict(st_p), dsdf.stats_dict(st_g)
+        prim = [a.elapsed_time(b) for a, b in prim_ms]
+        gradt = [a.elapsed_time(b) for a, b in grad_ms]
+        prim_avg = sum(prim) / len(prim)
+        # VALU-issue roofline of the primal launch (k_render_pass<false,true,false>): wave-level VALU instructions
+        m = VALU_MODEL['primal']
+        waves = sp['lanes'] / 64.0
+        traced_waves = sp['bbox_lanes'] / 64.0            # lanes that enter the trace loop (after the empty-space proof)
+        valu = m['per_wave_step'] * sp['wave_steps'] + m['per_traced_wave'] * traced_waves + m['per_wave'] * waves
+        achieved = valu / (prim_avg * 1e-3)
+        # SURVEY 8(d) HBM-equivalent figure, kept as a secondary field: 64 fp32 taps per cubic evaluation, film RMW, one grid read
+        evals = sp['steps'] + sp['refine_steps']
+        alg_bytes = 256.0 * evals + 16 * 2 * 8.0 * sp['lanes'] + 4.0 * args.res ** 3
+        roof = {"bound": "valu", "kernel": "k_render_pass<primal>", "achieved": achieved / 1e9, "peak": VALU_PEAK / 1e9,
+                "unit": "G wave-instr/s", "frac": achieved / VALU_PEAK, "traffic": None,
+                "valu_insts_per_launch": valu, "wave_steps_per_launch": sp['wave_steps'], "avg_launch_ms": prim_avg,
+                "lane_utilisation": evals / max(64.0 * sp['wave_steps'], 1.0), "calibration": VALU_MODEL['calibration'],
+                "hbm_equivalent": {"algorithmic_bytes_per_launch": alg_bytes, "GBps": alg_bytes / (prim_avg * 1e-3) / 1e9,
+                                   "frac_of_8TBps": alg_bytes / (prim_avg * 1e-3) / 8e12,
+                                   "note": "SURVEY 8(d) tap-byte model; taps are LDS/L1-resident, so this is not a bound "
+                                           "(measured HBM bytes: profiles/)"}}
+        out_cfg = {"mean_steps_per_bbox_lane": sp['steps'] / max(sp['bbox_lanes'], 1),
+                   "hit_fraction": sp['hits'] / max(sp['lanes'], 1), "traced_fraction": sp['bbox_lanes'] / max(sp['lanes'], 1),
+                   "backward_queue_fraction": sg['queue_len'] / max(sg['lanes'], 1),
+                   "primal_ms_per_launch": prim_avg, "grad_ms_per_launch": sum(gradt) / len(gradt)}
 
     if rank == 0:
+        strong = args.scaling == 'strong'
         out = {
-            "metric": "diff-renders/sec (fwd+bwd) 256^3 SDF, 512^2, 12 views",
-            "value": world * args.steps / elapsed, "unit": "renders/s", "n_gpus": world, "steps": args.steps,
+            "metric": "diff-renders/sec (fwd+bwd) 256^3 SDF, 512^2, 12 views" if strong else
+                      "weak-scaling diff-renders/sec (fwd+bwd) 256^3 SDF, 512^2, 12 views PER GPU",
+            "value": (1 if strong else world) * args.steps / elapsed, "unit": "renders/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"no-tex-12-hq sizes: {args.res}^3 SDF, {args.views} views x {args.img}^2, "
-                                   f"{args.integrator}, spp primal/grad {args.spp_primal}/{args.spp_grad} "
-                                   f"(reference semantics, configs.py:16,19)",
-                       "views_per_gpu": args.views, "spp_primal": args.spp_primal, "spp_grad": args.spp_grad,
-                       "mean_steps_per_bbox_lane": sp['steps'] / max(sp['bbox_lanes'], 1),
-                       "hit_fraction": sp['hits'] / max(sp['lanes'], 1),
-                       "bbox_fraction": sp['bbox_lanes'] / max(sp['lanes'], 1),
-                       "backward_queue_fraction": sg['queue_len'] / max(sg['lanes'], 1),
-                       "primal_ms_per_launch": prim_avg, "grad_ms_per_launch": sum(gradt) / len(gradt),
-                       "views_per_launch": args.views},
-            "roofline": {"bound": "hbm", "kernel": "k_render_pass<primal>", "achieved": achieved, "peak": 8000.0,
-                         "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic,
-                         "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": prim_avg,
-                         "note": "SURVEY 8(d) asks for algorithmic tap bytes / HBM peak AND measured HBM bytes: the taps are served "
-                                 "by L1/LDS (wave cell cache), so frac > 1 and traffic << algorithmic bytes; the kernel is "
-                                 "VALU-issue bound (DESIGN.md section 7)"},
+            "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": dict({"workload": f"no-tex-12-hq sizes: {args.res}^3 SDF, {args.views} views x {args.img}^2, "
+                                        f"{args.integrator}, spp primal/grad {args.spp_primal}/{args.spp_grad} "
+                                        f"(reference semantics, configs.py:16,19)",
+                            "views_total": args.views if strong else args.views * world, "views_this_rank": nv,
+                            "spp_primal": args.spp_primal, "spp_grad": args.spp_grad}, **out_cfg),
+            "roofline": roof,
         }
+        if low is not None:
+            out["low_spp"] = low
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args)
         print(json.dumps(out))

@@ -6,9 +6,12 @@
 // the 5x5 block-pixel window around it; the 25 (+25 weight) partial sums are reduced across the wave
 // through a wave-private LDS transpose (lane l writes column l, lane k sums row k with 16 conflict-free
 // ds_read_b128; two chunks of <= 13 rows) and leave as one atomic per window pixel and channel.
+// `part` (optional): instead of flushing with atomics, the wave leaves its 25 x NCH window sums in part[ch * 25 + slot]
+// for a block-level reduction (film_flush_block) -- used when all waves of the block sit in ONE pixel (spp % 256 == 0):
+// one flush per block instead of one per wave (PMC: the primal launch wrote 8.1 GB for a 25 MB film).
 template <int NCH>     // block channels: NCH - 1 value channels + weight
 __device__ __forceinline__ void film_splat_wave(float *__restrict__ block, const ViewArgs &A, int px, int py,
-                                                float u, float v, const float *vals, float *T, int lid) {
+                                                float u, float v, const float *vals, float *T, int lid, float *part = nullptr) {
     float pfx = u + (DSDF_BORDER - 0.5f), pfy = v + (DSDF_BORDER - 0.5f);
     float fx[5], fy[5];
 #pragma unroll
@@ -24,7 +27,10 @@ __device__ __forceinline__ void film_splat_wave(float *__restrict__ block, const
 #pragma unroll
     for (int ch = 0; ch < NCH; ++ch) {
         const float val = ch < NCH - 1 ? vals[ch] : 1.f;
-        if (ch < NCH - 1 && __ballot(val != 0.f) == 0) continue;     // pixels nobody hits skip the value channel
+        if (ch < NCH - 1 && __ballot(val != 0.f) == 0) {             // pixels nobody hits skip the value channel
+            if (part && lid < 25) part[ch * 25 + lid] = 0.f;
+            continue;
+        }
 #pragma unroll
         for (int k0 = 0; k0 < 25; k0 += DSDF_TROWS) {
             const int nk = (25 - k0) < DSDF_TROWS ? (25 - k0) : DSDF_TROWS;
@@ -52,9 +58,26 @@ __device__ __forceinline__ void film_splat_wave(float *__restrict__ block, const
                         (((a2.x + a2.y) + (a2.z + a2.w)) + ((a3.x + a3.y) + (a3.z + a3.w)));
             }
             wave_lds_sync();
-            if (own && total != 0.f) atomicAdd(block + NCH * ((size_t)qy * A.Wb + qx) + ch, total);
+            if (part) { if (lid < nk) part[ch * 25 + slot] = own ? total : 0.f; }
+            else if (own && total != 0.f) atomicAdd(block + NCH * ((size_t)qy * A.Wb + qx) + ch, total);
         }
     }
+}
+
+// Block-level flush of the per-wave window sums (all DSDF_BLOCK / 64 waves of the block sit in pixel (px, py)):
+// parts[w][ch * 25 + slot], summed over the waves by the first NCH * 25 threads, one atomic per window pixel and channel.
+// Call after __syncthreads().
+template <int NCH>
+__device__ __forceinline__ void film_flush_block(float *__restrict__ block, const ViewArgs &A, int px, int py,
+                                                 const float (*parts)[NCH * 25], int tid) {
+    if (tid >= NCH * 25) return;
+    float total = 0.f;
+#pragma unroll
+    for (int w = 0; w < DSDF_BLOCK / 64; ++w) total += parts[w][tid];
+    const int ch = tid / 25, slot = tid - 25 * ch;
+    const int j5 = slot / 5, i5 = slot - 5 * j5;
+    const int qx = px - 2 + i5, qy = py - 2 + j5;
+    if (total != 0.f && qx >= 0 && qx < A.Wb && qy >= 0 && qy < A.Hb) atomicAdd(block + NCH * ((size_t)qy * A.Wb + qx) + ch, total);
 }
 
 // HDRFilm.develop: crop the border, value / (weight == 0 ? 1 : weight), R=G=B.

@@ -235,6 +235,11 @@ __global__ __launch_bounds__(DSDF_BLOCK, DIRECT ? 1 : (DIFF ? DSDF_DIFF_MINWAVES
     TraceOut trs;                                           // shadow ray (DIRECT)
     bool lit = false;
     Lane L;
+    // wave_uniform == 2: all waves of the block sit in ONE pixel (spp % 256 == 0) -> one film flush per block
+    constexpr int NPART = (DIFF ? 1 : DSDF_BLOCK / 64);
+    __shared__ float film_part[NPART][NCH * 25];
+    const bool block_film = !DIFF && wave_uniform == 2;
+    float *part = block_film ? film_part[(threadIdx.x >> 6) % NPART] : nullptr;
     if (!far) {                                             // wave-uniform when CACHE / wave_uniform
         L = lane_setup(A, P, lane);
         if (CACHE) {
@@ -271,13 +276,18 @@ __global__ __launch_bounds__(DSDF_BLOCK, DIRECT ? 1 : (DIFF ? DSDF_DIFF_MINWAVES
             float rgb[3];
             lit = direct_value(G, P, A, S, L, lane, tr.its_t, DIFF, trs, rgb);
             // (wave_uniform: n_lanes % 64 == 0, so `valid` is wave-uniform too; the tail waves past n_lanes must not splat)
-            if (wave_uniform) { if (valid) film_splat_wave<4>(block, A, L.px, L.py, rp.u, rp.v, rgb, wave_lds[threadIdx.x >> 6], lid); }
+            if (wave_uniform) { if (valid) film_splat_wave<4>(block, A, L.px, L.py, rp.u, rp.v, rgb, wave_lds[threadIdx.x >> 6], lid, part); }
             else if (valid) splat_lane_rgb(block, A.Wb, A.Hb, rp.u, rp.v, rgb, AtomicAdd());
         } else {
             float val = shade_value(G, A, L, tr.its_t);
-            if (wave_uniform) { if (valid) film_splat_wave<2>(block, A, L.px, L.py, rp.u, rp.v, &val, wave_lds[threadIdx.x >> 6], lid); }
+            if (wave_uniform) { if (valid) film_splat_wave<2>(block, A, L.px, L.py, rp.u, rp.v, &val, wave_lds[threadIdx.x >> 6], lid, part); }
             else if (valid) splat_lane(block, A.Wb, A.Hb, rp.u, rp.v, val, AtomicAdd());
         }
+    }
+
+    if (block_film && !far && valid) {                      // `far` and `valid` are block-uniform here (one pixel per block)
+        __syncthreads();
+        film_flush_block<NCH>(block, A, L.px, L.py, film_part, threadIdx.x);
     }
 
     bool need = false;
@@ -313,6 +323,8 @@ __global__ __launch_bounds__(DSDF_BLOCK, DIRECT ? 1 : (DIFF ? DSDF_DIFF_MINWAVES
         int s_ref = wave_sum_i32(valid ? tr.refine_steps : 0);
         int s_val = wave_sum_i32(valid ? 1 : 0);
         int s_need = wave_sum_i32(need ? 1 : 0);
+        // lock-step iterations this wave executed: trace loop + refinement loop (what the VALU-issue roofline counts)
+        int s_wsteps = wave_max_i32(tr.steps) + wave_max_i32(tr.refine_steps);
         if (lid == 0) {
             // 64 interleaved copies of the counters (summed by the caller): spreads the atomics
             // of ~10^7 waves over 64 addresses instead of serialising them on one
@@ -323,6 +335,7 @@ __global__ __launch_bounds__(DSDF_BLOCK, DIRECT ? 1 : (DIFF ? DSDF_DIFF_MINWAVES
             atomicAdd(st + 3, (unsigned long long)s_hit);
             atomicAdd(st + 4, (unsigned long long)s_ref);
             atomicAdd(st + 6, (unsigned long long)s_need);
+            atomicAdd(st + 7, (unsigned long long)s_wsteps);
         }
     }
 }
@@ -334,7 +347,13 @@ __global__ __launch_bounds__(64) void k_backward(GridView G, dsdf_params P, View
                                                  const float *__restrict__ block_adjs,
                                                  float *__restrict__ grad_grid, float *__restrict__ grad_p,
                                                  unsigned long long *stats, ShadeArgs S) {
+#ifdef DSDF_BRICK_SCATTER
     __shared__ float brick[DSDF_BRICK_CAP];
+#define DSDF_WAVE_SCATTER wave_scatter
+#else
+    __shared__ __attribute__((aligned(16))) float brick[DSDF_SCAT_FLOATS];
+#define DSDF_WAVE_SCATTER wave_scatter_t
+#endif
     const ViewArgs &A = VB.v[blockIdx.y];
     constexpr int NCH = DIRECT ? 4 : 2;
     const float *__restrict__ block_adj = block_adjs + (size_t)blockIdx.y * NCH * A.Wb * A.Hb;
@@ -363,9 +382,9 @@ __global__ __launch_bounds__(64) void k_backward(GridView G, dsdf_params P, View
                 n_did += lane_backward(G, P, A, L, tr, block_adj, req) ? 1 : 0;
             }
         }
-        wave_scatter(G, grad_grid, req[0], brick, lid);
-        if (A.integrator != DSDF_SILHOUETTE) wave_scatter(G, grad_grid, req[1], brick, lid);
-        if (DIRECT) wave_scatter(G, grad_grid, req[2], brick, lid);
+        DSDF_WAVE_SCATTER(G, grad_grid, req[0], brick, lid);
+        if (A.integrator != DSDF_SILHOUETTE) DSDF_WAVE_SCATTER(G, grad_grid, req[1], brick, lid);
+        if (DIRECT) DSDF_WAVE_SCATTER(G, grad_grid, req[2], brick, lid);
         if (grad_p) {
             if (req[0].on) p_bar = p_bar + req[0].p_bar;
             if (req[1].on) p_bar = p_bar + req[1].p_bar;
@@ -663,10 +682,10 @@ int dsdf_render_forward(const float *padded, int rx, int ry, int rz, const dsdf_
         }
 #endif
         if (direct) {
-            if (spp % 64 == 0) hipLaunchKernelGGL((k_render_pass<false, true, true>), grid, blk, 0, st, G, pp, VB, ws.block, q, st64, nl, 1, skip, S, tq);
+            if (spp % 64 == 0) hipLaunchKernelGGL((k_render_pass<false, true, true>), grid, blk, 0, st, G, pp, VB, ws.block, q, st64, nl, spp % DSDF_BLOCK == 0 ? 2 : 1, skip, S, tq);
             else hipLaunchKernelGGL((k_render_pass<false, false, true>), grid, blk, 0, st, G, pp, VB, ws.block, q, st64, nl, 0, skip, S, tq);
         } else {
-            if (spp % 64 == 0) hipLaunchKernelGGL((k_render_pass<false, true, false>), grid, blk, 0, st, G, pp, VB, ws.block, q, st64, nl, 1, skip, S, tq);
+            if (spp % 64 == 0) hipLaunchKernelGGL((k_render_pass<false, true, false>), grid, blk, 0, st, G, pp, VB, ws.block, q, st64, nl, spp % DSDF_BLOCK == 0 ? 2 : 1, skip, S, tq);
             else hipLaunchKernelGGL((k_render_pass<false, false, false>), grid, blk, 0, st, G, pp, VB, ws.block, q, st64, nl, 0, skip, S, tq);
         }
         if ((rc = check_launch("k_render_pass<primal>"))) return rc;

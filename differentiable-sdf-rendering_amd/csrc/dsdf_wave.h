@@ -109,6 +109,69 @@ __device__ __forceinline__ void wave_scatter(const GridView &G, float *__restric
     wave_lds_sync();
 }
 
+// Transposed 64-tap scatter for one wave (replaces the ds_add_f32 brick: rocprof showed k_backward stalled on LDS
+// atomics -- SQ_WAIT_INST_LDS 6x SQ_ACTIVE_INST_VALU -- because the samples of a wave share a handful of cells, i.e.
+// their atomics hit the same addresses).  No LDS atomics at all:
+//   1. every active lane writes its 64 tap contributions as ROW `lane` of a 64 x 68 LDS tile (16 ds_write_b128);
+//   2. the wave groups its lanes by B-spline cell (v_readlane / ballot, like the cell cache);
+//   3. per distinct cell, lane k (= tap k) sums column k over the lanes of the group (conflict-free ds_read_b32)
+//      and issues ONE global atomic for that tap -- 64 coalesced atomics (16 rows x 4 consecutive floats) per cell.
+// Destination indices are clamped per tap exactly like scatter_cubic (base clamped to [-3, r-1] first, which leaves
+// every tap's clamped index unchanged).
+#define DSDF_SCAT_STRIDE 68   /* floats per tile row: 16-byte aligned rows, consecutive rows 4 banks apart */
+#define DSDF_SCAT_FLOATS (64 * DSDF_SCAT_STRIDE)
+__device__ __forceinline__ void wave_scatter_t(const GridView &G, float *__restrict__ grad, const ScatterReq &rq,
+                                               float *T, int lid) {
+    const bool on = rq.on;
+    uint64_t todo = __ballot(on);
+    if (!todo) return;
+    CubicSetup s = cubic_setup(G, on ? rq.x : mk(0.f, 0.f, 0.f));
+    const int bx = iclamp(s.ix, -DSDF_APRON, G.rx - 1), by = iclamp(s.iy, -DSDF_APRON, G.ry - 1), bz = iclamp(s.iz, -DSDF_APRON, G.rz - 1);
+    if (on) {
+        float wx[4], wy[4], wz[4], dwx[4], dwy[4], dwz[4];
+        bspline_w(s.ax, wx); bspline_w(s.ay, wy); bspline_w(s.az, wz);
+        bspline_dw(s.ax, dwx); bspline_dw(s.ay, dwy); bspline_dw(s.az, dwz);
+        const float gx = rq.cg.x * (float)G.rx, gy = rq.cg.y * (float)G.ry, gz = rq.cg.z * (float)G.rz;
+        float4 *row = reinterpret_cast<float4 *>(T + lid * DSDF_SCAT_STRIDE);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float azv = wz[k], azd = dwz[k] * gz;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float c0 = azv * wy[j] * rq.cv + azd * wy[j] + azv * dwy[j] * gy;
+                const float c1 = azv * wy[j] * gx;
+                row[k * 4 + j] = make_float4(fmaf(c0, wx[0], c1 * dwx[0]), fmaf(c0, wx[1], c1 * dwx[1]),
+                                             fmaf(c0, wx[2], c1 * dwx[2]), fmaf(c0, wx[3], c1 * dwx[3]));
+            }
+        }
+    }
+    wave_lds_sync();
+    // this lane's tap: k = z tap, j = y tap, i = x tap (tile column = (k*4 + j)*4 + i = lid)
+    const int tk = lid >> 4, tj = (lid >> 2) & 3, ti = lid & 3;
+    // cell key: the three clamped base indices are < 2^21 each for any grid this library accepts (res <= 2^20)
+    const uint64_t key = ((uint64_t)(uint32_t)(bz + DSDF_APRON) << 42) | ((uint64_t)(uint32_t)(by + DSDF_APRON) << 21) | (uint64_t)(uint32_t)(bx + DSDF_APRON);
+    const uint32_t klo = (uint32_t)key, khi = (uint32_t)(key >> 32);
+    while (todo != 0) {
+        const int leader = __builtin_ctzll(todo);
+        const uint32_t llo = (uint32_t)__builtin_amdgcn_readlane((int)klo, leader), lhi = (uint32_t)__builtin_amdgcn_readlane((int)khi, leader);
+        const uint64_t grp = __ballot(on && klo == llo && khi == lhi);
+        todo &= ~grp;
+        const int gbx = __builtin_amdgcn_readlane(bx, leader), gby = __builtin_amdgcn_readlane(by, leader), gbz = __builtin_amdgcn_readlane(bz, leader);
+        float sum = 0.f;
+        uint64_t m = grp;
+        while (m != 0) {                                   // wave-uniform: lanes of this cell
+            const int l = __builtin_ctzll(m);
+            m &= m - 1;
+            sum += T[l * DSDF_SCAT_STRIDE + lid];
+        }
+        if (sum != 0.f) {
+            const int zi = iclamp(gbz + tk, 0, G.rz - 1), yi = iclamp(gby + tj, 0, G.ry - 1), xi = iclamp(gbx + ti, 0, G.rx - 1);
+            atomicAdd(grad + ((size_t)zi * G.ry + yi) * G.rx + xi, sum);
+        }
+    }
+    wave_lds_sync();
+}
+
 // ------------------------------------------------------------------ wave cell cache
 // The 64 lanes of a wave are samples of ONE pixel, so at every trace step they sit in a
 // handful of B-spline cells (measured: 5 distinct cells on average, <= 8 in 87 % and <= 16

@@ -19,7 +19,7 @@ INTEGRATORS = {'sdf_silhouette_reparam': DSDF_SILHOUETTE, 'sdf_simple_shading_re
                'sdf_direct_reparam': DSDF_DIRECT,
                DSDF_SILHOUETTE: DSDF_SILHOUETTE, DSDF_SIMPLE_SHADING: DSDF_SIMPLE_SHADING, DSDF_DIRECT: DSDF_DIRECT}
 
-STAT_NAMES = ('lanes', 'bbox_lanes', 'steps', 'hits', 'refine_steps', 'warp_active', 'queue_len', 'reserved')
+STAT_NAMES = ('lanes', 'bbox_lanes', 'steps', 'hits', 'refine_steps', 'warp_active', 'queue_len', 'wave_steps')
 
 _workspaces = {}
 
@@ -79,11 +79,27 @@ class SdfGrid:
         with torch.cuda.device(data.device):
             _lib.check(lib.dsdf_pad_grid(_ptr(data), self.rx, self.ry, self.rz, _ptr(self.padded), _stream()))
         self.device = data.device
+        self._src = (data.data_ptr(), data._version)          # what the padded copy was built from
         return self
 
+    def in_sync_with(self, data):
+        """True when the padded copy was built from exactly this tensor state (storage and in-place version)."""
+        d = data.detach()
+        return getattr(self, '_src', None) == (d.data_ptr(), d._version)
+
     def set_translation(self, p):
-        """`sdf.p` (python/shapes.py:389, 412): lookups happen at x - p."""
-        px, py, pz = (float(v) for v in (p.detach().cpu().tolist() if isinstance(p, torch.Tensor) else p))
+        """`sdf.p` (python/shapes.py:389, 412): lookups happen at x - p.  A tensor is read back to the host only when
+        it changed since the last call."""
+        if isinstance(p, torch.Tensor):
+            key = (p.data_ptr(), p._version)
+            if getattr(self, '_p_src', None) == key:
+                return self
+            self._p_src = key
+            vals = p.detach().cpu().tolist()
+        else:
+            self._p_src = None
+            vals = p
+        px, py, pz = (float(v) for v in vals)
         self.params.sdf_p[0], self.params.sdf_p[1], self.params.sdf_p[2] = px, py, pz
         return self
 
@@ -355,6 +371,8 @@ class _RenderOp(torch.autograd.Function):
         ctx.shading = shading
         ctx.data_shape = data.shape
         ctx.p_meta = None if p is None else (p.shape, p.dtype, p.device)
+        if not grid.in_sync_with(data):                      # the caller stepped `data` without grid.update(): rebuild the padded copy
+            grid.update(data)
         if p is not None:
             grid.set_translation(p)
         n = len(sensors)

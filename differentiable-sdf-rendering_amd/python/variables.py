@@ -18,6 +18,9 @@ class Adam:
     different shape (i.e. at every upsampling)."""
 
     def __init__(self, lr, params=None, mask_updates=False):
+        # mask_updates (mi.ad.Adam): entries whose gradient is exactly zero keep their moments and their value
+        # ("sparse" update); the reference runs with False (python/configs.py:26)
+        self.mask_updates = bool(mask_updates)
         self.base_lr = lr
         self.lr = {}
         self.vars = {}
@@ -56,15 +59,24 @@ class Adam:
     @torch.no_grad()
     def step(self):
         for k, p in self.vars.items():
-            if p.grad is None:
-                continue
+            # a key without a gradient still takes a step with a zero gradient (the step count advances and the
+            # moments decay), like mi.ad.Adam
+            g = p.grad if p.grad is not None else torch.zeros_like(p)
             t, m, v = self.state[k]
             t += 1
-            m.mul_(0.9).add_(p.grad, alpha=0.1)
-            v.mul_(0.999).addcmul_(p.grad, p.grad, value=0.001)
-            self.state[k] = (t, m, v)
             step = self.lr[k] * math.sqrt(1 - 0.999 ** t) / (1 - 0.9 ** t)
-            p.addcdiv_(m, v.sqrt().add_(1e-8), value=-step)
+            if self.mask_updates:
+                nz = g != 0
+                m_new = 0.9 * m + 0.1 * g
+                v_new = 0.999 * v + 0.001 * g * g
+                m.copy_(torch.where(nz, m_new, m))
+                v.copy_(torch.where(nz, v_new, v))
+                p.sub_(torch.where(nz, step * m / (v.sqrt() + 1e-8), torch.zeros_like(p)))
+            else:
+                m.mul_(0.9).add_(g, alpha=0.1)
+                v.mul_(0.999).addcmul_(g, g, value=0.001)
+                p.addcdiv_(m, v.sqrt().add_(1e-8), value=-step)
+            self.state[k] = (t, m, v)
             p.grad = None
 
 

@@ -169,7 +169,8 @@ size_t dsdf_render_workspace_size(int width, int height, int spp, int n_views, i
  *   image_out : n_views x H x W x 3
  *   stats     : optional device int64[64][8] accumulators -- 64 interleaved copies (to
  *               spread the atomics; sum over the first axis) of {lanes, bbox_lanes,
- *               steps, hits, refine_steps, warp_active, queue_len, 0}
+ *               steps, hits, refine_steps, warp_active, queue_len, wave_steps}; wave_steps = lock-step loop
+ *               iterations summed over the 64-lane waves (trace + refinement), the unit of the VALU-issue roofline
  */
 int dsdf_render_forward(const float *padded, int rx, int ry, int rz, const dsdf_params *prm,
                         const dsdf_camera *cams, int n_views, int width, int height, int spp,

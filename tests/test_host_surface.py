@@ -107,6 +107,20 @@ def test_lr_schedule_and_adam():
     assert opt.lr['k'] == 0.5
     opt['k'] = torch.zeros(4)                      # new shape -> state reset
     assert opt.state['k'][0] == 0
+    # a missing gradient is a zero gradient: the step count advances and the moments decay (mi.ad.Adam)
+    o2 = variables.Adam(lr=0.1, params={'k': p0})
+    o2['k'].grad = torch.ones(3)
+    o2.step()
+    before = o2['k'].detach().clone()
+    o2.step()                                      # no .grad set
+    assert o2.state['k'][0] == 2 and torch.allclose(o2.state['k'][1], torch.full((3,), 0.09))
+    assert not torch.allclose(o2['k'].detach(), before)
+    # mask_updates: entries with a zero gradient keep value and moments
+    o3 = variables.Adam(lr=0.1, params={'k': p0}, mask_updates=True)
+    o3['k'].grad = torch.tensor([1.0, 0.0, -2.0])
+    o3.step()
+    assert float(o3['k'][1]) == -2.0 and float(o3.state['k'][1][1]) == 0.0 and float(o3.state['k'][2][1]) == 0.0
+    assert float(o3['k'][0]) < 1.0 and float(o3['k'][2]) > 3.0
 
 
 def test_vol_and_image_io(tmp_path):
