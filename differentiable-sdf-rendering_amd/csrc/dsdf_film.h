@@ -2,16 +2,15 @@
 // the develop kernels (HDRFilm.develop), their adjoints and tangents.
 #pragma once
 
-// Film splat of one wave whose 64 samples belong to ONE pixel (px,py): their contributions fall into
-// the 5x5 block-pixel window around it; the 25 (+25 weight) partial sums are reduced across the wave
-// through a wave-private LDS transpose (lane l writes column l, lane k sums row k with 16 conflict-free
-// ds_read_b128; two chunks of <= 13 rows) and leave as one atomic per window pixel and channel.
-// `part` (optional): instead of flushing with atomics, the wave leaves its 25 x NCH window sums in part[ch * 25 + slot]
-// for a block-level reduction (film_flush_block) -- used when all waves of the block sit in ONE pixel (spp % 256 == 0):
-// one flush per block instead of one per wave (PMC: the primal launch wrote 8.1 GB for a 25 MB film).
+// Film splat of one wave whose 64 samples belong to ONE pixel (px,py): their contributions fall into the 5x5 block-pixel
+// window around it.  film_accum_wave reduces the 25 (x NCH channels) partial sums across the wave through a wave-private
+// LDS transpose (lane l writes column l, lane k sums row k with 16 conflict-free ds_read_b128; two chunks of <= 13 rows)
+// and ADDS them to acc[ch][chunk] of lanes 0..12 -- so that a wave which renders several 64-sample chunks of the same
+// pixel (spp 256 = 4 chunks) touches memory once per pixel: film_flush_wave then issues one atomic per window pixel and
+// channel (PMC, round 1: the primal launch wrote 8.1 GB for a 25 MB film with one flush per chunk).
 template <int NCH>     // block channels: NCH - 1 value channels + weight
-__device__ __forceinline__ void film_splat_wave(float *__restrict__ block, const ViewArgs &A, int px, int py,
-                                                float u, float v, const float *vals, float *T, int lid, float *part = nullptr) {
+__device__ __forceinline__ void film_accum_wave(int px, int py, float u, float v, const float *vals, float *T, int lid,
+                                                float acc[NCH][2]) {
     float pfx = u + (DSDF_BORDER - 0.5f), pfy = v + (DSDF_BORDER - 0.5f);
     float fx[5], fy[5];
 #pragma unroll
@@ -27,22 +26,15 @@ __device__ __forceinline__ void film_splat_wave(float *__restrict__ block, const
 #pragma unroll
     for (int ch = 0; ch < NCH; ++ch) {
         const float val = ch < NCH - 1 ? vals[ch] : 1.f;
-        if (ch < NCH - 1 && __ballot(val != 0.f) == 0) {             // pixels nobody hits skip the value channel
-            if (part && lid < 25) part[ch * 25 + lid] = 0.f;
-            continue;
-        }
+        if (ch < NCH - 1 && __ballot(val != 0.f) == 0) continue;     // pixels nobody hits skip the value channel
 #pragma unroll
-        for (int k0 = 0; k0 < 25; k0 += DSDF_TROWS) {
+        for (int c = 0; c < 2; ++c) {
+            const int k0 = c * DSDF_TROWS;
             const int nk = (25 - k0) < DSDF_TROWS ? (25 - k0) : DSDF_TROWS;
 #pragma unroll
             for (int k = 0; k < DSDF_TROWS; ++k)
                 if (k < nk) T[k * DSDF_TSTRIDE + lid] = f[k0 + k] * val;
             wave_lds_sync();
-            float total = 0.f;
-            const int slot = k0 + lid;                   // window slot summed by this lane
-            const int j5 = slot / 5, i5 = slot - 5 * j5;
-            const int qx = px - 2 + i5, qy = py - 2 + j5;
-            const bool own = lid < nk && qx >= 0 && qx < A.Wb && qy >= 0 && qy < A.Hb;
             if (lid < nk) {
                 const float4 *row = reinterpret_cast<const float4 *>(T + lid * DSDF_TSTRIDE);
                 float4 a0 = row[0], a1 = row[1], a2 = row[2], a3 = row[3];
@@ -54,30 +46,27 @@ __device__ __forceinline__ void film_splat_wave(float *__restrict__ block, const
                     a2.x += b2.x; a2.y += b2.y; a2.z += b2.z; a2.w += b2.w;
                     a3.x += b3.x; a3.y += b3.y; a3.z += b3.z; a3.w += b3.w;
                 }
-                total = ((a0.x + a0.y) + (a0.z + a0.w)) + ((a1.x + a1.y) + (a1.z + a1.w)) +
-                        (((a2.x + a2.y) + (a2.z + a2.w)) + ((a3.x + a3.y) + (a3.z + a3.w)));
+                acc[ch][c] += ((a0.x + a0.y) + (a0.z + a0.w)) + ((a1.x + a1.y) + (a1.z + a1.w)) +
+                              (((a2.x + a2.y) + (a2.z + a2.w)) + ((a3.x + a3.y) + (a3.z + a3.w)));
             }
             wave_lds_sync();
-            if (part) { if (lid < nk) part[ch * 25 + slot] = own ? total : 0.f; }
-            else if (own && total != 0.f) atomicAdd(block + NCH * ((size_t)qy * A.Wb + qx) + ch, total);
         }
     }
 }
 
-// Block-level flush of the per-wave window sums (all DSDF_BLOCK / 64 waves of the block sit in pixel (px, py)):
-// parts[w][ch * 25 + slot], summed over the waves by the first NCH * 25 threads, one atomic per window pixel and channel.
-// Call after __syncthreads().
 template <int NCH>
-__device__ __forceinline__ void film_flush_block(float *__restrict__ block, const ViewArgs &A, int px, int py,
-                                                 const float (*parts)[NCH * 25], int tid) {
-    if (tid >= NCH * 25) return;
-    float total = 0.f;
+__device__ __forceinline__ void film_flush_wave(float *__restrict__ block, const ViewArgs &A, int px, int py, int lid,
+                                                const float acc[NCH][2]) {
 #pragma unroll
-    for (int w = 0; w < DSDF_BLOCK / 64; ++w) total += parts[w][tid];
-    const int ch = tid / 25, slot = tid - 25 * ch;
-    const int j5 = slot / 5, i5 = slot - 5 * j5;
-    const int qx = px - 2 + i5, qy = py - 2 + j5;
-    if (total != 0.f && qx >= 0 && qx < A.Wb && qy >= 0 && qy < A.Hb) atomicAdd(block + NCH * ((size_t)qy * A.Wb + qx) + ch, total);
+    for (int c = 0; c < 2; ++c) {
+        const int slot = c * DSDF_TROWS + lid;             // window slot owned by this lane in chunk c
+        const int j5 = slot / 5, i5 = slot - 5 * j5;
+        const int qx = px - 2 + i5, qy = py - 2 + j5;
+        const bool own = lid < DSDF_TROWS && slot < 25 && qx >= 0 && qx < A.Wb && qy >= 0 && qy < A.Hb;
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch)
+            if (own && acc[ch][c] != 0.f) atomicAdd(block + NCH * ((size_t)qy * A.Wb + qx) + ch, acc[ch][c]);
+    }
 }
 
 // HDRFilm.develop: crop the border, value / (weight == 0 ? 1 : weight), R=G=B.

@@ -34,7 +34,7 @@
 
 using namespace dsdf;
 
-#define DSDF_BLOCK 256
+#define DSDF_BLOCK 256    /* threads per block of the general (any spp) render pass */
 #define DSDF_TSTRIDE 68   /* 64 + 4: rows 16-byte aligned, ds_read_b128 conflict-free across lanes */
 #define DSDF_TROWS 13     /* film transpose processes the 25 window slots in two chunks of <= 13 rows */
 #define DSDF_WAVE_LDS 1104 /* floats per wave: max(16 cache slots * 68 + 16 slot bases, 13 * 68) */
@@ -141,18 +141,18 @@ __global__ void k_surface_interaction(GridView G, const float *__restrict__ ro, 
 
 #include "dsdf_wave.h"
 
-// Queue of samples that need the backward sweep.  Every render-pass block owns the slot
-// range [block*DSDF_BLOCK, (block+1)*DSDF_BLOCK) and compacts its samples to the front of
-// it (block-level ballot/mbcnt prefix), so queue order stays pixel order: a backward block
-// sees the samples of a few neighbouring pixels and its LDS brick stays small.
+// Queue of samples that need the backward sweep.  The lane space of a view is cut into UNITS of 64 consecutive samples
+// (one wave of the render pass; for spp % 64 == 0 a unit lies inside one pixel).  The wave that renders a unit compacts its
+// samples to the front of the unit's slot range [unit*64, unit*64 + 64) (ballot / v_mbcnt prefix), so queue order stays
+// pixel order: a backward wave gathers the samples of four neighbouring units, i.e. of one or a few neighbouring pixels.
 struct Queue {
-    uint32_t *count;  // per render-pass block
+    uint32_t *count;  // per unit
     uint32_t *lane;
     float *rec;       // `rows` rows (SoA, stride = cap), indexed by sample: its_t, warp_t, wtd.xyz, ww, wwd.xyz
                       // of the primary ray (9) and, for sdf_direct_reparam, of the shadow ray (18)
     uint32_t rows;
-    uint32_t cap;     // slots per view (= nblk * DSDF_BLOCK)
-    uint32_t nblk;    // render-pass blocks per view
+    uint32_t cap;     // slots per view (= nunits * 64)
+    uint32_t nunits;  // units per view
 };
 
 // Views of one launch (grid.y = view): all sensors of a batch are traced by ONE kernel so
@@ -162,7 +162,7 @@ struct Queue {
 struct ViewBatch { ViewArgs v[DSDF_MAX_BATCH]; };
 
 __device__ __forceinline__ Queue view_queue(Queue q, uint32_t view) {
-    q.count += (size_t)view * q.nblk;
+    q.count += (size_t)view * q.nunits;
     q.lane += (size_t)view * q.cap;
     q.rec += (size_t)view * q.cap * q.rows;
     return q;
@@ -187,187 +187,260 @@ __device__ __forceinline__ void load_record(const float *r, size_t c, TraceOut &
 #include "dsdf_tail.h"
 
 // ------------------------------------------------------------------ render pass
-#ifndef DSDF_DIFF_CACHE
-#define DSDF_DIFF_CACHE 0   /* the gradient pass is VALU-bound: per-lane fetch measured faster */
-#endif
+// Two kernels generate, trace, shade and splat the film samples (lane = pixel * spp + sample, reparam.py:140-155):
+//   k_render_items  spp % 64 == 0: every 64-lane wave sits in ONE pixel.  The pixels that survive the empty-space proof are
+//                   compacted into a work list (k_build_items) and traced by PERSISTENT single-wave workers: a wave takes the
+//                   next pixel with one atomic ticket, renders its spp / 64 chunks one after the other (cell cache for the
+//                   value-only march, per-lane gathers + tail hand-off for the differentiable one), reduces the film
+//                   contributions of ALL chunks across the wave and flushes the 5x5 window once.  (Round-2 PMC on the
+//                   block-per-256-lanes predecessor: 71 % of the launched waves were empty, resident waves 5.9 / SIMD of 8 --
+//                   the LDS and the four wave slots of a block stayed allocated until its slowest wave had finished.)
+//   k_render_pass   any spp: one lane per sample in reference order, per-lane fetches and film atomics.
+// DIRECT = sdf_direct_reparam: a second (shadow) ray per hit sample, rgb film block (4 channels), own instantiations so
+// that the one-channel integrators keep their register budget.
 #ifndef DSDF_DIFF_MINWAVES
 #define DSDF_DIFF_MINWAVES 1
 #endif
-// DIRECT = sdf_direct_reparam: a second (shadow) ray per hit sample, rgb film block (4 channels), own instantiation so
-// that the one-channel integrators keep their register budget.
-template <bool DIFF, bool CACHE, bool DIRECT>
-__global__ __launch_bounds__(DSDF_BLOCK, DIRECT ? 1 : (DIFF ? DSDF_DIFF_MINWAVES : DSDF_PRIMAL_MINWAVES)) void k_render_pass(GridView G, dsdf_params P, ViewBatch VB,
-                                                            float *__restrict__ blocks, Queue qall,
-                                                            unsigned long long *stats, uint32_t n_lanes,
-                                                            int wave_uniform, const unsigned char *__restrict__ skip,
-                                                            ShadeArgs S, TailQueue tq) {
+
+__device__ __forceinline__ void clear_trace(TraceOut &tr) {
+    tr.its_t = INFINITY; tr.warp_t = INFINITY; tr.warp_weight = 0.f; tr.weight_sum = 0.f;
+    tr.warp_t_d = mk(0.f, 0.f, 0.f); tr.warp_weight_d = mk(0.f, 0.f, 0.f);
+    tr.steps = 0; tr.refine_steps = 0;
+}
+
+struct WaveStats { int lanes, bbox, steps, hits, refine, need, wsteps; };
+
+__device__ __forceinline__ void add_stats(WaveStats &ws, const TraceOut &tr, bool valid, bool need) {
+    ws.lanes += wave_sum_i32(valid ? 1 : 0);
+    ws.bbox += wave_sum_i32(valid && tr.steps > 0 ? 1 : 0);
+    ws.steps += wave_sum_i32(valid ? tr.steps : 0);
+    ws.hits += wave_sum_i32(valid && tr.its_t < INFINITY ? 1 : 0);
+    ws.refine += wave_sum_i32(valid ? tr.refine_steps : 0);
+    ws.need += wave_sum_i32(need ? 1 : 0);
+    // lock-step iterations this wave executed: trace loop + refinement loop (what the VALU-issue roofline counts)
+    ws.wsteps += wave_max_i32(tr.steps) + wave_max_i32(tr.refine_steps);
+}
+
+__device__ __forceinline__ void flush_stats(unsigned long long *stats, const WaveStats &ws, uint32_t spread, int lid) {
+    if (lid != 0) return;
+    // 64 interleaved copies of the counters (summed by the caller): spreads the atomics over 64 addresses
+    unsigned long long *st = stats + (size_t)(spread & 63u) * 8;
+    atomicAdd(st + 0, (unsigned long long)ws.lanes);
+    atomicAdd(st + 1, (unsigned long long)ws.bbox);
+    atomicAdd(st + 2, (unsigned long long)ws.steps);
+    atomicAdd(st + 3, (unsigned long long)ws.hits);
+    atomicAdd(st + 4, (unsigned long long)ws.refine);
+    atomicAdd(st + 6, (unsigned long long)ws.need);
+    atomicAdd(st + 7, (unsigned long long)ws.wsteps);
+}
+
+// wave-level compaction of the samples that need the backward sweep into their unit's slots
+__device__ __forceinline__ void queue_unit(const Queue &q, uint32_t unit, uint32_t lane, bool need, int lid, const TraceOut &tr,
+                                           const TraceOut *trs) {
+    const uint64_t m = __ballot(need);
+    if (lid == 0) q.count[unit] = (uint32_t)__popcll(m);
+    if (need) {
+        q.lane[unit * 64 + mask_prefix(m)] = lane;
+        store_record(q.rec + lane, q.cap, tr);              // records are dense by sample index
+        if (trs) store_record(q.rec + lane + 9 * (size_t)q.cap, q.cap, *trs);
+    }
+}
+
+// Work list of a launch: the film-block pixels of all its views whose samples must be generated (k_skip_dilate bit 2 / 3
+// clear), appended block-wise (one atomic per 256 pixels), entry = view * Wb * Hb + pixel.  items[0] = count, items[1] = ticket.
+#define DSDF_ITEM_HDR 4
+__global__ void k_build_items(ViewBatch VB, int nv, const unsigned char *__restrict__ skip, unsigned far_bit, uint32_t *__restrict__ items) {
+    const ViewArgs &A = VB.v[0];
+    const uint32_t npix = (uint32_t)(A.Wb * A.Hb);
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool in = i < npix * (uint32_t)nv;
+    const bool live = in && !(skip && (skip[i] & far_bit));
+    const uint64_t m = __ballot(live);
+    __shared__ uint32_t wbase[4];
+    __shared__ uint32_t bbase;
+    const int w = threadIdx.x >> 6, lid = lane_id();
+    if (lid == 0) wbase[w] = (uint32_t)__popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t t = 0;
+        for (int k = 0; k < 4; ++k) { uint32_t c = wbase[k]; wbase[k] = t; t += c; }
+        bbase = t ? atomicAdd(items, t) : 0u;
+    }
+    __syncthreads();
+    if (live) items[DSDF_ITEM_HDR + bbase + wbase[w] + mask_prefix(m)] = i;
+}
+
+template <bool DIFF, bool DIRECT, bool STATS>
+__global__ __launch_bounds__(64, DIRECT ? 1 : (DIFF ? DSDF_DIFF_MINWAVES : DSDF_PRIMAL_MINWAVES))
+void k_render_items(GridView G, dsdf_params P, ViewBatch VB, float *__restrict__ blocks, Queue qall, unsigned long long *stats,
+                    const unsigned char *__restrict__ skip, ShadeArgs S, TailQueue tq, uint32_t *__restrict__ items) {
+    constexpr int NCH = DIRECT ? 4 : 2;
+    // wave-private LDS scratch: cell cache during tracing, film transpose afterwards
+    __shared__ __attribute__((aligned(16))) float wave_lds[DSDF_WAVE_LDS];
+    const int lid = lane_id();
+    const uint32_t npix = (uint32_t)(VB.v[0].Wb * VB.v[0].Hb);
+    const uint32_t chunks = (uint32_t)VB.v[0].spp >> 6;
+    // work item = one 64-sample chunk of one listed pixel (wave-uniform values are pinned to SGPRs)
+    const uint32_t n_items = (uint32_t)__builtin_amdgcn_readfirstlane((int)items[0]) * chunks;
+    WaveStats wst = {0, 0, 0, 0, 0, 0, 0};
+    // the ticket of the NEXT item is taken while the current one is traced (one L2 round trip, off the critical path)
+    uint32_t next = 0;
+    if (lid == 0) next = atomicAdd(items + 1, 1u);
+    next = (uint32_t)__builtin_amdgcn_readfirstlane((int)next);
+    while (next < n_items) {
+        const uint32_t item = next;
+        if (lid == 0) next = atomicAdd(items + 1, 1u);
+        const uint32_t e = (uint32_t)__builtin_amdgcn_readfirstlane((int)items[DSDF_ITEM_HDR + item / chunks]);
+        const uint32_t view = e / npix, pix = e - view * npix;
+        const ViewArgs &A = VB.v[view];
+        float *__restrict__ block = blocks + (size_t)view * NCH * npix;
+        const int py = (int)(pix / (uint32_t)A.Wb), px = (int)(pix - (uint32_t)py * (uint32_t)A.Wb);
+        // empty-space proof of this pixel: the result of tracing is known -- a miss with no warp -- so the loop is skipped
+        const bool skip_trace = skip && (__builtin_amdgcn_readfirstlane((int)skip[e]) & (DIFF ? 2 : 1));
+        const uint32_t unit = pix * chunks + item % chunks;
+        const uint32_t lane = unit * 64u + (uint32_t)lid;
+        TraceOut tr, trs;
+        clear_trace(tr);
+        bool lit = false;
+        const Lane L = lane_setup(A, P, lane);
+        if (!skip_trace) {
+            if (DIFF) {
+                DirectFetch F;
+                if (!DIRECT && !STATS && tq.state) {
+                    HandOff ho;
+                    ho.tq = tq; ho.sub = item % DSDF_TAIL_SUBQ; ho.view = view; ho.lane = lane;
+                    trace_diff(G, P, L.ray.o, L.ray.d, L.ray.maxt, tr, F, ho);
+                } else trace_diff(G, P, L.ray.o, L.ray.d, L.ray.maxt, tr, F);
+            } else {
+                WaveCellCache F; F.taps = wave_lds; F.lid = lid;
+                trace_plain(G, P, L.ray.o, L.ray.d, L.ray.maxt, tr, F);
+            }
+        }
+        float acc[NCH][2];
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch) { acc[ch][0] = 0.f; acc[ch][1] = 0.f; }
+        const Reproj rp = reproject(A.cam, P, L.ray.o + L.ray.d, A.W, A.H);
+        if (DIRECT) {
+            float rgb[3];
+            lit = direct_value(G, P, A, S, L, lane, tr.its_t, DIFF, trs, rgb);
+            film_accum_wave<NCH>(px, py, rp.u, rp.v, rgb, wave_lds, lid, acc);
+        } else {
+            const float val = shade_value(G, A, L, tr.its_t);
+            film_accum_wave<NCH>(px, py, rp.u, rp.v, &val, wave_lds, lid, acc);
+        }
+        film_flush_wave<NCH>(block, A, px, py, lid, acc);
+        bool need = false;
+        if (DIFF) {
+            const bool hit = tr.its_t < INFINITY;
+            const bool warp_cand = (A.flags & DSDF_REPARAM) && warp_weight_positive(G, P, L.ray.o, L.ray.d, tr);
+            need = warp_cand || (DIRECT ? lit : (hit && A.integrator == DSDF_SIMPLE_SHADING));
+            queue_unit(view_queue(qall, view), unit, lane, need, lid, tr, DIRECT ? &trs : nullptr);
+        }
+        if (STATS) add_stats(wst, tr, true, need);
+        next = (uint32_t)__builtin_amdgcn_readfirstlane((int)next);
+    }
+    if (STATS) flush_stats(stats, wst, blockIdx.x, lid);
+}
+
+// General pass (any spp): one lane per sample, per-lane fetches and film atomics.
+template <bool DIFF, bool DIRECT>
+__global__ __launch_bounds__(DSDF_BLOCK) void k_render_pass(GridView G, dsdf_params P, ViewBatch VB, float *__restrict__ blocks,
+                                                            Queue qall, unsigned long long *stats, uint32_t n_lanes,
+                                                            const unsigned char *__restrict__ skip, ShadeArgs S) {
     const ViewArgs &A = VB.v[blockIdx.y];
     constexpr int NCH = DIRECT ? 4 : 2;
     float *__restrict__ block = blocks + (size_t)blockIdx.y * NCH * A.Wb * A.Hb;
     const Queue q = view_queue(qall, blockIdx.y);
-    // (blocks are issued round-robin over the 8 XCDs; giving each XCD a contiguous eighth of the film for L2
-    //  locality was measured 1.7x SLOWER: film regions differ wildly in cost and the static split unbalances)
-    const uint32_t bid = blockIdx.x;
-    uint32_t lane = bid * DSDF_BLOCK + threadIdx.x;
+    uint32_t lane = blockIdx.x * DSDF_BLOCK + threadIdx.x;
     const bool valid = lane < n_lanes;
     if (!valid) lane = n_lanes - 1;   // keep the wave converged for the cross-lane code
     const int lid = lane_id();
-    // wave-private LDS scratch: cell cache during tracing, film transpose afterwards
-    __shared__ __attribute__((aligned(16))) float wave_lds[DSDF_BLOCK / 64][DSDF_WAVE_LDS];
-    TraceOut tr;
-    tr.its_t = INFINITY; tr.warp_t = INFINITY; tr.warp_weight = 0.f; tr.weight_sum = 0.f;
-    tr.warp_t_d = mk(0.f, 0.f, 0.f); tr.warp_weight_d = mk(0.f, 0.f, 0.f);
-    tr.steps = 0; tr.refine_steps = 0;
-    // empty-space proof for this pixel (wave-uniform when the wave sits in one pixel).  skip_trace: the
-    // result of tracing is known -- a miss with no warp -- so the loop is skipped; far: nothing this
-    // sample does can reach an output (k_skip_dilate), so it is not generated.
+    TraceOut tr, trs;
+    clear_trace(tr);
+    // empty-space proof for this sample's pixel.  skip_trace: a miss with no warp is known; far: nothing this sample does
+    // can reach an output (k_skip_dilate), so it is not generated.
     bool skip_trace = false, far = false;
     if (skip) {
         int px, py;
         lane_pixel(A, lane, px, py);
-        unsigned f = skip[(size_t)blockIdx.y * A.Wb * A.Hb + (size_t)py * A.Wb + px];
+        const unsigned f = skip[(size_t)blockIdx.y * A.Wb * A.Hb + (size_t)py * A.Wb + px];
         skip_trace = (f & (DIFF ? 2u : 1u)) != 0;
-#ifndef DSDF_NO_FAR
         far = (f & (DIFF ? 8u : 4u)) != 0;
-#endif
-        if (DIRECT && !S.hide_emitters) far = false;        // the background is the environment, not zero
     }
-    TraceOut trs;                                           // shadow ray (DIRECT)
     bool lit = false;
     Lane L;
-    // wave_uniform == 2: all waves of the block sit in ONE pixel (spp % 256 == 0) -> one film flush per block
-    constexpr int NPART = (DIFF ? 1 : DSDF_BLOCK / 64);
-    __shared__ float film_part[NPART][NCH * 25];
-    const bool block_film = !DIFF && wave_uniform == 2;
-    float *part = block_film ? film_part[(threadIdx.x >> 6) % NPART] : nullptr;
-    if (!far) {                                             // wave-uniform when CACHE / wave_uniform
+    if (!far) {
         L = lane_setup(A, P, lane);
-        if (CACHE) {
-            if (!skip_trace) {                              // wave-uniform branch (CACHE implies one pixel per wave)
-                WaveCellCache F; F.taps = wave_lds[threadIdx.x >> 6]; F.lid = lid;
-                if (DIFF) trace_diff(G, P, L.ray.o, L.ray.d, L.ray.maxt, tr, F);
-#if DSDF_TAIL_HANDOFF > 0
-                else if (!DIRECT && tq.entry) {
-                    bool unfinished; float resume_t;
-                    trace_plain_handoff(G, P, L.ray.o, L.ray.d, L.ray.maxt, tr, F, unfinished, resume_t);
-                    tail_enqueue(tq, blockIdx.y, blockIdx.x % DSDF_TAIL_SUBQ, valid && unfinished, lane, resume_t);
-                }
-#endif
-                else trace_plain(G, P, L.ray.o, L.ray.d, L.ray.maxt, tr, F);
-            }
-        } else if (!skip_trace) {
-#if DSDF_TAIL_HANDOFF > 0
-            if (DIFF && !DIRECT && tq.state && wave_uniform) {      // wave-uniform branch: the wave sits in one pixel
-                bool unfinished; float st[DSDF_TAIL_WORDS - 1];
-                trace_diff_handoff(G, P, L.ray.o, L.ray.d, L.ray.maxt, tr, unfinished, st);
-                tail_enqueue_diff(tq, blockIdx.y, blockIdx.x % DSDF_TAIL_SUBQ, valid && unfinished, lane, st);
-            } else
-#endif
+        if (!skip_trace) {
             if (DIFF) trace_diff(G, P, L.ray.o, L.ray.d, L.ray.maxt, tr);
             else trace_plain(G, P, L.ray.o, L.ray.d, L.ray.maxt, tr);
         }
-        if (skip_trace) {
-            tr.its_t = INFINITY; tr.warp_t = INFINITY; tr.warp_weight = 0.f; tr.weight_sum = 0.f;
-            tr.warp_t_d = mk(0.f, 0.f, 0.f); tr.warp_weight_d = mk(0.f, 0.f, 0.f);
-            tr.steps = 0; tr.refine_steps = 0;
-        }
-        Reproj rp = reproject(A.cam, P, L.ray.o + L.ray.d, A.W, A.H);
+        const Reproj rp = reproject(A.cam, P, L.ray.o + L.ray.d, A.W, A.H);
         if (DIRECT) {
             float rgb[3];
             lit = direct_value(G, P, A, S, L, lane, tr.its_t, DIFF, trs, rgb);
-            // (wave_uniform: n_lanes % 64 == 0, so `valid` is wave-uniform too; the tail waves past n_lanes must not splat)
-            if (wave_uniform) { if (valid) film_splat_wave<4>(block, A, L.px, L.py, rp.u, rp.v, rgb, wave_lds[threadIdx.x >> 6], lid, part); }
-            else if (valid) splat_lane_rgb(block, A.Wb, A.Hb, rp.u, rp.v, rgb, AtomicAdd());
+            if (valid) splat_lane_rgb(block, A.Wb, A.Hb, rp.u, rp.v, rgb, AtomicAdd());
         } else {
-            float val = shade_value(G, A, L, tr.its_t);
-            if (wave_uniform) { if (valid) film_splat_wave<2>(block, A, L.px, L.py, rp.u, rp.v, &val, wave_lds[threadIdx.x >> 6], lid, part); }
-            else if (valid) splat_lane(block, A.Wb, A.Hb, rp.u, rp.v, val, AtomicAdd());
+            const float val = shade_value(G, A, L, tr.its_t);
+            if (valid) splat_lane(block, A.Wb, A.Hb, rp.u, rp.v, val, AtomicAdd());
         }
     }
-
-    if (block_film && !far && valid) {                      // `far` and `valid` are block-uniform here (one pixel per block)
-        __syncthreads();
-        film_flush_block<NCH>(block, A, L.px, L.py, film_part, threadIdx.x);
-    }
-
     bool need = false;
     if (DIFF) {
-        bool hit = tr.its_t < INFINITY;
-        bool warp_cand = !far && (A.flags & DSDF_REPARAM) && warp_weight_positive(G, P, L.ray.o, L.ray.d, tr);
+        const bool hit = tr.its_t < INFINITY;
+        const bool warp_cand = !far && (A.flags & DSDF_REPARAM) && warp_weight_positive(G, P, L.ray.o, L.ray.d, tr);
         need = valid && (warp_cand || (DIRECT ? lit : (hit && A.integrator == DSDF_SIMPLE_SHADING)));
-        // block-level compaction: per-wave ballot + mbcnt prefix, wave totals through LDS
-        __shared__ uint32_t wave_cnt[DSDF_BLOCK / 64];
-        uint64_t m = __ballot(need);
-        const int w = threadIdx.x >> 6;
-        if (lid == 0) wave_cnt[w] = (uint32_t)__popcll(m);
-        __syncthreads();
-        uint32_t base = 0, total = 0;
-#pragma unroll
-        for (int i = 0; i < DSDF_BLOCK / 64; ++i) {
-            uint32_t c = wave_cnt[i];
-            if (i < w) base += c;
-            total += c;
-        }
-        if (threadIdx.x == 0) q.count[bid] = total;
-        if (need) {
-            uint32_t idx = bid * DSDF_BLOCK + base + mask_prefix(m);
-            q.lane[idx] = lane;
-            store_record(q.rec + lane, q.cap, tr);          // records are dense by sample index
-            if (DIRECT) store_record(q.rec + lane + 9 * (size_t)q.cap, q.cap, trs);
-        }
+        queue_unit(q, (blockIdx.x * DSDF_BLOCK + threadIdx.x) >> 6, lane, need, lid, tr, DIRECT ? &trs : nullptr);
     }
     if (stats) {
-        int s_bbox = wave_sum_i32(valid && tr.steps > 0 ? 1 : 0);
-        int s_steps = wave_sum_i32(valid ? tr.steps : 0);
-        int s_hit = wave_sum_i32(valid && tr.its_t < INFINITY ? 1 : 0);
-        int s_ref = wave_sum_i32(valid ? tr.refine_steps : 0);
-        int s_val = wave_sum_i32(valid ? 1 : 0);
-        int s_need = wave_sum_i32(need ? 1 : 0);
-        // lock-step iterations this wave executed: trace loop + refinement loop (what the VALU-issue roofline counts)
-        int s_wsteps = wave_max_i32(tr.steps) + wave_max_i32(tr.refine_steps);
-        if (lid == 0) {
-            // 64 interleaved copies of the counters (summed by the caller): spreads the atomics
-            // of ~10^7 waves over 64 addresses instead of serialising them on one
-            unsigned long long *st = stats + (size_t)(blockIdx.x & 63u) * 8;
-            atomicAdd(st + 0, (unsigned long long)s_val);
-            atomicAdd(st + 1, (unsigned long long)s_bbox);
-            atomicAdd(st + 2, (unsigned long long)s_steps);
-            atomicAdd(st + 3, (unsigned long long)s_hit);
-            atomicAdd(st + 4, (unsigned long long)s_ref);
-            atomicAdd(st + 6, (unsigned long long)s_need);
-            atomicAdd(st + 7, (unsigned long long)s_wsteps);
-        }
+        WaveStats wst = {0, 0, 0, 0, 0, 0, 0};
+        add_stats(wst, tr, valid, need);
+        flush_stats(stats, wst, blockIdx.x, lid);
     }
 }
 
-// One single-wave block per render-pass block: it walks that block's queued samples 64 at a time
-// (usually one round: ~12 % of 256 samples), holds one 8 KB brick, so a CU keeps ~20 working waves.
+// Backward sweep: one single-wave block per FOUR consecutive units of a view (256 samples: one pixel at spp 256, four at spp 64;
+// ~12 % of them are queued).  It gathers the queued samples of its units 64 at a time (usually one round).
+struct UnitGather {
+    uint32_t c[4], total, unit0;
+    __device__ __forceinline__ void init(const Queue &q, uint32_t group) {
+        unit0 = group * 4u;
+        total = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { c[k] = (unit0 + k < q.nunits) ? q.count[unit0 + k] : 0u; total += c[k]; }
+    }
+    // queue slot of the s-th queued sample of the group
+    __device__ __forceinline__ uint32_t slot(uint32_t s) const {
+        uint32_t u = 0, r = s;
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+            if (u == (uint32_t)k && r >= c[k]) { r -= c[k]; u = k + 1; }
+        return (unit0 + u) * 64u + r;
+    }
+};
+
 template <bool DIRECT>
 __global__ __launch_bounds__(64) void k_backward(GridView G, dsdf_params P, ViewBatch VB, Queue qall,
                                                  const float *__restrict__ block_adjs,
                                                  float *__restrict__ grad_grid, float *__restrict__ grad_p,
                                                  unsigned long long *stats, ShadeArgs S) {
-#ifdef DSDF_BRICK_SCATTER
-    __shared__ float brick[DSDF_BRICK_CAP];
-#define DSDF_WAVE_SCATTER wave_scatter
-#else
-    __shared__ __attribute__((aligned(16))) float brick[DSDF_SCAT_FLOATS];
-#define DSDF_WAVE_SCATTER wave_scatter_t
-#endif
+    __shared__ __attribute__((aligned(16))) float tile[DSDF_SCAT_FLOATS];
     const ViewArgs &A = VB.v[blockIdx.y];
     constexpr int NCH = DIRECT ? 4 : 2;
     const float *__restrict__ block_adj = block_adjs + (size_t)blockIdx.y * NCH * A.Wb * A.Hb;
     const Queue q = view_queue(qall, blockIdx.y);
-    const uint32_t count = q.count[blockIdx.x];            // samples queued by render-pass block blockIdx.x
+    UnitGather ug;
+    ug.init(q, blockIdx.x);
+    const uint32_t count = ug.total;
     const int lid = lane_id();
     int n_did = 0;
-    V3 p_bar = mk(0.f, 0.f, 0.f);                          // dL/d(sdf.p) of this block's samples
+    V3 p_bar = mk(0.f, 0.f, 0.f);                          // dL/d(sdf.p) of this group's samples
     for (uint32_t s0 = 0; s0 < count; s0 += 64) {
-        const uint32_t slot = s0 + threadIdx.x;
+        const uint32_t si = s0 + threadIdx.x;
         ScatterReq req[3];
         req[0].on = false; req[1].on = false; req[2].on = false;
-        if (slot < count) {
-            const uint32_t lane = q.lane[blockIdx.x * DSDF_BLOCK + slot];
+        if (si < count) {
+            const uint32_t lane = q.lane[ug.slot(si)];
             TraceOut tr;
             load_record(q.rec + lane, q.cap, tr);
             Lane L = lane_setup(A, P, lane);
@@ -382,9 +455,9 @@ __global__ __launch_bounds__(64) void k_backward(GridView G, dsdf_params P, View
                 n_did += lane_backward(G, P, A, L, tr, block_adj, req) ? 1 : 0;
             }
         }
-        DSDF_WAVE_SCATTER(G, grad_grid, req[0], brick, lid);
-        if (A.integrator != DSDF_SILHOUETTE) DSDF_WAVE_SCATTER(G, grad_grid, req[1], brick, lid);
-        if (DIRECT) DSDF_WAVE_SCATTER(G, grad_grid, req[2], brick, lid);
+        wave_scatter_t(G, grad_grid, req[0], tile, lid);
+        if (A.integrator != DSDF_SILHOUETTE) wave_scatter_t(G, grad_grid, req[1], tile, lid);
+        if (DIRECT) wave_scatter_t(G, grad_grid, req[2], tile, lid);
         if (grad_p) {
             if (req[0].on) p_bar = p_bar + req[0].p_bar;
             if (req[1].on) p_bar = p_bar + req[1].p_bar;
@@ -409,9 +482,10 @@ __global__ __launch_bounds__(64) void k_forward_tangent(GridView G, const float 
     const ViewArgs &A = VB.v[blockIdx.y];
     float *__restrict__ dblock = dblocks + (size_t)blockIdx.y * 2 * A.Wb * A.Hb;
     const Queue q = view_queue(qall, blockIdx.y);
-    const uint32_t count = q.count[blockIdx.x];
-    for (uint32_t slot = threadIdx.x; slot < count; slot += 64) {
-        const uint32_t lane = q.lane[blockIdx.x * DSDF_BLOCK + slot];
+    UnitGather ug;
+    ug.init(q, blockIdx.x);
+    for (uint32_t si = threadIdx.x; si < ug.total; si += 64) {
+        const uint32_t lane = q.lane[ug.slot(si)];
         TraceOut tr;
         load_record(q.rec + lane, q.cap, tr);
         Lane L = lane_setup(A, P, lane);
@@ -444,47 +518,53 @@ struct Workspace {
     uint32_t *count, *qlane;
     float *qrec;
     unsigned char *skip;
-    char *tail;            // tail hand-off of the gradient sweep (DSDF_TAIL_HANDOFF > 0)
+    uint32_t *items;       // work list of the persistent render kernel: header + one entry per film-block pixel and view
+    char *tail;            // tail hand-off queue of the gradient sweep
     size_t tail_bytes;
-    uint32_t cap, nblk;
+    uint32_t cap, nunits, tail_cap_sub;
     size_t bytes;
 };
 
 // Workspace for `nv` views processed by one launch (film channels and queue-record rows depend on the integrator).
-static Workspace carve(void *base, int W, int H, int spp, int nv, int integrator) {
+// A forward-only workspace (diff = false) carries no backward queue, film-block adjoint or tail queue.
+static Workspace carve(void *base, int W, int H, int spp, int nv, int integrator, bool diff = true) {
     Workspace ws;
     const size_t nch = (size_t)film_channels(integrator), rows = integrator == DSDF_DIRECT ? 18 : 9;
     size_t Wb = W + 2 * DSDF_BORDER, Hb = H + 2 * DSDF_BORDER;
     size_t nl = Wb * Hb * (size_t)spp;
-    size_t nblk = (nl + DSDF_BLOCK - 1) / DSDF_BLOCK;
-    size_t cap = nblk * DSDF_BLOCK;
+    size_t nunits = (nl + DSDF_BLOCK - 1) / DSDF_BLOCK * (DSDF_BLOCK / 64);
+    size_t cap = nunits * 64;
     size_t off = 0;
     char *p = (char *)base;
     ws.block = (float *)(p + off); off += align_up(nv * Wb * Hb * nch * sizeof(float), 256);
-    ws.block_adj = (float *)(p + off); off += align_up(nv * Wb * Hb * nch * sizeof(float), 256);
-    ws.count = (uint32_t *)(p + off); off += align_up(nv * nblk * sizeof(uint32_t), 256);
-    ws.qlane = (uint32_t *)(p + off); off += align_up(nv * cap * sizeof(uint32_t), 256);
-    ws.qrec = (float *)(p + off); off += align_up(nv * cap * rows * sizeof(float), 256);
     ws.skip = (unsigned char *)(p + off); off += align_up(nv * Wb * Hb, 256);
-    ws.tail = nullptr; ws.tail_bytes = 0;
-#if DSDF_TAIL_HANDOFF > 0
-    {   // per view: DSDF_TAIL_SUBQ counters + sub-queues of march states (at most DSDF_TAIL_HANDOFF rays per wave)
-        const size_t cap_sub = (nblk + DSDF_TAIL_SUBQ - 1) / DSDF_TAIL_SUBQ * (DSDF_BLOCK / 64) * DSDF_TAIL_HANDOFF;
-        ws.tail_bytes = align_up((size_t)nv * DSDF_TAIL_SUBQ * 2 * sizeof(uint32_t), 256) +
-                        align_up((size_t)nv * DSDF_TAIL_SUBQ * cap_sub * DSDF_TAIL_WORDS * sizeof(float), 256);
-        ws.tail = p + off; off += ws.tail_bytes;
+    ws.items = (uint32_t *)(p + off); off += align_up((DSDF_ITEM_HDR + nv * Wb * Hb) * sizeof(uint32_t), 256);
+    ws.block_adj = nullptr; ws.count = nullptr; ws.qlane = nullptr; ws.qrec = nullptr;
+    ws.tail = nullptr; ws.tail_bytes = 0; ws.tail_cap_sub = 0;
+    if (diff) {
+        ws.block_adj = (float *)(p + off); off += align_up(nv * Wb * Hb * nch * sizeof(float), 256);
+        ws.count = (uint32_t *)(p + off); off += align_up(nv * nunits * sizeof(uint32_t), 256);
+        ws.qlane = (uint32_t *)(p + off); off += align_up(nv * cap * sizeof(uint32_t), 256);
+        ws.qrec = (float *)(p + off); off += align_up(nv * cap * rows * sizeof(float), 256);
+        if (integrator != DSDF_DIRECT && spp % 64 == 0) {
+            // sub-queue `s` serves the pixels with work-list index % DSDF_TAIL_SUBQ == s; a wave hands off at most
+            // DSDF_TAIL_HANDOFF rays per 64-sample chunk
+            ws.tail_cap_sub = (uint32_t)((nv * Wb * Hb + DSDF_TAIL_SUBQ - 1) / DSDF_TAIL_SUBQ * (size_t)(spp / 64) * DSDF_TAIL_HANDOFF);
+            ws.tail_bytes = align_up((size_t)DSDF_TAIL_SUBQ * 2 * sizeof(uint32_t), 256) +
+                            align_up((size_t)DSDF_TAIL_SUBQ * ws.tail_cap_sub * DSDF_TAIL_WORDS * sizeof(float), 256);
+            ws.tail = p + off; off += ws.tail_bytes;
+        }
     }
-#endif
     ws.cap = (uint32_t)cap;
-    ws.nblk = (uint32_t)nblk;
+    ws.nunits = (uint32_t)nunits;
     ws.bytes = off;
     return ws;
 }
 
 // Largest number of views (<= DSDF_MAX_BATCH, <= n_views) one launch can take with this workspace.
-static int batch_size(int W, int H, int spp, int n_views, int integrator, size_t workspace_bytes) {
+static int batch_size(int W, int H, int spp, int n_views, int integrator, size_t workspace_bytes, bool diff = true) {
     int nv = n_views < DSDF_MAX_BATCH ? n_views : DSDF_MAX_BATCH;
-    while (nv > 1 && carve(nullptr, W, H, spp, nv, integrator).bytes > workspace_bytes) --nv;
+    while (nv > 1 && carve(nullptr, W, H, spp, nv, integrator, diff).bytes > workspace_bytes) --nv;
     return nv;
 }
 
@@ -518,7 +598,7 @@ static dsdf_params pass_params(const dsdf_params &prm, int integrator) {
 
 static int check_render_args(const float *padded, int rx, int ry, int rz, const dsdf_params *prm,
                              const dsdf_camera *cams, int n_views, int W, int H, int spp, int integrator,
-                             const dsdf_shading *shading, void *workspace, size_t workspace_bytes) {
+                             const dsdf_shading *shading, void *workspace, size_t workspace_bytes, bool diff) {
     if (!padded || !prm || !cams || !workspace) return fail(DSDF_ERR_INVALID_ARG, "null pointer argument");
     if (rx < 1 || ry < 1 || rz < 1 || n_views < 1 || W < 1 || H < 1 || spp < 1)
         return fail(DSDF_ERR_INVALID_ARG, "non-positive size argument");
@@ -529,7 +609,7 @@ static int check_render_args(const float *padded, int rx, int ry, int rz, const 
     size_t nl = (size_t)(W + 2 * DSDF_BORDER) * (H + 2 * DSDF_BORDER) * (size_t)spp;
     // reparam.py:48-50 wavefront-size limit
     if (nl > 0x40000000ull) return fail(DSDF_ERR_INVALID_ARG, "wavefront size exceeds 0x40000000 lanes");
-    if (workspace_bytes < dsdf_render_workspace_size(W, H, spp, 1, integrator)) return fail(DSDF_ERR_WORKSPACE, "workspace too small");
+    if (workspace_bytes < carve(nullptr, W, H, spp, 1, integrator, diff).bytes) return fail(DSDF_ERR_WORKSPACE, "workspace too small");
     return DSDF_OK;
 }
 
@@ -620,88 +700,152 @@ int dsdf_surface_interaction(const float *padded, int rx, int ry, int rz, const 
 
 size_t dsdf_render_workspace_size(int width, int height, int spp, int n_views, int integrator) {
     if (width < 1 || height < 1 || spp < 1 || n_views < 1) return 0;
-    return carve(nullptr, width, height, spp, n_views < DSDF_MAX_BATCH ? n_views : DSDF_MAX_BATCH, integrator).bytes;
+    return carve(nullptr, width, height, spp, n_views < DSDF_MAX_BATCH ? n_views : DSDF_MAX_BATCH, integrator, true).bytes;
 }
+
+size_t dsdf_forward_workspace_size(int width, int height, int spp, int n_views, int integrator) {
+    if (width < 1 || height < 1 || spp < 1 || n_views < 1) return 0;
+    return carve(nullptr, width, height, spp, n_views < DSDF_MAX_BATCH ? n_views : DSDF_MAX_BATCH, integrator, false).bytes;
+}
+
+}  // extern "C" (the shared host plumbing below is C++)
+
+// One batch of views of a render call: view arguments, empty-space proof, the render pass (primal or gradient sweep)
+// into ws.block.  Everything is enqueued on `st`.
+struct PassCtx {
+    const float *padded; int rx, ry, rz; const dsdf_params *prm; dsdf_params pp;
+    int W, H, spp, integrator, flags; bool direct;
+    const float *offsets, *emitter_u; const uint32_t *seeds; const dsdf_shading *shading;
+    size_t Wb, Hb; uint32_t nl;
+    hipStream_t st;
+};
+
+static PassCtx make_ctx(const float *padded, int rx, int ry, int rz, const dsdf_params *prm, int W, int H, int spp,
+                        const float *offsets, const uint32_t *seeds, int integrator, int flags, const dsdf_shading *shading,
+                        void *stream) {
+    PassCtx c;
+    c.padded = padded; c.rx = rx; c.ry = ry; c.rz = rz; c.prm = prm; c.pp = pass_params(*prm, integrator);
+    c.W = W; c.H = H; c.spp = spp; c.integrator = integrator; c.flags = flags; c.direct = integrator == DSDF_DIRECT;
+    c.offsets = offsets; c.seeds = seeds; c.shading = shading; c.emitter_u = c.direct ? shading->emitter_samples : nullptr;
+    c.Wb = W + 2 * DSDF_BORDER; c.Hb = H + 2 * DSDF_BORDER; c.nl = (uint32_t)(c.Wb * c.Hb * spp);
+    c.st = (hipStream_t)stream;
+    return c;
+}
+
+// persistent workers of k_render_items: enough single-wave blocks to fill every wave slot of the device
+static unsigned worker_blocks() {
+    static unsigned n = 0;
+    if (!n) {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
+            n = (unsigned)cus * 32u;
+        else n = 256u * 32u;
+    }
+    return n;
+}
+
+template <bool DIFF>
+static int run_pass(const PassCtx &c, const Workspace &ws, const dsdf_camera *cams, int v0, int nv, ViewBatch &VB, Queue q,
+                    int64_t *stats) {
+    int rc;
+    hipStream_t st = c.st;
+    for (int i = 0; i < nv; ++i)
+        VB.v[i] = make_view_args(cams[v0 + i], c.W, c.H, c.spp, c.offsets ? c.offsets + (size_t)(v0 + i) * c.nl * 2 : nullptr,
+                                 c.seeds ? c.seeds[v0 + i] : 0u, c.integrator, c.flags,
+                                 c.emitter_u ? c.emitter_u + (size_t)(v0 + i) * c.nl * 2 : nullptr);
+    const size_t nch = (size_t)film_channels(c.integrator), npix = c.Wb * c.Hb;
+    if (hipMemsetAsync(ws.block, 0, nv * npix * nch * sizeof(float), st) != hipSuccess)
+        return fail(DSDF_ERR_LAUNCH, "hipMemsetAsync(film block) failed");
+    float step = 0.f;
+    const int level = (c.flags & DSDF_NO_SKIP) ? -1 : skip_level(cams + v0, nv, c.W, c.rx, c.ry, c.rz, step);
+    const unsigned char *skip = nullptr;
+    if (level >= 0) {
+        hipLaunchKernelGGL(k_pixel_skip, dim3((unsigned)((npix + 255) / 256), nv), dim3(256), 0, st,
+                           device_view(c.padded, c.rx, c.ry, c.rz, *c.prm, level), c.pp, VB, ws.skip, step);
+        if ((rc = check_launch("k_pixel_skip"))) return rc;
+        hipLaunchKernelGGL(k_skip_dilate, dim3((unsigned)((npix + 255) / 256), nv), dim3(256), 0, st, VB, ws.skip);
+        if ((rc = check_launch("k_skip_dilate"))) return rc;
+        skip = ws.skip;
+    }
+    const GridView G = device_view(c.padded, c.rx, c.ry, c.rz, *c.prm);
+    const ShadeArgs S = make_shade_args(c.shading, DIFF);
+    unsigned long long *st64 = (unsigned long long *)stats;
+    if (c.spp % 64 == 0) {
+        // persistent workers over the compacted list of pixels that must be sampled
+        // (sdf_direct_reparam with a visible environment: the background is not zero, every pixel is sampled)
+        const unsigned far_bit = (c.direct && !S.hide_emitters) ? 0u : (DIFF ? 8u : 4u);
+        if (hipMemsetAsync(ws.items, 0, DSDF_ITEM_HDR * sizeof(uint32_t), st) != hipSuccess)
+            return fail(DSDF_ERR_LAUNCH, "hipMemsetAsync(work list) failed");
+        hipLaunchKernelGGL(k_build_items, dim3((unsigned)((nv * npix + 255) / 256)), dim3(256), 0, st, VB, nv, skip, far_bit, ws.items);
+        if ((rc = check_launch("k_build_items"))) return rc;
+        TailQueue tq;
+        memset(&tq, 0, sizeof(tq));
+        if (DIFF) {
+            if (hipMemsetAsync(ws.count, 0, (size_t)nv * ws.nunits * sizeof(uint32_t), st) != hipSuccess)
+                return fail(DSDF_ERR_LAUNCH, "hipMemsetAsync(queue counts) failed");
+            if (ws.tail && !stats) {             // (statistics runs march every ray in the sweep itself)
+                tq.cap_sub = ws.tail_cap_sub;
+                tq.count = (uint32_t *)ws.tail;
+                tq.state = (float *)(ws.tail + align_up((size_t)DSDF_TAIL_SUBQ * 2 * sizeof(uint32_t), 256));
+                if (hipMemsetAsync(tq.count, 0, (size_t)DSDF_TAIL_SUBQ * 2 * sizeof(uint32_t), st) != hipSuccess)
+                    return fail(DSDF_ERR_LAUNCH, "hipMemsetAsync(tail queue) failed");
+            }
+        }
+        const dim3 grid(worker_blocks()), blk(64);
+        if (c.direct) {
+            if (st64) hipLaunchKernelGGL((k_render_items<DIFF, true, true>), grid, blk, 0, st, G, c.pp, VB, ws.block, q, st64, skip, S, tq, ws.items);
+            else hipLaunchKernelGGL((k_render_items<DIFF, true, false>), grid, blk, 0, st, G, c.pp, VB, ws.block, q, st64, skip, S, tq, ws.items);
+        } else {
+            if (st64) hipLaunchKernelGGL((k_render_items<DIFF, false, true>), grid, blk, 0, st, G, c.pp, VB, ws.block, q, st64, skip, S, tq, ws.items);
+            else hipLaunchKernelGGL((k_render_items<DIFF, false, false>), grid, blk, 0, st, G, c.pp, VB, ws.block, q, st64, skip, S, tq, ws.items);
+        }
+        if ((rc = check_launch("k_render_items"))) return rc;
+        if (tq.state) {
+            hipLaunchKernelGGL(k_tail_trace_diff, dim3(DSDF_TAIL_SUBQ * DSDF_TAIL_BLOCKS_PER_SUBQ), dim3(256), 0, st, G, c.pp, VB, ws.block, tq, q);
+            if ((rc = check_launch("k_tail_trace_diff"))) return rc;
+        }
+    } else {
+        const dim3 grid((c.nl + DSDF_BLOCK - 1) / DSDF_BLOCK, nv), blk(DSDF_BLOCK);
+        if (c.direct) hipLaunchKernelGGL((k_render_pass<DIFF, true>), grid, blk, 0, st, G, c.pp, VB, ws.block, q, st64, c.nl, skip, S);
+        else hipLaunchKernelGGL((k_render_pass<DIFF, false>), grid, blk, 0, st, G, c.pp, VB, ws.block, q, st64, c.nl, skip, S);
+        if ((rc = check_launch("k_render_pass"))) return rc;
+    }
+    return DSDF_OK;
+}
+
+static Queue make_queue(const Workspace &ws, bool direct) {
+    Queue q;
+    q.count = ws.count; q.lane = ws.qlane; q.rec = ws.qrec; q.rows = direct ? 18u : 9u; q.cap = ws.cap; q.nunits = ws.nunits;
+    return q;
+}
+
+static int develop_batch(const PassCtx &c, const Workspace &ws, int nv, float *image) {
+    const dim3 grid((c.W * c.H + 255) / 256, nv);
+    if (c.direct) hipLaunchKernelGGL(k_develop_rgb, grid, dim3(256), 0, c.st, ws.block, c.W, c.H, image);
+    else hipLaunchKernelGGL(k_develop, grid, dim3(256), 0, c.st, ws.block, c.W, c.H, image);
+    return check_launch("k_develop");
+}
+
+extern "C" {
 
 int dsdf_render_forward(const float *padded, int rx, int ry, int rz, const dsdf_params *prm, const dsdf_camera *cams,
                         int n_views, int width, int height, int spp, const float *offsets, const uint32_t *seeds,
                         int integrator, int flags, const dsdf_shading *shading, float *image_out, void *workspace,
                         size_t workspace_bytes, int64_t *stats, void *stream) {
     int rc = check_render_args(padded, rx, ry, rz, prm, cams, n_views, width, height, spp, integrator, shading, workspace,
-                               workspace_bytes);
+                               workspace_bytes, false);
     if (rc) return rc;
     if (!image_out) return fail(DSDF_ERR_INVALID_ARG, "dsdf_render_forward: image_out is null");
     if (!offsets && !seeds) return fail(DSDF_ERR_INVALID_ARG, "dsdf_render_forward: need offsets or seeds");
-    hipStream_t st = (hipStream_t)stream;
-    const dsdf_params pp = pass_params(*prm, integrator);
-    const int nb = batch_size(width, height, spp, n_views, integrator, workspace_bytes);
-    Workspace ws = carve(workspace, width, height, spp, nb, integrator);
-    const bool direct = integrator == DSDF_DIRECT;
-    const size_t nch = (size_t)film_channels(integrator);
-    const float *emitter_u = direct ? shading->emitter_samples : nullptr;
-    GridView G = device_view(padded, rx, ry, rz, *prm);
-    size_t Wb = width + 2 * DSDF_BORDER, Hb = height + 2 * DSDF_BORDER;
-    uint32_t nl = (uint32_t)(Wb * Hb * spp);
-    Queue q; q.count = ws.count; q.lane = ws.qlane; q.rec = ws.qrec; q.rows = direct ? 18u : 9u; q.cap = ws.cap; q.nblk = ws.nblk;
+    const PassCtx c = make_ctx(padded, rx, ry, rz, prm, width, height, spp, offsets, seeds, integrator, flags, shading, stream);
+    const int nb = batch_size(width, height, spp, n_views, integrator, workspace_bytes, false);
+    const Workspace ws = carve(workspace, width, height, spp, nb, integrator, false);
+    const Queue q = make_queue(ws, c.direct);
     for (int v0 = 0; v0 < n_views; v0 += nb) {
         const int nv = (n_views - v0) < nb ? (n_views - v0) : nb;
         ViewBatch VB;
-        for (int i = 0; i < nv; ++i)
-            VB.v[i] = make_view_args(cams[v0 + i], width, height, spp, offsets ? offsets + (size_t)(v0 + i) * nl * 2 : nullptr,
-                                     seeds ? seeds[v0 + i] : 0u, integrator, flags,
-                                     emitter_u ? emitter_u + (size_t)(v0 + i) * nl * 2 : nullptr);
-        if (hipMemsetAsync(ws.block, 0, nv * Wb * Hb * nch * sizeof(float), st) != hipSuccess)
-            return fail(DSDF_ERR_LAUNCH, "hipMemsetAsync(block) failed");
-        float step = 0.f;
-        const int level = (flags & DSDF_NO_SKIP) ? -1 : skip_level(cams + v0, nv, width, rx, ry, rz, step);
-        const unsigned char *skip = nullptr;
-        if (level >= 0) {
-            hipLaunchKernelGGL(k_pixel_skip, dim3((unsigned)((Wb * Hb + 255) / 256), nv), dim3(256), 0, st,
-                               device_view(padded, rx, ry, rz, *prm, level), pp, VB, ws.skip, step);
-            if ((rc = check_launch("k_pixel_skip"))) return rc;
-            hipLaunchKernelGGL(k_skip_dilate, dim3((unsigned)((Wb * Hb + 255) / 256), nv), dim3(256), 0, st, VB, ws.skip);
-            if ((rc = check_launch("k_skip_dilate"))) return rc;
-            skip = ws.skip;
-        }
-        const ShadeArgs S = make_shade_args(shading, false);
-        const dim3 grid(ws.nblk, nv), blk(DSDF_BLOCK);
-        unsigned long long *st64 = (unsigned long long *)stats;
-        TailQueue tq;
-        memset(&tq, 0, sizeof(tq));
-#if DSDF_TAIL_HANDOFF > 0
-        // tail hand-off (wave-uniform one-channel passes without statistics): the queue lives in the backward-queue
-        // records, which are idle in a primal call -- at most DSDF_TAIL_HANDOFF entries per wave
-        const bool handoff = !direct && !stats && spp % 64 == 0;
-        if (handoff) {
-            // a sub-queue serves the blocks with blockIdx.x % DSDF_TAIL_SUBQ == sub; every wave queues at most DSDF_TAIL_HANDOFF rays
-            tq.cap_sub = (uint32_t)(((size_t)ws.nblk + DSDF_TAIL_SUBQ - 1) / DSDF_TAIL_SUBQ * (DSDF_BLOCK / 64) * DSDF_TAIL_HANDOFF);
-            tq.count = (uint32_t *)ws.qrec;
-            tq.entry = (uint2 *)((char *)ws.qrec + align_up((size_t)nv * DSDF_TAIL_SUBQ * 2 * sizeof(uint32_t), 256));
-            if (hipMemsetAsync(tq.count, 0, (size_t)nv * DSDF_TAIL_SUBQ * 2 * sizeof(uint32_t), st) != hipSuccess)
-                return fail(DSDF_ERR_LAUNCH, "hipMemsetAsync(tail queue) failed");
-        }
-#endif
-        if (direct) {
-            if (spp % 64 == 0) hipLaunchKernelGGL((k_render_pass<false, true, true>), grid, blk, 0, st, G, pp, VB, ws.block, q, st64, nl, spp % DSDF_BLOCK == 0 ? 2 : 1, skip, S, tq);
-            else hipLaunchKernelGGL((k_render_pass<false, false, true>), grid, blk, 0, st, G, pp, VB, ws.block, q, st64, nl, 0, skip, S, tq);
-        } else {
-            if (spp % 64 == 0) hipLaunchKernelGGL((k_render_pass<false, true, false>), grid, blk, 0, st, G, pp, VB, ws.block, q, st64, nl, spp % DSDF_BLOCK == 0 ? 2 : 1, skip, S, tq);
-            else hipLaunchKernelGGL((k_render_pass<false, false, false>), grid, blk, 0, st, G, pp, VB, ws.block, q, st64, nl, 0, skip, S, tq);
-        }
-        if ((rc = check_launch("k_render_pass<primal>"))) return rc;
-#if DSDF_TAIL_HANDOFF > 0
-        if (handoff) {
-            hipLaunchKernelGGL(k_tail_trace, dim3(DSDF_TAIL_SUBQ * DSDF_TAIL_BLOCKS_PER_SUBQ, nv), dim3(256), 0, st, G, pp, VB, ws.block, tq);
-            if ((rc = check_launch("k_tail_trace"))) return rc;
-        }
-#endif
-        if (direct)
-            hipLaunchKernelGGL(k_develop_rgb, dim3((width * height + 255) / 256, nv), dim3(256), 0, st, ws.block, width, height,
-                               image_out + (size_t)v0 * width * height * 3);
-        else
-            hipLaunchKernelGGL(k_develop, dim3((width * height + 255) / 256, nv), dim3(256), 0, st, ws.block, width, height,
-                               image_out + (size_t)v0 * width * height * 3);
-        if ((rc = check_launch("k_develop"))) return rc;
+        if ((rc = run_pass<false>(c, ws, cams, v0, nv, VB, q, stats))) return rc;
+        if ((rc = develop_batch(c, ws, nv, image_out + (size_t)v0 * width * height * 3))) return rc;
     }
     return DSDF_OK;
 }
@@ -712,147 +856,68 @@ int dsdf_render_backward(const float *padded, int rx, int ry, int rz, const dsdf
                          float *grad_p, float *image_out, void *workspace, size_t workspace_bytes, int64_t *stats,
                          void *stream) {
     int rc = check_render_args(padded, rx, ry, rz, prm, cams, n_views, width, height, spp, integrator, shading, workspace,
-                               workspace_bytes);
+                               workspace_bytes, true);
     if (rc) return rc;
     if (!grad_image || !grad_grid) return fail(DSDF_ERR_INVALID_ARG, "dsdf_render_backward: null gradient buffer");
     if (!offsets && !seeds) return fail(DSDF_ERR_INVALID_ARG, "dsdf_render_backward: need offsets or seeds");
-    hipStream_t st = (hipStream_t)stream;
-    const dsdf_params pp = pass_params(*prm, integrator);
-    const int nb = batch_size(width, height, spp, n_views, integrator, workspace_bytes);
-    Workspace ws = carve(workspace, width, height, spp, nb, integrator);
-    const bool direct = integrator == DSDF_DIRECT;
-    const size_t nch = (size_t)film_channels(integrator);
-    const float *emitter_u = direct ? shading->emitter_samples : nullptr;
-    GridView G = device_view(padded, rx, ry, rz, *prm);
-    size_t Wb = width + 2 * DSDF_BORDER, Hb = height + 2 * DSDF_BORDER;
-    uint32_t nl = (uint32_t)(Wb * Hb * spp);
-    Queue q; q.count = ws.count; q.lane = ws.qlane; q.rec = ws.qrec; q.rows = direct ? 18u : 9u; q.cap = ws.cap; q.nblk = ws.nblk;
+    const PassCtx c = make_ctx(padded, rx, ry, rz, prm, width, height, spp, offsets, seeds, integrator, flags, shading, stream);
+    hipStream_t st = c.st;
+    const int nb = batch_size(width, height, spp, n_views, integrator, workspace_bytes, true);
+    const Workspace ws = carve(workspace, width, height, spp, nb, integrator, true);
+    const Queue q = make_queue(ws, c.direct);
+    const GridView G = device_view(padded, rx, ry, rz, *prm);
+    const ShadeArgs S = make_shade_args(shading, true);
     for (int v0 = 0; v0 < n_views; v0 += nb) {
         const int nv = (n_views - v0) < nb ? (n_views - v0) : nb;
         ViewBatch VB;
-        for (int i = 0; i < nv; ++i)
-            VB.v[i] = make_view_args(cams[v0 + i], width, height, spp, offsets ? offsets + (size_t)(v0 + i) * nl * 2 : nullptr,
-                                     seeds ? seeds[v0 + i] : 0u, integrator, flags,
-                                     emitter_u ? emitter_u + (size_t)(v0 + i) * nl * 2 : nullptr);
-        if (hipMemsetAsync(ws.block, 0, nv * Wb * Hb * nch * sizeof(float), st) != hipSuccess)
-            return fail(DSDF_ERR_LAUNCH, "hipMemsetAsync(workspace) failed");
-        float step = 0.f;
-        const int level = (flags & DSDF_NO_SKIP) ? -1 : skip_level(cams + v0, nv, width, rx, ry, rz, step);
-        const unsigned char *skip = nullptr;
-        if (level >= 0) {
-            hipLaunchKernelGGL(k_pixel_skip, dim3((unsigned)((Wb * Hb + 255) / 256), nv), dim3(256), 0, st,
-                               device_view(padded, rx, ry, rz, *prm, level), pp, VB, ws.skip, step);
-            if ((rc = check_launch("k_pixel_skip"))) return rc;
-            hipLaunchKernelGGL(k_skip_dilate, dim3((unsigned)((Wb * Hb + 255) / 256), nv), dim3(256), 0, st, VB, ws.skip);
-            if ((rc = check_launch("k_skip_dilate"))) return rc;
-            skip = ws.skip;
-        }
-        const ShadeArgs S = make_shade_args(shading, true);
-        TailQueue tq;
-        memset(&tq, 0, sizeof(tq));
-#if DSDF_TAIL_HANDOFF > 0
-        const bool handoff = !direct && !stats && spp % 64 == 0;
-        if (handoff) {
-            tq.cap_sub = (uint32_t)(((size_t)ws.nblk + DSDF_TAIL_SUBQ - 1) / DSDF_TAIL_SUBQ * (DSDF_BLOCK / 64) * DSDF_TAIL_HANDOFF);
-            tq.count = (uint32_t *)ws.tail;
-            tq.state = (float *)(ws.tail + align_up((size_t)nb * DSDF_TAIL_SUBQ * 2 * sizeof(uint32_t), 256));
-            if (hipMemsetAsync(tq.count, 0, (size_t)nv * DSDF_TAIL_SUBQ * 2 * sizeof(uint32_t), st) != hipSuccess)
-                return fail(DSDF_ERR_LAUNCH, "hipMemsetAsync(tail queue) failed");
-        }
-#endif
-        const dim3 grid(ws.nblk, nv), blk(DSDF_BLOCK);
-        unsigned long long *st64 = (unsigned long long *)stats;
-        if (direct) {
-            if (spp % 64 == 0) hipLaunchKernelGGL((k_render_pass<true, false, true>), grid, blk, 0, st, G, pp, VB, ws.block, q, st64, nl, 1, skip, S, tq);
-            else hipLaunchKernelGGL((k_render_pass<true, false, true>), grid, blk, 0, st, G, pp, VB, ws.block, q, st64, nl, 0, skip, S, tq);
-        } else {
-            if (spp % 64 == 0) hipLaunchKernelGGL((k_render_pass<true, DSDF_DIFF_CACHE != 0, false>), grid, blk, 0, st, G, pp, VB, ws.block, q, st64, nl, 1, skip, S, tq);
-            else hipLaunchKernelGGL((k_render_pass<true, false, false>), grid, blk, 0, st, G, pp, VB, ws.block, q, st64, nl, 0, skip, S, tq);
-        }
-        if ((rc = check_launch("k_render_pass<grad>"))) return rc;
-#if DSDF_TAIL_HANDOFF > 0
-        if (handoff) {
-            hipLaunchKernelGGL(k_tail_trace_diff, dim3(DSDF_TAIL_SUBQ * DSDF_TAIL_BLOCKS_PER_SUBQ, nv), dim3(256), 0, st, G, pp, VB, ws.block, tq, q);
-            if ((rc = check_launch("k_tail_trace_diff"))) return rc;
-        }
-#endif
-        const dim3 dev_grid((width * height + 255) / 256, nv), adj_grid((unsigned)((Wb * Hb + 255) / 256), nv);
-        if (image_out) {
-            float *img = image_out + (size_t)v0 * width * height * 3;
-            if (direct) hipLaunchKernelGGL(k_develop_rgb, dev_grid, dim3(256), 0, st, ws.block, width, height, img);
-            else hipLaunchKernelGGL(k_develop, dev_grid, dim3(256), 0, st, ws.block, width, height, img);
-            if ((rc = check_launch("k_develop"))) return rc;
-        }
+        if ((rc = run_pass<true>(c, ws, cams, v0, nv, VB, q, stats))) return rc;
+        if (image_out && (rc = develop_batch(c, ws, nv, image_out + (size_t)v0 * width * height * 3))) return rc;
+        const dim3 adj_grid((unsigned)((c.Wb * c.Hb + 255) / 256), nv);
         const float *gi = grad_image + (size_t)v0 * width * height * 3;
-        if (direct) hipLaunchKernelGGL(k_develop_adjoint_rgb, adj_grid, dim3(256), 0, st, ws.block, gi, width, height, ws.block_adj);
+        if (c.direct) hipLaunchKernelGGL(k_develop_adjoint_rgb, adj_grid, dim3(256), 0, st, ws.block, gi, width, height, ws.block_adj);
         else hipLaunchKernelGGL(k_develop_adjoint, adj_grid, dim3(256), 0, st, ws.block, gi, width, height, ws.block_adj);
         if ((rc = check_launch("k_develop_adjoint"))) return rc;
-        if (direct) hipLaunchKernelGGL(k_backward<true>, grid, dim3(64), 0, st, G, pp, VB, q, ws.block_adj, grad_grid, grad_p, st64, S);
-        else hipLaunchKernelGGL(k_backward<false>, grid, dim3(64), 0, st, G, pp, VB, q, ws.block_adj, grad_grid, grad_p, st64, S);
+        const dim3 grid((ws.nunits + 3) / 4, nv);
+        unsigned long long *st64 = (unsigned long long *)stats;
+        if (c.direct) hipLaunchKernelGGL(k_backward<true>, grid, dim3(64), 0, st, G, c.pp, VB, q, ws.block_adj, grad_grid, grad_p, st64, S);
+        else hipLaunchKernelGGL(k_backward<false>, grid, dim3(64), 0, st, G, c.pp, VB, q, ws.block_adj, grad_grid, grad_p, st64, S);
         if ((rc = check_launch("k_backward"))) return rc;
     }
     return DSDF_OK;
 }
-
 
 int dsdf_render_forward_grad(const float *padded, int rx, int ry, int rz, const dsdf_params *prm, const dsdf_camera *cams,
                              int n_views, int width, int height, int spp, const float *offsets, const uint32_t *seeds,
                              int integrator, int flags, const float *tangent_padded, const float *tangent_p,
                              float *grad_image_out, float *image_out, void *workspace, size_t workspace_bytes, void *stream) {
     int rc = check_render_args(padded, rx, ry, rz, prm, cams, n_views, width, height, spp, integrator, nullptr, workspace,
-                               workspace_bytes);
+                               workspace_bytes, true);
     if (rc) return rc;
     if (integrator == DSDF_DIRECT) return fail(DSDF_ERR_INVALID_ARG, "dsdf_render_forward_grad: sdf_direct_reparam is not supported");
     if (!grad_image_out) return fail(DSDF_ERR_INVALID_ARG, "dsdf_render_forward_grad: grad_image_out is null");
     if (!tangent_padded && !tangent_p) return fail(DSDF_ERR_INVALID_ARG, "dsdf_render_forward_grad: need a tangent");
     if (!offsets && !seeds) return fail(DSDF_ERR_INVALID_ARG, "dsdf_render_forward_grad: need offsets or seeds");
-    hipStream_t st = (hipStream_t)stream;
-    const dsdf_params pp = pass_params(*prm, integrator);
-    const int nb = batch_size(width, height, spp, n_views, integrator, workspace_bytes);
-    Workspace ws = carve(workspace, width, height, spp, nb, integrator);
-    GridView G = device_view(padded, rx, ry, rz, *prm);
-    size_t Wb = width + 2 * DSDF_BORDER, Hb = height + 2 * DSDF_BORDER;
-    uint32_t nl = (uint32_t)(Wb * Hb * spp);
-    Queue q; q.count = ws.count; q.lane = ws.qlane; q.rec = ws.qrec; q.rows = 9u; q.cap = ws.cap; q.nblk = ws.nblk;
+    const PassCtx c = make_ctx(padded, rx, ry, rz, prm, width, height, spp, offsets, seeds, integrator, flags, nullptr, stream);
+    hipStream_t st = c.st;
+    const int nb = batch_size(width, height, spp, n_views, integrator, workspace_bytes, true);
+    const Workspace ws = carve(workspace, width, height, spp, nb, integrator, true);
+    const Queue q = make_queue(ws, false);
+    const GridView G = device_view(padded, rx, ry, rz, *prm);
     const V3 dp = tangent_p ? mk(tangent_p[0], tangent_p[1], tangent_p[2]) : mk(0.f, 0.f, 0.f);
-    const ShadeArgs S = make_shade_args(nullptr, false);
-    TailQueue tq;
-    memset(&tq, 0, sizeof(tq));
     for (int v0 = 0; v0 < n_views; v0 += nb) {
         const int nv = (n_views - v0) < nb ? (n_views - v0) : nb;
         ViewBatch VB;
-        for (int i = 0; i < nv; ++i)
-            VB.v[i] = make_view_args(cams[v0 + i], width, height, spp, offsets ? offsets + (size_t)(v0 + i) * nl * 2 : nullptr,
-                                     seeds ? seeds[v0 + i] : 0u, integrator, flags);
-        // film block and its tangent (the adjoint block's storage) are adjacent in the workspace
-        if (hipMemsetAsync(ws.block, 0, nv * Wb * Hb * 2 * sizeof(float), st) != hipSuccess ||
-            hipMemsetAsync(ws.block_adj, 0, nv * Wb * Hb * 2 * sizeof(float), st) != hipSuccess)
-            return fail(DSDF_ERR_LAUNCH, "hipMemsetAsync(workspace) failed");
-        float step = 0.f;
-        const int level = (flags & DSDF_NO_SKIP) ? -1 : skip_level(cams + v0, nv, width, rx, ry, rz, step);
-        const unsigned char *skip = nullptr;
-        if (level >= 0) {
-            hipLaunchKernelGGL(k_pixel_skip, dim3((unsigned)((Wb * Hb + 255) / 256), nv), dim3(256), 0, st,
-                               device_view(padded, rx, ry, rz, *prm, level), pp, VB, ws.skip, step);
-            if ((rc = check_launch("k_pixel_skip"))) return rc;
-            hipLaunchKernelGGL(k_skip_dilate, dim3((unsigned)((Wb * Hb + 255) / 256), nv), dim3(256), 0, st, VB, ws.skip);
-            if ((rc = check_launch("k_skip_dilate"))) return rc;
-            skip = ws.skip;
-        }
-        const dim3 grid(ws.nblk, nv), blk(DSDF_BLOCK);
-        if (spp % 64 == 0) hipLaunchKernelGGL((k_render_pass<true, DSDF_DIFF_CACHE != 0, false>), grid, blk, 0, st, G, pp, VB, ws.block, q, (unsigned long long *)nullptr, nl, 1, skip, S, tq);
-        else hipLaunchKernelGGL((k_render_pass<true, false, false>), grid, blk, 0, st, G, pp, VB, ws.block, q, (unsigned long long *)nullptr, nl, 0, skip, S, tq);
-        if ((rc = check_launch("k_render_pass<grad>"))) return rc;
-        hipLaunchKernelGGL(k_forward_tangent, grid, dim3(64), 0, st, G, tangent_padded, dp, pp, VB, q, ws.block_adj);
+        if ((rc = run_pass<true>(c, ws, cams, v0, nv, VB, q, nullptr))) return rc;
+        // the tangent film block lives in the adjoint block's storage
+        if (hipMemsetAsync(ws.block_adj, 0, nv * c.Wb * c.Hb * 2 * sizeof(float), st) != hipSuccess)
+            return fail(DSDF_ERR_LAUNCH, "hipMemsetAsync(tangent block) failed");
+        hipLaunchKernelGGL(k_forward_tangent, dim3((ws.nunits + 3) / 4, nv), dim3(64), 0, st, G, tangent_padded, dp, c.pp, VB, q, ws.block_adj);
         if ((rc = check_launch("k_forward_tangent"))) return rc;
         const dim3 dev_grid((width * height + 255) / 256, nv);
         hipLaunchKernelGGL(k_develop_tangent, dev_grid, dim3(256), 0, st, ws.block, ws.block_adj, width, height,
                            grad_image_out + (size_t)v0 * width * height * 3);
         if ((rc = check_launch("k_develop_tangent"))) return rc;
-        if (image_out) {
-            hipLaunchKernelGGL(k_develop, dev_grid, dim3(256), 0, st, ws.block, width, height, image_out + (size_t)v0 * width * height * 3);
-            if ((rc = check_launch("k_develop"))) return rc;
-        }
+        if (image_out && (rc = develop_batch(c, ws, nv, image_out + (size_t)v0 * width * height * 3))) return rc;
     }
     return DSDF_OK;
 }

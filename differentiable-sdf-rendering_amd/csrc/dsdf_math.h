@@ -483,10 +483,18 @@ DSDF_HD void trace_plain(const GridView &G, const dsdf_params &P, V3 o, V3 d_in,
     out.warp_t_d = mk(0.f, 0.f, 0.f); out.warp_weight_d = mk(0.f, 0.f, 0.f);
 }
 
+// Loop control of trace_diff.  MarchToEnd: every ray of the wave marches until it is done.  The gradient sweep of the render
+// kernels uses HandOff (dsdf_tail.h) instead: the loop of a wave ends as soon as only a few of its rays are still marching,
+// and their state is exported for a tail kernel (a handful of grazing rays carry the long tail of every pixel-wave).
+struct MarchToEnd {
+    template <class Fetch> DSDF_HD bool more(const Fetch &F, bool active) const { return F.any(active); }
+    DSDF_HD void leftover(bool, float, float, float, float, float, V3, V3, V3, V3, V3, int) const {}
+};
+
 // A2: SDFBase.ray_intersect (shapes.py:115-288) -- differentiable sphere tracing
 // with the weighted warp-t accumulation and its analytic direction derivative.
-template <class Fetch>
-DSDF_HD void trace_diff(const GridView &G, const dsdf_params &P, V3 o, V3 d_in, float ray_maxt, TraceOut &out, Fetch &F) {
+template <class Fetch, class Ctl>
+DSDF_HD void trace_diff(const GridView &G, const dsdf_params &P, V3 o, V3 d_in, float ray_maxt, TraceOut &out, Fetch &F, Ctl &C) {
     float invn = rsqf(dot(d_in, d_in));
     V3 d = d_in * invn;                                              // :124
     float lo = -P.bbox_delta, hi = 1.f + P.bbox_delta;
@@ -508,7 +516,7 @@ DSDF_HD void trace_diff(const GridView &G, const dsdf_params &P, V3 o, V3 d_in, 
     V3 t_d = mk(0.f, 0.f, 0.f);
     if (!b.inside && fabsf(ddn) > 0.f) t_d = n * (-t / ddn);
 
-    while (F.any(active)) {
+    while (C.more(F, active)) {
         V3 x = fma3(t, d, o);
         float v = 0.f; V3 g = mk(0.f, 0.f, 0.f); float H[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         F.template eval<2>(G, x, active, v, g, H);                   // :178
@@ -549,6 +557,8 @@ DSDF_HD void trace_diff(const GridView &G, const dsdf_params &P, V3 o, V3 d_in, 
             active = (t <= maxt) && !hit;                            // :238
         }
     }
+    // rays the loop control stopped early (still `active`) hand their state over and report "no hit, no warp" for now
+    C.leftover(active, t, warp_t, prev_sd, wsum, ews, t_d, prev_gc, mixed, wdsum, ews_d, i);
     out.steps = i;
     out.weight_sum = wsum;
     out.its_t = refine_hit(G, P, o, d, its_t, trace_eps, out.refine_steps, F);
@@ -557,11 +567,17 @@ DSDF_HD void trace_diff(const GridView &G, const dsdf_params &P, V3 o, V3 d_in, 
     V3 warp_t_d = (mixed - warp_t * wdsum) * inv;
     float ww = fminf(fmaxf(wsum, 0.f), 1.f);                         // :271-272
     V3 ww_d = (wsum > 0.f && wsum < 1.f) ? wdsum : mk(0.f, 0.f, 0.f);
-    bool invalid = (wsum < 1e-7f) || !hit_box;                       // :278-283
+    bool invalid = (wsum < 1e-7f) || !hit_box || active;             // :278-283
     if (invalid) {
         warp_t = INFINITY; warp_t_d = mk(0.f, 0.f, 0.f); ww = 0.f; ww_d = mk(0.f, 0.f, 0.f);
     }
     out.warp_t = warp_t; out.warp_t_d = warp_t_d; out.warp_weight = ww; out.warp_weight_d = ww_d;
+}
+
+template <class Fetch>
+DSDF_HD void trace_diff(const GridView &G, const dsdf_params &P, V3 o, V3 d_in, float ray_maxt, TraceOut &out, Fetch &F) {
+    MarchToEnd C;
+    trace_diff(G, P, o, d_in, ray_maxt, out, F, C);
 }
 
 // The same march in resumable form (begin / step / finish): the state of a ray can be handed to another wave

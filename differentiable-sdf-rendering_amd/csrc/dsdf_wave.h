@@ -3,6 +3,13 @@
 #pragma once
 
 // ------------------------------------------------------------------ wave helpers
+// An opaque copy of a lane-constant value: what is derived from it cannot be hoisted out of the enclosing loops (the
+// persistent render kernel keeps ~40 such values live across its march loops otherwise and spills).
+__device__ __forceinline__ int opaque(int v) {
+    asm volatile("" : "+v"(v));
+    return v;
+}
+
 __device__ __forceinline__ int lane_id() {
     return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
 }
@@ -198,57 +205,53 @@ struct LdsRows {
 struct WaveCellCache {
     float *taps;      // wave-private LDS: DSDF_CACHE_SLOTS * DSDF_SLOT_STRIDE floats, then DSDF_CACHE_SLOTS slot bases
     int lid;
-#ifdef DSDF_CACHE_REUSE
-    // Opt-in (not timed yet): near convergence the steps are a fraction of a voxel, so whole waves stay in the cells of
-    // the previous step; the slots filled then are still valid and phases 1-2 are skipped.  A lane that was inactive
-    // at the last fill holds an invalid key, i.e. it forces a refill before it may read a slot again.
+    // Near convergence the steps are a fraction of a voxel, so whole waves stay in the cells of the previous step (24-29 % of the
+    // primal wave-steps on the bench scene): the slots filled then are still valid and phases 1-2 are skipped (measured
+    // 32.9 -> 31.8 ms).  A lane that was inactive at the last fill holds an invalid key, i.e. it forces a refill before it may
+    // read a slot again.
     uint32_t prev_base = 0xffffffffu;
     int prev_slot = -1;
-#endif
     __device__ __forceinline__ bool any(bool b) const { return __ballot(b) != 0; }
 
     template <int ORDER>
     __device__ __forceinline__ void eval(const GridView &G, V3 x, bool active, float &v, V3 &g, float H[6]) {
         const CubicCell c = cubic_cell(G, active ? x : mk(0.f, 0.f, 0.f));
         uint32_t *slot_base = reinterpret_cast<uint32_t *>(taps + DSDF_CACHE_SLOTS * DSDF_SLOT_STRIDE);
-        // 1. group the lanes by cell: leader = first unassigned active lane; every lane holding the
-        //    same cell key takes the slot (v_readlane + v_cmp + v_cndmask + scalar mask update per cell)
-#ifdef DSDF_CACHE_REUSE
-        int slot = prev_slot, n = 0;
+        int slot = prev_slot;
         if (__ballot(active && c.base != prev_base) != 0) {
-        slot = -1;
-#else
-        int slot = -1, n = 0;
-        {
-#endif
-        uint64_t todo = __ballot(active);
-        while (todo != 0 && n < DSDF_CACHE_SLOTS) {
-            const int leader = __builtin_ctzll(todo);
-            const uint32_t k = (uint32_t)__builtin_amdgcn_readlane((int)c.base, leader);
-            const bool same = c.base == k;
-            slot = same ? n : slot;
-            todo &= ~__ballot(same);
-            ++n;
-        }
-        if (slot >= 0) slot_base[slot] = c.base;        // all lanes of a slot write the same value
-        wave_lds_sync();
-        // 2. load every distinct cell once: lane (grp, r) fetches row r of slot 4*round + grp
-        const int grp = lid >> 4, r = lid & 15;
-        const uint32_t rowoff = (uint32_t)(r >> 2) * (4u * (uint32_t)G.sxy) + (uint32_t)(r & 3) * (4u * (uint32_t)G.sx);
-        for (int s0 = 0; s0 < n; s0 += 4) {
-            const int sl = s0 + grp;
-            if (sl < n) {
-                typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
-                const uint32_t b = slot_base[sl];
-                f4u t = *reinterpret_cast<const f4u *>(reinterpret_cast<const char *>(G.p) + (b + rowoff));
-                *reinterpret_cast<float4 *>(taps + sl * DSDF_SLOT_STRIDE + r * 4) = make_float4(t.x, t.y, t.z, t.w);
+            // 1. group the lanes by cell: leader = first unassigned active lane; every lane holding the
+            //    same cell key takes the slot (v_readlane + v_cmp + v_cndmask + scalar mask update per cell)
+            slot = -1;
+            int n = 0;
+            uint64_t todo = __ballot(active);
+            while (todo != 0 && n < DSDF_CACHE_SLOTS) {
+                const int leader = __builtin_ctzll(todo);
+                const uint32_t k = (uint32_t)__builtin_amdgcn_readlane((int)c.base, leader);
+                const bool same = c.base == k;
+                slot = same ? n : slot;
+                todo &= ~__ballot(same);
+                ++n;
             }
-        }
-        wave_lds_sync();
-#ifdef DSDF_CACHE_REUSE
-        prev_slot = slot;
-        prev_base = active ? c.base : 0xffffffffu;
-#endif
+            if (slot >= 0) slot_base[slot] = c.base;        // all lanes of a slot write the same value
+            wave_lds_sync();
+            // 2. load every distinct cell once: lane (grp, r) fetches row r of slot 4*round + grp; the (<= 4) rounds are
+            //    issued back to back and land in LDS after ONE wait (two rounds per batch: 8 VGPRs of staging)
+            int lf = lid;
+            asm volatile("" : "+v"(lf));                   // keep the lane-constant addresses below out of registers across the march
+            const int grp = lf >> 4, r = lf & 15;
+            const uint32_t rowoff = (uint32_t)(r >> 2) * (4u * (uint32_t)G.sxy) + (uint32_t)(r & 3) * (4u * (uint32_t)G.sx);
+            typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+            for (int s0 = 0; s0 < n; s0 += 8) {
+                const int sa = s0 + grp, sb = s0 + 4 + grp;
+                f4u ta, tb;
+                if (sa < n) ta = *reinterpret_cast<const f4u *>(reinterpret_cast<const char *>(G.p) + (slot_base[sa] + rowoff));
+                if (sb < n) tb = *reinterpret_cast<const f4u *>(reinterpret_cast<const char *>(G.p) + (slot_base[sb] + rowoff));
+                if (sa < n) *reinterpret_cast<float4 *>(taps + sa * DSDF_SLOT_STRIDE + r * 4) = make_float4(ta.x, ta.y, ta.z, ta.w);
+                if (sb < n) *reinterpret_cast<float4 *>(taps + sb * DSDF_SLOT_STRIDE + r * 4) = make_float4(tb.x, tb.y, tb.z, tb.w);
+            }
+            wave_lds_sync();
+            prev_slot = slot;
+            prev_base = active ? c.base : 0xffffffffu;
         }
         // 3. every lane evaluates from its slot (lanes beyond 16 distinct cells read global memory)
         if (active) {

@@ -60,6 +60,7 @@ SYMBOLS = {
     'dsdf_surface_interaction': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(DsdfParams), C.c_void_p, C.c_void_p,
                                            C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'dsdf_render_workspace_size': (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    'dsdf_forward_workspace_size': (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     'dsdf_render_forward': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(DsdfParams),
                                       C.POINTER(DsdfCamera), C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                       C.POINTER(C.c_uint32), C.c_int, C.c_int, C.POINTER(DsdfShading), C.c_void_p, C.c_void_p,

@@ -23,8 +23,8 @@ STAT_NAMES = ('lanes', 'bbox_lanes', 'steps', 'hits', 'refine_steps', 'warp_acti
 
 _workspaces = {}
 
-# Views traced by one kernel launch (bounded by the workspace: the backward queue holds
-# 40 B per gradient-pass sample and view; 288 GB of HBM makes 16 views x 512^2 x 64 spp = 11 GB cheap).
+# Views traced by one kernel launch (bounded by the workspace: the backward queue of a GRADIENT pass holds 40 B per
+# sample and view -- 16 views x 512^2 x 64 spp = 11 GB, cheap in 288 GB of HBM; a primal render carries no queue).
 MAX_VIEWS_PER_LAUNCH = 16
 
 
@@ -45,12 +45,32 @@ def _require_dev(t, name, dtype=torch.float32):
     return t.contiguous()
 
 
-def _workspace(device, nbytes):
+def _workspace(device, nbytes, min_bytes=None):
+    """Per-device scratch buffer, grown on demand.  When the device cannot provide `nbytes` (a gradient-pass workspace for
+    16 views x 512^2 x 64 spp is 11 GB) the request is halved down to `min_bytes` (one view per launch): the C side batches
+    as many views per launch as the workspace it is given allows."""
     ws = _workspaces.get(device)
-    if ws is None or ws.numel() < nbytes:
-        ws = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
-        _workspaces[device] = ws
+    if ws is not None and ws.numel() >= nbytes:
+        return ws
+    _workspaces.pop(device, None)
+    del ws
+    want = int(nbytes)
+    while True:
+        try:
+            ws = torch.empty(want, dtype=torch.uint8, device=device)
+            break
+        except torch.OutOfMemoryError:
+            if min_bytes is None or want <= int(min_bytes):
+                raise
+            torch.cuda.empty_cache()
+            want = max(int(min_bytes), want // 2)
+    _workspaces[device] = ws
     return ws
+
+
+def release_workspaces():
+    """Frees the cached scratch buffers (they are kept between calls otherwise)."""
+    _workspaces.clear()
 
 
 class SdfGrid:
@@ -252,8 +272,9 @@ def render_forward(grid, sensors, spp, seeds=None, offsets=None, integrator=DSDF
     offsets, cseeds = _sampler_args(nv, seeds, offsets, n_lanes)
     dev = grid.device
     img = torch.empty(nv, H, W, 3, dtype=torch.float32, device=dev)
-    wsb = lib.dsdf_render_workspace_size(W, H, int(spp), min(nv, MAX_VIEWS_PER_LAUNCH), INTEGRATORS[integrator])
-    ws = _workspace(dev, wsb)
+    wsb = lib.dsdf_forward_workspace_size(W, H, int(spp), min(nv, MAX_VIEWS_PER_LAUNCH), INTEGRATORS[integrator])
+    ws = _workspace(dev, wsb, lib.dsdf_forward_workspace_size(W, H, int(spp), 1, INTEGRATORS[integrator]))
+    wsb = ws.numel()
     sh, _keep = _shading_arg(integrator, shading, nv, n_lanes, emitter_samples)
     with torch.cuda.device(dev):
         _lib.check(lib.dsdf_render_forward(_ptr(grid.padded), grid.rx, grid.ry, grid.rz, C.byref(grid.params), cams, nv,
@@ -290,7 +311,8 @@ def render_backward(grid, sensors, spp, grad_image, grad_grid=None, seeds=None, 
         _require_dev(grad_p, 'grad_p')
     img = torch.empty(nv, H, W, 3, dtype=torch.float32, device=dev) if return_image else None
     wsb = lib.dsdf_render_workspace_size(W, H, int(spp), min(nv, MAX_VIEWS_PER_LAUNCH), INTEGRATORS[integrator])
-    ws = _workspace(dev, wsb)
+    ws = _workspace(dev, wsb, lib.dsdf_render_workspace_size(W, H, int(spp), 1, INTEGRATORS[integrator]))
+    wsb = ws.numel()
     sh, _keep = _shading_arg(integrator, shading, nv, n_lanes, emitter_samples, grad_albedo)
     with torch.cuda.device(dev):
         _lib.check(lib.dsdf_render_backward(_ptr(grid.padded), grid.rx, grid.ry, grid.rz, C.byref(grid.params), cams, nv,
@@ -326,7 +348,8 @@ def render_forward_grad(grid, sensors, spp, tangent_data=None, tangent_p=None, s
     out = torch.empty(nv, H, W, 3, dtype=torch.float32, device=dev)
     img = torch.empty(nv, H, W, 3, dtype=torch.float32, device=dev) if return_image else None
     wsb = lib.dsdf_render_workspace_size(W, H, int(spp), min(nv, MAX_VIEWS_PER_LAUNCH), INTEGRATORS[integrator])
-    ws = _workspace(dev, wsb)
+    ws = _workspace(dev, wsb, lib.dsdf_render_workspace_size(W, H, int(spp), 1, INTEGRATORS[integrator]))
+    wsb = ws.numel()
     with torch.cuda.device(dev):
         _lib.check(lib.dsdf_render_forward_grad(_ptr(grid.padded), grid.rx, grid.ry, grid.rz, C.byref(grid.params), cams, nv,
                                                 W, H, int(spp), _ptr(offsets), cseeds, INTEGRATORS[integrator],

@@ -156,6 +156,10 @@ int dsdf_surface_interaction(const float *padded, int rx, int ry, int rz, const 
  * is always sufficient, larger ones overlap the ray-tracing tails of the views. */
 size_t dsdf_render_workspace_size(int width, int height, int spp, int n_views, int integrator);
 
+/* The same for dsdf_render_forward alone: no backward queue, film-block adjoint or tail queue (a primal render of 12 views
+ * x 512^2 x 256 spp needs 0.1 GB instead of the 33 GB a gradient-pass workspace of that shape would take). */
+size_t dsdf_forward_workspace_size(int width, int height, int spp, int n_views, int integrator);
+
 /* `ReparamIntegrator.render` (python/integrators/reparam.py:120-185) for n_views
  * sensors: ray generation (Mitsuba perspective sensor), sphere tracing,
  * `sample()` of the selected integrator, re-projection, Gaussian-filter splat
