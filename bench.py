@@ -42,7 +42,7 @@ import torch
 # (hipcc -S, instruction histogram of the loop bodies; cross-checked against SQ_INSTS_VALU: profiles/r02_sq.json)
 VALU_MODEL = {
     'calibration': 'profiles/r02_sq.json',
-    'primal': {'per_wave_step': 262.0, 'per_traced_wave': 520.0, 'per_wave': 40.0},
+    'primal': {'per_wave_step': 215.0, 'per_traced_wave': 400.0, 'per_wave': 250.0},
 }
 VALU_PEAK = 1024 * 2.4e9 / 2.0        # wave64 VALU instructions / s: 256 CUs x 4 SIMD-32, 2 clk per instruction
 
@@ -248,7 +248,8 @@ def main():
         prim_avg = sum(prim) / len(prim)
         # VALU-issue roofline of the primal launch (k_render_pass<false,true,false>): wave-level VALU instructions
         m = VALU_MODEL['primal']
-        waves = sp['lanes'] / 64.0
+        total_lanes = nv * (args.img + 4) ** 2 * args.spp_primal
+        waves = sp['lanes'] / 64.0                        # generated samples (pixels that are not proven far), in waves
         traced_waves = sp['bbox_lanes'] / 64.0            # lanes that enter the trace loop (after the empty-space proof)
         valu = m['per_wave_step'] * sp['wave_steps'] + m['per_traced_wave'] * traced_waves + m['per_wave'] * waves
         achieved = valu / (prim_avg * 1e-3)
@@ -264,8 +265,9 @@ def main():
                                    "note": "SURVEY 8(d) tap-byte model; taps are LDS/L1-resident, so this is not a bound "
                                            "(measured HBM bytes: profiles/)"}}
         out_cfg = {"mean_steps_per_bbox_lane": sp['steps'] / max(sp['bbox_lanes'], 1),
-                   "hit_fraction": sp['hits'] / max(sp['lanes'], 1), "traced_fraction": sp['bbox_lanes'] / max(sp['lanes'], 1),
-                   "backward_queue_fraction": sg['queue_len'] / max(sg['lanes'], 1),
+                   "hit_fraction": sp['hits'] / total_lanes, "traced_fraction": sp['bbox_lanes'] / total_lanes,
+                   "generated_fraction": sp['lanes'] / total_lanes,
+                   "backward_queue_fraction": sg['queue_len'] / max(nv * (args.img + 4) ** 2 * args.spp_grad, 1),
                    "primal_ms_per_launch": prim_avg, "grad_ms_per_launch": sum(gradt) / len(gradt)}
 
     if rank == 0:

@@ -342,18 +342,40 @@ void k_render_items(GridView G, dsdf_params P, ViewBatch VB, float *__restrict__
     if (STATS) flush_stats(stats, wst, blockIdx.x, lid);
 }
 
+// Thread -> sample of the general pass.  The reference's lane order (lane = pixel * spp + sample, pixels row-major,
+// reparam.py:140-155) is only a convention -- the sampler is keyed by the lane index, so any thread may render any lane.
+// For spp < 64 (a power of two) a wave takes a tile_w x tile_h PIXEL TILE (64 / spp pixels) instead of 64 / spp consecutive
+// pixels of a row: its rays stay within a few voxels of each other (coherent row gathers, far fewer divergent march
+// lengths).  tile_w == 0: linear order.
+struct LaneMap { int tile_w, tile_h; uint32_t n_lanes; };
+
+__device__ __forceinline__ uint32_t thread_lane(const ViewArgs &A, const LaneMap &M, uint32_t t, bool &valid) {
+    if (M.tile_w == 0) {
+        valid = t < M.n_lanes;
+        return valid ? t : M.n_lanes - 1;             // (clamped: keeps the wave converged for the cross-lane code)
+    }
+    const uint32_t wave = t >> 6, l = t & 63u;
+    const uint32_t tiles_x = ((uint32_t)A.Wb + M.tile_w - 1) / (uint32_t)M.tile_w;
+    const uint32_t ty = wave / tiles_x, tx = wave - ty * tiles_x;
+    const uint32_t p = l / (uint32_t)A.spp, smp = l - p * (uint32_t)A.spp;
+    uint32_t px = tx * M.tile_w + p % (uint32_t)M.tile_w, py = ty * M.tile_h + p / (uint32_t)M.tile_w;
+    valid = px < (uint32_t)A.Wb && py < (uint32_t)A.Hb;
+    px = px < (uint32_t)A.Wb ? px : (uint32_t)A.Wb - 1;
+    py = py < (uint32_t)A.Hb ? py : (uint32_t)A.Hb - 1;
+    return (py * (uint32_t)A.Wb + px) * (uint32_t)A.spp + smp;
+}
+
 // General pass (any spp): one lane per sample, per-lane fetches and film atomics.
 template <bool DIFF, bool DIRECT>
 __global__ __launch_bounds__(DSDF_BLOCK) void k_render_pass(GridView G, dsdf_params P, ViewBatch VB, float *__restrict__ blocks,
-                                                            Queue qall, unsigned long long *stats, uint32_t n_lanes,
+                                                            Queue qall, unsigned long long *stats, LaneMap M,
                                                             const unsigned char *__restrict__ skip, ShadeArgs S) {
     const ViewArgs &A = VB.v[blockIdx.y];
     constexpr int NCH = DIRECT ? 4 : 2;
     float *__restrict__ block = blocks + (size_t)blockIdx.y * NCH * A.Wb * A.Hb;
     const Queue q = view_queue(qall, blockIdx.y);
-    uint32_t lane = blockIdx.x * DSDF_BLOCK + threadIdx.x;
-    const bool valid = lane < n_lanes;
-    if (!valid) lane = n_lanes - 1;   // keep the wave converged for the cross-lane code
+    bool valid;
+    const uint32_t lane = thread_lane(A, M, blockIdx.x * DSDF_BLOCK + threadIdx.x, valid);
     const int lid = lane_id();
     TraceOut tr, trs;
     clear_trace(tr);
@@ -513,6 +535,20 @@ static int check_launch(const char *what) {
 
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+// Lane order of the general pass for this spp (see thread_lane) and the number of 64-thread units it launches per view.
+static void pass_shape(int W, int H, int spp, int &tile_w, int &tile_h, size_t &nunits) {
+    const size_t Wb = W + 2 * DSDF_BORDER, Hb = H + 2 * DSDF_BORDER;
+    tile_w = tile_h = 0;
+    size_t waves = (Wb * Hb * (size_t)spp + 63) / 64;
+    if (spp < 64 && (spp & (spp - 1)) == 0) {
+        const int pix = 64 / spp;                      // pixels per wave: 64, 32, 16, 8, 4, 2
+        tile_w = pix >= 32 ? 8 : (pix >= 8 ? 4 : 2);
+        tile_h = pix / tile_w;
+        waves = ((Wb + tile_w - 1) / tile_w) * ((Hb + tile_h - 1) / tile_h);
+    }
+    nunits = (waves + 3) / 4 * 4;
+}
+
 struct Workspace {
     float *block, *block_adj;
     uint32_t *count, *qlane;
@@ -531,8 +567,9 @@ static Workspace carve(void *base, int W, int H, int spp, int nv, int integrator
     Workspace ws;
     const size_t nch = (size_t)film_channels(integrator), rows = integrator == DSDF_DIRECT ? 18 : 9;
     size_t Wb = W + 2 * DSDF_BORDER, Hb = H + 2 * DSDF_BORDER;
-    size_t nl = Wb * Hb * (size_t)spp;
-    size_t nunits = (nl + DSDF_BLOCK - 1) / DSDF_BLOCK * (DSDF_BLOCK / 64);
+    size_t nunits;
+    int tile_w, tile_h;
+    pass_shape(W, H, spp, tile_w, tile_h, nunits);
     size_t cap = nunits * 64;
     size_t off = 0;
     char *p = (char *)base;
@@ -805,9 +842,13 @@ static int run_pass(const PassCtx &c, const Workspace &ws, const dsdf_camera *ca
             if ((rc = check_launch("k_tail_trace_diff"))) return rc;
         }
     } else {
-        const dim3 grid((c.nl + DSDF_BLOCK - 1) / DSDF_BLOCK, nv), blk(DSDF_BLOCK);
-        if (c.direct) hipLaunchKernelGGL((k_render_pass<DIFF, true>), grid, blk, 0, st, G, c.pp, VB, ws.block, q, st64, c.nl, skip, S);
-        else hipLaunchKernelGGL((k_render_pass<DIFF, false>), grid, blk, 0, st, G, c.pp, VB, ws.block, q, st64, c.nl, skip, S);
+        LaneMap M;
+        size_t nunits;
+        pass_shape(c.W, c.H, c.spp, M.tile_w, M.tile_h, nunits);
+        M.n_lanes = c.nl;
+        const dim3 grid((unsigned)(nunits / 4), nv), blk(DSDF_BLOCK);
+        if (c.direct) hipLaunchKernelGGL((k_render_pass<DIFF, true>), grid, blk, 0, st, G, c.pp, VB, ws.block, q, st64, M, skip, S);
+        else hipLaunchKernelGGL((k_render_pass<DIFF, false>), grid, blk, 0, st, G, c.pp, VB, ws.block, q, st64, M, skip, S);
         if ((rc = check_launch("k_render_pass"))) return rc;
     }
     return DSDF_OK;

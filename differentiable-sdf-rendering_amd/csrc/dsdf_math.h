@@ -271,7 +271,7 @@ struct DirectFetch {
 // ReuseFetch: a lane keeps the 64 taps of the last cell it visited in registers and only gathers again when
 // its ray enters another cell.  Rays that leave a surface (shadow rays: Mitsuba's offset_p starts them 1e-4 away)
 // or converge onto one spend many consecutive steps inside one cell.  Same rows, same arithmetic: bit-identical
-// to DirectFetch (tests/test_kernel_math_host.py).  Opt-in on the device (DSDF_SHADOW_REUSE): it costs 64 VGPRs.
+// to DirectFetch (tests/test_kernel_math_host.py).  Used by the value-only shadow rays of sdf_direct_reparam (dsdf_lane.h): it costs 64 VGPRs.
 struct RegRows {
     const float *t;
     DSDF_HD void get(int k, int j, v2f &lo, v2f &hi) const {

@@ -11,7 +11,9 @@
 // its loop is 3x cheaper per step, the hand-off costs the same) and was dropped.
 #pragma once
 
-#define DSDF_TAIL_HANDOFF 8         /* rays of a wave that may still be marching when its loop ends */
+#ifndef DSDF_TAIL_HANDOFF
+#define DSDF_TAIL_HANDOFF 8         /* rays of a wave that may still be marching when its loop ends (tunable: A/B 4 vs 8 vs 16) */
+#endif
 #define DSDF_TAIL_SUBQ 64           /* sub-queues per launch: spreads the reservation atomics */
 #define DSDF_TAIL_REFILL 24         /* idle lanes that trigger a refill in the tail kernel */
 #define DSDF_TAIL_BLOCKS_PER_SUBQ 16   /* 4096 persistent tail waves */
