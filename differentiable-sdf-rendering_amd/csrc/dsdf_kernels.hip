@@ -249,11 +249,13 @@ __device__ __forceinline__ void queue_unit(const Queue &q, uint32_t unit, uint32
 // Work list of a launch: the film-block pixels of all its views whose samples must be generated (k_skip_dilate bit 2 / 3
 // clear), appended block-wise (one atomic per 256 pixels), entry = view * Wb * Hb + pixel.  items[0] = count, items[1] = ticket.
 #define DSDF_ITEM_HDR 4
-__global__ void k_build_items(ViewBatch VB, int nv, const unsigned char *__restrict__ skip, unsigned far_bit, uint32_t *__restrict__ items) {
+__global__ void k_build_items(ViewBatch VB, int nv, const unsigned char *__restrict__ skip, unsigned far_bit, int row0, int row1,
+                              uint32_t *__restrict__ items) {
     const ViewArgs &A = VB.v[0];
     const uint32_t npix = (uint32_t)(A.Wb * A.Hb);
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    const bool in = i < npix * (uint32_t)nv;
+    const int py = (int)((i % npix) / (uint32_t)A.Wb);       // film-block row: only the rows [row0, row1) of this call's window
+    const bool in = i < npix * (uint32_t)nv && py >= row0 && py < row1;
     const bool live = in && !(skip && (skip[i] & far_bit));
     const uint64_t m = __ballot(live);
     __shared__ uint32_t wbase[4];
@@ -347,7 +349,7 @@ void k_render_items(GridView G, dsdf_params P, ViewBatch VB, float *__restrict__
 // For spp < 64 (a power of two) a wave takes a tile_w x tile_h PIXEL TILE (64 / spp pixels) instead of 64 / spp consecutive
 // pixels of a row: its rays stay within a few voxels of each other (coherent row gathers, far fewer divergent march
 // lengths).  tile_w == 0: linear order.
-struct LaneMap { int tile_w, tile_h; uint32_t n_lanes; };
+struct LaneMap { int tile_w, tile_h; uint32_t n_lanes; int row0, row1; };   // rows: film-block row window of the call
 
 __device__ __forceinline__ uint32_t thread_lane(const ViewArgs &A, const LaneMap &M, uint32_t t, bool &valid) {
     if (M.tile_w == 0) {
@@ -382,12 +384,15 @@ __global__ __launch_bounds__(DSDF_BLOCK) void k_render_pass(GridView G, dsdf_par
     // empty-space proof for this sample's pixel.  skip_trace: a miss with no warp is known; far: nothing this sample does
     // can reach an output (k_skip_dilate), so it is not generated.
     bool skip_trace = false, far = false;
-    if (skip) {
+    {
         int px, py;
         lane_pixel(A, lane, px, py);
-        const unsigned f = skip[(size_t)blockIdx.y * A.Wb * A.Hb + (size_t)py * A.Wb + px];
-        skip_trace = (f & (DIFF ? 2u : 1u)) != 0;
-        far = (f & (DIFF ? 8u : 4u)) != 0;
+        if (skip) {
+            const unsigned f = skip[(size_t)blockIdx.y * A.Wb * A.Hb + (size_t)py * A.Wb + px];
+            skip_trace = (f & (DIFF ? 2u : 1u)) != 0;
+            far = (f & (DIFF ? 8u : 4u)) != 0 && !(DIRECT && !S.hide_emitters);   // (a visible environment is not zero)
+        }
+        if (py < M.row0 || py >= M.row1) { far = true; valid = false; }         // outside this call's row window
     }
     bool lit = false;
     Lane L;
@@ -754,6 +759,8 @@ struct PassCtx {
     int W, H, spp, integrator, flags; bool direct;
     const float *offsets, *emitter_u; const uint32_t *seeds; const dsdf_shading *shading;
     size_t Wb, Hb; uint32_t nl;
+    int row0, row1;        // film-block rows of this call (multi-GPU pixel-tile split; the whole film by default)
+    float *film;           // caller-owned film block to ACCUMULATE into (tile calls), or nullptr: the workspace's, zeroed
     hipStream_t st;
 };
 
@@ -765,6 +772,7 @@ static PassCtx make_ctx(const float *padded, int rx, int ry, int rz, const dsdf_
     c.W = W; c.H = H; c.spp = spp; c.integrator = integrator; c.flags = flags; c.direct = integrator == DSDF_DIRECT;
     c.offsets = offsets; c.seeds = seeds; c.shading = shading; c.emitter_u = c.direct ? shading->emitter_samples : nullptr;
     c.Wb = W + 2 * DSDF_BORDER; c.Hb = H + 2 * DSDF_BORDER; c.nl = (uint32_t)(c.Wb * c.Hb * spp);
+    c.row0 = 0; c.row1 = (int)c.Hb; c.film = nullptr;
     c.st = (hipStream_t)stream;
     return c;
 }
@@ -791,7 +799,8 @@ static int run_pass(const PassCtx &c, const Workspace &ws, const dsdf_camera *ca
                                  c.seeds ? c.seeds[v0 + i] : 0u, c.integrator, c.flags,
                                  c.emitter_u ? c.emitter_u + (size_t)(v0 + i) * c.nl * 2 : nullptr);
     const size_t nch = (size_t)film_channels(c.integrator), npix = c.Wb * c.Hb;
-    if (hipMemsetAsync(ws.block, 0, nv * npix * nch * sizeof(float), st) != hipSuccess)
+    float *film = c.film ? c.film + (size_t)v0 * npix * nch : ws.block;
+    if (!c.film && hipMemsetAsync(ws.block, 0, nv * npix * nch * sizeof(float), st) != hipSuccess)
         return fail(DSDF_ERR_LAUNCH, "hipMemsetAsync(film block) failed");
     float step = 0.f;
     const int level = (c.flags & DSDF_NO_SKIP) ? -1 : skip_level(cams + v0, nv, c.W, c.rx, c.ry, c.rz, step);
@@ -813,7 +822,7 @@ static int run_pass(const PassCtx &c, const Workspace &ws, const dsdf_camera *ca
         const unsigned far_bit = (c.direct && !S.hide_emitters) ? 0u : (DIFF ? 8u : 4u);
         if (hipMemsetAsync(ws.items, 0, DSDF_ITEM_HDR * sizeof(uint32_t), st) != hipSuccess)
             return fail(DSDF_ERR_LAUNCH, "hipMemsetAsync(work list) failed");
-        hipLaunchKernelGGL(k_build_items, dim3((unsigned)((nv * npix + 255) / 256)), dim3(256), 0, st, VB, nv, skip, far_bit, ws.items);
+        hipLaunchKernelGGL(k_build_items, dim3((unsigned)((nv * npix + 255) / 256)), dim3(256), 0, st, VB, nv, skip, far_bit, c.row0, c.row1, ws.items);
         if ((rc = check_launch("k_build_items"))) return rc;
         TailQueue tq;
         memset(&tq, 0, sizeof(tq));
@@ -830,25 +839,25 @@ static int run_pass(const PassCtx &c, const Workspace &ws, const dsdf_camera *ca
         }
         const dim3 grid(worker_blocks()), blk(64);
         if (c.direct) {
-            if (st64) hipLaunchKernelGGL((k_render_items<DIFF, true, true>), grid, blk, 0, st, G, c.pp, VB, ws.block, q, st64, skip, S, tq, ws.items);
-            else hipLaunchKernelGGL((k_render_items<DIFF, true, false>), grid, blk, 0, st, G, c.pp, VB, ws.block, q, st64, skip, S, tq, ws.items);
+            if (st64) hipLaunchKernelGGL((k_render_items<DIFF, true, true>), grid, blk, 0, st, G, c.pp, VB, film, q, st64, skip, S, tq, ws.items);
+            else hipLaunchKernelGGL((k_render_items<DIFF, true, false>), grid, blk, 0, st, G, c.pp, VB, film, q, st64, skip, S, tq, ws.items);
         } else {
-            if (st64) hipLaunchKernelGGL((k_render_items<DIFF, false, true>), grid, blk, 0, st, G, c.pp, VB, ws.block, q, st64, skip, S, tq, ws.items);
-            else hipLaunchKernelGGL((k_render_items<DIFF, false, false>), grid, blk, 0, st, G, c.pp, VB, ws.block, q, st64, skip, S, tq, ws.items);
+            if (st64) hipLaunchKernelGGL((k_render_items<DIFF, false, true>), grid, blk, 0, st, G, c.pp, VB, film, q, st64, skip, S, tq, ws.items);
+            else hipLaunchKernelGGL((k_render_items<DIFF, false, false>), grid, blk, 0, st, G, c.pp, VB, film, q, st64, skip, S, tq, ws.items);
         }
         if ((rc = check_launch("k_render_items"))) return rc;
         if (tq.state) {
-            hipLaunchKernelGGL(k_tail_trace_diff, dim3(DSDF_TAIL_SUBQ * DSDF_TAIL_BLOCKS_PER_SUBQ), dim3(256), 0, st, G, c.pp, VB, ws.block, tq, q);
+            hipLaunchKernelGGL(k_tail_trace_diff, dim3(DSDF_TAIL_SUBQ * DSDF_TAIL_BLOCKS_PER_SUBQ), dim3(256), 0, st, G, c.pp, VB, film, tq, q);
             if ((rc = check_launch("k_tail_trace_diff"))) return rc;
         }
     } else {
         LaneMap M;
         size_t nunits;
         pass_shape(c.W, c.H, c.spp, M.tile_w, M.tile_h, nunits);
-        M.n_lanes = c.nl;
+        M.n_lanes = c.nl; M.row0 = c.row0; M.row1 = c.row1;
         const dim3 grid((unsigned)(nunits / 4), nv), blk(DSDF_BLOCK);
-        if (c.direct) hipLaunchKernelGGL((k_render_pass<DIFF, true>), grid, blk, 0, st, G, c.pp, VB, ws.block, q, st64, M, skip, S);
-        else hipLaunchKernelGGL((k_render_pass<DIFF, false>), grid, blk, 0, st, G, c.pp, VB, ws.block, q, st64, M, skip, S);
+        if (c.direct) hipLaunchKernelGGL((k_render_pass<DIFF, true>), grid, blk, 0, st, G, c.pp, VB, film, q, st64, M, skip, S);
+        else hipLaunchKernelGGL((k_render_pass<DIFF, false>), grid, blk, 0, st, G, c.pp, VB, film, q, st64, M, skip, S);
         if ((rc = check_launch("k_render_pass"))) return rc;
     }
     return DSDF_OK;
@@ -961,6 +970,97 @@ int dsdf_render_forward_grad(const float *padded, int rx, int ry, int rz, const 
         if (image_out && (rc = develop_batch(c, ws, nv, image_out + (size_t)v0 * width * height * 3))) return rc;
     }
     return DSDF_OK;
+}
+
+// ---- multi-GPU pixel-tile split: when there are more ranks than views, a view is cut into row windows of
+// its film block; every rank renders the samples of its window into a FULL-SIZE film block, the blocks are summed
+// across the ranks of the view (one RCCL all-reduce, dsdf/parallel.py) and developed; the gradient pass does the same for
+// its film, then every rank back-propagates ITS samples against the summed film.  Samples keep their reference lane
+// index, so the union over the windows is sample for sample the un-split render.
+static int check_rows(int height, int row0, int row1) {
+    if (row0 < 0 || row1 > height + 2 * DSDF_BORDER || row0 >= row1) return fail(DSDF_ERR_INVALID_ARG, "bad film-block row window");
+    return DSDF_OK;
+}
+
+int dsdf_render_film(const float *padded, int rx, int ry, int rz, const dsdf_params *prm, const dsdf_camera *cams,
+                     int n_views, int width, int height, int spp, const float *offsets, const uint32_t *seeds,
+                     int integrator, int flags, const dsdf_shading *shading, int row0, int row1, float *film,
+                     void *workspace, size_t workspace_bytes, int64_t *stats, void *stream) {
+    int rc = check_render_args(padded, rx, ry, rz, prm, cams, n_views, width, height, spp, integrator, shading, workspace,
+                               workspace_bytes, false);
+    if (rc) return rc;
+    if ((rc = check_rows(height, row0, row1))) return rc;
+    if (!film) return fail(DSDF_ERR_INVALID_ARG, "dsdf_render_film: film is null");
+    if (!offsets && !seeds) return fail(DSDF_ERR_INVALID_ARG, "dsdf_render_film: need offsets or seeds");
+    PassCtx c = make_ctx(padded, rx, ry, rz, prm, width, height, spp, offsets, seeds, integrator, flags, shading, stream);
+    c.row0 = row0; c.row1 = row1; c.film = film;
+    const int nb = batch_size(width, height, spp, n_views, integrator, workspace_bytes, false);
+    const Workspace ws = carve(workspace, width, height, spp, nb, integrator, false);
+    const Queue q = make_queue(ws, c.direct);
+    for (int v0 = 0; v0 < n_views; v0 += nb) {
+        const int nv = (n_views - v0) < nb ? (n_views - v0) : nb;
+        ViewBatch VB;
+        if ((rc = run_pass<false>(c, ws, cams, v0, nv, VB, q, stats))) return rc;
+    }
+    return DSDF_OK;
+}
+
+int dsdf_develop(const float *film, int n_views, int width, int height, int integrator, float *image_out, void *stream) {
+    if (!film || !image_out || n_views < 1 || width < 1 || height < 1) return fail(DSDF_ERR_INVALID_ARG, "dsdf_develop: bad argument");
+    const dim3 grid((width * height + 255) / 256, n_views);
+    if (integrator == DSDF_DIRECT) hipLaunchKernelGGL(k_develop_rgb, grid, dim3(256), 0, (hipStream_t)stream, film, width, height, image_out);
+    else hipLaunchKernelGGL(k_develop, grid, dim3(256), 0, (hipStream_t)stream, film, width, height, image_out);
+    return check_launch("k_develop");
+}
+
+int dsdf_grad_sweep(const float *padded, int rx, int ry, int rz, const dsdf_params *prm, const dsdf_camera *cams,
+                    int n_views, int width, int height, int spp, const float *offsets, const uint32_t *seeds,
+                    int integrator, int flags, const dsdf_shading *shading, int row0, int row1, float *film,
+                    void *workspace, size_t workspace_bytes, void *stream) {
+    int rc = check_render_args(padded, rx, ry, rz, prm, cams, n_views, width, height, spp, integrator, shading, workspace,
+                               workspace_bytes, true);
+    if (rc) return rc;
+    if ((rc = check_rows(height, row0, row1))) return rc;
+    if (!film) return fail(DSDF_ERR_INVALID_ARG, "dsdf_grad_sweep: film is null");
+    if (!offsets && !seeds) return fail(DSDF_ERR_INVALID_ARG, "dsdf_grad_sweep: need offsets or seeds");
+    if (batch_size(width, height, spp, n_views, integrator, workspace_bytes, true) < n_views)
+        return fail(DSDF_ERR_WORKSPACE, "dsdf_grad_sweep: the workspace must hold all views of the call (the backward queue stays in it)");
+    PassCtx c = make_ctx(padded, rx, ry, rz, prm, width, height, spp, offsets, seeds, integrator, flags, shading, stream);
+    c.row0 = row0; c.row1 = row1; c.film = film;
+    const Workspace ws = carve(workspace, width, height, spp, n_views, integrator, true);
+    ViewBatch VB;
+    return run_pass<true>(c, ws, cams, 0, n_views, VB, make_queue(ws, c.direct), nullptr);
+}
+
+int dsdf_grad_backward(const float *padded, int rx, int ry, int rz, const dsdf_params *prm, const dsdf_camera *cams,
+                       int n_views, int width, int height, int spp, const float *offsets, const uint32_t *seeds,
+                       int integrator, int flags, const dsdf_shading *shading, const float *film_total,
+                       const float *grad_image, float *grad_grid, float *grad_p, void *workspace, size_t workspace_bytes,
+                       void *stream) {
+    int rc = check_render_args(padded, rx, ry, rz, prm, cams, n_views, width, height, spp, integrator, shading, workspace,
+                               workspace_bytes, true);
+    if (rc) return rc;
+    if (!film_total || !grad_image || !grad_grid) return fail(DSDF_ERR_INVALID_ARG, "dsdf_grad_backward: null buffer");
+    if (batch_size(width, height, spp, n_views, integrator, workspace_bytes, true) < n_views)
+        return fail(DSDF_ERR_WORKSPACE, "dsdf_grad_backward: the workspace must be the one dsdf_grad_sweep filled");
+    const PassCtx c = make_ctx(padded, rx, ry, rz, prm, width, height, spp, offsets, seeds, integrator, flags, shading, stream);
+    hipStream_t st = c.st;
+    const Workspace ws = carve(workspace, width, height, spp, n_views, integrator, true);
+    const Queue q = make_queue(ws, c.direct);
+    ViewBatch VB;
+    for (int i = 0; i < n_views; ++i)
+        VB.v[i] = make_view_args(cams[i], width, height, spp, offsets ? offsets + (size_t)i * c.nl * 2 : nullptr, seeds ? seeds[i] : 0u,
+                                 integrator, flags, c.emitter_u ? c.emitter_u + (size_t)i * c.nl * 2 : nullptr);
+    const dim3 adj_grid((unsigned)((c.Wb * c.Hb + 255) / 256), n_views);
+    if (c.direct) hipLaunchKernelGGL(k_develop_adjoint_rgb, adj_grid, dim3(256), 0, st, film_total, grad_image, width, height, ws.block_adj);
+    else hipLaunchKernelGGL(k_develop_adjoint, adj_grid, dim3(256), 0, st, film_total, grad_image, width, height, ws.block_adj);
+    if ((rc = check_launch("k_develop_adjoint"))) return rc;
+    const GridView G = device_view(padded, rx, ry, rz, *prm);
+    const ShadeArgs S = make_shade_args(shading, true);
+    const dim3 grid((ws.nunits + 3) / 4, n_views);
+    if (c.direct) hipLaunchKernelGGL(k_backward<true>, grid, dim3(64), 0, st, G, c.pp, VB, q, ws.block_adj, grad_grid, grad_p, (unsigned long long *)nullptr, S);
+    else hipLaunchKernelGGL(k_backward<false>, grid, dim3(64), 0, st, G, c.pp, VB, q, ws.block_adj, grad_grid, grad_p, (unsigned long long *)nullptr, S);
+    return check_launch("k_backward");
 }
 
 }  // extern "C"

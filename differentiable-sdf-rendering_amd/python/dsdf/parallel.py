@@ -9,6 +9,8 @@ into a single flat bucket so xGMI sees one large collective instead of several
 small ones.  Works with any torch.distributed backend (`nccl` = RCCL on ROCm;
 `gloo` for the CPU tests of the host logic).
 """
+import math
+
 import torch
 
 
@@ -27,6 +29,77 @@ def strided_view_shard(indices, rank, world):
     `get_sensor_iterator` batch, python/opt_configs.py:57-66): round-robin so that each
     rank's views are spread around the ring."""
     return list(indices)[rank::world]
+
+
+def work_partition(n_views, film_rows, world):
+    """Work units of one step for `world` ranks: a list (one entry per rank) of lists of (view, row0, row1) with
+    film-block row windows [row0, row1) of a film block with `film_rows` (= H + 4) rows.
+
+    world divides n_views : whole views, dealt round-robin over the ring (every rank sees equally expensive views).
+    otherwise             : every view is cut into t = world / gcd(n_views, world) row windows ("pixel tiles within a view
+                            when N > views-per-iteration") and the n_views * t windows are dealt round-robin --
+                            12 views on 8 ranks: 24 half-views, 3 per rank, instead of the 2/1 imbalance of whole views."""
+    if world < 1 or n_views < 1:
+        raise ValueError("bad n_views / world")
+    # smallest number of windows per view that makes the units divide evenly over the ranks (1 when world divides n_views)
+    tiles = world // math.gcd(n_views, world)
+    edges = [round(k * film_rows / tiles) for k in range(tiles + 1)]
+    units = [(v, edges[k], edges[k + 1]) for v in range(n_views) for k in range(tiles)]
+    return [units[r::world] for r in range(world)]
+
+
+def rank_windows(units):
+    """Groups a rank's (view, row0, row1) units by row window: [((row0, row1), [views...]), ...] -- one library call per
+    window renders all of the rank's views that share it."""
+    out = {}
+    for v, r0, r1 in units:
+        out.setdefault((r0, r1), []).append(v)
+    return sorted(out.items())
+
+
+def all_reduce_sum(t, group=None):
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return t
+
+
+def render_step(ops, n_views, W, H, rank, world, loss_grad, grad_grid, group=None):
+    """One differentiable render of `n_views` views shared by `world` ranks, split by views and -- when world does not
+    divide them -- by pixel tiles (work_partition).  `ops` supplies the four film-level operators of the renderer for a
+    list of views and a row window (dsdf.render_film / develop / GradSweep on a GPU; the oracle's in the CPU tests):
+        ops.film(views, rows)                      -> primal film blocks (len(views), H+4, W+4, C) of the window's samples
+        ops.develop(film_total)                    -> images (n, H, W, 3)
+        ops.sweep(views, rows)                     -> (gradient-pass film blocks, handle)
+        ops.backward(handle, film_total, grad_image, grad_grid)   accumulates dL/dsdf of the window's samples
+    Exchange steps: sum of the primal films, sum of the gradient-pass films (only views that are actually split would need
+    them; all views are reduced here for simplicity: 2 x n_views x 2 MiB at 512^2), and the ONE sum of dL/dsdf.
+    loss_grad(images) -> dL/d(images).  Returns the images (identical on every rank)."""
+    import torch
+    units = work_partition(n_views, H + 4, world)[rank]
+    wins = rank_windows(units)
+    film = None
+    for rows, views in wins:
+        f = ops.film(views, rows)
+        if film is None:
+            film = torch.zeros((n_views,) + tuple(f.shape[1:]), dtype=f.dtype, device=f.device)
+        film[views] += f
+    if film is None:
+        film = ops.empty_film(n_views)
+    all_reduce_sum(film, group)
+    images = ops.develop(film)
+    grad_images = loss_grad(images)
+    film_g = torch.zeros_like(film)
+    handles = []
+    for rows, views in wins:
+        f, h = ops.sweep(views, rows)
+        film_g[views] += f
+        handles.append((views, h))
+    all_reduce_sum(film_g, group)
+    for views, h in handles:
+        ops.backward(h, film_g[views].contiguous(), grad_images[views].contiguous(), grad_grid)
+    all_reduce_gradients([grad_grid], group)
+    return images
 
 
 def all_reduce_gradients(tensors, group=None):

@@ -358,6 +358,88 @@ def render_forward_grad(grid, sensors, spp, tangent_data=None, tangent_p=None, s
     return (out, img) if return_image else out
 
 
+# ---- multi-GPU pixel-tile split of a view (include/dsdf.h; driver: dsdf/parallel.py) ------------------------------------
+def film_channels(integrator):
+    return 4 if INTEGRATORS[integrator] == DSDF_DIRECT else 2
+
+
+def new_film(n_views, W, H, integrator, device):
+    """Zeroed film blocks (n_views, H+4, W+4, C)."""
+    return torch.zeros(n_views, H + 4, W + 4, film_channels(integrator), dtype=torch.float32, device=device)
+
+
+def render_film(grid, sensors, spp, film, rows, seeds=None, offsets=None, integrator=DSDF_SILHOUETTE, reparam=True,
+                empty_space_skip=True, shading=None, emitter_samples=None, stats=None):
+    """Primal samples of the film-block rows [rows[0], rows[1]) of every view, ACCUMULATED into `film`."""
+    lib = _lib.load()
+    sensors, cams, W, H = _views(sensors)
+    nv = len(sensors)
+    n_lanes = (W + 4) * (H + 4) * int(spp)
+    offsets, cseeds = _sampler_args(nv, seeds, offsets, n_lanes)
+    dev = grid.device
+    _require_dev(film, 'film')
+    wsb = lib.dsdf_forward_workspace_size(W, H, int(spp), min(nv, MAX_VIEWS_PER_LAUNCH), INTEGRATORS[integrator])
+    ws = _workspace(dev, wsb, lib.dsdf_forward_workspace_size(W, H, int(spp), 1, INTEGRATORS[integrator]))
+    sh, _keep = _shading_arg(integrator, shading, nv, n_lanes, emitter_samples)
+    with torch.cuda.device(dev):
+        _lib.check(lib.dsdf_render_film(_ptr(grid.padded), grid.rx, grid.ry, grid.rz, C.byref(grid.params), cams, nv, W, H, int(spp),
+                                        _ptr(offsets), cseeds, INTEGRATORS[integrator],
+                                        (DSDF_REPARAM if reparam else 0) | (0 if empty_space_skip else DSDF_NO_SKIP), sh,
+                                        int(rows[0]), int(rows[1]), _ptr(film), _ptr(ws), ws.numel(), _ptr(stats), _stream()))
+    return film
+
+
+def develop(film, W, H, integrator=DSDF_SILHOUETTE):
+    """`HDRFilm.develop` of film blocks -> (n_views, H, W, 3)."""
+    lib = _lib.load()
+    _require_dev(film, 'film')
+    nv = film.shape[0]
+    img = torch.empty(nv, H, W, 3, dtype=torch.float32, device=film.device)
+    with torch.cuda.device(film.device):
+        _lib.check(lib.dsdf_develop(_ptr(film), nv, W, H, INTEGRATORS[integrator], _ptr(img), _stream()))
+    return img
+
+
+class GradSweep:
+    """The two halves of a gradient pass split at the film block: sweep() traces the window's samples (film accumulated,
+    backward queue left in this object's workspace); after the films of all ranks were summed, backward() propagates the
+    window's samples against the total film."""
+
+    def __init__(self, grid, sensors, spp, rows, seeds=None, offsets=None, integrator=DSDF_SILHOUETTE, reparam=True,
+                 empty_space_skip=True, shading=None, emitter_samples=None, grad_albedo=None):
+        self.lib = _lib.load()
+        self.grid = grid
+        self.sensors, self.cams, self.W, self.H = _views(sensors)
+        self.nv = len(self.sensors)
+        self.spp = int(spp)
+        n_lanes = (self.W + 4) * (self.H + 4) * self.spp
+        self.offsets, self.cseeds = _sampler_args(self.nv, seeds, offsets, n_lanes)
+        self.integrator = INTEGRATORS[integrator]
+        self.flags = (DSDF_REPARAM if reparam else 0) | (0 if empty_space_skip else DSDF_NO_SKIP)
+        self.rows = (int(rows[0]), int(rows[1]))
+        self.sh, self._keep = _shading_arg(integrator, shading, self.nv, n_lanes, emitter_samples, grad_albedo)
+        wsb = self.lib.dsdf_render_workspace_size(self.W, self.H, self.spp, self.nv, self.integrator)
+        self.ws = torch.empty(int(wsb), dtype=torch.uint8, device=grid.device)     # private: the queue lives here between the halves
+
+    def _args(self):
+        g = self.grid
+        return (_ptr(g.padded), g.rx, g.ry, g.rz, C.byref(g.params), self.cams, self.nv, self.W, self.H, self.spp,
+                _ptr(self.offsets), self.cseeds, self.integrator, self.flags, self.sh)
+
+    def sweep(self, film):
+        _require_dev(film, 'film')
+        with torch.cuda.device(self.grid.device):
+            _lib.check(self.lib.dsdf_grad_sweep(*self._args(), self.rows[0], self.rows[1], _ptr(film), _ptr(self.ws), self.ws.numel(), _stream()))
+        return film
+
+    def backward(self, film_total, grad_image, grad_grid, grad_p=None):
+        _require_dev(film_total, 'film_total'); grad_image = _require_dev(grad_image, 'grad_image'); _require_dev(grad_grid, 'grad_grid')
+        with torch.cuda.device(self.grid.device):
+            _lib.check(self.lib.dsdf_grad_backward(*self._args(), _ptr(film_total), _ptr(grad_image), _ptr(grad_grid), _ptr(grad_p),
+                                                   _ptr(self.ws), self.ws.numel(), _stream()))
+        return grad_grid
+
+
 def redistance(phi):
     """`redistancing.redistance`: signed distance field with the zero level set of phi (Z,Y,X[,1])."""
     lib = _lib.load()

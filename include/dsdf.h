@@ -213,6 +213,39 @@ int dsdf_render_forward_grad(const float *padded, int rx, int ry, int rz, const 
                              float *grad_image_out, float *image_out,
                              void *workspace, size_t workspace_bytes, void *stream);
 
+/* ---- multi-GPU pixel-tile split of a view ("pixel tiles within a view when N > views-per-iteration") --------
+ * The reference is single-device; these four entry points split `ReparamIntegrator.render` / `render_backward`
+ * (python/integrators/reparam.py:120-190) at the film block so that several ranks can share ONE view:
+ *   film   : n_views x (H+4) x (W+4) x C fp32 film blocks (C = 2: value, weight; 4 for DSDF_DIRECT: r,g,b,weight), caller-owned.
+ *   row0/1 : the rank's window of film-BLOCK rows [row0, row1), 0 <= row0 < row1 <= H+4.  Only samples whose pixel lies in
+ *            the window are generated; they keep the lane index (hence the sampler stream / offsets entry) they have in the
+ *            un-split render, so the windows of all ranks add up to exactly that render.
+ * Protocol per step (dsdf/parallel.py): zero film; dsdf_render_film; all-reduce(film); dsdf_develop -> image, loss, grad_image;
+ * zero film_g; dsdf_grad_sweep; all-reduce(film_g); dsdf_grad_backward (same workspace, same arguments); all-reduce(grad_grid). */
+int dsdf_render_film(const float *padded, int rx, int ry, int rz, const dsdf_params *prm,
+                     const dsdf_camera *cams, int n_views, int width, int height, int spp,
+                     const float *offsets, const uint32_t *seeds, int integrator, int flags, const dsdf_shading *shading,
+                     int row0, int row1, float *film /* ACCUMULATED */, void *workspace, size_t workspace_bytes /* dsdf_forward_workspace_size */,
+                     int64_t *stats, void *stream);
+
+/* `HDRFilm.develop` of film blocks (crop the border, value / weight): image_out n_views x H x W x 3. */
+int dsdf_develop(const float *film, int n_views, int width, int height, int integrator, float *image_out, void *stream);
+
+/* Forward sweep of the gradient pass for the window: accumulates the gradient-pass film and leaves the backward queue of the
+ * window's samples in `workspace` (which must hold all n_views: dsdf_render_workspace_size(..., n_views, ...)). */
+int dsdf_grad_sweep(const float *padded, int rx, int ry, int rz, const dsdf_params *prm,
+                    const dsdf_camera *cams, int n_views, int width, int height, int spp,
+                    const float *offsets, const uint32_t *seeds, int integrator, int flags, const dsdf_shading *shading,
+                    int row0, int row1, float *film /* ACCUMULATED */, void *workspace, size_t workspace_bytes, void *stream);
+
+/* Backward of the samples queued by the preceding dsdf_grad_sweep (same arguments, same workspace) against the film summed
+ * over all ranks of the view: accumulates dL/dsdf (and dL/d sdf.p, dL/d albedo) like dsdf_render_backward. */
+int dsdf_grad_backward(const float *padded, int rx, int ry, int rz, const dsdf_params *prm,
+                       const dsdf_camera *cams, int n_views, int width, int height, int spp,
+                       const float *offsets, const uint32_t *seeds, int integrator, int flags, const dsdf_shading *shading,
+                       const float *film_total, const float *grad_image, float *grad_grid, float *grad_p,
+                       void *workspace, size_t workspace_bytes, void *stream);
+
 /* `redistancing.redistance(phi)` (python/redistancing.py:4-13 -> fastsweep.redistance, an
  * un-vendored native dependency): re-initialises phi (rz,ry,rx) to a signed distance field
  * with the same zero level set, grid spacing 1/res on the unit cube.  Spec: frozen sub-voxel

@@ -759,14 +759,21 @@ def lane_positions(W, H, spp, offsets):
 
 
 def render(sdf, cam, W, H, spp, offsets, integrator=SILHOUETTE, reparam=True,
-           return_aux=False, chunk=1 << 17, albedo=None, emitter_u=None, env=1.0, hide_emitters=False):
+           return_aux=False, chunk=1 << 17, albedo=None, emitter_u=None, env=1.0, hide_emitters=False, rows=None,
+           return_block=False):
     """One view.  offsets: (Wb*Hb*spp, 2) in [0,1) (the sampler's next_2d per
     lane).  Returns image (H,W,3), differentiable w.r.t. sdf.data / sdf.p when
     they require grad.  `reparam=False` gives the DummyWarpField path
-    (warp.py:179-196)."""
+    (warp.py:179-196).  rows = (row0, row1): only the samples of the film-BLOCK rows [row0, row1) are generated
+    (multi-GPU pixel-tile split; they keep their lane index); return_block: the un-developed film block (Hb, Wb, 4)."""
     Wb, Hb = W + 2 * BORDER, H + 2 * BORDER
     dt = offsets.dtype
     pos_all = lane_positions(W, H, spp, offsets)
+    if rows is not None:
+        lo, hi = rows[0] * Wb * spp, rows[1] * Wb * spp          # lanes are pixel-major, pixels row-major
+        pos_all = pos_all[lo:hi]
+        if emitter_u is not None:
+            emitter_u = emitter_u[lo:hi]
     block = torch.zeros(Hb * Wb * 4, dtype=dt)
     aux = dict(steps=0, lanes=0, bbox=0, hits=0, refine=0, warp_active=0)
     light = torch.tensor([1.0, 1.0, 1.0], dtype=dt) / math.sqrt(3.0)
@@ -819,6 +826,8 @@ def render(sdf, cam, W, H, spp, offsets, integrator=SILHOUETTE, reparam=True,
         aux['steps'] += int(tr['steps'].sum()); aux['lanes'] += N
         aux['bbox'] += int((tr['steps'] > 0).sum()); aux['hits'] += int(hit.sum())
         aux['refine'] += int(tr['refine_steps'].sum())
+    if return_block:
+        return block.reshape(Hb, Wb, 4)
     img = develop(block, W, H)
     if return_aux:
         return img, aux

@@ -48,6 +48,99 @@ def _worker(rank, world, port, out):
     dist.destroy_process_group()
 
 
+def _tile_worker(rank, world, port, out, n_views):
+    """render_step (dsdf/parallel.py) with the ORACLE's film-level operators: the split by views and by pixel tiles, the two
+    film sums and the gradient sum reproduce the single-process image and gradient."""
+    for p in (os.path.join(ROOT, 'oracle'), os.path.join(ROOT, 'differentiable-sdf-rendering_amd', 'python'), os.path.join(ROOT, 'tests')):
+        sys.path.insert(0, p)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    import sdf_oracle as O
+    from dsdf import parallel
+    R, W, H, spp = 16, 10, 8, 4
+    grid = O.sphere_grid(R)
+    gen = torch.Generator().manual_seed(7)
+    offs = [torch.rand((W + 4) * (H + 4) * spp, 2, generator=gen, dtype=torch.float64) for _ in range(n_views)]
+    tgt = torch.rand(n_views, H, W, 3, generator=gen, dtype=torch.float64)
+    cams = [O.Camera(o) for o in O.regular_camera_origins(max(n_views, 3))[:n_views]]
+    integ = O.SIMPLE_SHADING
+
+    class Ops:                                     # the four film-level operators, from the oracle (C = 4: r, g, b, weight)
+        def film(self, views, rows):
+            with torch.no_grad():
+                return torch.stack([O.render(O.Grid3d(grid), cams[v], W, H, spp, offs[v], integ, rows=rows, return_block=True) for v in views])
+
+        def empty_film(self, n):
+            return torch.zeros(n, H + 4, W + 4, 4, dtype=torch.float64)
+
+        def develop(self, film):
+            return torch.stack([O.develop(f.reshape(-1), W, H) for f in film])
+
+        def sweep(self, views, rows):
+            leaf = grid.clone().requires_grad_(True)
+            blocks = torch.stack([O.render(O.Grid3d(leaf), cams[v], W, H, spp, offs[v], integ, rows=rows, return_block=True) for v in views])
+            return blocks.detach(), (leaf, blocks)
+
+        def backward(self, handle, film_total, grad_image, grad_grid):
+            leaf, mine = handle
+            # the window's samples against the film of ALL samples: total = mine (attached) + the others' (constants)
+            total = mine + (film_total - mine.detach())
+            img = torch.stack([O.develop(f.reshape(-1), W, H) for f in total])
+            if img.requires_grad:
+                (img * grad_image).sum().backward()
+                grad_grid += leaf.grad
+
+    g = torch.zeros(R, R, R, dtype=torch.float64)
+    images = parallel.render_step(Ops(), n_views, W, H, rank, world, lambda im: 2.0 * (im - tgt), g)
+    if rank == 0:
+        leaf = grid.clone().requires_grad_(True)
+        ref = torch.stack([O.render(O.Grid3d(leaf), cams[v], W, H, spp, offs[v], integ) for v in range(n_views)])
+        ((ref - tgt) ** 2).sum().backward()
+        out.put((float((images - ref.detach()).abs().max()), float((g - leaf.grad).abs().max()), float(leaf.grad.abs().max()),
+                 parallel.work_partition(n_views, H + 4, world)[0]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('n_views', [1, 3, 2])
+def test_tile_split_equals_single_process(n_views):
+    """world 2: one view -> two row windows of the same view; three views -> 6 half-views; two views -> whole views."""
+    ctx = mp.get_context('spawn')
+    out = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000) + 7 * n_views
+    procs = [ctx.Process(target=_tile_worker, args=(r, 2, port, out, n_views)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=600)
+        assert p.exitcode == 0
+    err_img, err_g, mag, units = out.get(timeout=10)
+    assert mag > 0 and err_img < 1e-12 and err_g <= 1e-10 * max(mag, 1.0), (err_img, err_g, mag)
+    if n_views == 1:
+        assert units == [(0, 0, 6)]                       # rank 0 renders rows [0, 6) of the 12-row film block of view 0
+    if n_views == 2:
+        assert units == [(0, 0, 12)]
+
+
+def test_work_partition():
+    sys.path.insert(0, os.path.join(ROOT, 'differentiable-sdf-rendering_amd', 'python'))
+    from dsdf import parallel
+    for n in (1, 3, 12, 48):
+        for world in (1, 2, 4, 5, 8):
+            P = parallel.work_partition(n, 516, world)
+            assert len(P) == world and len({len(u) for u in P}) == 1            # perfectly balanced unit counts
+            cover = {}
+            for u in P:
+                for v, r0, r1 in u:
+                    cover.setdefault(v, []).append((r0, r1))
+            for v in range(n):                                                   # every view: windows tile [0, 516) exactly once
+                w = sorted(cover[v])
+                assert w[0][0] == 0 and w[-1][1] == 516 and all(a[1] == b[0] for a, b in zip(w, w[1:]))
+    assert [len(u) for u in parallel.work_partition(12, 516, 8)] == [3] * 8     # 24 half-views instead of 2/1 whole views
+
+
 def test_view_shard_partition():
     sys.path.insert(0, os.path.join(ROOT, 'differentiable-sdf-rendering_amd', 'python'))
     from dsdf import parallel

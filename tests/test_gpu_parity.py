@@ -175,6 +175,38 @@ def test_odd_film_tail_waves_do_not_splat(dsdf):
         assert np.abs(img[-2:, -2:] - ref[-2:, -2:]).max() < 1e-5
 
 
+@pytest.mark.parametrize('spp', [64, 4])
+def test_tile_split_equals_whole_view_gpu(dsdf, spp):
+    """Multi-GPU pixel-tile split (dsdf_render_film / dsdf_develop / dsdf_grad_sweep / dsdf_grad_backward): two row windows of
+    the film block, rendered one after the other like two ranks would, add up to the un-split render -- image and dL/dsdf --
+    on the persistent-worker path (spp 64) and on the general path (spp 4)."""
+    case = make_case('blob48_rect')
+    W, H = case['W'], case['H']
+    grid = dev_grid(dsdf, case)
+    sens = dsdf.get_regular_cameras(12, resx=W, resy=H)[4:6]
+    seeds = [21, 22]
+    for integ in (O.SILHOUETTE, O.SIMPLE_SHADING):
+        whole = dsdf.render_forward(grid, sens, spp, seeds=seeds, integrator=integ)
+        gi = torch.randn(2, H, W, 3, device='cuda')
+        g_whole = dsdf.render_backward(grid, sens, spp, gi, seeds=seeds, integrator=integ)
+        wins = [(0, 9), (9, H + 4)]
+        film = dsdf.new_film(2, W, H, integ, 'cuda')
+        for rows in wins:
+            dsdf.render_film(grid, sens, spp, film, rows, seeds=seeds, integrator=integ)
+        img = dsdf.develop(film, W, H, integ)
+        assert rel_l2(img.cpu(), whole.cpu()) < 1e-6
+        film_g = dsdf.new_film(2, W, H, integ, 'cuda')
+        sweeps = [dsdf.GradSweep(grid, sens, spp, rows, seeds=seeds, integrator=integ) for rows in wins]
+        for sw in sweeps:
+            sw.sweep(film_g)
+        g = torch.zeros_like(g_whole)
+        for sw in sweeps:
+            sw.backward(film_g, gi, g)
+        assert rel_l2(g.cpu(), g_whole.cpu()) < 1e-5
+    with pytest.raises(dsdf.DsdfError):
+        dsdf.render_film(grid, sens, spp, film, (5, 5), seeds=seeds)               # empty window
+
+
 def test_backward_accumulates(dsdf):
     case = make_case('blob32')
     grid, sen = dev_grid(dsdf, case), sensor(dsdf, case)
