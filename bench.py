@@ -155,11 +155,15 @@ def main():
     data = synth_grid(args.res, dev)
     grid = dsdf.SdfGrid(data)
     target = dsdf.SdfGrid(synth_grid(args.res, dev, seed=1))
+    tiled = False
     if args.scaling == 'strong':
         # the metric's 12 views, partitioned: every rank renders its shard of the SAME ring (round-robin, so that all
-        # ranks see equally expensive views); the job is the same at every N
+        # ranks see equally expensive views); the job is the same at every N.  When N does not divide the views (12 on 8
+        # GPUs) the views are cut into pixel-row windows (parallel.work_partition: 24 half-views, 3 per rank) and the film
+        # blocks are summed across ranks before develop / before the backward (parallel.render_step)
         ring = dsdf.get_regular_cameras(args.views, resx=args.img, resy=args.img)
-        mine = parallel.strided_view_shard(list(range(args.views)), rank, world)
+        tiled = args.views % world != 0
+        mine = list(range(args.views)) if tiled else parallel.strided_view_shard(list(range(args.views)), rank, world)
     else:
         # weak scaling: a ring of views*world sensors, `views` per rank
         ring = dsdf.get_regular_cameras(args.views * world, resx=args.img, resy=args.img)
@@ -183,6 +187,11 @@ def main():
         def step(it, timed):
             # one launch traces all views of this rank's shard (primal), one launch the gradient pass
             grad.zero_()
+            if tiled:
+                seeds = [(it * args.views + i) * 2 for i in range(args.views)]
+                ops = parallel.HipOps(grid, ring, spp_p, spp_g, seeds, [s + 1 for s in seeds], args.integrator)
+                parallel.render_step(ops, args.views, args.img, args.img, rank, world, lambda im: torch.sign(im - tgt) * scale, grad)
+                return
             if nv:
                 seeds = [(it * args.views + i) * 2 for i in mine]
                 e0, e1, e2 = ev(), ev(), ev()
@@ -236,7 +245,7 @@ def main():
 
     # per-launch statistics (untimed; same launch shape as the timed ones)
     out_cfg, roof = {}, None
-    if nv:
+    if nv and not tiled:
         st_p, st_g = dsdf.new_stats(dev), dsdf.new_stats(dev)
         dsdf.render_forward(grid, sensors, args.spp_primal, seeds=list(range(nv)), integrator=args.integrator, stats=st_p, **shade)
         dsdf.render_backward(grid, sensors, args.spp_grad, torch.ones(nv, args.img, args.img, 3, device=dev) * scale,
@@ -282,6 +291,7 @@ def main():
                                         f"{args.integrator}, spp primal/grad {args.spp_primal}/{args.spp_grad} "
                                         f"(reference semantics, configs.py:16,19)",
                             "views_total": args.views if strong else args.views * world, "views_this_rank": nv,
+                            "partition": ("pixel-row windows of views: %d units per rank" % len(parallel.work_partition(args.views, args.img + 4, world)[0])) if tiled else "whole views",
                             "spp_primal": args.spp_primal, "spp_grad": args.spp_grad}, **out_cfg),
             "roofline": roof,
         }

@@ -102,6 +102,36 @@ def render_step(ops, n_views, W, H, rank, world, loss_grad, grad_grid, group=Non
     return images
 
 
+class HipOps:
+    """The film-level operators of render_step on the HIP path (dsdf.render_film / develop / GradSweep)."""
+
+    def __init__(self, grid, sensors, spp, spp_grad, seeds, seeds_grad, integrator=0, **kw):
+        from . import renderer
+        self.r = renderer
+        self.grid, self.sensors, self.spp, self.spp_grad = grid, list(sensors), int(spp), int(spp_grad)
+        self.seeds, self.seeds_grad, self.integrator, self.kw = list(seeds), list(seeds_grad), integrator, kw
+        self.W, self.H = self.sensors[0].film_size()
+
+    def empty_film(self, n):
+        return self.r.new_film(n, self.W, self.H, self.integrator, self.grid.device)
+
+    def film(self, views, rows):
+        f = self.empty_film(len(views))
+        return self.r.render_film(self.grid, [self.sensors[v] for v in views], self.spp, f, rows,
+                                  seeds=[self.seeds[v] for v in views], integrator=self.integrator, **self.kw)
+
+    def develop(self, film):
+        return self.r.develop(film, self.W, self.H, self.integrator)
+
+    def sweep(self, views, rows):
+        h = self.r.GradSweep(self.grid, [self.sensors[v] for v in views], self.spp_grad, rows,
+                             seeds=[self.seeds_grad[v] for v in views], integrator=self.integrator, **self.kw)
+        return h.sweep(self.empty_film(len(views))), h
+
+    def backward(self, handle, film_total, grad_image, grad_grid):
+        handle.backward(film_total, grad_image, grad_grid)
+
+
 def all_reduce_gradients(tensors, group=None):
     """Sums the given gradient tensors over all ranks in place with ONE collective."""
     import torch.distributed as dist
