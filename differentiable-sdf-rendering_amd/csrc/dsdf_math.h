@@ -71,6 +71,8 @@ struct GridView {
     const float *p;
     int rx, ry, rz;
     int sx, sxy;
+    float frx, fry, frz;   // the resolution as floats (kernel arguments: they stay in SGPRs; converting in the kernel made
+                           // them VGPR values that were spilled and re-loaded inside the march loop)
     float tx, ty, tz;   // sdf.p translation
     const float *coarse;   // (cz,cy,cx) dilated block minima of ONE level (device only; nullptr = absent)
     int cx, cy, cz, cshift;   // blocks per axis, log2(voxels per block)
@@ -80,6 +82,7 @@ DSDF_HD GridView make_view(const float *padded, int rx, int ry, int rz, const ds
     GridView g;
     g.p = padded; g.rx = rx; g.ry = ry; g.rz = rz;
     g.sx = rx + 2 * DSDF_APRON; g.sxy = g.sx * (ry + 2 * DSDF_APRON);
+    g.frx = (float)rx; g.fry = (float)ry; g.frz = (float)rz;
     g.tx = prm.sdf_p[0]; g.ty = prm.sdf_p[1]; g.tz = prm.sdf_p[2];
     g.cx = g.cy = g.cz = 0; g.cshift = 0;
     g.coarse = nullptr;
@@ -117,9 +120,9 @@ DSDF_HD int iclamp(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : 
 
 DSDF_HD CubicSetup cubic_setup(const GridView &G, V3 x) {
     // pf = (x - p) * res - 0.5 ; shapes.py:412 + Dr.Jit texel-centre convention
-    float pfx = fmaf(x.x - G.tx, (float)G.rx, -0.5f);
-    float pfy = fmaf(x.y - G.ty, (float)G.ry, -0.5f);
-    float pfz = fmaf(x.z - G.tz, (float)G.rz, -0.5f);
+    float pfx = fmaf(x.x - G.tx, G.frx, -0.5f);
+    float pfy = fmaf(x.y - G.ty, G.fry, -0.5f);
+    float pfz = fmaf(x.z - G.tz, G.frz, -0.5f);
     float fx = floorf(pfx), fy = floorf(pfy), fz = floorf(pfz);
     CubicSetup s;
     s.ax = pfx - fx; s.ay = pfy - fy; s.az = pfz - fz;
@@ -241,7 +244,7 @@ DSDF_HD void eval_cubic_rows(const GridView &G, const CubicCell &c, const Rows &
         }
     }
     v = av;
-    float fx = (float)G.rx, fy = (float)G.ry, fz = (float)G.rz;
+    float fx = G.frx, fy = G.fry, fz = G.frz;
     g = mk(agx * fx, agy * fy, agz * fz);
     if (ORDER >= 2) {
         H[0] = axx * fx * fx; H[1] = ayy * fy * fy; H[2] = azz * fz * fz;
@@ -324,7 +327,7 @@ DSDF_HD void scatter_cubic(const GridView &G, float *grad, V3 x, float cv, V3 cg
     float wx[4], wy[4], wz[4], dwx[4], dwy[4], dwz[4];
     bspline_w(s.ax, wx); bspline_w(s.ay, wy); bspline_w(s.az, wz);
     bspline_dw(s.ax, dwx); bspline_dw(s.ay, dwy); bspline_dw(s.az, dwz);
-    float gx = cg.x * (float)G.rx, gy = cg.y * (float)G.ry, gz = cg.z * (float)G.rz;
+    float gx = cg.x * G.frx, gy = cg.y * G.fry, gz = cg.z * G.frz;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         int zi = iclamp(s.iz + k, 0, G.rz - 1);

@@ -34,7 +34,7 @@ __global__ void k_redist_init(const float *__restrict__ phi, int rx, int ry, int
                               unsigned char *__restrict__ frozen, unsigned int *flags) {
     size_t n = (size_t)rx * ry * rz;
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i == 0) { flags[0] = 0; flags[1] = 0; flags[2] = 0; }
+    if (i == 0) { flags[0] = 0; flags[1] = 0; flags[2] = 0; flags[4] = 0; flags[5] = 0; }     // [4]: last launch that changed a value, [5]: status
     if (i >= n) return;
     int x = (int)(i % rx); size_t r = i / rx; int y = (int)(r % ry), z = (int)(r / ry);
     float p = phi[i];
@@ -118,11 +118,15 @@ __global__ __launch_bounds__(512) void k_redist_iter(float *__restrict__ u, cons
     }
     if (cur < start) { u[gi] = cur; tile_changed = 1; }
     __syncthreads();
-    if (threadIdx.x == 0 && tile_changed) { cur_map[tid] = 1; flags[iter % 3] = 1; }
+    if (threadIdx.x == 0 && tile_changed) { cur_map[tid] = 1; flags[iter % 3] = 1; atomicMax(flags + 4, (unsigned)iter + 1u); }
 }
 
-__global__ void k_redist_finish(const float *__restrict__ phi, const float *__restrict__ u, size_t n, float *__restrict__ out) {
+// status (flags[5]): 0 = the relaxation reached its fixed point (the last launch changed nothing), 1 = the launch budget ran out
+// while values were still moving -- the result is then an upper bound of the distance, not the fixed point.
+__global__ void k_redist_finish(const float *__restrict__ phi, const float *__restrict__ u, size_t n, float *__restrict__ out,
+                                unsigned int *flags, unsigned max_iter) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) flags[5] = flags[4] >= max_iter ? 1u : 0u;
     if (i < n) out[i] = phi[i] < 0.f ? -u[i] : u[i];
 }
 
@@ -154,14 +158,24 @@ int dsdf_redistance(const float *phi, int rx, int ry, int rz, float *out, void *
     hipLaunchKernelGGL(k_redist_init, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, phi, rx, ry, rz, u, frozen, flags);
     if ((rc = check_launch("k_redist_init"))) return rc;
     // information crosses at least one tile per launch (Manhattan tile distance <= sum of the tile
-    // counts); 25 % margin, converged launches return at once
+    // counts); 25 % margin, converged launches return at once.  Whether the budget sufficed is recorded on the device
+    // (dsdf_redistance_status) -- the library never synchronises.
     int max_iter = (int)(tiles.x + tiles.y + tiles.z) + (int)(tiles.x + tiles.y + tiles.z) / 4 + 8;
     for (int it = 0; it < max_iter; ++it) {
         hipLaunchKernelGGL(k_redist_iter, tiles, dim3(512), 0, st, u, frozen, rx, ry, rz, flags, tmap, it);
         if ((rc = check_launch("k_redist_iter"))) return rc;
     }
-    hipLaunchKernelGGL(k_redist_finish, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, phi, u, n, out);
+    hipLaunchKernelGGL(k_redist_finish, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, phi, u, n, out, flags, (unsigned)max_iter);
     return check_launch("k_redist_finish");
+}
+
+int dsdf_redistance_status(const void *workspace, int rx, int ry, int rz, int32_t *status, void *stream) {
+    if (!workspace || !status || rx < 1 || ry < 1 || rz < 1) return fail(DSDF_ERR_INVALID_ARG, "dsdf_redistance_status: bad argument");
+    const size_t n = (size_t)rx * ry * rz;
+    const char *flags = (const char *)workspace + align_up(n * sizeof(float), 256) + align_up(n, 256);
+    if (hipMemcpyAsync(status, flags + 5 * sizeof(unsigned int), sizeof(int32_t), hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess)
+        return fail(DSDF_ERR_LAUNCH, "dsdf_redistance_status: copy failed");
+    return DSDF_OK;
 }
 
 }  // extern "C"

@@ -53,9 +53,9 @@ __global__ void k_pixel_skip(GridView G, dsdf_params P, ViewBatch VB, unsigned c
         float m = INFINITY;
         for (float t = t0; t < t1 + step; t += step) {
             V3 x = fma3(fminf(t, t1), d, r.o);
-            int bx = iclamp((int)floorf((x.x - G.tx) * (float)G.rx) >> G.cshift, 0, G.cx - 1);
-            int by = iclamp((int)floorf((x.y - G.ty) * (float)G.ry) >> G.cshift, 0, G.cy - 1);
-            int bz = iclamp((int)floorf((x.z - G.tz) * (float)G.rz) >> G.cshift, 0, G.cz - 1);
+            int bx = iclamp((int)floorf((x.x - G.tx) * G.frx) >> G.cshift, 0, G.cx - 1);
+            int by = iclamp((int)floorf((x.y - G.ty) * G.fry) >> G.cshift, 0, G.cy - 1);
+            int bz = iclamp((int)floorf((x.z - G.tz) * G.frz) >> G.cshift, 0, G.cz - 1);
             m = fminf(m, G.coarse[(bz * G.cy + by) * G.cx + bx]);
         }
         float thr_p = 2.f * P.trace_eps * fmaxf(t1, 1.f) + 1e-5f;

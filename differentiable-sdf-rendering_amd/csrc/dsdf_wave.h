@@ -84,7 +84,7 @@ __device__ __forceinline__ void wave_scatter(const GridView &G, float *__restric
         float wx[4], wy[4], wz[4], dwx[4], dwy[4], dwz[4];
         bspline_w(s.ax, wx); bspline_w(s.ay, wy); bspline_w(s.az, wz);
         bspline_dw(s.ax, dwx); bspline_dw(s.ay, dwy); bspline_dw(s.az, dwz);
-        float gx = rq.cg.x * (float)G.rx, gy = rq.cg.y * (float)G.ry, gz = rq.cg.z * (float)G.rz;
+        float gx = rq.cg.x * G.frx, gy = rq.cg.y * G.fry, gz = rq.cg.z * G.frz;
         int xo[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) xo[i] = iclamp(s.ix + i, 0, G.rx - 1) - minx;
@@ -138,7 +138,7 @@ __device__ __forceinline__ void wave_scatter_t(const GridView &G, float *__restr
         float wx[4], wy[4], wz[4], dwx[4], dwy[4], dwz[4];
         bspline_w(s.ax, wx); bspline_w(s.ay, wy); bspline_w(s.az, wz);
         bspline_dw(s.ax, dwx); bspline_dw(s.ay, dwy); bspline_dw(s.az, dwz);
-        const float gx = rq.cg.x * (float)G.rx, gy = rq.cg.y * (float)G.ry, gz = rq.cg.z * (float)G.rz;
+        const float gx = rq.cg.x * G.frx, gy = rq.cg.y * G.fry, gz = rq.cg.z * G.frz;
         float4 *row = reinterpret_cast<float4 *>(T + lid * DSDF_SCAT_STRIDE);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {

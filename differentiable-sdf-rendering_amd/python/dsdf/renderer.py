@@ -440,8 +440,9 @@ class GradSweep:
         return grad_grid
 
 
-def redistance(phi):
-    """`redistancing.redistance`: signed distance field with the zero level set of phi (Z,Y,X[,1])."""
+def redistance(phi, return_status=False):
+    """`redistancing.redistance`: signed distance field with the zero level set of phi (Z,Y,X[,1]).  return_status: also a
+    device int32 tensor, 0 = converged, 1 = the launch budget ran out first (read it when you synchronise anyway)."""
     lib = _lib.load()
     shape = phi.shape
     p3 = phi[..., 0] if phi.dim() == 4 else phi
@@ -452,6 +453,10 @@ def redistance(phi):
     ws = torch.empty(int(wsb), dtype=torch.uint8, device=p3.device)
     with torch.cuda.device(p3.device):
         _lib.check(lib.dsdf_redistance(_ptr(p3), rx, ry, rz, _ptr(out), _ptr(ws), wsb, _stream()))
+        if return_status:
+            status = torch.zeros(1, dtype=torch.int32, device=p3.device)
+            _lib.check(lib.dsdf_redistance_status(_ptr(ws), rx, ry, rz, _ptr(status), _stream()))
+            return out.reshape(shape), status
     return out.reshape(shape)
 
 

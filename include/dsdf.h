@@ -254,6 +254,11 @@ size_t dsdf_redistance_workspace_size(int rx, int ry, int rz);
 int dsdf_redistance(const float *phi, int rx, int ry, int rz, float *out,
                     void *workspace, size_t workspace_bytes, void *stream);
 
+/* Convergence status of the dsdf_redistance call that last used `workspace`, copied (device to device, on `stream`) into
+ * *status: 0 = the relaxation reached its fixed point, 1 = the launch budget ran out while values were still moving.
+ * The library never synchronises: read it whenever the caller synchronises anyway. */
+int dsdf_redistance_status(const void *workspace, int rx, int ry, int rz, int32_t *status, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -40,8 +40,9 @@ def test_redistance_matches_c_oracle(dsdf, shape):
     out = dsdf.redistance(torch.from_numpy(phi).cuda()).cpu().numpy()
     assert ((out < 0) == (phi < 0)).all()
     assert np.abs(out - ref).max() < 1e-5          # same discrete fixed point (Godunov upwind, frozen band)
-    out4 = dsdf.redistance(torch.from_numpy(phi).cuda()[..., None])
+    out4, status = dsdf.redistance(torch.from_numpy(phi).cuda()[..., None], return_status=True)
     assert out4.shape == (*shape, 1)
+    assert int(status.item()) == 0                  # converged within the launch budget (device-side flag, no sync in the library)
 
 
 def test_redistance_large_and_idempotent(dsdf):
