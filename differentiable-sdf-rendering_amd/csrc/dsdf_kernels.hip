@@ -249,8 +249,13 @@ __device__ __forceinline__ void queue_unit(const Queue &q, uint32_t unit, uint32
 // Work list of a launch: the film-block pixels of all its views whose samples must be generated (k_skip_dilate bit 2 / 3
 // clear), appended block-wise (one atomic per 256 pixels), entry = view * Wb * Hb + pixel.  items[0] = count, items[1] = ticket.
 #define DSDF_ITEM_HDR 4
-#ifndef DSDF_ITEM_BATCH
-#define DSDF_ITEM_BATCH 16     /* items (64-sample chunks) per ticket of the persistent workers */
+// items (64-sample chunks) per ticket of the persistent workers: a value-only chunk takes ~10 us, a differentiable one ~35 us;
+// the batch bounds the idle time at the end of the launch (measured: 16 for both cost the gradient sweep 16.1 -> 18.6 ms)
+#ifndef DSDF_ITEM_BATCH_PRIMAL
+#define DSDF_ITEM_BATCH_PRIMAL 16
+#endif
+#ifndef DSDF_ITEM_BATCH_DIFF
+#define DSDF_ITEM_BATCH_DIFF 4
 #endif
 __global__ void k_build_items(ViewBatch VB, int nv, const unsigned char *__restrict__ skip, unsigned far_bit, int row0, int row1,
                               uint32_t *__restrict__ items) {
@@ -286,10 +291,11 @@ void k_render_items(GridView G, dsdf_params P, ViewBatch VB, float *__restrict__
     const uint32_t npix = (uint32_t)(VB.v[0].Wb * VB.v[0].Hb);
     const uint32_t chunks = (uint32_t)VB.v[0].spp >> 6;
     // work item = one 64-sample chunk of one listed pixel (wave-uniform values are pinned to SGPRs).  Items are handed out in
-    // BATCHES of DSDF_ITEM_BATCH consecutive ones: batch b < gridDim.x belongs to worker b, later ones are claimed with an
+    // BATCHES of DSDF_ITEM_BATCH_* consecutive ones: batch b < gridDim.x belongs to worker b, later ones are claimed with an
     // atomic ticket (items[1]), taken one batch ahead so that its round trip is off the critical path.  (One ticket per item
     // serialised the whole chip on that address: same-address device atomics retire at ~8 ns, 3.8 M items -> 32 of the 50 ms.)
     const uint32_t n_items = (uint32_t)__builtin_amdgcn_readfirstlane((int)items[0]) * chunks;
+    constexpr uint32_t DSDF_ITEM_BATCH = DIFF ? DSDF_ITEM_BATCH_DIFF : DSDF_ITEM_BATCH_PRIMAL;
     const uint32_t n_batches = (n_items + DSDF_ITEM_BATCH - 1) / DSDF_ITEM_BATCH;
     WaveStats wst = {0, 0, 0, 0, 0, 0, 0};
     uint32_t batch = blockIdx.x, next = 0;
