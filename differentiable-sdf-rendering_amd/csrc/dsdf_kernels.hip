@@ -247,37 +247,61 @@ __device__ __forceinline__ void queue_unit(const Queue &q, uint32_t unit, uint32
 }
 
 // Work list of a launch: the film-block pixels of all its views whose samples must be generated (k_skip_dilate bit 2 / 3
-// clear), appended block-wise (one atomic per 256 pixels), entry = view * Wb * Hb + pixel.  items[0] = count, items[1] = ticket.
+// clear, row inside the call's window), entry = view * Wb * Hb + pixel.  items[0] = count, items[1] = ticket.
+// ORDER MATTERS: the workers that run at the same time must be in the same part of the same view, or the 8 L2s (4 MiB each)
+// thrash on the 64 MiB grid -- a first version appended 256-pixel runs in atomic (i.e. arbitrary) order and the primal pass
+// went from 2 GB to 121 GB of L2 fills (33 -> 50 ms).  A block therefore compacts a REGION of DSDF_ITEM_REGION consecutive
+// pixels (32 film rows at 512^2) in order -- count, ONE atomic reservation, write -- so the list is a sequence of long
+// in-order runs.
 #define DSDF_ITEM_HDR 4
+#define DSDF_ITEM_REGION 16384
 // items (64-sample chunks) per ticket of the persistent workers: a value-only chunk takes ~10 us, a differentiable one ~35 us;
 // the batch bounds the idle time at the end of the launch (measured: 16 for both cost the gradient sweep 16.1 -> 18.6 ms)
 #ifndef DSDF_ITEM_BATCH_PRIMAL
-#define DSDF_ITEM_BATCH_PRIMAL 16
+#define DSDF_ITEM_BATCH_PRIMAL 8
 #endif
 #ifndef DSDF_ITEM_BATCH_DIFF
 #define DSDF_ITEM_BATCH_DIFF 4
 #endif
-__global__ void k_build_items(ViewBatch VB, int nv, const unsigned char *__restrict__ skip, unsigned far_bit, int row0, int row1,
-                              uint32_t *__restrict__ items) {
+__global__ __launch_bounds__(256) void k_build_items(ViewBatch VB, int nv, const unsigned char *__restrict__ skip, unsigned far_bit,
+                                                     int row0, int row1, uint32_t *__restrict__ items) {
     const ViewArgs &A = VB.v[0];
-    const uint32_t npix = (uint32_t)(A.Wb * A.Hb);
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    const int py = (int)((i % npix) / (uint32_t)A.Wb);       // film-block row: only the rows [row0, row1) of this call's window
-    const bool in = i < npix * (uint32_t)nv && py >= row0 && py < row1;
-    const bool live = in && !(skip && (skip[i] & far_bit));
-    const uint64_t m = __ballot(live);
-    __shared__ uint32_t wbase[4];
-    __shared__ uint32_t bbase;
+    const uint32_t npix = (uint32_t)(A.Wb * A.Hb), total = npix * (uint32_t)nv;
+    const uint32_t begin = blockIdx.x * DSDF_ITEM_REGION;
     const int w = threadIdx.x >> 6, lid = lane_id();
-    if (lid == 0) wbase[w] = (uint32_t)__popcll(m);
+    __shared__ uint32_t wcount[4];
+    __shared__ uint32_t base;
+    auto live = [&](uint32_t i) {
+        if (i >= total) return false;
+        const int py = (int)((i % npix) / (uint32_t)A.Wb);   // film-block row: only the rows [row0, row1) of this call's window
+        return py >= row0 && py < row1 && !(skip && (skip[i] & far_bit));
+    };
+    // pass 1: live pixels of the region
+    uint32_t mine = 0;
+    for (uint32_t o = 0; o < DSDF_ITEM_REGION; o += 256) mine += live(begin + o + threadIdx.x) ? 1u : 0u;
+    const uint32_t wsum = (uint32_t)wave_sum_i32((int)mine);
+    if (lid == 0) wcount[w] = wsum;
     __syncthreads();
     if (threadIdx.x == 0) {
-        uint32_t t = 0;
-        for (int k = 0; k < 4; ++k) { uint32_t c = wbase[k]; wbase[k] = t; t += c; }
-        bbase = t ? atomicAdd(items, t) : 0u;
+        const uint32_t t = wcount[0] + wcount[1] + wcount[2] + wcount[3];
+        base = t ? atomicAdd(items, t) : 0u;
     }
     __syncthreads();
-    if (live) items[DSDF_ITEM_HDR + bbase + wbase[w] + mask_prefix(m)] = i;
+    // pass 2: write them in pixel order
+    uint32_t run = base;
+    for (uint32_t o = 0; o < DSDF_ITEM_REGION; o += 256) {
+        const uint32_t i = begin + o + threadIdx.x;
+        const bool l = live(i);
+        const uint64_t m = __ballot(l);
+        __syncthreads();                                     // (wcount is reused)
+        if (lid == 0) wcount[w] = (uint32_t)__popcll(m);
+        __syncthreads();
+        uint32_t before = 0, all = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { const uint32_t c = wcount[k]; before += k < w ? c : 0u; all += c; }
+        if (l) items[DSDF_ITEM_HDR + run + before + mask_prefix(m)] = i;
+        run += all;
+    }
 }
 
 template <bool DIFF, bool DIRECT, bool STATS>
@@ -835,7 +859,7 @@ static int run_pass(const PassCtx &c, const Workspace &ws, const dsdf_camera *ca
         const unsigned far_bit = (c.direct && !S.hide_emitters) ? 0u : (DIFF ? 8u : 4u);
         if (hipMemsetAsync(ws.items, 0, DSDF_ITEM_HDR * sizeof(uint32_t), st) != hipSuccess)
             return fail(DSDF_ERR_LAUNCH, "hipMemsetAsync(work list) failed");
-        hipLaunchKernelGGL(k_build_items, dim3((unsigned)((nv * npix + 255) / 256)), dim3(256), 0, st, VB, nv, skip, far_bit, c.row0, c.row1, ws.items);
+        hipLaunchKernelGGL(k_build_items, dim3((unsigned)((nv * npix + DSDF_ITEM_REGION - 1) / DSDF_ITEM_REGION)), dim3(256), 0, st, VB, nv, skip, far_bit, c.row0, c.row1, ws.items);
         if ((rc = check_launch("k_build_items"))) return rc;
         TailQueue tq;
         memset(&tq, 0, sizeof(tq));
