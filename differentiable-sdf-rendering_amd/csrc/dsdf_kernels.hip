@@ -247,21 +247,25 @@ __device__ __forceinline__ void queue_unit(const Queue &q, uint32_t unit, uint32
 }
 
 // Work list of a launch: the film-block pixels of all its views whose samples must be generated (k_skip_dilate bit 2 / 3
-// clear, row inside the call's window), entry = view * Wb * Hb + pixel.  items[0] = count, items[1] = ticket.
+// clear, row inside the call's window), entry = view * Wb * Hb + pixel.  items[0] = count, then the ticket counters.
 // ORDER MATTERS: the workers that run at the same time must be in the same part of the same view, or the 8 L2s (4 MiB each)
 // thrash on the 64 MiB grid -- a first version appended 256-pixel runs in atomic (i.e. arbitrary) order and the primal pass
 // went from 2 GB to 121 GB of L2 fills (33 -> 50 ms).  A block therefore compacts a REGION of DSDF_ITEM_REGION consecutive
 // pixels (32 film rows at 512^2) in order -- count, ONE atomic reservation, write -- so the list is a sequence of long
 // in-order runs.
-#define DSDF_ITEM_HDR 4
 #define DSDF_ITEM_REGION 16384
-// items (64-sample chunks) per ticket of the persistent workers: a value-only chunk takes ~10 us, a differentiable one ~35 us;
-// the batch bounds the idle time at the end of the launch (measured: 16 for both cost the gradient sweep 16.1 -> 18.6 ms)
+// Tickets.  The workers that run at the same time should also be NEAR each other in the list (the active window is
+// workers x batch items: at 8192 workers a batch of 8 chunks is 32 film rows, whose rays no longer share an L2), so batches
+// are small -- and the ticket traffic is spread over DSDF_TICKETS counters on separate cache lines instead (counter c hands
+// out the batches c, c + 64, c + 128, ...; one counter for everybody serialised the chip: same-address atomics retire at
+// ~8 ns).  Header of the list: [0] = number of listed pixels, then the counters (16 words apart).
+#define DSDF_TICKETS 64
+#define DSDF_ITEM_HDR (16 + 16 * DSDF_TICKETS)
 #ifndef DSDF_ITEM_BATCH_PRIMAL
-#define DSDF_ITEM_BATCH_PRIMAL 8
+#define DSDF_ITEM_BATCH_PRIMAL 2
 #endif
 #ifndef DSDF_ITEM_BATCH_DIFF
-#define DSDF_ITEM_BATCH_DIFF 4
+#define DSDF_ITEM_BATCH_DIFF 1
 #endif
 __global__ __launch_bounds__(256) void k_build_items(ViewBatch VB, int nv, const unsigned char *__restrict__ skip, unsigned far_bit,
                                                      int row0, int row1, uint32_t *__restrict__ items) {
@@ -315,15 +319,17 @@ void k_render_items(GridView G, dsdf_params P, ViewBatch VB, float *__restrict__
     const uint32_t npix = (uint32_t)(VB.v[0].Wb * VB.v[0].Hb);
     const uint32_t chunks = (uint32_t)VB.v[0].spp >> 6;
     // work item = one 64-sample chunk of one listed pixel (wave-uniform values are pinned to SGPRs).  Items are handed out in
-    // BATCHES of DSDF_ITEM_BATCH_* consecutive ones: batch b < gridDim.x belongs to worker b, later ones are claimed with an
-    // atomic ticket (items[1]), taken one batch ahead so that its round trip is off the critical path.  (One ticket per item
-    // serialised the whole chip on that address: same-address device atomics retire at ~8 ns, 3.8 M items -> 32 of the 50 ms.)
+    // batches of DSDF_ITEM_BATCH_* consecutive ones: batch b < gridDim.x belongs to worker b, later ones are claimed from the
+    // worker's ticket counter, one batch ahead so that the round trip is off the critical path.
     const uint32_t n_items = (uint32_t)__builtin_amdgcn_readfirstlane((int)items[0]) * chunks;
     constexpr uint32_t DSDF_ITEM_BATCH = DIFF ? DSDF_ITEM_BATCH_DIFF : DSDF_ITEM_BATCH_PRIMAL;
     const uint32_t n_batches = (n_items + DSDF_ITEM_BATCH - 1) / DSDF_ITEM_BATCH;
     WaveStats wst = {0, 0, 0, 0, 0, 0, 0};
+    const uint32_t tc = blockIdx.x % DSDF_TICKETS;                       // this worker's counter
+    uint32_t *ticket = items + 16 + 16 * tc;
+    const uint32_t first = gridDim.x / DSDF_TICKETS;                      // tickets of a counter that are pre-assigned (gridDim.x % 64 == 0)
     uint32_t batch = blockIdx.x, next = 0;
-    if (batch < n_batches && lid == 0) next = gridDim.x + atomicAdd(items + 1, 1u);
+    if (batch < n_batches && lid == 0) next = tc + DSDF_TICKETS * (first + atomicAdd(ticket, 1u));
     while (batch < n_batches) {
       const uint32_t item_end = min((batch + 1) * DSDF_ITEM_BATCH, n_items);
       for (uint32_t item = batch * DSDF_ITEM_BATCH; item < item_end; ++item) {
@@ -376,7 +382,7 @@ void k_render_items(GridView G, dsdf_params P, ViewBatch VB, float *__restrict__
         if (STATS) add_stats(wst, tr, true, need);
       }
       batch = (uint32_t)__builtin_amdgcn_readfirstlane((int)next);
-      if (batch < n_batches && lid == 0) next = gridDim.x + atomicAdd(items + 1, 1u);
+      if (batch < n_batches && lid == 0) next = tc + DSDF_TICKETS * (first + atomicAdd(ticket, 1u));
     }
     if (STATS) flush_stats(stats, wst, blockIdx.x, lid);
 }
@@ -820,7 +826,7 @@ static unsigned worker_blocks() {
     if (!n) {
         int dev = 0, cus = 0;
         if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
-            n = (unsigned)cus * 32u;
+            n = ((unsigned)cus * 32u + DSDF_TICKETS - 1) / DSDF_TICKETS * DSDF_TICKETS;      // a multiple of DSDF_TICKETS
         else n = 256u * 32u;
     }
     return n;
