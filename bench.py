@@ -42,7 +42,7 @@ import torch
 # (hipcc -S, instruction histogram of the loop bodies; cross-checked against SQ_INSTS_VALU: profiles/r02_sq.json)
 VALU_MODEL = {
     'calibration': 'profiles/r02_sq.json',
-    'primal': {'per_wave_step': 215.0, 'per_traced_wave': 400.0, 'per_wave': 250.0},
+    'primal': {'per_wave_step': 209.0, 'per_traced_wave': 600.0, 'per_wave': 430.0},
 }
 VALU_PEAK = 1024 * 2.4e9 / 2.0        # wave64 VALU instructions / s: 256 CUs x 4 SIMD-32, 2 clk per instruction
 
@@ -265,7 +265,7 @@ def main():
         # SURVEY 8(d) HBM-equivalent figure, kept as a secondary field: 64 fp32 taps per cubic evaluation, film RMW, one grid read
         evals = sp['steps'] + sp['refine_steps']
         alg_bytes = 256.0 * evals + 16 * 2 * 8.0 * sp['lanes'] + 4.0 * args.res ** 3
-        roof = {"bound": "valu", "kernel": "k_render_pass<primal>", "achieved": achieved / 1e9, "peak": VALU_PEAK / 1e9,
+        roof = {"bound": "valu", "kernel": "k_render_items<primal>", "achieved": achieved / 1e9, "peak": VALU_PEAK / 1e9,
                 "unit": "G wave-instr/s", "frac": achieved / VALU_PEAK, "traffic": None,
                 "valu_insts_per_launch": valu, "wave_steps_per_launch": sp['wave_steps'], "avg_launch_ms": prim_avg,
                 "lane_utilisation": evals / max(64.0 * sp['wave_steps'], 1.0), "calibration": VALU_MODEL['calibration'],

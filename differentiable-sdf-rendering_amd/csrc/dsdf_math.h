@@ -116,7 +116,13 @@ struct CubicSetup {
     float ax, ay, az;    // fractional offsets
 };
 
-DSDF_HD int iclamp(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+DSDF_HD int iclamp(int v, int lo, int hi) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return min(max(v, lo), hi);          // v_max_i32 + v_min_i32 (v_med3_i32) instead of two compare/select pairs
+#else
+    return v < lo ? lo : (v > hi ? hi : v);
+#endif
+}
 
 DSDF_HD CubicSetup cubic_setup(const GridView &G, V3 x) {
     // pf = (x - p) * res - 0.5 ; shapes.py:412 + Dr.Jit texel-centre convention
@@ -149,7 +155,12 @@ DSDF_HD CubicCell cubic_cell(const GridView &G, V3 x) {
     int by = iclamp(s.iy, -DSDF_APRON, G.ry - 1) + DSDF_APRON;
     int bz = iclamp(s.iz, -DSDF_APRON, G.rz - 1) + DSDF_APRON;
     CubicCell c;
+#if defined(__HIP_DEVICE_COMPILE__)
+    // 24-bit multiplies (full rate; v_mul_lo_u32 is quarter rate): bz, by < 2^11 and sxy < 2^24 for every grid up to 4090^2 per slice
+    c.base = 4u * (__umul24((uint32_t)bz, (uint32_t)G.sxy) + __umul24((uint32_t)by, (uint32_t)G.sx) + (uint32_t)bx);
+#else
     c.base = 4u * ((uint32_t)bz * (uint32_t)G.sxy + (uint32_t)by * (uint32_t)G.sx + (uint32_t)bx);
+#endif
     c.ax = s.ax; c.ay = s.ay; c.az = s.az;
     return c;
 }
