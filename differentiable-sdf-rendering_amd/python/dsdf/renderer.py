@@ -12,7 +12,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import (DSDF_DIRECT, DSDF_NO_SKIP, DSDF_REPARAM, DSDF_SILHOUETTE, DSDF_SIMPLE_SHADING, DsdfCamera,
+from ._lib import (DSDF_DIRECT, DSDF_NO_SKIP, DSDF_NO_STREAM, DSDF_REPARAM, DSDF_SILHOUETTE, DSDF_SIMPLE_SHADING, DsdfCamera,
                    DsdfShading)
 
 INTEGRATORS = {'sdf_silhouette_reparam': DSDF_SILHOUETTE, 'sdf_simple_shading_reparam': DSDF_SIMPLE_SHADING,
@@ -262,7 +262,7 @@ def _sampler_args(n_views, seeds, offsets, n_lanes):
 
 
 def render_forward(grid, sensors, spp, seeds=None, offsets=None, integrator=DSDF_SILHOUETTE, reparam=True, stats=None,
-                   empty_space_skip=True, shading=None, emitter_samples=None):
+                   empty_space_skip=True, shading=None, emitter_samples=None, stream=True):
     """`ReparamIntegrator.render` for a batch of views -> (n_views, H, W, 3).  `shading` (dsdf.Shading) and the
     optional per-lane `emitter_samples` belong to sdf_direct_reparam."""
     lib = _lib.load()
@@ -279,7 +279,8 @@ def render_forward(grid, sensors, spp, seeds=None, offsets=None, integrator=DSDF
     with torch.cuda.device(dev):
         _lib.check(lib.dsdf_render_forward(_ptr(grid.padded), grid.rx, grid.ry, grid.rz, C.byref(grid.params), cams, nv,
                                            W, H, int(spp), _ptr(offsets), cseeds, INTEGRATORS[integrator],
-                                           (DSDF_REPARAM if reparam else 0) | (0 if empty_space_skip else DSDF_NO_SKIP),
+                                           (DSDF_REPARAM if reparam else 0) | (0 if empty_space_skip else DSDF_NO_SKIP) |
+                                           (0 if stream else DSDF_NO_STREAM),
                                            sh, _ptr(img), _ptr(ws), wsb, _ptr(stats), _stream()))
     return img
 

@@ -207,6 +207,24 @@ def test_tile_split_equals_whole_view_gpu(dsdf, spp):
         dsdf.render_film(grid, sens, spp, film, (5, 5), seeds=seeds)               # empty window
 
 
+@pytest.mark.parametrize('spp', [64, 100, 256])
+def test_streaming_primal_equals_chunked(dsdf, spp):
+    """The sample-streaming primal workers (default for spp >= 64, any spp) against the chunk-at-a-time workers / the
+    general per-lane pass: every sample executes the same march, so the films agree to atomic-order noise; statistics too."""
+    case = make_case('blob48_rect')
+    grid = dev_grid(dsdf, case)
+    sens = dsdf.get_regular_cameras(12, resx=case['W'], resy=case['H'])[2:5]
+    for integ in (O.SILHOUETTE, O.SIMPLE_SHADING):
+        sa, sb = dsdf.new_stats('cuda'), dsdf.new_stats('cuda')
+        a = dsdf.render_forward(grid, sens, spp, seeds=[1, 2, 3], integrator=integ, stats=sa)
+        b = dsdf.render_forward(grid, sens, spp, seeds=[1, 2, 3], integrator=integ, stats=sb, stream=False)
+        assert rel_l2(a.cpu(), b.cpu()) < 1e-6
+        da, db = dsdf.stats_dict(sa), dsdf.stats_dict(sb)
+        for k in ('lanes', 'hits', 'steps', 'bbox_lanes', 'refine_steps'):
+            assert da[k] == db[k], (k, da[k], db[k])
+        assert da['wave_steps'] < db['wave_steps']            # fuller waves: fewer lock-step iterations for the same rays
+
+
 def test_backward_accumulates(dsdf):
     case = make_case('blob32')
     grid, sen = dev_grid(dsdf, case), sensor(dsdf, case)
