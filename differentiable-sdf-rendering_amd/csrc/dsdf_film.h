@@ -8,15 +8,14 @@
 // and ADDS them to acc[ch][chunk] of lanes 0..12 -- so that a wave which renders several 64-sample chunks of the same
 // pixel (spp 256 = 4 chunks) touches memory once per pixel: film_flush_wave then issues one atomic per window pixel and
 // channel (PMC, round 1: the primal launch wrote 8.1 GB for a 25 MB film with one flush per chunk).
-// `on` = false: the lane carries no sample (a partially filled batch of the streaming pass) and contributes nothing.
 template <int NCH>     // block channels: NCH - 1 value channels + weight
 __device__ __forceinline__ void film_accum_wave(int px, int py, float u, float v, const float *vals, float *T, int lid,
-                                                float acc[NCH][2], bool on = true) {
+                                                float acc[NCH][2]) {
     float pfx = u + (DSDF_BORDER - 0.5f), pfy = v + (DSDF_BORDER - 0.5f);
     float fx[5], fy[5];
 #pragma unroll
     for (int i = 0; i < 5; ++i) {
-        fx[i] = on ? gauss_f((float)(px - 2 + i) - pfx) : 0.f;
+        fx[i] = gauss_f((float)(px - 2 + i) - pfx);
         fy[i] = gauss_f((float)(py - 2 + i) - pfy);
     }
     float f[25];

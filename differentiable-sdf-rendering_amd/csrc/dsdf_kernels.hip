@@ -387,138 +387,6 @@ void k_render_items(GridView G, dsdf_params P, ViewBatch VB, float *__restrict__
     if (STATS) flush_stats(stats, wst, blockIdx.x, lid);
 }
 
-// STREAMING primal pass (silhouette / shading integrators, any spp >= 64).  A persistent worker takes one listed PIXEL per
-// ticket and streams its spp samples through the 64 lanes: a lane whose ray has finished is handed the next sample of the
-// pixel at once, so the lock-step march loop stays full (the chunk-at-a-time form idles 28 % of its lanes on the bench scene:
-// every 64-sample chunk waits for its slowest ray).  The loop only marches.  A finished sample leaves (sample id, hit distance)
-// in a 128-entry LDS ring; whenever 64 are staged they are completed together, all lanes busy: the ray is regenerated from the
-// sample id (~60 instructions against ~5000 of its march), the hit refined, shaded, re-projected and reduced into the pixel's
-// 5x5 film window.  Every sample executes exactly the statements of trace_plain / refine_hit: results are identical.
-#define DSDF_STAGE_CAP 128
-#ifndef DSDF_STREAM_MINWAVES
-#define DSDF_STREAM_MINWAVES DSDF_PRIMAL_MINWAVES
-#endif
-template <bool STATS>
-__global__ __launch_bounds__(64, DSDF_STREAM_MINWAVES)
-void k_render_stream(GridView G, dsdf_params P, ViewBatch VB, float *__restrict__ blocks, unsigned long long *stats,
-                     const unsigned char *__restrict__ skip, uint32_t *__restrict__ items) {
-    __shared__ __attribute__((aligned(16))) float wave_lds[DSDF_WAVE_LDS];
-    __shared__ uint2 stage[DSDF_STAGE_CAP];
-    const int lid = lane_id();
-    const uint32_t npix = (uint32_t)(VB.v[0].Wb * VB.v[0].Hb);
-    const uint32_t spp = (uint32_t)VB.v[0].spp;
-    const uint32_t n_items = (uint32_t)__builtin_amdgcn_readfirstlane((int)items[0]);      // listed pixels
-    const uint32_t tc = blockIdx.x % DSDF_TICKETS;
-    uint32_t *ticket = items + 16 + 16 * tc;
-    const uint32_t first = gridDim.x / DSDF_TICKETS;
-    WaveStats wst = {0, 0, 0, 0, 0, 0, 0};
-    uint32_t item = blockIdx.x, next = 0;
-    if (item < n_items && lid == 0) next = tc + DSDF_TICKETS * (first + atomicAdd(ticket, 1u));
-    while (item < n_items) {
-        const uint32_t e = (uint32_t)__builtin_amdgcn_readfirstlane((int)items[DSDF_ITEM_HDR + item]);
-        const uint32_t view = e / npix, pix = e - view * npix;
-        const ViewArgs &A = VB.v[view];
-        float *__restrict__ block = blocks + (size_t)view * 2 * npix;
-        const int py = (int)(pix / (uint32_t)A.Wb), px = (int)(pix - (uint32_t)py * (uint32_t)A.Wb);
-        const bool skip_trace = skip && (__builtin_amdgcn_readfirstlane((int)skip[e]) & 1);
-        const uint32_t lane0 = pix * spp;
-        float acc[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
-        uint32_t head = 0, staged = 0;                    // LDS ring of finished samples (wave-uniform)
-
-        // completes `count` staged samples (count <= 64): lane i takes ring entry head + i
-        auto complete = [&](uint32_t count) {
-            const bool on = (uint32_t)lid < count;
-            const uint2 se = stage[(head + (uint32_t)lid) & (DSDF_STAGE_CAP - 1)];
-            const Lane L = lane_setup(A, P, lane0 + (on ? se.x : 0u));
-            float its_t = on ? __uint_as_float(se.y) : INFINITY;
-            int nref = 0;
-            if (P.refine_steps > 0) {                      // (wave-uniform; the silhouette integrator runs with 0)
-                const PlainMarch mm = plain_march_begin(P, L.ray.o, L.ray.d, L.ray.maxt);
-                WaveCellCache RF; RF.taps = wave_lds; RF.lid = lid;
-                its_t = refine_hit(G, P, mm.o, mm.d, its_t, mm.trace_eps, nref, RF);
-            }
-            const float val = on ? shade_value(G, A, L, its_t) : 0.f;
-            const Reproj rp = reproject(A.cam, P, L.ray.o + L.ray.d, A.W, A.H);
-            film_accum_wave<2>(px, py, rp.u, rp.v, &val, wave_lds, lid, acc, on);
-            if (STATS) {
-                wst.lanes += (int)count;
-                wst.hits += wave_sum_i32(on && its_t < INFINITY ? 1 : 0);
-                wst.refine += wave_sum_i32(on ? nref : 0);
-                wst.wsteps += wave_max_i32(on ? nref : 0);
-            }
-        };
-
-        if (skip_trace) {
-            // proven empty: every sample is a miss -- only the weights are splatted
-            for (uint32_t s0 = 0; s0 < spp; s0 += 64) {
-                const bool on = s0 + (uint32_t)lid < spp;
-                const Lane L = lane_setup(A, P, lane0 + (on ? s0 + (uint32_t)lid : 0u));
-                const Reproj rp = reproject(A.cam, P, L.ray.o + L.ray.d, A.W, A.H);
-                const float val = 0.f;
-                film_accum_wave<2>(px, py, rp.u, rp.v, &val, wave_lds, lid, acc, on);
-                if (STATS) wst.lanes += (int)min(64u, spp - s0);
-            }
-        } else {
-            PlainMarch m;
-            m.active = false; m.its_t = INFINITY; m.t = 0.f; m.maxt = 0.f; m.trace_eps = 0.f;
-            m.o = mk(0.f, 0.f, 0.f); m.d = mk(0.f, 0.f, 1.f);
-            uint32_t my_s = 0, next_s = 0;
-            int my_steps = 0;
-            WaveCellCache F; F.taps = wave_lds; F.lid = lid;
-            while (true) {
-                bool fin = false;
-                // ---- hand the next samples of the pixel to the idle lanes
-                const uint64_t idle = __ballot(!m.active);
-                if (idle != 0 && next_s < spp) {
-                    const uint32_t k = next_s + mask_prefix(idle);
-                    if (!m.active && k < spp) {
-                        my_s = k;
-                        const Lane L = lane_setup(A, P, lane0 + k);
-                        m = plain_march_begin(P, L.ray.o, L.ray.d, L.ray.maxt);
-                        F.prev_base = 0xffffffffu;         // the lane's cached slot belongs to its previous ray
-                        fin = !m.active;                   // the ray misses the bounding box: finished at once (a miss)
-                        if (STATS) my_steps = 0;
-                    }
-                    next_s = min(spp, next_s + (uint32_t)__popcll(idle));
-                }
-                // ---- one lock-step march step
-                if (__ballot(m.active) != 0) {
-                    float v = 0.f; V3 gd; float Hd[6];
-                    F.template eval<0>(G, fma3(m.t, m.d, m.o), m.active, v, gd, Hd);
-                    if (m.active) {
-                        plain_march_step(m, v);
-                        fin = !m.active;
-                        if (STATS) ++my_steps;
-                    }
-                    if (STATS) ++wst.wsteps;
-                }
-                // ---- stage the samples that finished in this iteration
-                const uint64_t fm = __ballot(fin);
-                if (fm != 0) {
-                    if (fin) stage[(head + staged + mask_prefix(fm)) & (DSDF_STAGE_CAP - 1)] = make_uint2(my_s, __float_as_uint(m.its_t));
-                    staged += (uint32_t)__popcll(fm);
-                    if (STATS) { wst.steps += wave_sum_i32(fin ? my_steps : 0); wst.bbox += wave_sum_i32(fin && my_steps > 0 ? 1 : 0); }
-                    wave_lds_sync();
-                }
-                // ---- complete 64 staged samples at a time (the rest once the pixel is finished): ONE call site
-                const bool done = next_s >= spp && __ballot(m.active) == 0;
-                if (staged >= 64 || (done && staged != 0)) {
-                    const uint32_t cnt = min(staged, 64u);
-                    complete(cnt);
-                    head = (head + cnt) & (DSDF_STAGE_CAP - 1);
-                    staged -= cnt;
-                    F.prev_base = 0xffffffffu;             // the completion used the cache's LDS
-                }
-                if (done && staged == 0) break;
-            }
-        }
-        film_flush_wave<2>(block, A, px, py, lid, acc);
-        item = (uint32_t)__builtin_amdgcn_readfirstlane((int)next);
-        if (item < n_items && lid == 0) next = tc + DSDF_TICKETS * (first + atomicAdd(ticket, 1u));
-    }
-    if (STATS) flush_stats(stats, wst, blockIdx.x, lid);
-}
-
 // Thread -> sample of the general pass.  The reference's lane order (lane = pixel * spp + sample, pixels row-major,
 // reparam.py:140-155) is only a convention -- the sampler is keyed by the lane index, so any thread may render any lane.
 // For spp < 64 (a power of two) a wave takes a tile_w x tile_h PIXEL TILE (64 / spp pixels) instead of 64 / spp consecutive
@@ -621,8 +489,11 @@ struct UnitGather {
     }
 };
 
+#ifndef DSDF_BWD_MINWAVES
+#define DSDF_BWD_MINWAVES 1
+#endif
 template <bool DIRECT>
-__global__ __launch_bounds__(64) void k_backward(GridView G, dsdf_params P, ViewBatch VB, Queue qall,
+__global__ __launch_bounds__(64, DIRECT ? 1 : DSDF_BWD_MINWAVES) void k_backward(GridView G, dsdf_params P, ViewBatch VB, Queue qall,
                                                  const float *__restrict__ block_adjs,
                                                  float *__restrict__ grad_grid, float *__restrict__ grad_p,
                                                  unsigned long long *stats, ShadeArgs S) {
@@ -991,8 +862,7 @@ static int run_pass(const PassCtx &c, const Workspace &ws, const dsdf_camera *ca
     const GridView G = device_view(c.padded, c.rx, c.ry, c.rz, *c.prm);
     const ShadeArgs S = make_shade_args(c.shading, DIFF);
     unsigned long long *st64 = (unsigned long long *)stats;
-    const bool stream = !DIFF && !c.direct && c.spp >= 64 && !(c.flags & DSDF_NO_STREAM);
-    if (c.spp % 64 == 0 || stream) {
+    if (c.spp % 64 == 0) {
         // persistent workers over the compacted list of pixels that must be sampled
         // (sdf_direct_reparam with a visible environment: the background is not zero, every pixel is sampled)
         const unsigned far_bit = (c.direct && !S.hide_emitters) ? 0u : (DIFF ? 8u : 4u);
@@ -1014,11 +884,6 @@ static int run_pass(const PassCtx &c, const Workspace &ws, const dsdf_camera *ca
             }
         }
         const dim3 grid(worker_blocks()), blk(64);
-        if (stream) {
-            if (st64) hipLaunchKernelGGL((k_render_stream<true>), grid, blk, 0, st, G, c.pp, VB, film, st64, skip, ws.items);
-            else hipLaunchKernelGGL((k_render_stream<false>), grid, blk, 0, st, G, c.pp, VB, film, st64, skip, ws.items);
-            return check_launch("k_render_stream");
-        }
         if (c.direct) {
             if (st64) hipLaunchKernelGGL((k_render_items<DIFF, true, true>), grid, blk, 0, st, G, c.pp, VB, film, q, st64, skip, S, tq, ws.items);
             else hipLaunchKernelGGL((k_render_items<DIFF, true, false>), grid, blk, 0, st, G, c.pp, VB, film, q, st64, skip, S, tq, ws.items);

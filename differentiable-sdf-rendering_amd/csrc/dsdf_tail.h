@@ -57,7 +57,10 @@ struct HandOff {
 };
 
 // Resumes the queued rays of the gradient sweep and finishes their samples: value splat, backward-queue entry.
-__global__ __launch_bounds__(256) void k_tail_trace_diff(GridView G, dsdf_params P, ViewBatch VB, float *__restrict__ blocks,
+#ifndef DSDF_TAIL_MINWAVES
+#define DSDF_TAIL_MINWAVES 1
+#endif
+__global__ __launch_bounds__(256, DSDF_TAIL_MINWAVES) void k_tail_trace_diff(GridView G, dsdf_params P, ViewBatch VB, float *__restrict__ blocks,
                                                          TailQueue tq, Queue qall) {
     const uint32_t sub = blockIdx.x % DSDF_TAIL_SUBQ;
     uint32_t *cnt = tq.count + 2 * sub;
@@ -69,9 +72,7 @@ __global__ __launch_bounds__(256) void k_tail_trace_diff(GridView G, dsdf_params
     Lane L;
     uint32_t sample = 0, view = 0;
     bool exhausted = false;
-#ifdef DSDF_TAIL_REUSE
-    ReuseFetch RF;      // tail rays graze: most of their (tiny) steps stay in one B-spline cell, whose 64 taps then stay in registers
-#endif
+
     while (true) {
         const uint64_t idle = __ballot(!m.active);
         if (!exhausted && __popcll(idle) >= DSDF_TAIL_REFILL) {
@@ -103,11 +104,7 @@ __global__ __launch_bounds__(256) void k_tail_trace_diff(GridView G, dsdf_params
         if (m.active) {
             V3 x = fma3(m.t, m.d, m.o);
             float v; V3 g; float H[6];
-#ifdef DSDF_TAIL_REUSE
-            RF.eval<2>(G, x, true, v, g, H);
-#else
             eval_cubic<2>(G, x, v, g, H);
-#endif
             diff_march_step(P, m, x, v, g, H);
             if (!m.active) {                                            // the sample is complete: what the render pass does after its loop
                 const ViewArgs &A = VB.v[view];

@@ -12,7 +12,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import (DSDF_DIRECT, DSDF_NO_SKIP, DSDF_NO_STREAM, DSDF_REPARAM, DSDF_SILHOUETTE, DSDF_SIMPLE_SHADING, DsdfCamera,
+from ._lib import (DSDF_DIRECT, DSDF_NO_SKIP, DSDF_REPARAM, DSDF_SILHOUETTE, DSDF_SIMPLE_SHADING, DsdfCamera,
                    DsdfShading)
 
 INTEGRATORS = {'sdf_silhouette_reparam': DSDF_SILHOUETTE, 'sdf_simple_shading_reparam': DSDF_SIMPLE_SHADING,
@@ -71,6 +71,7 @@ def _workspace(device, nbytes, min_bytes=None):
 def release_workspaces():
     """Frees the cached scratch buffers (they are kept between calls otherwise)."""
     _workspaces.clear()
+    _sweep_workspaces.clear()
 
 
 class SdfGrid:
@@ -262,7 +263,7 @@ def _sampler_args(n_views, seeds, offsets, n_lanes):
 
 
 def render_forward(grid, sensors, spp, seeds=None, offsets=None, integrator=DSDF_SILHOUETTE, reparam=True, stats=None,
-                   empty_space_skip=True, shading=None, emitter_samples=None, stream=True):
+                   empty_space_skip=True, shading=None, emitter_samples=None):
     """`ReparamIntegrator.render` for a batch of views -> (n_views, H, W, 3).  `shading` (dsdf.Shading) and the
     optional per-lane `emitter_samples` belong to sdf_direct_reparam."""
     lib = _lib.load()
@@ -279,8 +280,7 @@ def render_forward(grid, sensors, spp, seeds=None, offsets=None, integrator=DSDF
     with torch.cuda.device(dev):
         _lib.check(lib.dsdf_render_forward(_ptr(grid.padded), grid.rx, grid.ry, grid.rz, C.byref(grid.params), cams, nv,
                                            W, H, int(spp), _ptr(offsets), cseeds, INTEGRATORS[integrator],
-                                           (DSDF_REPARAM if reparam else 0) | (0 if empty_space_skip else DSDF_NO_SKIP) |
-                                           (0 if stream else DSDF_NO_STREAM),
+                                           (DSDF_REPARAM if reparam else 0) | (0 if empty_space_skip else DSDF_NO_SKIP),
                                            sh, _ptr(img), _ptr(ws), wsb, _ptr(stats), _stream()))
     return img
 
@@ -401,13 +401,16 @@ def develop(film, W, H, integrator=DSDF_SILHOUETTE):
     return img
 
 
+_sweep_workspaces = {}
+
+
 class GradSweep:
     """The two halves of a gradient pass split at the film block: sweep() traces the window's samples (film accumulated,
     backward queue left in this object's workspace); after the films of all ranks were summed, backward() propagates the
     window's samples against the total film."""
 
     def __init__(self, grid, sensors, spp, rows, seeds=None, offsets=None, integrator=DSDF_SILHOUETTE, reparam=True,
-                 empty_space_skip=True, shading=None, emitter_samples=None, grad_albedo=None):
+                 empty_space_skip=True, shading=None, emitter_samples=None, grad_albedo=None, workspace=None):
         self.lib = _lib.load()
         self.grid = grid
         self.sensors, self.cams, self.W, self.H = _views(sensors)
@@ -419,8 +422,12 @@ class GradSweep:
         self.flags = (DSDF_REPARAM if reparam else 0) | (0 if empty_space_skip else DSDF_NO_SKIP)
         self.rows = (int(rows[0]), int(rows[1]))
         self.sh, self._keep = _shading_arg(integrator, shading, self.nv, n_lanes, emitter_samples, grad_albedo)
-        wsb = self.lib.dsdf_render_workspace_size(self.W, self.H, self.spp, self.nv, self.integrator)
-        self.ws = torch.empty(int(wsb), dtype=torch.uint8, device=grid.device)     # private: the queue lives here between the halves
+        wsb = int(self.lib.dsdf_render_workspace_size(self.W, self.H, self.spp, self.nv, self.integrator))
+        # the backward queue lives in this buffer between the two halves: private to the sweep unless the caller lends one
+        if workspace is not None and workspace.numel() >= wsb:
+            self.ws = workspace
+        else:
+            self.ws = torch.empty(wsb, dtype=torch.uint8, device=grid.device)
 
     def _args(self):
         g = self.grid
@@ -439,6 +446,43 @@ class GradSweep:
             _lib.check(self.lib.dsdf_grad_backward(*self._args(), _ptr(film_total), _ptr(grad_image), _ptr(grad_grid), _ptr(grad_p),
                                                    _ptr(self.ws), self.ws.numel(), _stream()))
         return grad_grid
+
+
+_side_streams = {}
+
+
+def render_step(grid, sensors, spp, spp_grad, loss_grad, grad_grid, seeds, seeds_grad, integrator=DSDF_SILHOUETTE, reparam=True,
+                shading=None, grad_albedo=None, grad_p=None, overlap=True):
+    """One differentiable render step (python/shape_opt.py:77-83 for a batch of views): primal render at `spp`, image
+    gradient `loss_grad(images)`, gradient pass at `spp_grad` accumulating into `grad_grid` -- the same three library calls as
+    render_forward + render_backward, scheduled on TWO HIP streams: the forward sweep of the gradient pass (tracing, film,
+    backward queue: dsdf_grad_sweep) does not depend on the image gradient, so it runs on a side stream concurrently with the
+    primal render; only the backward proper (dsdf_grad_backward) waits for both.  The latency-bound ends of the two passes
+    (a handful of 1000-step grazing rays each) then overlap with the other pass' bulk.  Returns the images."""
+    sensors = list(sensors) if isinstance(sensors, (list, tuple)) else [sensors]
+    W, H = sensors[0].film_size()
+    dev = grid.device
+    if not overlap:
+        img = render_forward(grid, sensors, spp, seeds=seeds, integrator=integrator, reparam=reparam, shading=shading)
+        render_backward(grid, sensors, spp_grad, loss_grad(img), grad_grid=grad_grid, seeds=seeds_grad, integrator=integrator,
+                        reparam=reparam, shading=shading, grad_albedo=grad_albedo, grad_p=grad_p)
+        return img
+    main = torch.cuda.current_stream(dev)
+    side = _side_streams.get(dev)
+    if side is None:
+        side = _side_streams[dev] = torch.cuda.Stream(dev)
+    side.wait_stream(main)                                    # the grid (and whatever produced it) is ready
+    with torch.cuda.stream(side):
+        sweep = GradSweep(grid, sensors, spp_grad, (0, H + 4), seeds=seeds_grad, integrator=integrator, reparam=reparam,
+                          shading=shading, grad_albedo=grad_albedo, workspace=_sweep_workspaces.get(dev))
+        _sweep_workspaces[dev] = sweep.ws                  # re-used by the next step's sweep (stream-ordered after this backward)
+        film_g = sweep.sweep(new_film(len(sensors), W, H, integrator, dev))
+    img = render_forward(grid, sensors, spp, seeds=seeds, integrator=integrator, reparam=reparam, shading=shading)
+    gi = loss_grad(img)
+    main.wait_stream(side)
+    film_g.record_stream(main); sweep.ws.record_stream(main)
+    sweep.backward(film_g, gi.contiguous(), grad_grid, grad_p)
+    return img
 
 
 def redistance(phi, return_status=False):

@@ -48,8 +48,7 @@ enum dsdf_integrator {
  * without it the DummyWarpField path is taken (python/warp.py:179-196). */
 enum dsdf_flags {
     DSDF_REPARAM = 1,
-    DSDF_NO_SKIP = 2,  /* disable the exact per-pixel empty-space proof (A/B and testing) */
-    DSDF_NO_STREAM = 4 /* primal pass: chunk-at-a-time workers instead of the sample-streaming ones (A/B and testing) */
+    DSDF_NO_SKIP = 2   /* disable the exact per-pixel empty-space proof (A/B and testing) */
 };
 
 /* Perspective sensor as built by python/util.py:115-138 (`get_regular_cameras`):

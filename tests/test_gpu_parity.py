@@ -207,24 +207,6 @@ def test_tile_split_equals_whole_view_gpu(dsdf, spp):
         dsdf.render_film(grid, sens, spp, film, (5, 5), seeds=seeds)               # empty window
 
 
-@pytest.mark.parametrize('spp', [64, 100, 256])
-def test_streaming_primal_equals_chunked(dsdf, spp):
-    """The sample-streaming primal workers (default for spp >= 64, any spp) against the chunk-at-a-time workers / the
-    general per-lane pass: every sample executes the same march, so the films agree to atomic-order noise; statistics too."""
-    case = make_case('blob48_rect')
-    grid = dev_grid(dsdf, case)
-    sens = dsdf.get_regular_cameras(12, resx=case['W'], resy=case['H'])[2:5]
-    for integ in (O.SILHOUETTE, O.SIMPLE_SHADING):
-        sa, sb = dsdf.new_stats('cuda'), dsdf.new_stats('cuda')
-        a = dsdf.render_forward(grid, sens, spp, seeds=[1, 2, 3], integrator=integ, stats=sa)
-        b = dsdf.render_forward(grid, sens, spp, seeds=[1, 2, 3], integrator=integ, stats=sb, stream=False)
-        assert rel_l2(a.cpu(), b.cpu()) < 1e-6
-        da, db = dsdf.stats_dict(sa), dsdf.stats_dict(sb)
-        for k in ('lanes', 'hits', 'steps', 'bbox_lanes', 'refine_steps'):
-            assert da[k] == db[k], (k, da[k], db[k])
-        assert da['wave_steps'] < db['wave_steps']            # fuller waves: fewer lock-step iterations for the same rays
-
-
 def test_backward_accumulates(dsdf):
     case = make_case('blob32')
     grid, sen = dev_grid(dsdf, case), sensor(dsdf, case)
@@ -576,3 +558,21 @@ def test_forward_mode_gpu(dsdf, integ):
     assert abs(lhs_p - rhs_p) < 2e-3 * max(abs(rhs_p), 1.0), (lhs_p, rhs_p)
     with pytest.raises(dsdf.DsdfError):
         dsdf.render_forward_grad(grid, sens, 64, seeds=[4, 5, 6], integrator=integ)           # no tangent
+
+
+def test_two_stream_step_equals_sequential(dsdf):
+    """dsdf.render_step (primal pass and gradient sweep on two HIP streams, backward after both) == render_forward +
+    render_backward: same image, same dL/dsdf (atomic-order noise), repeated to exercise the workspace hand-over."""
+    case = make_case('blob48_rect')
+    grid = dev_grid(dsdf, case)
+    sens = dsdf.get_regular_cameras(12, resx=case['W'], resy=case['H'])[:3]
+    tgt = torch.rand(3, case['H'], case['W'], 3, device='cuda')
+    lg = lambda im: 2.0 * (im - tgt)
+    for it in range(3):
+        seeds, seeds_g = [10 * it + i for i in range(3)], [100 + 10 * it + i for i in range(3)]
+        for integ in (O.SILHOUETTE, O.SIMPLE_SHADING):
+            ga, gb = torch.zeros(grid.shape, device='cuda'), torch.zeros(grid.shape, device='cuda')
+            ia = dsdf.render_step(grid, sens, 64, 64, lg, ga, seeds, seeds_g, integrator=integ, overlap=True)
+            ib = dsdf.render_step(grid, sens, 64, 64, lg, gb, seeds, seeds_g, integrator=integ, overlap=False)
+            torch.cuda.synchronize()
+            assert rel_l2(ia.cpu(), ib.cpu()) < 1e-6 and rel_l2(ga.cpu(), gb.cpu()) < 1e-5

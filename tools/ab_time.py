@@ -24,7 +24,6 @@ def t(fn, n=3):
 S = list(range(12))
 out = {'lib': os.path.basename(os.environ.get('DSDF_LIB_PATH', 'libdsdf.so'))}
 out['primal256'] = t(lambda: dsdf.render_forward(grid, sens, 256, seeds=S))
-out['primal256_chunks'] = t(lambda: dsdf.render_forward(grid, sens, 256, seeds=S, stream=False))
 out['grad64'] = t(lambda: dsdf.render_backward(grid, sens, 64, gi, grad_grid=g, seeds=S))
 out['primal4'] = t(lambda: dsdf.render_forward(grid, sens, 4, seeds=S), 10)
 out['grad1'] = t(lambda: dsdf.render_backward(grid, sens, 1, gi, grad_grid=g, seeds=S), 10)
