@@ -489,11 +489,8 @@ struct UnitGather {
     }
 };
 
-#ifndef DSDF_BWD_MINWAVES
-#define DSDF_BWD_MINWAVES 1
-#endif
 template <bool DIRECT>
-__global__ __launch_bounds__(64, DIRECT ? 1 : DSDF_BWD_MINWAVES) void k_backward(GridView G, dsdf_params P, ViewBatch VB, Queue qall,
+__global__ __launch_bounds__(64) void k_backward(GridView G, dsdf_params P, ViewBatch VB, Queue qall,
                                                  const float *__restrict__ block_adjs,
                                                  float *__restrict__ grad_grid, float *__restrict__ grad_p,
                                                  unsigned long long *stats, ShadeArgs S) {

@@ -57,10 +57,7 @@ struct HandOff {
 };
 
 // Resumes the queued rays of the gradient sweep and finishes their samples: value splat, backward-queue entry.
-#ifndef DSDF_TAIL_MINWAVES
-#define DSDF_TAIL_MINWAVES 1
-#endif
-__global__ __launch_bounds__(256, DSDF_TAIL_MINWAVES) void k_tail_trace_diff(GridView G, dsdf_params P, ViewBatch VB, float *__restrict__ blocks,
+__global__ __launch_bounds__(256) void k_tail_trace_diff(GridView G, dsdf_params P, ViewBatch VB, float *__restrict__ blocks,
                                                          TailQueue tq, Queue qall) {
     const uint32_t sub = blockIdx.x % DSDF_TAIL_SUBQ;
     uint32_t *cnt = tq.count + 2 * sub;

@@ -470,7 +470,9 @@ def render_step(grid, sensors, spp, spp_grad, loss_grad, grad_grid, seeds, seeds
     main = torch.cuda.current_stream(dev)
     side = _side_streams.get(dev)
     if side is None:
-        side = _side_streams[dev] = torch.cuda.Stream(dev)
+        # high priority: the sweep's workers get the wave slots first, so it finishes early and its latency-bound tail kernel
+        # (a handful of 1000-step rays) runs beside the bulk of the primal pass instead of after it
+        side = _side_streams[dev] = torch.cuda.Stream(dev, priority=-1)
     side.wait_stream(main)                                    # the grid (and whatever produced it) is ready
     with torch.cuda.stream(side):
         sweep = GradSweep(grid, sensors, spp_grad, (0, H + 4), seeds=seeds_grad, integrator=integrator, reparam=reparam,

@@ -91,7 +91,7 @@ def reference_gradient(case, integ, reparam=True):
         live = np.abs(g64).max() > 0
         fc = rel_l2(g32, g64) if live else 0.0
         ft = 0.0
-        if live and case['offsets'].shape[0] <= 60000:
+        if live and case['offsets'].shape[0] <= 20000:
             ft = rel_l2(torch_backward(case, integ, reparam, torch.float32), g64)
         _cache[key] = dict(g64=g64, img64=img64, floor=max(fc, ft), floor_c=fc, floor_torch=ft,
                            floor_trim=trimmed_rel_l2(g32, g64) if live else 0.0)
