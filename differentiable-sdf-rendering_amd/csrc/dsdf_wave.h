@@ -49,76 +49,9 @@ __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// LDS-aggregated 64-tap scatter for one wave.  The samples of a wave come from a few
-// neighbouring pixels, so their 4^3 footprints overlap heavily: accumulate them in a
-// wave-private LDS brick spanning the bounding box of all taps (ds_add_f32), then
-// flush only the non-zero voxels with one global atomic each.  Falls back to direct
-// global atomics when the bounding box does not fit the brick.
-#define DSDF_BRICK_CAP 2048   /* floats per wave-private brick (8 KB): ~20 single-wave blocks per CU */
-__device__ __forceinline__ void wave_scatter(const GridView &G, float *__restrict__ grad, const ScatterReq &rq,
-                                             float *brick, int lid) {
-    const bool on = rq.on;
-    if (!__ballot(on)) return;
-    CubicSetup s = cubic_setup(G, on ? rq.x : mk(0.f, 0.f, 0.f));
-    const int big = 1 << 30;
-    int minx = wave_min_i32(on ? iclamp(s.ix, 0, G.rx - 1) : big), maxx = wave_max_i32(on ? iclamp(s.ix + 3, 0, G.rx - 1) : -big);
-    int miny = wave_min_i32(on ? iclamp(s.iy, 0, G.ry - 1) : big), maxy = wave_max_i32(on ? iclamp(s.iy + 3, 0, G.ry - 1) : -big);
-    int minz = wave_min_i32(on ? iclamp(s.iz, 0, G.rz - 1) : big), maxz = wave_max_i32(on ? iclamp(s.iz + 3, 0, G.rz - 1) : -big);
-    int ex = maxx - minx + 1, ey = maxy - miny + 1, ez = maxz - minz + 1;
-    bool fits = ex <= 64 && ey <= 64 && ez <= 64 && ex * ey * ez <= DSDF_BRICK_CAP;
-    if (!fits) {
-        if (on) scatter_cubic(G, grad, rq.x, rq.cv, rq.cg, AtomicAdd());
-        return;
-    }
-    const int vol = ex * ey * ez;
-    // Privatisation: the samples of a wave mostly share one cell, i.e. their ds_add_f32 hit the
-    // same addresses and serialise.  K copies of the brick (copy = lane mod K) cut the conflict
-    // degree K-fold; the flush sums the copies.
-    int K = 1;
-    while (K < 8 && 2 * K * vol <= DSDF_BRICK_CAP) K *= 2;
-    const int tot = K * vol;
-    for (int e = lid; e < tot; e += 64) brick[e] = 0.f;
-    wave_lds_sync();
-    if (on) {
-        float *mine = brick + (lid & (K - 1)) * vol;
-        float wx[4], wy[4], wz[4], dwx[4], dwy[4], dwz[4];
-        bspline_w(s.ax, wx); bspline_w(s.ay, wy); bspline_w(s.az, wz);
-        bspline_dw(s.ax, dwx); bspline_dw(s.ay, dwy); bspline_dw(s.az, dwz);
-        float gx = rq.cg.x * G.frx, gy = rq.cg.y * G.fry, gz = rq.cg.z * G.frz;
-        int xo[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) xo[i] = iclamp(s.ix + i, 0, G.rx - 1) - minx;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            int zo = iclamp(s.iz + k, 0, G.rz - 1) - minz;
-            float azv = wz[k], azd = dwz[k] * gz;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                int yo = iclamp(s.iy + j, 0, G.ry - 1) - miny;
-                float *row = mine + (zo * ey + yo) * ex;
-                float c0 = azv * wy[j] * rq.cv + azd * wy[j] + azv * dwy[j] * gy;
-                float c1 = azv * wy[j] * gx;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) atomicAdd(row + xo[i], fmaf(c0, wx[i], c1 * dwx[i]));
-            }
-        }
-    }
-    wave_lds_sync();
-    for (int e = lid; e < vol; e += 64) {
-        float v = brick[e];
-        for (int c = 1; c < K; ++c) v += brick[c * vol + e];
-        if (v != 0.f) {
-            int x = e % ex, t = e / ex;
-            int y = t % ey, z = t / ey;
-            atomicAdd(grad + ((size_t)(minz + z) * G.ry + (miny + y)) * G.rx + (minx + x), v);
-        }
-    }
-    wave_lds_sync();
-}
-
-// Transposed 64-tap scatter for one wave (replaces the ds_add_f32 brick: rocprof showed k_backward stalled on LDS
-// atomics -- SQ_WAIT_INST_LDS 6x SQ_ACTIVE_INST_VALU -- because the samples of a wave share a handful of cells, i.e.
-// their atomics hit the same addresses).  No LDS atomics at all:
+// Transposed 64-tap scatter for one wave.  (Round 1 accumulated the taps with ds_add_f32 in a wave-private LDS brick; rocprof
+// showed k_backward stalled on those atomics -- LDS 89 % busy, VALU 9 % -- because the samples of a wave share a handful of
+// cells, i.e. their atomics hit the same addresses.  8.5 -> 3.0 ms.)  No LDS atomics at all:
 //   1. every active lane writes its 64 tap contributions as ROW `lane` of a 64 x 68 LDS tile (16 ds_write_b128);
 //   2. the wave groups its lanes by B-spline cell (v_readlane / ballot, like the cell cache);
 //   3. per distinct cell, lane k (= tap k) sums column k over the lanes of the group (conflict-free ds_read_b32)
