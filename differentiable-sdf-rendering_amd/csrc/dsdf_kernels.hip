@@ -1109,3 +1109,4 @@ int dsdf_grad_backward(const float *padded, int rx, int ry, int rz, const dsdf_p
 }  // extern "C"
 
 #include "dsdf_redistance.h"
+#include "dsdf_mesh.h"

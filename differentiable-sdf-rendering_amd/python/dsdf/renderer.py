@@ -507,6 +507,21 @@ def redistance(phi, return_status=False):
     return out.reshape(shape)
 
 
+def mesh_raycast(triangles, rays_o, rays_d, t_min=0.0):
+    """Closest hit of rays against a triangle soup (T,3,3) -> (t (n,), backface (n,) int32): what `mesh_to_sdf.create_sdf`
+    takes from `scene.ray_intersect` (python/mesh_to_sdf.py:24-26, 45)."""
+    lib = _lib.load()
+    tri = _require_dev(triangles.reshape(-1, 9), 'triangles')
+    rays_o = _require_dev(rays_o, 'rays_o'); rays_d = _require_dev(rays_d, 'rays_d')
+    n = rays_o.shape[0]
+    t = torch.empty(n, dtype=torch.float32, device=rays_o.device)
+    back = torch.empty(n, dtype=torch.int32, device=rays_o.device)
+    with torch.cuda.device(rays_o.device):
+        _lib.check(lib.dsdf_mesh_raycast(_ptr(tri), int(tri.shape[0]), _ptr(rays_o), _ptr(rays_d), n, C.c_float(t_min), _ptr(t), _ptr(back),
+                                         _stream()))
+    return t, back
+
+
 def new_stats(device):
     return torch.zeros(64, 8, dtype=torch.int64, device=device)
 

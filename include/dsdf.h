@@ -259,6 +259,14 @@ int dsdf_redistance(const float *phi, int rx, int ry, int rz, float *out,
  * The library never synchronises: read it whenever the caller synchronises anyway. */
 int dsdf_redistance_status(const void *workspace, int rx, int ry, int rz, int32_t *status, void *stream);
 
+/* The native operation behind `mesh_to_sdf.create_sdf` (python/mesh_to_sdf.py:9-57): Mitsuba's `scene.ray_intersect` on a
+ * triangle mesh.  triangles: n_triangles x 9 device floats (p0, p1, p2 per triangle); rays_o / rays_d: n x 3.
+ * t_out n: distance of the closest hit with t > t_min (+inf: none); backface_out n (optional, int32): 1 when the geometric
+ * normal (p1 - p0) x (p2 - p0) of the hit triangle has a positive component along the ray -- `dot(si.n, ray.d) > 0`,
+ * mesh_to_sdf.py:26: the ray leaves the solid, its origin is inside.  Brute force (asset preparation, not the hot path). */
+int dsdf_mesh_raycast(const float *triangles, int n_triangles, const float *rays_o, const float *rays_d, int64_t n,
+                      float t_min, float *t_out, int32_t *backface_out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

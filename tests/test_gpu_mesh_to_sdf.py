@@ -1,0 +1,94 @@
+"""GPU parity of the mesh -> SDF asset path (`mesh_to_sdf.create_sdf`, python/mesh_to_sdf.py:9-57) against the numpy fp64
+oracle (oracle/mesh_oracle.py) and analytic distances."""
+import numpy as np
+import pytest
+import torch
+
+import c_oracle
+import mesh_oracle as M
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def dsdf(built):
+    import dsdf as m
+    m.load()
+    assert torch.cuda.is_available()
+    return m
+
+
+@pytest.mark.parametrize('n_rays', [1, 63, 5000])
+def test_raycast_matches_oracle(dsdf, n_rays):
+    v, f = M.icosphere(0.3, 2, centre=(0.05, -0.02, 0.01))                # 320 triangles: two LDS tiles, the second partial
+    tri = v[f]
+    rng = np.random.default_rng(n_rays)
+    o = rng.uniform(-0.5, 0.5, (n_rays, 3)).astype(np.float32)
+    d = rng.normal(size=(n_rays, 3)); d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    t_ref, back_ref, margin = M.raycast(tri, o, d)
+    t, back = dsdf.mesh_raycast(torch.from_numpy(tri).cuda(), torch.from_numpy(o).cuda(), torch.from_numpy(d).cuda())
+    t, back = t.cpu().numpy(), back.cpu().numpy()
+    sure = margin > 1e-4                                                  # an edge-grazing hit is an fp32 coin toss
+    assert sure.mean() > 0.95
+    assert (np.isfinite(t) == np.isfinite(t_ref))[sure].all()
+    hit = sure & np.isfinite(t_ref)
+    np.testing.assert_allclose(t[hit], t_ref[hit], rtol=2e-5, atol=2e-6)
+    assert (back[hit] != 0).tolist() == back_ref[hit].tolist()
+
+
+def test_raycast_t_min_and_empty(dsdf):
+    v, f = M.box(half=(0.3, 0.2, 0.25))
+    tri = torch.from_numpy(v[f]).cuda()
+    o = torch.tensor([[0.0, 0.0, 0.0], [0.0, 0.0, 0.0]], device='cuda'); d = torch.tensor([[1.0, 0, 0], [0, 0, -1.0]], device='cuda')
+    t, back = dsdf.mesh_raycast(tri, o, d)
+    np.testing.assert_allclose(t.cpu().numpy(), [0.3, 0.25], rtol=1e-6)
+    assert back.cpu().tolist() == [1, 1]
+    t, _ = dsdf.mesh_raycast(tri, o, d, t_min=0.28)
+    assert t.cpu().tolist()[0] == pytest.approx(0.3, rel=1e-6) and np.isinf(t.cpu().numpy()[1])
+    t, back = dsdf.mesh_raycast(tri, o[:0], d[:0])
+    assert t.numel() == 0 and back.numel() == 0
+
+
+@pytest.mark.parametrize('shape', ['box', 'sphere'])
+def test_create_sdf_matches_oracle(dsdf, shape, tmp_path):
+    import mesh_to_sdf
+    res = 32
+    v, f = M.box(half=(0.3, 0.2, 0.25)) if shape == 'box' else M.icosphere(0.3, 2, centre=(0.03, 0.0, -0.02))
+    lib = c_oracle.load()
+    ref = M.create_sdf(v[f], res, lambda p: c_oracle.redistance(lib, p))
+    fn = str(tmp_path / ('m.obj' if shape == 'box' else 'm.ply'))
+    (M.write_obj if shape == 'box' else M.write_ply)(fn, v, f)
+    grid = mesh_to_sdf.create_sdf(fn, res)
+    assert grid.shape == (res, res, res) and grid.dtype == torch.float32 and grid.is_cuda
+    g = grid.cpu().numpy()
+    # occupancy: identical away from coin-toss voxels (a +y ray through an edge / a centre within fp32 of a face)
+    occ_ref, margin = M.occupancy(v[f], res)
+    occ, _ = mesh_to_sdf.occupancy(torch.from_numpy(v[f]).cuda(), res)
+    sure = margin > 1e-4
+    assert (occ.cpu().numpy() == occ_ref)[sure].all()
+    if sure.all():
+        assert np.abs(g - ref).max() < 2e-5, np.abs(g - ref).max()         # same algorithm, fp32 vs fp64 ray casts
+    assert ((g < 0) == (ref < 0))[np.abs(ref) > 1e-4].all()
+    assert np.abs(g - ref).max() < 0.25 / res
+    coarse = mesh_to_sdf.create_sdf(torch.from_numpy(v[f]), res, refine_surface=False).cpu().numpy()
+    ref_c = M.create_sdf(v[f], res, lambda p: c_oracle.redistance(lib, p), refine_surface=False)
+    if sure.all():
+        assert np.abs(coarse - ref_c).max() < 2e-5
+
+
+def test_create_sdf_sphere_is_analytic_and_renders(dsdf):
+    """End to end: the grid a mesh produces is a usable SDF for the integrator (128^3, ~2.6 M refinement rays x 1280 triangles)."""
+    import mesh_to_sdf
+    res = 64
+    v, f = M.icosphere(0.3, 3)
+    grid = mesh_to_sdf.create_sdf(v[f], res)
+    x = M.voxel_centres(res)
+    ref = (np.linalg.norm(x, axis=1) - 0.3).reshape(res, res, res)
+    err = np.abs(grid.cpu().numpy() - ref)
+    assert err[np.abs(ref) < 1.0 / res].max() < 0.004                     # the polyhedron is inscribed: <= r (1 - cos) of a facet
+    assert err.max() < 1.5 / res
+    sdf = dsdf.SdfGrid(grid)
+    sen = dsdf.get_regular_cameras(1, resx=64, resy=64)[0]
+    img = dsdf.render_forward(sdf, sen, 16)[0].cpu().numpy()
+    cov = (img > 0.5).mean()
+    assert 0.02 < cov < 0.6
