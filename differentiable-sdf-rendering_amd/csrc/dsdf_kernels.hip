@@ -261,25 +261,30 @@ __device__ __forceinline__ void queue_unit(const Queue &q, uint32_t unit, uint32
 // ~8 ns).  Header of the list: [0] = number of listed pixels, then the counters (16 words apart).
 #define DSDF_TICKETS 64
 #define DSDF_ITEM_HDR (16 + 16 * DSDF_TICKETS)
-#ifndef DSDF_ITEM_BATCH_PRIMAL
-#define DSDF_ITEM_BATCH_PRIMAL 1    /* measured 32.3 / 34.9 / 38.6 ms at 1 / 2 / 4 chunks per ticket (L2 locality of the window) */
-#endif
-#ifndef DSDF_ITEM_BATCH_DIFF
-#define DSDF_ITEM_BATCH_DIFF 1
-#endif
+#define DSDF_ITEM_SEG 1024u         /* items per segment = the resident waves of an XCD; the list is tile-major with 1024-chunk tiles
+                                       (measured: 28.9 / 28.7 / 28.6 / 28.5 ms at 256 / 512 / 1024 / 4096) */
+struct ItemOrder { int tw_log2, th_log2; uint32_t tiles_x, per_view; };    // candidate index -> pixel: tile-major within a view
+
 __global__ __launch_bounds__(256) void k_build_items(ViewBatch VB, int nv, const unsigned char *__restrict__ skip, unsigned far_bit,
-                                                     int row0, int row1, uint32_t *__restrict__ items) {
+                                                     int row0, int row1, ItemOrder O, uint32_t *__restrict__ items) {
     const ViewArgs &A = VB.v[0];
-    const uint32_t npix = (uint32_t)(A.Wb * A.Hb), total = npix * (uint32_t)nv;
+    const uint32_t npix = (uint32_t)(A.Wb * A.Hb), total = O.per_view * (uint32_t)nv;
     const uint32_t begin = blockIdx.x * DSDF_ITEM_REGION;
     const int w = threadIdx.x >> 6, lid = lane_id();
     __shared__ uint32_t wcount[4];
     __shared__ uint32_t base;
-    auto live = [&](uint32_t i) {
-        if (i >= total) return false;
-        const int py = (int)((i % npix) / (uint32_t)A.Wb);   // film-block row: only the rows [row0, row1) of this call's window
-        return py >= row0 && py < row1 && !(skip && (skip[i] & far_bit));
+    // candidate i -> list entry (view * npix + film-block pixel), or ~0u when it is not to be sampled
+    auto entry = [&](uint32_t i) -> uint32_t {
+        if (i >= total) return ~0u;
+        const uint32_t view = i / O.per_view, r = i - view * O.per_view;
+        const uint32_t tile = r >> (O.tw_log2 + O.th_log2), in = r & ((1u << (O.tw_log2 + O.th_log2)) - 1u);
+        const uint32_t ty = tile / O.tiles_x, tx = tile - ty * O.tiles_x;
+        const int px = (int)((tx << O.tw_log2) + (in & ((1u << O.tw_log2) - 1u))), py = (int)((ty << O.th_log2) + (in >> O.tw_log2));
+        if (px >= A.Wb || py >= A.Hb || py < row0 || py >= row1) return ~0u;     // (rows: this call's window of the film block)
+        const uint32_t e = view * npix + (uint32_t)py * (uint32_t)A.Wb + (uint32_t)px;
+        return (skip && (skip[e] & far_bit)) ? ~0u : e;
     };
+    auto live = [&](uint32_t i) { return entry(i) != ~0u; };
     // pass 1: live pixels of the region
     uint32_t mine = 0;
     for (uint32_t o = 0; o < DSDF_ITEM_REGION; o += 256) mine += live(begin + o + threadIdx.x) ? 1u : 0u;
@@ -294,8 +299,8 @@ __global__ __launch_bounds__(256) void k_build_items(ViewBatch VB, int nv, const
     // pass 2: write them in pixel order
     uint32_t run = base;
     for (uint32_t o = 0; o < DSDF_ITEM_REGION; o += 256) {
-        const uint32_t i = begin + o + threadIdx.x;
-        const bool l = live(i);
+        const uint32_t e = entry(begin + o + threadIdx.x);
+        const bool l = e != ~0u;
         const uint64_t m = __ballot(l);
         __syncthreads();                                     // (wcount is reused)
         if (lid == 0) wcount[w] = (uint32_t)__popcll(m);
@@ -303,7 +308,7 @@ __global__ __launch_bounds__(256) void k_build_items(ViewBatch VB, int nv, const
         uint32_t before = 0, all = 0;
 #pragma unroll
         for (int k = 0; k < 4; ++k) { const uint32_t c = wcount[k]; before += k < w ? c : 0u; all += c; }
-        if (l) items[DSDF_ITEM_HDR + run + before + mask_prefix(m)] = i;
+        if (l) items[DSDF_ITEM_HDR + run + before + mask_prefix(m)] = e;
         run += all;
     }
 }
@@ -317,22 +322,34 @@ void k_render_items(GridView G, dsdf_params P, ViewBatch VB, float *__restrict__
     __shared__ __attribute__((aligned(16))) float wave_lds[DSDF_WAVE_LDS];
     const int lid = lane_id();
     const uint32_t npix = (uint32_t)(VB.v[0].Wb * VB.v[0].Hb);
-    const uint32_t chunks = (uint32_t)VB.v[0].spp >> 6;
-    // work item = one 64-sample chunk of one listed pixel (wave-uniform values are pinned to SGPRs).  Items are handed out in
-    // batches of DSDF_ITEM_BATCH_* consecutive ones: batch b < gridDim.x belongs to worker b, later ones are claimed from the
-    // worker's ticket counter, one batch ahead so that the round trip is off the critical path.
+    const uint32_t chunks = (uint32_t)__builtin_amdgcn_readfirstlane(VB.v[0].spp >> 6);
+    // work item = one 64-sample chunk of one listed pixel (wave-uniform values are pinned to SGPRs)
     const uint32_t n_items = (uint32_t)__builtin_amdgcn_readfirstlane((int)items[0]) * chunks;
-    constexpr uint32_t DSDF_ITEM_BATCH = DIFF ? DSDF_ITEM_BATCH_DIFF : DSDF_ITEM_BATCH_PRIMAL;
-    const uint32_t n_batches = (n_items + DSDF_ITEM_BATCH - 1) / DSDF_ITEM_BATCH;
     WaveStats wst = {0, 0, 0, 0, 0, 0, 0};
-    const uint32_t tc = blockIdx.x % DSDF_TICKETS;                       // this worker's counter
-    uint32_t *ticket = items + 16 + 16 * tc;
-    const uint32_t first = gridDim.x / DSDF_TICKETS;                      // tickets of a counter that are pre-assigned (gridDim.x % 64 == 0)
-    uint32_t batch = blockIdx.x, next = 0;
-    if (batch < n_batches && lid == 0) next = tc + DSDF_TICKETS * (first + atomicAdd(ticket, 1u));
-    while (batch < n_batches) {
-      const uint32_t item_end = min((batch + 1) * DSDF_ITEM_BATCH, n_items);
-      for (uint32_t item = batch * DSDF_ITEM_BATCH; item < item_end; ++item) {
+    // Tickets.  The list is cut into segments of DSDF_ITEM_SEG items (one pixel tile); segment s is the SHARE of XCD s % 8 --
+    // workgroups are dealt round-robin to the 8 XCDs, so blockIdx.x % 8 names the worker's XCD (probed with
+    // tools/probe/hwid_probe.hip; a performance assumption only).  The ~1024 resident waves of an XCD therefore work on ONE
+    // tile at a time and its 4 MiB L2 holds that tile's part of the grid.  Within a share the items go out in order through 8
+    // counters (counter `sub` hands out the share's items sub, sub + 8, ...; the first gridDim.x / 64 of each are
+    // pre-assigned).  A worker whose share is exhausted moves on to the next XCD's.
+    const uint32_t sub = (blockIdx.x >> 3) & 7u, first = gridDim.x / DSDF_TICKETS;
+    uint32_t share = blockIdx.x & 7u, hops = 0;
+    auto item_of = [&](uint32_t sh, uint32_t j) { return ((j / DSDF_ITEM_SEG) * 8u + sh) * DSDF_ITEM_SEG + j % DSDF_ITEM_SEG; };
+    auto draw = [&](uint32_t sh) {            // lane 0: the next item of share sh (one round trip ahead of its use)
+        return item_of(sh, sub + 8u * (first + atomicAdd(items + 16 + 16 * (sh * 8u + sub), 1u)));
+    };
+    uint32_t item = item_of(share, blockIdx.x >> 3), next = 0;
+    if (lid == 0) next = draw(share);
+    while (true) {
+        if (item >= n_items) {                                     // (the items of a share ascend: it is exhausted)
+            if (++hops == 8u) break;
+            share = (share + 1u) & 7u;
+            if (lid == 0) next = draw(share);
+            item = (uint32_t)__builtin_amdgcn_readfirstlane((int)next);
+            if (lid == 0) next = draw(share);
+            continue;
+        }
+      {
         const uint32_t e = (uint32_t)__builtin_amdgcn_readfirstlane((int)items[DSDF_ITEM_HDR + item / chunks]);
         const uint32_t view = e / npix, pix = e - view * npix;
         const ViewArgs &A = VB.v[view];
@@ -381,8 +398,8 @@ void k_render_items(GridView G, dsdf_params P, ViewBatch VB, float *__restrict__
         }
         if (STATS) add_stats(wst, tr, true, need);
       }
-      batch = (uint32_t)__builtin_amdgcn_readfirstlane((int)next);
-      if (batch < n_batches && lid == 0) next = tc + DSDF_TICKETS * (first + atomicAdd(ticket, 1u));
+        item = (uint32_t)__builtin_amdgcn_readfirstlane((int)next);
+        if (lid == 0) next = draw(share);
     }
     if (STATS) flush_stats(stats, wst, blockIdx.x, lid);
 }
@@ -865,7 +882,19 @@ static int run_pass(const PassCtx &c, const Workspace &ws, const dsdf_camera *ca
         const unsigned far_bit = (c.direct && !S.hide_emitters) ? 0u : (DIFF ? 8u : 4u);
         if (hipMemsetAsync(ws.items, 0, DSDF_ITEM_HDR * sizeof(uint32_t), st) != hipSuccess)
             return fail(DSDF_ERR_LAUNCH, "hipMemsetAsync(work list) failed");
-        hipLaunchKernelGGL(k_build_items, dim3((unsigned)((nv * npix + DSDF_ITEM_REGION - 1) / DSDF_ITEM_REGION)), dim3(256), 0, st, VB, nv, skip, far_bit, c.row0, c.row1, ws.items);
+        // tile-major order: a tile = DSDF_ITEM_SEG chunks of 64 samples (16 x 16 pixels at 256 spp, 32 x 32 at 64 spp)
+        ItemOrder O;
+        {
+            unsigned tile_px = DSDF_ITEM_SEG / (unsigned)(c.spp / 64);
+            if (tile_px < 1) tile_px = 1;
+            int lg = 0;
+            while ((2u << lg) <= tile_px) ++lg;
+            O.tw_log2 = (lg + 1) / 2; O.th_log2 = lg / 2;
+            O.tiles_x = (unsigned)((c.Wb + (1u << O.tw_log2) - 1) >> O.tw_log2);
+            const unsigned tiles_y = (unsigned)((c.Hb + (1u << O.th_log2) - 1) >> O.th_log2);
+            O.per_view = (O.tiles_x * tiles_y) << (O.tw_log2 + O.th_log2);
+        }
+        hipLaunchKernelGGL(k_build_items, dim3((unsigned)(((size_t)nv * O.per_view + DSDF_ITEM_REGION - 1) / DSDF_ITEM_REGION)), dim3(256), 0, st, VB, nv, skip, far_bit, c.row0, c.row1, O, ws.items);
         if ((rc = check_launch("k_build_items"))) return rc;
         TailQueue tq;
         memset(&tq, 0, sizeof(tq));

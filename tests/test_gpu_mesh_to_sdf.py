@@ -91,6 +91,6 @@ def test_create_sdf_sphere_is_analytic_and_renders(dsdf):
     assert err.max() < 1.5 / res
     sdf = dsdf.SdfGrid(grid)
     sen = dsdf.get_regular_cameras(1, resx=64, resy=64)[0]
-    img = dsdf.render_forward(sdf, sen, 16)[0].cpu().numpy()
+    img = dsdf.render_forward(sdf, [sen], 16, seeds=[0])[0].cpu().numpy()
     cov = (img > 0.5).mean()
     assert 0.02 < cov < 0.6
