@@ -69,6 +69,77 @@ __device__ __forceinline__ void film_flush_wave(float *__restrict__ block, const
     }
 }
 
+// Film splat of a wave whose samples cover a small PIXEL TILE (the general pass at spp < 64: 4 x 4 pixels x 4 spp,
+// 8 x 8 x 1, ...): the 4 x 4 footprints of all its samples fall into the tile grown by two pixels on every side.  The
+// wave adds them into a wave-private LDS window (ds_add_f32) and flushes every touched window entry with ONE global atomic
+// -- 128 instead of 2 048 at 4 spp (measured, 12 views x 512^2: the 4-spp pass was bound by its 120 M film atomics).
+#define DSDF_WIN_MAX (12 * 12)
+typedef __attribute__((address_space(3))) float lds_float;
+// ds_add_f32 (a generic pointer would make it a flat atomic)
+__device__ __forceinline__ void lds_add(float *p, float v) { __builtin_amdgcn_ds_faddf((lds_float *)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP, false); }
+struct TileWindow {
+    float *win;          // wave-private, (tw + 4) x (th + 4) x NCH floats
+    int x0, y0, w, h;    // window origin (film-block pixels, may be negative) and size
+};
+
+template <int NCH>
+__device__ __forceinline__ void tile_window_clear(const TileWindow &T, int lid) {
+    for (int i = lid; i < T.w * T.h * NCH; i += 64) T.win[i] = 0.f;
+    wave_lds_sync();
+}
+
+// one sample: vals[NCH - 1] value channels + the weight channel (same statements as splat_lane / splat_lane_rgb)
+template <int NCH>
+__device__ __forceinline__ void tile_window_splat(const TileWindow &T, float *__restrict__ block, int Wb, int Hb, float u, float v,
+                                                  const float *vals) {
+    const float pfx = u + (DSDF_BORDER - 0.5f), pfy = v + (DSDF_BORDER - 0.5f);
+    const int x0 = (int)ceilf(pfx - DSDF_FILTER_RADIUS), y0 = (int)ceilf(pfy - DSDF_FILTER_RADIUS);
+    float wx[4], wy[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        wx[i] = gauss_f((float)(x0 + i) - pfx);
+        wy[i] = gauss_f((float)(y0 + i) - pfy);
+    }
+    const bool inside = x0 >= T.x0 && x0 + 4 <= T.x0 + T.w && y0 >= T.y0 && y0 + 4 <= T.y0 + T.h;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int qy = y0 + j;
+        if (qy < 0 || qy >= Hb) continue;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int qx = x0 + i;
+            if (qx < 0 || qx >= Wb) continue;
+            const float f = wx[i] * wy[j];
+            if (f == 0.f) continue;
+            if (inside) {
+                float *dst = T.win + NCH * ((qy - T.y0) * T.w + (qx - T.x0));
+#pragma unroll
+                for (int c = 0; c < NCH - 1; ++c)
+                    if (vals[c] != 0.f) lds_add(dst + c, f * vals[c]);
+                lds_add(dst + (NCH - 1), f);
+            } else {        // (cannot happen for a sample of the tile; it would still be counted)
+                float *dst = block + NCH * ((size_t)qy * Wb + qx);
+#pragma unroll
+                for (int c = 0; c < NCH - 1; ++c)
+                    if (vals[c] != 0.f) atomicAdd(dst + c, f * vals[c]);
+                atomicAdd(dst + (NCH - 1), f);
+            }
+        }
+    }
+}
+
+template <int NCH>
+__device__ __forceinline__ void tile_window_flush(const TileWindow &T, float *__restrict__ block, int Wb, int Hb, int lid) {
+    wave_lds_sync();
+    for (int i = lid; i < T.w * T.h * NCH; i += 64) {
+        const float s = T.win[i];
+        if (s == 0.f) continue;
+        const int cell = i / NCH, ch = i - cell * NCH;
+        const int qy = T.y0 + cell / T.w, qx = T.x0 + cell - (cell / T.w) * T.w;
+        if (qx >= 0 && qx < Wb && qy >= 0 && qy < Hb) atomicAdd(block + NCH * ((size_t)qy * Wb + qx) + ch, s);
+    }
+}
+
 // HDRFilm.develop: crop the border, value / (weight == 0 ? 1 : weight), R=G=B.
 __global__ void k_develop(const float *__restrict__ blocks, int W, int H, float *__restrict__ images) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;

@@ -439,6 +439,15 @@ __global__ __launch_bounds__(DSDF_BLOCK) void k_render_pass(GridView G, dsdf_par
     bool valid;
     const uint32_t lane = thread_lane(A, M, blockIdx.x * DSDF_BLOCK + threadIdx.x, valid);
     const int lid = lane_id();
+    // pixel-tile order: the wave's film contributions go through a wave-private LDS window (dsdf_film.h)
+    __shared__ float win_lds[DSDF_BLOCK / 64][DSDF_WIN_MAX * NCH];
+    TileWindow TW;
+    TW.win = win_lds[threadIdx.x >> 6];
+    if (M.tile_w) {
+        const uint32_t wave = (blockIdx.x * DSDF_BLOCK + threadIdx.x) >> 6, tiles_x = ((uint32_t)A.Wb + M.tile_w - 1) / (uint32_t)M.tile_w;
+        const uint32_t ty = wave / tiles_x, tx = wave - ty * tiles_x;
+        TW.x0 = (int)tx * M.tile_w - 2; TW.y0 = (int)ty * M.tile_h - 2; TW.w = M.tile_w + 4; TW.h = M.tile_h + 4;
+    }
     TraceOut tr, trs;
     clear_trace(tr);
     // empty-space proof for this sample's pixel.  skip_trace: a miss with no warp is known; far: nothing this sample does
@@ -456,6 +465,8 @@ __global__ __launch_bounds__(DSDF_BLOCK) void k_render_pass(GridView G, dsdf_par
     }
     bool lit = false;
     Lane L;
+    const bool windowed = M.tile_w && __ballot(!far) != 0;       // (a wave of far pixels touches nothing)
+    if (windowed) tile_window_clear<NCH>(TW, lid);
     if (!far) {
         L = lane_setup(A, P, lane);
         if (!skip_trace) {
@@ -466,12 +477,19 @@ __global__ __launch_bounds__(DSDF_BLOCK) void k_render_pass(GridView G, dsdf_par
         if (DIRECT) {
             float rgb[3];
             lit = direct_value(G, P, A, S, L, lane, tr.its_t, DIFF, trs, rgb);
-            if (valid) splat_lane_rgb(block, A.Wb, A.Hb, rp.u, rp.v, rgb, AtomicAdd());
+            if (valid) {
+                if (windowed) tile_window_splat<NCH>(TW, block, A.Wb, A.Hb, rp.u, rp.v, rgb);
+                else splat_lane_rgb(block, A.Wb, A.Hb, rp.u, rp.v, rgb, AtomicAdd());
+            }
         } else {
             const float val = shade_value(G, A, L, tr.its_t);
-            if (valid) splat_lane(block, A.Wb, A.Hb, rp.u, rp.v, val, AtomicAdd());
+            if (valid) {
+                if (windowed) tile_window_splat<NCH>(TW, block, A.Wb, A.Hb, rp.u, rp.v, &val);
+                else splat_lane(block, A.Wb, A.Hb, rp.u, rp.v, val, AtomicAdd());
+            }
         }
     }
+    if (windowed) tile_window_flush<NCH>(TW, block, A.Wb, A.Hb, lid);
     bool need = false;
     if (DIFF) {
         const bool hit = tr.its_t < INFINITY;
