@@ -2,8 +2,9 @@
 
 The reference loads `scenes/<scene>/<scene>.xml` (meshes, BSDFs, emitters; a separate download
 that is not part of the repository, README.md:59-68) and renders the reference images from the
-mesh.  Here a scene is just a target SDF volume: `scenes/<scene>/<scene>.vol` if present, else
-a procedural shape (`sphere`, `torus`, `blobs`, or -- for any other name such as `dragon` -- a
+mesh.  Here a scene is just a target SDF volume: `scenes/<scene>/<scene>.vol` if present, a
+watertight mesh `scenes/<scene>/<scene>.obj` / `.ply` inside [-0.5, 0.5]^3 converted with
+`mesh_to_sdf.create_sdf` (python/mesh_to_sdf.py:9-57), else a procedural shape (`sphere`, `torus`, `blobs`, or -- for any other name such as `dragon` -- a
 union of primitives seeded by the scene name), rendered with the same integrator."""
 import hashlib
 import os
@@ -42,6 +43,12 @@ def load_target_sdf(scene_name, res=128, device='cuda'):
     path = os.path.join(SCENE_DIR, scene_name, f'{scene_name}.vol')
     if os.path.isfile(path):
         return read_vol(path, device)
+    for ext in ('.obj', '.ply'):
+        mesh = os.path.join(SCENE_DIR, scene_name, scene_name + ext)
+        if os.path.isfile(mesh):
+            import mesh_to_sdf
+            print(f"[scenes] target SDF of '{scene_name}' from {mesh} at {res}^3")
+            return mesh_to_sdf.create_sdf(mesh, res, device=device)
     z, y, x = _axes(res, device)
     if scene_name == 'sphere':
         return torch.sqrt((x - 0.5) ** 2 + (y - 0.5) ** 2 + (z - 0.5) ** 2) - 0.36

@@ -94,3 +94,18 @@ def test_create_sdf_sphere_is_analytic_and_renders(dsdf):
     img = dsdf.render_forward(sdf, [sen], 16, seeds=[0])[0].cpu().numpy()
     cov = (img > 0.5).mean()
     assert 0.02 < cov < 0.6
+
+
+def test_scene_target_from_mesh(dsdf, tmp_path, monkeypatch):
+    """A scene directory holding a mesh yields its SDF as the optimisation target (scenes.load_target_sdf)."""
+    import scenes
+    v, f = M.icosphere(0.3, 2)
+    d = tmp_path / 'ball'
+    d.mkdir()
+    M.write_obj(str(d / 'ball.obj'), v, f)
+    monkeypatch.setattr(scenes, 'SCENE_DIR', str(tmp_path))
+    sdf = scenes.load_target_sdf('ball', res=32)
+    assert sdf.shape == (32, 32, 32) and sdf.is_cuda
+    x = M.voxel_centres(32)
+    ref = (np.linalg.norm(x, axis=1) - 0.3).reshape(32, 32, 32)
+    assert np.abs(sdf.cpu().numpy() - ref).max() < 1.5 / 32
