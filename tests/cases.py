@@ -13,6 +13,10 @@ def make_case(name):
         'blob32': (lambda: O.blob_grid(32, n=6, seed=1), 3, 1, 24, 24, 8, 2),
         'blob32_spp64': (lambda: O.blob_grid(32, n=6, seed=1), 3, 2, 12, 12, 64, 3),
         'blob48_rect': (lambda: O.blob_grid(48, n=10, seed=3), 12, 5, 32, 20, 4, 4),
+        # three 64-sample chunks per pixel (not a power of two: work-list tiles, chunk -> unit arithmetic)
+        'blob32_spp192': (lambda: O.blob_grid(32, n=6, seed=1), 3, 2, 6, 6, 192, 5),
+        # 2 spp: 8 x 4 pixel-tile waves of the general pass, film window in LDS, ragged tiles at the right / bottom edge
+        'blob32_spp2': (lambda: O.blob_grid(32, n=6, seed=1), 3, 2, 21, 13, 2, 6),
     }[name]
     gridfn, ncam, icam, W, H, spp, seed = cfg
     gen = torch.Generator().manual_seed(seed)

@@ -117,7 +117,7 @@ def test_surface_interaction_gpu(dsdf):
     assert rel_l2(data2.grad.numpy(), gsum.numpy()) < 1e-4
 
 
-@pytest.mark.parametrize('name', ['sphere16', 'blob32', 'blob32_spp64', 'blob48_rect'])
+@pytest.mark.parametrize('name', ['sphere16', 'blob32', 'blob32_spp64', 'blob48_rect', 'blob32_spp192', 'blob32_spp2'])
 @pytest.mark.parametrize('integ', [O.SILHOUETTE, O.SIMPLE_SHADING])
 def test_render_forward_gpu(dsdf, name, integ):
     case = make_case(name)
@@ -135,7 +135,7 @@ def test_render_forward_gpu(dsdf, name, integ):
     assert abs(st['steps'] - aux['steps']) <= 0.01 * aux['steps']
 
 
-@pytest.mark.parametrize('name', ['sphere16', 'blob32', 'blob32_spp64', 'blob48_rect'])
+@pytest.mark.parametrize('name', ['sphere16', 'blob32', 'blob32_spp64', 'blob48_rect', 'blob32_spp192', 'blob32_spp2'])
 @pytest.mark.parametrize('integ', [O.SILHOUETTE, O.SIMPLE_SHADING])
 @pytest.mark.parametrize('reparam', [True, False])
 def test_render_backward_gpu(dsdf, name, integ, reparam):
