@@ -145,13 +145,21 @@ def main():
     import dsdf
     from dsdf import parallel
     dsdf.load()
-    torch.cuda.set_device(local_rank)
-    dev = torch.device('cuda', local_rank)
+    # (dry run of the multi-process path on a box with fewer GPUs than ranks: BENCH_SHARE_GPU=1 maps the ranks onto the
+    # GPUs that exist, BENCH_DIST_BACKEND=gloo replaces RCCL, which refuses two ranks on one device -- never a measurement)
+    share = os.environ.get('BENCH_SHARE_GPU') == '1'
+    dev_index = local_rank % torch.cuda.device_count() if share else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device('cuda', dev_index)
     dist = None
     # (BENCH_FORCE_DIST=1 exercises the RCCL path with a single rank, e.g. under `torchrun --nproc-per-node 1`)
     if world > 1 or os.environ.get('BENCH_FORCE_DIST') == '1':
         import torch.distributed as dist
-        dist.init_process_group('nccl', device_id=dev)
+        backend = os.environ.get('BENCH_DIST_BACKEND', 'nccl')
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     data = synth_grid(args.res, dev)
     grid = dsdf.SdfGrid(data)
@@ -239,6 +247,8 @@ def main():
 
     prim_ms, grad_ms = [], []
     elapsed = timed_run(make_step(args.spp_primal, args.spp_grad, prim_ms, grad_ms), args.warmup, args.steps)
+    # dL/dsdf of the last timed step (summed over ranks): must agree at every N up to the order of the float atomics
+    grad_l1 = float(grad.double().abs().sum())
     if args.overlap and nv and not tiled:
         # the roofline needs the dominant kernel's OWN launch time: in the timed region above it shares the chip with the
         # gradient sweep of the other stream, so a few launches are timed alone (HIP events, same process, same inputs)
@@ -317,7 +327,7 @@ def main():
                                         f"(reference semantics, configs.py:16,19)",
                             "views_total": args.views if strong else args.views * world, "views_this_rank": nv,
                             "partition": ("pixel-row windows of views: %d units per rank" % len(parallel.work_partition(args.views, args.img + 4, world)[0])) if tiled else "whole views",
-                            "spp_primal": args.spp_primal, "spp_grad": args.spp_grad,
+                            "spp_primal": args.spp_primal, "spp_grad": args.spp_grad, "grad_l1_last_step": grad_l1,
                             "schedule": "primal pass and gradient sweep on two HIP streams (dsdf.render_step)" if args.overlap and not tiled
                             else "sequential launches"}, **out_cfg),
             "roofline": roof,
