@@ -471,7 +471,13 @@ __global__ __launch_bounds__(DSDF_BLOCK) void k_render_pass(GridView G, dsdf_par
         L = lane_setup(A, P, lane);
         if (!skip_trace) {
             if (DIFF) trace_diff(G, P, L.ray.o, L.ray.d, L.ray.maxt, tr);
-            else trace_plain(G, P, L.ray.o, L.ray.d, L.ray.maxt, tr);
+            else if (!DIRECT) {
+                // the pass ends with its longest rays, a few lanes sliding along a surface in sub-voxel steps: they keep the
+                // 64 taps of their cell in registers and gather only on entering another cell (bit-identical; 12 views x
+                // 512^2: 3.19 -> 2.58 ms at 4 spp, 10.1 -> 8.3 ms at 32 spp)
+                ReuseFetch F;
+                trace_plain(G, P, L.ray.o, L.ray.d, L.ray.maxt, tr, F);
+            } else trace_plain(G, P, L.ray.o, L.ray.d, L.ray.maxt, tr);
         }
         const Reproj rp = reproject(A.cam, P, L.ray.o + L.ray.d, A.W, A.H);
         if (DIRECT) {
