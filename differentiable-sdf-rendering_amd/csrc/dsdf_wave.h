@@ -154,10 +154,12 @@ struct WaveCellCache {
         if (__ballot(active && c.base != prev_base) != 0) {
             // 1. group the lanes by cell: leader = first unassigned active lane; every lane holding the
             //    same cell key takes the slot (v_readlane + v_cmp + v_cndmask + scalar mask update per cell)
+            //    (the loop is a serial scalar chain in front of every fill, so it carries no slot-limit test: groups beyond
+            //    the 16th are dropped afterwards)
             slot = -1;
             int n = 0;
             uint64_t todo = __ballot(active);
-            while (todo != 0 && n < DSDF_CACHE_SLOTS) {
+            while (todo != 0) {
                 const int leader = __builtin_ctzll(todo);
                 const uint32_t k = (uint32_t)__builtin_amdgcn_readlane((int)c.base, leader);
                 const bool same = c.base == k;
@@ -165,22 +167,40 @@ struct WaveCellCache {
                 todo &= ~__ballot(same);
                 ++n;
             }
+            slot = slot < DSDF_CACHE_SLOTS ? slot : -1;
+            n = n < DSDF_CACHE_SLOTS ? n : DSDF_CACHE_SLOTS;
             if (slot >= 0) slot_base[slot] = c.base;        // all lanes of a slot write the same value
             wave_lds_sync();
             // 2. load every distinct cell once: lane (grp, r) fetches row r of slot 4*round + grp; the (<= 4) rounds are
             //    issued back to back and land in LDS after ONE wait (two rounds per batch: 8 VGPRs of staging)
-            int lf = lid;
-            asm volatile("" : "+v"(lf));                   // keep the lane-constant addresses below out of registers across the march
+            // (the lane id is recomputed here -- two v_mbcnt -- so that neither it nor the lane-constant offsets below occupy
+            // registers across the march: under the 64-VGPR budget of the primal kernel they were spilled and the reload
+            // from scratch sat in front of every fill)
+            int lf;
+            asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lf));
             const int grp = lf >> 4, r = lf & 15;
-            const uint32_t rowoff = (uint32_t)(r >> 2) * (4u * (uint32_t)G.sxy) + (uint32_t)(r & 3) * (4u * (uint32_t)G.sx);
+            const uint32_t rowoff = 4u * (__umul24((uint32_t)(r >> 2), (uint32_t)G.sxy) + __umul24((uint32_t)(r & 3), (uint32_t)G.sx));
             typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
-            for (int s0 = 0; s0 < n; s0 += 8) {
+            const char *gp = reinterpret_cast<const char *>(G.p);
+            float *dst = taps + __umul24((uint32_t)grp, DSDF_SLOT_STRIDE) + r * 4;
+            {   // slots 0..7 (87 % of the fills need no more): both loads issued back to back, ONE wait
+                const bool ha = grp < n, hb = grp + 4 < n;
+                uint32_t ba = 0u, bb = 0u;
+                if (ha) ba = slot_base[grp];
+                if (hb) bb = slot_base[grp + 4];
+                f4u ta, tb;
+                if (ha) ta = *reinterpret_cast<const f4u *>(gp + (ba + rowoff));
+                if (hb) tb = *reinterpret_cast<const f4u *>(gp + (bb + rowoff));
+                if (ha) *reinterpret_cast<float4 *>(dst) = make_float4(ta.x, ta.y, ta.z, ta.w);
+                if (hb) *reinterpret_cast<float4 *>(dst + 4 * DSDF_SLOT_STRIDE) = make_float4(tb.x, tb.y, tb.z, tb.w);
+            }
+            for (int s0 = 8; s0 < n; s0 += 8) {
                 const int sa = s0 + grp, sb = s0 + 4 + grp;
                 f4u ta, tb;
-                if (sa < n) ta = *reinterpret_cast<const f4u *>(reinterpret_cast<const char *>(G.p) + (slot_base[sa] + rowoff));
-                if (sb < n) tb = *reinterpret_cast<const f4u *>(reinterpret_cast<const char *>(G.p) + (slot_base[sb] + rowoff));
-                if (sa < n) *reinterpret_cast<float4 *>(taps + sa * DSDF_SLOT_STRIDE + r * 4) = make_float4(ta.x, ta.y, ta.z, ta.w);
-                if (sb < n) *reinterpret_cast<float4 *>(taps + sb * DSDF_SLOT_STRIDE + r * 4) = make_float4(tb.x, tb.y, tb.z, tb.w);
+                if (sa < n) ta = *reinterpret_cast<const f4u *>(gp + (slot_base[sa] + rowoff));
+                if (sb < n) tb = *reinterpret_cast<const f4u *>(gp + (slot_base[sb] + rowoff));
+                if (sa < n) *reinterpret_cast<float4 *>(dst + s0 * DSDF_SLOT_STRIDE) = make_float4(ta.x, ta.y, ta.z, ta.w);
+                if (sb < n) *reinterpret_cast<float4 *>(dst + (s0 + 4) * DSDF_SLOT_STRIDE) = make_float4(tb.x, tb.y, tb.z, tb.w);
             }
             wave_lds_sync();
             prev_slot = slot;
@@ -189,7 +209,7 @@ struct WaveCellCache {
         // 3. every lane evaluates from its slot (lanes beyond 16 distinct cells read global memory)
         if (active) {
             if (slot >= 0) {
-                LdsRows R; R.slot = taps + slot * DSDF_SLOT_STRIDE;
+                LdsRows R; R.slot = taps + __umul24((uint32_t)slot, DSDF_SLOT_STRIDE);
                 eval_cubic_rows<ORDER>(G, c, R, v, g, H);
             } else {
                 eval_cubic_rows<ORDER>(G, c, global_rows(G, c), v, g, H);
