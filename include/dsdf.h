@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define DSDF_VERSION 200
+#define DSDF_VERSION 201   /* 201: + dsdf_mesh_raycast */
 
 enum dsdf_status {
     DSDF_OK = 0,
