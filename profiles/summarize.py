@@ -41,6 +41,14 @@ def main():
         for k, v in d.items():
             s = sorted(v)
             f.write(f"{k},{len(v)},{s[len(s) // 2]:.3f},{s[0]:.3f},{s[-1]:.3f}\n")
+            # the persistent-worker kernels have ONE grid for every workload (bench launches of 12 views x 256 spp and the
+            # single-view 64-spp target renders of the set-up share a row above): split the dispatches where consecutive
+            # sorted durations jump by more than 3x, so that each workload has its own line
+            cuts = [i for i in range(1, len(s)) if s[i] > 3.0 * s[i - 1]]
+            if cuts:
+                for a, b in zip([0] + cuts, cuts + [len(s)]):
+                    c = s[a:b]
+                    f.write(f"{k} [durations {c[0]:.2f}-{c[-1]:.2f} ms],{len(c)},{c[len(c) // 2]:.3f},{c[0]:.3f},{c[-1]:.3f}\n")
     if len(sys.argv) >= 6:
         out = {}
         for col, path in (('FETCH_SIZE', sys.argv[4]), ('WRITE_SIZE', sys.argv[5])):
