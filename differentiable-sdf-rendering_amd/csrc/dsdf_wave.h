@@ -148,7 +148,11 @@ struct WaveCellCache {
 
     template <int ORDER>
     __device__ __forceinline__ void eval(const GridView &G, V3 x, bool active, float &v, V3 &g, float H[6]) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        const CubicCell c = cubic_cell(G, x);          // (the float clamp of cubic_cell takes whatever a finished lane holds)
+#else
         const CubicCell c = cubic_cell(G, active ? x : mk(0.f, 0.f, 0.f));
+#endif
         uint32_t *slot_base = reinterpret_cast<uint32_t *>(taps + DSDF_CACHE_SLOTS * DSDF_SLOT_STRIDE);
         int slot = prev_slot;
         if (__ballot(active && c.base != prev_base) != 0) {
