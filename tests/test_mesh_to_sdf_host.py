@@ -80,3 +80,27 @@ def test_oracle_create_sdf_box_is_analytic(built):
     assert np.abs(coarse - ref)[near & face].max() > 0.005                # occupancy alone: half a voxel off
     # edges / corners: the closing redistance re-initialises from axis-aligned crossings, first order (the algorithm's own error)
     assert np.abs(grid - ref).max() < 2.0 / res
+
+
+def test_ply_big_endian_and_extra_properties(tmp_path, built):
+    """binary_big_endian, per-vertex normals / colours before and after x y z, uint8 list counts with uint32 indices, quads."""
+    import struct
+    import mesh_to_sdf
+    v = np.asarray([[0, 0, 0], [1, 0, 0], [1, 1, 0], [0, 1, 0], [0, 0, 1]], np.float32)
+    faces = [[0, 1, 2, 3], [0, 1, 4]]
+    with open(tmp_path / 'be.ply', 'wb') as fh:
+        fh.write(b'ply\nformat binary_big_endian 1.0\ncomment test\nelement vertex 5\nproperty uchar red\nproperty float x\n'
+                 b'property float y\nproperty float z\nproperty double quality\nelement face 2\n'
+                 b'property list uchar uint vertex_indices\nend_header\n')
+        for p in v:
+            fh.write(struct.pack('>Bfffd', 7, p[0], p[1], p[2], 0.25))
+        for f in faces:
+            fh.write(struct.pack('>B', len(f)) + struct.pack('>%dI' % len(f), *f))
+    tri = mesh_to_sdf.load_mesh(str(tmp_path / 'be.ply'))
+    assert tri.shape == (3, 3, 3)
+    np.testing.assert_array_equal(tri[0], v[[0, 1, 2]])
+    np.testing.assert_array_equal(tri[1], v[[0, 2, 3]])
+    np.testing.assert_array_equal(tri[2], v[[0, 1, 4]])
+    (tmp_path / 'bad.ply').write_bytes(b'plx\n')
+    with pytest.raises(ValueError):
+        mesh_to_sdf.load_mesh(str(tmp_path / 'bad.ply'))
