@@ -41,3 +41,21 @@ for name in ('sphere16', 'blob32'):
            'img_hidden': oracle_direct(case, ex, reparam=False, hide_emitters=True).numpy().astype(np.float32)}
     np.savez_compressed(os.path.join(HERE, f'{name}_direct.npz'), **out)
     print(name + '_direct', {k: v.shape for k, v in out.items()})
+
+# mesh -> SDF (oracle/mesh_oracle.py + the C redistancing oracle): a box and an icosphere at 16^3, per-ray casts of the box
+import c_oracle
+import mesh_oracle as M
+
+lib = c_oracle.load()
+out = {}
+for tag, (v, f) in (('box', M.box(half=(0.3, 0.2, 0.25))), ('ico', M.icosphere(0.3, 1, centre=(0.02, -0.01, 0.03)))):
+    out[f'{tag}_tri'] = v[f]
+    out[f'{tag}_sdf'] = M.create_sdf(v[f], 16, lambda p: c_oracle.redistance(lib, p)).astype(np.float32)
+    out[f'{tag}_sdf_coarse'] = M.create_sdf(v[f], 16, lambda p: c_oracle.redistance(lib, p), refine_surface=False).astype(np.float32)
+rng = np.random.default_rng(5)
+o = rng.uniform(-0.5, 0.5, (512, 3)).astype(np.float32)
+d = rng.normal(size=(512, 3)); d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+t, back, margin = M.raycast(out['box_tri'], o, d)
+out.update(ray_o=o, ray_d=d, ray_t=t, ray_back=back, ray_margin=margin)
+np.savez_compressed(os.path.join(HERE, 'mesh16.npz'), **out)
+print('mesh16', {k: v.shape for k, v in out.items()})

@@ -104,3 +104,16 @@ def test_ply_big_endian_and_extra_properties(tmp_path, built):
     (tmp_path / 'bad.ply').write_bytes(b'plx\n')
     with pytest.raises(ValueError):
         mesh_to_sdf.load_mesh(str(tmp_path / 'bad.ply'))
+
+
+def test_oracle_reproduces_mesh_golden(built):
+    """tests/golden/mesh16.npz (make_golden.py) pins the mesh oracle against silent changes."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'mesh16.npz'))
+    lib = c_oracle.load()
+    for tag in ('box', 'ico'):
+        sdf = M.create_sdf(g[f'{tag}_tri'], 16, lambda p: c_oracle.redistance(lib, p))
+        np.testing.assert_allclose(sdf, g[f'{tag}_sdf'], atol=1e-6)
+    t, back, _ = M.raycast(g['box_tri'], g['ray_o'], g['ray_d'])
+    np.testing.assert_allclose(t, g['ray_t'], rtol=1e-12)
+    np.testing.assert_array_equal(back, g['ray_back'])
