@@ -23,9 +23,19 @@ __device__ __forceinline__ void film_accum_wave(int px, int py, float u, float v
     for (int j = 0; j < 5; ++j)
 #pragma unroll
         for (int i = 0; i < 5; ++i) f[j * 5 + i] = fx[i] * fy[j];
+    // weight channel first; a wave whose 64 samples all carry the value 1 (silhouette integrator, pixel inside the shape: 79 %
+    // of the traced chunks of the bench scene) adds the SAME sums to its value channel -- f * 1.f == f, same order -- instead
+    // of transposing them a second time
+    const bool all_one = NCH == 2 && __ballot(vals[0] != 1.f) == 0;
+    float wsum[2] = {0.f, 0.f};
 #pragma unroll
-    for (int ch = 0; ch < NCH; ++ch) {
+    for (int cc = 0; cc < NCH; ++cc) {
+        const int ch = cc == 0 ? NCH - 1 : cc - 1;
         const float val = ch < NCH - 1 ? vals[ch] : 1.f;
+        if (ch < NCH - 1 && all_one) {
+            if (lid < DSDF_TROWS) { acc[ch][0] += wsum[0]; acc[ch][1] += wsum[1]; }
+            continue;
+        }
         if (ch < NCH - 1 && __ballot(val != 0.f) == 0) continue;     // pixels nobody hits skip the value channel
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
@@ -46,8 +56,10 @@ __device__ __forceinline__ void film_accum_wave(int px, int py, float u, float v
                     a2.x += b2.x; a2.y += b2.y; a2.z += b2.z; a2.w += b2.w;
                     a3.x += b3.x; a3.y += b3.y; a3.z += b3.z; a3.w += b3.w;
                 }
-                acc[ch][c] += ((a0.x + a0.y) + (a0.z + a0.w)) + ((a1.x + a1.y) + (a1.z + a1.w)) +
-                              (((a2.x + a2.y) + (a2.z + a2.w)) + ((a3.x + a3.y) + (a3.z + a3.w)));
+                const float sum = ((a0.x + a0.y) + (a0.z + a0.w)) + ((a1.x + a1.y) + (a1.z + a1.w)) +
+                                  (((a2.x + a2.y) + (a2.z + a2.w)) + ((a3.x + a3.y) + (a3.z + a3.w)));
+                acc[ch][c] += sum;
+                if (ch == NCH - 1) wsum[c] = sum;
             }
             wave_lds_sync();
         }

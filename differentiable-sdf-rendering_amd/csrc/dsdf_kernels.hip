@@ -6,30 +6,35 @@
 //   dsdf_redistance.h          Eikonal redistancing kernels + entry points
 //   this file                  render pass, backward / forward-tangent sweeps, workspace, C-ABI
 //
-// Kernel inventory (DESIGN.md has the roofline for each):
-//   k_pad_grid          clamp-to-edge padded copy of sdf.data (Texture3f.set_tensor)
-//   k_eval_cubic        A1  tricubic B-spline value/gradient/Hessian at points
-//   k_trace             A2/A4/A5 per-ray sphere tracing (standalone entry)
-//   k_coarse_min/dilate conservative min-grids of the SDF (8^3- and 4^3-voxel blocks, dilated)
-//   k_pixel_skip        exact per-pixel empty-space proof against that grid
-//   k_skip_dilate       pixels whose samples cannot reach any output (not generated at all)
-//   k_render_pass<DIFF,CACHE> ray-gen + trace + shade + Gaussian splat; DIFF adds the
-//                       warp-t accumulators and emits a compacted backward queue;
-//                       CACHE = wave-cooperative LDS cache of the B-spline cells
-//   k_develop           HDRFilm.develop
-//   k_develop_adjoint   adjoint of develop -> film-block adjoint
-//   k_backward          per queued sample: film-adjoint gather, warp/shading
-//                       adjoint, 64-tap scatter into dL/dsdf through LDS bricks
-//   k_redist_init/iter/finish  Eikonal redistancing (fastsweep replacement)
+// Kernel inventory (DESIGN.md section 4 has the roofline for each):
+//   k_pad_grid                 clamp-to-edge padded copy of sdf.data (Texture3f.set_tensor)
+//   k_eval_cubic, k_trace, k_warp_eval, k_surface_interaction   the per-ray boundary (A1, A2/A4/A5, A9, A6)
+//   k_coarse_min/dilate        conservative min-grids of the SDF (8^3- and 4^3-voxel blocks, dilated)        [dsdf_skip.h]
+//   k_pixel_skip, k_skip_dilate   exact per-pixel empty-space proof; pixels whose samples cannot reach any output
+//   k_build_items              ordered, tile-major compaction of the pixels that must be sampled into a work list
+//   k_render_items<DIFF,DIRECT,STATS>   spp % 64 == 0: PERSISTENT single-wave workers over the work list, one 64-sample chunk
+//                              of a pixel per ticket, one tile per XCD at a time; DIFF = 0 value-only march through the wave
+//                              cell cache, DIFF = 1 Hessian march with the warp accumulators + backward-queue compaction;
+//                              both hand the last few rays of a wave to a tail queue                         [dsdf_tail.h]
+//   k_tail_trace_plain/diff    persistent waves that resume the handed-off rays (on helper streams, beside the next
+//                              view group's render kernel)
+//   k_render_pass<DIFF,DIRECT> any spp: one lane per sample; for spp < 64 a wave = a pixel tile with an LDS film window
+//   k_develop*, k_develop_adjoint*, k_develop_tangent   HDRFilm.develop, its adjoint and tangent              [dsdf_film.h]
+//   k_backward<DIRECT>         per queued sample: film-adjoint gather, warp / shading adjoint, transposed 64-tap LDS
+//                              scatter into dL/dsdf                                                           [dsdf_wave.h]
+//   k_forward_tangent          forward mode: the same queue, tangent film
+//   k_redist_*, k_mesh_raycast redistancing, mesh ray caster                              [dsdf_redistance.h, dsdf_mesh.h]
 //
 // wave = 64 lanes; one lane = one film sample, consecutive lanes = consecutive
 // samples of the same pixel (reference lane order, reparam.py:140-155), so for
 // spp % 64 == 0 every wave sits in one pixel: its 64 rays walk almost the same
-// voxels (L1/L2-coherent 16-byte row loads) and its film contribution collapses
-// to one 5x5x2 window, reduced across the wave before touching memory.
+// voxels and its film contribution collapses to one 5x5x2 window, reduced across the wave before touching memory.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
+#include <mutex>
+#include <vector>
 #include "dsdf_lane.h"
 
 using namespace dsdf;
@@ -224,7 +229,7 @@ __device__ __forceinline__ void add_stats(WaveStats &ws, const TraceOut &tr, boo
 __device__ __forceinline__ void flush_stats(unsigned long long *stats, const WaveStats &ws, uint32_t spread, int lid) {
     if (lid != 0) return;
     // 64 interleaved copies of the counters (summed by the caller): spreads the atomics over 64 addresses
-    unsigned long long *st = stats + (size_t)(spread & 63u) * 8;
+    unsigned long long *st = stats + (size_t)(spread & 63u) * DSDF_STAT_SLOTS;
     atomicAdd(st + 0, (unsigned long long)ws.lanes);
     atomicAdd(st + 1, (unsigned long long)ws.bbox);
     atomicAdd(st + 2, (unsigned long long)ws.steps);
@@ -246,8 +251,9 @@ __device__ __forceinline__ void queue_unit(const Queue &q, uint32_t unit, uint32
     }
 }
 
-// Work list of a launch: the film-block pixels of all its views whose samples must be generated (k_skip_dilate bit 2 / 3
-// clear, row inside the call's window), entry = view * Wb * Hb + pixel.  items[0] = count, then the ticket counters.
+// Work list of a render-kernel launch: the film-block pixels of its views [view0, view0 + nv) whose samples must be generated
+// (k_skip_dilate bit 2 / 3 clear, row inside the call's window), entry = view * Wb * Hb + pixel.  hdr[0] = count, then the
+// ticket counters; the entries follow in `list`.
 // ORDER MATTERS: the workers that run at the same time must be in the same part of the same view, or the 8 L2s (4 MiB each)
 // thrash on the 64 MiB grid -- a first version appended 256-pixel runs in atomic (i.e. arbitrary) order and the primal pass
 // went from 2 GB to 121 GB of L2 fills (33 -> 50 ms).  A block therefore compacts a REGION of DSDF_ITEM_REGION consecutive
@@ -265,8 +271,8 @@ __device__ __forceinline__ void queue_unit(const Queue &q, uint32_t unit, uint32
                                        (measured: 28.9 / 28.7 / 28.6 / 28.5 ms at 256 / 512 / 1024 / 4096) */
 struct ItemOrder { int tw_log2, th_log2; uint32_t tiles_x, per_view; };    // candidate index -> pixel: tile-major within a view
 
-__global__ __launch_bounds__(256) void k_build_items(ViewBatch VB, int nv, const unsigned char *__restrict__ skip, unsigned far_bit,
-                                                     int row0, int row1, ItemOrder O, uint32_t *__restrict__ items) {
+__global__ __launch_bounds__(256) void k_build_items(ViewBatch VB, int view0, int nv, const unsigned char *__restrict__ skip, unsigned far_bit,
+                                                     int row0, int row1, ItemOrder O, uint32_t *__restrict__ hdr, uint32_t *__restrict__ list) {
     const ViewArgs &A = VB.v[0];
     const uint32_t npix = (uint32_t)(A.Wb * A.Hb), total = O.per_view * (uint32_t)nv;
     const uint32_t begin = blockIdx.x * DSDF_ITEM_REGION;
@@ -276,7 +282,7 @@ __global__ __launch_bounds__(256) void k_build_items(ViewBatch VB, int nv, const
     // candidate i -> list entry (view * npix + film-block pixel), or ~0u when it is not to be sampled
     auto entry = [&](uint32_t i) -> uint32_t {
         if (i >= total) return ~0u;
-        const uint32_t view = i / O.per_view, r = i - view * O.per_view;
+        const uint32_t gv = i / O.per_view, r = i - gv * O.per_view, view = (uint32_t)view0 + gv;
         const uint32_t tile = r >> (O.tw_log2 + O.th_log2), in = r & ((1u << (O.tw_log2 + O.th_log2)) - 1u);
         const uint32_t ty = tile / O.tiles_x, tx = tile - ty * O.tiles_x;
         const int px = (int)((tx << O.tw_log2) + (in & ((1u << O.tw_log2) - 1u))), py = (int)((ty << O.th_log2) + (in >> O.tw_log2));
@@ -293,7 +299,7 @@ __global__ __launch_bounds__(256) void k_build_items(ViewBatch VB, int nv, const
     __syncthreads();
     if (threadIdx.x == 0) {
         const uint32_t t = wcount[0] + wcount[1] + wcount[2] + wcount[3];
-        base = t ? atomicAdd(items, t) : 0u;
+        base = t ? atomicAdd(hdr, t) : 0u;
     }
     __syncthreads();
     // pass 2: write them in pixel order
@@ -308,7 +314,7 @@ __global__ __launch_bounds__(256) void k_build_items(ViewBatch VB, int nv, const
         uint32_t before = 0, all = 0;
 #pragma unroll
         for (int k = 0; k < 4; ++k) { const uint32_t c = wcount[k]; before += k < w ? c : 0u; all += c; }
-        if (l) items[DSDF_ITEM_HDR + run + before + mask_prefix(m)] = e;
+        if (l) list[run + before + mask_prefix(m)] = e;
         run += all;
     }
 }
@@ -316,7 +322,8 @@ __global__ __launch_bounds__(256) void k_build_items(ViewBatch VB, int nv, const
 template <bool DIFF, bool DIRECT, bool STATS>
 __global__ __launch_bounds__(64, DIRECT ? 1 : (DIFF ? DSDF_DIFF_MINWAVES : DSDF_PRIMAL_MINWAVES))
 void k_render_items(GridView G, dsdf_params P, ViewBatch VB, float *__restrict__ blocks, Queue qall, unsigned long long *stats,
-                    const unsigned char *__restrict__ skip, ShadeArgs S, TailQueue tq, uint32_t *__restrict__ items) {
+                    const unsigned char *__restrict__ skip, ShadeArgs S, TailQueue tq, uint32_t *__restrict__ items,
+                    const uint32_t *__restrict__ list) {
     constexpr int NCH = DIRECT ? 4 : 2;
     // wave-private LDS scratch: cell cache during tracing, film transpose afterwards
     __shared__ __attribute__((aligned(16))) float wave_lds[DSDF_WAVE_LDS];
@@ -350,7 +357,7 @@ void k_render_items(GridView G, dsdf_params P, ViewBatch VB, float *__restrict__
             continue;
         }
       {
-        const uint32_t e = (uint32_t)__builtin_amdgcn_readfirstlane((int)items[DSDF_ITEM_HDR + item / chunks]);
+        const uint32_t e = (uint32_t)__builtin_amdgcn_readfirstlane((int)list[item / chunks]);
         const uint32_t view = e / npix, pix = e - view * npix;
         const ViewArgs &A = VB.v[view];
         float *__restrict__ block = blocks + (size_t)view * NCH * npix;
@@ -364,16 +371,21 @@ void k_render_items(GridView G, dsdf_params P, ViewBatch VB, float *__restrict__
         bool lit = false;
         const Lane L = lane_setup(A, P, lane);
         if (!skip_trace) {
+            // (the last few rays of the wave are handed to the tail queue: dsdf_tail.h)
             if (DIFF) {
                 DirectFetch F;
-                if (!DIRECT && !STATS && tq.state) {
+                if (!DIRECT && tq.state) {
                     HandOff ho;
                     ho.tq = tq; ho.sub = item % DSDF_TAIL_SUBQ; ho.view = view; ho.lane = lane;
                     trace_diff(G, P, L.ray.o, L.ray.d, L.ray.maxt, tr, F, ho);
                 } else trace_diff(G, P, L.ray.o, L.ray.d, L.ray.maxt, tr, F);
             } else {
                 WaveCellCache F; F.taps = wave_lds; F.lid = lid;
-                trace_plain(G, P, L.ray.o, L.ray.d, L.ray.maxt, tr, F);
+                if (!DIRECT && tq.state) {
+                    PlainHandOff ho;
+                    ho.tq = tq; ho.sub = item % DSDF_TAIL_SUBQ; ho.view = view; ho.lane = lane;
+                    trace_plain(G, P, L.ray.o, L.ray.d, L.ray.maxt, tr, F, ho);
+                } else trace_plain(G, P, L.ray.o, L.ray.d, L.ray.maxt, tr, F);
             }
         }
         float acc[NCH][2];
@@ -581,7 +593,7 @@ __global__ __launch_bounds__(64) void k_backward(GridView G, dsdf_params P, View
     }
     if (stats && count) {
         int s = wave_sum_i32(n_did);
-        if (lid == 0 && s) atomicAdd(stats + (size_t)(blockIdx.x & 63u) * 8 + 5, (unsigned long long)s);
+        if (lid == 0 && s) atomicAdd(stats + (size_t)(blockIdx.x & 63u) * DSDF_STAT_SLOTS + 5, (unsigned long long)s);
     }
 }
 
@@ -638,20 +650,25 @@ static void pass_shape(int W, int H, int spp, int &tile_w, int &tile_h, size_t &
     nunits = (waves + 3) / 4 * 4;
 }
 
+// A launch of up to DSDF_MAX_BATCH views is cut into at most DSDF_MAX_GROUPS view groups, one render-kernel launch each,
+// so that the tail kernel of a group (latency-bound: its longest rays) runs beside the render kernel of the next group.
+#define DSDF_MAX_GROUPS 4
+
 struct Workspace {
     float *block, *block_adj;
     uint32_t *count, *qlane;
     float *qrec;
     unsigned char *skip;
-    uint32_t *items;       // work list of the persistent render kernel: header + one entry per film-block pixel and view
-    char *tail;            // tail hand-off queue of the gradient sweep
+    uint32_t *items;       // work lists of the persistent render kernel: DSDF_MAX_GROUPS headers, then one entry per film-block pixel and view
+    char *tail;            // tail hand-off queues: DSDF_MAX_GROUPS x (counters | march states)
     size_t tail_bytes;
-    uint32_t cap, nunits, tail_cap_sub;
+    uint32_t cap, nunits, tail_cap_sub, tail_words, group_views;
     size_t bytes;
 };
 
 // Workspace for `nv` views processed by one launch (film channels and queue-record rows depend on the integrator).
-// A forward-only workspace (diff = false) carries no backward queue, film-block adjoint or tail queue.
+// A forward-only workspace (diff = false) carries no backward queue or film-block adjoint, and the 3-word tail entries of
+// the value-only march instead of the 23-word ones of the gradient sweep.
 static Workspace carve(void *base, int W, int H, int spp, int nv, int integrator, bool diff = true) {
     Workspace ws;
     const size_t nch = (size_t)film_channels(integrator), rows = integrator == DSDF_DIRECT ? 18 : 9;
@@ -664,22 +681,25 @@ static Workspace carve(void *base, int W, int H, int spp, int nv, int integrator
     char *p = (char *)base;
     ws.block = (float *)(p + off); off += align_up(nv * Wb * Hb * nch * sizeof(float), 256);
     ws.skip = (unsigned char *)(p + off); off += align_up(nv * Wb * Hb, 256);
-    ws.items = (uint32_t *)(p + off); off += align_up((DSDF_ITEM_HDR + nv * Wb * Hb) * sizeof(uint32_t), 256);
+    ws.items = (uint32_t *)(p + off); off += align_up((DSDF_MAX_GROUPS * DSDF_ITEM_HDR + nv * Wb * Hb) * sizeof(uint32_t), 256);
     ws.block_adj = nullptr; ws.count = nullptr; ws.qlane = nullptr; ws.qrec = nullptr;
-    ws.tail = nullptr; ws.tail_bytes = 0; ws.tail_cap_sub = 0;
+    ws.tail = nullptr; ws.tail_bytes = 0; ws.tail_cap_sub = 0; ws.tail_words = 0;
+    ws.group_views = (uint32_t)((nv + DSDF_MAX_GROUPS - 1) / DSDF_MAX_GROUPS);
     if (diff) {
         ws.block_adj = (float *)(p + off); off += align_up(nv * Wb * Hb * nch * sizeof(float), 256);
         ws.count = (uint32_t *)(p + off); off += align_up(nv * nunits * sizeof(uint32_t), 256);
         ws.qlane = (uint32_t *)(p + off); off += align_up(nv * cap * sizeof(uint32_t), 256);
         ws.qrec = (float *)(p + off); off += align_up(nv * cap * rows * sizeof(float), 256);
-        if (integrator != DSDF_DIRECT && spp % 64 == 0) {
-            // sub-queue `s` serves the pixels with work-list index % DSDF_TAIL_SUBQ == s; a wave hands off at most
-            // DSDF_TAIL_HANDOFF rays per 64-sample chunk
-            ws.tail_cap_sub = (uint32_t)((nv * Wb * Hb + DSDF_TAIL_SUBQ - 1) / DSDF_TAIL_SUBQ * (size_t)(spp / 64) * DSDF_TAIL_HANDOFF);
-            ws.tail_bytes = align_up((size_t)DSDF_TAIL_SUBQ * 2 * sizeof(uint32_t), 256) +
-                            align_up((size_t)DSDF_TAIL_SUBQ * ws.tail_cap_sub * DSDF_TAIL_WORDS * sizeof(float), 256);
-            ws.tail = p + off; off += ws.tail_bytes;
-        }
+    }
+    if (integrator != DSDF_DIRECT && spp % 64 == 0) {
+        // per group: sub-queue `s` serves the chunks with work-list index % DSDF_TAIL_SUBQ == s; a wave hands off at most
+        // `handoff` rays per 64-sample chunk
+        const size_t handoff = diff ? DSDF_TAIL_HANDOFF : DSDF_PTAIL_HANDOFF;
+        ws.tail_words = diff ? DSDF_TAIL_WORDS : DSDF_PTAIL_WORDS;
+        ws.tail_cap_sub = (uint32_t)((ws.group_views * Wb * Hb * (size_t)(spp / 64) + DSDF_TAIL_SUBQ - 1) / DSDF_TAIL_SUBQ * handoff);
+        ws.tail_bytes = align_up((size_t)DSDF_MAX_GROUPS * DSDF_TAIL_SUBQ * 2 * sizeof(uint32_t), 256) +
+                        (size_t)DSDF_MAX_GROUPS * align_up((size_t)DSDF_TAIL_SUBQ * ws.tail_cap_sub * ws.tail_words * sizeof(float), 256);
+        ws.tail = p + off; off += ws.tail_bytes;
     }
     ws.cap = (uint32_t)cap;
     ws.nunits = (uint32_t)nunits;
@@ -873,6 +893,58 @@ static unsigned worker_blocks() {
     return n;
 }
 
+// Helper streams for the tail kernels.  A tail kernel is a few thousand waves that wait on the latency of their longest
+// rays; on a stream of its own it runs beside the next render kernel of the caller's stream.  Two high-priority streams per
+// (device, caller stream), created on first use; events come from a ring (an event may be re-recorded while an earlier
+// wait on it is still queued: the wait refers to the record that preceded it).  DSDF_TAIL_STREAMS=0 keeps everything on the
+// caller's stream, DSDF_GROUPS=n (1..4) sets the number of view groups.
+struct TailStreams {
+    int dev; hipStream_t owner; hipStream_t s[2];
+};
+static std::mutex g_helper_mutex;
+static std::vector<TailStreams> g_helpers;
+static std::vector<hipEvent_t> g_events;
+static size_t g_next_event = 0;
+
+static int env_int(const char *name, int dflt) {
+    const char *v = getenv(name);
+    return (v && *v) ? atoi(v) : dflt;
+}
+static int tail_streams_enabled() { static int v = env_int("DSDF_TAIL_STREAMS", 1); return v; }
+static int max_groups() {
+    static int v = 0;
+    if (!v) { v = env_int("DSDF_GROUPS", DSDF_MAX_GROUPS); v = v < 1 ? 1 : (v > DSDF_MAX_GROUPS ? DSDF_MAX_GROUPS : v); }
+    return v;
+}
+
+static bool helper_streams(hipStream_t owner, hipStream_t out[2]) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return false;
+    std::lock_guard<std::mutex> lock(g_helper_mutex);
+    for (const TailStreams &t : g_helpers)
+        if (t.dev == dev && t.owner == owner) { out[0] = t.s[0]; out[1] = t.s[1]; return true; }
+    TailStreams t;
+    t.dev = dev; t.owner = owner;
+    int lo = 0, hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);           // (hi = numerically lowest = highest priority)
+    for (int k = 0; k < 2; ++k)
+        if (hipStreamCreateWithPriority(&t.s[k], hipStreamNonBlocking, hi) != hipSuccess) return false;
+    g_helpers.push_back(t);
+    out[0] = t.s[0]; out[1] = t.s[1];
+    return true;
+}
+
+static hipEvent_t next_event() {
+    std::lock_guard<std::mutex> lock(g_helper_mutex);
+    if (g_events.size() < 256) {
+        hipEvent_t e;
+        if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
+        g_events.push_back(e);
+        return e;
+    }
+    return g_events[g_next_event++ % g_events.size()];
+}
+
 template <bool DIFF>
 static int run_pass(const PassCtx &c, const Workspace &ws, const dsdf_camera *cams, int v0, int nv, ViewBatch &VB, Queue q,
                     int64_t *stats) {
@@ -904,7 +976,7 @@ static int run_pass(const PassCtx &c, const Workspace &ws, const dsdf_camera *ca
         // persistent workers over the compacted list of pixels that must be sampled
         // (sdf_direct_reparam with a visible environment: the background is not zero, every pixel is sampled)
         const unsigned far_bit = (c.direct && !S.hide_emitters) ? 0u : (DIFF ? 8u : 4u);
-        if (hipMemsetAsync(ws.items, 0, DSDF_ITEM_HDR * sizeof(uint32_t), st) != hipSuccess)
+        if (hipMemsetAsync(ws.items, 0, (size_t)DSDF_MAX_GROUPS * DSDF_ITEM_HDR * sizeof(uint32_t), st) != hipSuccess)
             return fail(DSDF_ERR_LAUNCH, "hipMemsetAsync(work list) failed");
         // tile-major order: a tile = DSDF_ITEM_SEG chunks of 64 samples (16 x 16 pixels at 256 spp, 32 x 32 at 64 spp)
         ItemOrder O;
@@ -918,34 +990,71 @@ static int run_pass(const PassCtx &c, const Workspace &ws, const dsdf_camera *ca
             const unsigned tiles_y = (unsigned)((c.Hb + (1u << O.th_log2) - 1) >> O.th_log2);
             O.per_view = (O.tiles_x * tiles_y) << (O.tw_log2 + O.th_log2);
         }
-        hipLaunchKernelGGL(k_build_items, dim3((unsigned)(((size_t)nv * O.per_view + DSDF_ITEM_REGION - 1) / DSDF_ITEM_REGION)), dim3(256), 0, st, VB, nv, skip, far_bit, c.row0, c.row1, O, ws.items);
-        if ((rc = check_launch("k_build_items"))) return rc;
-        TailQueue tq;
-        memset(&tq, 0, sizeof(tq));
-        if (DIFF) {
-            if (hipMemsetAsync(ws.count, 0, (size_t)nv * ws.nunits * sizeof(uint32_t), st) != hipSuccess)
-                return fail(DSDF_ERR_LAUNCH, "hipMemsetAsync(queue counts) failed");
-            if (ws.tail && !stats) {             // (statistics runs march every ray in the sweep itself)
-                tq.cap_sub = ws.tail_cap_sub;
-                tq.count = (uint32_t *)ws.tail;
-                tq.state = (float *)(ws.tail + align_up((size_t)DSDF_TAIL_SUBQ * 2 * sizeof(uint32_t), 256));
-                if (hipMemsetAsync(tq.count, 0, (size_t)DSDF_TAIL_SUBQ * 2 * sizeof(uint32_t), st) != hipSuccess)
-                    return fail(DSDF_ERR_LAUNCH, "hipMemsetAsync(tail queue) failed");
+        if (DIFF && hipMemsetAsync(ws.count, 0, (size_t)nv * ws.nunits * sizeof(uint32_t), st) != hipSuccess)
+            return fail(DSDF_ERR_LAUNCH, "hipMemsetAsync(queue counts) failed");
+        // view groups: render kernel g on the caller's stream, tail kernel g on a helper stream beside render kernel g + 1
+        const bool handoff = ws.tail != nullptr;
+        const size_t cnt_bytes = align_up((size_t)DSDF_MAX_GROUPS * DSDF_TAIL_SUBQ * 2 * sizeof(uint32_t), 256);
+        const size_t grp_bytes = align_up((size_t)DSDF_TAIL_SUBQ * ws.tail_cap_sub * ws.tail_words * sizeof(float), 256);
+        if (handoff && hipMemsetAsync(ws.tail, 0, cnt_bytes, st) != hipSuccess)
+            return fail(DSDF_ERR_LAUNCH, "hipMemsetAsync(tail queue) failed");
+        // a group = k x ws.group_views views (k = 1 unless DSDF_GROUPS asks for fewer, larger groups: the tail regions of k
+        // nominal groups are contiguous and serve as one with k times the sub-queue capacity)
+        int per = nv, kreg = 1;
+        if (handoff) {
+            const int gviews = (int)ws.group_views, want = (nv + max_groups() - 1) / max_groups();
+            kreg = (want + gviews - 1) / gviews;
+            per = kreg * gviews;
+        }
+        const int ngroups = (nv + per - 1) / per;
+        hipStream_t hs[2] = {st, st};
+        const bool forked = handoff && tail_streams_enabled() && helper_streams(st, hs);
+        hipEvent_t joins[DSDF_MAX_BATCH];
+        int njoin = 0;
+        const dim3 grid(worker_blocks()), blk(64);
+        for (int g = 0; g < ngroups; ++g) {
+            const int a = g * per, b = (a + per) < nv ? (a + per) : nv;
+            uint32_t *hdr = ws.items + (size_t)g * DSDF_ITEM_HDR;
+            uint32_t *list = ws.items + (size_t)DSDF_MAX_GROUPS * DSDF_ITEM_HDR + (size_t)a * npix;
+            hipLaunchKernelGGL(k_build_items, dim3((unsigned)(((size_t)(b - a) * O.per_view + DSDF_ITEM_REGION - 1) / DSDF_ITEM_REGION)), dim3(256), 0, st,
+                               VB, a, b - a, skip, far_bit, c.row0, c.row1, O, hdr, list);
+            if ((rc = check_launch("k_build_items"))) return rc;
+            TailQueue tq;
+            memset(&tq, 0, sizeof(tq));
+            if (handoff) {
+                tq.cap_sub = ws.tail_cap_sub * (uint32_t)kreg;
+                tq.count = (uint32_t *)ws.tail + (size_t)g * DSDF_TAIL_SUBQ * 2;
+                tq.state = (float *)(ws.tail + cnt_bytes + (size_t)g * kreg * grp_bytes);
+            }
+            if (c.direct) {
+                if (st64) hipLaunchKernelGGL((k_render_items<DIFF, true, true>), grid, blk, 0, st, G, c.pp, VB, film, q, st64, skip, S, tq, hdr, list);
+                else hipLaunchKernelGGL((k_render_items<DIFF, true, false>), grid, blk, 0, st, G, c.pp, VB, film, q, st64, skip, S, tq, hdr, list);
+            } else {
+                if (st64) hipLaunchKernelGGL((k_render_items<DIFF, false, true>), grid, blk, 0, st, G, c.pp, VB, film, q, st64, skip, S, tq, hdr, list);
+                else hipLaunchKernelGGL((k_render_items<DIFF, false, false>), grid, blk, 0, st, G, c.pp, VB, film, q, st64, skip, S, tq, hdr, list);
+            }
+            if ((rc = check_launch("k_render_items"))) return rc;
+            if (handoff) {
+                hipStream_t ts = st;
+                if (forked) {
+                    ts = hs[g & 1];
+                    hipEvent_t e = next_event();
+                    if (!e || hipEventRecord(e, st) != hipSuccess || hipStreamWaitEvent(ts, e, 0) != hipSuccess)
+                        return fail(DSDF_ERR_LAUNCH, "tail stream fork failed");
+                }
+                const dim3 tgrid(DSDF_TAIL_SUBQ * DSDF_TAIL_BLOCKS_PER_SUBQ), tblk(256);
+                if (DIFF) hipLaunchKernelGGL(k_tail_trace_diff, tgrid, tblk, 0, ts, G, c.pp, VB, film, tq, q, st64);
+                else hipLaunchKernelGGL(k_tail_trace_plain, tgrid, tblk, 0, ts, G, c.pp, VB, film, tq, st64);
+                if ((rc = check_launch("k_tail_trace"))) return rc;
+                if (forked) {
+                    hipEvent_t e = next_event();
+                    if (!e || hipEventRecord(e, ts) != hipSuccess) return fail(DSDF_ERR_LAUNCH, "tail stream join failed");
+                    joins[njoin++] = e;
+                }
             }
         }
-        const dim3 grid(worker_blocks()), blk(64);
-        if (c.direct) {
-            if (st64) hipLaunchKernelGGL((k_render_items<DIFF, true, true>), grid, blk, 0, st, G, c.pp, VB, film, q, st64, skip, S, tq, ws.items);
-            else hipLaunchKernelGGL((k_render_items<DIFF, true, false>), grid, blk, 0, st, G, c.pp, VB, film, q, st64, skip, S, tq, ws.items);
-        } else {
-            if (st64) hipLaunchKernelGGL((k_render_items<DIFF, false, true>), grid, blk, 0, st, G, c.pp, VB, film, q, st64, skip, S, tq, ws.items);
-            else hipLaunchKernelGGL((k_render_items<DIFF, false, false>), grid, blk, 0, st, G, c.pp, VB, film, q, st64, skip, S, tq, ws.items);
-        }
-        if ((rc = check_launch("k_render_items"))) return rc;
-        if (tq.state) {
-            hipLaunchKernelGGL(k_tail_trace_diff, dim3(DSDF_TAIL_SUBQ * DSDF_TAIL_BLOCKS_PER_SUBQ), dim3(256), 0, st, G, c.pp, VB, film, tq, q);
-            if ((rc = check_launch("k_tail_trace_diff"))) return rc;
-        }
+        for (int k = 0; k < njoin; ++k)
+            if (hipStreamWaitEvent(st, joins[k], 0) != hipSuccess) return fail(DSDF_ERR_LAUNCH, "tail stream join failed");
     } else {
         LaneMap M;
         size_t nunits;

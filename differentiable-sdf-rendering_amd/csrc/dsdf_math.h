@@ -494,11 +494,20 @@ DSDF_HD void plain_march_step(PlainMarch &m, float v) {
     m.active = (m.t <= m.maxt) && !hit;
 }
 
-template <class Fetch>
-DSDF_HD void trace_plain(const GridView &G, const dsdf_params &P, V3 o, V3 d_in, float ray_maxt, TraceOut &out, Fetch &F) {
+// Loop control of the marches.  MarchToEnd: every ray of the wave marches until it is done.  The render kernels use the
+// hand-off controls of dsdf_tail.h instead: the loop of a wave ends as soon as only a few of its rays are still marching, and
+// their state is exported for a tail kernel (a handful of grazing rays carry the long tail of every pixel-wave).
+struct MarchToEnd {
+    template <class Fetch> DSDF_HD bool more(const Fetch &F, bool active) { return F.any(active); }
+    DSDF_HD void leftover(bool, float, float, float, float, float, V3, V3, V3, V3, V3, int) const {}
+    DSDF_HD void leftover_plain(bool, float) const {}
+};
+
+template <class Fetch, class Ctl>
+DSDF_HD void trace_plain(const GridView &G, const dsdf_params &P, V3 o, V3 d_in, float ray_maxt, TraceOut &out, Fetch &F, Ctl &C) {
     PlainMarch m = plain_march_begin(P, o, d_in, ray_maxt);
     int steps = 0;
-    while (F.any(m.active)) {
+    while (C.more(F, m.active)) {
         float v = 0.f; V3 gd; float Hd[6];
         F.template eval<0>(G, fma3(m.t, m.d, m.o), m.active, v, gd, Hd);
         if (m.active) {
@@ -506,19 +515,18 @@ DSDF_HD void trace_plain(const GridView &G, const dsdf_params &P, V3 o, V3 d_in,
             ++steps;
         }
     }
+    // rays the loop control stopped early (still active) hand their position over and report a miss for now
+    C.leftover_plain(m.active, m.t);
     out.steps = steps;
     out.its_t = refine_hit(G, P, m.o, m.d, m.its_t, m.trace_eps, out.refine_steps, F);
     out.warp_t = 0.f; out.warp_weight = 0.f; out.weight_sum = 0.f;
     out.warp_t_d = mk(0.f, 0.f, 0.f); out.warp_weight_d = mk(0.f, 0.f, 0.f);
 }
-
-// Loop control of trace_diff.  MarchToEnd: every ray of the wave marches until it is done.  The gradient sweep of the render
-// kernels uses HandOff (dsdf_tail.h) instead: the loop of a wave ends as soon as only a few of its rays are still marching,
-// and their state is exported for a tail kernel (a handful of grazing rays carry the long tail of every pixel-wave).
-struct MarchToEnd {
-    template <class Fetch> DSDF_HD bool more(const Fetch &F, bool active) const { return F.any(active); }
-    DSDF_HD void leftover(bool, float, float, float, float, float, V3, V3, V3, V3, V3, int) const {}
-};
+template <class Fetch>
+DSDF_HD void trace_plain(const GridView &G, const dsdf_params &P, V3 o, V3 d_in, float ray_maxt, TraceOut &out, Fetch &F) {
+    MarchToEnd C;
+    trace_plain(G, P, o, d_in, ray_maxt, out, F, C);
+}
 
 // A2: SDFBase.ray_intersect (shapes.py:115-288) -- differentiable sphere tracing
 // with the weighted warp-t accumulation and its analytic direction derivative.

@@ -1,49 +1,78 @@
-// dsdf_tail.h -- tail hand-off of the gradient sweep (device only; included by dsdf_kernels.hip).
+// dsdf_tail.h -- tail hand-off of the render kernels (device only; included by dsdf_kernels.hip).
 //
-// A pixel-wave marches its 64 rays in lock-step; a handful of grazing rays carry its long tail (measured on the bench
-// scene: lane utilisation 65 % in the gradient sweep).  The sweep therefore ends a wave's differentiable march as soon as at
-// most DSDF_TAIL_HANDOFF of its rays are still going, finishes the samples that are done (film value, backward-queue
-// entry) and exports the state of the others (22 words) to a tail queue.  PERSISTENT tail waves resume them: a lane whose ray
-// has finished takes the next queued one, continues the march from the recorded state with the resumable form of the same
-// statements (diff_march_step; bit-identical to the closed loop, tests/test_kernel_math_host.py), adds the sample's film
-// value and appends it to the backward queue.  Measured (MI355X, 12 views x 512^2 x 64 spp, 256^3): gradient pass
-// 41.6 -> 34.1 ms at 8 rays; the same scheme on the primal (value-only) march did not pay (32.9 -> 32.5 / 35.5 ms at 4 / 8 rays:
-// its loop is 3x cheaper per step, the hand-off costs the same) and was dropped.
+// A pixel-wave marches its 64 rays in lock-step; a handful of grazing rays carry its long tail.  Replaying the per-ray step
+// counts of one bench view (tools/sim_waves.py, fp32 C oracle): lane utilisation 0.61; 15 % of the primal wave-steps run with
+// ONE active lane, 32 % with <= 8; the 2.4 % of the waves that mix hits and misses take 22 % of the wave-steps at 24 %
+// utilisation (mean longest ray 239 steps, longest 2135) -- but the MEDIAN ray still marching when 8 are left needs one more
+// step.  So a wave ends its march loop when at most DSDF_*TAIL_HANDOFF of its rays are still going AND they have been given
+// DSDF_*TAIL_GRACE more iterations (simulated: 0.70 of the wave-steps, 0.9 % of the rays handed off; without the grace
+// iterations 2.9 % for 0.68), finishes the samples that are done (film value, backward-queue entry) and exports the state of
+// the others to a tail queue.  PERSISTENT tail waves resume them: a lane whose ray has finished takes the next queued one,
+// continues the march from the recorded state with the resumable form of the same statements (plain_march_step /
+// diff_march_step; bit-identical to the closed loops, tests/test_kernel_math_host.py), adds the sample's film value and, in
+// the gradient pass, appends it to the backward queue.
+//
+// A tail kernel is bound by the LATENCY of its longest rays (1000+ dependent steps on an otherwise empty chip), so the
+// host side (run_pass, dsdf_kernels.hip) cuts a launch into view groups and runs the tail kernel of group g on a helper
+// stream beside the main kernel of group g + 1; only the last group's tail is exposed.
 #pragma once
 
 #ifndef DSDF_TAIL_HANDOFF
-#define DSDF_TAIL_HANDOFF 8         /* rays of a wave that may still be marching when its loop ends (tunable: A/B 4 vs 8 vs 16) */
+#define DSDF_TAIL_HANDOFF 8         /* gradient sweep: rays of a wave that may still be marching when its loop ends */
+#endif
+#ifndef DSDF_TAIL_GRACE
+#define DSDF_TAIL_GRACE 2           /* ... after this many more lock-step iterations */
+#endif
+#ifndef DSDF_PTAIL_HANDOFF
+#define DSDF_PTAIL_HANDOFF 8        /* the same two for the primal (value-only) march */
+#endif
+#ifndef DSDF_PTAIL_GRACE
+#define DSDF_PTAIL_GRACE 2
 #endif
 #define DSDF_TAIL_SUBQ 64           /* sub-queues per launch: spreads the reservation atomics */
-#define DSDF_TAIL_REFILL 24         /* idle lanes that trigger a refill in the tail kernel */
-#define DSDF_TAIL_BLOCKS_PER_SUBQ 16   /* 4096 persistent tail waves */
-#define DSDF_TAIL_WORDS 23          /* view, sample id, t, warp_t, prev_sd, wsum, ews, 5 x V3, step counter */
+#define DSDF_TAIL_REFILL 24         /* idle lanes that trigger a refill in the tail kernels */
+#ifndef DSDF_TAIL_BLOCKS_PER_SUBQ
+#define DSDF_TAIL_BLOCKS_PER_SUBQ 16   /* x 4 waves: 4096 persistent tail waves */
+#endif
+#define DSDF_TAIL_WORDS 23          /* gradient sweep: view, sample id, t, warp_t, prev_sd, wsum, ews, 5 x V3, step counter */
+#define DSDF_PTAIL_WORDS 3          /* primal: view, sample id, t (everything else follows from the sample id) */
+#define DSDF_TAIL_HANDOFF_MAX (DSDF_TAIL_HANDOFF > DSDF_PTAIL_HANDOFF ? DSDF_TAIL_HANDOFF : DSDF_PTAIL_HANDOFF)
 
 struct TailQueue {
     uint32_t *count;   // [DSDF_TAIL_SUBQ][2]: {queued, claimed}
-    float *state;      // [DSDF_TAIL_SUBQ][cap_sub][DSDF_TAIL_WORDS] march states
+    float *state;      // [DSDF_TAIL_SUBQ][cap_sub][words] march states
     uint32_t cap_sub;
 };
 
-// Loop control of trace_diff (dsdf_math.h): stop when at most DSDF_TAIL_HANDOFF rays of the wave are still marching and
-// export their state at once -- one reservation per wave in sub-queue `sub` -- so that the 21 words die before the
-// refinement loop of the finished rays.
-struct HandOff {
+// one reservation per wave in sub-queue `sub`; returns this lane's entry index (valid for the lanes of `m`)
+__device__ __forceinline__ uint32_t tail_reserve(const TailQueue &tq, uint32_t sub, uint64_t m) {
+    uint32_t base = 0;
+    const int leader = __builtin_ctzll(m);
+    if (lane_id() == leader) base = atomicAdd(tq.count + 2 * sub, (uint32_t)__popcll(m));
+    base = (uint32_t)__builtin_amdgcn_readlane((int)base, leader);
+    return base + mask_prefix(m);
+}
+
+// Loop control of trace_diff / trace_plain (dsdf_math.h): stop when at most HANDOFF rays of the wave are still marching and
+// GRACE more iterations have passed; export the state of the rays that are still active at once -- one reservation per wave
+// -- so that the words die before the refinement loop of the finished rays.
+template <int HANDOFF, int GRACE>
+struct HandOffCtl {
     TailQueue tq;
     uint32_t sub, view, lane;
-    template <class Fetch> __device__ __forceinline__ bool more(const Fetch &, bool active) const {
-        return __popcll(__ballot(active)) > DSDF_TAIL_HANDOFF;
+    int low = 0;       // iterations spent at or below the threshold (wave-uniform)
+    template <class Fetch> __device__ __forceinline__ bool more(const Fetch &, bool active) {
+        const int n = __popcll(__ballot(active));
+        if (n > HANDOFF) return true;
+        return n != 0 && low++ < GRACE;
     }
     __device__ __forceinline__ void leftover(bool active, float t, float warp_t, float prev_sd, float wsum, float ews, V3 t_d,
                                              V3 prev_gc, V3 mixed, V3 wdsum, V3 ews_d, int i) const {
         const uint64_t m = __ballot(active);
         if (m == 0) return;
-        uint32_t base = 0;
-        const int leader = __builtin_ctzll(m);
-        if (lane_id() == leader) base = atomicAdd(tq.count + 2 * sub, (uint32_t)__popcll(m));
-        base = (uint32_t)__builtin_amdgcn_readlane((int)base, leader);
+        const uint32_t idx = tail_reserve(tq, sub, m);
         if (active) {
-            float *e = tq.state + ((size_t)sub * tq.cap_sub + base + mask_prefix(m)) * DSDF_TAIL_WORDS;
+            float *e = tq.state + ((size_t)sub * tq.cap_sub + idx) * DSDF_TAIL_WORDS;
             e[0] = __uint_as_float(view); e[1] = __uint_as_float(lane);
             e[2] = t; e[3] = warp_t; e[4] = prev_sd; e[5] = wsum; e[6] = ews;
             e[7] = t_d.x; e[8] = t_d.y; e[9] = t_d.z;
@@ -54,11 +83,45 @@ struct HandOff {
             e[22] = __int_as_float(i);
         }
     }
+    __device__ __forceinline__ void leftover_plain(bool active, float t) const {
+        const uint64_t m = __ballot(active);
+        if (m == 0) return;
+        const uint32_t idx = tail_reserve(tq, sub, m);
+        if (active) {
+            float *e = tq.state + ((size_t)sub * tq.cap_sub + idx) * DSDF_PTAIL_WORDS;
+            e[0] = __uint_as_float(view); e[1] = __uint_as_float(lane); e[2] = t;
+        }
+    }
 };
+typedef HandOffCtl<DSDF_TAIL_HANDOFF, DSDF_TAIL_GRACE> HandOff;
+typedef HandOffCtl<DSDF_PTAIL_HANDOFF, DSDF_PTAIL_GRACE> PlainHandOff;
+
+// refill of a persistent tail wave: the idle lanes claim the next queued entries; returns this lane's entry or ~0u
+__device__ __forceinline__ uint32_t tail_claim(uint32_t *cnt, uint32_t total, uint64_t idle, bool mine, bool &exhausted) {
+    uint32_t base = 0;
+    const int leader = __builtin_ctzll(idle);
+    if (lane_id() == leader) base = atomicAdd(cnt + 1, (uint32_t)__popcll(idle));
+    base = (uint32_t)__builtin_amdgcn_readlane((int)base, leader);
+    if (base >= total) exhausted = true;
+    const uint32_t idx = base + mask_prefix(idle);
+    if (base + (uint32_t)__popcll(idle) >= total) exhausted = true;      // (everything queued has been claimed)
+    return (mine && idx < total) ? idx : ~0u;
+}
+
+// tail statistics (slots 8..10 of the caller's stats rows, include/dsdf.h): lane-steps, lock-step iterations, rays
+__device__ __forceinline__ void tail_stats(unsigned long long *stats, int lane_steps, int wave_steps, int rays) {
+    const int ls = wave_sum_i32(lane_steps), r = wave_sum_i32(rays);
+    if (lane_id() == 0) {
+        unsigned long long *st = stats + (size_t)(blockIdx.x & 63u) * DSDF_STAT_SLOTS;
+        atomicAdd(st + 8, (unsigned long long)ls);
+        atomicAdd(st + 9, (unsigned long long)wave_steps);
+        atomicAdd(st + 10, (unsigned long long)r);
+    }
+}
 
 // Resumes the queued rays of the gradient sweep and finishes their samples: value splat, backward-queue entry.
 __global__ __launch_bounds__(256) void k_tail_trace_diff(GridView G, dsdf_params P, ViewBatch VB, float *__restrict__ blocks,
-                                                         TailQueue tq, Queue qall) {
+                                                         TailQueue tq, Queue qall, unsigned long long *stats) {
     const uint32_t sub = blockIdx.x % DSDF_TAIL_SUBQ;
     uint32_t *cnt = tq.count + 2 * sub;
     const float *ent = tq.state + (size_t)sub * tq.cap_sub * DSDF_TAIL_WORDS;
@@ -69,40 +132,37 @@ __global__ __launch_bounds__(256) void k_tail_trace_diff(GridView G, dsdf_params
     Lane L;
     uint32_t sample = 0, view = 0;
     bool exhausted = false;
+    int n_steps = 0, n_wsteps = 0, n_rays = 0, n_hits = 0, n_need = 0;
 
     while (true) {
         const uint64_t idle = __ballot(!m.active);
         if (!exhausted && __popcll(idle) >= DSDF_TAIL_REFILL) {
-            uint32_t base = 0;
-            const int leader = __builtin_ctzll(idle);
-            if (lane_id() == leader) base = atomicAdd(cnt + 1, (uint32_t)__popcll(idle));
-            base = (uint32_t)__builtin_amdgcn_readlane((int)base, leader);
-            if (base >= total) exhausted = true;
-            if (!m.active) {
-                const uint32_t idx = base + mask_prefix(idle);
-                if (idx < total) {
-                    const float *e = ent + (size_t)idx * DSDF_TAIL_WORDS;
-                    view = __float_as_uint(e[0]);
-                    sample = __float_as_uint(e[1]);
-                    const ViewArgs &A = VB.v[view];
-                    L = lane_setup(A, P, sample);
-                    m = diff_march_begin(P, L.ray.o, L.ray.d, L.ray.maxt);
-                    m.t = e[2]; m.warp_t = e[3]; m.prev_sd = e[4]; m.wsum = e[5]; m.ews = e[6];
-                    m.t_d = mk(e[7], e[8], e[9]); m.prev_gc = mk(e[10], e[11], e[12]); m.mixed = mk(e[13], e[14], e[15]);
-                    m.wdsum = mk(e[16], e[17], e[18]); m.ews_d = mk(e[19], e[20], e[21]);
-                    m.i = __float_as_int(e[22]);
-                }
+            const uint32_t idx = tail_claim(cnt, total, idle, !m.active, exhausted);
+            if (idx != ~0u) {
+                const float *e = ent + (size_t)idx * DSDF_TAIL_WORDS;
+                view = __float_as_uint(e[0]);
+                sample = __float_as_uint(e[1]);
+                const ViewArgs &A = VB.v[view];
+                L = lane_setup(A, P, sample);
+                m = diff_march_begin(P, L.ray.o, L.ray.d, L.ray.maxt);
+                m.t = e[2]; m.warp_t = e[3]; m.prev_sd = e[4]; m.wsum = e[5]; m.ews = e[6];
+                m.t_d = mk(e[7], e[8], e[9]); m.prev_gc = mk(e[10], e[11], e[12]); m.mixed = mk(e[13], e[14], e[15]);
+                m.wdsum = mk(e[16], e[17], e[18]); m.ews_d = mk(e[19], e[20], e[21]);
+                m.i = __float_as_int(e[22]);
+                ++n_rays;
             }
         }
         if (__ballot(m.active) == 0) {
             if (exhausted) break;
             continue;
         }
+        ++n_wsteps;
         if (m.active) {
             V3 x = fma3(m.t, m.d, m.o);
             float v; V3 g; float H[6];
             eval_cubic<2>(G, x, v, g, H);
             diff_march_step(P, m, x, v, g, H);
+            ++n_steps;
             if (!m.active) {                                            // the sample is complete: what the render pass does after its loop
                 const ViewArgs &A = VB.v[view];
                 DirectFetch F;
@@ -115,6 +175,7 @@ __global__ __launch_bounds__(256) void k_tail_trace_diff(GridView G, dsdf_params
                     splat_value_lane(blocks + (size_t)view * 2 * A.Wb * A.Hb, A.Wb, A.Hb, rp.u, rp.v, val, AtomicAdd());
                 }
                 const bool hit = tr.its_t < INFINITY;
+                n_hits += hit ? 1 : 0;
                 const bool warp_cand = (A.flags & DSDF_REPARAM) && warp_weight_positive(G, P, L.ray.o, L.ray.d, tr);
                 if (warp_cand || (hit && A.integrator == DSDF_SIMPLE_SHADING)) {
                     const Queue qv = view_queue(qall, view);
@@ -122,8 +183,85 @@ __global__ __launch_bounds__(256) void k_tail_trace_diff(GridView G, dsdf_params
                     const uint32_t slot = atomicAdd(qv.count + unit, 1u);   // behind the entries the sweep compacted
                     qv.lane[unit * 64 + slot] = sample;
                     store_record(qv.rec + sample, qv.cap, tr);
+                    ++n_need;
                 }
             }
+        }
+    }
+    if (stats) {
+        tail_stats(stats, n_steps, n_wsteps, n_rays);
+        const int h = wave_sum_i32(n_hits), q = wave_sum_i32(n_need);
+        if (lane_id() == 0) {
+            unsigned long long *st = stats + (size_t)(blockIdx.x & 63u) * DSDF_STAT_SLOTS;
+            atomicAdd(st + 3, (unsigned long long)h);
+            atomicAdd(st + 6, (unsigned long long)q);
+        }
+    }
+}
+
+// Resumes the queued rays of the primal pass (value-only march) and adds the film value of those that hit.  The rays that
+// end up here slide along a surface in sub-voxel steps: the lane keeps the 64 taps of its cell in registers (ReuseFetch) and
+// gathers only on entering another cell -- the step is then a dependent ALU chain without a memory round trip.
+__global__ __launch_bounds__(256) void k_tail_trace_plain(GridView G, dsdf_params P, ViewBatch VB, float *__restrict__ blocks,
+                                                          TailQueue tq, unsigned long long *stats) {
+    const uint32_t sub = blockIdx.x % DSDF_TAIL_SUBQ;
+    uint32_t *cnt = tq.count + 2 * sub;
+    const float *ent = tq.state + (size_t)sub * tq.cap_sub * DSDF_PTAIL_WORDS;
+    const uint32_t total = cnt[0];
+    if (total == 0) return;
+    PlainMarch m;
+    m.active = false;
+    Lane L;
+    ReuseFetch F;
+    uint32_t view = 0;
+    bool exhausted = false;
+    int n_steps = 0, n_wsteps = 0, n_rays = 0, n_hits = 0, n_ref = 0;
+
+    while (true) {
+        const uint64_t idle = __ballot(!m.active);
+        if (!exhausted && __popcll(idle) >= DSDF_TAIL_REFILL) {
+            const uint32_t idx = tail_claim(cnt, total, idle, !m.active, exhausted);
+            if (idx != ~0u) {
+                const float *e = ent + (size_t)idx * DSDF_PTAIL_WORDS;
+                view = __float_as_uint(e[0]);
+                L = lane_setup(VB.v[view], P, __float_as_uint(e[1]));
+                m = plain_march_begin(P, L.ray.o, L.ray.d, L.ray.maxt);
+                m.t = e[2];
+                F.valid = false;
+                ++n_rays;
+            }
+        }
+        if (__ballot(m.active) == 0) {
+            if (exhausted) break;
+            continue;
+        }
+        ++n_wsteps;
+        if (m.active) {
+            float v = 0.f; V3 gd; float Hd[6];
+            F.template eval<0>(G, fma3(m.t, m.d, m.o), true, v, gd, Hd);
+            plain_march_step(m, v);
+            ++n_steps;
+            if (!m.active && m.its_t < INFINITY) {                      // a hit: refine, shade, add the value (the weight is on the film)
+                const ViewArgs &A = VB.v[view];
+                DirectFetch D;
+                int nref;
+                const float its_t = refine_hit(G, P, m.o, m.d, m.its_t, m.trace_eps, nref, D);
+                const float val = shade_value(G, A, L, its_t);
+                if (val != 0.f) {
+                    Reproj rp = reproject(A.cam, P, L.ray.o + L.ray.d, A.W, A.H);
+                    splat_value_lane(blocks + (size_t)view * 2 * A.Wb * A.Hb, A.Wb, A.Hb, rp.u, rp.v, val, AtomicAdd());
+                }
+                ++n_hits; n_ref += nref;
+            }
+        }
+    }
+    if (stats) {
+        tail_stats(stats, n_steps, n_wsteps, n_rays);
+        const int h = wave_sum_i32(n_hits), r = wave_sum_i32(n_ref);
+        if (lane_id() == 0) {
+            unsigned long long *st = stats + (size_t)(blockIdx.x & 63u) * DSDF_STAT_SLOTS;
+            atomicAdd(st + 3, (unsigned long long)h);
+            atomicAdd(st + 4, (unsigned long long)r);
         }
     }
 }

@@ -19,7 +19,9 @@ INTEGRATORS = {'sdf_silhouette_reparam': DSDF_SILHOUETTE, 'sdf_simple_shading_re
                'sdf_direct_reparam': DSDF_DIRECT,
                DSDF_SILHOUETTE: DSDF_SILHOUETTE, DSDF_SIMPLE_SHADING: DSDF_SIMPLE_SHADING, DSDF_DIRECT: DSDF_DIRECT}
 
-STAT_NAMES = ('lanes', 'bbox_lanes', 'steps', 'hits', 'refine_steps', 'warp_active', 'queue_len', 'wave_steps')
+STAT_NAMES = ('lanes', 'bbox_lanes', 'steps', 'hits', 'refine_steps', 'warp_active', 'queue_len', 'wave_steps',
+              'tail_steps', 'tail_wave_steps', 'tail_rays')
+STAT_SLOTS = 16          # include/dsdf.h: DSDF_STAT_SLOTS
 
 _workspaces = {}
 
@@ -100,26 +102,26 @@ class SdfGrid:
         with torch.cuda.device(data.device):
             _lib.check(lib.dsdf_pad_grid(_ptr(data), self.rx, self.ry, self.rz, _ptr(self.padded), _stream()))
         self.device = data.device
-        self._src = (data.data_ptr(), data._version)          # what the padded copy was built from
+        # what the padded copy was built from: the tensor OBJECT (held, so its storage cannot be recycled for another tensor
+        # while it is the key) and its in-place version
+        self._src = (data, data._version)
         return self
 
     def in_sync_with(self, data):
         """True when the padded copy was built from exactly this tensor state (storage and in-place version)."""
+        src = getattr(self, '_src', None)
+        if src is None:
+            return False
+        t, ver = src
         d = data.detach()
-        return getattr(self, '_src', None) == (d.data_ptr(), d._version)
+        # `t` is held, so its storage is alive: an equal address is the same memory, not a recycled block
+        return t.data_ptr() == d.data_ptr() and t.numel() == d.numel() and d._version == ver
 
     def set_translation(self, p):
-        """`sdf.p` (python/shapes.py:389, 412): lookups happen at x - p.  A tensor is read back to the host only when
-        it changed since the last call."""
-        if isinstance(p, torch.Tensor):
-            key = (p.data_ptr(), p._version)
-            if getattr(self, '_p_src', None) == key:
-                return self
-            self._p_src = key
-            vals = p.detach().cpu().tolist()
-        else:
-            self._p_src = None
-            vals = p
+        """`sdf.p` (python/shapes.py:389, 412): lookups happen at x - p.  A tensor is ALWAYS read back (3 floats): its
+        address and in-place version do not identify its contents -- a temporary (`p0 + eps * e` in a finite-difference
+        loop) is freed and re-allocated at the same address with version 0."""
+        vals = p.detach().cpu().tolist() if isinstance(p, torch.Tensor) else p
         px, py, pz = (float(v) for v in vals)
         self.params.sdf_p[0], self.params.sdf_p[1], self.params.sdf_p[2] = px, py, pz
         return self
@@ -407,7 +409,14 @@ _sweep_workspaces = {}
 class GradSweep:
     """The two halves of a gradient pass split at the film block: sweep() traces the window's samples (film accumulated,
     backward queue left in this object's workspace); after the films of all ranks were summed, backward() propagates the
-    window's samples against the total film."""
+    window's samples against the total film.  More than MAX_VIEWS_PER_LAUNCH sensors (the reference's default batch is all
+    sensors of a config) are handled as consecutive parts of at most that many views, each with its own queue."""
+
+    def __new__(cls, grid, sensors, *a, **kw):
+        sensors = list(sensors) if isinstance(sensors, (list, tuple)) else [sensors]
+        if len(sensors) > MAX_VIEWS_PER_LAUNCH and cls is GradSweep:
+            return object.__new__(_GradSweepParts)
+        return object.__new__(cls)
 
     def __init__(self, grid, sensors, spp, rows, seeds=None, offsets=None, integrator=DSDF_SILHOUETTE, reparam=True,
                  empty_space_skip=True, shading=None, emitter_samples=None, grad_albedo=None, workspace=None):
@@ -447,6 +456,40 @@ class GradSweep:
                                                    _ptr(self.ws), self.ws.numel(), _stream()))
         return grad_grid
 
+    def record_stream(self, stream):
+        self.ws.record_stream(stream)
+
+
+class _GradSweepParts(GradSweep):
+    """GradSweep over more sensors than one launch takes: consecutive parts with private workspaces."""
+
+    def __init__(self, grid, sensors, spp, rows, seeds=None, offsets=None, emitter_samples=None, workspace=None, **kw):
+        sensors = list(sensors)
+        n, m = len(sensors), MAX_VIEWS_PER_LAUNCH
+        W, H = sensors[0].film_size()
+        n_lanes = (W + 4) * (H + 4) * int(spp)
+        if seeds is not None and isinstance(seeds, int):
+            seeds = [seeds] * n
+        per_view = lambda t, a, b: None if t is None else t.reshape(n, n_lanes, 2)[a:b].contiguous()
+        self.parts = [(a, min(a + m, n), GradSweep(grid, sensors[a:a + m], spp, rows, seeds=None if seeds is None else list(seeds)[a:a + m],
+                                                   offsets=per_view(offsets, a, a + m), emitter_samples=per_view(emitter_samples, a, a + m), **kw))
+                      for a in range(0, n, m)]
+        self.nv, self.ws = n, None
+
+    def sweep(self, film):
+        for a, b, part in self.parts:
+            part.sweep(film[a:b])
+        return film
+
+    def backward(self, film_total, grad_image, grad_grid, grad_p=None):
+        for a, b, part in self.parts:
+            part.backward(film_total[a:b], grad_image[a:b], grad_grid, grad_p)
+        return grad_grid
+
+    def record_stream(self, stream):
+        for _, _, part in self.parts:
+            part.ws.record_stream(stream)
+
 
 _side_streams = {}
 
@@ -477,12 +520,13 @@ def render_step(grid, sensors, spp, spp_grad, loss_grad, grad_grid, seeds, seeds
     with torch.cuda.stream(side):
         sweep = GradSweep(grid, sensors, spp_grad, (0, H + 4), seeds=seeds_grad, integrator=integrator, reparam=reparam,
                           shading=shading, grad_albedo=grad_albedo, workspace=_sweep_workspaces.get(dev))
-        _sweep_workspaces[dev] = sweep.ws                  # re-used by the next step's sweep (stream-ordered after this backward)
+        if sweep.ws is not None:
+            _sweep_workspaces[dev] = sweep.ws              # re-used by the next step's sweep (stream-ordered after this backward)
         film_g = sweep.sweep(new_film(len(sensors), W, H, integrator, dev))
     img = render_forward(grid, sensors, spp, seeds=seeds, integrator=integrator, reparam=reparam, shading=shading)
     gi = loss_grad(img)
     main.wait_stream(side)
-    film_g.record_stream(main); sweep.ws.record_stream(main)
+    film_g.record_stream(main); sweep.record_stream(main)
     sweep.backward(film_g, gi.contiguous(), grad_grid, grad_p)
     return img
 
@@ -523,11 +567,15 @@ def mesh_raycast(triangles, rays_o, rays_d, t_min=0.0):
 
 
 def new_stats(device):
-    return torch.zeros(64, 8, dtype=torch.int64, device=device)
+    return torch.zeros(64, STAT_SLOTS, dtype=torch.int64, device=device)
 
 
 def stats_dict(stats):
-    return dict(zip(STAT_NAMES, (int(x) for x in stats.sum(0).cpu())))
+    """Sums the 64 interleaved copies.  `steps` / `wave_steps` count the render kernel only; `all_steps` adds what the tail
+    kernels marched for the rays handed over to them."""
+    d = dict(zip(STAT_NAMES, (int(x) for x in stats.sum(0).cpu())))
+    d['all_steps'] = d['steps'] + d['tail_steps']
+    return d
 
 
 class _RenderOp(torch.autograd.Function):

@@ -165,7 +165,7 @@ def refine(triangles, grid, origins, res, chunk=1 << 16):
         d = dirs.repeat(idx.numel(), 1)
         t, _ = dsdf.mesh_raycast(triangles, o, d)
         md = torch.clamp(t.reshape(-1, nd).min(1).values, max=100.0)
-        flat[idx] = md * torch.sign(flat[idx])
+        flat[idx] = torch.where(flat[idx] < 0, -md, md)          # dr.sign(0) = +1
     return flat.reshape(res, res, res)
 
 

@@ -71,7 +71,9 @@ class Adam:
                 v_new = 0.999 * v + 0.001 * g * g
                 m.copy_(torch.where(nz, m_new, m))
                 v.copy_(torch.where(nz, v_new, v))
-                p.sub_(torch.where(nz, step * m / (v.sqrt() + 1e-8), torch.zeros_like(p)))
+                # mi.ad.Adam masks the MOMENT updates only: entries with a zero gradient keep their moments and are still
+                # stepped with them
+                p.addcdiv_(m, v.sqrt().add_(1e-8), value=-step)
             else:
                 m.mul_(0.9).add_(g, alpha=0.1)
                 v.mul_(0.999).addcmul_(g, g, value=0.001)

@@ -26,7 +26,8 @@
 extern "C" {
 #endif
 
-#define DSDF_VERSION 201   /* 201: + dsdf_mesh_raycast */
+#define DSDF_VERSION 300   /* 300: stats rows of DSDF_STAT_SLOTS (16) counters; tail hand-off on library-owned helper streams */
+#define DSDF_STAT_SLOTS 16
 
 enum dsdf_status {
     DSDF_OK = 0,
@@ -171,10 +172,13 @@ size_t dsdf_forward_workspace_size(int width, int height, int spp, int n_views, 
  *               with seed = seeds[view]
  *   seeds     : n_views uint32 (HOST memory; ignored when offsets != NULL)
  *   image_out : n_views x H x W x 3
- *   stats     : optional device int64[64][8] accumulators -- 64 interleaved copies (to
+ *   stats     : optional device int64[64][DSDF_STAT_SLOTS] accumulators -- 64 interleaved copies (to
  *               spread the atomics; sum over the first axis) of {lanes, bbox_lanes,
- *               steps, hits, refine_steps, warp_active, queue_len, wave_steps}; wave_steps = lock-step loop
- *               iterations summed over the 64-lane waves (trace + refinement), the unit of the VALU-issue roofline
+ *               steps, hits, refine_steps, warp_active, queue_len, wave_steps, tail_steps, tail_wave_steps, tail_rays};
+ *               wave_steps = lock-step loop iterations of the render kernel summed over its 64-lane waves (trace +
+ *               refinement), the unit of the VALU-issue roofline; steps / wave_steps count the render kernel only, the
+ *               tail_* slots what the tail kernels added for the rays handed over to them (tail_rays of them)
+ * Tail kernels run on library-owned helper streams (forked from and joined back into `stream` inside the call).
  */
 int dsdf_render_forward(const float *padded, int rx, int ry, int rz, const dsdf_params *prm,
                         const dsdf_camera *cams, int n_views, int width, int height, int spp,
