@@ -13,17 +13,24 @@ exchange step); value = steps / time means the same at every N.  `--scaling weak
 kept under a different metric string.
 
 The JSON line carries, besides the contract's fields:
-  roofline     -- VALU-issue roofline of the dominant kernel (the primal k_render_pass): the path is not HBM-bound (taps
+  roofline     -- VALU-issue roofline of the dominant kernel (the primal k_render_items): the path is not HBM-bound (taps
                   are LDS/L1-resident: measured HBM traffic is ~1 % of the algorithmic tap bytes), it issues vector ALU
                   instructions.  achieved = wave-level VALU instructions per launch / launch time; peak = 1024 SIMDs x
                   2.4 GHz / 2 clk per wave64 instruction (MI355X_MICROARCH.md: SIMD-32, `v_fma_f32` 2 cyc).  The
-                  instruction count is LIVE: lock-step wave iterations counted by the kernel itself (stats[7]) x the
-                  per-iteration VALU instruction counts of the shipped ISA, calibrated against SQ_INSTS_VALU of the
-                  committed PMC pass (profiles/, tag in `calibration`).  The HBM-equivalent algorithmic-bytes figure of
-                  SURVEY 8(d) is kept as a secondary field (`hbm_equivalent`); `traffic` is null here (PMC counters cannot
-                  be read in-process; the measured bytes live in profiles/).
-  low_spp      -- the same step at 4/1 spp (the sampling rate at which north_star's >= 50 renders/s target and its 60 %
-                  roofline coincide), timed in the same process after the headline region.
+                  instruction count is LIVE x MEASURED: lock-step wave iterations counted by the kernel itself in this
+                  process (stats slot 7) x the VALU instructions per wave iteration of the SAME kernel measured with
+                  rocprofv3 --pmc (SQ_INSTS_VALU / wave iterations of tools/pmc_workload.py), read from
+                  profiles/valu_model.json (written by profiles/summarize_pmc.py -- no literals here).
+                  frac_lane_weighted = frac x lane utilisation (active lanes per VALU instruction);
+                  useful_flop_frac   = spline FLOPs (168 per lane-evaluation: 84 FMA) / time / 157.3 TFLOP/s fp32 vector peak;
+                  traffic            = measured HBM bytes per launch of that kernel from the same PMC run (FETCH_SIZE /
+                                       WRITE_SIZE passes; provenance in `traffic_from`), null when the file is absent.
+                  The HBM-equivalent algorithmic-bytes figure of SURVEY 8(d) is kept as a secondary field.
+  low_spp      -- the same step at 4/1 spp (north_star's >= 50 renders/s point).
+  direct       -- BASELINE.json configs[4] sizes on ONE GPU: sdf_direct_reparam, 256^3 + 256^3 x 3 albedo, 12 x 512^2, 256/64 spp.
+  opt_iteration-- one whole optimiser iteration at the headline sizes (python/shape_opt.py:75-105): 6 of 12 views
+                  (opt_configs.py:245), multiscale-L1 loss, Laplacian regulariser, gradient scrub, Adam, box constraint,
+                  redistancing, texture refresh -- the pieces timed one by one with HIP events.
   cpu_baseline -- oracle/dsdf_oracle.c (fp32 build) on the host cores, bounded sample (rank 0, N = 1 only).
 """
 import argparse
@@ -38,13 +45,19 @@ sys.path.insert(0, os.path.join(ROOT, 'differentiable-sdf-rendering_amd', 'pytho
 
 import torch
 
-# VALU instructions per lock-step wave iteration / per wave, from the ISA of the shipped kernels
-# (hipcc -S, instruction histogram of the loop bodies; cross-checked against SQ_INSTS_VALU: profiles/r02_sq.json)
-VALU_MODEL = {
-    'calibration': 'profiles/r02_sq.json',
-    'primal': {'per_wave_step': 209.0, 'per_traced_wave': 600.0, 'per_wave': 430.0},
-}
 VALU_PEAK = 1024 * 2.4e9 / 2.0        # wave64 VALU instructions / s: 256 CUs x 4 SIMD-32, 2 clk per instruction
+FP32_VECTOR_PEAK = 157.3e12           # MI355X_MICROARCH.md: fp32 vector peak (packed FMA)
+SPLINE_FLOP_PER_EVAL = 168.0          # 64 + 16 + 4 FMAs of one value-only tricubic lookup
+
+
+def load_valu_model():
+    """profiles/valu_model.json: VALU instructions per lock-step wave iteration of the shipped kernels, measured with
+    rocprofv3 --pmc on tools/pmc_workload.py and written by profiles/summarize_pmc.py."""
+    path = os.path.join(ROOT, 'profiles', 'valu_model.json')
+    try:
+        return json.load(open(path))
+    except (OSError, ValueError):
+        return None
 
 
 def synth_grid(res, device, n=32, seed=0):
@@ -122,6 +135,113 @@ def cpu_baseline(args, target_seconds=15.0):
                       f"{args.res}^3 grid; {tp + tg:.1f}s measured, scaled linearly in spp and views"}
 
 
+def direct_block(args, dev, grid, sensors, steps=4):
+    """BASELINE.json configs[4] sizes on one GPU: sdf_direct_reparam with a 256^3 x 3 albedo volume, the same two-stream step."""
+    import dsdf
+    albedo = torch.rand(args.res, args.res, args.res, 3, device=dev) * 0.6 + 0.2
+    sh = dsdf.Shading(albedo, 1.0, hide_emitters=False)
+    galb = torch.zeros_like(albedo)
+    grad = torch.zeros(args.res, args.res, args.res, device=dev)
+    nv = len(sensors)
+    tgt = dsdf.render_forward(grid, sensors, 64, seeds=[2000 + i for i in range(nv)], integrator='sdf_direct_reparam', shading=sh)
+    scale = 1.0 / (args.img * args.img * 3)
+
+    def step(it):
+        grad.zero_(); galb.zero_()
+        seeds = [(it * nv + i) * 2 for i in range(nv)]
+        dsdf.render_step(grid, sensors, args.spp_primal, args.spp_grad, lambda im: torch.sign(im - tgt) * scale, grad, seeds,
+                         [x + 1 for x in seeds], integrator='sdf_direct_reparam', shading=sh, grad_albedo=galb)
+    step(0)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(steps):
+        step(1 + k)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+    e0.record()
+    img = dsdf.render_forward(grid, sensors, args.spp_primal, seeds=list(range(nv)), integrator='sdf_direct_reparam', shading=sh)
+    e1.record()
+    dsdf.render_backward(grid, sensors, args.spp_grad, torch.sign(img - tgt) * scale, grad_grid=grad, seeds=list(range(50, 50 + nv)),
+                         integrator='sdf_direct_reparam', shading=sh, grad_albedo=galb)
+    e2.record()
+    torch.cuda.synchronize()
+    out = {"value": steps / el, "unit": "renders/s", "steps": steps, "ms_per_step": 1e3 * el / steps,
+           "primal_ms_per_launch": e0.elapsed_time(e1), "grad_ms_per_launch": e1.elapsed_time(e2),
+           "grad_l1": float(grad.double().abs().sum()), "grad_albedo_l1": float(galb.double().abs().sum()),
+           "config": {"workload": f"diffuse-12-hqq sizes (BASELINE.json configs[4]) on ONE GPU: {args.res}^3 SDF + {args.res}^3 x 3 albedo, "
+                                  f"{nv} views x {args.img}^2, sdf_direct_reparam (emitter sampling), spp {args.spp_primal}/{args.spp_grad}"}}
+    del albedo, galb, grad, tgt
+    return out
+
+
+def opt_iteration_block(args, dev, data0, ring, iters=6):
+    """One whole optimiser iteration (python/shape_opt.py:75-105) at the headline sizes, with the host modules the CLI uses:
+    a batch of 6 of the 12 views (opt_configs.py:245) rendered through the autograd op (primal 256 spp, gradient pass 64 spp),
+    multiscale-L1 loss (losses.py:33-42) per view / batch_size, Laplacian regulariser (regularizations.py:5-25,
+    weight 1e-5 as `no-tex-12`), gradient scrub (variables.py:193-199), Adam (mi.ad.Adam conventions), learning-rate
+    schedule + box constraint + redistancing (variables.py:168-190), texture refresh.  Every piece is bracketed by HIP
+    events; the iteration time is wall-clock over `iters` iterations."""
+    import dsdf
+    import losses
+    import regularizations
+    import variables
+    key = 'SamplingIntegrator.sdf.data'
+    opt = variables.Adam(lr=2e-3)
+    var = variables.SdfVariable(key, args.res, upsample_iter=None, regularizer=regularizations.eval_discrete_laplacian_reg,
+                                regularizer_weight=1e-5)
+    var.initialize(opt)
+    opt[key] = variables.atleast_4d(data0.clone())
+    grid = dsdf.SdfGrid(opt[key])
+    batch = 6
+    tgt_grid = dsdf.SdfGrid(synth_grid(args.res, dev, seed=1))
+    refs = dsdf.render_forward(tgt_grid, ring, 64, seeds=[3000 + i for i in range(len(ring))])
+    names = ('render_primal', 'loss_and_gradient_pass', 'regulariser', 'scrub', 'adam', 'box_redistance', 'texture_refresh')
+    acc = {n: 0.0 for n in names}
+    pending = []
+
+    def iteration(i, timed):
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(len(names) + 1)]
+        idx = [(i * batch + j) % len(ring) for j in range(batch)]
+        ev[0].record()
+        imgs = dsdf.render(opt[key], grid, [ring[j] for j in idx], spp=args.spp_primal, seed=17 * i, spp_grad=args.spp_grad,
+                           seed_grad=17 * i + 7)
+        ev[1].record()
+        loss = sum(losses.multiscale_l1(imgs[j], refs[v]) for j, v in enumerate(idx)) / batch
+        loss.backward()
+        ev[2].record()
+        reg = var.eval_regularizer(opt, None, i)
+        if isinstance(reg, torch.Tensor) and reg.requires_grad:
+            reg.backward()
+        ev[3].record()
+        var.validate_gradient(opt, i)
+        ev[4].record()
+        opt.step()
+        ev[5].record()
+        var.validate(opt, i)
+        ev[6].record()
+        grid.update(opt[key])
+        ev[7].record()
+        if timed:
+            pending.append(ev)
+
+    iteration(0, False)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(iters):
+        iteration(1 + i, True)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    for ev in pending:
+        for k, n in enumerate(names):
+            acc[n] += ev[k].elapsed_time(ev[k + 1])
+    parts = {n: acc[n] / iters for n in names}
+    return {"value": iters / el, "unit": "iterations/s", "iterations": iters, "ms_per_iteration": 1e3 * el / iters,
+            "ms_parts": parts, "ms_parts_sum": sum(parts.values()),
+            "config": {"workload": f"{args.res}^3 SDF, batch of {batch} of {len(ring)} views x {args.img}^2, sdf_silhouette_reparam, spp "
+                                   f"{args.spp_primal}/{args.spp_grad}, multiscale-L1 + Laplacian (1e-5), Adam, box constraint, redistance"}}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -136,6 +256,8 @@ def main():
     ap.add_argument('--scaling', choices=('strong', 'weak'), default='strong')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-low-spp', action='store_true')
+    ap.add_argument('--no-direct', action='store_true')
+    ap.add_argument('--no-opt-iteration', action='store_true')
     ap.add_argument('--overlap', type=int, default=1, help='1: primal pass and gradient sweep on two HIP streams (dsdf.render_step)')
     args = ap.parse_args()
 
@@ -151,7 +273,7 @@ def main():
     dev_index = local_rank % torch.cuda.device_count() if share else local_rank
     torch.cuda.set_device(dev_index)
     dev = torch.device('cuda', dev_index)
-    dist = None
+    dist, backend = None, None
     # (BENCH_FORCE_DIST=1 exercises the RCCL path with a single rank, e.g. under `torchrun --nproc-per-node 1`)
     if world > 1 or os.environ.get('BENCH_FORCE_DIST') == '1':
         import torch.distributed as dist
@@ -171,7 +293,7 @@ def main():
         # GPUs) the views are cut into pixel-row windows (parallel.work_partition: 24 half-views, 3 per rank) and the film
         # blocks are summed across ranks before develop / before the backward (parallel.render_step)
         ring = dsdf.get_regular_cameras(args.views, resx=args.img, resy=args.img)
-        tiled = args.views % world != 0
+        tiled = args.views % world != 0 or os.environ.get('BENCH_FORCE_TILED') == '1'
         mine = list(range(args.views)) if tiled else parallel.strided_view_shard(list(range(args.views)), rank, world)
     else:
         # weak scaling: a ring of views*world sensors, `views` per rank
@@ -179,27 +301,47 @@ def main():
         mine = list(range(args.views * world))[rank::world]
     sensors = [ring[i] for i in mine]
     nv = len(sensors)
-    grad = torch.zeros_like(data)
+    # two gradient buffers, used alternately: the RCCL all-reduce of step i is issued non-blocking and overlaps the rendering of
+    # step i + 1, which accumulates into the other buffer
+    grads = [torch.zeros_like(data), torch.zeros_like(data)]
     # BASELINE.json C5 (--integrator sdf_direct_reparam): a 3-channel albedo volume of the grid's resolution is optimised too
-    shade, shade_g = {}, {}
+    shade, galbs = {}, [None, None]
     if args.integrator == 'sdf_direct_reparam':
         albedo = torch.rand(args.res, args.res, args.res, 3, device=dev) * 0.6 + 0.2
         shade = {'shading': dsdf.Shading(albedo, 1.0, hide_emitters=False)}
-        shade_g = dict(shade, grad_albedo=torch.zeros_like(albedo))
+        galbs = [torch.zeros_like(albedo), torch.zeros_like(albedo)]
     # target images (outside the timed region) -> L1 image gradient sign(img - target)/(H*W*3)
     tgt = torch.cat([dsdf.render_forward(target, s, 64, seeds=[1000 + i]) for i, s in zip(mine, sensors)]) if nv else None
     scale = 1.0 / (args.img * args.img * 3)
 
     ev = lambda: torch.cuda.Event(enable_timing=True)
+    hip_ops = {}
+    pending = [None, None]                      # work handles of the all-reduces in flight, per gradient buffer
 
     def make_step(spp_p, spp_g, prim_ms, grad_ms):
         def step(it, timed):
             # one launch traces all views of this rank's shard (primal), one launch the gradient pass
+            b = it & 1
+            if pending[b] is not None:          # the reduce that last used this buffer (two steps ago)
+                pending[b].wait(); pending[b] = None
+            grad, galb = grads[b], galbs[b]
             grad.zero_()
+            if galb is not None:
+                galb.zero_()
+            extra = [galb] if galb is not None else []
             if tiled:
                 seeds = [(it * args.views + i) * 2 for i in range(args.views)]
-                ops = parallel.HipOps(grid, ring, spp_p, spp_g, seeds, [s + 1 for s in seeds], args.integrator)
-                parallel.render_step(ops, args.views, args.img, args.img, rank, world, lambda im: torch.sign(im - tgt) * scale, grad)
+                key = (spp_p, spp_g)
+                if key not in hip_ops:          # (kept across steps: its sweep workspaces and side stream are re-used)
+                    hip_ops[key] = parallel.HipOps(grid, ring, spp_p, spp_g, seeds, [x + 1 for x in seeds], args.integrator,
+                                                   two_streams=bool(args.overlap), **shade)
+                ops = hip_ops[key]
+                ops.set_seeds(seeds, [x + 1 for x in seeds])
+                ops.kw = dict(shade, **({'grad_albedo': galb} if galb is not None else {}))
+                _, work = parallel.render_step(ops, args.views, args.img, args.img, rank, world,
+                                               lambda im, views: torch.sign(im - tgt[views]) * scale, grad, extra_grads=extra,
+                                               gather_images=False, async_reduce=True)
+                pending[b] = work
                 return
             if nv:
                 seeds = [(it * args.views + i) * 2 for i in mine]
@@ -208,24 +350,30 @@ def main():
                     # primal render and the forward sweep of the gradient pass on two HIP streams (dsdf.render_step)
                     e0.record()
                     dsdf.render_step(grid, sensors, spp_p, spp_g, lambda im: torch.sign(im - tgt) * scale, grad, seeds,
-                                     [s + 1 for s in seeds], integrator=args.integrator, shading=shade.get('shading'),
-                                     grad_albedo=shade_g.get('grad_albedo'))
+                                     [x + 1 for x in seeds], integrator=args.integrator, shading=shade.get('shading'),
+                                     grad_albedo=galb)
                     e1.record(); e2.record()
                 else:
                     e0.record()
                     img = dsdf.render_forward(grid, sensors, spp_p, seeds=seeds, integrator=args.integrator, **shade)
                     e1.record()
                     gi = torch.sign(img - tgt) * scale
-                    dsdf.render_backward(grid, sensors, spp_g, gi, grad_grid=grad, seeds=[s + 1 for s in seeds],
-                                         integrator=args.integrator, **shade_g)
+                    dsdf.render_backward(grid, sensors, spp_g, gi, grad_grid=grad, seeds=[x + 1 for x in seeds],
+                                         integrator=args.integrator, grad_albedo=galb, **shade)
                     e2.record()
                 if timed:
                     prim_ms.append((e0, e1)); grad_ms.append((e1, e2))
             if dist is not None:
-                parallel.all_reduce_gradients([grad] + ([shade_g['grad_albedo']] if shade_g else []))
+                pending[b] = parallel.all_reduce_gradients([grad] + extra, async_op=True, force=True)
         return step
 
+    def drain():
+        for b in (0, 1):
+            if pending[b] is not None:
+                pending[b].wait(); pending[b] = None
+
     def barrier():
+        drain()
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
@@ -248,18 +396,19 @@ def main():
     prim_ms, grad_ms = [], []
     elapsed = timed_run(make_step(args.spp_primal, args.spp_grad, prim_ms, grad_ms), args.warmup, args.steps)
     # dL/dsdf of the last timed step (summed over ranks): must agree at every N up to the order of the float atomics
-    grad_l1 = float(grad.double().abs().sum())
+    grad_l1 = float(grads[(args.warmup + args.steps - 1) & 1].double().abs().sum())
     if args.overlap and nv and not tiled:
         # the roofline needs the dominant kernel's OWN launch time: in the timed region above it shares the chip with the
         # gradient sweep of the other stream, so a few launches are timed alone (HIP events, same process, same inputs)
         prim_ms, grad_ms = [], []
         ov, args.overlap = args.overlap, 0
+        dist_saved, dist = dist, None
         probe = make_step(args.spp_primal, args.spp_grad, prim_ms, grad_ms)
         probe(args.warmup + args.steps, False)                 # (untimed: the stand-alone calls allocate their own workspaces)
         for k in range(3):
             probe(args.warmup + args.steps + 1 + k, True)
         torch.cuda.synchronize()
-        args.overlap = ov
+        args.overlap, dist = ov, dist_saved
 
     low = None
     if not args.no_low_spp:
@@ -281,38 +430,56 @@ def main():
     out_cfg, roof = {}, None
     if nv and not tiled:
         st_p, st_g = dsdf.new_stats(dev), dsdf.new_stats(dev)
+        galb = galbs[0]
         dsdf.render_forward(grid, sensors, args.spp_primal, seeds=list(range(nv)), integrator=args.integrator, stats=st_p, **shade)
         dsdf.render_backward(grid, sensors, args.spp_grad, torch.ones(nv, args.img, args.img, 3, device=dev) * scale,
-                             grad_grid=torch.zeros_like(data), seeds=list(range(50, 50 + nv)), integrator=args.integrator, **shade_g,
-                             stats=st_g)
+                             grad_grid=torch.zeros_like(data), seeds=list(range(50, 50 + nv)), integrator=args.integrator,
+                             grad_albedo=galb, stats=st_g, **shade)
         sp, sg = dsdf.stats_dict(st_p), dsdf.stats_dict(st_g)
         prim = [a.elapsed_time(b) for a, b in prim_ms]
         gradt = [a.elapsed_time(b) for a, b in grad_ms]
         prim_avg = sum(prim) / len(prim)
-        # VALU-issue roofline of the primal launch (k_render_pass<false,true,false>): wave-level VALU instructions
-        m = VALU_MODEL['primal']
         total_lanes = nv * (args.img + 4) ** 2 * args.spp_primal
-        waves = sp['lanes'] / 64.0                        # generated samples (pixels that are not proven far), in waves
-        traced_waves = sp['bbox_lanes'] / 64.0            # lanes that enter the trace loop (after the empty-space proof)
-        valu = m['per_wave_step'] * sp['wave_steps'] + m['per_traced_wave'] * traced_waves + m['per_wave'] * waves
-        achieved = valu / (prim_avg * 1e-3)
-        # SURVEY 8(d) HBM-equivalent figure, kept as a secondary field: 64 fp32 taps per cubic evaluation, film RMW, one grid read
-        evals = sp['steps'] + sp['refine_steps']
-        alg_bytes = 256.0 * evals + 16 * 2 * 8.0 * sp['lanes'] + 4.0 * args.res ** 3
-        roof = {"bound": "valu", "kernel": "k_render_items<primal>", "achieved": achieved / 1e9, "peak": VALU_PEAK / 1e9,
-                "unit": "G wave-instr/s", "frac": achieved / VALU_PEAK, "traffic": None,
-                "valu_insts_per_launch": valu, "wave_steps_per_launch": sp['wave_steps'], "avg_launch_ms": prim_avg,
-                "launch_time_from": "3 launches timed alone after the timed region" if args.overlap else "the timed region",
-                "lane_utilisation": evals / max(64.0 * sp['wave_steps'], 1.0), "calibration": VALU_MODEL['calibration'],
+        # VALU-issue roofline of the primal launch: measured VALU instructions per wave iteration x live wave iterations
+        model = load_valu_model()
+        evals = sp['steps'] + sp['refine_steps']                     # lane-evaluations of the render kernel (the tail kernel's: tail_steps)
+        lane_util = evals / max(64.0 * sp['wave_steps'], 1.0)
+        alg_bytes = 256.0 * (evals + sp['tail_steps']) + 16 * 2 * 8.0 * sp['lanes'] + 4.0 * args.res ** 3
+        roof = {"bound": "valu", "kernel": "k_render_items<primal>", "unit": "G wave-instr/s", "peak": VALU_PEAK / 1e9,
+                "achieved": None, "frac": None, "frac_lane_weighted": None, "traffic": None,
+                "wave_steps_per_launch": sp['wave_steps'], "avg_launch_ms": prim_avg,
+                "launch_time_from": ("3 dsdf_render_forward calls timed alone after the timed region" if args.overlap else "the timed region") +
+                                    " (HIP events on the launch stream around the call: pixel-skip + list build + render kernel + tail kernel + develop)",
+                "lane_utilisation": lane_util,
+                "useful_flop_frac": SPLINE_FLOP_PER_EVAL * (evals + sp['tail_steps']) / (prim_avg * 1e-3) / FP32_VECTOR_PEAK,
+                "tail": {"rays": sp['tail_rays'], "lane_steps": sp['tail_steps'], "wave_steps": sp['tail_wave_steps']},
                 "hbm_equivalent": {"algorithmic_bytes_per_launch": alg_bytes, "GBps": alg_bytes / (prim_avg * 1e-3) / 1e9,
                                    "frac_of_8TBps": alg_bytes / (prim_avg * 1e-3) / 8e12,
-                                   "note": "SURVEY 8(d) tap-byte model; taps are LDS/L1-resident, so this is not a bound "
-                                           "(measured HBM bytes: profiles/)"}}
-        out_cfg = {"mean_steps_per_bbox_lane": sp['steps'] / max(sp['bbox_lanes'], 1),
+                                   "note": "SURVEY 8(d) tap-byte model; taps are LDS/L1-resident, so this is not a bound"}}
+        if model and 'primal' in model:
+            m = model['primal']
+            valu = m['valu_per_wave_step'] * sp['wave_steps']
+            achieved = valu / (prim_avg * 1e-3)
+            roof.update({"achieved": achieved / 1e9, "frac": achieved / VALU_PEAK, "frac_lane_weighted": achieved / VALU_PEAK * lane_util,
+                         "valu_insts_per_launch": valu, "valu_per_wave_step": m['valu_per_wave_step'],
+                         "calibration": f"profiles/valu_model.json (tag {model.get('tag')}): SQ_INSTS_VALU {m.get('valu_insts_per_launch')} / "
+                                        f"{m.get('wave_steps_per_launch')} wave iterations of tools/pmc_workload.py",
+                         "traffic": m.get('hbm_bytes_per_launch'), "traffic_unit": "bytes per launch (2 x FETCH_SIZE + WRITE_SIZE, separate PMC passes)",
+                         "traffic_from": model.get('source')})
+        out_cfg = {"mean_steps_per_bbox_lane": (sp['steps'] + sp['tail_steps']) / max(sp['bbox_lanes'], 1),
                    "hit_fraction": sp['hits'] / total_lanes, "traced_fraction": sp['bbox_lanes'] / total_lanes,
-                   "generated_fraction": sp['lanes'] / total_lanes,
+                   "generated_fraction": sp['lanes'] / total_lanes, "handed_off_fraction": sp['tail_rays'] / max(sp['bbox_lanes'], 1),
                    "backward_queue_fraction": sg['queue_len'] / max(nv * (args.img + 4) ** 2 * args.spp_grad, 1),
                    "primal_ms_per_launch": prim_avg, "grad_ms_per_launch": sum(gradt) / len(gradt)}
+
+    direct = opt_it = None
+    if world == 1 and dist is None and args.integrator == 'sdf_silhouette_reparam':
+        if not args.no_direct:
+            dsdf.release_workspaces()
+            direct = direct_block(args, dev, grid, sensors)
+        if not args.no_opt_iteration:
+            dsdf.release_workspaces()
+            opt_it = opt_iteration_block(args, dev, data, ring)
 
     if rank == 0:
         strong = args.scaling == 'strong'
@@ -328,12 +495,17 @@ def main():
                             "views_total": args.views if strong else args.views * world, "views_this_rank": nv,
                             "partition": ("pixel-row windows of views: %d units per rank" % len(parallel.work_partition(args.views, args.img + 4, world)[0])) if tiled else "whole views",
                             "spp_primal": args.spp_primal, "spp_grad": args.spp_grad, "grad_l1_last_step": grad_l1,
-                            "schedule": "primal pass and gradient sweep on two HIP streams (dsdf.render_step)" if args.overlap and not tiled
-                            else "sequential launches"}, **out_cfg),
+                            "dist_backend": backend,
+                            "gradient_exchange": None if dist is None else "one non-blocking all-reduce of dL/dsdf per step, overlapped with the next step's rendering (two gradient buffers)",
+                            "schedule": "primal pass and gradient sweep on two HIP streams" if args.overlap else "sequential launches"}, **out_cfg),
             "roofline": roof,
         }
         if low is not None:
             out["low_spp"] = low
+        if direct is not None:
+            out["direct"] = direct
+        if opt_it is not None:
+            out["opt_iteration"] = opt_it
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args)
         print(json.dumps(out))

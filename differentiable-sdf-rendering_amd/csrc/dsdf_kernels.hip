@@ -522,21 +522,29 @@ __global__ __launch_bounds__(DSDF_BLOCK) void k_render_pass(GridView G, dsdf_par
     }
 }
 
-// Backward sweep: one single-wave block per FOUR consecutive units of a view (256 samples: one pixel at spp 256, four at spp 64;
-// ~12 % of them are queued).  It gathers the queued samples of its units 64 at a time (usually one round).
+// Backward sweep: one single-wave block per DSDF_BWD_UNITS consecutive units of a view (a unit = 64 samples: one pixel at
+// spp 64; ~12 % of the samples are queued, many more on silhouette pixels, none on far ones).  The wave gathers the queued
+// samples of its units PACKED, 64 at a time: with 4 units per wave (round 2) a round held ~30 samples, i.e. half of the
+// lanes of a latency-bound kernel idled; 16 units fill the rounds (profiles/r03*_ab).
+#ifndef DSDF_BWD_UNITS
+#define DSDF_BWD_UNITS 16
+#endif
 struct UnitGather {
-    uint32_t c[4], total, unit0;
+    uint32_t c[DSDF_BWD_UNITS], total, unit0;
     __device__ __forceinline__ void init(const Queue &q, uint32_t group) {
-        unit0 = group * 4u;
+        unit0 = group * (uint32_t)DSDF_BWD_UNITS;
         total = 0;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) { c[k] = (unit0 + k < q.nunits) ? q.count[unit0 + k] : 0u; total += c[k]; }
+        for (int k = 0; k < DSDF_BWD_UNITS; ++k) {
+            c[k] = (unit0 + k < q.nunits) ? (uint32_t)__builtin_amdgcn_readfirstlane((int)q.count[unit0 + k]) : 0u;
+            total += c[k];
+        }
     }
     // queue slot of the s-th queued sample of the group
     __device__ __forceinline__ uint32_t slot(uint32_t s) const {
         uint32_t u = 0, r = s;
 #pragma unroll
-        for (int k = 0; k < 3; ++k)
+        for (int k = 0; k < DSDF_BWD_UNITS - 1; ++k)
             if (u == (uint32_t)k && r >= c[k]) { r -= c[k]; u = k + 1; }
         return (unit0 + u) * 64u + r;
     }
@@ -897,7 +905,10 @@ static unsigned worker_blocks() {
 // rays; on a stream of its own it runs beside the next render kernel of the caller's stream.  Two high-priority streams per
 // (device, caller stream), created on first use; events come from a ring (an event may be re-recorded while an earlier
 // wait on it is still queued: the wait refers to the record that preceded it).  DSDF_TAIL_STREAMS=0 keeps everything on the
-// caller's stream, DSDF_GROUPS=n (1..4) sets the number of view groups.
+// caller's stream, DSDF_GROUPS=n (1..4) sets the number of view groups.  Measured (profiles/r03a_tail_ab.md): a resident tail
+// kernel takes registers from the render kernel beside it (main kernels 6.0 -> 7.2-7.6 ms per 3-view group) and every group
+// boundary costs a list build + ramp, so ONE group is the default: the tail then runs behind its render kernel and
+// overlaps with whatever the caller has on its other streams (dsdf.render_step: the other pass).
 struct TailStreams {
     int dev; hipStream_t owner; hipStream_t s[2];
 };
@@ -911,9 +922,15 @@ static int env_int(const char *name, int dflt) {
     return (v && *v) ? atoi(v) : dflt;
 }
 static int tail_streams_enabled() { static int v = env_int("DSDF_TAIL_STREAMS", 1); return v; }
+// blocks (4 waves) per sub-queue of a tail kernel: DSDF_TAIL_BLOCKS overrides the built-in value
+static unsigned tail_blocks() {
+    static int v = 0;
+    if (!v) { v = env_int("DSDF_TAIL_BLOCKS", DSDF_TAIL_BLOCKS_PER_SUBQ); v = v < 1 ? 1 : (v > 64 ? 64 : v); }
+    return (unsigned)v;
+}
 static int max_groups() {
     static int v = 0;
-    if (!v) { v = env_int("DSDF_GROUPS", DSDF_MAX_GROUPS); v = v < 1 ? 1 : (v > DSDF_MAX_GROUPS ? DSDF_MAX_GROUPS : v); }
+    if (!v) { v = env_int("DSDF_GROUPS", 1); v = v < 1 ? 1 : (v > DSDF_MAX_GROUPS ? DSDF_MAX_GROUPS : v); }
     return v;
 }
 
@@ -1042,7 +1059,7 @@ static int run_pass(const PassCtx &c, const Workspace &ws, const dsdf_camera *ca
                     if (!e || hipEventRecord(e, st) != hipSuccess || hipStreamWaitEvent(ts, e, 0) != hipSuccess)
                         return fail(DSDF_ERR_LAUNCH, "tail stream fork failed");
                 }
-                const dim3 tgrid(DSDF_TAIL_SUBQ * DSDF_TAIL_BLOCKS_PER_SUBQ), tblk(256);
+                const dim3 tgrid(DSDF_TAIL_SUBQ * tail_blocks()), tblk(256);
                 if (DIFF) hipLaunchKernelGGL(k_tail_trace_diff, tgrid, tblk, 0, ts, G, c.pp, VB, film, tq, q, st64);
                 else hipLaunchKernelGGL(k_tail_trace_plain, tgrid, tblk, 0, ts, G, c.pp, VB, film, tq, st64);
                 if ((rc = check_launch("k_tail_trace"))) return rc;
@@ -1132,7 +1149,7 @@ int dsdf_render_backward(const float *padded, int rx, int ry, int rz, const dsdf
         if (c.direct) hipLaunchKernelGGL(k_develop_adjoint_rgb, adj_grid, dim3(256), 0, st, ws.block, gi, width, height, ws.block_adj);
         else hipLaunchKernelGGL(k_develop_adjoint, adj_grid, dim3(256), 0, st, ws.block, gi, width, height, ws.block_adj);
         if ((rc = check_launch("k_develop_adjoint"))) return rc;
-        const dim3 grid((ws.nunits + 3) / 4, nv);
+        const dim3 grid((ws.nunits + DSDF_BWD_UNITS - 1) / DSDF_BWD_UNITS, nv);
         unsigned long long *st64 = (unsigned long long *)stats;
         if (c.direct) hipLaunchKernelGGL(k_backward<true>, grid, dim3(64), 0, st, G, c.pp, VB, q, ws.block_adj, grad_grid, grad_p, st64, S);
         else hipLaunchKernelGGL(k_backward<false>, grid, dim3(64), 0, st, G, c.pp, VB, q, ws.block_adj, grad_grid, grad_p, st64, S);
@@ -1166,7 +1183,7 @@ int dsdf_render_forward_grad(const float *padded, int rx, int ry, int rz, const 
         // the tangent film block lives in the adjoint block's storage
         if (hipMemsetAsync(ws.block_adj, 0, nv * c.Wb * c.Hb * 2 * sizeof(float), st) != hipSuccess)
             return fail(DSDF_ERR_LAUNCH, "hipMemsetAsync(tangent block) failed");
-        hipLaunchKernelGGL(k_forward_tangent, dim3((ws.nunits + 3) / 4, nv), dim3(64), 0, st, G, tangent_padded, dp, c.pp, VB, q, ws.block_adj);
+        hipLaunchKernelGGL(k_forward_tangent, dim3((ws.nunits + DSDF_BWD_UNITS - 1) / DSDF_BWD_UNITS, nv), dim3(64), 0, st, G, tangent_padded, dp, c.pp, VB, q, ws.block_adj);
         if ((rc = check_launch("k_forward_tangent"))) return rc;
         const dim3 dev_grid((width * height + 255) / 256, nv);
         hipLaunchKernelGGL(k_develop_tangent, dev_grid, dim3(256), 0, st, ws.block, ws.block_adj, width, height,
@@ -1262,7 +1279,7 @@ int dsdf_grad_backward(const float *padded, int rx, int ry, int rz, const dsdf_p
     if ((rc = check_launch("k_develop_adjoint"))) return rc;
     const GridView G = device_view(padded, rx, ry, rz, *prm);
     const ShadeArgs S = make_shade_args(shading, true);
-    const dim3 grid((ws.nunits + 3) / 4, n_views);
+    const dim3 grid((ws.nunits + DSDF_BWD_UNITS - 1) / DSDF_BWD_UNITS, n_views);
     if (c.direct) hipLaunchKernelGGL(k_backward<true>, grid, dim3(64), 0, st, G, c.pp, VB, q, ws.block_adj, grad_grid, grad_p, (unsigned long long *)nullptr, S);
     else hipLaunchKernelGGL(k_backward<false>, grid, dim3(64), 0, st, G, c.pp, VB, q, ws.block_adj, grad_grid, grad_p, (unsigned long long *)nullptr, S);
     return check_launch("k_backward");

@@ -64,7 +64,19 @@ def all_reduce_sum(t, group=None):
     return t
 
 
-def render_step(ops, n_views, W, H, rank, world, loss_grad, grad_grid, group=None):
+def _call_loss_grad(loss_grad, images, views):
+    """loss_grad(images) for callables written against ALL views, loss_grad(images, views) for those that take the view
+    indices of the images they are handed."""
+    import inspect
+    try:
+        two = len(inspect.signature(loss_grad).parameters) >= 2
+    except (TypeError, ValueError):
+        two = False
+    return loss_grad(images, views) if two else loss_grad(images)
+
+
+def render_step(ops, n_views, W, H, rank, world, loss_grad, grad_grid, group=None, extra_grads=(), gather_images=True,
+                async_reduce=False):
     """One differentiable render of `n_views` views shared by `world` ranks, split by views and -- when world does not
     divide them -- by pixel tiles (work_partition).  `ops` supplies the four film-level operators of the renderer for a
     list of views and a row window (dsdf.render_film / develop / GradSweep on a GPU; the oracle's in the CPU tests):
@@ -72,12 +84,34 @@ def render_step(ops, n_views, W, H, rank, world, loss_grad, grad_grid, group=Non
         ops.develop(film_total)                    -> images (n, H, W, 3)
         ops.sweep(views, rows)                     -> (gradient-pass film blocks, handle)
         ops.backward(handle, film_total, grad_image, grad_grid)   accumulates dL/dsdf of the window's samples
-    Exchange steps: sum of the primal films, sum of the gradient-pass films (only views that are actually split would need
-    them; all views are reduced here for simplicity: 2 x n_views x 2 MiB at 512^2), and the ONE sum of dL/dsdf.
-    loss_grad(images) -> dL/d(images).  Returns the images (identical on every rank)."""
+      optional: ops.begin_sweeps() / ops.end_sweeps() bracket the sweep calls (the HIP operators run them on a side stream
+      beside the primal films: they do not depend on the image gradient).
+    Exchange steps: when views are SPLIT into row windows, the sum of the primal films and the sum of the gradient-pass
+    films (2 x n_views x 2 MiB at 512^2); whole views need neither (a view's film lives on one rank).  Always: ONE sum of
+    dL/dsdf and of `extra_grads` (e.g. the albedo gradient of sdf_direct_reparam) in a single bucket -- with
+    async_reduce=True it is issued non-blocking and its work handle returned, so that it overlaps whatever the caller
+    enqueues next (wait before reading the gradients).
+    loss_grad(images[, views]) -> dL/d(images).  Returns the images: of all views on every rank (whole views:
+    all-gathered when gather_images, else only this rank's rows are filled), or (images, work) with async_reduce."""
     import torch
+    import torch.distributed as dist
     units = work_partition(n_views, H + 4, world)[rank]
     wins = rank_windows(units)
+    split = world // math.gcd(n_views, world) > 1
+    mine = sorted({v for v, _, _ in units})
+    # ---- gradient-pass sweeps first: independent of the primal images (HIP: a side stream)
+    if hasattr(ops, 'begin_sweeps'):
+        ops.begin_sweeps()
+    film_g, handles = None, []
+    for rows, views in wins:
+        f, h = ops.sweep(views, rows)
+        if film_g is None:
+            film_g = torch.zeros((n_views,) + tuple(f.shape[1:]), dtype=f.dtype, device=f.device)
+        film_g[views] += f
+        handles.append((views, h))
+    if hasattr(ops, 'end_sweeps'):
+        ops.end_sweeps()
+    # ---- primal films
     film = None
     for rows, views in wins:
         f = ops.film(views, rows)
@@ -86,31 +120,61 @@ def render_step(ops, n_views, W, H, rank, world, loss_grad, grad_grid, group=Non
         film[views] += f
     if film is None:
         film = ops.empty_film(n_views)
-    all_reduce_sum(film, group)
-    images = ops.develop(film)
-    grad_images = loss_grad(images)
-    film_g = torch.zeros_like(film)
-    handles = []
-    for rows, views in wins:
-        f, h = ops.sweep(views, rows)
-        film_g[views] += f
-        handles.append((views, h))
-    all_reduce_sum(film_g, group)
+        film_g = torch.zeros_like(film)
+    if split:
+        all_reduce_sum(film, group)
+        images = ops.develop(film)
+        grad_images = _call_loss_grad(loss_grad, images, list(range(n_views)))
+    else:
+        images = torch.zeros((n_views, H, W, 3), dtype=film.dtype, device=film.device)
+        if mine:
+            images[mine] = ops.develop(film[mine].contiguous())
+        if gather_images and dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+            all_reduce_sum(images, group)                  # every view is non-zero on exactly one rank
+            grad_images = _call_loss_grad(loss_grad, images, list(range(n_views)))
+        else:
+            gi = _call_loss_grad(loss_grad, images[mine] if _wants_views(loss_grad) else images, mine)
+            grad_images = torch.zeros_like(images)
+            if mine:
+                grad_images[mine] = gi if gi.shape[0] == len(mine) else gi[mine]
+    if hasattr(ops, 'join_sweeps'):
+        ops.join_sweeps()
+    if split:
+        all_reduce_sum(film_g, group)
     for views, h in handles:
         ops.backward(h, film_g[views].contiguous(), grad_images[views].contiguous(), grad_grid)
-    all_reduce_gradients([grad_grid], group)
-    return images
+    work = all_reduce_gradients([grad_grid] + list(extra_grads), group, async_op=async_reduce)
+    return (images, work) if async_reduce else images
+
+
+def _wants_views(loss_grad):
+    import inspect
+    try:
+        return len(inspect.signature(loss_grad).parameters) >= 2
+    except (TypeError, ValueError):
+        return False
 
 
 class HipOps:
-    """The film-level operators of render_step on the HIP path (dsdf.render_film / develop / GradSweep)."""
+    """The film-level operators of render_step on the HIP path (dsdf.render_film / develop / GradSweep).  Sweeps run on a
+    side stream beside the primal films (two-stream schedule of dsdf.render_step); their workspaces (the backward queue
+    lives in them between sweep and backward) are kept and re-used by the next step's sweeps."""
 
-    def __init__(self, grid, sensors, spp, spp_grad, seeds, seeds_grad, integrator=0, **kw):
+    def __init__(self, grid, sensors, spp, spp_grad, seeds, seeds_grad, integrator=0, two_streams=True, **kw):
+        import torch
         from . import renderer
         self.r = renderer
         self.grid, self.sensors, self.spp, self.spp_grad = grid, list(sensors), int(spp), int(spp_grad)
-        self.seeds, self.seeds_grad, self.integrator, self.kw = list(seeds), list(seeds_grad), integrator, kw
+        self.integrator, self.kw = integrator, kw
+        self.kw_film = {k: v for k, v in kw.items() if k != 'grad_albedo'}
         self.W, self.H = self.sensors[0].film_size()
+        self.set_seeds(seeds, seeds_grad)
+        self._ws, self._next_ws = [], 0
+        self._side = torch.cuda.Stream(grid.device, priority=-1) if two_streams else None
+        self._in_sweeps = False
+
+    def set_seeds(self, seeds, seeds_grad):
+        self.seeds, self.seeds_grad = list(seeds), list(seeds_grad)
 
     def empty_film(self, n):
         return self.r.new_film(n, self.W, self.H, self.integrator, self.grid.device)
@@ -118,37 +182,86 @@ class HipOps:
     def film(self, views, rows):
         f = self.empty_film(len(views))
         return self.r.render_film(self.grid, [self.sensors[v] for v in views], self.spp, f, rows,
-                                  seeds=[self.seeds[v] for v in views], integrator=self.integrator, **self.kw)
+                                  seeds=[self.seeds[v] for v in views], integrator=self.integrator, **self.kw_film)
 
     def develop(self, film):
         return self.r.develop(film, self.W, self.H, self.integrator)
 
+    # ---- sweeps: on the side stream, between begin_sweeps() and end_sweeps(); joined before the backward
+    def begin_sweeps(self):
+        import torch
+        self._next_ws = 0
+        if self._side is not None:
+            self._side.wait_stream(torch.cuda.current_stream(self.grid.device))
+            self._in_sweeps = True
+
+    def end_sweeps(self):
+        self._in_sweeps = False
+
+    def join_sweeps(self):
+        import torch
+        if self._side is not None:
+            torch.cuda.current_stream(self.grid.device).wait_stream(self._side)
+
     def sweep(self, views, rows):
-        h = self.r.GradSweep(self.grid, [self.sensors[v] for v in views], self.spp_grad, rows,
-                             seeds=[self.seeds_grad[v] for v in views], integrator=self.integrator, **self.kw)
-        return h.sweep(self.empty_film(len(views))), h
+        import contextlib
+        import torch
+        ctx = torch.cuda.stream(self._side) if (self._side is not None and self._in_sweeps) else contextlib.nullcontext()
+        with ctx:
+            lend = self._ws[self._next_ws] if self._next_ws < len(self._ws) else None
+            h = self.r.GradSweep(self.grid, [self.sensors[v] for v in views], self.spp_grad, rows,
+                                 seeds=[self.seeds_grad[v] for v in views], integrator=self.integrator, workspace=lend, **self.kw)
+            if h.ws is not None:
+                if self._next_ws < len(self._ws):
+                    self._ws[self._next_ws] = h.ws
+                else:
+                    self._ws.append(h.ws)
+            self._next_ws += 1
+            film = h.sweep(self.empty_film(len(views)))
+        if self._side is not None:
+            main = torch.cuda.current_stream(self.grid.device)
+            film.record_stream(main)
+            h.record_stream(main)
+        return film, h
 
     def backward(self, handle, film_total, grad_image, grad_grid):
         handle.backward(film_total, grad_image, grad_grid)
 
 
-def all_reduce_gradients(tensors, group=None):
-    """Sums the given gradient tensors over all ranks in place with ONE collective."""
+def all_reduce_gradients(tensors, group=None, async_op=False, force=False):
+    """Sums the given gradient tensors over all ranks in place with ONE collective.  async_op: the collective is issued
+    non-blocking and a handle with .wait() is returned (None when there is nothing to reduce); several tensors are then
+    copied back from the flat bucket by wait().  force: issue the collective even in a world of one rank (exercises the
+    transport on a single GPU)."""
     import torch.distributed as dist
-    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
-        return tensors
     tensors = list(tensors)
+    if not dist.is_available() or not dist.is_initialized() or (dist.get_world_size(group) == 1 and not force):
+        return None if async_op else tensors
     if len(tensors) == 1 and tensors[0].is_contiguous():
-        dist.all_reduce(tensors[0], op=dist.ReduceOp.SUM, group=group)
-        return tensors
+        w = dist.all_reduce(tensors[0], op=dist.ReduceOp.SUM, group=group, async_op=async_op)
+        return w if async_op else tensors
     flat = torch.cat([t.reshape(-1) for t in tensors])
-    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
-    off = 0
-    for t in tensors:
-        n = t.numel()
-        t.copy_(flat[off:off + n].view_as(t))
-        off += n
-    return tensors
+    w = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
+
+    def unpack():
+        off = 0
+        for t in tensors:
+            n = t.numel()
+            t.copy_(flat[off:off + n].view_as(t))
+            off += n
+    if not async_op:
+        unpack()
+        return tensors
+    return _BucketWork(w, unpack)
+
+
+class _BucketWork:
+    def __init__(self, work, unpack):
+        self.work, self.unpack = work, unpack
+
+    def wait(self):
+        self.work.wait()
+        self.unpack()
 
 
 def broadcast_parameters(tensors, src=0, group=None):

@@ -48,7 +48,7 @@ def _worker(rank, world, port, out):
     dist.destroy_process_group()
 
 
-def _tile_worker(rank, world, port, out, n_views):
+def _tile_worker(rank, world, port, out, n_views, variant=False):
     """render_step (dsdf/parallel.py) with the ORACLE's film-level operators: the split by views and by pixel tiles, the two
     film sums and the gradient sum reproduce the single-process image and gradient."""
     for p in (os.path.join(ROOT, 'oracle'), os.path.join(ROOT, 'differentiable-sdf-rendering_amd', 'python'), os.path.join(ROOT, 'tests')):
@@ -93,7 +93,23 @@ def _tile_worker(rank, world, port, out, n_views):
                 grad_grid += leaf.grad
 
     g = torch.zeros(R, R, R, dtype=torch.float64)
-    images = parallel.render_step(Ops(), n_views, W, H, rank, world, lambda im: 2.0 * (im - tgt), g)
+    if variant:
+        # whole views without the image gather, loss gradient per owned view, a second gradient tensor in the bucket, and the
+        # non-blocking reduce
+        extra = torch.full((5,), float(rank + 1), dtype=torch.float64)
+        images, work = parallel.render_step(Ops(), n_views, W, H, rank, world, lambda im, views: 2.0 * (im - tgt[views]), g,
+                                            extra_grads=[extra], gather_images=False, async_reduce=True)
+        assert work is not None
+        work.wait()
+        assert float(extra[0]) == 3.0
+        mine = [v for v, _, _ in parallel.work_partition(n_views, H + 4, world)[rank]]
+        others = [v for v in range(n_views) if v not in mine]
+        assert float(images[others].abs().max()) == 0.0 if others else True
+        full = images.clone()
+        dist.all_reduce(full)
+        images = full
+    else:
+        images = parallel.render_step(Ops(), n_views, W, H, rank, world, lambda im: 2.0 * (im - tgt), g)
     if rank == 0:
         leaf = grid.clone().requires_grad_(True)
         ref = torch.stack([O.render(O.Grid3d(leaf), cams[v], W, H, spp, offs[v], integ) for v in range(n_views)])
@@ -122,6 +138,21 @@ def test_tile_split_equals_single_process(n_views):
         assert units == [(0, 0, 6)]                       # rank 0 renders rows [0, 6) of the 12-row film block of view 0
     if n_views == 2:
         assert units == [(0, 0, 12)]
+
+
+def test_whole_views_async_bucket_no_gather():
+    ctx = mp.get_context('spawn')
+    out = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000) + 91
+    procs = [ctx.Process(target=_tile_worker, args=(r, 2, port, out, 4, True)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=600)
+        assert p.exitcode == 0
+    err_img, err_g, mag, units = out.get(timeout=10)
+    assert mag > 0 and err_img < 1e-12 and err_g <= 1e-10 * max(mag, 1.0), (err_img, err_g, mag)
+    assert len(units) == 2
 
 
 def test_work_partition():
