@@ -340,7 +340,7 @@ def main():
                 ops.kw = dict(shade, **({'grad_albedo': galb} if galb is not None else {}))
                 _, work = parallel.render_step(ops, args.views, args.img, args.img, rank, world,
                                                lambda im, views: torch.sign(im - tgt[views]) * scale, grad, extra_grads=extra,
-                                               gather_images=False, async_reduce=True)
+                                               gather_images=False, async_reduce=True, force_reduce=dist is not None)
                 pending[b] = work
                 return
             if nv:

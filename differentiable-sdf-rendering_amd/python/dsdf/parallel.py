@@ -76,7 +76,7 @@ def _call_loss_grad(loss_grad, images, views):
 
 
 def render_step(ops, n_views, W, H, rank, world, loss_grad, grad_grid, group=None, extra_grads=(), gather_images=True,
-                async_reduce=False):
+                async_reduce=False, force_reduce=False):
     """One differentiable render of `n_views` views shared by `world` ranks, split by views and -- when world does not
     divide them -- by pixel tiles (work_partition).  `ops` supplies the four film-level operators of the renderer for a
     list of views and a row window (dsdf.render_film / develop / GradSweep on a GPU; the oracle's in the CPU tests):
@@ -143,7 +143,7 @@ def render_step(ops, n_views, W, H, rank, world, loss_grad, grad_grid, group=Non
         all_reduce_sum(film_g, group)
     for views, h in handles:
         ops.backward(h, film_g[views].contiguous(), grad_images[views].contiguous(), grad_grid)
-    work = all_reduce_gradients([grad_grid] + list(extra_grads), group, async_op=async_reduce)
+    work = all_reduce_gradients([grad_grid] + list(extra_grads), group, async_op=async_reduce, force=force_reduce)
     return (images, work) if async_reduce else images
 
 

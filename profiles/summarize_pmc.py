@@ -4,7 +4,11 @@ scene; separate passes, <= 8 SQ counters each, never combined with tracing domai
 profiles/<tag>_sq.json: per library kernel the per-launch counter values, launch duration in each pass, and the derived
 figures the VALU-issue roofline uses.
 
-  python profiles/summarize_pmc.py <tag> <dir with pmc_*/ subdirs>
+  python profiles/summarize_pmc.py <tag> <dir with pmc_*/ subdirs> [<pmc_stats.json written by tools/pmc_workload.py>]
+
+With the statistics file it also writes profiles/valu_model.json: VALU instructions per lock-step wave iteration of the
+primal render kernel and of the gradient sweep (SQ_INSTS_VALU of the one profiled call / the wave iterations the kernel counted
+on the same inputs) and the measured HBM bytes per call -- the only constants bench.py's roofline block uses.
 
 Derived (MI355X_MICROARCH.md: 256 CUs x 4 SIMD-32, wave64 VALU instruction = 2 clk; SQ_* are summed over the 32 SEs;
 SQ_CYCLES / 32 = shader clock ticks; SQ_WAVE_CYCLES in quad-cycles):
@@ -48,6 +52,7 @@ def main():
             n = len(disp[k])
             for c, v in agg[k].items():
                 res[k][c] = v / n
+                res[k].setdefault('per_call', {})[c] = v          # summed over the dispatches of the (one) library call
             res[k].setdefault('launch_ms', {})[p] = round(sum(disp[k].values()) / n, 4)
             res[k]['dispatches_per_pass'] = n
     for k, v in res.items():
@@ -70,6 +75,21 @@ def main():
                 d['hbm_bytes'] = (2 * v['FETCH_SIZE'] + v['WRITE_SIZE']) * 1024
                 d['hbm_GBps'] = d['hbm_bytes'] / t / 1e9
     json.dump(res, open(os.path.join(HERE, f'{tag}_sq.json'), 'w'), indent=1, sort_keys=True)
+    if len(sys.argv) > 3:
+        st = json.load(open(sys.argv[3]))
+        model = {'tag': tag, 'source': f'profiles/{tag}_sq.json', 'workload': 'tools/pmc_workload.py: bench scene, %d views x 512^2, spp %d/%d' % (st['views'], st['spp'][0], st['spp'][1])}
+        for name, kern, key in (('primal', 'k_render_items<false, false, false>', 'primal'), ('sweep', 'k_render_items<true, false, false>', 'grad')):
+            v = res.get(kern)
+            if not v or 'SQ_INSTS_VALU' not in v.get('per_call', {}):
+                continue
+            valu, ws = v['per_call']['SQ_INSTS_VALU'], st[key]['wave_steps']
+            m = {'kernel': kern, 'valu_insts_per_launch': valu, 'wave_steps_per_launch': ws, 'valu_per_wave_step': valu / ws,
+                 'launch_ms': sum(v.get('launch_ms', {}).values()) / max(len(v.get('launch_ms', {})), 1) * v.get('dispatches_per_pass', 1)}
+            if 'FETCH_SIZE' in v['per_call'] and 'WRITE_SIZE' in v['per_call']:
+                m['hbm_bytes_per_launch'] = (2 * v['per_call']['FETCH_SIZE'] + v['per_call']['WRITE_SIZE']) * 1024
+            model[name] = m
+        json.dump(model, open(os.path.join(HERE, 'valu_model.json'), 'w'), indent=1, sort_keys=True)
+        print('valu_model', json.dumps(model))
     for k, v in res.items():
         if 'derived' in v:
             print(k, json.dumps({a: round(b, 4) for a, b in v['derived'].items()}), v['launch_ms'])
