@@ -4,13 +4,17 @@
 
 // ------------------------------------------------------------------ redistancing
 // |grad u| = 1 with a frozen sub-voxel interface band (spec: include/dsdf.h, dsdf_redistance).
-// Block-iterative solver: a 512-thread block relaxes an 8^3 tile (+1 halo) in LDS for 8 inner
-// Jacobi passes per launch (Godunov upwind update, monotone => same fixed point as fast sweeping);
-// launches are chained without host synchronisation through three rotating "changed" flags:
-// launch i returns immediately once launch i-1 reported no change.
+// Block-iterative solver (a fast iterative method): a 512-thread block relaxes an 8^3 tile (+1 halo) in LDS for 8 inner
+// Jacobi passes (Godunov upwind update, monotone => same fixed point as fast sweeping).  Work follows the moving front through
+// a device-side ACTIVE-TILE LIST: round r relaxes the tiles of list r and appends every tile that changed, and its six
+// neighbours, to list r + 1 (de-duplicated with a per-tile round stamp).  A round is one launch of a FIXED grid of
+// DSDF_RD_BLOCKS persistent blocks that stride over the list; a round whose list is empty returns at once (converged).
+// (Rounds 1-2 launched one block per TILE per round -- 32 768 blocks at 256^3, 262 144 at 512^3, 128 / 248 times, almost all of
+// them exiting after reading their neighbours' flags: 17 ms / 185 ms.)  Launches are chained without host synchronisation.
 #define DSDF_RD_BIG 1e10f
 #define DSDF_RD_TILE 8
 #define DSDF_RD_INNER 8
+#define DSDF_RD_BLOCKS 2048
 
 __device__ __forceinline__ float eikonal_update(float a, float b, float c, float ha, float hb, float hc) {
     // sort (value, spacing) ascending by value
@@ -34,7 +38,7 @@ __global__ void k_redist_init(const float *__restrict__ phi, int rx, int ry, int
                               unsigned char *__restrict__ frozen, unsigned int *flags) {
     size_t n = (size_t)rx * ry * rz;
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i == 0) { flags[0] = 0; flags[1] = 0; flags[2] = 0; flags[4] = 0; flags[5] = 0; }     // [4]: last launch that changed a value, [5]: status
+    if (i == 0) { flags[0] = 0; flags[1] = 0; flags[2] = 0; flags[4] = 0; flags[5] = 0; }     // [0..2]: list counters, [4]: rounds that did work, [5]: status
     if (i >= n) return;
     int x = (int)(i % rx); size_t r = i / rx; int y = (int)(r % ry), z = (int)(r / ry);
     float p = phi[i];
@@ -59,85 +63,88 @@ __global__ void k_redist_init(const float *__restrict__ phi, int rx, int ry, int
     frozen[i] = any ? 1 : 0;
 }
 
-// `tmap` holds three rotating per-tile "changed" maps: launch i reads map (i-1), writes map i and
-// clears map (i+1); a tile is relaxed only if it or one of its 6 neighbours changed in launch i-1,
-// so work follows the moving front instead of sweeping the whole grid every launch.
-__global__ __launch_bounds__(512) void k_redist_iter(float *__restrict__ u, const unsigned char *__restrict__ frozen,
-                                                     int rx, int ry, int rz, unsigned int *flags,
-                                                     unsigned char *__restrict__ tmap, int iter) {
-    if (iter > 0 && flags[(iter + 2) % 3] == 0) return;       // previous launch changed nothing: converged
+// flags: [0..2] rotating list counters (round r reads [r % 3], fills [(r + 1) % 3], clears [(r + 2) % 3]); [4] rounds that did
+// work; [5] status.  lists: two buffers of one entry per tile; round 0 takes every tile (list = nullptr).
+__global__ __launch_bounds__(512) void k_redist_round(float *__restrict__ u, const unsigned char *__restrict__ frozen,
+                                                      int rx, int ry, int rz, int ntx, int nty, int ntz, unsigned int *flags,
+                                                      unsigned int *__restrict__ stamp, const unsigned int *__restrict__ list_in,
+                                                      unsigned int *__restrict__ list_out, int round) {
     const int T = DSDF_RD_TILE, S = T + 2;
-    const int ntx = gridDim.x, nty = gridDim.y, ntz = gridDim.z;
-    const size_t ntiles = (size_t)ntx * nty * ntz;
-    const size_t tid = ((size_t)blockIdx.z * nty + blockIdx.y) * ntx + blockIdx.x;
-    unsigned char *prev = tmap + (size_t)((iter + 2) % 3) * ntiles, *cur_map = tmap + (size_t)(iter % 3) * ntiles,
-                  *next = tmap + (size_t)((iter + 1) % 3) * ntiles;
-    if (threadIdx.x == 0) {
-        next[tid] = 0;
-        if (tid == 0) flags[(iter + 1) % 3] = 0;
-    }
-    if (iter > 0) {
-        bool act = prev[tid];
-        if (blockIdx.x > 0) act = act || prev[tid - 1];
-        if ((int)blockIdx.x < ntx - 1) act = act || prev[tid + 1];
-        if (blockIdx.y > 0) act = act || prev[tid - ntx];
-        if ((int)blockIdx.y < nty - 1) act = act || prev[tid + ntx];
-        if (blockIdx.z > 0) act = act || prev[tid - (size_t)ntx * nty];
-        if ((int)blockIdx.z < ntz - 1) act = act || prev[tid + (size_t)ntx * nty];
-        if (!act) return;                                     // block-uniform
-    }
+    const unsigned ntiles = (unsigned)ntx * nty * ntz;
+    const unsigned count = round == 0 ? ntiles : flags[round % 3];
+    if (blockIdx.x == 0 && threadIdx.x == 0) flags[(round + 2) % 3] = 0;
+    if (count == 0) return;                                      // the previous round changed nothing: converged
+    if (blockIdx.x == 0 && threadIdx.x == 0) flags[4] = (unsigned)round + 1u;
+    unsigned int *count_out = flags + (round + 1) % 3;
     __shared__ float tile[S * S * S];
     __shared__ int tile_changed;
-    if (threadIdx.x == 0) tile_changed = 0;
-    const int x0 = blockIdx.x * T, y0 = blockIdx.y * T, z0 = blockIdx.z * T;
-    for (int e = threadIdx.x; e < S * S * S; e += 512) {
-        int lx = e % S, ly = (e / S) % S, lz = e / (S * S);
-        int gx = x0 + lx - 1, gy = y0 + ly - 1, gz = z0 + lz - 1;
-        bool in = gx >= 0 && gx < rx && gy >= 0 && gy < ry && gz >= 0 && gz < rz;
-        tile[e] = in ? u[((size_t)gz * ry + gy) * rx + gx] : DSDF_RD_BIG;
-    }
     const int lx = threadIdx.x % T, ly = (threadIdx.x / T) % T, lz = threadIdx.x / (T * T);
-    const int gx = x0 + lx, gy = y0 + ly, gz = z0 + lz;
-    const bool in = gx < rx && gy < ry && gz < rz;
-    const size_t gi = ((size_t)gz * ry + gy) * rx + gx;
-    const bool fixed = !in || frozen[gi];
     const int c = ((lz + 1) * S + (ly + 1)) * S + (lx + 1);
     const float hx = 1.f / rx, hy = 1.f / ry, hz = 1.f / rz;
-    __syncthreads();
-    const float start = tile[c];
-    float cur = start;
-    for (int it = 0; it < DSDF_RD_INNER; ++it) {
-        float a = fminf(tile[c - 1], tile[c + 1]);
-        float b = fminf(tile[c - S], tile[c + S]);
-        float d = fminf(tile[c - S * S], tile[c + S * S]);
-        float un = cur;
-        if (!fixed && fminf(a, fminf(b, d)) < DSDF_RD_BIG) un = fminf(cur, eikonal_update(a, b, d, hx, hy, hz));
+    for (unsigned w = blockIdx.x; w < count; w += gridDim.x) {
+        const unsigned tid = round == 0 ? w : list_in[w];
+        const int tx = (int)(tid % (unsigned)ntx), ty = (int)((tid / (unsigned)ntx) % (unsigned)nty), tz = (int)(tid / ((unsigned)ntx * nty));
+        const int x0 = tx * T, y0 = ty * T, z0 = tz * T;
+        __syncthreads();                                         // (the tile of the previous list entry is no longer read)
+        if (threadIdx.x == 0) tile_changed = 0;
+        for (int e = threadIdx.x; e < S * S * S; e += 512) {
+            int ex = e % S, ey = (e / S) % S, ez = e / (S * S);
+            int gx = x0 + ex - 1, gy = y0 + ey - 1, gz = z0 + ez - 1;
+            bool in = gx >= 0 && gx < rx && gy >= 0 && gy < ry && gz >= 0 && gz < rz;
+            tile[e] = in ? u[((size_t)gz * ry + gy) * rx + gx] : DSDF_RD_BIG;
+        }
+        const int gx = x0 + lx, gy = y0 + ly, gz = z0 + lz;
+        const bool in = gx < rx && gy < ry && gz < rz;
+        const size_t gi = ((size_t)gz * ry + gy) * rx + gx;
+        const bool fixed = !in || frozen[gi];
         __syncthreads();
-        if (un < cur) { cur = un; tile[c] = un; }
+        const float start = tile[c];
+        float cur = start;
+        for (int it = 0; it < DSDF_RD_INNER; ++it) {
+            float a = fminf(tile[c - 1], tile[c + 1]);
+            float b = fminf(tile[c - S], tile[c + S]);
+            float d = fminf(tile[c - S * S], tile[c + S * S]);
+            float un = cur;
+            if (!fixed && fminf(a, fminf(b, d)) < DSDF_RD_BIG) un = fminf(cur, eikonal_update(a, b, d, hx, hy, hz));
+            __syncthreads();
+            if (un < cur) { cur = un; tile[c] = un; }
+            __syncthreads();
+        }
+        if (cur < start) { u[gi] = cur; tile_changed = 1; }
         __syncthreads();
+        if (tile_changed && threadIdx.x < 7) {
+            // this tile and its six neighbours go on the next round's list, once each (round stamp)
+            const int k = threadIdx.x;
+            const int nx = tx + (k == 1) - (k == 2), ny = ty + (k == 3) - (k == 4), nz = tz + (k == 5) - (k == 6);
+            if (nx >= 0 && nx < ntx && ny >= 0 && ny < nty && nz >= 0 && nz < ntz) {
+                const unsigned nb = ((unsigned)nz * nty + ny) * ntx + nx;
+                if (atomicExch(stamp + nb, (unsigned)round + 1u) != (unsigned)round + 1u) list_out[atomicAdd(count_out, 1u)] = nb;
+            }
+        }
     }
-    if (cur < start) { u[gi] = cur; tile_changed = 1; }
-    __syncthreads();
-    if (threadIdx.x == 0 && tile_changed) { cur_map[tid] = 1; flags[iter % 3] = 1; atomicMax(flags + 4, (unsigned)iter + 1u); }
 }
 
-// status (flags[5]): 0 = the relaxation reached its fixed point (the last launch changed nothing), 1 = the launch budget ran out
-// while values were still moving -- the result is then an upper bound of the distance, not the fixed point.
+// status (flags[5]): 0 = the relaxation reached its fixed point (a round found its list empty, or the last round left none),
+// 1 = the round budget ran out while values were still moving -- the result is then an upper bound of the distance, not the
+// fixed point.
 __global__ void k_redist_finish(const float *__restrict__ phi, const float *__restrict__ u, size_t n, float *__restrict__ out,
                                 unsigned int *flags, unsigned max_iter) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i == 0) flags[5] = flags[4] >= max_iter ? 1u : 0u;
+    if (i == 0) flags[5] = (flags[4] >= max_iter && flags[max_iter % 3] != 0u) ? 1u : 0u;
     if (i < n) out[i] = phi[i] < 0.f ? -u[i] : u[i];
 }
 
 extern "C" {
 
+static size_t redist_tiles(int rx, int ry, int rz) {
+    return (size_t)((rx + DSDF_RD_TILE - 1) / DSDF_RD_TILE) * ((ry + DSDF_RD_TILE - 1) / DSDF_RD_TILE) * ((rz + DSDF_RD_TILE - 1) / DSDF_RD_TILE);
+}
+
 size_t dsdf_redistance_workspace_size(int rx, int ry, int rz) {
     if (rx < 1 || ry < 1 || rz < 1) return 0;
     size_t n = (size_t)rx * ry * rz;
-    size_t ntiles = (size_t)((rx + DSDF_RD_TILE - 1) / DSDF_RD_TILE) * ((ry + DSDF_RD_TILE - 1) / DSDF_RD_TILE) *
-                    ((rz + DSDF_RD_TILE - 1) / DSDF_RD_TILE);
-    return align_up(n * sizeof(float), 256) + align_up(n, 256) + 256 + align_up(3 * ntiles, 256);
+    // u | frozen | flags | round stamps | two tile lists
+    return align_up(n * sizeof(float), 256) + align_up(n, 256) + 256 + 3 * align_up(redist_tiles(rx, ry, rz) * sizeof(unsigned int), 256);
 }
 
 int dsdf_redistance(const float *phi, int rx, int ry, int rz, float *out, void *workspace, size_t workspace_bytes,
@@ -146,24 +153,29 @@ int dsdf_redistance(const float *phi, int rx, int ry, int rz, float *out, void *
     if (workspace_bytes < dsdf_redistance_workspace_size(rx, ry, rz)) return fail(DSDF_ERR_WORKSPACE, "workspace too small");
     hipStream_t st = (hipStream_t)stream;
     size_t n = (size_t)rx * ry * rz;
+    const int ntx = (rx + DSDF_RD_TILE - 1) / DSDF_RD_TILE, nty = (ry + DSDF_RD_TILE - 1) / DSDF_RD_TILE, ntz = (rz + DSDF_RD_TILE - 1) / DSDF_RD_TILE;
+    const size_t ntiles = redist_tiles(rx, ry, rz), lbytes = align_up(ntiles * sizeof(unsigned int), 256);
     char *p = (char *)workspace;
     float *u = (float *)p; p += align_up(n * sizeof(float), 256);
     unsigned char *frozen = (unsigned char *)p; p += align_up(n, 256);
     unsigned int *flags = (unsigned int *)p; p += 256;
-    unsigned char *tmap = (unsigned char *)p;
-    dim3 tiles((rx + DSDF_RD_TILE - 1) / DSDF_RD_TILE, (ry + DSDF_RD_TILE - 1) / DSDF_RD_TILE, (rz + DSDF_RD_TILE - 1) / DSDF_RD_TILE);
+    unsigned int *stamp = (unsigned int *)p; p += lbytes;
+    unsigned int *lists[2] = {(unsigned int *)p, (unsigned int *)(p + lbytes)};
     int rc;
-    if (hipMemsetAsync(tmap, 0, 3 * (size_t)tiles.x * tiles.y * tiles.z, st) != hipSuccess)
-        return fail(DSDF_ERR_LAUNCH, "hipMemsetAsync(tile map) failed");
+    if (hipMemsetAsync(stamp, 0, ntiles * sizeof(unsigned int), st) != hipSuccess)
+        return fail(DSDF_ERR_LAUNCH, "hipMemsetAsync(tile stamps) failed");
     hipLaunchKernelGGL(k_redist_init, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, phi, rx, ry, rz, u, frozen, flags);
     if ((rc = check_launch("k_redist_init"))) return rc;
-    // information crosses at least one tile per launch (Manhattan tile distance <= sum of the tile
-    // counts); 25 % margin, converged launches return at once.  Whether the budget sufficed is recorded on the device
+    // information crosses at least one tile per round (Manhattan tile distance <= sum of the tile counts); 25 % margin,
+    // rounds with an empty list return at once.  Whether the budget sufficed is recorded on the device
     // (dsdf_redistance_status) -- the library never synchronises.
-    int max_iter = (int)(tiles.x + tiles.y + tiles.z) + (int)(tiles.x + tiles.y + tiles.z) / 4 + 8;
+    const int max_iter = (ntx + nty + ntz) + (ntx + nty + ntz) / 4 + 8;
+    const unsigned blocks = ntiles < DSDF_RD_BLOCKS ? (unsigned)ntiles : DSDF_RD_BLOCKS;
     for (int it = 0; it < max_iter; ++it) {
-        hipLaunchKernelGGL(k_redist_iter, tiles, dim3(512), 0, st, u, frozen, rx, ry, rz, flags, tmap, it);
-        if ((rc = check_launch("k_redist_iter"))) return rc;
+        // round `it` reads lists[it & 1] (round 0: every tile) and fills lists[(it + 1) & 1]
+        hipLaunchKernelGGL(k_redist_round, dim3(blocks), dim3(512), 0, st, u, frozen, rx, ry, rz, ntx, nty, ntz, flags, stamp,
+                           (const unsigned int *)lists[it & 1], lists[(it + 1) & 1], it);
+        if ((rc = check_launch("k_redist_round"))) return rc;
     }
     hipLaunchKernelGGL(k_redist_finish, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, phi, u, n, out, flags, (unsigned)max_iter);
     return check_launch("k_redist_finish");

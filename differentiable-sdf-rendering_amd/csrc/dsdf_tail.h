@@ -27,7 +27,7 @@
 #define DSDF_PTAIL_HANDOFF 8        /* the same two for the primal (value-only) march */
 #endif
 #ifndef DSDF_PTAIL_GRACE
-#define DSDF_PTAIL_GRACE 2
+#define DSDF_PTAIL_GRACE 4
 #endif
 #define DSDF_TAIL_SUBQ 64           /* sub-queues per launch: spreads the reservation atomics */
 #define DSDF_TAIL_REFILL 24         /* idle lanes that trigger a refill in the tail kernels */

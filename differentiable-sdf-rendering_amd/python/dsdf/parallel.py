@@ -102,13 +102,10 @@ def render_step(ops, n_views, W, H, rank, world, loss_grad, grad_grid, group=Non
     # ---- gradient-pass sweeps first: independent of the primal images (HIP: a side stream)
     if hasattr(ops, 'begin_sweeps'):
         ops.begin_sweeps()
-    film_g, handles = None, []
+    swept = []
     for rows, views in wins:
         f, h = ops.sweep(views, rows)
-        if film_g is None:
-            film_g = torch.zeros((n_views,) + tuple(f.shape[1:]), dtype=f.dtype, device=f.device)
-        film_g[views] += f
-        handles.append((views, h))
+        swept.append((views, f, h))                       # (the films are summed after join_sweeps(): they may still be in flight)
     if hasattr(ops, 'end_sweeps'):
         ops.end_sweeps()
     # ---- primal films
@@ -120,7 +117,6 @@ def render_step(ops, n_views, W, H, rank, world, loss_grad, grad_grid, group=Non
         film[views] += f
     if film is None:
         film = ops.empty_film(n_views)
-        film_g = torch.zeros_like(film)
     if split:
         all_reduce_sum(film, group)
         images = ops.develop(film)
@@ -139,6 +135,10 @@ def render_step(ops, n_views, W, H, rank, world, loss_grad, grad_grid, group=Non
                 grad_images[mine] = gi if gi.shape[0] == len(mine) else gi[mine]
     if hasattr(ops, 'join_sweeps'):
         ops.join_sweeps()
+    film_g, handles = torch.zeros_like(film), []
+    for views, f, h in swept:
+        film_g[views] += f
+        handles.append((views, h))
     if split:
         all_reduce_sum(film_g, group)
     for views, h in handles:
