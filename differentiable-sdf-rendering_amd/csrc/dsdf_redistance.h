@@ -4,16 +4,17 @@
 
 // ------------------------------------------------------------------ redistancing
 // |grad u| = 1 with a frozen sub-voxel interface band (spec: include/dsdf.h, dsdf_redistance).
-// Block-iterative solver (a fast iterative method): a 512-thread block relaxes an 8^3 tile (+1 halo) in LDS for 8 inner
-// Jacobi passes (Godunov upwind update, monotone => same fixed point as fast sweeping).  Work follows the moving front through
-// a device-side ACTIVE-TILE LIST: round r relaxes the tiles of list r and appends every tile that changed, and its six
-// neighbours, to list r + 1 (de-duplicated with a per-tile round stamp).  A round is one launch of a FIXED grid of
+// Block-iterative solver (a fast iterative method): a 512-thread block relaxes an 8^3 tile (+1 halo) in LDS with Jacobi
+// passes UNTIL THE TILE IS CONSISTENT WITH ITS HALO (Godunov upwind update, monotone => same fixed point as fast sweeping).
+// Work follows the moving front through a device-side ACTIVE-TILE LIST: round r relaxes the tiles of list r and appends to
+// list r + 1 the neighbours across every FACE on which a value changed (and the tile itself if the pass cap cut it short),
+// de-duplicated with a per-tile round stamp.  A round is one launch of a FIXED grid of
 // DSDF_RD_BLOCKS persistent blocks that stride over the list; a round whose list is empty returns at once (converged).
 // (Rounds 1-2 launched one block per TILE per round -- 32 768 blocks at 256^3, 262 144 at 512^3, 128 / 248 times, almost all of
 // them exiting after reading their neighbours' flags: 17 ms / 185 ms.)  Launches are chained without host synchronisation.
 #define DSDF_RD_BIG 1e10f
 #define DSDF_RD_TILE 8
-#define DSDF_RD_INNER 8
+#define DSDF_RD_INNER 48      /* cap of the Jacobi passes on a tile in LDS; the loop ends as soon as a pass changes nothing */
 #define DSDF_RD_BLOCKS 2048
 
 __device__ __forceinline__ float eikonal_update(float a, float b, float c, float ha, float hb, float hc) {
@@ -100,25 +101,34 @@ __global__ __launch_bounds__(512) void k_redist_round(float *__restrict__ u, con
         __syncthreads();
         const float start = tile[c];
         float cur = start;
-        for (int it = 0; it < DSDF_RD_INNER; ++it) {
+        int more = 1;
+        for (int it = 0; it < DSDF_RD_INNER && more; ++it) {
             float a = fminf(tile[c - 1], tile[c + 1]);
             float b = fminf(tile[c - S], tile[c + S]);
             float d = fminf(tile[c - S * S], tile[c + S * S]);
             float un = cur;
             if (!fixed && fminf(a, fminf(b, d)) < DSDF_RD_BIG) un = fminf(cur, eikonal_update(a, b, d, hx, hy, hz));
             __syncthreads();
-            if (un < cur) { cur = un; tile[c] = un; }
-            __syncthreads();
+            const int ch = un < cur;
+            if (ch) { cur = un; tile[c] = un; }
+            more = __syncthreads_or(ch);
         }
-        if (cur < start) { u[gi] = cur; tile_changed = 1; }
+        // which neighbours must look again: those across a face on which a value moved; this tile itself when the cap hit
+        int bits = (more && threadIdx.x == 0) ? 64 : 0;
+        if (cur < start) {
+            u[gi] = cur;
+            bits |= (lx == 0 ? 2 : 0) | (lx == T - 1 ? 1 : 0) | (ly == 0 ? 8 : 0) | (ly == T - 1 ? 4 : 0) | (lz == 0 ? 32 : 0) | (lz == T - 1 ? 16 : 0);
+        }
+        if (bits) atomicOr(&tile_changed, bits);
         __syncthreads();
-        if (tile_changed && threadIdx.x < 7) {
-            // this tile and its six neighbours go on the next round's list, once each (round stamp)
-            const int k = threadIdx.x;
-            const int nx = tx + (k == 1) - (k == 2), ny = ty + (k == 3) - (k == 4), nz = tz + (k == 5) - (k == 6);
-            if (nx >= 0 && nx < ntx && ny >= 0 && ny < nty && nz >= 0 && nz < ntz) {
-                const unsigned nb = ((unsigned)nz * nty + ny) * ntx + nx;
-                if (atomicExch(stamp + nb, (unsigned)round + 1u) != (unsigned)round + 1u) list_out[atomicAdd(count_out, 1u)] = nb;
+        if (threadIdx.x < 7) {
+            const int k = threadIdx.x;          // 0..5: +x, -x, +y, -y, +z, -z; 6: this tile
+            if (tile_changed & (1 << k)) {
+                const int nx = tx + (k == 0) - (k == 1), ny = ty + (k == 2) - (k == 3), nz = tz + (k == 4) - (k == 5);
+                if (nx >= 0 && nx < ntx && ny >= 0 && ny < nty && nz >= 0 && nz < ntz) {
+                    const unsigned nb = ((unsigned)nz * nty + ny) * ntx + nx;
+                    if (atomicExch(stamp + nb, (unsigned)round + 1u) != (unsigned)round + 1u) list_out[atomicAdd(count_out, 1u)] = nb;
+                }
             }
         }
     }

@@ -54,20 +54,23 @@ def render_backward(lib, grid, cam16, W, H, spp, offsets, grad_image, integrator
     return gg, img
 
 
-def render_direct(lib, grid, cam16, W, H, spp, offsets, emitter_u, albedo, env=(1.0, 1.0, 1.0), hide_emitters=False):
+def render_direct(lib, grid, cam16, W, H, spp, offsets, emitter_u, albedo, env=(1.0, 1.0, 1.0), hide_emitters=False, bsdf_u=None):
+    """bsdf_u (n,2): use_mis = True with these next_2d() samples of the BSDF-sampling branch."""
     grid = np.ascontiguousarray(grid, _dt(lib)); offsets = np.ascontiguousarray(offsets, _dt(lib))
     cam16 = np.ascontiguousarray(cam16, _dt(lib)); emitter_u = np.ascontiguousarray(emitter_u, _dt(lib))
     albedo = np.ascontiguousarray(albedo, _dt(lib)); env = np.asarray(env, _dt(lib))
     img = np.zeros((H, W, 3), _dt(lib))
     rz, ry, rx = grid.shape
     az, ay, ax = albedo.shape[:3]
+    bu = None if bsdf_u is None else np.ascontiguousarray(bsdf_u, _dt(lib))
     lib.o_render_direct(_p(grid), rx, ry, rz, _p(cam16), W, H, spp, _p(offsets), _p(emitter_u), _p(albedo), ax, ay, az,
-                        _p(env), int(hide_emitters), _p(img))
+                        _p(env), int(hide_emitters), _p(img), int(bu is not None), _p(bu))
     return img
 
 
 def render_direct_backward(lib, grid, cam16, W, H, spp, offsets, emitter_u, albedo, grad_image, env=(1.0, 1.0, 1.0),
-                           hide_emitters=False, reparam=True):
+                           hide_emitters=False, reparam=True, bsdf_u=None, variant=0):
+    """bsdf_u: use_mis (see render_direct); variant 1 = detach_indirect_si, 2 = decouple_reparam."""
     grid = np.ascontiguousarray(grid, _dt(lib)); offsets = np.ascontiguousarray(offsets, _dt(lib))
     cam16 = np.ascontiguousarray(cam16, _dt(lib)); emitter_u = np.ascontiguousarray(emitter_u, _dt(lib))
     albedo = np.ascontiguousarray(albedo, _dt(lib)); env = np.asarray(env, _dt(lib))
@@ -76,8 +79,10 @@ def render_direct_backward(lib, grid, cam16, W, H, spp, offsets, emitter_u, albe
     img = np.zeros((H, W, 3), _dt(lib))
     rz, ry, rx = grid.shape
     az, ay, ax = albedo.shape[:3]
+    bu = None if bsdf_u is None else np.ascontiguousarray(bsdf_u, _dt(lib))
     lib.o_render_direct_backward(_p(grid), rx, ry, rz, _p(cam16), W, H, spp, _p(offsets), _p(emitter_u), _p(albedo), ax, ay, az,
-                                 _p(env), int(hide_emitters), int(reparam), _p(gi), _p(gg), _p(ga), _p(img))
+                                 _p(env), int(hide_emitters), int(reparam), _p(gi), _p(gg), _p(ga), _p(img), int(bu is not None), _p(bu),
+                                 int(variant))
     return gg, ga, img
 
 

@@ -529,24 +529,73 @@ static void develop4(const real *block, int W, int H, real *img) {
     }
 }
 
-/* one sample's radiance; ts = shadow-ray trace (its_t = inf <=> unoccluded); returns 1 when lit */
-static int direct_sample(const grid_t *G, const vol3_t *A, const ray_t *r, real its_t, const real *u, const real *env,
-                         int hide, int diff, dhit_t *h, trace_t *ts, real *rgb, real *alb, real ag[3][3], size_t *tix, real *tw) {
-    rgb[0] = rgb[1] = rgb[2] = 0.f;
+/* sdf_direct_reparam.py:77-105 (use_mis): BSDF sampling of the `diffuse` BSDF -- cosine-weighted hemisphere direction
+ * (mitsuba warp.h square_to_cosine_hemisphere: concentric disk), local frame of the detached hit (vector.h coordinate_system),
+ * ray spawned from the attached hit point (interaction.h spawn_ray / offset_p), power-heuristic weights
+ * (mitsuba.ad.integrators.common.mis_weight, detached). */
+#define INV_4PI 0.07957747154594767f
+#define INV_PI 0.3183098861837907f
+typedef struct { int active; real o[3], d[3], woz, pdf; } bray_t;
+
+static real mis_w(real a, real b) { return a > 0.f ? a*a/(b*b + a*a) : 0.f; }
+
+static void bsdf_setup(const ray_t *r, const dhit_t *h, const real *u, bray_t *b) {
+    real x = 2.f*u[0] - 1.f, y = 2.f*u[1] - 1.f;
+    int zero = (x == 0.f && y == 0.f), q13 = fabsf(x) < fabsf(y);
+    real rr = q13 ? y : x, rp = q13 ? x : y;
+    real phi = zero ? 0.f : 0.7853981633974483f*rp/rr;
+    if (q13) phi = 1.5707963267948966f - phi;
+    if (zero) phi = 0.f;
+    real wx = rr*cosf(phi), wy = rr*sinf(phi), wz = sqrtf(fmaxf(1.f - wx*wx - wy*wy, 0.f));
+    const real *n = h->n;
+    real sign = n[2] >= 0.f ? 1.f : -1.f, a = -1.f/(sign + n[2]), bb = n[0]*n[1]*a;
+    real sv[3] = { sign*(n[0]*n[0]*a) + 1.f, sign*bb, -sign*n[0] }, tv[3] = { bb, n[1]*(n[1]*a) + sign, -n[1] };
+    for (int k = 0; k < 3; ++k) b->d[k] = sv[k]*wx + tv[k]*wy + n[k]*wz;
+    real mag = (1.f + fmaxf(fabsf(h->p[0]), fmaxf(fabsf(h->p[1]), fabsf(h->p[2]))))*RAY_EPSILON;
+    if (dot3(n, b->d) < 0.f) mag = -mag;
+    for (int k = 0; k < 3; ++k) b->o[k] = h->p[k] + mag*n[k];
+    b->woz = wz; b->pdf = wz*INV_PI;
+    real md[3] = { -r->d[0], -r->d[1], -r->d[2] };
+    b->active = dot3(n, md) > 0.f && b->pdf > 0.f;
+}
+
+/* one sample's radiance; ts = shadow-ray trace (its_t = inf <=> unoccluded), tb = trace of the BSDF-sampled ray (use_mis).
+ * kk[0] = factor of alb*env in the emitter-sampling term (4 cos_o [* mis weight]) or 0, kk[1] = the same for the
+ * BSDF-sampling term ((wo.z / pi) / pdf * mis weight) or 0.  Returns bit 0: emitter sampling lit, bit 1: BSDF sampling lit */
+static int direct_sample(const grid_t *G, const vol3_t *A, const ray_t *r, real its_t, const real *u, const real *bu, int use_mis,
+                         const real *env, int hide, int diff, dhit_t *h, trace_t *ts, bray_t *br, trace_t *tb, real *kk,
+                         real *rgb, real *alb, real ag[3][3], size_t *tix, real *tw) {
+    rgb[0] = rgb[1] = rgb[2] = 0.f; kk[0] = kk[1] = 0.f;
     if (!(its_t < INFINITY)) { if (!hide) { rgb[0] = env[0]; rgb[1] = env[1]; rgb[2] = env[2]; } return 0; }
     direct_setup(G, r, its_t, u, h);
-    if (!h->front) return 0;
-    trace(G, h->so, h->sd, h->smaxt, diff, ts);
-    if (ts->its_t < INFINITY) return 0;
+    int lit = 0;
+    if (h->front) {
+        trace(G, h->so, h->sd, h->smaxt, diff, ts);
+        if (!(ts->its_t < INFINITY)) {
+            real cos_o = dot3(h->n, h->sd);
+            kk[0] = 4.f*cos_o*(use_mis ? mis_w(INV_4PI, cos_o*INV_PI) : 1.f);
+            lit |= 1;
+        }
+    }
+    if (use_mis) {
+        bsdf_setup(r, h, bu, br);
+        if (br->active) {
+            trace(G, br->o, br->d, 1e30f, diff, tb);
+            if (!(tb->its_t < INFINITY)) {                              /* escaped: the environment, emitter pdf 1/(4 pi) */
+                kk[1] = br->woz*INV_PI/br->pdf*mis_w(br->pdf, INV_4PI);
+                lit |= 2;
+            }
+        }
+    }
+    if (!lit) return 0;
     trilinear(A, h->p, alb, ag, tix, tw);
-    real k = 4.f*dot3(h->n, h->sd);
-    for (int c = 0; c < 3; ++c) rgb[c] = alb[c]*k*env[c];
-    return 1;
+    for (int c = 0; c < 3; ++c) rgb[c] = alb[c]*kk[0]*env[c] + alb[c]*kk[1]*env[c];
+    return lit;
 }
 
 void o_render_direct(const real *grid, int rx, int ry, int rz, const real *cam, int W, int H, int spp, const real *offsets,
                      const real *emitter_u, const real *albedo, int ax, int ay, int az, const real *env, int hide,
-                     real *image) {
+                     real *image, int use_mis, const real *bsdf_u) {
     grid_t G = { grid, rx, ry, rz };
     vol3_t A = { albedo, ax, ay, az };
     int Wb = W + 2*BORDER, Hb = H + 2*BORDER;
@@ -554,10 +603,11 @@ void o_render_direct(const real *grid, int rx, int ry, int rz, const real *cam, 
     real *block = (real *)calloc((size_t)4*Wb*Hb, sizeof(real));
 #pragma omp parallel for schedule(dynamic, 256)
     for (long lane = 0; lane < n; ++lane) {
-        ray_t r; trace_t t, ts; dhit_t h; real rgb[3], alb[3], ag[3][3], tw[8], uv[2], ref[3]; size_t tix[8];
+        ray_t r; trace_t t, ts, tb; dhit_t h; bray_t br; real rgb[3], alb[3], ag[3][3], tw[8], uv[2], ref[3], kk[2]; size_t tix[8];
         lane_ray(cam, W, H, spp, offsets, lane, &r);
         trace(&G, r.o, r.d, r.maxt, 0, &t);
-        direct_sample(&G, &A, &r, t.its_t, emitter_u + 2*lane, env, hide, 0, &h, &ts, rgb, alb, ag, tix, tw);
+        direct_sample(&G, &A, &r, t.its_t, emitter_u + 2*lane, use_mis ? bsdf_u + 2*lane : NULL, use_mis, env, hide, 0, &h, &ts, &br, &tb,
+                      kk, rgb, alb, ag, tix, tw);
         real p[3] = { r.o[0] + r.d[0], r.o[1] + r.d[1], r.o[2] + r.d[2] };
         reproject(cam, p, W, H, uv, ref);
         splat4(block, Wb, Hb, uv, rgb);
@@ -603,7 +653,9 @@ static int warp_coef(const grid_t *G, const real *o, const real *d, const trace_
 void o_render_direct_backward(const real *grid, int rx, int ry, int rz, const real *cam, int W, int H, int spp,
                               const real *offsets, const real *emitter_u, const real *albedo, int ax, int ay, int az,
                               const real *env, int hide, int reparam, const real *grad_image, real *grad_grid,
-                              real *grad_albedo, real *image) {
+                              real *grad_albedo, real *image, int use_mis, const real *bsdf_u, int variant) {
+    /* variant: 1 = detach_indirect_si (shadow ray from the detached hit), 2 = decouple_reparam (from the hit of the un-warped
+     * ray, si_d0); sdf_direct_reparam.py:44-47 */
     grid_t G = { grid, rx, ry, rz };
     vol3_t A = { albedo, ax, ay, az };
     int Wb = W + 2*BORDER, Hb = H + 2*BORDER;
@@ -611,14 +663,15 @@ void o_render_direct_backward(const real *grid, int rx, int ry, int rz, const re
     real *block = (real *)calloc((size_t)4*Wb*Hb, sizeof(real));
     real *badj = (real *)calloc((size_t)4*Wb*Hb, sizeof(real));
     trace_t *tr = (trace_t *)malloc((size_t)n*sizeof(trace_t)), *trs = (trace_t *)malloc((size_t)n*sizeof(trace_t));
+    trace_t *trb = use_mis ? (trace_t *)malloc((size_t)n*sizeof(trace_t)) : NULL;
     unsigned char *lit = (unsigned char *)calloc((size_t)n, 1);
 #pragma omp parallel for schedule(dynamic, 256)
     for (long lane = 0; lane < n; ++lane) {
-        ray_t r; dhit_t h; real rgb[3], alb[3], ag[3][3], tw[8], uv[2], ref[3]; size_t tix[8];
+        ray_t r; dhit_t h; bray_t br; trace_t tbl; real rgb[3], alb[3], ag[3][3], tw[8], uv[2], ref[3], kk[2]; size_t tix[8];
         lane_ray(cam, W, H, spp, offsets, lane, &r);
         trace(&G, r.o, r.d, r.maxt, 1, &tr[lane]);
-        lit[lane] = (unsigned char)direct_sample(&G, &A, &r, tr[lane].its_t, emitter_u + 2*lane, env, hide, 1, &h, &trs[lane],
-                                                 rgb, alb, ag, tix, tw);
+        lit[lane] = (unsigned char)direct_sample(&G, &A, &r, tr[lane].its_t, emitter_u + 2*lane, use_mis ? bsdf_u + 2*lane : NULL, use_mis,
+                                                 env, hide, 1, &h, &trs[lane], &br, use_mis ? &trb[lane] : &tbl, kk, rgb, alb, ag, tix, tw);
         real p[3] = { r.o[0] + r.d[0], r.o[1] + r.d[1], r.o[2] + r.d[2] };
         reproject(cam, p, W, H, uv, ref);
         splat4(block, Wb, Hb, uv, rgb);
@@ -641,14 +694,23 @@ void o_render_direct_backward(const real *grid, int rx, int ry, int rz, const re
         int warp_on = reparam && warp_coef(&G, o, d, t, &wc);
         if (!warp_on && !lit[lane]) continue;
         int hit = t->its_t < INFINITY;
-        real rgb[3] = {0, 0, 0}, alb[3] = {0, 0, 0}, ag[3][3], tw[8], uv[2], ref[3], cos_o = 0.f; size_t tix[8];
-        dhit_t h;
+        real rgb[3] = {0, 0, 0}, rgb_e[3] = {0, 0, 0}, rgb_b[3] = {0, 0, 0}, alb[3] = {0, 0, 0}, ag[3][3], tw[8], uv[2], ref[3]; size_t tix[8];
+        real ke = 0.f, kb = 0.f, we = 1.f;          /* rgb_c = alb_c env_c (ke + kb): emitter / BSDF sampling factors */
+        dhit_t h; bray_t br;
         if (!hit) { if (!hide) { rgb[0] = env[0]; rgb[1] = env[1]; rgb[2] = env[2]; } }
         else if (lit[lane]) {
             direct_setup(&G, &r, t->its_t, emitter_u + 2*lane, &h);
             trilinear(&A, h.p, alb, ag, tix, tw);
-            cos_o = dot3(h.n, h.sd);
-            for (int c = 0; c < 3; ++c) rgb[c] = alb[c]*4.f*cos_o*env[c];
+            if (lit[lane] & 1) {
+                real cos_o = dot3(h.n, h.sd);
+                we = use_mis ? mis_w(INV_4PI, cos_o*INV_PI) : 1.f;
+                ke = 4.f*cos_o*we;
+            }
+            if (lit[lane] & 2) {
+                bsdf_setup(&r, &h, bsdf_u + 2*lane, &br);
+                kb = br.woz*INV_PI/br.pdf*mis_w(br.pdf, INV_4PI);
+            }
+            for (int c = 0; c < 3; ++c) { rgb_e[c] = alb[c]*ke*env[c]; rgb_b[c] = alb[c]*kb*env[c]; rgb[c] = rgb_e[c] + rgb_b[c]; }
         }
         real p1[3] = { o[0] + d[0], o[1] + d[1], o[2] + d[2] };
         int inside = reproject(cam, p1, W, H, uv, ref);
@@ -673,33 +735,51 @@ void o_render_direct_backward(const real *grid, int rx, int ry, int rz, const re
         real dir_bar[3];
         for (int a = 0; a < 3; ++a) dir_bar[a] = cam[3+a]*rb[0] + cam[6+a]*rb[1] + cam[9+a]*rb[2];
         if (lit[lane]) {
-            /* albedo: a_c-bar = A_c 4 cos_o L_c ; cos-bar = sum_c A_c a_c 4 L_c */
-            real pbar[3] = {0, 0, 0}, cos_bar = 0.f;
+            /* albedo: a_c-bar = A_c (ke + kb) L_c ; cos-bar = sum_c A_c a_c 4 w_e L_c (w_e, kb: detached) */
+            real pbar[3] = {0, 0, 0}, psh[3] = {0, 0, 0}, cos_bar = 0.f, dot_e = 0.f, dot_b = 0.f;
             for (int c = 0; c < 3; ++c) {
-                real k = 4.f*env[c]*ac[c], abar = k*cos_o;
+                real abar = env[c]*ac[c]*(ke + kb);
                 for (int m = 0; m < 8; ++m) {
 #pragma omp atomic
                     grad_albedo[tix[m] + c] += tw[m]*abar;
                 }
                 for (int a = 0; a < 3; ++a) pbar[a] += abar*ag[c][a];
-                cos_bar += k*alb[c];
+                if (lit[lane] & 1) cos_bar += 4.f*we*env[c]*ac[c]*alb[c];
+                dot_e += rgb_e[c]*ac[c]; dot_b += rgb_b[c]*ac[c];
             }
             real gl = sqrtf(dot3(h.g, h.g)), nbar[3], sdbar[3], Gb[3], nn = 0.f, HG[3];
             for (int a = 0; a < 3; ++a) { nbar[a] = cos_bar*h.sd[a]; sdbar[a] = cos_bar*h.n[a]; nn += h.n[a]*nbar[a]; }
             for (int a = 0; a < 3; ++a) Gb[a] = (nbar[a] - nn*h.n[a])/gl;
-            /* shadow-ray warp (warp.py:110-115 with the attached origin si.p): det_e multiplies the rgb channels only */
+            /* shadow-ray warp (warp.py:110-115 with the attached origin si.p): det_e multiplies the emitter-sampling term only */
             wcoef_t ws;
-            if (reparam && warp_coef(&G, h.so, h.sd, ts, &ws)) {
-                real vs = dot3(ws.cdir, sdbar) + ws.a*rgb_dot, gs[3], Hgs[3];
-                for (int a = 0; a < 3; ++a) gs[a] = rgb_dot*ws.b[a];
+            if ((lit[lane] & 1) && reparam && warp_coef(&G, h.so, h.sd, ts, &ws)) {
+                real vs = dot3(ws.cdir, sdbar) + ws.a*dot_e, gs[3], Hgs[3];
+                for (int a = 0; a < 3; ++a) gs[a] = dot_e*ws.b[a];
+                scatter_cubic(&G, grad_grid, ws.x, vs, gs);
+                symmul(ws.H, gs, Hgs);
+                for (int a = 0; a < 3; ++a) psh[a] = vs*ws.g[a] + Hgs[a];          /* through the shadow-ray ORIGIN */
+            }
+            /* BSDF-sampled ray (sdf_direct_reparam.py:93-96): origin attached to si.p, direction detached; only its determinant
+             * carries a gradient (a constant environment does not depend on the direction) */
+            if ((lit[lane] & 2) && reparam && warp_coef(&G, br.o, br.d, &trb[lane], &ws)) {
+                real vs = ws.a*dot_b, gs[3], Hgs[3];
+                for (int a = 0; a < 3; ++a) gs[a] = dot_b*ws.b[a];
                 scatter_cubic(&G, grad_grid, ws.x, vs, gs);
                 symmul(ws.H, gs, Hgs);
                 for (int a = 0; a < 3; ++a) pbar[a] += vs*ws.g[a] + Hgs[a];
             }
             symmul(h.H, Gb, HG);
             for (int a = 0; a < 3; ++a) pbar[a] += HG[a];
-            real c = -dot3(h.g, d), v0 = dot3(pbar, d)/c;
-            for (int a = 0; a < 3; ++a) dir_bar[a] += t->its_t*pbar[a] + v0*t->its_t*h.g[a];
+            real c = -dot3(h.g, d), v0, v0d;
+            if (variant == 1) { psh[0] = psh[1] = psh[2] = 0.f; }                   /* detach_indirect_si: no origin dependence */
+            if (variant == 2) {                                                     /* decouple_reparam: through t of the un-warped ray only */
+                v0d = dot3(pbar, d)/c; v0 = v0d + dot3(psh, d)/c;
+                for (int a = 0; a < 3; ++a) dir_bar[a] += t->its_t*pbar[a] + v0d*t->its_t*h.g[a];
+            } else {
+                for (int a = 0; a < 3; ++a) pbar[a] += psh[a];
+                v0 = dot3(pbar, d)/c;
+                for (int a = 0; a < 3; ++a) dir_bar[a] += t->its_t*pbar[a] + v0*t->its_t*h.g[a];
+            }
             scatter_cubic(&G, grad_grid, h.p, v0, Gb);
         }
         if (warp_on) {
@@ -708,7 +788,7 @@ void o_render_direct_backward(const real *grid, int rx, int ry, int rz, const re
             scatter_cubic(&G, grad_grid, wc.x, vbar, gbar);
         }
     }
-    free(block); free(badj); free(tr); free(trs); free(lit);
+    free(block); free(badj); free(tr); free(trs); free(trb); free(lit);
 }
 
 /* per-point / per-ray entry points for the cross-checks */

@@ -534,9 +534,13 @@ def warped_ray(sdf, o, d, maxt, reparam):
     return tr['its_t'], d_att, det
 
 
-def direct_radiance(sdf, albedo, o, d_att, its_t, emitter_u, reparam, env=1.0, hide_emitters=False):
-    """sdf_direct_reparam.py:29-75 for the hit lanes + the environment term of the others (without the
-    primary determinant, which the caller multiplies in).  -> rgb (N,3)."""
+def direct_radiance(sdf, albedo, o, d_att, its_t, emitter_u, reparam, env=1.0, hide_emitters=False, use_mis=False,
+                    bsdf_u=None, detach_indirect_si=False, decouple_reparam=False, d_det=None):
+    """sdf_direct_reparam.py:29-105 for the hit lanes + the environment term of the others (without the
+    primary determinant, which the caller multiplies in).  -> rgb (N,3).
+    use_mis: emitter sampling weighted by the power heuristic plus the BSDF-sampling branch (:77-105) with `bsdf_u` (N,2) as
+    its next_2d() (the next_1d() before it selects a lobe: unused by `diffuse`).  detach_indirect_si / decouple_reparam
+    (:44-47): the shadow ray starts from the detached hit / from the hit of the un-warped ray (si_d0)."""
     N = o.shape[0]
     dt = o.dtype
     hit = torch.isfinite(its_t)
@@ -549,20 +553,53 @@ def direct_radiance(sdf, albedo, o, d_att, its_t, emitter_u, reparam, env=1.0, h
     oh, dh = o[hsel], d_att[hsel]
     _, p, n = compute_surface_interaction(sdf, oh, dh, its_t[hsel], None)
     wdir = square_to_uniform_sphere(emitter_u[hsel].to(dt))           # :40 constant emitter, pdf = 1/(4 pi)
-    so, sd, smaxt = spawn_ray_to(p, n, p.detach() + wdir * ENV_DIST)   # :51 (ds.p from the detached si)
+    if detach_indirect_si:                                              # :44-45 si_d.spawn_ray_to
+        p_src = p.detach()
+    elif decouple_reparam:                                              # :46-47 si_d0: compute_surface_interaction(detach(ray), detach(t))
+        dd = (d_det if d_det is not None else d_att.detach())[hsel].detach()
+        _, p_src, _ = compute_surface_interaction(sdf, oh.detach(), dd, its_t[hsel].detach(), None)
+    else:
+        p_src = p
+    so, sd, smaxt = spawn_ray_to(p_src, n, p.detach() + wdir * ENV_DIST)   # :51 (ds.p from the detached si)
     sd = sd.detach()                                                    # :53
     cos_i = dot(n, -dh).detach()
     front = (dot(n, sd).detach() > 0) & (cos_i > 0)                     # diffuse::eval: both cosines positive
     fsel = front.nonzero()[:, 0]
-    if fsel.numel() == 0:
-        return rgb
-    s_t, sd_att, det_e = warped_ray(sdf, so[fsel], sd[fsel], smaxt[fsel], reparam)   # :54 ray_test
-    vis = (~torch.isfinite(s_t)).to(dt)
-    cos_o = dot(n[fsel], sd_att)                                        # wo = si.to_local(shadow_ray.d)
-    a = eval_trilinear(albedo, p[fsel])                               # reflectance volume lives on the unit cube
-    bsdf = a * (cos_o / math.pi)[:, None]
-    contrib = bsdf * (env * 4.0 * math.pi) * (vis * det_e)[:, None]     # emitter_val / ds.pdf ; * det_e (:84)
-    return rgb.index_put((hsel[fsel],), contrib)
+    contrib_all = torch.zeros(hsel.numel(), 3, dtype=dt)
+    inv_4pi = 1.0 / (4.0 * math.pi)
+    if fsel.numel() > 0:
+        s_t, sd_att, det_e = warped_ray(sdf, so[fsel], sd[fsel], smaxt[fsel], reparam)   # :54 ray_test
+        vis = (~torch.isfinite(s_t)).to(dt)
+        cos_o = dot(n[fsel], sd_att)                                    # wo = si.to_local(shadow_ray.d)
+        a = eval_trilinear(albedo, p[fsel])                           # reflectance volume lives on the unit cube
+        bsdf = a * (cos_o / math.pi)[:, None]
+        contrib = bsdf * (env * 4.0 * math.pi) * (vis * det_e)[:, None]   # emitter_val / ds.pdf ; * det_e (:84)
+        if use_mis:                                                     # :78-79 mis_weight(ds.pdf, detach(bsdf_pdf))
+            contrib = contrib * mis_weight(torch.full_like(cos_o, inv_4pi), (cos_o / math.pi).detach())[:, None]
+        contrib_all = contrib_all.index_put((fsel,), contrib)
+    if use_mis:                                                         # ---- BSDF sampling, :86-105
+        wo = square_to_cosine_hemisphere(bsdf_u[hsel].to(dt))           # bs.wo (local frame of the detached si)
+        pdf_b = wo[:, 2] / math.pi
+        act = (cos_i > 0) & (pdf_b > 0)                                 # diffuse::sample: cos_theta_i > 0; :92 bs.pdf > 0
+        bsel = act.nonzero()[:, 0]
+        if bsel.numel() > 0:
+            nb = n[bsel].detach()
+            sb, tb = coordinate_system(nb)
+            wob = wo[bsel]
+            db = sb * wob[:, 0:1] + tb * wob[:, 1:2] + nb * wob[:, 2:3]   # si_d.to_world(bs.wo); :94 detached
+            pb = p[bsel]
+            mag = (1.0 + pb.detach().abs().max(dim=-1).values) * RAY_EPSILON     # si.spawn_ray -> offset_p (attached to p only)
+            sgn = torch.where(dot(nb, db) >= 0, torch.ones_like(mag), -torch.ones_like(mag))
+            ob = pb + (mag * sgn)[:, None] * nb
+            b_t, _, det_b = warped_ray(sdf, ob, db, torch.full_like(mag, 1e30), reparam)    # :95-96 ray_intersect, depth 1
+            escaped = ~torch.isfinite(b_t)                              # si_bsdf invalid -> the environment emitter
+            ab = eval_trilinear(albedo, pb)
+            bsdf_val = ab * (wob[:, 2] / math.pi)[:, None]              # :97 bsdf.eval(ctx, si, bs.wo): local wo, cos detached
+            emitter_pdf = torch.where(escaped, torch.full_like(pdf_b[bsel], inv_4pi), torch.zeros_like(pdf_b[bsel]))   # :100-102
+            w = mis_weight(pdf_b[bsel], emitter_pdf)
+            cb = bsdf_val / pdf_b[bsel][:, None] * (env * escaped.to(dt)[:, None]) * (w * det_b)[:, None]   # :104-105
+            contrib_all = contrib_all.index_put((bsel,), cb, accumulate=True)
+    return rgb.index_put((hsel,), contrib_all)
 
 
 # --------------------------------------------------------------------------
@@ -647,6 +684,39 @@ class Camera:
         return uv, torch.where(ok, imp, torch.zeros_like(imp))
 
 
+def square_to_cosine_hemisphere(u):
+    """mitsuba warp.h: concentric disk mapping (Shirley-Chiu), z = safe_sqrt(1 - x^2 - y^2); pdf = z / pi."""
+    x = 2.0 * u[:, 0] - 1.0
+    y = 2.0 * u[:, 1] - 1.0
+    is_zero = (x == 0) & (y == 0)
+    q13 = x.abs() < y.abs()
+    r = torch.where(q13, y, x)
+    rp = torch.where(q13, x, y)
+    phi = 0.25 * math.pi * rp / torch.where(is_zero, torch.ones_like(r), r)
+    phi = torch.where(q13, 0.5 * math.pi - phi, phi)
+    phi = torch.where(is_zero, torch.zeros_like(phi), phi)
+    dx, dy = r * torch.cos(phi), r * torch.sin(phi)
+    z = torch.sqrt(torch.clamp(1.0 - dx * dx - dy * dy, min=0.0))
+    return torch.stack([dx, dy, z], -1)
+
+
+def coordinate_system(n):
+    """mitsuba vector.h coordinate_system (Duff et al., "Building an Orthonormal Basis, Revisited"): (s, t) with
+    Frame3f(n).to_world(v) = s v.x + t v.y + n v.z."""
+    sign = torch.where(n[:, 2] >= 0, torch.ones_like(n[:, 2]), -torch.ones_like(n[:, 2]))
+    a = -1.0 / (sign + n[:, 2])
+    b = n[:, 0] * n[:, 1] * a
+    s = torch.stack([sign * (n[:, 0] * n[:, 0] * a) + 1.0, sign * b, -sign * n[:, 0]], -1)
+    t = torch.stack([b, n[:, 1] * (n[:, 1] * a) + sign, -n[:, 1]], -1)
+    return s, t
+
+
+def mis_weight(pdf_a, pdf_b):
+    """mitsuba.ad.integrators.common.mis_weight: power heuristic, detached."""
+    a2 = pdf_a * pdf_a
+    return torch.where(pdf_a > 0, a2 / (pdf_b * pdf_b + a2), torch.zeros_like(a2)).detach()
+
+
 # --------------------------------------------------------------------------
 # Sampler: Mitsuba `independent` = PCG32 seeded by sample_tea_32 (SURVEY C.4)
 # --------------------------------------------------------------------------
@@ -706,6 +776,12 @@ def independent_sampler_emitter_2d(seed, n):
     return independent_sampler(seed, n, 5)[:, 3:5]
 
 
+def independent_sampler_bsdf_2d(seed, n):
+    """The `next_2d()` of the BSDF-sampling branch (sdf_direct_reparam.py:90-91): after the film position (2 floats), the
+    wavelength sample (1), the emitter sample (2) and bsdf.sample's next_1d (1) -- floats 6 and 7 of the lane's stream."""
+    return independent_sampler(seed, n, 8)[:, 6:8]
+
+
 # --------------------------------------------------------------------------
 # Film: Gaussian rfilter + ImageBlock.put + HDRFilm.develop (SURVEY C.3)
 # --------------------------------------------------------------------------
@@ -760,7 +836,7 @@ def lane_positions(W, H, spp, offsets):
 
 def render(sdf, cam, W, H, spp, offsets, integrator=SILHOUETTE, reparam=True,
            return_aux=False, chunk=1 << 17, albedo=None, emitter_u=None, env=1.0, hide_emitters=False, rows=None,
-           return_block=False):
+           return_block=False, use_mis=False, bsdf_u=None, detach_indirect_si=False, decouple_reparam=False):
     """One view.  offsets: (Wb*Hb*spp, 2) in [0,1) (the sampler's next_2d per
     lane).  Returns image (H,W,3), differentiable w.r.t. sdf.data / sdf.p when
     they require grad.  `reparam=False` gives the DummyWarpField path
@@ -774,6 +850,8 @@ def render(sdf, cam, W, H, spp, offsets, integrator=SILHOUETTE, reparam=True,
         pos_all = pos_all[lo:hi]
         if emitter_u is not None:
             emitter_u = emitter_u[lo:hi]
+        if bsdf_u is not None:
+            bsdf_u = bsdf_u[lo:hi]
     block = torch.zeros(Hb * Wb * 4, dtype=dt)
     aux = dict(steps=0, lanes=0, bbox=0, hits=0, refine=0, warp_active=0)
     light = torch.tensor([1.0, 1.0, 1.0], dtype=dt) / math.sqrt(3.0)
@@ -804,7 +882,8 @@ def render(sdf, cam, W, H, spp, offsets, integrator=SILHOUETTE, reparam=True,
                 div = div.index_put((sel,), replace_grad(torch.ones_like(dv[keep]), dv[keep]))   # warp.py:115
                 aux['warp_active'] += int(keep.numel())
         if integrator == DIRECT:                                         # sdf_direct_reparam.py:16-111
-            rgb = direct_radiance(sdf, albedo, o, d_att, its_t, emitter_u[s:s + chunk], reparam, env, hide_emitters) * div[:, None]
+            rgb = direct_radiance(sdf, albedo, o, d_att, its_t, emitter_u[s:s + chunk], reparam, env, hide_emitters, use_mis,
+                                  None if bsdf_u is None else bsdf_u[s:s + chunk], detach_indirect_si, decouple_reparam, d) * div[:, None]
         elif integrator == SILHOUETTE:                                   # sdf_silhouette_reparam.py:20-22
             val = hit.to(dt) * div
         else:                                                            # sdf_simple_shading_reparam.py:20-22
