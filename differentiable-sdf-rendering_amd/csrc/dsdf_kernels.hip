@@ -154,7 +154,7 @@ struct Queue {
     uint32_t *count;  // per unit
     uint32_t *lane;
     float *rec;       // `rows` rows (SoA, stride = cap), indexed by sample: its_t, warp_t, wtd.xyz, ww, wwd.xyz
-                      // of the primary ray (9) and, for sdf_direct_reparam, of the shadow ray (18)
+                      // of the primary ray (9) and, for sdf_direct_reparam, of the shadow ray (18) and the BSDF-sampled ray (27)
     uint32_t rows;
     uint32_t cap;     // slots per view (= nunits * 64)
     uint32_t nunits;  // units per view
@@ -241,13 +241,14 @@ __device__ __forceinline__ void flush_stats(unsigned long long *stats, const Wav
 
 // wave-level compaction of the samples that need the backward sweep into their unit's slots
 __device__ __forceinline__ void queue_unit(const Queue &q, uint32_t unit, uint32_t lane, bool need, int lid, const TraceOut &tr,
-                                           const TraceOut *trs) {
+                                           const TraceOut *trs, const TraceOut *trb = nullptr) {
     const uint64_t m = __ballot(need);
     if (lid == 0) q.count[unit] = (uint32_t)__popcll(m);
     if (need) {
         q.lane[unit * 64 + mask_prefix(m)] = lane;
         store_record(q.rec + lane, q.cap, tr);              // records are dense by sample index
         if (trs) store_record(q.rec + lane + 9 * (size_t)q.cap, q.cap, *trs);
+        if (trb) store_record(q.rec + lane + 18 * (size_t)q.cap, q.cap, *trb);
     }
 }
 
@@ -366,9 +367,9 @@ void k_render_items(GridView G, dsdf_params P, ViewBatch VB, float *__restrict__
         const bool skip_trace = skip && (__builtin_amdgcn_readfirstlane((int)skip[e]) & (DIFF ? 2 : 1));
         const uint32_t unit = pix * chunks + item % chunks;
         const uint32_t lane = unit * 64u + (uint32_t)lid;
-        TraceOut tr, trs;
+        TraceOut tr, trs, trb;
         clear_trace(tr);
-        bool lit = false;
+        int lit = 0;
         const Lane L = lane_setup(A, P, lane);
         if (!skip_trace) {
             // (the last few rays of the wave are handed to the tail queue: dsdf_tail.h)
@@ -394,7 +395,7 @@ void k_render_items(GridView G, dsdf_params P, ViewBatch VB, float *__restrict__
         const Reproj rp = reproject(A.cam, P, L.ray.o + L.ray.d, A.W, A.H);
         if (DIRECT) {
             float rgb[3];
-            lit = direct_value(G, P, A, S, L, lane, tr.its_t, DIFF, trs, rgb);
+            lit = direct_value(G, P, A, S, L, lane, tr.its_t, DIFF, trs, trb, rgb);
             film_accum_wave<NCH>(px, py, rp.u, rp.v, rgb, wave_lds, lid, acc);
         } else {
             const float val = shade_value(G, A, L, tr.its_t);
@@ -405,8 +406,8 @@ void k_render_items(GridView G, dsdf_params P, ViewBatch VB, float *__restrict__
         if (DIFF) {
             const bool hit = tr.its_t < INFINITY;
             const bool warp_cand = (A.flags & DSDF_REPARAM) && warp_weight_positive(G, P, L.ray.o, L.ray.d, tr);
-            need = warp_cand || (DIRECT ? lit : (hit && A.integrator == DSDF_SIMPLE_SHADING));
-            queue_unit(view_queue(qall, view), unit, lane, need, lid, tr, DIRECT ? &trs : nullptr);
+            need = warp_cand || (DIRECT ? lit != 0 : (hit && A.integrator == DSDF_SIMPLE_SHADING));
+            queue_unit(view_queue(qall, view), unit, lane, need, lid, tr, DIRECT ? &trs : nullptr, (DIRECT && S.use_mis) ? &trb : nullptr);
         }
         if (STATS) add_stats(wst, tr, true, need);
       }
@@ -460,7 +461,7 @@ __global__ __launch_bounds__(DSDF_BLOCK) void k_render_pass(GridView G, dsdf_par
         const uint32_t ty = wave / tiles_x, tx = wave - ty * tiles_x;
         TW.x0 = (int)tx * M.tile_w - 2; TW.y0 = (int)ty * M.tile_h - 2; TW.w = M.tile_w + 4; TW.h = M.tile_h + 4;
     }
-    TraceOut tr, trs;
+    TraceOut tr, trs, trb;
     clear_trace(tr);
     // empty-space proof for this sample's pixel.  skip_trace: a miss with no warp is known; far: nothing this sample does
     // can reach an output (k_skip_dilate), so it is not generated.
@@ -475,7 +476,7 @@ __global__ __launch_bounds__(DSDF_BLOCK) void k_render_pass(GridView G, dsdf_par
         }
         if (py < M.row0 || py >= M.row1) { far = true; valid = false; }         // outside this call's row window
     }
-    bool lit = false;
+    int lit = 0;
     Lane L;
     const bool windowed = M.tile_w && __ballot(!far) != 0;       // (a wave of far pixels touches nothing)
     if (windowed) tile_window_clear<NCH>(TW, lid);
@@ -494,7 +495,7 @@ __global__ __launch_bounds__(DSDF_BLOCK) void k_render_pass(GridView G, dsdf_par
         const Reproj rp = reproject(A.cam, P, L.ray.o + L.ray.d, A.W, A.H);
         if (DIRECT) {
             float rgb[3];
-            lit = direct_value(G, P, A, S, L, lane, tr.its_t, DIFF, trs, rgb);
+            lit = direct_value(G, P, A, S, L, lane, tr.its_t, DIFF, trs, trb, rgb);
             if (valid) {
                 if (windowed) tile_window_splat<NCH>(TW, block, A.Wb, A.Hb, rp.u, rp.v, rgb);
                 else splat_lane_rgb(block, A.Wb, A.Hb, rp.u, rp.v, rgb, AtomicAdd());
@@ -512,8 +513,9 @@ __global__ __launch_bounds__(DSDF_BLOCK) void k_render_pass(GridView G, dsdf_par
     if (DIFF) {
         const bool hit = tr.its_t < INFINITY;
         const bool warp_cand = !far && (A.flags & DSDF_REPARAM) && warp_weight_positive(G, P, L.ray.o, L.ray.d, tr);
-        need = valid && (warp_cand || (DIRECT ? lit : (hit && A.integrator == DSDF_SIMPLE_SHADING)));
-        queue_unit(q, (blockIdx.x * DSDF_BLOCK + threadIdx.x) >> 6, lane, need, lid, tr, DIRECT ? &trs : nullptr);
+        need = valid && (warp_cand || (DIRECT ? lit != 0 : (hit && A.integrator == DSDF_SIMPLE_SHADING)));
+        queue_unit(q, (blockIdx.x * DSDF_BLOCK + threadIdx.x) >> 6, lane, need, lid, tr, DIRECT ? &trs : nullptr,
+                   (DIRECT && S.use_mis) ? &trb : nullptr);
     }
     if (stats) {
         WaveStats wst = {0, 0, 0, 0, 0, 0, 0};
@@ -568,18 +570,19 @@ __global__ __launch_bounds__(64) void k_backward(GridView G, dsdf_params P, View
     V3 p_bar = mk(0.f, 0.f, 0.f);                          // dL/d(sdf.p) of this group's samples
     for (uint32_t s0 = 0; s0 < count; s0 += 64) {
         const uint32_t si = s0 + threadIdx.x;
-        ScatterReq req[3];
-        req[0].on = false; req[1].on = false; req[2].on = false;
+        ScatterReq req[4];
+        req[0].on = false; req[1].on = false; req[2].on = false; req[3].on = false;
         if (si < count) {
             const uint32_t lane = q.lane[ug.slot(si)];
             TraceOut tr;
             load_record(q.rec + lane, q.cap, tr);
             Lane L = lane_setup(A, P, lane);
             if (DIRECT) {
-                TraceOut trs;
+                TraceOut trs, trb;
                 load_record(q.rec + lane + 9 * (size_t)q.cap, q.cap, trs);
+                if (S.use_mis) load_record(q.rec + lane + 18 * (size_t)q.cap, q.cap, trb); else clear_trace_out(trb, 0.f);
                 AlbedoReq areq;
-                n_did += lane_backward_direct(G, P, A, S, L, lane, tr, trs, block_adj, req, areq) ? 1 : 0;
+                n_did += lane_backward_direct(G, P, A, S, L, lane, tr, trs, trb, block_adj, req, areq) ? 1 : 0;
                 // the albedo volume is small and its adjoint 24 floats per lit sample: plain atomics
                 if (areq.on && S.grad_albedo) scatter_trilinear(S.albedo, S.grad_albedo, areq.x, areq.a_bar, AtomicAdd());
             } else {
@@ -589,10 +592,12 @@ __global__ __launch_bounds__(64) void k_backward(GridView G, dsdf_params P, View
         wave_scatter_t(G, grad_grid, req[0], tile, lid);
         if (A.integrator != DSDF_SILHOUETTE) wave_scatter_t(G, grad_grid, req[1], tile, lid);
         if (DIRECT) wave_scatter_t(G, grad_grid, req[2], tile, lid);
+        if (DIRECT && S.use_mis) wave_scatter_t(G, grad_grid, req[3], tile, lid);
         if (grad_p) {
             if (req[0].on) p_bar = p_bar + req[0].p_bar;
             if (req[1].on) p_bar = p_bar + req[1].p_bar;
             if (DIRECT && req[2].on) p_bar = p_bar + req[2].p_bar;
+            if (DIRECT && req[3].on) p_bar = p_bar + req[3].p_bar;
         }
     }
     if (grad_p && count) {
@@ -679,7 +684,7 @@ struct Workspace {
 // the value-only march instead of the 23-word ones of the gradient sweep.
 static Workspace carve(void *base, int W, int H, int spp, int nv, int integrator, bool diff = true) {
     Workspace ws;
-    const size_t nch = (size_t)film_channels(integrator), rows = integrator == DSDF_DIRECT ? 18 : 9;
+    const size_t nch = (size_t)film_channels(integrator), rows = integrator == DSDF_DIRECT ? 27 : 9;       // (27: room for the use_mis record)
     size_t Wb = W + 2 * DSDF_BORDER, Hb = H + 2 * DSDF_BORDER;
     size_t nunits;
     int tile_w, tile_h;
@@ -723,10 +728,10 @@ static int batch_size(int W, int H, int spp, int n_views, int integrator, size_t
 }
 
 static ViewArgs make_view_args(const dsdf_camera &cam, int W, int H, int spp, const float *offsets, uint32_t seed,
-                               int integrator, int flags, const float *emitter_u = nullptr) {
+                               int integrator, int flags, const float *emitter_u = nullptr, const float *bsdf_u = nullptr) {
     ViewArgs A;
     A.cam = cam; A.W = W; A.H = H; A.Wb = W + 2 * DSDF_BORDER; A.Hb = H + 2 * DSDF_BORDER; A.spp = spp;
-    A.integrator = integrator; A.flags = flags; A.seed = seed; A.offsets = offsets; A.emitter_u = emitter_u;
+    A.integrator = integrator; A.flags = flags; A.seed = seed; A.offsets = offsets; A.emitter_u = emitter_u; A.bsdf_u = bsdf_u;
     return A;
 }
 
@@ -737,6 +742,7 @@ static ShadeArgs make_shade_args(const dsdf_shading *sh, bool with_grad) {
         S.albedo.data = sh->albedo; S.albedo.rx = sh->ax; S.albedo.ry = sh->ay; S.albedo.rz = sh->az;
         S.env[0] = sh->env_radiance[0]; S.env[1] = sh->env_radiance[1]; S.env[2] = sh->env_radiance[2];
         S.hide_emitters = sh->hide_emitters;
+        S.use_mis = sh->use_mis != 0; S.variant = sh->variant;
         S.grad_albedo = with_grad ? sh->grad_albedo : nullptr;
     }
     return S;
@@ -760,6 +766,8 @@ static int check_render_args(const float *padded, int rx, int ry, int rz, const 
         return fail(DSDF_ERR_INVALID_ARG, "unknown integrator id");
     if (integrator == DSDF_DIRECT && (!shading || !shading->albedo || shading->ax < 1 || shading->ay < 1 || shading->az < 1))
         return fail(DSDF_ERR_INVALID_ARG, "sdf_direct_reparam needs a dsdf_shading with an albedo volume");
+    if (integrator == DSDF_DIRECT && (shading->variant < 0 || shading->variant > 2))
+        return fail(DSDF_ERR_INVALID_ARG, "dsdf_shading.variant must be 0, 1 (detach_indirect_si) or 2 (decouple_reparam)");
     size_t nl = (size_t)(W + 2 * DSDF_BORDER) * (H + 2 * DSDF_BORDER) * (size_t)spp;
     // reparam.py:48-50 wavefront-size limit
     if (nl > 0x40000000ull) return fail(DSDF_ERR_INVALID_ARG, "wavefront size exceeds 0x40000000 lanes");
@@ -869,7 +877,7 @@ size_t dsdf_forward_workspace_size(int width, int height, int spp, int n_views, 
 struct PassCtx {
     const float *padded; int rx, ry, rz; const dsdf_params *prm; dsdf_params pp;
     int W, H, spp, integrator, flags; bool direct;
-    const float *offsets, *emitter_u; const uint32_t *seeds; const dsdf_shading *shading;
+    const float *offsets, *emitter_u, *bsdf_u; const uint32_t *seeds; const dsdf_shading *shading;
     size_t Wb, Hb; uint32_t nl;
     int row0, row1;        // film-block rows of this call (multi-GPU pixel-tile split; the whole film by default)
     float *film;           // caller-owned film block to ACCUMULATE into (tile calls), or nullptr: the workspace's, zeroed
@@ -883,6 +891,7 @@ static PassCtx make_ctx(const float *padded, int rx, int ry, int rz, const dsdf_
     c.padded = padded; c.rx = rx; c.ry = ry; c.rz = rz; c.prm = prm; c.pp = pass_params(*prm, integrator);
     c.W = W; c.H = H; c.spp = spp; c.integrator = integrator; c.flags = flags; c.direct = integrator == DSDF_DIRECT;
     c.offsets = offsets; c.seeds = seeds; c.shading = shading; c.emitter_u = c.direct ? shading->emitter_samples : nullptr;
+    c.bsdf_u = (c.direct && shading->use_mis) ? shading->bsdf_samples : nullptr;
     c.Wb = W + 2 * DSDF_BORDER; c.Hb = H + 2 * DSDF_BORDER; c.nl = (uint32_t)(c.Wb * c.Hb * spp);
     c.row0 = 0; c.row1 = (int)c.Hb; c.film = nullptr;
     c.st = (hipStream_t)stream;
@@ -970,7 +979,8 @@ static int run_pass(const PassCtx &c, const Workspace &ws, const dsdf_camera *ca
     for (int i = 0; i < nv; ++i)
         VB.v[i] = make_view_args(cams[v0 + i], c.W, c.H, c.spp, c.offsets ? c.offsets + (size_t)(v0 + i) * c.nl * 2 : nullptr,
                                  c.seeds ? c.seeds[v0 + i] : 0u, c.integrator, c.flags,
-                                 c.emitter_u ? c.emitter_u + (size_t)(v0 + i) * c.nl * 2 : nullptr);
+                                 c.emitter_u ? c.emitter_u + (size_t)(v0 + i) * c.nl * 2 : nullptr,
+                                 c.bsdf_u ? c.bsdf_u + (size_t)(v0 + i) * c.nl * 2 : nullptr);
     const size_t nch = (size_t)film_channels(c.integrator), npix = c.Wb * c.Hb;
     float *film = c.film ? c.film + (size_t)v0 * npix * nch : ws.block;
     if (!c.film && hipMemsetAsync(ws.block, 0, nv * npix * nch * sizeof(float), st) != hipSuccess)
@@ -1087,7 +1097,7 @@ static int run_pass(const PassCtx &c, const Workspace &ws, const dsdf_camera *ca
 
 static Queue make_queue(const Workspace &ws, bool direct) {
     Queue q;
-    q.count = ws.count; q.lane = ws.qlane; q.rec = ws.qrec; q.rows = direct ? 18u : 9u; q.cap = ws.cap; q.nunits = ws.nunits;
+    q.count = ws.count; q.lane = ws.qlane; q.rec = ws.qrec; q.rows = direct ? 27u : 9u; q.cap = ws.cap; q.nunits = ws.nunits;
     return q;
 }
 
@@ -1272,7 +1282,8 @@ int dsdf_grad_backward(const float *padded, int rx, int ry, int rz, const dsdf_p
     ViewBatch VB;
     for (int i = 0; i < n_views; ++i)
         VB.v[i] = make_view_args(cams[i], width, height, spp, offsets ? offsets + (size_t)i * c.nl * 2 : nullptr, seeds ? seeds[i] : 0u,
-                                 integrator, flags, c.emitter_u ? c.emitter_u + (size_t)i * c.nl * 2 : nullptr);
+                                 integrator, flags, c.emitter_u ? c.emitter_u + (size_t)i * c.nl * 2 : nullptr,
+                                 c.bsdf_u ? c.bsdf_u + (size_t)i * c.nl * 2 : nullptr);
     const dim3 adj_grid((unsigned)((c.Wb * c.Hb + 255) / 256), n_views);
     if (c.direct) hipLaunchKernelGGL(k_develop_adjoint_rgb, adj_grid, dim3(256), 0, st, film_total, grad_image, width, height, ws.block_adj);
     else hipLaunchKernelGGL(k_develop_adjoint, adj_grid, dim3(256), 0, st, film_total, grad_image, width, height, ws.block_adj);

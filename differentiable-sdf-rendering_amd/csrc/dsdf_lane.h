@@ -18,6 +18,7 @@ struct ViewArgs {
     uint32_t seed;
     const float *offsets;   // per-lane (r0,r1) or nullptr -> built-in sampler
     const float *emitter_u; // sdf_direct_reparam: per-lane emitter sample or nullptr -> built-in sampler
+    const float *bsdf_u;    // sdf_direct_reparam, use_mis: per-lane BSDF sample (next_2d) or nullptr -> built-in sampler
 };
 
 // Scene-side inputs of sdf_direct_reparam (shared by all views of a call).
@@ -25,6 +26,8 @@ struct ShadeArgs {
     AlbedoView albedo;      // 'main-bsdf.reflectance.volume.data'
     float env[3];           // radiance of the constant environment emitter
     int hide_emitters;      // sdf_direct_reparam.py:12
+    int use_mis;            // reparam.py:17 / sdf_direct_reparam.py:77-105: emitter sampling + BSDF sampling, power heuristic
+    int variant;            // 1 = detach_indirect_si, 2 = decouple_reparam (sdf_direct_reparam.py:13-14, 44-47)
     float *grad_albedo;     // dL/d(albedo) accumulator (gradient pass) or nullptr
 };
 
@@ -279,40 +282,100 @@ DSDF_HD bool direct_setup(const GridView &G, const ViewArgs &A, const Lane &L, u
     return dot(h.n, h.sr.d) > 0.f && dot(h.n, -L.ray.d) > 0.f;
 }
 
-DSDF_HD void direct_radiance(const ShadeArgs &S, const DirectHit &h, float rgb[3]) {
-    float alb[3]; V3 ag[3];
-    eval_trilinear(S.albedo, h.p, alb, ag);
-    float k = 4.f * dot(h.n, h.sr.d);                                  // (cos / pi) * (4 pi): bsdf * emitter / pdf
-#pragma unroll
-    for (int c = 0; c < 3; ++c) rgb[c] = alb[c] * k * S.env[c];
+// ---- use_mis (sdf_direct_reparam.py:77-105): BSDF sampling of the `diffuse` BSDF.  wo = square_to_cosine_hemisphere (mitsuba
+// warp.h: concentric disk) in the local frame of the DETACHED hit (vector.h coordinate_system), ray spawned from the attached
+// hit point (interaction.h spawn_ray / offset_p), power-heuristic weights (mitsuba.ad.integrators.common.mis_weight, detached).
+#define DSDF_INV_4PI 0.07957747154594767f
+#define DSDF_INV_PI 0.3183098861837907f
+struct BsdfRay { bool active; V3 o, d; float woz, pdf; };
+
+DSDF_HD float mis_weight(float a, float b) { return a > 0.f ? a * a / (b * b + a * a) : 0.f; }
+
+DSDF_HD void bsdf_sample(const ViewArgs &A, uint32_t lane, float &b0, float &b1) {
+    if (A.bsdf_u) { b0 = A.bsdf_u[2 * (size_t)lane]; b1 = A.bsdf_u[2 * (size_t)lane + 1]; }
+    else sampler_bsdf_2d(A.seed, lane, b0, b1);
 }
 
-// forward value of one sample; `diff` selects the differentiable shadow trace (gradient pass)
-DSDF_HD bool direct_value(const GridView &G, const dsdf_params &P, const ViewArgs &A, const ShadeArgs &S, const Lane &L,
-                          uint32_t lane, float its_t, bool diff, TraceOut &trs, float rgb[3]) {
+DSDF_HD BsdfRay bsdf_setup(const ViewArgs &A, const Lane &L, uint32_t lane, const DirectHit &h) {
+    float u0, u1;
+    bsdf_sample(A, lane, u0, u1);
+    const float x = 2.f * u0 - 1.f, y = 2.f * u1 - 1.f;
+    const bool zero = x == 0.f && y == 0.f, q13 = fabsf(x) < fabsf(y);
+    const float rr = q13 ? y : x, rp = q13 ? x : y;
+    float phi = zero ? 0.f : 0.7853981633974483f * rp / rr;
+    if (q13) phi = 1.5707963267948966f - phi;
+    if (zero) phi = 0.f;
+    const float wx = rr * cosf(phi), wy = rr * sinf(phi), wz = sqrtf(fmaxf(1.f - wx * wx - wy * wy, 0.f));
+    const V3 n = h.n;
+    const float sign = n.z >= 0.f ? 1.f : -1.f, a = -1.f / (sign + n.z), bb = n.x * n.y * a;
+    const V3 sv = mk(sign * (n.x * n.x * a) + 1.f, sign * bb, -sign * n.x), tv = mk(bb, n.y * (n.y * a) + sign, -n.y);
+    BsdfRay b;
+    b.d = sv * wx + tv * wy + n * wz;
+    float mag = (1.f + fmaxf(fabsf(h.p.x), fmaxf(fabsf(h.p.y), fabsf(h.p.z)))) * DSDF_RAY_EPSILON;
+    if (dot(n, b.d) < 0.f) mag = -mag;
+    b.o = fma3(mag, n, h.p);
+    b.woz = wz; b.pdf = wz * DSDF_INV_PI;
+    b.active = dot(n, -L.ray.d) > 0.f && b.pdf > 0.f;
+    return b;
+}
+
+// factors of alb * env in the two terms: emitter sampling 4 cos_o [* mis weight], BSDF sampling (wo.z / pi) / pdf * mis weight
+DSDF_HD float emitter_factor(const ShadeArgs &S, const DirectHit &h, float &we) {
+    const float cos_o = dot(h.n, h.sr.d);
+    we = S.use_mis ? mis_weight(DSDF_INV_4PI, cos_o * DSDF_INV_PI) : 1.f;
+    return 4.f * cos_o * we;
+}
+DSDF_HD float bsdf_factor(const BsdfRay &b) { return b.woz * DSDF_INV_PI / b.pdf * mis_weight(b.pdf, DSDF_INV_4PI); }
+
+DSDF_HD void clear_trace_out(TraceOut &t, float its_t) {
+    t.its_t = its_t; t.warp_t = INFINITY; t.warp_weight = 0.f; t.weight_sum = 0.f;
+    t.warp_t_d = mk(0.f, 0.f, 0.f); t.warp_weight_d = mk(0.f, 0.f, 0.f); t.steps = 0; t.refine_steps = 0;
+}
+
+// forward value of one sample; `diff` selects the differentiable traces (gradient pass).  trs / trb receive the shadow-ray and
+// the BSDF-ray trace (its_t = inf <=> escaped).  Returns bit 0: the emitter-sampling term is lit (hit, both cosines positive,
+// shadow ray escapes), bit 1: the BSDF-sampling term is lit (use_mis; the sampled ray escapes to the environment).
+DSDF_HD int direct_value(const GridView &G, const dsdf_params &P, const ViewArgs &A, const ShadeArgs &S, const Lane &L,
+                         uint32_t lane, float its_t, bool diff, TraceOut &trs, TraceOut &trb, float rgb[3]) {
     rgb[0] = rgb[1] = rgb[2] = 0.f;
-    trs.its_t = 0.f; trs.warp_t = INFINITY; trs.warp_weight = 0.f; trs.weight_sum = 0.f;
-    trs.warp_t_d = mk(0.f, 0.f, 0.f); trs.warp_weight_d = mk(0.f, 0.f, 0.f); trs.steps = 0; trs.refine_steps = 0;
+    clear_trace_out(trs, 0.f);
+    clear_trace_out(trb, 0.f);
     if (!(its_t < INFINITY)) {
         if (!S.hide_emitters) { rgb[0] = S.env[0]; rgb[1] = S.env[1]; rgb[2] = S.env[2]; }   // :25-26, 33
-        return false;
+        return 0;
     }
     DirectHit h;
-    if (!direct_setup(G, A, L, lane, its_t, h)) return false;
+    const bool front = direct_setup(G, A, L, lane, its_t, h);
     dsdf_params Ps = P;
     Ps.refine_steps = 0;                                               // ray_test consumes only isfinite(its_t)
-    if (diff) trace_diff(G, Ps, h.sr.o, h.sr.d, h.sr.maxt, trs);
-    else {
-        // shadow rays dwell in the cell they start in (Mitsuba's offset_p starts them 1.8e-4 off the surface and their steps
-        // grow geometrically): the value-only march keeps the 64 taps of its current cell in registers and gathers only
-        // when the ray enters another cell -- bit-identical (test_reuse_fetch_is_bit_identical), primal 161 -> 135 ms per
-        // 12-view launch; the differentiable march (177 VGPRs already) gains nothing from it and keeps per-step gathers
-        ReuseFetch F;
-        trace_plain(G, Ps, h.sr.o, h.sr.d, h.sr.maxt, trs, F);
+    int lit = 0;
+    float ke = 0.f, kb = 0.f;
+    if (front) {
+        if (diff) trace_diff(G, Ps, h.sr.o, h.sr.d, h.sr.maxt, trs);
+        else {
+            // shadow rays dwell in the cell they start in (Mitsuba's offset_p starts them 1.8e-4 off the surface and their steps
+            // grow geometrically): the value-only march keeps the 64 taps of its current cell in registers and gathers only
+            // when the ray enters another cell -- bit-identical (test_reuse_fetch_is_bit_identical), primal 161 -> 135 ms per
+            // 12-view launch; the differentiable march (177 VGPRs already) gains nothing from it and keeps per-step gathers
+            ReuseFetch F;
+            trace_plain(G, Ps, h.sr.o, h.sr.d, h.sr.maxt, trs, F);
+        }
+        if (!(trs.its_t < INFINITY)) { float we; ke = emitter_factor(S, h, we); lit |= 1; }
     }
-    if (trs.its_t < INFINITY) return false;                            // occluded
-    direct_radiance(S, h, rgb);
-    return true;
+    if (S.use_mis) {
+        const BsdfRay b = bsdf_setup(A, L, lane, h);
+        if (b.active) {
+            if (diff) trace_diff(G, Ps, b.o, b.d, 1e30f, trb);
+            else { ReuseFetch F; trace_plain(G, Ps, b.o, b.d, 1e30f, trb, F); }
+            if (!(trb.its_t < INFINITY)) { kb = bsdf_factor(b); lit |= 2; }   // escaped: the environment, emitter pdf 1/(4 pi)
+        }
+    }
+    if (!lit) return 0;
+    float alb[3]; V3 ag[3];
+    eval_trilinear(S.albedo, h.p, alb, ag);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) rgb[c] = alb[c] * ke * S.env[c] + alb[c] * kb * S.env[c];
+    return lit;
 }
 
 // One 64-tap scatter into dL/dsdf: grad[tap] += cv * W_tap + cg . (res * dW_tap) at point x.
@@ -426,36 +489,45 @@ DSDF_HD bool lane_backward(const GridView &G, const dsdf_params &P, const ViewAr
     return did;
 }
 
-// Adjoint of one gradient-pass sample of sdf_direct_reparam.  tr / trs: (detached) primary and shadow trace
+// Adjoint of one gradient-pass sample of sdf_direct_reparam.  tr / trs / trb: (detached) primary, shadow and BSDF-ray trace
 // outputs; block_adj: adjoint of the 4-channel film block.  Scatter requests: req[0] primary warp point,
-// req[1] hit point (t and the normal), req[2] shadow-ray warp point, areq the albedo volume.
-// With rgb_c = a_c(p) * 4 cos_o * env_c * det * det_e (values det = det_e = 1), cos_o = n . d_s':
-//   a_c-bar = A_c * 4 cos_o env_c,   cos-bar = sum_c A_c a_c 4 env_c,   n-bar = cos-bar d_s,   d_s'-bar = cos-bar n,
-//   div_s-bar = sum_c A_c rgb_c,     p-bar = sum_c a_c-bar grad a_c + H_p G-bar + (v_s-bar g_s + H_s g_s-bar)
-// (the last term because the shadow ray starts at the attached hit point: its lookups move with p), then
+// req[1] hit point (t and the normal), req[2] shadow-ray warp point, req[3] BSDF-ray warp point (use_mis), areq the albedo volume.
+// With rgb_c = a_c(p) env_c (ke det_e + kb det_b) det, ke = 4 cos_o w_e, cos_o = n . d_s' (w_e, kb detached; values det = 1):
+//   a_c-bar = A_c env_c (ke + kb),   cos-bar = sum_c A_c a_c 4 w_e env_c,   n-bar = cos-bar d_s,   d_s'-bar = cos-bar n,
+//   div_e-bar = sum_c A_c rgb_e,c,   div_b-bar = sum_c A_c rgb_b,c,
+//   p-bar = sum_c a_c-bar grad a_c + H_p G-bar + sum over the two secondary rays of (v-bar g + H g-bar) at their warp points
+// (the last terms because the secondary rays start at the attached hit point: their lookups move with p), then
 // t-bar = p-bar . d, v0-bar = t-bar / (G . -d), d'-bar += t (p-bar + v0-bar G) as for simple shading.
+// variant 1 (detach_indirect_si): the shadow ray starts at the detached hit -- its origin term is dropped;
+// variant 2 (decouple_reparam): at the hit of the un-warped ray (si_d0) -- its origin term reaches t only, not d'.
 DSDF_HD bool lane_backward_direct(const GridView &G, const dsdf_params &P, const ViewArgs &A, const ShadeArgs &S,
-                                  const Lane &L, uint32_t lane, const TraceOut &tr, const TraceOut &trs,
-                                  const float *block_adj, ScatterReq req[3], AlbedoReq &areq) {
-    req[0].on = false; req[1].on = false; req[2].on = false; areq.on = false;
+                                  const Lane &L, uint32_t lane, const TraceOut &tr, const TraceOut &trs, const TraceOut &trb,
+                                  const float *block_adj, ScatterReq req[4], AlbedoReq &areq) {
+    req[0].on = false; req[1].on = false; req[2].on = false; req[3].on = false; areq.on = false;
     const V3 o = L.ray.o, d = L.ray.d;
     const bool hit = tr.its_t < INFINITY;
     Reproj rp = reproject(A.cam, P, o + d, A.W, A.H);
     float pfx = rp.u + (DSDF_BORDER - 0.5f), pfy = rp.v + (DSDF_BORDER - 0.5f);
     int x0 = (int)ceilf(pfx - DSDF_FILTER_RADIUS), y0 = (int)ceilf(pfy - DSDF_FILTER_RADIUS);
-    float rgb[3] = {0.f, 0.f, 0.f};
+    float rgb[3] = {0.f, 0.f, 0.f}, rgb_e[3] = {0.f, 0.f, 0.f}, rgb_b[3] = {0.f, 0.f, 0.f};
     DirectHit h;
-    bool lit = false;
-    float alb[3] = {0.f, 0.f, 0.f}; V3 ag[3]; float cos_o = 0.f;
+    BsdfRay br;
+    br.active = false;
+    int lit = 0;
+    float alb[3] = {0.f, 0.f, 0.f}; V3 ag[3]; float ke = 0.f, kb = 0.f, we = 1.f;
     if (!hit) {
         if (!S.hide_emitters) { rgb[0] = S.env[0]; rgb[1] = S.env[1]; rgb[2] = S.env[2]; }
     } else {
-        lit = direct_setup(G, A, L, lane, tr.its_t, h) && !(trs.its_t < INFINITY);
+        const bool front = direct_setup(G, A, L, lane, tr.its_t, h);
+        if (front && !(trs.its_t < INFINITY)) { ke = emitter_factor(S, h, we); lit |= 1; }
+        if (S.use_mis) {
+            br = bsdf_setup(A, L, lane, h);
+            if (br.active && !(trb.its_t < INFINITY)) { kb = bsdf_factor(br); lit |= 2; }
+        }
         if (lit) {
             eval_trilinear(S.albedo, h.p, alb, ag);
-            cos_o = dot(h.n, h.sr.d);
 #pragma unroll
-            for (int c = 0; c < 3; ++c) rgb[c] = alb[c] * 4.f * cos_o * S.env[c];
+            for (int c = 0; c < 3; ++c) { rgb_e[c] = alb[c] * ke * S.env[c]; rgb_b[c] = alb[c] * kb * S.env[c]; rgb[c] = rgb_e[c] + rgb_b[c]; }
         }
     }
     float a_c[3] = {0.f, 0.f, 0.f}, a_w = 0.f, u_bar = 0.f, v_bar = 0.f;
@@ -506,34 +578,52 @@ DSDF_HD bool lane_backward_direct(const GridView &G, const dsdf_params &P, const
         eval_cubic<2>(G, h.p, vhit, ghit, Hhit);
         const float gl = sqrtf(dot(ghit, ghit));
         const V3 n = ghit * (1.f / gl);
-        V3 p_bar = mk(0.f, 0.f, 0.f);
-        float cos_bar = 0.f;
+        V3 p_bar = mk(0.f, 0.f, 0.f), p_sh = mk(0.f, 0.f, 0.f);
+        float cos_bar = 0.f, dot_e = 0.f, dot_b = 0.f;
         areq.on = true; areq.x = h.p;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            float k = 4.f * S.env[c] * a_c[c];
-            areq.a_bar[c] = k * cos_o;
-            p_bar = fma3(k * cos_o, ag[c], p_bar);
-            cos_bar = fmaf(k, alb[c], cos_bar);
+            const float abar = S.env[c] * a_c[c] * (ke + kb);
+            areq.a_bar[c] = abar;
+            p_bar = fma3(abar, ag[c], p_bar);
+            if (lit & 1) cos_bar = fmaf(4.f * we * S.env[c] * a_c[c], alb[c], cos_bar);
+            dot_e = fmaf(rgb_e[c], a_c[c], dot_e); dot_b = fmaf(rgb_b[c], a_c[c], dot_b);
         }
         const V3 n_bar = cos_bar * h.sr.d, sd_bar = cos_bar * n;
         const V3 G_bar = (n_bar - dot(n, n_bar) * n) * (1.f / gl);
         if (A.flags & DSDF_REPARAM) {
             WarpCoef ws;
-            if (warp_coefficients(G, P, h.sr.o, h.sr.d, trs, ws)) {
-                float vs_bar = dot(ws.cdir, sd_bar) + ws.a * rgb_dot;          // det_e multiplies the rgb channels only
-                V3 gs_bar = rgb_dot * ws.b;
+            if ((lit & 1) && warp_coefficients(G, P, h.sr.o, h.sr.d, trs, ws)) {
+                float vs_bar = dot(ws.cdir, sd_bar) + ws.a * dot_e;            // det_e multiplies the emitter-sampling term only
+                V3 gs_bar = dot_e * ws.b;
                 V3 xs_bar = vs_bar * ws.g + symmul(ws.H, gs_bar);
                 req[2].on = true; req[2].x = fma3(trs.warp_t, h.sr.d, h.sr.o); req[2].cv = vs_bar; req[2].cg = gs_bar;
                 req[2].p_bar = -xs_bar;
-                p_bar = p_bar + xs_bar;
+                p_sh = xs_bar;                                                 // through the shadow-ray ORIGIN
+            }
+            if ((lit & 2) && warp_coefficients(G, P, br.o, br.d, trb, ws)) {
+                // BSDF-sampled ray: origin attached to si.p, direction detached; only its determinant carries a gradient
+                float vb_bar = ws.a * dot_b;
+                V3 gb_bar = dot_b * ws.b;
+                V3 xb_bar = vb_bar * ws.g + symmul(ws.H, gb_bar);
+                req[3].on = true; req[3].x = fma3(trb.warp_t, br.d, br.o); req[3].cv = vb_bar; req[3].cg = gb_bar;
+                req[3].p_bar = -xb_bar;
+                p_bar = p_bar + xb_bar;
             }
         }
         p_bar = p_bar + symmul(Hhit, G_bar);
         const float cden = dot(ghit, -d);
-        const float t_bar = dot(p_bar, d);
-        const float v0_bar = t_bar / cden;
-        dir_bar = dir_bar + tr.its_t * p_bar + (v0_bar * tr.its_t) * ghit;
+        float v0_bar;
+        if (S.variant == 1) p_sh = mk(0.f, 0.f, 0.f);
+        if (S.variant == 2) {
+            const float v0d = dot(p_bar, d) / cden;
+            v0_bar = v0d + dot(p_sh, d) / cden;
+            dir_bar = dir_bar + tr.its_t * p_bar + (v0d * tr.its_t) * ghit;
+        } else {
+            p_bar = p_bar + p_sh;
+            v0_bar = dot(p_bar, d) / cden;
+            dir_bar = dir_bar + tr.its_t * p_bar + (v0_bar * tr.its_t) * ghit;
+        }
         req[1].on = true; req[1].x = h.p; req[1].cv = v0_bar; req[1].cg = G_bar;
         req[1].p_bar = -(v0_bar * ghit + symmul(Hhit, G_bar));
         did = true;

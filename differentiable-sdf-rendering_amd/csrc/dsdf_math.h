@@ -848,6 +848,20 @@ DSDF_HD void sampler_emitter_2d(uint32_t seed, uint32_t lane, float &e0, float &
     e0 = pcg32_float(r);
     e1 = pcg32_float(r);
 }
+// The `next_2d()` of the BSDF-sampling branch (sdf_direct_reparam.py:90-91, use_mis): after the film position (2 floats), the
+// wavelength sample (1), the emitter sample (2) and bsdf.sample's next_1d (1) -- floats 6 and 7 of the lane's stream.
+DSDF_HD void sampler_bsdf_2d(uint32_t seed, uint32_t lane, float &b0, float &b1) {
+    uint32_t v0, v1;
+    sample_tea_32(seed, lane, v0, v1);
+    Pcg32 r;
+    r.state = 0; r.inc = ((uint64_t)v1 << 1u) | 1u;
+    pcg32_next(r);
+    r.state += (uint64_t)v0;
+    pcg32_next(r);
+    for (int k = 0; k < 6; ++k) pcg32_next(r);
+    b0 = pcg32_float(r);
+    b1 = pcg32_float(r);
+}
 
 // ---------------------------------------------------------------------------
 // sdf_direct_reparam (integrators/sdf_direct_reparam.py:16-75) building blocks.  The BSDF and the emitter

@@ -134,14 +134,22 @@ class SdfGrid:
 class Shading:
     """Scene-side inputs of `sdf_direct_reparam` (python/integrators/sdf_direct_reparam.py): the diffuse
     BSDF's reflectance volume `albedo` (Z,Y,X,3) -- 'main-bsdf.reflectance.volume.data',
-    python/opt_configs.py:286 -- and a constant environment emitter (include/dsdf.h: dsdf_shading)."""
+    python/opt_configs.py:286 -- and a constant environment emitter (include/dsdf.h: dsdf_shading).
+    use_mis (reparam.py:17): emitter sampling + BSDF sampling with the power heuristic; detach_indirect_si /
+    decouple_reparam: the integrator properties of the same names (sdf_direct_reparam.py:13-14, 44-47)."""
 
-    def __init__(self, albedo, env_radiance=(1.0, 1.0, 1.0), hide_emitters=False):
+    def __init__(self, albedo, env_radiance=(1.0, 1.0, 1.0), hide_emitters=False, use_mis=False, detach_indirect_si=False,
+                 decouple_reparam=False):
         self.albedo = albedo
         self.env_radiance = (float(env_radiance),) * 3 if isinstance(env_radiance, (int, float)) else tuple(env_radiance)
         self.hide_emitters = bool(hide_emitters)
+        self.use_mis = bool(use_mis)
+        self.detach_indirect_si, self.decouple_reparam = bool(detach_indirect_si), bool(decouple_reparam)
 
-    def to_struct(self, n_views, n_lanes, emitter_samples=None, grad_albedo=None):
+    def with_albedo(self, albedo):
+        return Shading(albedo, self.env_radiance, self.hide_emitters, self.use_mis, self.detach_indirect_si, self.decouple_reparam)
+
+    def to_struct(self, n_views, n_lanes, emitter_samples=None, grad_albedo=None, bsdf_samples=None):
         a = self.albedo.detach()
         if a.dim() != 4 or a.shape[3] != 3:
             raise _lib.DsdfError(f"albedo must be (Z,Y,X,3), got {tuple(a.shape)}")
@@ -151,13 +159,17 @@ class Shading:
         st.az, st.ay, st.ax = (int(v) for v in a.shape[:3])
         st.env_radiance[0], st.env_radiance[1], st.env_radiance[2] = self.env_radiance
         st.hide_emitters = int(self.hide_emitters)
+        st.use_mis = int(self.use_mis)
+        st.variant = 1 if self.detach_indirect_si else (2 if self.decouple_reparam else 0)   # (the reference tests them in this order)
         keep = [a]
-        if emitter_samples is not None:
-            emitter_samples = _require_dev(emitter_samples, 'emitter_samples')
-            if emitter_samples.numel() != n_views * n_lanes * 2:
-                raise _lib.DsdfError(f"emitter_samples must hold n_views*(W+4)*(H+4)*spp*2 = {n_views * n_lanes * 2} floats")
-            st.emitter_samples = emitter_samples.data_ptr()
-            keep.append(emitter_samples)
+        for name, t in (('emitter_samples', emitter_samples), ('bsdf_samples', bsdf_samples)):
+            if t is None:
+                continue
+            t = _require_dev(t, name)
+            if t.numel() != n_views * n_lanes * 2:
+                raise _lib.DsdfError(f"{name} must hold n_views*(W+4)*(H+4)*spp*2 = {n_views * n_lanes * 2} floats")
+            setattr(st, name, t.data_ptr())
+            keep.append(t)
         if grad_albedo is not None:
             if tuple(grad_albedo.shape) != tuple(a.shape) or not grad_albedo.is_contiguous():
                 raise _lib.DsdfError("grad_albedo must be a contiguous tensor shaped like albedo")
@@ -166,12 +178,12 @@ class Shading:
         return st, keep
 
 
-def _shading_arg(integrator, shading, n_views, n_lanes, emitter_samples=None, grad_albedo=None):
+def _shading_arg(integrator, shading, n_views, n_lanes, emitter_samples=None, grad_albedo=None, bsdf_samples=None):
     if INTEGRATORS[integrator] != DSDF_DIRECT:
         return None, None
     if shading is None:
         raise _lib.DsdfError("sdf_direct_reparam needs shading=dsdf.Shading(albedo, ...)")
-    st, keep = shading.to_struct(n_views, n_lanes, emitter_samples, grad_albedo)
+    st, keep = shading.to_struct(n_views, n_lanes, emitter_samples, grad_albedo, bsdf_samples)
     return C.byref(st), (st, keep)
 
 
@@ -265,7 +277,7 @@ def _sampler_args(n_views, seeds, offsets, n_lanes):
 
 
 def render_forward(grid, sensors, spp, seeds=None, offsets=None, integrator=DSDF_SILHOUETTE, reparam=True, stats=None,
-                   empty_space_skip=True, shading=None, emitter_samples=None):
+                   empty_space_skip=True, shading=None, emitter_samples=None, bsdf_samples=None):
     """`ReparamIntegrator.render` for a batch of views -> (n_views, H, W, 3).  `shading` (dsdf.Shading) and the
     optional per-lane `emitter_samples` belong to sdf_direct_reparam."""
     lib = _lib.load()
@@ -278,7 +290,7 @@ def render_forward(grid, sensors, spp, seeds=None, offsets=None, integrator=DSDF
     wsb = lib.dsdf_forward_workspace_size(W, H, int(spp), min(nv, MAX_VIEWS_PER_LAUNCH), INTEGRATORS[integrator])
     ws = _workspace(dev, wsb, lib.dsdf_forward_workspace_size(W, H, int(spp), 1, INTEGRATORS[integrator]))
     wsb = ws.numel()
-    sh, _keep = _shading_arg(integrator, shading, nv, n_lanes, emitter_samples)
+    sh, _keep = _shading_arg(integrator, shading, nv, n_lanes, emitter_samples, bsdf_samples=bsdf_samples)
     with torch.cuda.device(dev):
         _lib.check(lib.dsdf_render_forward(_ptr(grid.padded), grid.rx, grid.ry, grid.rz, C.byref(grid.params), cams, nv,
                                            W, H, int(spp), _ptr(offsets), cseeds, INTEGRATORS[integrator],
@@ -289,7 +301,7 @@ def render_forward(grid, sensors, spp, seeds=None, offsets=None, integrator=DSDF
 
 def render_backward(grid, sensors, spp, grad_image, grad_grid=None, seeds=None, offsets=None,
                     integrator=DSDF_SILHOUETTE, reparam=True, stats=None, return_image=False, empty_space_skip=True,
-                    grad_p=None, shading=None, emitter_samples=None, grad_albedo=None):
+                    grad_p=None, shading=None, emitter_samples=None, grad_albedo=None, bsdf_samples=None):
     """`ReparamIntegrator.render_backward`: accumulates dL/dsdf into grad_grid (Z,Y,X) and, if given,
     dL/d(sdf.p) into grad_p (3 floats on the device; `sdf.p`, python/shapes.py:471) and, for
     sdf_direct_reparam, dL/d(albedo) into grad_albedo (shaped like shading.albedo)."""
@@ -316,7 +328,7 @@ def render_backward(grid, sensors, spp, grad_image, grad_grid=None, seeds=None, 
     wsb = lib.dsdf_render_workspace_size(W, H, int(spp), min(nv, MAX_VIEWS_PER_LAUNCH), INTEGRATORS[integrator])
     ws = _workspace(dev, wsb, lib.dsdf_render_workspace_size(W, H, int(spp), 1, INTEGRATORS[integrator]))
     wsb = ws.numel()
-    sh, _keep = _shading_arg(integrator, shading, nv, n_lanes, emitter_samples, grad_albedo)
+    sh, _keep = _shading_arg(integrator, shading, nv, n_lanes, emitter_samples, grad_albedo, bsdf_samples)
     with torch.cuda.device(dev):
         _lib.check(lib.dsdf_render_backward(_ptr(grid.padded), grid.rx, grid.ry, grid.rz, C.byref(grid.params), cams, nv,
                                             W, H, int(spp), _ptr(offsets), cseeds, INTEGRATORS[integrator],
@@ -586,7 +598,7 @@ class _RenderOp(torch.autograd.Function):
     def forward(ctx, data, grid, sensors, spp, seed, spp_grad, seed_grad, integrator, reparam, p=None, albedo=None,
                 shading=None):
         if albedo is not None:
-            shading = Shading(albedo, shading.env_radiance, shading.hide_emitters)
+            shading = shading.with_albedo(albedo)
         ctx.cfg = (grid, sensors, spp_grad, seed_grad, integrator, reparam)
         ctx.shading = shading
         ctx.data_shape = data.shape

@@ -4,7 +4,8 @@ configs (python/configs.py:17): direct illumination by emitter sampling through 
 The reference reads BSDF and emitter from scene files that are not part of its repository; here they are
 fixed as a Mitsuba `diffuse` BSDF over a trilinear reflectance volume -- the optimised parameter
 'main-bsdf.reflectance.volume.data' (python/opt_configs.py:286) -- and a `constant` environment emitter
-(include/dsdf.h: dsdf_shading).  `use_mis` (BSDF sampling + MIS, sdf_direct_reparam.py:87-107) is not provided."""
+(include/dsdf.h: dsdf_shading).  Properties as in the reference: `hide_emitters`, `use_mis` (BSDF sampling + power heuristic,
+sdf_direct_reparam.py:77-105; read by the base class, reparam.py:17), `detach_indirect_si`, `decouple_reparam` (:13-14, 44-47)."""
 import torch
 
 import dsdf
@@ -21,11 +22,9 @@ class SdfDirectReparamIntegrator(ReparamIntegrator):
     def __init__(self, props=None):
         props = props or {}
         super().__init__(props)
-        if props.get('use_mis', False):
-            raise NotImplementedError("sdf_direct_reparam: use_mis=True (BSDF sampling) is outside the supported path")
-        for k in ('detach_indirect_si', 'decouple_reparam'):
-            if props.get(k, False):
-                raise NotImplementedError(f"sdf_direct_reparam: {k} is outside the supported path")
+        self.use_mis = bool(props.get('use_mis', False))                      # reparam.py:17
+        self.detach_indirect_si = bool(props.get('detach_indirect_si', False))  # sdf_direct_reparam.py:13
+        self.decouple_reparam = bool(props.get('decouple_reparam', False))      # sdf_direct_reparam.py:14
         self.hide_emitters = bool(props.get('hide_emitters', False))          # sdf_direct_reparam.py:12
         self.env_radiance = props.get('env_radiance', 1.0)
         refl = props.get('reflectance', 0.5)
@@ -34,7 +33,8 @@ class SdfDirectReparamIntegrator(ReparamIntegrator):
         self.reflectance = refl
 
     def shading(self):
-        return dsdf.Shading(self.reflectance, self.env_radiance, self.hide_emitters)
+        return dsdf.Shading(self.reflectance, self.env_radiance, self.hide_emitters, self.use_mis, self.detach_indirect_si,
+                            self.decouple_reparam)
 
     def traverse(self, cb):
         super().traverse(cb)

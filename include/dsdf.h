@@ -82,8 +82,7 @@ typedef struct dsdf_params {
     int   reserved[2];
 } dsdf_params;
 
-/* Scene-side inputs of sdf_direct_reparam (python/integrators/sdf_direct_reparam.py:16-75, emitter
- * sampling only).  The reference takes BSDF and emitter from scene files it does not ship; this library
+/* Scene-side inputs of sdf_direct_reparam (python/integrators/sdf_direct_reparam.py:16-111).  The reference takes BSDF and emitter from scene files it does not ship; this library
  * fixes them as Mitsuba `diffuse` over a trilinear reflectance volume on the unit cube
  * ('main-bsdf.reflectance.volume.data', python/opt_configs.py:286) and a `constant` environment emitter. */
 typedef struct dsdf_shading {
@@ -94,6 +93,12 @@ typedef struct dsdf_shading {
     const float *emitter_samples; /* device, n_views x (W+4)(H+4)*spp x 2 in [0,1): the lane's emitter `next_2d()`
                                      (sdf_direct_reparam.py:40), or NULL for the built-in sampler */
     float *grad_albedo;           /* device, (az,ay,ax,3): dL/d(albedo) accumulator of dsdf_render_backward, or NULL */
+    int   use_mis;                /* reparam.py:17, sdf_direct_reparam.py:77-105: emitter sampling + BSDF sampling combined with the
+                                     power heuristic (0 = emitter sampling only, the reference default) */
+    int   variant;                /* sdf_direct_reparam.py:13-14, 44-47: 0 = shadow ray from the attached hit, 1 = detach_indirect_si,
+                                     2 = decouple_reparam */
+    const float *bsdf_samples;    /* device, like emitter_samples: the lane's `next_2d()` of bsdf.sample (sdf_direct_reparam.py:90-91),
+                                     or NULL for the built-in sampler; only read when use_mis */
 } dsdf_shading;
 
 int         dsdf_version(void);

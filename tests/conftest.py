@@ -136,7 +136,7 @@ class HostHarness:
         return out
 
     def render_direct_forward(self, grid, cam, W, H, spp, offsets, emitter_u, albedo, env=(1.0, 1.0, 1.0), hide_emitters=False,
-                              reparam=True, diff=False, seed=0):
+                              reparam=True, diff=False, seed=0, bsdf_u=None, use_mis=None, variant=0):
         grid = np.ascontiguousarray(grid, np.float32)
         offsets = None if offsets is None else np.ascontiguousarray(offsets, np.float32)
         emitter_u = None if emitter_u is None else np.ascontiguousarray(emitter_u, np.float32)
@@ -147,11 +147,13 @@ class HostHarness:
         az, ay, ax = albedo.shape[:3]
         self.lib.hh_render_direct_forward(self._p(grid), rx, ry, rz, C.byref(self.params), self._p(cam), W, H, spp,
                                           self._p(offsets), self._p(emitter_u), C.c_uint(seed), int(reparam), int(diff),
-                                          self._p(albedo), ax, ay, az, self._p(env), int(hide_emitters), self._p(img))
+                                          self._p(albedo), ax, ay, az, self._p(env), int(hide_emitters), self._p(img),
+                                          int(bsdf_u is not None if use_mis is None else use_mis),
+                                          self._p(None if bsdf_u is None else np.ascontiguousarray(bsdf_u, np.float32)), int(variant))
         return img
 
     def render_direct_backward(self, grid, cam, W, H, spp, offsets, emitter_u, albedo, grad_image, env=(1.0, 1.0, 1.0),
-                               hide_emitters=False, reparam=True, seed=0):
+                               hide_emitters=False, reparam=True, seed=0, bsdf_u=None, use_mis=None, variant=0):
         grid = np.ascontiguousarray(grid, np.float32)
         offsets = None if offsets is None else np.ascontiguousarray(offsets, np.float32)
         emitter_u = None if emitter_u is None else np.ascontiguousarray(emitter_u, np.float32)
@@ -167,8 +169,15 @@ class HostHarness:
         self.lib.hh_render_direct_backward(self._p(grid), rx, ry, rz, C.byref(self.params), self._p(cam), W, H, spp,
                                            self._p(offsets), self._p(emitter_u), C.c_uint(seed), int(reparam),
                                            self._p(albedo), ax, ay, az, self._p(env), int(hide_emitters), self._p(gi),
-                                           self._p(gg), self._p(ga), self._p(gp), self._p(img))
+                                           self._p(gg), self._p(ga), self._p(gp), self._p(img),
+                                           int(bsdf_u is not None if use_mis is None else use_mis),
+                                           self._p(None if bsdf_u is None else np.ascontiguousarray(bsdf_u, np.float32)), int(variant))
         return gg, ga, gp, img
+
+    def sampler_bsdf(self, seed, n):
+        out = np.zeros((n, 2), np.float32)
+        self.lib.hh_sampler_bsdf(C.c_uint(seed), C.c_long(n), self._p(out))
+        return out
 
     def sampler_emitter(self, seed, n):
         out = np.zeros((n, 2), np.float32)

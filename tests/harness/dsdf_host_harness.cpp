@@ -88,7 +88,7 @@ static ViewArgs view_args(const dsdf_camera *cam, int W, int H, int spp, const f
                           int integrator, int flags) {
     ViewArgs A;
     A.cam = *cam; A.W = W; A.H = H; A.Wb = W + 2 * DSDF_BORDER; A.Hb = H + 2 * DSDF_BORDER; A.spp = spp;
-    A.integrator = integrator; A.flags = flags; A.seed = seed; A.offsets = offsets; A.emitter_u = nullptr;
+    A.integrator = integrator; A.flags = flags; A.seed = seed; A.offsets = offsets; A.emitter_u = nullptr; A.bsdf_u = nullptr;
     return A;
 }
 
@@ -244,7 +244,7 @@ static ShadeArgs shade_args(const float *albedo, int ax, int ay, int az, const f
     ShadeArgs S;
     S.albedo.data = albedo; S.albedo.rx = ax; S.albedo.ry = ay; S.albedo.rz = az;
     S.env[0] = env[0]; S.env[1] = env[1]; S.env[2] = env[2];
-    S.hide_emitters = hide; S.grad_albedo = grad_albedo;
+    S.hide_emitters = hide; S.grad_albedo = grad_albedo; S.use_mis = 0; S.variant = 0;
     return S;
 }
 
@@ -262,21 +262,23 @@ static void develop_rgb(const std::vector<float> &block, int W, int H, float *im
 // diff=0: primal pass; diff=1: forward sweep of the gradient pass (differentiable traces)
 void hh_render_direct_forward(const float *data, int rx, int ry, int rz, const dsdf_params *prm, const dsdf_camera *cam,
                               int W, int H, int spp, const float *offsets, const float *emitter_u, unsigned seed, int flags,
-                              int diff, const float *albedo, int ax, int ay, int az, const float *env, int hide, float *image) {
+                              int diff, const float *albedo, int ax, int ay, int az, const float *env, int hide, float *image,
+                              int use_mis, const float *bsdf_u, int variant) {
     std::vector<float> p = pad(data, rx, ry, rz);
     GridView G = make_view(p.data(), rx, ry, rz, *prm);
     ViewArgs A = view_args(cam, W, H, spp, offsets, seed, DSDF_DIRECT, flags);
-    A.emitter_u = emitter_u;
+    A.emitter_u = emitter_u; A.bsdf_u = bsdf_u;
     ShadeArgs S = shade_args(albedo, ax, ay, az, env, hide, nullptr);
+    S.use_mis = use_mis; S.variant = variant;
     std::vector<float> block((size_t)4 * A.Wb * A.Hb, 0.f);
     long n = (long)A.Wb * A.Hb * spp;
     for (long lane = 0; lane < n; ++lane) {
         Lane L = lane_setup(A, *prm, (uint32_t)lane);
-        TraceOut t, ts;
+        TraceOut t, ts, tb;
         if (diff) trace_diff(G, *prm, L.ray.o, L.ray.d, L.ray.maxt, t);
         else trace_plain(G, *prm, L.ray.o, L.ray.d, L.ray.maxt, t);
         float rgb[3];
-        direct_value(G, *prm, A, S, L, (uint32_t)lane, t.its_t, diff != 0, ts, rgb);
+        direct_value(G, *prm, A, S, L, (uint32_t)lane, t.its_t, diff != 0, ts, tb, rgb);
         Reproj rp = reproject(A.cam, *prm, L.ray.o + L.ray.d, W, H);
         splat_lane_rgb(block.data(), A.Wb, A.Hb, rp.u, rp.v, rgb, PlainAdd());
     }
@@ -286,20 +288,22 @@ void hh_render_direct_forward(const float *data, int rx, int ry, int rz, const d
 void hh_render_direct_backward(const float *data, int rx, int ry, int rz, const dsdf_params *prm, const dsdf_camera *cam,
                                int W, int H, int spp, const float *offsets, const float *emitter_u, unsigned seed, int flags,
                                const float *albedo, int ax, int ay, int az, const float *env, int hide,
-                               const float *grad_image, float *grad_grid, float *grad_albedo, float *grad_p, float *image) {
+                               const float *grad_image, float *grad_grid, float *grad_albedo, float *grad_p, float *image,
+                               int use_mis, const float *bsdf_u, int variant) {
     std::vector<float> p = pad(data, rx, ry, rz);
     GridView G = make_view(p.data(), rx, ry, rz, *prm);
     ViewArgs A = view_args(cam, W, H, spp, offsets, seed, DSDF_DIRECT, flags);
-    A.emitter_u = emitter_u;
+    A.emitter_u = emitter_u; A.bsdf_u = bsdf_u;
     ShadeArgs S = shade_args(albedo, ax, ay, az, env, hide, grad_albedo);
+    S.use_mis = use_mis; S.variant = variant;
     std::vector<float> block((size_t)4 * A.Wb * A.Hb, 0.f), badj((size_t)4 * A.Wb * A.Hb, 0.f);
     long n = (long)A.Wb * A.Hb * spp;
-    std::vector<TraceOut> tr(n), trs(n);
+    std::vector<TraceOut> tr(n), trs(n), trb(n);
     for (long lane = 0; lane < n; ++lane) {
         Lane L = lane_setup(A, *prm, (uint32_t)lane);
         trace_diff(G, *prm, L.ray.o, L.ray.d, L.ray.maxt, tr[lane]);
         float rgb[3];
-        direct_value(G, *prm, A, S, L, (uint32_t)lane, tr[lane].its_t, true, trs[lane], rgb);
+        direct_value(G, *prm, A, S, L, (uint32_t)lane, tr[lane].its_t, true, trs[lane], trb[lane], rgb);
         Reproj rp = reproject(A.cam, *prm, L.ray.o + L.ray.d, W, H);
         splat_lane_rgb(block.data(), A.Wb, A.Hb, rp.u, rp.v, rgb, PlainAdd());
     }
@@ -318,9 +322,9 @@ void hh_render_direct_backward(const float *data, int rx, int ry, int rz, const 
         }
     for (long lane = 0; lane < n; ++lane) {
         Lane L = lane_setup(A, *prm, (uint32_t)lane);
-        ScatterReq req[3]; AlbedoReq areq;
-        lane_backward_direct(G, *prm, A, S, L, (uint32_t)lane, tr[lane], trs[lane], badj.data(), req, areq);
-        for (int r = 0; r < 3; ++r)
+        ScatterReq req[4]; AlbedoReq areq;
+        lane_backward_direct(G, *prm, A, S, L, (uint32_t)lane, tr[lane], trs[lane], trb[lane], badj.data(), req, areq);
+        for (int r = 0; r < 4; ++r)
             if (req[r].on) {
                 scatter_cubic(G, grad_grid, req[r].x, req[r].cv, req[r].cg, PlainAdd());
                 if (grad_p) { grad_p[0] += req[r].p_bar.x; grad_p[1] += req[r].p_bar.y; grad_p[2] += req[r].p_bar.z; }
@@ -331,6 +335,10 @@ void hh_render_direct_backward(const float *data, int rx, int ry, int rz, const 
 
 void hh_sampler_emitter(unsigned seed, long n, float *out) {
     for (long i = 0; i < n; ++i) sampler_emitter_2d(seed, (uint32_t)i, out[2 * i], out[2 * i + 1]);
+}
+
+void hh_sampler_bsdf(unsigned seed, long n, float *out) {
+    for (long i = 0; i < n; ++i) sampler_bsdf_2d(seed, (uint32_t)i, out[2 * i], out[2 * i + 1]);
 }
 
 }  // extern "C"

@@ -75,6 +75,32 @@ def test_c_direct_matches_torch_oracle(clib, name, reparam):
 
 
 @pytest.mark.parametrize('name', ['sphere16', 'blob32', 'blob32_spp64', 'blob48_rect'])
+@pytest.mark.parametrize('mode', ['mis', 'detach_indirect_si', 'decouple_reparam', 'mis+decouple'])
+def test_c64_direct_variants_match_torch_oracle(name, mode):
+    """use_mis (sdf_direct_reparam.py:77-105) and the two shadow-origin properties (:44-47): the fp64 C build's hand-written
+    adjoint == torch autograd of the function-by-function restatement, on bit-identical inputs."""
+    case = make_case(name)
+    ex = direct_inputs(case)
+    gen = torch.Generator().manual_seed(3)
+    bu = torch.rand(case['offsets'].shape[0], 2, generator=gen, dtype=torch.float32) if 'mis' in mode else None
+    variant = 1 if 'detach' in mode else (2 if 'decouple' in mode else 0)
+    kw = dict(detach_indirect_si=variant == 1, decouple_reparam=variant == 2)
+    if bu is not None:
+        kw.update(use_mis=True, bsdf_u=bu.double())
+    data = case['grid'].clone().requires_grad_(True)
+    alb = ex['albedo'].double().clone().requires_grad_(True)
+    img = O.render(O.Grid3d(data), case['cam'], case['W'], case['H'], case['spp'], case['offsets'].double(), O.DIRECT, True, albedo=alb,
+                   emitter_u=ex['emitter_u'].double(), env=torch.tensor(ex['env'], dtype=torch.float64), **kw)
+    gd, ga = torch.autograd.grad((img * case['grad_image'].double()).sum(), (data, alb))
+    gg, galb, ci = c_oracle.render_direct_backward(P.clib(True), case['grid'].float().numpy(), case['cam'].params(), case['W'], case['H'],
+                                                   case['spp'], case['offsets'].numpy(), ex['emitter_u'].numpy(), ex['albedo'].numpy(),
+                                                   case['grad_image'].numpy(), ex['env'], bsdf_u=None if bu is None else bu.numpy(),
+                                                   variant=variant)
+    assert rel_l2(ci, img.detach().numpy()) < 2e-7
+    assert rel_l2(galb, ga.numpy()) < 1e-6 and rel_l2(gg, gd.numpy()) < 1e-6, (rel_l2(galb, ga.numpy()), rel_l2(gg, gd.numpy()))
+
+
+@pytest.mark.parametrize('name', ['sphere16', 'blob32', 'blob32_spp64', 'blob48_rect'])
 @pytest.mark.parametrize('integ', [O.SILHOUETTE, O.SIMPLE_SHADING])
 @pytest.mark.parametrize('reparam', [True, False])
 def test_c64_matches_torch_oracle(name, integ, reparam):

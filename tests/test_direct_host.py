@@ -93,3 +93,76 @@ def test_direct_translation_gradient_host(harness):
                                                  case['spp'], case['offsets'].numpy(), ex['emitter_u'].numpy(),
                                                  ex['albedo'].numpy(), case['grad_image'].numpy(), ex['env'])
     assert rel_l2(gp, gp_ref) < tol, (rel_l2(gp, gp_ref), tol)
+
+
+# ---- use_mis (sdf_direct_reparam.py:77-105) and the detach_indirect_si / decouple_reparam properties (:13-14, 44-47)
+def _bsdf_u(case, seed=3):
+    gen = torch.Generator().manual_seed(seed)
+    return torch.rand(case['offsets'].shape[0], 2, generator=gen, dtype=torch.float32)
+
+
+def test_bsdf_sampler_host(harness):
+    """floats 6,7 of the lane's PCG32 stream (film 0,1; wavelength 2; emitter 3,4; bsdf.sample's next_1d 5)."""
+    assert np.array_equal(harness.sampler_bsdf(91, 4000), O.independent_sampler_bsdf_2d(91, 4000))
+
+
+def test_cosine_hemisphere_and_frame():
+    """The restated Mitsuba conventions of the BSDF-sampling branch: the concentric-disk cosine warp maps the unit square onto
+    the upper unit hemisphere with density cos / pi; coordinate_system gives an orthonormal right-handed frame."""
+    u = torch.rand(20000, 2, dtype=torch.float64, generator=torch.Generator().manual_seed(1))
+    w = O.square_to_cosine_hemisphere(u)
+    assert torch.allclose(w.norm(dim=-1), torch.ones(len(w), dtype=torch.float64), atol=1e-12) and (w[:, 2] >= 0).all()
+    assert abs(float(w[:, 2].mean()) - 2.0 / 3.0) < 5e-3                       # E[cos] under the density cos / pi
+    n = torch.nn.functional.normalize(torch.randn(1000, 3, dtype=torch.float64, generator=torch.Generator().manual_seed(2)), dim=-1)
+    s, t = O.coordinate_system(n)
+    for a, b in ((s, t), (s, n), (t, n)):
+        assert float(O.dot(a, b).abs().max()) < 1e-12
+    assert torch.allclose(torch.cross(s, t, dim=-1), n, atol=1e-12)
+
+
+def test_oracle_mis_is_unbiased():
+    """Emitter sampling and its MIS combination with BSDF sampling estimate the same integral: convex object under a constant
+    environment -> both give albedo * L on the interior pixels."""
+    torch.manual_seed(0)
+    W = H = 24
+    spp = 64
+    n = (W + 4) * (H + 4) * spp
+    cam = O.Camera(O.regular_camera_origins(4)[1])
+    alb = torch.zeros(3, 3, 3, 3, dtype=torch.float64)
+    alb[..., 0], alb[..., 1], alb[..., 2] = 0.8, 0.5, 0.2
+    offs, eu, bu = (torch.rand(n, 2, dtype=torch.float64) for _ in range(3))
+    g = O.Grid3d(O.sphere_grid(32, radius=0.3))
+    img = O.render(g, cam, W, H, spp, offs, O.DIRECT, reparam=False, albedo=alb, emitter_u=eu, env=2.0, hide_emitters=True, use_mis=True, bsdf_u=bu)
+    sil = O.render(g, cam, W, H, spp, offs, O.SILHOUETTE, reparam=False)
+    inside = sil[..., 0] > 0.999
+    assert torch.allclose(img[inside].mean(0), 2.0 * torch.tensor([0.8, 0.5, 0.2], dtype=torch.float64), rtol=0.05)
+
+
+@pytest.mark.parametrize('name', ['sphere16', 'blob32', 'blob48_rect'])
+@pytest.mark.parametrize('mode', ['mis', 'detach_indirect_si', 'decouple_reparam', 'mis+decouple'])
+def test_direct_variants_host(harness, name, mode):
+    """Kernel arithmetic (host build) of use_mis and of the two shadow-origin properties against the fp64 C oracle, whose
+    hand-written adjoint test_c_oracle.py pins to torch autograd; gates = 2 x (fp32 C build vs fp64 C build)."""
+    import c_oracle
+    case = make_case(name)
+    ex = direct_inputs(case)
+    bu = _bsdf_u(case) if 'mis' in mode else None
+    variant = 1 if 'detach' in mode else (2 if 'decouple' in mode else 0)
+    a = (case['grid'].float().numpy(), cam_params(case), case['W'], case['H'], case['spp'], case['offsets'].numpy(), ex['emitter_u'].numpy(),
+         ex['albedo'].numpy(), case['grad_image'].numpy(), ex['env'])
+    kw = dict(bsdf_u=None if bu is None else bu.numpy(), variant=variant)
+    gd64, ga64, img64 = c_oracle.render_direct_backward(P.clib(True), *a, **kw)
+    gd32, ga32, _ = c_oracle.render_direct_backward(P.clib(False), *a, **kw)
+    gg, galb, _, img = harness.render_direct_backward(*a[:8], a[8], a[9], bsdf_u=None if bu is None else bu.numpy(), variant=variant)
+    assert rel_l2(img, img64) < FWD_TOL
+    tol_d, tol_a = max(2 * rel_l2(gd32, gd64), 1e-4), max(2 * rel_l2(ga32, ga64), 1e-4)
+    assert rel_l2(galb, ga64) < tol_a, (rel_l2(galb, ga64), tol_a)
+    assert rel_l2(gg, gd64) < tol_d, (rel_l2(gg, gd64), tol_d)
+    if mode != 'mis':                                                          # the variants change the gradient, never the image
+        base = c_oracle.render_direct_backward(P.clib(True), *a, bsdf_u=kw['bsdf_u'])
+        assert rel_l2(img64, base[2]) < 1e-12
+        if name == 'blob32':                                                   # (the shadow-ray warp is active on this case only)
+            assert rel_l2(gd64, base[0]) > 1e-4
+    # primal pass (value-only traces) renders the same image
+    fwd = harness.render_direct_forward(*a[:8], a[9], bsdf_u=None if bu is None else bu.numpy(), variant=variant)
+    assert rel_l2(fwd, img64) < FWD_TOL

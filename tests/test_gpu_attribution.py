@@ -31,11 +31,10 @@ def dsdf(built):
     return m
 
 
-def _per_ray_disagreement(dsdf, case, grid, lanes):
+def _per_ray_disagreement(dsdf, case, grid, rays, lanes):
     """fp32 HIP (dsdf_trace) vs fp64 C oracle on identical fp32 rays: per ray, the largest relative difference among the warp
     outputs the gradient is built from (warp_t, warp_t_d, warp_weight, warp_weight_d; warp.py:56-88)."""
-    o, d, maxt = P.lane_rays(case)
-    o, d, maxt = o[lanes], d[lanes], maxt[lanes]
+    o, d, maxt = (t[lanes] for t in rays)
     hip = dsdf.trace(grid, o.cuda(), d.cuda(), maxt.cuda(), differentiable=True)
     ref = c_oracle.trace(P.clib(True), case['grid'].float().numpy(), o.double().numpy(), d.double().numpy(), maxt.double().numpy(), diff=True)
     ok = np.isfinite(ref['warp_t']) & np.isfinite(hip['warp_t'].cpu().numpy())
@@ -71,7 +70,8 @@ def test_gradient_error_is_attributed_to_named_samples(dsdf, name):
     if not centres:
         return
     # ---- name the samples: warp points of all lanes (HIP per-ray kernel), those inside a removed cube
-    o, d, maxt = P.lane_rays(case)
+    rays = P.lane_rays(case)
+    o, d, maxt = rays
     tr = dsdf.trace(grid, o.cuda(), d.cuda(), maxt.cuda(), differentiable=True)
     wt = tr['warp_t'].cpu()
     fin = torch.isfinite(wt) & (tr['warp_weight'].cpu() > 0)
@@ -82,14 +82,14 @@ def test_gradient_error_is_attributed_to_named_samples(dsdf, name):
     # bulk disagreement between fp32 and fp64 on a random sample of warped rays
     gen = torch.Generator().manual_seed(0)
     bulk_l = idx[torch.randperm(len(idx), generator=gen)[:20000]].numpy()
-    bulk, _, _ = _per_ray_disagreement(dsdf, case, grid, bulk_l)
+    bulk, _, _ = _per_ray_disagreement(dsdf, case, grid, rays, bulk_l)
     med = float(np.median(bulk[bulk > 0])) if (bulk > 0).any() else 0.0
     named = []
     for (cz, cy, cx) in centres:
         m = ((cell[:, 0] - cx).abs() <= 4) & ((cell[:, 1] - cy).abs() <= 4) & ((cell[:, 2] - cz).abs() <= 4)
         cand = idx[m].numpy()
         assert len(cand) > 0, f"{name}: no sample warps into the cube at {(cz, cy, cx)} -- unexplained error"
-        dis, hip, ref = _per_ray_disagreement(dsdf, case, grid, cand)
+        dis, hip, ref = _per_ray_disagreement(dsdf, case, grid, rays, cand)
         w = int(np.argmax(dis))
         named.append(dict(cube=(cz, cy, cx), samples_in_cube=int(len(cand)), lane=int(cand[w]), disagreement=float(dis[w]),
                           steps_hip=int(hip['steps'][w].cpu()), steps_fp64=int(ref['steps'][w]), bulk_median=med))

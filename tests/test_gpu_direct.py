@@ -141,3 +141,68 @@ def test_direct_gradient_vs_finite_differences_gpu(dsdf):
     fd_a = (L(scale=1.01) - L(scale=0.99)) / 0.02                      # the render is linear in the albedo
     ad_a = float((galb * alb).sum())
     assert abs(ad_a - fd_a) < 0.01 * abs(fd_a) + 1e-3, (ad_a, fd_a)
+
+
+@pytest.mark.parametrize('name', ['sphere16', 'blob32', 'blob32_spp64', 'blob48_rect'])
+@pytest.mark.parametrize('mode', ['mis', 'detach_indirect_si', 'decouple_reparam', 'mis+decouple'])
+def test_direct_variants_gpu(dsdf, name, mode):
+    """use_mis (sdf_direct_reparam.py:77-105: emitter + BSDF sampling, power heuristic) and the detach_indirect_si /
+    decouple_reparam properties (:13-14, 44-47) through the C-ABI against the fp64 C oracle (its adjoint is pinned to torch
+    autograd by tests/test_c_oracle.py); gates = 2 x (fp32 C build vs fp64 C build)."""
+    import c_oracle
+    case = make_case(name)
+    ex = direct_inputs(case)
+    gen = torch.Generator().manual_seed(3)
+    bu = torch.rand(case['offsets'].shape[0], 2, generator=gen, dtype=torch.float32) if 'mis' in mode else None
+    variant = 1 if 'detach' in mode else (2 if 'decouple' in mode else 0)
+    a = (case['grid'].float().numpy(), case['cam'].params(), case['W'], case['H'], case['spp'], case['offsets'].numpy(), ex['emitter_u'].numpy(),
+         ex['albedo'].numpy(), case['grad_image'].numpy(), ex['env'])
+    kw = dict(bsdf_u=None if bu is None else bu.numpy(), variant=variant)
+    gd64, ga64, img64 = c_oracle.render_direct_backward(P.clib(True), *a, **kw)
+    gd32, ga32, _ = c_oracle.render_direct_backward(P.clib(False), *a, **kw)
+    grid = dsdf.SdfGrid(case['grid'].float().cuda())
+    sen = dsdf.get_regular_cameras(case['ncam'], resx=case['W'], resy=case['H'])[case['icam']]
+    sh = dsdf.Shading(ex['albedo'].cuda(), ex['env'], use_mis=bu is not None, detach_indirect_si=variant == 1, decouple_reparam=variant == 2)
+    galb = torch.zeros_like(sh.albedo)
+    bs = None if bu is None else bu.cuda()
+    gg, img = dsdf.render_backward(grid, sen, case['spp'], case['grad_image'].cuda()[None], offsets=case['offsets'].cuda(),
+                                   integrator='sdf_direct_reparam', return_image=True, shading=sh, emitter_samples=ex['emitter_u'].cuda(),
+                                   grad_albedo=galb, bsdf_samples=bs)
+    assert rel_l2(img[0].cpu(), img64) < FWD_TOL
+    fwd = dsdf.render_forward(grid, sen, case['spp'], offsets=case['offsets'].cuda(), integrator='sdf_direct_reparam', shading=sh,
+                              emitter_samples=ex['emitter_u'].cuda(), bsdf_samples=bs)
+    assert rel_l2(fwd[0].cpu(), img64) < FWD_TOL                               # primal pass: value-only traces, same image
+    tol_d, tol_a = max(2 * rel_l2(gd32, gd64), 1e-4), max(2 * rel_l2(ga32, ga64), 1e-4)
+    ea, ed = rel_l2(galb.cpu(), ga64), rel_l2(gg.cpu(), gd64)
+    P.record('grad_direct_variant', case=name, mode=mode, err_data=ed, err_albedo=ea, tol_data=tol_d, tol_albedo=tol_a)
+    assert ea < tol_a, (ea, tol_a)
+    assert ed < tol_d, (ed, tol_d)
+
+
+def test_direct_mis_builtin_sampler_and_known_answer(dsdf):
+    """The built-in sampler's BSDF sample (floats 6,7 of the lane's stream) equals explicit samples; MIS is unbiased: a convex
+    object under a constant environment radiates albedo * L with and without it."""
+    case = make_case('blob48_rect')
+    ex = direct_inputs(case)
+    grid = dsdf.SdfGrid(case['grid'].float().cuda())
+    sh = dsdf.Shading(ex['albedo'].cuda(), ex['env'], use_mis=True)
+    sens = dsdf.get_regular_cameras(12, resx=case['W'], resy=case['H'])[:2]
+    n = (case['W'] + 4) * (case['H'] + 4) * 4
+    offs = torch.cat([torch.tensor(O.independent_sampler_2d(5 + i, n)) for i in range(2)]).cuda()
+    emit = torch.cat([torch.tensor(O.independent_sampler_emitter_2d(5 + i, n)) for i in range(2)]).cuda()
+    bsdf = torch.cat([torch.tensor(O.independent_sampler_bsdf_2d(5 + i, n)) for i in range(2)]).cuda()
+    a = dsdf.render_forward(grid, sens, 4, seeds=[5, 6], integrator='sdf_direct_reparam', shading=sh)
+    b = dsdf.render_forward(grid, sens, 4, offsets=offs, integrator='sdf_direct_reparam', shading=sh, emitter_samples=emit, bsdf_samples=bsdf)
+    assert rel_l2(a.cpu(), b.cpu()) < 1e-6
+    R, W, H = 64, 48, 48
+    g2 = dsdf.SdfGrid(O.sphere_grid(R, radius=0.3).float().cuda())
+    alb = torch.zeros(4, 4, 4, 3, device='cuda')
+    alb[..., 0], alb[..., 1], alb[..., 2] = 0.8, 0.5, 0.2
+    s2 = dsdf.get_regular_cameras(4, resx=W, resy=H)[:2]
+    sil = dsdf.render_forward(g2, s2, 256, seeds=[3, 4])
+    inside = sil[..., 0] > 0.999
+    for mis in (False, True):
+        img = dsdf.render_forward(g2, s2, 256, seeds=[3, 4], integrator='sdf_direct_reparam',
+                                  shading=dsdf.Shading(alb, 2.0, hide_emitters=True, use_mis=mis))
+        mean = img[inside].mean(0).cpu()
+        assert torch.allclose(mean, 2.0 * torch.tensor([0.8, 0.5, 0.2]), rtol=0.02), (mis, mean)
