@@ -8,7 +8,7 @@ import torch
 
 import c_oracle
 import sdf_oracle as O
-from cases import make_case, oracle_backward, oracle_forward
+from cases import direct_inputs, make_case, oracle_backward, oracle_forward
 import precision as P
 from conftest import rel_l2
 
