@@ -237,3 +237,20 @@ __global__ void k_develop_tangent(const float *__restrict__ blocks, const float 
     float *o = grad_images + (size_t)blockIdx.y * 3 * W * H + 3 * (size_t)i;
     o[0] = g; o[1] = g; o[2] = g;
 }
+
+// the same for the 4-channel (r,g,b,weight) block of sdf_direct_reparam
+__global__ void k_develop_tangent_rgb(const float *__restrict__ blocks, const float *__restrict__ dblocks, int W, int H,
+                                      float *__restrict__ grad_images) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= W * H) return;
+    int y = i / W, x = i - y * W;
+    int Wb = W + 2 * DSDF_BORDER, Hb = H + 2 * DSDF_BORDER;
+    size_t qi = (size_t)blockIdx.y * Wb * Hb + (size_t)(y + DSDF_BORDER) * Wb + x + DSDF_BORDER;
+    float4 b = reinterpret_cast<const float4 *>(blocks)[qi], db = reinterpret_cast<const float4 *>(dblocks)[qi];
+    float *o = grad_images + (size_t)blockIdx.y * 3 * W * H + 3 * (size_t)i;
+    if (b.w == 0.f) { o[0] = db.x; o[1] = db.y; o[2] = db.z; }
+    else {
+        const float iw = 1.f / b.w, k = db.w * iw * iw;
+        o[0] = db.x * iw - b.x * k; o[1] = db.y * iw - b.y * k; o[2] = db.z * iw - b.z * k;
+    }
+}

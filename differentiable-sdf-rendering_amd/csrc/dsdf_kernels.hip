@@ -613,10 +613,12 @@ __global__ __launch_bounds__(64) void k_backward(GridView G, dsdf_params P, View
 // Forward mode (`render_forward`, integrators/reparam.py:192-196): the queued samples of the gradient pass push
 // the tangent of their film contribution into a tangent film block (the transpose of k_backward: gathers from
 // the tangent grid instead of scattering into the gradient grid).
+template <bool DIRECT>
 __global__ __launch_bounds__(64) void k_forward_tangent(GridView G, const float *__restrict__ tangent, V3 dp, dsdf_params P,
-                                                        ViewBatch VB, Queue qall, float *__restrict__ dblocks) {
+                                                        ViewBatch VB, Queue qall, float *__restrict__ dblocks, ShadeArgs S) {
     const ViewArgs &A = VB.v[blockIdx.y];
-    float *__restrict__ dblock = dblocks + (size_t)blockIdx.y * 2 * A.Wb * A.Hb;
+    constexpr int NCH = DIRECT ? 4 : 2;
+    float *__restrict__ dblock = dblocks + (size_t)blockIdx.y * NCH * A.Wb * A.Hb;
     const Queue q = view_queue(qall, blockIdx.y);
     UnitGather ug;
     ug.init(q, blockIdx.x);
@@ -625,8 +627,16 @@ __global__ __launch_bounds__(64) void k_forward_tangent(GridView G, const float 
         TraceOut tr;
         load_record(q.rec + lane, q.cap, tr);
         Lane L = lane_setup(A, P, lane);
-        SampleTangent st;
-        if (lane_forward_tangent(G, tangent, dp, P, A, L, tr, st)) splat_tangent(dblock, A.Wb, A.Hb, st, AtomicAdd());
+        if (DIRECT) {
+            TraceOut trs, trb;
+            load_record(q.rec + lane + 9 * (size_t)q.cap, q.cap, trs);
+            if (S.use_mis) load_record(q.rec + lane + 18 * (size_t)q.cap, q.cap, trb); else clear_trace_out(trb, 0.f);
+            SampleTangentRgb st;
+            if (lane_forward_tangent_direct(G, tangent, dp, P, A, S, L, lane, tr, trs, trb, st)) splat_tangent_rgb(dblock, A.Wb, A.Hb, st, AtomicAdd());
+        } else {
+            SampleTangent st;
+            if (lane_forward_tangent(G, tangent, dp, P, A, L, tr, st)) splat_tangent(dblock, A.Wb, A.Hb, st, AtomicAdd());
+        }
     }
 }
 
@@ -1170,34 +1180,38 @@ int dsdf_render_backward(const float *padded, int rx, int ry, int rz, const dsdf
 
 int dsdf_render_forward_grad(const float *padded, int rx, int ry, int rz, const dsdf_params *prm, const dsdf_camera *cams,
                              int n_views, int width, int height, int spp, const float *offsets, const uint32_t *seeds,
-                             int integrator, int flags, const float *tangent_padded, const float *tangent_p,
+                             int integrator, int flags, const dsdf_shading *shading, const float *tangent_padded, const float *tangent_p,
                              float *grad_image_out, float *image_out, void *workspace, size_t workspace_bytes, void *stream) {
-    int rc = check_render_args(padded, rx, ry, rz, prm, cams, n_views, width, height, spp, integrator, nullptr, workspace,
+    int rc = check_render_args(padded, rx, ry, rz, prm, cams, n_views, width, height, spp, integrator, shading, workspace,
                                workspace_bytes, true);
     if (rc) return rc;
-    if (integrator == DSDF_DIRECT) return fail(DSDF_ERR_INVALID_ARG, "dsdf_render_forward_grad: sdf_direct_reparam is not supported");
     if (!grad_image_out) return fail(DSDF_ERR_INVALID_ARG, "dsdf_render_forward_grad: grad_image_out is null");
     if (!tangent_padded && !tangent_p) return fail(DSDF_ERR_INVALID_ARG, "dsdf_render_forward_grad: need a tangent");
     if (!offsets && !seeds) return fail(DSDF_ERR_INVALID_ARG, "dsdf_render_forward_grad: need offsets or seeds");
-    const PassCtx c = make_ctx(padded, rx, ry, rz, prm, width, height, spp, offsets, seeds, integrator, flags, nullptr, stream);
+    const PassCtx c = make_ctx(padded, rx, ry, rz, prm, width, height, spp, offsets, seeds, integrator, flags, shading, stream);
     hipStream_t st = c.st;
     const int nb = batch_size(width, height, spp, n_views, integrator, workspace_bytes, true);
     const Workspace ws = carve(workspace, width, height, spp, nb, integrator, true);
-    const Queue q = make_queue(ws, false);
+    const Queue q = make_queue(ws, c.direct);
     const GridView G = device_view(padded, rx, ry, rz, *prm);
+    const ShadeArgs S = make_shade_args(shading, false);
+    const size_t nch = (size_t)film_channels(integrator);
     const V3 dp = tangent_p ? mk(tangent_p[0], tangent_p[1], tangent_p[2]) : mk(0.f, 0.f, 0.f);
     for (int v0 = 0; v0 < n_views; v0 += nb) {
         const int nv = (n_views - v0) < nb ? (n_views - v0) : nb;
         ViewBatch VB;
         if ((rc = run_pass<true>(c, ws, cams, v0, nv, VB, q, nullptr))) return rc;
         // the tangent film block lives in the adjoint block's storage
-        if (hipMemsetAsync(ws.block_adj, 0, nv * c.Wb * c.Hb * 2 * sizeof(float), st) != hipSuccess)
+        if (hipMemsetAsync(ws.block_adj, 0, nv * c.Wb * c.Hb * nch * sizeof(float), st) != hipSuccess)
             return fail(DSDF_ERR_LAUNCH, "hipMemsetAsync(tangent block) failed");
-        hipLaunchKernelGGL(k_forward_tangent, dim3((ws.nunits + DSDF_BWD_UNITS - 1) / DSDF_BWD_UNITS, nv), dim3(64), 0, st, G, tangent_padded, dp, c.pp, VB, q, ws.block_adj);
+        const dim3 tgrid((ws.nunits + DSDF_BWD_UNITS - 1) / DSDF_BWD_UNITS, nv);
+        if (c.direct) hipLaunchKernelGGL(k_forward_tangent<true>, tgrid, dim3(64), 0, st, G, tangent_padded, dp, c.pp, VB, q, ws.block_adj, S);
+        else hipLaunchKernelGGL(k_forward_tangent<false>, tgrid, dim3(64), 0, st, G, tangent_padded, dp, c.pp, VB, q, ws.block_adj, S);
         if ((rc = check_launch("k_forward_tangent"))) return rc;
         const dim3 dev_grid((width * height + 255) / 256, nv);
-        hipLaunchKernelGGL(k_develop_tangent, dev_grid, dim3(256), 0, st, ws.block, ws.block_adj, width, height,
-                           grad_image_out + (size_t)v0 * width * height * 3);
+        float *gout = grad_image_out + (size_t)v0 * width * height * 3;
+        if (c.direct) hipLaunchKernelGGL(k_develop_tangent_rgb, dev_grid, dim3(256), 0, st, ws.block, ws.block_adj, width, height, gout);
+        else hipLaunchKernelGGL(k_develop_tangent, dev_grid, dim3(256), 0, st, ws.block, ws.block_adj, width, height, gout);
         if ((rc = check_launch("k_develop_tangent"))) return rc;
         if (image_out && (rc = develop_batch(c, ws, nv, image_out + (size_t)v0 * width * height * 3))) return rc;
     }

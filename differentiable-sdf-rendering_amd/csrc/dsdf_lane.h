@@ -641,4 +641,158 @@ DSDF_HD bool lane_backward_direct(const GridView &G, const dsdf_params &P, const
     return did;
 }
 
+// ---------------------------------------------------------------------------
+// Forward mode of sdf_direct_reparam (`render_forward`, integrators/reparam.py:192-196): the transpose of
+// lane_backward_direct.  Tangent inputs as in lane_forward_tangent: a tangent grid T (d sdf.data, may be absent) and a
+// tangent dp of sdf.p; at a lookup point x that itself moves by dx,  dv = T(x) - g . dp + g . dx,  dg = grad T(x) - H dp + H dx.
+//   primary warp      d d' = cdir dv_w,  d div = a dv_w + b . dg_w
+//   hit point         dt = (dv_0 + t G . d d') / (G . -d),  d p = t d d' + d dt,  dG = dg_0 + H d p,  dn = (I - n n^T) dG / |G|
+//   secondary rays    start at the attached hit (shadow ray: or detached / at the hit of the un-warped ray, ShadeArgs.variant):
+//                     d d_s' = cdir_s dv_sw,  d det_e = a_s dv_sw + b_s . dg_sw  (the same with b for the BSDF-sampled ray)
+//   radiance          d rgb_c = env_c (ke + kb) grad a_c . d p + a_c env_c 4 w_e (dn . d_s + n . d d_s') + rgb_e,c d det_e + rgb_b,c d det_b
+// Outputs: tangents of the sample's three value channel entries, of its weight entry and of its film position.
+// ---------------------------------------------------------------------------
+struct SampleTangentRgb { float val[3], d_val[3], d_w, d_u, d_v, u, v; };
+
+DSDF_HD void tangent_lookup(const GridView &G, const GridView &T, bool has_t, V3 x, V3 g, const float H[6], V3 dp, V3 dx, float &dv, V3 &dg) {
+    float tv = 0.f; V3 tg = mk(0.f, 0.f, 0.f); float tH[6];
+    if (has_t) eval_cubic<1>(T, x, tv, tg, tH);
+    const V3 m = dx - dp;
+    dv = tv + dot(g, m);
+    dg = tg + symmul(H, m);
+}
+
+DSDF_HD bool lane_forward_tangent_direct(const GridView &G, const float *tangent, V3 dp, const dsdf_params &P, const ViewArgs &A,
+                                         const ShadeArgs &S, const Lane &L, uint32_t lane, const TraceOut &tr, const TraceOut &trs,
+                                         const TraceOut &trb, SampleTangentRgb &out) {
+    const V3 o = L.ray.o, d = L.ray.d;
+    const bool hit = tr.its_t < INFINITY;
+    GridView T = G;
+    T.p = tangent;
+    const bool has_t = tangent != nullptr;
+    Reproj rp = reproject(A.cam, P, o + d, A.W, A.H);
+    out.u = rp.u; out.v = rp.v;
+    out.d_w = 0.f; out.d_u = 0.f; out.d_v = 0.f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { out.val[c] = 0.f; out.d_val[c] = 0.f; }
+    const V3 zero = mk(0.f, 0.f, 0.f);
+    V3 d_dir = zero;
+    float d_div = 0.f;
+    bool did = false;
+    if (A.flags & DSDF_REPARAM) {
+        WarpCoef wc;
+        if (warp_coefficients(G, P, o, d, tr, wc)) {
+            float dv; V3 dg;
+            tangent_lookup(G, T, has_t, fma3(tr.warp_t, d, o), wc.g, wc.H, dp, zero, dv, dg);
+            d_dir = dv * wc.cdir;
+            d_div = wc.a * dv + dot(wc.b, dg);
+            did = true;
+        }
+    }
+    if (!hit) {
+        if (!S.hide_emitters) { out.val[0] = S.env[0]; out.val[1] = S.env[1]; out.val[2] = S.env[2]; }
+    } else {
+        DirectHit h;
+        const bool front = direct_setup(G, A, L, lane, tr.its_t, h);
+        BsdfRay br;
+        br.active = false;
+        int lit = 0;
+        float ke = 0.f, kb = 0.f, we = 1.f;
+        if (front && !(trs.its_t < INFINITY)) { ke = emitter_factor(S, h, we); lit |= 1; }
+        if (S.use_mis) {
+            br = bsdf_setup(A, L, lane, h);
+            if (br.active && !(trb.its_t < INFINITY)) { kb = bsdf_factor(br); lit |= 2; }
+        }
+        if (lit) {
+            float alb[3]; V3 ag[3];
+            eval_trilinear(S.albedo, h.p, alb, ag);
+            float vhit; V3 ghit; float Hhit[6];
+            eval_cubic<2>(G, h.p, vhit, ghit, Hhit);
+            const float gl = sqrtf(dot(ghit, ghit));
+            const V3 n = ghit * (1.f / gl);
+            const float cden = dot(ghit, -d);
+            // hit point: value tangent at the hit without / with the warped direction
+            float dv_plain; V3 dg0;
+            tangent_lookup(G, T, has_t, h.p, ghit, Hhit, dp, zero, dv_plain, dg0);
+            const float dt0 = dv_plain / cden;                                   // hit of the UN-warped ray (si_d0)
+            const float dt = (dv_plain + tr.its_t * dot(ghit, d_dir)) / cden;
+            const V3 dpos = tr.its_t * d_dir + dt * d, dpos0 = dt0 * d;
+            const V3 dG = dg0 + symmul(Hhit, dpos);
+            const V3 dn = (dG - dot(n, dG) * n) * (1.f / gl);
+            float d_det_e = 0.f, d_det_b = 0.f;
+            V3 d_sdir = zero;
+            if (A.flags & DSDF_REPARAM) {
+                WarpCoef ws;
+                if ((lit & 1) && warp_coefficients(G, P, h.sr.o, h.sr.d, trs, ws)) {
+                    const V3 dorig = S.variant == 1 ? zero : (S.variant == 2 ? dpos0 : dpos);
+                    float dv; V3 dg;
+                    tangent_lookup(G, T, has_t, fma3(trs.warp_t, h.sr.d, h.sr.o), ws.g, ws.H, dp, dorig, dv, dg);
+                    d_sdir = dv * ws.cdir;
+                    d_det_e = ws.a * dv + dot(ws.b, dg);
+                }
+                if ((lit & 2) && warp_coefficients(G, P, br.o, br.d, trb, ws)) {
+                    float dv; V3 dg;
+                    tangent_lookup(G, T, has_t, fma3(trb.warp_t, br.d, br.o), ws.g, ws.H, dp, dpos, dv, dg);
+                    d_det_b = ws.a * dv + dot(ws.b, dg);
+                }
+            }
+            const float d_cos = (lit & 1) ? dot(dn, h.sr.d) + dot(n, d_sdir) : 0.f;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float re = alb[c] * ke * S.env[c], rb = alb[c] * kb * S.env[c];
+                out.val[c] = re + rb;
+                out.d_val[c] = S.env[c] * (ke + kb) * dot(ag[c], dpos) + alb[c] * S.env[c] * 4.f * we * d_cos + re * d_det_e + rb * d_det_b;
+            }
+            did = true;
+        }
+    }
+    const V3 dref = mk(A.cam.left[0] * d_dir.x + A.cam.left[1] * d_dir.y + A.cam.left[2] * d_dir.z,
+                       A.cam.up[0] * d_dir.x + A.cam.up[1] * d_dir.y + A.cam.up[2] * d_dir.z,
+                       A.cam.dir[0] * d_dir.x + A.cam.dir[1] * d_dir.y + A.cam.dir[2] * d_dir.z);
+    const float iz = 1.f / rp.ref.z;
+    const float ku = -0.5f * (float)A.W / A.cam.tan_half_fov;
+    out.d_u = ku * iz * (dref.x - rp.ref.x * iz * dref.z);
+    out.d_v = ku * iz * (dref.y - rp.ref.y * iz * dref.z);
+    float d_rw = 0.f;
+    if (rp.inside) d_rw = dot(rp.ref, dref) / (rp.dist * rp.dist) - 3.f * iz * dref.z;
+    out.d_w = d_div + d_rw;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) out.d_val[c] = out.d_val[c] + out.val[c] * out.d_w;
+    return did;
+}
+
+// splat of a sample tangent into the 4-channel tangent film block
+template <class Adder>
+DSDF_HD void splat_tangent_rgb(float *dblock, int Wb, int Hb, const SampleTangentRgb &s, Adder add) {
+    float pfx = s.u + (DSDF_BORDER - 0.5f), pfy = s.v + (DSDF_BORDER - 0.5f);
+    int x0 = (int)ceilf(pfx - DSDF_FILTER_RADIUS), y0 = (int)ceilf(pfy - DSDF_FILTER_RADIUS);
+    float wx[4], wy[4], dwx[4], dwy[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        float rx = (float)(x0 + i) - pfx, ry = (float)(y0 + i) - pfy;
+        wx[i] = gauss_f(rx); dwx[i] = gauss_df(rx);
+        wy[i] = gauss_f(ry); dwy[i] = gauss_df(ry);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        int qy = y0 + j;
+        if (qy < 0 || qy >= Hb) continue;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int qx = x0 + i;
+            if (qx < 0 || qx >= Wb) continue;
+            float f = wx[i] * wy[j];
+            float dfp = -dwx[i] * wy[j] * s.d_u - wx[i] * dwy[j] * s.d_v;
+            float *dst = dblock + 4 * ((size_t)qy * Wb + qx);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                float tv = f * s.d_val[c] + s.val[c] * dfp;
+                if (tv != 0.f) add(dst + c, tv);
+            }
+            float tw = f * s.d_w + dfp;
+            if (tw != 0.f) add(dst + 3, tw);
+        }
+    }
+}
+
 }  // namespace dsdf

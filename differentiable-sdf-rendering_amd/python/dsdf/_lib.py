@@ -67,7 +67,7 @@ SYMBOLS = {
                                       C.c_size_t, C.c_void_p, C.c_void_p]),
     'dsdf_render_forward_grad': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(DsdfParams),
                                            C.POINTER(DsdfCamera), C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
-                                           C.POINTER(C.c_uint32), C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_float),
+                                           C.POINTER(C.c_uint32), C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_float),
                                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     'dsdf_render_film': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(DsdfParams), C.POINTER(DsdfCamera), C.c_int, C.c_int,
                                    C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_uint32), C.c_int, C.c_int, C.POINTER(DsdfShading), C.c_int,

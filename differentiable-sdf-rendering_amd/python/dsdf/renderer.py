@@ -339,7 +339,8 @@ def render_backward(grid, sensors, spp, grad_image, grad_grid=None, seeds=None, 
 
 
 def render_forward_grad(grid, sensors, spp, tangent_data=None, tangent_p=None, seeds=None, offsets=None,
-                        integrator=DSDF_SILHOUETTE, reparam=True, return_image=False, empty_space_skip=True):
+                        integrator=DSDF_SILHOUETTE, reparam=True, return_image=False, empty_space_skip=True, shading=None,
+                        emitter_samples=None, bsdf_samples=None):
     """`ReparamIntegrator.render_forward` (python/integrators/reparam.py:192-196): forward-mode gradient image(s)
     (n_views,H,W,3) for a tangent on sdf.data (tensor shaped like the grid) and / or on sdf.p (3 floats)."""
     lib = _lib.load()
@@ -365,10 +366,11 @@ def render_forward_grad(grid, sensors, spp, tangent_data=None, tangent_p=None, s
     wsb = lib.dsdf_render_workspace_size(W, H, int(spp), min(nv, MAX_VIEWS_PER_LAUNCH), INTEGRATORS[integrator])
     ws = _workspace(dev, wsb, lib.dsdf_render_workspace_size(W, H, int(spp), 1, INTEGRATORS[integrator]))
     wsb = ws.numel()
+    sh, _keep = _shading_arg(integrator, shading, nv, n_lanes, emitter_samples, bsdf_samples=bsdf_samples)
     with torch.cuda.device(dev):
         _lib.check(lib.dsdf_render_forward_grad(_ptr(grid.padded), grid.rx, grid.ry, grid.rz, C.byref(grid.params), cams, nv,
                                                 W, H, int(spp), _ptr(offsets), cseeds, INTEGRATORS[integrator],
-                                                (DSDF_REPARAM if reparam else 0) | (0 if empty_space_skip else DSDF_NO_SKIP),
+                                                (DSDF_REPARAM if reparam else 0) | (0 if empty_space_skip else DSDF_NO_SKIP), sh,
                                                 _ptr(tpad), tp, _ptr(out), _ptr(img), _ptr(ws), wsb, _stream()))
     return (out, img) if return_image else out
 

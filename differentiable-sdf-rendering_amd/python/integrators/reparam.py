@@ -150,7 +150,8 @@ class ReparamIntegrator:
         if td is None and tp is None:
             raise ValueError("render_forward: set the tangent of sdf.data and / or sdf.p through their .grad fields")
         g = dsdf.render_forward_grad(self.sdf.grid, sens, spp or 4, tangent_data=td, tangent_p=tp,
-                                     seeds=[seed + i for i in range(len(sens))], integrator=self.integrator_id, reparam=reparam)
+                                     seeds=[seed + i for i in range(len(sens))], integrator=self.integrator_id, reparam=reparam,
+                                     shading=self.shading())
         return g[0] if len(sens) == 1 and not isinstance(sensor, (list, tuple)) else g
 
     def traverse(self, cb):

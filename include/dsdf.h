@@ -214,10 +214,12 @@ int dsdf_render_backward(const float *padded, int rx, int ry, int rz, const dsdf
  *   tangent_padded : d(sdf.data)/d theta as a padded grid buffer (dsdf_pad_grid of the tangent tensor), or NULL
  *   tangent_p      : d(sdf.p)/d theta, 3 HOST floats, or NULL -- the reference's gradient-image validation
  *                    differentiates with respect to one axis of sdf.p (figures/result_utils.py:126-161).
- * Silhouette and simple-shading integrators.  image_out (optional) receives the gradient-pass image. */
+ * All three integrators (sdf_direct_reparam: the albedo volume carries no tangent).  image_out (optional) receives the
+ * gradient-pass image. */
 int dsdf_render_forward_grad(const float *padded, int rx, int ry, int rz, const dsdf_params *prm,
                              const dsdf_camera *cams, int n_views, int width, int height, int spp,
                              const float *offsets, const uint32_t *seeds, int integrator, int flags,
+                             const dsdf_shading *shading /* DSDF_DIRECT only, else NULL */,
                              const float *tangent_padded, const float *tangent_p,
                              float *grad_image_out, float *image_out,
                              void *workspace, size_t workspace_bytes, void *stream);

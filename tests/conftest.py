@@ -174,6 +174,25 @@ class HostHarness:
                                            self._p(None if bsdf_u is None else np.ascontiguousarray(bsdf_u, np.float32)), int(variant))
         return gg, ga, gp, img
 
+    def render_direct_forward_grad(self, grid, cam, W, H, spp, offsets, emitter_u, albedo, env=(1.0, 1.0, 1.0), hide_emitters=False,
+                                   reparam=True, seed=0, bsdf_u=None, variant=0, tangent=None, tangent_p=None):
+        grid = np.ascontiguousarray(grid, np.float32)
+        offsets = None if offsets is None else np.ascontiguousarray(offsets, np.float32)
+        emitter_u = None if emitter_u is None else np.ascontiguousarray(emitter_u, np.float32)
+        albedo = np.ascontiguousarray(albedo, np.float32)
+        env = np.asarray(env, np.float32)
+        bu = None if bsdf_u is None else np.ascontiguousarray(bsdf_u, np.float32)
+        t = None if tangent is None else np.ascontiguousarray(tangent, np.float32)
+        tp = None if tangent_p is None else np.ascontiguousarray(tangent_p, np.float32)
+        out = np.zeros((H, W, 3), np.float32)
+        rz, ry, rx = grid.shape
+        az, ay, ax = albedo.shape[:3]
+        self.lib.hh_render_direct_forward_grad(self._p(grid), rx, ry, rz, C.byref(self.params), self._p(cam), W, H, spp,
+                                               self._p(offsets), self._p(emitter_u), C.c_uint(seed), int(reparam), self._p(albedo), ax, ay, az,
+                                               self._p(env), int(hide_emitters), int(bu is not None), self._p(bu), int(variant),
+                                               self._p(t), self._p(tp), self._p(out))
+        return out
+
     def sampler_bsdf(self, seed, n):
         out = np.zeros((n, 2), np.float32)
         self.lib.hh_sampler_bsdf(C.c_uint(seed), C.c_long(n), self._p(out))

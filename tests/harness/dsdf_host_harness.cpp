@@ -333,6 +333,46 @@ void hh_render_direct_backward(const float *data, int rx, int ry, int rz, const 
     }
 }
 
+// Forward mode of sdf_direct_reparam: d image (H,W,3) for a tangent grid (may be null) and a tangent of sdf.p.
+void hh_render_direct_forward_grad(const float *data, int rx, int ry, int rz, const dsdf_params *prm, const dsdf_camera *cam,
+                                   int W, int H, int spp, const float *offsets, const float *emitter_u, unsigned seed, int flags,
+                                   const float *albedo, int ax, int ay, int az, const float *env, int hide, int use_mis,
+                                   const float *bsdf_u, int variant, const float *tangent, const float *tangent_p, float *grad_image) {
+    std::vector<float> p = pad(data, rx, ry, rz);
+    std::vector<float> tp;
+    if (tangent) tp = pad(tangent, rx, ry, rz);
+    GridView G = make_view(p.data(), rx, ry, rz, *prm);
+    ViewArgs A = view_args(cam, W, H, spp, offsets, seed, DSDF_DIRECT, flags);
+    A.emitter_u = emitter_u; A.bsdf_u = bsdf_u;
+    ShadeArgs S = shade_args(albedo, ax, ay, az, env, hide, nullptr);
+    S.use_mis = use_mis; S.variant = variant;
+    V3 dp = tangent_p ? mk(tangent_p[0], tangent_p[1], tangent_p[2]) : mk(0.f, 0.f, 0.f);
+    std::vector<float> block((size_t)4 * A.Wb * A.Hb, 0.f), dblock((size_t)4 * A.Wb * A.Hb, 0.f);
+    long n = (long)A.Wb * A.Hb * spp;
+    for (long lane = 0; lane < n; ++lane) {
+        Lane L = lane_setup(A, *prm, (uint32_t)lane);
+        TraceOut t, ts, tb;
+        trace_diff(G, *prm, L.ray.o, L.ray.d, L.ray.maxt, t);
+        float rgb[3];
+        direct_value(G, *prm, A, S, L, (uint32_t)lane, t.its_t, true, ts, tb, rgb);
+        Reproj rp = reproject(A.cam, *prm, L.ray.o + L.ray.d, W, H);
+        splat_lane_rgb(block.data(), A.Wb, A.Hb, rp.u, rp.v, rgb, PlainAdd());
+        SampleTangentRgb st;
+        if (lane_forward_tangent_direct(G, tangent ? tp.data() : nullptr, dp, *prm, A, S, L, (uint32_t)lane, t, ts, tb, st))
+            splat_tangent_rgb(dblock.data(), A.Wb, A.Hb, st, PlainAdd());
+    }
+    for (int y = 0; y < H; ++y)
+        for (int x = 0; x < W; ++x) {
+            size_t q = (size_t)(y + DSDF_BORDER) * A.Wb + x + DSDF_BORDER;
+            float w = block[4 * q + 3], dw = dblock[4 * q + 3];
+            float *o = grad_image + 3 * ((size_t)y * W + x);
+            for (int c = 0; c < 3; ++c) {
+                float sv = block[4 * q + c], ds = dblock[4 * q + c];
+                o[c] = w == 0.f ? ds : ds / w - sv * dw / (w * w);
+            }
+        }
+}
+
 void hh_sampler_emitter(unsigned seed, long n, float *out) {
     for (long i = 0; i < n; ++i) sampler_emitter_2d(seed, (uint32_t)i, out[2 * i], out[2 * i + 1]);
 }

@@ -166,3 +166,26 @@ def test_direct_variants_host(harness, name, mode):
     # primal pass (value-only traces) renders the same image
     fwd = harness.render_direct_forward(*a[:8], a[9], bsdf_u=None if bu is None else bu.numpy(), variant=variant)
     assert rel_l2(fwd, img64) < FWD_TOL
+
+
+@pytest.mark.parametrize('mode', ['plain', 'mis', 'detach_indirect_si', 'mis+decouple'])
+def test_direct_forward_mode_is_transpose_of_backward_host(harness, mode):
+    """`render_forward` of sdf_direct_reparam (integrators/reparam.py:192-196): <J dtheta, G> = <dtheta, J^T G> for a tangent on
+    sdf.data and on sdf.p -- forward mode and the hand-derived adjoint are transposes of each other on the same samples."""
+    case = make_case('blob32')
+    ex = direct_inputs(case)
+    bu = _bsdf_u(case).numpy() if 'mis' in mode else None
+    variant = 1 if 'detach' in mode else (2 if 'decouple' in mode else 0)
+    a = (case['grid'].float().numpy(), cam_params(case), case['W'], case['H'], case['spp'], case['offsets'].numpy(), ex['emitter_u'].numpy(),
+         ex['albedo'].numpy())
+    gi = case['grad_image'].numpy()
+    gg, _, gp, _ = harness.render_direct_backward(*a, gi, ex['env'], bsdf_u=bu, variant=variant)
+    rng = np.random.default_rng(5)
+    tdata = rng.standard_normal(gg.shape).astype(np.float32)
+    tp = np.array([0.3, -0.2, 0.5], np.float32)
+    jd = harness.render_direct_forward_grad(*a, ex['env'], bsdf_u=bu, variant=variant, tangent=tdata)
+    jp = harness.render_direct_forward_grad(*a, ex['env'], bsdf_u=bu, variant=variant, tangent_p=tp)
+    lhs_d, rhs_d = float((jd.astype(np.float64) * gi).sum()), float((tdata.astype(np.float64) * gg).sum())
+    lhs_p, rhs_p = float((jp.astype(np.float64) * gi).sum()), float((tp.astype(np.float64) * gp).sum())
+    assert abs(lhs_d - rhs_d) <= 2e-3 * max(abs(rhs_d), 1e-6), (lhs_d, rhs_d)
+    assert abs(lhs_p - rhs_p) <= 2e-3 * max(abs(rhs_p), 1e-6), (lhs_p, rhs_p)

@@ -206,3 +206,42 @@ def test_direct_mis_builtin_sampler_and_known_answer(dsdf):
                                   shading=dsdf.Shading(alb, 2.0, hide_emitters=True, use_mis=mis))
         mean = img[inside].mean(0).cpu()
         assert torch.allclose(mean, 2.0 * torch.tensor([0.8, 0.5, 0.2]), rtol=0.02), (mis, mean)
+
+
+@pytest.mark.parametrize('mode', ['plain', 'mis', 'mis+decouple'])
+def test_direct_forward_mode_gpu(dsdf, mode):
+    """`render_forward` of sdf_direct_reparam through the C-ABI (dsdf_render_forward_grad): transpose identity
+    <J dtheta, G> = <dtheta, J^T G> against dsdf_render_backward on the same samples, for tangents on sdf.data and sdf.p, and the
+    translation tangent against central differences of the un-reparameterised render (figures/result_utils.py:126-161)."""
+    R, W, H = 48, 32, 32
+    data = O.blob_grid(R, n=10, seed=3).float().cuda()
+    grid = dsdf.SdfGrid(data)
+    sens = dsdf.get_regular_cameras(6, resx=W, resy=H)[:2]
+    torch.manual_seed(2)
+    alb = torch.rand(6, 5, 4, 3, device='cuda') * 0.6 + 0.2
+    sh = dsdf.Shading(alb, (1.0, 0.9, 0.8), use_mis='mis' in mode, decouple_reparam='decouple' in mode)
+    gi = torch.randn(2, H, W, 3, device='cuda')
+    gp = torch.zeros(3, device='cuda')
+    gg = dsdf.render_backward(grid, sens, 64, gi, seeds=[4, 5], integrator='sdf_direct_reparam', shading=sh, grad_p=gp)
+    tdata = torch.randn_like(data)
+    tpv = [0.3, -0.2, 0.5]
+    jd = dsdf.render_forward_grad(grid, sens, 64, tangent_data=tdata, seeds=[4, 5], integrator='sdf_direct_reparam', shading=sh)
+    jp = dsdf.render_forward_grad(grid, sens, 64, tangent_p=tpv, seeds=[4, 5], integrator='sdf_direct_reparam', shading=sh)
+    lhs_d, rhs_d = float((jd.double() * gi).sum()), float((tdata.double() * gg).sum())
+    lhs_p, rhs_p = float((jp.double() * gi).sum()), float(sum(a * float(b) for a, b in zip(tpv, gp)))
+    assert abs(lhs_d - rhs_d) <= 5e-3 * max(abs(rhs_d), 1e-6), (lhs_d, rhs_d)
+    assert abs(lhs_p - rhs_p) <= 5e-3 * max(abs(rhs_p), 1e-6), (lhs_p, rhs_p)
+    if mode == 'plain':
+        # gradient image w.r.t. a translation along x at 2048 spp vs central differences with common random numbers
+        spp = 2048
+        yy, xx = torch.meshgrid(torch.arange(H, device='cuda'), torch.arange(W, device='cuda'), indexing='ij')
+        Gw = torch.stack([xx / W, yy / H, (xx + yy) / (W + H)], -1).float()[None].repeat(2, 1, 1, 1)
+        fwd = dsdf.render_forward_grad(grid, sens, spp, tangent_p=[1.0, 0.0, 0.0], seeds=[11, 12], integrator='sdf_direct_reparam', shading=sh)
+        eps = 2e-3
+
+        def L(shift):
+            g = dsdf.SdfGrid(data).set_translation([shift, 0.0, 0.0])
+            return float((dsdf.render_forward(g, sens, spp, seeds=[11, 12], integrator='sdf_direct_reparam', reparam=False, shading=sh) * Gw).sum())
+        fd = (L(eps) - L(-eps)) / (2 * eps)
+        ad = float((fwd * Gw).sum())
+        assert abs(ad - fd) < 0.10 * abs(fd) + 1.0, (ad, fd)
