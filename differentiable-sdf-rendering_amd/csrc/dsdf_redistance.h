@@ -17,6 +17,20 @@
 #define DSDF_RD_INNER 48      /* cap of the Jacobi passes on a tile in LDS; the loop ends as soon as a pass changes nothing */
 #define DSDF_RD_BLOCKS 2048
 
+// The same update for equal spacings h (cubic grids: every grid the optimiser uses): no per-axis weights, no divisions.
+//   1 term: a + h;  2 terms: (a + b + sqrt(2 h^2 - (a - b)^2)) / 2;  3 terms: (s + sqrt(s^2 - 3 (q - h^2))) / 3, s = a+b+c, q = a^2+b^2+c^2
+__device__ __forceinline__ float eikonal_update_iso(float a, float b, float c, float h) {
+    const float lo = fminf(a, fminf(b, c)), hi = fmaxf(a, fmaxf(b, c));
+    const float mid = __builtin_amdgcn_fmed3f(a, b, c);
+    float u = lo + h;
+    if (u <= mid) return u;
+    const float d = lo - mid;
+    u = 0.5f * (lo + mid + sqrtf(fmaxf(2.f * h * h - d * d, 0.f)));
+    if (u <= hi) return u;
+    const float sum = lo + mid + hi, q = lo * lo + mid * mid + hi * hi;
+    return (sum + sqrtf(fmaxf(sum * sum - 3.f * (q - h * h), 0.f))) * (1.f / 3.f);
+}
+
 __device__ __forceinline__ float eikonal_update(float a, float b, float c, float ha, float hb, float hc) {
     // sort (value, spacing) ascending by value
     if (a > b) { float t = a; a = b; b = t; t = ha; ha = hb; hb = t; }
@@ -39,7 +53,7 @@ __global__ void k_redist_init(const float *__restrict__ phi, int rx, int ry, int
                               unsigned char *__restrict__ frozen, unsigned int *flags) {
     size_t n = (size_t)rx * ry * rz;
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i == 0) { flags[0] = 0; flags[1] = 0; flags[2] = 0; flags[4] = 0; flags[5] = 0; }     // [0..2]: list counters, [4]: rounds that did work, [5]: status
+    if (i == 0) { flags[0] = 0; flags[1] = 0; flags[2] = 0; flags[4] = 0; flags[5] = 0; flags[6] = 0; flags[7] = 0; }     // [0..2]: list counters, [4]: rounds that did work, [5]: status
     if (i >= n) return;
     int x = (int)(i % rx); size_t r = i / rx; int y = (int)(r % ry), z = (int)(r / ry);
     float p = phi[i];
@@ -82,6 +96,8 @@ __global__ __launch_bounds__(512) void k_redist_round(float *__restrict__ u, con
     const int lx = threadIdx.x % T, ly = (threadIdx.x / T) % T, lz = threadIdx.x / (T * T);
     const int c = ((lz + 1) * S + (ly + 1)) * S + (lx + 1);
     const float hx = 1.f / rx, hy = 1.f / ry, hz = 1.f / rz;
+    const bool iso = rx == ry && ry == rz;
+    unsigned n_visits = 0, n_passes = 0;
     for (unsigned w = blockIdx.x; w < count; w += gridDim.x) {
         const unsigned tid = round == 0 ? w : list_in[w];
         const int tx = (int)(tid % (unsigned)ntx), ty = (int)((tid / (unsigned)ntx) % (unsigned)nty), tz = (int)(tid / ((unsigned)ntx * nty));
@@ -107,12 +123,15 @@ __global__ __launch_bounds__(512) void k_redist_round(float *__restrict__ u, con
             float b = fminf(tile[c - S], tile[c + S]);
             float d = fminf(tile[c - S * S], tile[c + S * S]);
             float un = cur;
-            if (!fixed && fminf(a, fminf(b, d)) < DSDF_RD_BIG) un = fminf(cur, eikonal_update(a, b, d, hx, hy, hz));
+            if (!fixed && fminf(a, fminf(b, d)) < DSDF_RD_BIG)
+                un = fminf(cur, iso ? eikonal_update_iso(a, b, d, hx) : eikonal_update(a, b, d, hx, hy, hz));
             __syncthreads();
             const int ch = un < cur;
             if (ch) { cur = un; tile[c] = un; }
             more = __syncthreads_or(ch);
+            ++n_passes;
         }
+        ++n_visits;
         // which neighbours must look again: those across a face on which a value moved; this tile itself when the cap hit
         int bits = (more && threadIdx.x == 0) ? 64 : 0;
         if (cur < start) {
@@ -132,6 +151,7 @@ __global__ __launch_bounds__(512) void k_redist_round(float *__restrict__ u, con
             }
         }
     }
+    if (threadIdx.x == 0) { atomicAdd(flags + 6, n_visits); atomicAdd(flags + 7, n_passes); }     // (work counters: dsdf_redistance_counters)
 }
 
 // status (flags[5]): 0 = the relaxation reached its fixed point (a round found its list empty, or the last round left none),
@@ -197,6 +217,20 @@ int dsdf_redistance_status(const void *workspace, int rx, int ry, int rz, int32_
     const char *flags = (const char *)workspace + align_up(n * sizeof(float), 256) + align_up(n, 256);
     if (hipMemcpyAsync(status, flags + 5 * sizeof(unsigned int), sizeof(int32_t), hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess)
         return fail(DSDF_ERR_LAUNCH, "dsdf_redistance_status: copy failed");
+    return DSDF_OK;
+}
+
+/* Work counters of the dsdf_redistance call that last used `workspace`: {rounds that did work, tile visits, Jacobi passes
+ * summed over the visits, status} -> 4 int32 on the device (stream-ordered copy). */
+int dsdf_redistance_counters(const void *workspace, int rx, int ry, int rz, int32_t *out4, void *stream) {
+    if (!workspace || !out4 || rx < 1 || ry < 1 || rz < 1) return fail(DSDF_ERR_INVALID_ARG, "dsdf_redistance_counters: bad argument");
+    const size_t n = (size_t)rx * ry * rz;
+    const char *flags = (const char *)workspace + align_up(n * sizeof(float), 256) + align_up(n, 256);
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemcpyAsync(out4, flags + 4 * sizeof(unsigned int), sizeof(int32_t), hipMemcpyDeviceToDevice, st) != hipSuccess ||
+        hipMemcpyAsync(out4 + 1, flags + 6 * sizeof(unsigned int), 2 * sizeof(int32_t), hipMemcpyDeviceToDevice, st) != hipSuccess ||
+        hipMemcpyAsync(out4 + 3, flags + 5 * sizeof(unsigned int), sizeof(int32_t), hipMemcpyDeviceToDevice, st) != hipSuccess)
+        return fail(DSDF_ERR_LAUNCH, "dsdf_redistance_counters: copy failed");
     return DSDF_OK;
 }
 

@@ -545,9 +545,10 @@ def render_step(grid, sensors, spp, spp_grad, loss_grad, grad_grid, seeds, seeds
     return img
 
 
-def redistance(phi, return_status=False):
+def redistance(phi, return_status=False, return_counters=False):
     """`redistancing.redistance`: signed distance field with the zero level set of phi (Z,Y,X[,1]).  return_status: also a
-    device int32 tensor, 0 = converged, 1 = the launch budget ran out first (read it when you synchronise anyway)."""
+    device int32 tensor, 0 = converged, 1 = the launch budget ran out first (read it when you synchronise anyway).
+    return_counters: instead a device int32[4] = {rounds that did work, tile visits, Jacobi passes, status}."""
     lib = _lib.load()
     shape = phi.shape
     p3 = phi[..., 0] if phi.dim() == 4 else phi
@@ -558,6 +559,10 @@ def redistance(phi, return_status=False):
     ws = torch.empty(int(wsb), dtype=torch.uint8, device=p3.device)
     with torch.cuda.device(p3.device):
         _lib.check(lib.dsdf_redistance(_ptr(p3), rx, ry, rz, _ptr(out), _ptr(ws), wsb, _stream()))
+        if return_counters:
+            cnt = torch.zeros(4, dtype=torch.int32, device=p3.device)
+            _lib.check(lib.dsdf_redistance_counters(_ptr(ws), rx, ry, rz, _ptr(cnt), _stream()))
+            return out.reshape(shape), cnt
         if return_status:
             status = torch.zeros(1, dtype=torch.int32, device=p3.device)
             _lib.check(lib.dsdf_redistance_status(_ptr(ws), rx, ry, rz, _ptr(status), _stream()))

@@ -270,6 +270,10 @@ int dsdf_redistance(const float *phi, int rx, int ry, int rz, float *out,
  * The library never synchronises: read it whenever the caller synchronises anyway. */
 int dsdf_redistance_status(const void *workspace, int rx, int ry, int rz, int32_t *status, void *stream);
 
+/* Work counters of the dsdf_redistance call that last used `workspace`, copied into 4 DEVICE int32: {rounds that did work,
+ * tile visits, Jacobi passes summed over the visits, status}. */
+int dsdf_redistance_counters(const void *workspace, int rx, int ry, int rz, int32_t *out4, void *stream);
+
 /* The native operation behind `mesh_to_sdf.create_sdf` (python/mesh_to_sdf.py:9-57): Mitsuba's `scene.ray_intersect` on a
  * triangle mesh.  triangles: n_triangles x 9 device floats (p0, p1, p2 per triangle); rays_o / rays_d: n x 3.
  * t_out n: distance of the closest hit with t > t_min (+inf: none); backface_out n (optional, int32): 1 when the geometric

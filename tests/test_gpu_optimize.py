@@ -173,8 +173,15 @@ def test_direct_integrator_plugin(dsdf):
     gref = dsdf.render_backward(dsdf.SdfGrid(data), [sens[0], sens[2]], 64, torch.ones(2, 24, 24, 3, device='cuda'),
                                 seeds=[9, 10], integrator='sdf_direct_reparam', shading=sh, grad_albedo=ga)
     assert rel_l2(p.grad[..., 0].cpu(), gref.cpu()) < 1e-5 and rel_l2(a.grad.cpu(), ga.cpu()) < 1e-5
-    with pytest.raises(NotImplementedError):
-        create_integrator('sdf_direct_reparam', {'use_mis': True})
+    # the integrator properties of the reference (reparam.py:17, sdf_direct_reparam.py:12-14) reach the library
+    mis = create_integrator('sdf_direct_reparam', {'use_mis': True, 'decouple_reparam': True, 'sdf': shapes.Grid3d(data.clone()),
+                                                   'reflectance': alb, 'hide_emitters': True})
+    sm = mis.shading()
+    assert sm.use_mis and sm.decouple_reparam and not sm.detach_indirect_si
+    scene_m = Scene(sens, mis)
+    img_m = mis.render(scene_m, sensor=1, seed=5, spp=256)
+    img_e = integ.render(scene, sensor=1, seed=5, spp=256)
+    assert abs(float(img_m.mean()) - float(img_e.mean())) < 0.02 * float(img_e.mean())      # MIS estimates the same integral
 
 
 def test_optimize_cli_textured(dsdf, tmp_path, monkeypatch):

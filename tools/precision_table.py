@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
-"""Gradient / image precision table of the HIP path: case x build x rel-L2 against the fp64 oracle,
-next to the measured fp32 floor of the reference algorithm itself.
+"""Gradient / image precision table of the HIP path: case x build x rel-L2 against the fp64 oracle, next to the measured fp32
+floor of the reference algorithm itself; the HIP gradient against the fp32 C oracle DIRECTLY (the reference's llvm_ad_rgb path is
+fp32 too); the 1 % and 0.1 % trimmed statistics; and the sample attribution (tests/test_gpu_attribution.py: cubes removed /
+budget, rel-L2 of the rest against its gate).
 
   build `fast` = the shipped libdsdf.so (v_rcp_f32 / v_rsq_f32 / v_exp_f32, 1 ulp)
   build `ieee` = lib/variants/libdsdf_ieee.so (-DDSDF_FAST_RCP=0: IEEE division / sqrt / expf sequences)
@@ -45,10 +47,18 @@ def worker(cases):
             gg, img = dsdf.render_backward(grid, sen, case['spp'], case['grad_image'].cuda()[None], offsets=offs,
                                            integrator=integ, return_image=True)
             g = gg.cpu().numpy()
-            rows.append(dict(case=name, integ=integ, lanes=int(case['offsets'].shape[0]),
+            lanes = int(case['offsets'].shape[0])
+            K = max(3, int(np.ceil(1e-5 * lanes)))
+            floor_k, _, _ = P.greedy_blocks(r['g32'], r['g64'], 0.0, K)
+            gate = max(P.FLOOR_FACTOR * floor_k, P.NORTH_STAR)
+            rest, centres, _ = P.greedy_blocks(g, r['g64'], gate, K)
+            rows.append(dict(case=name, integ=integ, lanes=lanes,
                              img_err=P.rel_l2(img[0].cpu().numpy(), r['img64']),
                              grad_err=P.rel_l2(g, r['g64']), grad_err_trim=P.trimmed_rel_l2(g, r['g64']),
-                             floor_c=r['floor_c'], floor_torch=r['floor_torch'], floor_trim=r['floor_trim']))
+                             grad_err_trim01=P.trimmed_rel_l2(g, r['g64'], 0.001), grad_vs_c32=P.rel_l2(g, r['g32']),
+                             grad_trim_vs_c32=P.trimmed_rel_l2(g, r['g32']),
+                             attr_budget=K, attr_removed=len(centres), attr_rest=rest, attr_gate=gate,
+                             floor_c=r['floor_c'], floor_torch=r['floor_torch'], floor_trim=r['floor_trim'], floor_trim01=r['floor_trim01']))
             print(json.dumps(rows[-1]), file=sys.stderr, flush=True)
     print('ROWS=' + json.dumps(rows))
 
@@ -79,18 +89,22 @@ def main():
         for row in json.loads(line[0][5:]):
             e = table.setdefault((row['case'], row['integ']), dict(case=row['case'], integ=row['integ'], lanes=row['lanes'],
                                                                   floor_c=row['floor_c'], floor_torch=row['floor_torch'],
-                                                                  floor_trim=row['floor_trim']))
+                                                                  floor_trim=row['floor_trim'], floor_trim01=row['floor_trim01']))
             e[f'img_{tag}'] = row['img_err']; e[f'grad_{tag}'] = row['grad_err']; e[f'grad_trim_{tag}'] = row['grad_err_trim']
+            for k in ('grad_err_trim01', 'grad_vs_c32', 'grad_trim_vs_c32', 'attr_budget', 'attr_removed', 'attr_rest', 'attr_gate'):
+                e[f'{k}_{tag}'] = row[k]
     rows = list(table.values())
     os.makedirs(os.path.dirname(args.out), exist_ok=True)
     json.dump(dict(note=__doc__.strip().splitlines()[0], rows=rows), open(args.out, 'w'), indent=1)
     f = lambda v: '   -    ' if v is None else f'{v:8.2e}'
-    print('| case | integrator | lanes | image fast | grad fast | grad ieee | floor C fp32 | floor torch fp32 | trimmed fast | trimmed ieee | trimmed floor |')
-    print('|---|---|---|---|---|---|---|---|---|---|---|')
+    print('| case | integrator | lanes | image fast | grad fast | grad ieee | floor C fp32 | floor torch fp32 | **fast vs fp32 oracle** | trimmed 1 % fast | '
+          'trimmed 1 % floor | trimmed 0.1 % fast | trimmed 0.1 % floor | attribution: cubes removed / budget | rest | gate |')
+    print('|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|')
     for e in rows:
         print(f"| {e['case']} | {'silhouette' if e['integ'] == 0 else 'shading'} | {e['lanes']} | {f(e.get('img_fast'))} | {f(e.get('grad_fast'))} | "
-              f"{f(e.get('grad_ieee'))} | {f(e['floor_c'])} | {f(e['floor_torch'] or None)} | {f(e.get('grad_trim_fast'))} | "
-              f"{f(e.get('grad_trim_ieee'))} | {f(e['floor_trim'])} |")
+              f"{f(e.get('grad_ieee'))} | {f(e['floor_c'])} | {f(e['floor_torch'] or None)} | {f(e.get('grad_vs_c32_fast'))} | {f(e.get('grad_trim_fast'))} | "
+              f"{f(e['floor_trim'])} | {f(e.get('grad_err_trim01_fast'))} | {f(e['floor_trim01'])} | "
+              f"{e.get('attr_removed_fast', '-')} / {e.get('attr_budget_fast', '-')} | {f(e.get('attr_rest_fast'))} | {f(e.get('attr_gate_fast'))} |")
 
 
 if __name__ == '__main__':
