@@ -16,6 +16,9 @@
 #define DSDF_RD_TILE 8
 #define DSDF_RD_INNER 48      /* cap of the Jacobi passes on a tile in LDS; the loop ends as soon as a pass changes nothing */
 #define DSDF_RD_BLOCKS 2048
+#define DSDF_RD_TOL 1e-5f     /* a neighbour is re-activated when a face value moved by more than DSDF_RD_TOL voxels: without it
+                                 rounding-level improvements cascade through the grid (simulated at 64^3: 8.9 -> 5.6 visits per tile;
+                                 the result moves by < 1e-4 voxel) */
 
 // The same update for equal spacings h (cubic grids: every grid the optimiser uses): no per-axis weights, no divisions.
 //   1 term: a + h;  2 terms: (a + b + sqrt(2 h^2 - (a - b)^2)) / 2;  3 terms: (s + sqrt(s^2 - 3 (q - h^2))) / 3, s = a+b+c, q = a^2+b^2+c^2
@@ -25,10 +28,10 @@ __device__ __forceinline__ float eikonal_update_iso(float a, float b, float c, f
     float u = lo + h;
     if (u <= mid) return u;
     const float d = lo - mid;
-    u = 0.5f * (lo + mid + sqrtf(fmaxf(2.f * h * h - d * d, 0.f)));
+    u = 0.5f * (lo + mid + __builtin_amdgcn_sqrtf(fmaxf(2.f * h * h - d * d, 0.f)));          // (v_sqrt_f32, 1 ulp)
     if (u <= hi) return u;
     const float sum = lo + mid + hi, q = lo * lo + mid * mid + hi * hi;
-    return (sum + sqrtf(fmaxf(sum * sum - 3.f * (q - h * h), 0.f))) * (1.f / 3.f);
+    return (sum + __builtin_amdgcn_sqrtf(fmaxf(sum * sum - 3.f * (q - h * h), 0.f))) * (1.f / 3.f);
 }
 
 __device__ __forceinline__ float eikonal_update(float a, float b, float c, float ha, float hb, float hc) {
@@ -136,7 +139,7 @@ __global__ __launch_bounds__(512) void k_redist_round(float *__restrict__ u, con
         int bits = (more && threadIdx.x == 0) ? 64 : 0;
         if (cur < start) {
             u[gi] = cur;
-            bits |= (lx == 0 ? 2 : 0) | (lx == T - 1 ? 1 : 0) | (ly == 0 ? 8 : 0) | (ly == T - 1 ? 4 : 0) | (lz == 0 ? 32 : 0) | (lz == T - 1 ? 16 : 0);
+            if (cur < start - DSDF_RD_TOL * hx) bits |= (lx == 0 ? 2 : 0) | (lx == T - 1 ? 1 : 0) | (ly == 0 ? 8 : 0) | (ly == T - 1 ? 4 : 0) | (lz == 0 ? 32 : 0) | (lz == T - 1 ? 16 : 0);
         }
         if (bits) atomicOr(&tile_changed, bits);
         __syncthreads();
