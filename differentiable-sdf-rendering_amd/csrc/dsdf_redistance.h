@@ -16,6 +16,10 @@
 #define DSDF_RD_TILE 8
 #define DSDF_RD_INNER 48      /* cap of the Jacobi passes on a tile; the loop ends as soon as a pass changes nothing */
 #define DSDF_RD_BLOCKS 8192    /* single-wave blocks: 32 per CU */
+#define DSDF_RD_LISTS 32u      /* sub-lists of the active-tile list */
+#define DSDF_RD_STAT0 32u      /* flags layout (uint32): [4] rounds, [5] status, [32..63] 16 x {visits, passes}, [64..] 3 x 32 counters, 16 apart */
+#define DSDF_RD_CNT0 64u
+#define DSDF_RD_FLAG_WORDS (DSDF_RD_CNT0 + 3u * DSDF_RD_LISTS * 16u)
 #define DSDF_RD_TOL 1e-5f     /* a neighbour is re-activated when a face value moved by more than DSDF_RD_TOL voxels: without it
                                  rounding-level improvements cascade through the grid (simulated at 64^3: 8.9 -> 5.6 visits per tile;
                                  the result moves by < 1e-4 voxel) */
@@ -56,7 +60,6 @@ __global__ void k_redist_init(const float *__restrict__ phi, int rx, int ry, int
                               unsigned char *__restrict__ frozen, unsigned int *flags) {
     size_t n = (size_t)rx * ry * rz;
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i == 0) { flags[0] = 0; flags[1] = 0; flags[2] = 0; flags[4] = 0; flags[5] = 0; flags[6] = 0; flags[7] = 0; }     // [0..2]: list counters, [4]: rounds that did work, [5]: status
     if (i >= n) return;
     int x = (int)(i % rx); size_t r = i / rx; int y = (int)(r % ry), z = (int)(r / ry);
     float p = phi[i];
@@ -112,19 +115,25 @@ __global__ __launch_bounds__(64) void k_redist_round(float *__restrict__ u, cons
                                                      unsigned int *__restrict__ list_out, int round) {
     constexpr int T = DSDF_RD_TILE, S = T + 2;
     const unsigned ntiles = (unsigned)ntx * nty * ntz;
-    const unsigned count = round == 0 ? ntiles : flags[round % 3];
-    if (blockIdx.x == 0 && threadIdx.x == 0) flags[(round + 2) % 3] = 0;
-    if (count == 0) return;                                      // the previous round changed nothing: converged
-    if (blockIdx.x == 0 && threadIdx.x == 0) flags[4] = (unsigned)round + 1u;
-    unsigned int *count_out = flags + (round + 1) % 3;
+    // The active list is cut into DSDF_RD_LISTS sub-lists (tile t lives in sub-list t % DSDF_RD_LISTS) with counters on
+    // separate cache lines: appends to ONE counter serialised the round (same-address device atomics retire at ~8 ns each;
+    // the kernel trace showed 200-430 us per round at 256^3 with ~6 k appends and 16 k statistics atomics).  Block b serves
+    // sub-list b % DSDF_RD_LISTS.
+    const unsigned sl = blockIdx.x % DSDF_RD_LISTS, lane_in_list = blockIdx.x / DSDF_RD_LISTS, stride = gridDim.x / DSDF_RD_LISTS;
+    const unsigned cap = (ntiles + DSDF_RD_LISTS - 1) / DSDF_RD_LISTS;
+    unsigned int *cnt_in = flags + DSDF_RD_CNT0 + (round % 3) * DSDF_RD_LISTS * 16, *cnt_out = flags + DSDF_RD_CNT0 + ((round + 1) % 3) * DSDF_RD_LISTS * 16;
+    const unsigned count = round == 0 ? (ntiles + DSDF_RD_LISTS - 1 - sl) / DSDF_RD_LISTS : cnt_in[sl * 16];
+    if (blockIdx.x < DSDF_RD_LISTS && threadIdx.x == 0) flags[DSDF_RD_CNT0 + ((round + 2) % 3) * DSDF_RD_LISTS * 16 + blockIdx.x * 16] = 0;
+    if (count == 0) return;                                      // nothing for this sub-list (all empty: converged)
+    if (lane_in_list == 0 && threadIdx.x == 0) flags[4] = (unsigned)round + 1u;
     __shared__ float tile[S * S * S];
     const int lid = threadIdx.x, lx = lid & 7, ly = lid >> 3;
     const float h = 1.f / rx, hy = 1.f / ry, hz = 1.f / rz;
     const bool iso = rx == ry && ry == rz;
     const float tol = DSDF_RD_TOL * h;
     unsigned n_visits = 0, n_passes = 0;
-    for (unsigned w = blockIdx.x; w < count; w += gridDim.x) {
-        const unsigned tid = round == 0 ? w : list_in[w];
+    for (unsigned w = lane_in_list; w < count; w += stride) {
+        const unsigned tid = round == 0 ? w * DSDF_RD_LISTS + sl : list_in[(size_t)sl * cap + w];
         const int tx = (int)(tid % (unsigned)ntx), ty = (int)((tid / (unsigned)ntx) % (unsigned)nty), tz = (int)(tid / ((unsigned)ntx * nty));
         const int x0 = tx * T, y0 = ty * T, z0 = tz * T;
         wave_lds_sync();
@@ -200,11 +209,15 @@ __global__ __launch_bounds__(64) void k_redist_round(float *__restrict__ u, cons
             const int nx = tx + (k == 0) - (k == 1), ny = ty + (k == 2) - (k == 3), nz = tz + (k == 4) - (k == 5);
             if (nx >= 0 && nx < ntx && ny >= 0 && ny < nty && nz >= 0 && nz < ntz) {
                 const unsigned nb = ((unsigned)nz * nty + ny) * ntx + nx;
-                if (atomicExch(stamp + nb, (unsigned)round + 1u) != (unsigned)round + 1u) list_out[atomicAdd(count_out, 1u)] = nb;
+                if (atomicExch(stamp + nb, (unsigned)round + 1u) != (unsigned)round + 1u) {
+                    const unsigned l2 = nb % DSDF_RD_LISTS;
+                    list_out[(size_t)l2 * cap + atomicAdd(cnt_out + l2 * 16, 1u)] = nb;
+                }
             }
         }
     }
-    if (lid == 0) { atomicAdd(flags + 6, n_visits); atomicAdd(flags + 7, n_passes); }     // (work counters: dsdf_redistance_counters)
+    // (work counters, dsdf_redistance_counters: spread over 16 slots, summed when read)
+    if (lid == 0 && n_visits) { atomicAdd(flags + DSDF_RD_STAT0 + 2 * (blockIdx.x & 15u), n_visits); atomicAdd(flags + DSDF_RD_STAT0 + 2 * (blockIdx.x & 15u) + 1, n_passes); }
 }
 
 // status (flags[5]): 0 = the relaxation reached its fixed point (a round found its list empty, or the last round left none),
@@ -213,7 +226,14 @@ __global__ __launch_bounds__(64) void k_redist_round(float *__restrict__ u, cons
 __global__ void k_redist_finish(const float *__restrict__ phi, const float *__restrict__ u, size_t n, float *__restrict__ out,
                                 unsigned int *flags, unsigned max_iter) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i == 0) flags[5] = (flags[4] >= max_iter && flags[max_iter % 3] != 0u) ? 1u : 0u;
+    if (i == 0) {
+        unsigned left = 0;
+        for (unsigned l = 0; l < DSDF_RD_LISTS; ++l) left |= flags[DSDF_RD_CNT0 + (max_iter % 3) * DSDF_RD_LISTS * 16 + l * 16];
+        flags[5] = (flags[4] >= max_iter && left != 0u) ? 1u : 0u;
+        unsigned v = 0, ps = 0;
+        for (unsigned k = 0; k < 16; ++k) { v += flags[DSDF_RD_STAT0 + 2 * k]; ps += flags[DSDF_RD_STAT0 + 2 * k + 1]; }
+        flags[6] = v; flags[7] = ps;
+    }
     if (i < n) out[i] = phi[i] < 0.f ? -u[i] : u[i];
 }
 
@@ -227,8 +247,8 @@ size_t dsdf_redistance_workspace_size(int rx, int ry, int rz) {
     if (rx < 1 || ry < 1 || rz < 1) return 0;
     size_t n = (size_t)rx * ry * rz;
     // u | frozen | flags | round stamps | two tile lists | per-column frozen masks
-    return align_up(n * sizeof(float), 256) + align_up(n, 256) + 256 + 3 * align_up(redist_tiles(rx, ry, rz) * sizeof(unsigned int), 256) +
-           align_up(redist_tiles(rx, ry, rz) * 64, 256);
+    return align_up(n * sizeof(float), 256) + align_up(n, 256) + align_up(DSDF_RD_FLAG_WORDS * sizeof(unsigned int), 256) +
+           3 * align_up((redist_tiles(rx, ry, rz) + DSDF_RD_LISTS) * sizeof(unsigned int), 256) + align_up(redist_tiles(rx, ry, rz) * 64, 256);
 }
 
 int dsdf_redistance(const float *phi, int rx, int ry, int rz, float *out, void *workspace, size_t workspace_bytes,
@@ -238,17 +258,18 @@ int dsdf_redistance(const float *phi, int rx, int ry, int rz, float *out, void *
     hipStream_t st = (hipStream_t)stream;
     size_t n = (size_t)rx * ry * rz;
     const int ntx = (rx + DSDF_RD_TILE - 1) / DSDF_RD_TILE, nty = (ry + DSDF_RD_TILE - 1) / DSDF_RD_TILE, ntz = (rz + DSDF_RD_TILE - 1) / DSDF_RD_TILE;
-    const size_t ntiles = redist_tiles(rx, ry, rz), lbytes = align_up(ntiles * sizeof(unsigned int), 256);
+    const size_t ntiles = redist_tiles(rx, ry, rz), lbytes = align_up((ntiles + DSDF_RD_LISTS) * sizeof(unsigned int), 256);
     char *p = (char *)workspace;
     float *u = (float *)p; p += align_up(n * sizeof(float), 256);
     unsigned char *frozen = (unsigned char *)p; p += align_up(n, 256);
-    unsigned int *flags = (unsigned int *)p; p += 256;
+    unsigned int *flags = (unsigned int *)p; p += align_up(DSDF_RD_FLAG_WORDS * sizeof(unsigned int), 256);
     unsigned int *stamp = (unsigned int *)p; p += lbytes;
     unsigned int *lists[2] = {(unsigned int *)p, (unsigned int *)(p + lbytes)};
     unsigned char *colmask = (unsigned char *)(p + 2 * lbytes);
     int rc;
-    if (hipMemsetAsync(stamp, 0, ntiles * sizeof(unsigned int), st) != hipSuccess)
-        return fail(DSDF_ERR_LAUNCH, "hipMemsetAsync(tile stamps) failed");
+    if (hipMemsetAsync(stamp, 0, ntiles * sizeof(unsigned int), st) != hipSuccess ||
+        hipMemsetAsync(flags, 0, DSDF_RD_FLAG_WORDS * sizeof(unsigned int), st) != hipSuccess)      // counters, status, statistics
+        return fail(DSDF_ERR_LAUNCH, "hipMemsetAsync(tile stamps / flags) failed");
     hipLaunchKernelGGL(k_redist_init, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, phi, rx, ry, rz, u, frozen, flags);
     if ((rc = check_launch("k_redist_init"))) return rc;
     hipLaunchKernelGGL(k_redist_colmask, dim3((unsigned)ntiles), dim3(64), 0, st, frozen, rx, ry, rz, ntx, nty, colmask);
@@ -257,7 +278,8 @@ int dsdf_redistance(const float *phi, int rx, int ry, int rz, float *out, void *
     // rounds with an empty list return at once.  Whether the budget sufficed is recorded on the device
     // (dsdf_redistance_status) -- the library never synchronises.
     const int max_iter = (ntx + nty + ntz) + (ntx + nty + ntz) / 4 + 8;
-    const unsigned blocks = ntiles < DSDF_RD_BLOCKS ? (unsigned)ntiles : DSDF_RD_BLOCKS;
+    unsigned blocks = ntiles < DSDF_RD_BLOCKS ? (unsigned)ntiles : DSDF_RD_BLOCKS;
+    blocks = (blocks + DSDF_RD_LISTS - 1) / DSDF_RD_LISTS * DSDF_RD_LISTS;        // (a multiple of the sub-list count, >= one block per sub-list)
     for (int it = 0; it < max_iter; ++it) {
         // round `it` reads lists[it & 1] (round 0: every tile) and fills lists[(it + 1) & 1]
         hipLaunchKernelGGL(k_redist_round, dim3(blocks), dim3(64), 0, st, u, colmask, rx, ry, rz, ntx, nty, ntz, flags, stamp,
