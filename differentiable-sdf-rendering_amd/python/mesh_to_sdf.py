@@ -143,12 +143,24 @@ def sphere_directions(device, angular_res=ANGULAR_RES):
 
 
 def occupancy(triangles, res):
-    """0.5 - inside, inside = the +y ray from the voxel centre leaves the solid through its first hit (mesh_to_sdf.py:23-27)."""
+    """0.5 - inside, inside = the +y ray from the voxel centre leaves the solid through its first hit (mesh_to_sdf.py:23-27).
+    The reference casts that one ray with Embree / OptiX, whose intersectors are edge-consistent; dsdf_mesh_raycast tests every
+    triangle on its own (Moeller-Trumbore), so a ray through a shared edge or vertex -- voxel centres sit on the symmetry planes
+    of many meshes -- can slip between two triangles.  The -y ray answers the same question (a watertight mesh is left
+    through a back face in every direction); where the two disagree a third, generic direction decides."""
     dev = triangles.device
     o = voxel_centres(res, dev)
-    d = torch.zeros_like(o); d[:, 1] = 1.0
-    t, back = dsdf.mesh_raycast(triangles, o, d)
-    inside = torch.isfinite(t) & (back != 0)
+
+    def inside_along(direction):
+        d = torch.tensor(direction, dtype=torch.float32, device=dev).expand_as(o).contiguous()
+        t, back = dsdf.mesh_raycast(triangles, o, d)
+        return torch.isfinite(t) & (back != 0)
+    up, down = inside_along((0.0, 1.0, 0.0)), inside_along((0.0, -1.0, 0.0))
+    inside = up
+    split = up != down
+    if bool(split.any()):
+        n = (0.2718 ** 2 + 0.5772 ** 2 + 0.7071 ** 2) ** 0.5
+        inside = torch.where(split, inside_along((0.2718 / n, 0.5772 / n, 0.7071 / n)), up)
     return (0.5 - inside.float()).reshape(res, res, res), o
 
 
