@@ -42,6 +42,26 @@ for name in ('sphere16', 'blob32'):
     np.savez_compressed(os.path.join(HERE, f'{name}_direct.npz'), **out)
     print(name + '_direct', {k: v.shape for k, v in out.items()})
 
+# sdf_direct_reparam with use_mis (BSDF sampling + power heuristic) and with decouple_reparam / detach_indirect_si:
+# torch-autograd oracle, blob32 (the case on which the shadow-ray warp is active)
+import torch
+case = make_case('blob32')
+ex = direct_inputs(case)
+bu = torch.rand(case['offsets'].shape[0], 2, generator=torch.Generator().manual_seed(3), dtype=torch.float32)
+out = {'bsdf_u': bu.numpy()}
+for tag, kw in (('mis', dict(use_mis=True, bsdf_u=bu.double())), ('detach', dict(detach_indirect_si=True)),
+                ('decouple', dict(decouple_reparam=True)), ('mis_decouple', dict(use_mis=True, bsdf_u=bu.double(), decouple_reparam=True))):
+    data = case['grid'].clone().requires_grad_(True)
+    alb = ex['albedo'].double().clone().requires_grad_(True)
+    img = O.render(O.Grid3d(data), case['cam'], case['W'], case['H'], case['spp'], case['offsets'].double(), O.DIRECT, True, albedo=alb,
+                   emitter_u=ex['emitter_u'].double(), env=torch.tensor(ex['env'], dtype=torch.float64), **kw)
+    gd, ga = torch.autograd.grad((img * case['grad_image'].double()).sum(), (data, alb))
+    out[f'img_{tag}'] = img.detach().numpy().astype(np.float32)
+    out[f'grad_data_{tag}'] = gd.numpy().astype(np.float32)
+    out[f'grad_albedo_{tag}'] = ga.numpy().astype(np.float32)
+np.savez_compressed(os.path.join(HERE, 'blob32_direct_variants.npz'), **out)
+print('blob32_direct_variants', {k: v.shape for k, v in out.items()})
+
 # mesh -> SDF (oracle/mesh_oracle.py + the C redistancing oracle): a box and an icosphere at 16^3, per-ray casts of the box
 import c_oracle
 import mesh_oracle as M
