@@ -164,20 +164,16 @@ DSDF_HD CubicCell cubic_cell(const GridView &G, V3 x) {
               qz = (int)__builtin_amdgcn_fmed3f(fz, -2.f, G.frz);
     cc.base = 4u * (uint32_t)(__mul24(qz, G.sxy) + __mul24(qy, G.sx) + qx + 2 * (G.sxy + G.sx + 1));
     return cc;
-#endif
+#else
     CubicSetup s = cubic_setup(G, x);
     int bx = iclamp(s.ix, -DSDF_APRON, G.rx - 1) + DSDF_APRON;
     int by = iclamp(s.iy, -DSDF_APRON, G.ry - 1) + DSDF_APRON;
     int bz = iclamp(s.iz, -DSDF_APRON, G.rz - 1) + DSDF_APRON;
     CubicCell c;
-#if defined(__HIP_DEVICE_COMPILE__)
-    // 24-bit multiplies (full rate; v_mul_lo_u32 is quarter rate): bz, by < 2^11 and sxy < 2^24 for every grid up to 4090^2 per slice
-    c.base = 4u * (__umul24((uint32_t)bz, (uint32_t)G.sxy) + __umul24((uint32_t)by, (uint32_t)G.sx) + (uint32_t)bx);
-#else
     c.base = 4u * ((uint32_t)bz * (uint32_t)G.sxy + (uint32_t)by * (uint32_t)G.sx + (uint32_t)bx);
-#endif
     c.ax = s.ax; c.ay = s.ay; c.az = s.az;
     return c;
+#endif
 }
 
 // Row provider reading the 16 rows (k = z tap, j = y tap; four x-consecutive floats each)
