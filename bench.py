@@ -158,6 +158,11 @@ def direct_block(args, dev, grid, sensors, steps=4):
         step(1 + k)
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
+    # (the stand-alone calls allocate their own workspaces -- 23 GB for the gradient pass of 12 views: once, untimed)
+    img = dsdf.render_forward(grid, sensors, args.spp_primal, seeds=list(range(nv)), integrator='sdf_direct_reparam', shading=sh)
+    dsdf.render_backward(grid, sensors, args.spp_grad, torch.sign(img - tgt) * scale, grad_grid=grad, seeds=list(range(50, 50 + nv)),
+                         integrator='sdf_direct_reparam', shading=sh, grad_albedo=galb)
+    torch.cuda.synchronize()
     e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
     e0.record()
     img = dsdf.render_forward(grid, sensors, args.spp_primal, seeds=list(range(nv)), integrator='sdf_direct_reparam', shading=sh)
@@ -397,9 +402,12 @@ def main():
     elapsed = timed_run(make_step(args.spp_primal, args.spp_grad, prim_ms, grad_ms), args.warmup, args.steps)
     # dL/dsdf of the last timed step (summed over ranks): must agree at every N up to the order of the float atomics
     grad_l1 = float(grads[(args.warmup + args.steps - 1) & 1].double().abs().sum())
-    if args.overlap and nv and not tiled:
+    kern_p, kern_g = [], []
+    if nv and not tiled:
         # the roofline needs the dominant kernel's OWN launch time: in the timed region above it shares the chip with the
-        # gradient sweep of the other stream, so a few launches are timed alone (HIP events, same process, same inputs)
+        # gradient sweep of the other stream, so a few calls are timed alone afterwards, same process, same inputs -- the whole
+        # call with HIP events on the launch stream (prim_ms / grad_ms), the RENDER KERNEL inside it with the library's
+        # measurement hook (dsdf_kernel_timing_arm / _read: two HIP events around k_render_items on the same stream)
         prim_ms, grad_ms = [], []
         ov, args.overlap = args.overlap, 0
         dist_saved, dist = dist, None
@@ -408,6 +416,16 @@ def main():
         for k in range(3):
             probe(args.warmup + args.steps + 1 + k, True)
         torch.cuda.synchronize()
+        gi0 = torch.ones(nv, args.img, args.img, 3, device=dev) * scale
+        for k in range(3):
+            seeds = [(7 * k + i) * 2 for i in range(nv)]
+            dsdf.kernel_timing_arm()
+            dsdf.render_forward(grid, sensors, args.spp_primal, seeds=seeds, integrator=args.integrator, **shade)
+            kern_p.append(dsdf.kernel_timing_read())
+            dsdf.kernel_timing_arm()
+            dsdf.render_backward(grid, sensors, args.spp_grad, gi0, grad_grid=grads[0], seeds=[x + 1 for x in seeds], integrator=args.integrator,
+                                 grad_albedo=galbs[0], **shade)
+            kern_g.append(dsdf.kernel_timing_read())
         args.overlap, dist = ov, dist_saved
 
     low = None
@@ -439,27 +457,30 @@ def main():
         prim = [a.elapsed_time(b) for a, b in prim_ms]
         gradt = [a.elapsed_time(b) for a, b in grad_ms]
         prim_avg = sum(prim) / len(prim)
+        kern_avg = sum(kern_p) / len(kern_p)                          # the render kernel alone (measurement hook)
         total_lanes = nv * (args.img + 4) ** 2 * args.spp_primal
         # VALU-issue roofline of the primal launch: measured VALU instructions per wave iteration x live wave iterations
         model = load_valu_model()
         evals = sp['steps'] + sp['refine_steps']                     # lane-evaluations of the render kernel (the tail kernel's: tail_steps)
         lane_util = evals / max(64.0 * sp['wave_steps'], 1.0)
-        alg_bytes = 256.0 * (evals + sp['tail_steps']) + 16 * 2 * 8.0 * sp['lanes'] + 4.0 * args.res ** 3
-        roof = {"bound": "valu", "kernel": "k_render_items<primal>", "unit": "G wave-instr/s", "peak": VALU_PEAK / 1e9,
+        alg_bytes = 256.0 * evals + 16 * 2 * 8.0 * sp['lanes'] + 4.0 * args.res ** 3
+        roof = {"bound": "valu", "kernel": "k_render_items<false, false, false> (primal render kernel)", "unit": "G wave-instr/s", "peak": VALU_PEAK / 1e9,
                 "achieved": None, "frac": None, "frac_lane_weighted": None, "traffic": None,
-                "wave_steps_per_launch": sp['wave_steps'], "avg_launch_ms": prim_avg,
-                "launch_time_from": ("3 dsdf_render_forward calls timed alone after the timed region" if args.overlap else "the timed region") +
-                                    " (HIP events on the launch stream around the call: pixel-skip + list build + render kernel + tail kernel + develop)",
+                "wave_steps_per_launch": sp['wave_steps'], "avg_launch_ms": kern_avg, "call_ms": prim_avg,
+                "launch_time_from": "3 launches after the timed region, alone on the chip: HIP events recorded by the library on the launch stream "
+                                    "directly around k_render_items (dsdf_kernel_timing_arm / _read); call_ms = the whole dsdf_render_forward call "
+                                    "(pixel-skip + list build + render kernel + tail kernel + develop) by events around the call",
                 "lane_utilisation": lane_util,
-                "useful_flop_frac": SPLINE_FLOP_PER_EVAL * (evals + sp['tail_steps']) / (prim_avg * 1e-3) / FP32_VECTOR_PEAK,
+                "useful_flop_frac": SPLINE_FLOP_PER_EVAL * evals / (kern_avg * 1e-3) / FP32_VECTOR_PEAK,
+                "sweep_kernel_ms": sum(kern_g) / len(kern_g),
                 "tail": {"rays": sp['tail_rays'], "lane_steps": sp['tail_steps'], "wave_steps": sp['tail_wave_steps']},
-                "hbm_equivalent": {"algorithmic_bytes_per_launch": alg_bytes, "GBps": alg_bytes / (prim_avg * 1e-3) / 1e9,
-                                   "frac_of_8TBps": alg_bytes / (prim_avg * 1e-3) / 8e12,
+                "hbm_equivalent": {"algorithmic_bytes_per_launch": alg_bytes, "GBps": alg_bytes / (kern_avg * 1e-3) / 1e9,
+                                   "frac_of_8TBps": alg_bytes / (kern_avg * 1e-3) / 8e12,
                                    "note": "SURVEY 8(d) tap-byte model; taps are LDS/L1-resident, so this is not a bound"}}
         if model and 'primal' in model:
             m = model['primal']
             valu = m['valu_per_wave_step'] * sp['wave_steps']
-            achieved = valu / (prim_avg * 1e-3)
+            achieved = valu / (kern_avg * 1e-3)
             roof.update({"achieved": achieved / 1e9, "frac": achieved / VALU_PEAK, "frac_lane_weighted": achieved / VALU_PEAK * lane_util,
                          "valu_insts_per_launch": valu, "valu_per_wave_step": m['valu_per_wave_step'],
                          "calibration": f"profiles/valu_model.json (tag {model.get('tag')}): SQ_INSTS_VALU {m.get('valu_insts_per_launch')} / "

@@ -981,6 +981,18 @@ static hipEvent_t next_event() {
     return g_events[g_next_event++ % g_events.size()];
 }
 
+// Measurement hook (include/dsdf.h: dsdf_kernel_timing_arm / _read): when armed, the next render call of this thread brackets
+// its render kernel(s) -- k_render_items / k_render_pass only, not the list build before or the tail kernel after -- with two
+// library-owned HIP events on the caller's stream.  bench.py's roofline divides by THIS duration.
+static thread_local hipEvent_t g_time_ev[2] = {nullptr, nullptr};
+static thread_local int g_time_state = 0;          // 0 idle, 1 armed, 2 recorded
+
+static void timing_mark(int which, hipStream_t st) {
+    if (g_time_state != 1 && !(which == 1 && g_time_state == 3)) return;
+    if (which == 0) { if (hipEventRecord(g_time_ev[0], st) == hipSuccess) g_time_state = 3; }
+    else { if (hipEventRecord(g_time_ev[1], st) == hipSuccess) g_time_state = 2; }
+}
+
 template <bool DIFF>
 static int run_pass(const PassCtx &c, const Workspace &ws, const dsdf_camera *cams, int v0, int nv, ViewBatch &VB, Queue q,
                     int64_t *stats) {
@@ -1063,6 +1075,7 @@ static int run_pass(const PassCtx &c, const Workspace &ws, const dsdf_camera *ca
                 tq.count = (uint32_t *)ws.tail + (size_t)g * DSDF_TAIL_SUBQ * 2;
                 tq.state = (float *)(ws.tail + cnt_bytes + (size_t)g * kreg * grp_bytes);
             }
+            if (g == 0) timing_mark(0, st);
             if (c.direct) {
                 if (st64) hipLaunchKernelGGL((k_render_items<DIFF, true, true>), grid, blk, 0, st, G, c.pp, VB, film, q, st64, skip, S, tq, hdr, list);
                 else hipLaunchKernelGGL((k_render_items<DIFF, true, false>), grid, blk, 0, st, G, c.pp, VB, film, q, st64, skip, S, tq, hdr, list);
@@ -1071,6 +1084,7 @@ static int run_pass(const PassCtx &c, const Workspace &ws, const dsdf_camera *ca
                 else hipLaunchKernelGGL((k_render_items<DIFF, false, false>), grid, blk, 0, st, G, c.pp, VB, film, q, st64, skip, S, tq, hdr, list);
             }
             if ((rc = check_launch("k_render_items"))) return rc;
+            if (g == ngroups - 1) timing_mark(1, st);
             if (handoff) {
                 hipStream_t ts = st;
                 if (forked) {
@@ -1098,9 +1112,11 @@ static int run_pass(const PassCtx &c, const Workspace &ws, const dsdf_camera *ca
         pass_shape(c.W, c.H, c.spp, M.tile_w, M.tile_h, nunits);
         M.n_lanes = c.nl; M.row0 = c.row0; M.row1 = c.row1;
         const dim3 grid((unsigned)(nunits / 4), nv), blk(DSDF_BLOCK);
+        timing_mark(0, st);
         if (c.direct) hipLaunchKernelGGL((k_render_pass<DIFF, true>), grid, blk, 0, st, G, c.pp, VB, film, q, st64, M, skip, S);
         else hipLaunchKernelGGL((k_render_pass<DIFF, false>), grid, blk, 0, st, G, c.pp, VB, film, q, st64, M, skip, S);
         if ((rc = check_launch("k_render_pass"))) return rc;
+        timing_mark(1, st);
     }
     return DSDF_OK;
 }
@@ -1308,6 +1324,26 @@ int dsdf_grad_backward(const float *padded, int rx, int ry, int rz, const dsdf_p
     if (c.direct) hipLaunchKernelGGL(k_backward<true>, grid, dim3(64), 0, st, G, c.pp, VB, q, ws.block_adj, grad_grid, grad_p, (unsigned long long *)nullptr, S);
     else hipLaunchKernelGGL(k_backward<false>, grid, dim3(64), 0, st, G, c.pp, VB, q, ws.block_adj, grad_grid, grad_p, (unsigned long long *)nullptr, S);
     return check_launch("k_backward");
+}
+
+}  // extern "C"
+
+extern "C" {
+
+int dsdf_kernel_timing_arm(void) {
+    for (int k = 0; k < 2; ++k)
+        if (!g_time_ev[k] && hipEventCreate(&g_time_ev[k]) != hipSuccess) return fail(DSDF_ERR_LAUNCH, "dsdf_kernel_timing_arm: hipEventCreate failed");
+    g_time_state = 1;
+    return DSDF_OK;
+}
+
+int dsdf_kernel_timing_read(float *ms) {
+    if (!ms) return fail(DSDF_ERR_INVALID_ARG, "dsdf_kernel_timing_read: null pointer");
+    if (g_time_state != 2) return fail(DSDF_ERR_INVALID_ARG, "dsdf_kernel_timing_read: no render call since dsdf_kernel_timing_arm");
+    g_time_state = 0;
+    if (hipEventSynchronize(g_time_ev[1]) != hipSuccess || hipEventElapsedTime(ms, g_time_ev[0], g_time_ev[1]) != hipSuccess)
+        return fail(DSDF_ERR_LAUNCH, "dsdf_kernel_timing_read: hipEventElapsedTime failed");
+    return DSDF_OK;
 }
 
 }  // extern "C"

@@ -45,6 +45,8 @@ _lib = None
 # name -> (restype, argtypes); every symbol include/dsdf.h declares
 SYMBOLS = {
     'dsdf_version': (C.c_int, []),
+    'dsdf_kernel_timing_arm': (C.c_int, []),
+    'dsdf_kernel_timing_read': (C.c_int, [C.POINTER(C.c_float)]),
     'dsdf_last_error': (C.c_char_p, []),
     'dsdf_default_params': (None, [C.POINTER(DsdfParams)]),
     'dsdf_padded_size': (C.c_size_t, [C.c_int, C.c_int, C.c_int]),

@@ -585,6 +585,18 @@ def mesh_raycast(triangles, rays_o, rays_d, t_min=0.0):
     return t, back
 
 
+def kernel_timing_arm():
+    """Measurement hook (include/dsdf.h): the next render call brackets its render kernel with HIP events."""
+    _lib.check(_lib.load().dsdf_kernel_timing_arm())
+
+
+def kernel_timing_read():
+    """Milliseconds the render kernel of the call after kernel_timing_arm() took (waits for it)."""
+    ms = C.c_float(0.0)
+    _lib.check(_lib.load().dsdf_kernel_timing_read(C.byref(ms)))
+    return float(ms.value)
+
+
 def new_stats(device):
     return torch.zeros(64, STAT_SLOTS, dtype=torch.int64, device=device)
 

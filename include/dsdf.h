@@ -270,6 +270,15 @@ int dsdf_redistance(const float *phi, int rx, int ry, int rz, float *out,
  * The library never synchronises: read it whenever the caller synchronises anyway. */
 int dsdf_redistance_status(const void *workspace, int rx, int ry, int rz, int32_t *status, void *stream);
 
+/* Measurement hook: after dsdf_kernel_timing_arm() the next render call of the calling thread (dsdf_render_forward /
+ * _backward / _film / dsdf_grad_sweep ...) brackets ITS RENDER KERNEL -- k_render_items / k_render_pass alone, without the list
+ * build before it or the tail kernel after it -- with two library-owned HIP events on the caller's stream (the first view batch
+ * of the call); dsdf_kernel_timing_read() waits for the second event (it SYNCHRONISES on it: a measurement call, the only one
+ * in this header that blocks) and returns the elapsed milliseconds.  bench.py's roofline uses it for the launch duration of the
+ * dominant kernel. */
+int dsdf_kernel_timing_arm(void);
+int dsdf_kernel_timing_read(float *ms);
+
 /* Work counters of the dsdf_redistance call that last used `workspace`, copied into 4 DEVICE int32: {rounds that did work,
  * tile visits, Jacobi passes summed over the visits, status}. */
 int dsdf_redistance_counters(const void *workspace, int rx, int ry, int rz, int32_t *out4, void *stream);
