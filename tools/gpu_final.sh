@@ -6,6 +6,7 @@ cd "$(dirname "$0")/.."
 export TMPDIR=/tmp HSA_ENABLE_IPC_MODE_LEGACY=0
 TAG=${1:-final}
 O=gpurun_out/$TAG; mkdir -p $O; rm -f gpurun_out/precision.jsonl
+python -c "import __graft_entry__ as g; g.build()" || exit 1          # (library, IEEE variant, harness, oracles: all at this tree's state)
 if [ "$2" != "skip-tests" ]; then
 echo "== tests"; date
 timeout 2400 python -m pytest tests -q -m gpu -p no:cacheprovider --durations=15 > $O/gpu_tests.log 2>&1; echo "pytest rc $?" | tee -a $O/gpu_tests.log; tail -25 $O/gpu_tests.log
