@@ -552,8 +552,11 @@ struct UnitGather {
     }
 };
 
+#ifndef DSDF_BWD_MINWAVES
+#define DSDF_BWD_MINWAVES 1
+#endif
 template <bool DIRECT>
-__global__ __launch_bounds__(64) void k_backward(GridView G, dsdf_params P, ViewBatch VB, Queue qall,
+__global__ __launch_bounds__(64, DIRECT ? 1 : DSDF_BWD_MINWAVES) void k_backward(GridView G, dsdf_params P, ViewBatch VB, Queue qall,
                                                  const float *__restrict__ block_adjs,
                                                  float *__restrict__ grad_grid, float *__restrict__ grad_p,
                                                  unsigned long long *stats, ShadeArgs S) {
@@ -963,8 +966,10 @@ static bool helper_streams(hipStream_t owner, hipStream_t out[2]) {
     t.dev = dev; t.owner = owner;
     int lo = 0, hi = 0;
     (void)hipDeviceGetStreamPriorityRange(&lo, &hi);           // (hi = numerically lowest = highest priority)
+    static const int prio_mode = env_int("DSDF_TAIL_PRIORITY", 1);      // 1: highest (default), 0: default priority, -1: lowest
+    const int prio = prio_mode > 0 ? hi : (prio_mode < 0 ? lo : 0);
     for (int k = 0; k < 2; ++k)
-        if (hipStreamCreateWithPriority(&t.s[k], hipStreamNonBlocking, hi) != hipSuccess) return false;
+        if (hipStreamCreateWithPriority(&t.s[k], hipStreamNonBlocking, prio) != hipSuccess) return false;
     g_helpers.push_back(t);
     out[0] = t.s[0]; out[1] = t.s[1];
     return true;
@@ -1057,7 +1062,9 @@ static int run_pass(const PassCtx &c, const Workspace &ws, const dsdf_camera *ca
         }
         const int ngroups = (nv + per - 1) / per;
         hipStream_t hs[2] = {st, st};
-        const bool forked = handoff && tail_streams_enabled() && helper_streams(st, hs);
+        // (helper streams only pay with several view groups: with one group the tail kernel simply follows its render kernel on
+        // the caller's stream -- two-stream step 47.5 ms against 48.5 with the fork / join, profiles/r03a_tail_ab.md)
+        const bool forked = handoff && ngroups > 1 && tail_streams_enabled() && helper_streams(st, hs);
         hipEvent_t joins[DSDF_MAX_BATCH];
         int njoin = 0;
         const dim3 grid(worker_blocks()), blk(64);
