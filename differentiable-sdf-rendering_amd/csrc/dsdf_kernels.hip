@@ -158,6 +158,9 @@ struct Queue {
     uint32_t rows;
     uint32_t cap;     // slots per view (= nunits * 64)
     uint32_t nunits;  // units per view
+    uint32_t coef_rows;   // 8 (silhouette) or DSDF_COEF_WORDS
+    float *coef;      // coef_rows rows (SoA, stride = cap), indexed by QUEUE SLOT: the image-independent half of the adjoint
+                      // (k_backward_coef -> k_backward_apply); nullptr for sdf_direct_reparam
 };
 
 // Views of one launch (grid.y = view): all sensors of a batch are traced by ONE kernel so
@@ -170,6 +173,7 @@ __device__ __forceinline__ Queue view_queue(Queue q, uint32_t view) {
     q.count += (size_t)view * q.nunits;
     q.lane += (size_t)view * q.cap;
     q.rec += (size_t)view * q.cap * q.rows;
+    if (q.coef) q.coef += (size_t)view * q.cap * q.coef_rows;
     return q;
 }
 
@@ -613,6 +617,73 @@ __global__ __launch_bounds__(64, DIRECT ? 1 : DSDF_BWD_MINWAVES) void k_backward
     }
 }
 
+// The backward sweep in two kernels (silhouette / simple shading, no dL/d(sdf.p)): k_backward_coef right after the gradient
+// sweep -- Hessian lookups and warp coefficients, everything that does not need the image gradient; in dsdf.render_step it runs
+// on the sweep's stream while the primal pass is still busy -- and k_backward_apply once the image gradient exists: film-adjoint
+// gather, 30 FMAs, transposed scatter (lane_backward_coef / _apply, dsdf_lane.h).  (The fused k_backward is 3.5 ms of dependent
+// chains at 1.4 waves/SIMD, exposed at the end of every step.)
+__global__ __launch_bounds__(64) void k_backward_coef(GridView G, dsdf_params P, ViewBatch VB, Queue qall) {
+    const ViewArgs &A = VB.v[blockIdx.y];
+    const Queue q = view_queue(qall, blockIdx.y);
+    UnitGather ug;
+    ug.init(q, blockIdx.x);
+    for (uint32_t si = threadIdx.x; si < ug.total; si += 64) {
+        const uint32_t slot = ug.slot(si), lane = q.lane[slot];
+        TraceOut tr;
+        load_record(q.rec + lane, q.cap, tr);
+        const Lane L = lane_setup(A, P, lane);
+        BackCoef c;
+        lane_backward_coef(G, P, A, L, tr, c);
+        float *o = q.coef + slot;
+        const size_t cs = q.cap;
+        o[0] = __uint_as_float(c.flags);
+        o[cs] = c.cdir.x; o[2 * cs] = c.cdir.y; o[3 * cs] = c.cdir.z; o[4 * cs] = c.a;
+        o[5 * cs] = c.b.x; o[6 * cs] = c.b.y; o[7 * cs] = c.b.z;
+        if (A.integrator == DSDF_SIMPLE_SHADING) {
+            o[8 * cs] = c.U.x; o[9 * cs] = c.U.y; o[10 * cs] = c.U.z; o[11 * cs] = c.k0;
+            o[12 * cs] = c.W.x; o[13 * cs] = c.W.y; o[14 * cs] = c.W.z; o[15 * cs] = c.val;
+        }
+    }
+}
+
+__global__ __launch_bounds__(64) void k_backward_apply(GridView G, dsdf_params P, ViewBatch VB, Queue qall,
+                                                       const float *__restrict__ block_adjs, float *__restrict__ grad_grid) {
+    __shared__ __attribute__((aligned(16))) float tile[DSDF_SCAT_FLOATS];
+    const ViewArgs &A = VB.v[blockIdx.y];
+    const float *__restrict__ block_adj = block_adjs + (size_t)blockIdx.y * 2 * A.Wb * A.Hb;
+    const Queue q = view_queue(qall, blockIdx.y);
+    UnitGather ug;
+    ug.init(q, blockIdx.x);
+    const uint32_t count = ug.total;
+    const int lid = lane_id();
+    for (uint32_t s0 = 0; s0 < count; s0 += 64) {
+        const uint32_t si = s0 + threadIdx.x;
+        ScatterReq req[2];
+        req[0].on = false; req[1].on = false;
+        if (si < count) {
+            const uint32_t slot = ug.slot(si), lane = q.lane[slot];
+            const float *o = q.coef + slot;
+            const size_t cs = q.cap;
+            BackCoef c;
+            c.flags = __float_as_uint(o[0]);
+            c.cdir = mk(o[cs], o[2 * cs], o[3 * cs]); c.a = o[4 * cs]; c.b = mk(o[5 * cs], o[6 * cs], o[7 * cs]);
+            TraceOut tr;
+            clear_trace_out(tr, q.rec[lane]);                    // its_t ...
+            tr.warp_t = q.rec[lane + q.cap];                     // ... and warp_t locate the two scatter points
+            if (A.integrator == DSDF_SIMPLE_SHADING) {
+                c.U = mk(o[8 * cs], o[9 * cs], o[10 * cs]); c.k0 = o[11 * cs];
+                c.W = mk(o[12 * cs], o[13 * cs], o[14 * cs]); c.val = o[15 * cs];
+            } else {
+                c.U = mk(0.f, 0.f, 0.f); c.k0 = 0.f; c.W = mk(0.f, 0.f, 0.f); c.val = tr.its_t < INFINITY ? 1.f : 0.f;
+            }
+            const Lane L = lane_setup(A, P, lane);
+            lane_backward_apply(P, A, L, tr, c, block_adj, req);
+        }
+        wave_scatter_t(G, grad_grid, req[0], tile, lid);
+        if (A.integrator != DSDF_SILHOUETTE) wave_scatter_t(G, grad_grid, req[1], tile, lid);
+    }
+}
+
 // Forward mode (`render_forward`, integrators/reparam.py:192-196): the queued samples of the gradient pass push
 // the tangent of their film contribution into a tangent film block (the transpose of k_backward: gathers from
 // the tangent grid instead of scattering into the gradient grid).
@@ -683,12 +754,12 @@ static void pass_shape(int W, int H, int spp, int &tile_w, int &tile_h, size_t &
 struct Workspace {
     float *block, *block_adj;
     uint32_t *count, *qlane;
-    float *qrec;
+    float *qrec, *qcoef;   // qcoef: DSDF_COEF_WORDS rows per queue slot (split backward; not for sdf_direct_reparam)
     unsigned char *skip;
     uint32_t *items;       // work lists of the persistent render kernel: DSDF_MAX_GROUPS headers, then one entry per film-block pixel and view
     char *tail;            // tail hand-off queues: DSDF_MAX_GROUPS x (counters | march states)
     size_t tail_bytes;
-    uint32_t cap, nunits, tail_cap_sub, tail_words, group_views;
+    uint32_t cap, nunits, tail_cap_sub, tail_words, group_views, coef_rows;
     size_t bytes;
 };
 
@@ -708,7 +779,7 @@ static Workspace carve(void *base, int W, int H, int spp, int nv, int integrator
     ws.block = (float *)(p + off); off += align_up(nv * Wb * Hb * nch * sizeof(float), 256);
     ws.skip = (unsigned char *)(p + off); off += align_up(nv * Wb * Hb, 256);
     ws.items = (uint32_t *)(p + off); off += align_up((DSDF_MAX_GROUPS * DSDF_ITEM_HDR + nv * Wb * Hb) * sizeof(uint32_t), 256);
-    ws.block_adj = nullptr; ws.count = nullptr; ws.qlane = nullptr; ws.qrec = nullptr;
+    ws.block_adj = nullptr; ws.count = nullptr; ws.qlane = nullptr; ws.qrec = nullptr; ws.qcoef = nullptr; ws.coef_rows = 0;
     ws.tail = nullptr; ws.tail_bytes = 0; ws.tail_cap_sub = 0; ws.tail_words = 0;
     ws.group_views = (uint32_t)((nv + DSDF_MAX_GROUPS - 1) / DSDF_MAX_GROUPS);
     if (diff) {
@@ -716,6 +787,10 @@ static Workspace carve(void *base, int W, int H, int spp, int nv, int integrator
         ws.count = (uint32_t *)(p + off); off += align_up(nv * nunits * sizeof(uint32_t), 256);
         ws.qlane = (uint32_t *)(p + off); off += align_up(nv * cap * sizeof(uint32_t), 256);
         ws.qrec = (float *)(p + off); off += align_up(nv * cap * rows * sizeof(float), 256);
+        if (integrator != DSDF_DIRECT) {
+            ws.coef_rows = integrator == DSDF_SILHOUETTE ? 8 : DSDF_COEF_WORDS;         // (the silhouette integrator uses the first 8 rows)
+            ws.qcoef = (float *)(p + off); off += align_up(nv * cap * ws.coef_rows * sizeof(float), 256);
+        }
     }
     if (integrator != DSDF_DIRECT && spp % 64 == 0) {
         // per group: sub-queue `s` serves the chunks with work-list index % DSDF_TAIL_SUBQ == s; a wave hands off at most
@@ -943,6 +1018,9 @@ static int env_int(const char *name, int dflt) {
     const char *v = getenv(name);
     return (v && *v) ? atoi(v) : dflt;
 }
+
+// DSDF_BWD_SPLIT=0: dsdf_grad_backward runs the fused k_backward instead of k_backward_coef (in dsdf_grad_sweep) + k_backward_apply
+static bool backward_split() { static const int v = env_int("DSDF_BWD_SPLIT", 1); return v != 0; }
 static int tail_streams_enabled() { static int v = env_int("DSDF_TAIL_STREAMS", 1); return v; }
 // blocks (4 waves) per sub-queue of a tail kernel: DSDF_TAIL_BLOCKS overrides the built-in value
 static unsigned tail_blocks() {
@@ -1131,6 +1209,7 @@ static int run_pass(const PassCtx &c, const Workspace &ws, const dsdf_camera *ca
 static Queue make_queue(const Workspace &ws, bool direct) {
     Queue q;
     q.count = ws.count; q.lane = ws.qlane; q.rec = ws.qrec; q.rows = direct ? 27u : 9u; q.cap = ws.cap; q.nunits = ws.nunits;
+    q.coef = direct ? nullptr : ws.qcoef; q.coef_rows = ws.coef_rows;
     return q;
 }
 
@@ -1298,7 +1377,17 @@ int dsdf_grad_sweep(const float *padded, int rx, int ry, int rz, const dsdf_para
     c.row0 = row0; c.row1 = row1; c.film = film;
     const Workspace ws = carve(workspace, width, height, spp, n_views, integrator, true);
     ViewBatch VB;
-    return run_pass<true>(c, ws, cams, 0, n_views, VB, make_queue(ws, c.direct), nullptr);
+    const Queue q = make_queue(ws, c.direct);
+    int rc2 = run_pass<true>(c, ws, cams, 0, n_views, VB, q, nullptr);
+    if (rc2) return rc2;
+    if (q.coef && backward_split()) {
+        // the image-independent half of the adjoint of the queued samples, now: the caller has the primal pass to run (or
+        // running on another stream) before it can hand over the image gradient
+        const dim3 grid((ws.nunits + DSDF_BWD_UNITS - 1) / DSDF_BWD_UNITS, n_views);
+        hipLaunchKernelGGL(k_backward_coef, grid, dim3(64), 0, c.st, device_view(padded, rx, ry, rz, *prm), c.pp, VB, q);
+        return check_launch("k_backward_coef");
+    }
+    return DSDF_OK;
 }
 
 int dsdf_grad_backward(const float *padded, int rx, int ry, int rz, const dsdf_params *prm, const dsdf_camera *cams,
@@ -1329,7 +1418,8 @@ int dsdf_grad_backward(const float *padded, int rx, int ry, int rz, const dsdf_p
     const ShadeArgs S = make_shade_args(shading, true);
     const dim3 grid((ws.nunits + DSDF_BWD_UNITS - 1) / DSDF_BWD_UNITS, n_views);
     if (c.direct) hipLaunchKernelGGL(k_backward<true>, grid, dim3(64), 0, st, G, c.pp, VB, q, ws.block_adj, grad_grid, grad_p, (unsigned long long *)nullptr, S);
-    else hipLaunchKernelGGL(k_backward<false>, grid, dim3(64), 0, st, G, c.pp, VB, q, ws.block_adj, grad_grid, grad_p, (unsigned long long *)nullptr, S);
+    else if (grad_p || !q.coef || !backward_split()) hipLaunchKernelGGL(k_backward<false>, grid, dim3(64), 0, st, G, c.pp, VB, q, ws.block_adj, grad_grid, grad_p, (unsigned long long *)nullptr, S);
+    else hipLaunchKernelGGL(k_backward_apply, grid, dim3(64), 0, st, G, c.pp, VB, q, ws.block_adj, grad_grid);     // (coefficients: dsdf_grad_sweep)
     return check_launch("k_backward");
 }
 

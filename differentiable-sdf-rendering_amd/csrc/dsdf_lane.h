@@ -642,6 +642,111 @@ DSDF_HD bool lane_backward_direct(const GridView &G, const dsdf_params &P, const
 }
 
 // ---------------------------------------------------------------------------
+// The adjoint of lane_backward in TWO HALVES (silhouette / simple shading).  Everything expensive in it -- the Hessian lookup
+// at the warp point, WarpField2D.eval's coefficients, the hit-point Hessian of the shading channel -- is independent of the
+// image gradient; only four scalars of the film-adjoint gather (a_val, a_w, u_bar, v_bar) are not, and the sample's adjoint
+// is LINEAR in them.  lane_backward_coef computes the image-independent half right after the gradient sweep (on the sweep's
+// stream, beside the primal pass of dsdf.render_step); lane_backward_apply finishes the sample once the image gradient
+// exists: film gather, 30 FMAs, scatter requests.  Same algebra as lane_backward with the film scalars factored out.
+//   warp channel:    v_w-bar = cdir . d'-bar + a div-bar,  g_w-bar = div-bar b
+//   shading channel: G-bar = a_val U,  v_0-bar = a_val k0,  d'-bar += a_val W      (U, k0, W carry the [n.l > 0] indicator)
+// ---------------------------------------------------------------------------
+#define DSDF_COEF_WORDS 16
+struct BackCoef { uint32_t flags; V3 cdir; float a; V3 b; V3 U; float k0; V3 W; float val; };   // flags: 1 warp, 2 shading
+
+DSDF_HD bool lane_backward_coef(const GridView &G, const dsdf_params &P, const ViewArgs &A, const Lane &L, const TraceOut &tr,
+                                BackCoef &c) {
+    const V3 o = L.ray.o, d = L.ray.d;
+    const bool hit = tr.its_t < INFINITY;
+    c.flags = 0u; c.cdir = mk(0.f, 0.f, 0.f); c.a = 0.f; c.b = mk(0.f, 0.f, 0.f);
+    c.U = mk(0.f, 0.f, 0.f); c.k0 = 0.f; c.W = mk(0.f, 0.f, 0.f);
+    c.val = hit ? 1.f : 0.f;
+    if (hit && A.integrator == DSDF_SIMPLE_SHADING) {
+        const V3 phit = fma3(tr.its_t, d, o);
+        float vhit; V3 ghit; float Hhit[6];
+        eval_cubic<2>(G, phit, vhit, ghit, Hhit);
+        const float gl = sqrtf(dot(ghit, ghit));
+        const V3 n = ghit * (1.f / gl), l = light_dir();
+        const float ndl = dot(n, l);
+        c.val = fmaxf(ndl, 0.f);
+        if (ndl > 0.f) {
+            c.U = (l - ndl * n) * (1.f / gl);                          // (I - n n^T) l / |g|
+            const V3 HU = symmul(Hhit, c.U);
+            c.k0 = dot(HU, d) / dot(ghit, -d);
+            c.W = tr.its_t * (HU + c.k0 * ghit);
+        }
+        c.flags |= 2u;
+    }
+    if (A.flags & DSDF_REPARAM) {
+        WarpCoef wc;
+        if (warp_coefficients(G, P, o, d, tr, wc)) { c.cdir = wc.cdir; c.a = wc.a; c.b = wc.b; c.flags |= 1u; }
+    }
+    return c.flags != 0u;
+}
+
+DSDF_HD bool lane_backward_apply(const dsdf_params &P, const ViewArgs &A, const Lane &L, const TraceOut &tr, const BackCoef &c,
+                                 const float *block_adj, ScatterReq req[2]) {
+    req[0].on = false; req[1].on = false;
+    if (!c.flags) return false;
+    const V3 o = L.ray.o, d = L.ray.d;
+    Reproj rp = reproject(A.cam, P, o + d, A.W, A.H);
+    float pfx = rp.u + (DSDF_BORDER - 0.5f), pfy = rp.v + (DSDF_BORDER - 0.5f);
+    int x0 = (int)ceilf(pfx - DSDF_FILTER_RADIUS), y0 = (int)ceilf(pfy - DSDF_FILTER_RADIUS);
+    const float val = c.val;
+    float a_val = 0.f, a_w = 0.f, u_bar = 0.f, v_bar = 0.f;
+    float wx[4], wy[4], dwx[4], dwy[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        float rx = (float)(x0 + i) - pfx, ry = (float)(y0 + i) - pfy;
+        wx[i] = gauss_f(rx); dwx[i] = gauss_df(rx);
+        wy[i] = gauss_f(ry); dwy[i] = gauss_df(ry);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        int qy = y0 + j;
+        if (qy < 0 || qy >= A.Hb) continue;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int qx = x0 + i;
+            if (qx < 0 || qx >= A.Wb) continue;
+            const float *ba = block_adj + 2 * ((size_t)qy * A.Wb + qx);
+            float bs = ba[0], bw = ba[1];
+            float f = wx[i] * wy[j];
+            a_val = fmaf(f, bs, a_val);
+            a_w = fmaf(f, bw, a_w);
+            float s = bs * val + bw;
+            u_bar = fmaf(s, -dwx[i] * wy[j], u_bar);
+            v_bar = fmaf(s, -wx[i] * dwy[j], v_bar);
+        }
+    }
+    const float div_bar = val * a_val + a_w;
+    const float rw_bar = rp.inside ? div_bar : 0.f;
+    V3 dir_bar;
+    {
+        const float cot = 1.f / A.cam.tan_half_fov, iz = 1.f / rp.ref.z;
+        const float ku = -0.5f * (float)A.W * cot, kv = ku;
+        V3 ref_bar = mk(u_bar * ku * iz, v_bar * kv * iz, -(u_bar * ku * rp.ref.x + v_bar * kv * rp.ref.y) * iz * iz);
+        const float id2 = 1.f / (rp.dist * rp.dist);
+        ref_bar = ref_bar + rw_bar * mk(rp.ref.x * id2, rp.ref.y * id2, rp.ref.z * id2 - 3.f * iz);
+        dir_bar = mk(A.cam.left[0] * ref_bar.x + A.cam.up[0] * ref_bar.y + A.cam.dir[0] * ref_bar.z,
+                     A.cam.left[1] * ref_bar.x + A.cam.up[1] * ref_bar.y + A.cam.dir[1] * ref_bar.z,
+                     A.cam.left[2] * ref_bar.x + A.cam.up[2] * ref_bar.y + A.cam.dir[2] * ref_bar.z);
+    }
+    if (c.flags & 2u) {
+        dir_bar = dir_bar + a_val * c.W;
+        req[1].on = true; req[1].x = fma3(tr.its_t, d, o); req[1].cv = a_val * c.k0; req[1].cg = a_val * c.U;
+        req[1].p_bar = mk(0.f, 0.f, 0.f);
+    }
+    if (c.flags & 1u) {
+        req[0].on = true; req[0].x = fma3(tr.warp_t, d, o);
+        req[0].cv = dot(c.cdir, dir_bar) + c.a * div_bar;
+        req[0].cg = div_bar * c.b;
+        req[0].p_bar = mk(0.f, 0.f, 0.f);
+    }
+    return true;
+}
+
+// ---------------------------------------------------------------------------
 // Forward mode of sdf_direct_reparam (`render_forward`, integrators/reparam.py:192-196): the transpose of
 // lane_backward_direct.  Tangent inputs as in lane_forward_tangent: a tangent grid T (d sdf.data, may be absent) and a
 // tangent dp of sdf.p; at a lookup point x that itself moves by dx,  dv = T(x) - g . dp + g . dx,  dg = grad T(x) - H dp + H dx.

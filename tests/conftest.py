@@ -110,7 +110,7 @@ class HostHarness:
                                    self._p(offsets), C.c_uint(seed), integrator, int(reparam), int(diff), self._p(img))
         return img
 
-    def render_backward(self, grid, cam, W, H, spp, offsets, grad_image, integrator, reparam=True, seed=0):
+    def render_backward(self, grid, cam, W, H, spp, offsets, grad_image, integrator, reparam=True, seed=0, split=False):
         grid = np.ascontiguousarray(grid, np.float32)
         offsets = None if offsets is None else np.ascontiguousarray(offsets, np.float32)
         gi = np.ascontiguousarray(grad_image, np.float32)
@@ -119,7 +119,7 @@ class HostHarness:
         self.last_grad_p = np.zeros(3, np.float32)
         rz, ry, rx = grid.shape
         self.lib.hh_render_backward(self._p(grid), rx, ry, rz, C.byref(self.params), self._p(cam), W, H, spp,
-                                    self._p(offsets), C.c_uint(seed), integrator, int(reparam), self._p(gi),
+                                    self._p(offsets), C.c_uint(seed), integrator, int(reparam) | (0x1000 if split else 0), self._p(gi),
                                     self._p(gg), self._p(img), self._p(self.last_grad_p))
         return gg, img
 

@@ -130,7 +130,8 @@ void hh_render_backward(const float *data, int rx, int ry, int rz, const dsdf_pa
                         const float *grad_image, float *grad_grid, float *image, float *grad_p) {
     std::vector<float> p = pad(data, rx, ry, rz);
     GridView G = make_view(p.data(), rx, ry, rz, *prm);
-    ViewArgs A = view_args(cam, W, H, spp, offsets, seed, integrator, flags);
+    const bool split = (flags & 0x1000) != 0;          // harness-only: the two-half adjoint (lane_backward_coef / _apply)
+    ViewArgs A = view_args(cam, W, H, spp, offsets, seed, integrator, flags & 0xfff);
     std::vector<float> block((size_t)2 * A.Wb * A.Hb, 0.f), badj((size_t)2 * A.Wb * A.Hb, 0.f);
     long n = (long)A.Wb * A.Hb * spp;
     std::vector<TraceOut> tr(n);
@@ -154,7 +155,11 @@ void hh_render_backward(const float *data, int rx, int ry, int rz, const dsdf_pa
     for (long lane = 0; lane < n; ++lane) {
         Lane L = lane_setup(A, *prm, (uint32_t)lane);
         ScatterReq req[2];
-        lane_backward(G, *prm, A, L, tr[lane], badj.data(), req);
+        if (split) {
+            BackCoef bc;
+            req[0].on = req[1].on = false;
+            if (lane_backward_coef(G, *prm, A, L, tr[lane], bc)) lane_backward_apply(*prm, A, L, tr[lane], bc, badj.data(), req);
+        } else lane_backward(G, *prm, A, L, tr[lane], badj.data(), req);
         for (int r = 0; r < 2; ++r)
             if (req[r].on) {
                 scatter_cubic(G, grad_grid, req[r].x, req[r].cv, req[r].cg, PlainAdd());

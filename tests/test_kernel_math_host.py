@@ -232,3 +232,16 @@ def test_handed_off_march_resumes_bit_identically(harness, split):
     for k in a:
         assert np.array_equal(a[k], b[k], equal_nan=True), k
     assert (a['steps'] > split).sum() > 100
+
+
+@pytest.mark.parametrize('name', ['sphere16', 'blob32', 'blob48_rect'])
+@pytest.mark.parametrize('integ', [O.SILHOUETTE, O.SIMPLE_SHADING])
+def test_split_adjoint_equals_fused(harness, name, integ):
+    """lane_backward_coef (image-independent half, computed beside the primal pass) + lane_backward_apply (film adjoint
+    gather + scatter requests) is the fused lane_backward with the film scalars factored out."""
+    case = make_case(name)
+    a = (case['grid'].float().numpy(), cam_params(case), case['W'], case['H'], case['spp'], case['offsets'].numpy(), case['grad_image'].numpy(), integ)
+    fused, _ = harness.render_backward(*a)
+    split, _ = harness.render_backward(*a, split=True)
+    assert np.abs(fused).max() > 0
+    assert rel_l2(split, fused) < 2e-6, rel_l2(split, fused)

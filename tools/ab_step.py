@@ -43,5 +43,9 @@ if '--shade' in sys.argv:
     g.zero_()
     dsdf.render_backward(grid, sens, 64, gi, grad_grid=g, seeds=S, integrator=1)
     cs['grad64_shade'] = [float(g.double().abs().sum()), float((g.double() ** 2).sum())]
+g.zero_()
+dsdf.render_step(grid, sens, 256, 64, lambda im: gi, g, S, [s + 100 for s in S])
+torch.cuda.synchronize()
+cs['step_grad'] = [float(g.double().abs().sum()), float((g.double() ** 2).sum())]
 out['checksums'] = cs
 print('AB ' + json.dumps(out))
