@@ -816,8 +816,10 @@ static int batch_size(int W, int H, int spp, int n_views, int integrator, size_t
 }
 
 static ViewArgs make_view_args(const dsdf_camera &cam, int W, int H, int spp, const float *offsets, uint32_t seed,
-                               int integrator, int flags, const float *emitter_u = nullptr, const float *bsdf_u = nullptr) {
+                               int integrator, int flags, const dsdf_params &prm, const float *emitter_u = nullptr,
+                               const float *bsdf_u = nullptr) {
     ViewArgs A;
+    for (int k = 0; k < 3; ++k) A.light[k] = prm.light_dir[k];
     A.cam = cam; A.W = W; A.H = H; A.Wb = W + 2 * DSDF_BORDER; A.Hb = H + 2 * DSDF_BORDER; A.spp = spp;
     A.integrator = integrator; A.flags = flags; A.seed = seed; A.offsets = offsets; A.emitter_u = emitter_u; A.bsdf_u = bsdf_u;
     return A;
@@ -873,6 +875,7 @@ void dsdf_default_params(dsdf_params *p) {
     p->trace_eps = 1e-6f; p->extra_thresh = 0.05f; p->sil_weight_offset = 0.05f; p->sil_weight_epsilon = 1e-6f;
     p->bbox_delta = 0.05f; p->edge_eps = 0.01f; p->clamping_thresh = 0.05f; p->near_clip = 1e-2f; p->far_clip = 1e4f;
     p->weight_strategy = 6; p->refine_steps = 10;
+    p->light_dir[0] = p->light_dir[1] = p->light_dir[2] = 0.57735026918962576f;
 }
 
 size_t dsdf_padded_size(int rx, int ry, int rz) {
@@ -1083,7 +1086,7 @@ static int run_pass(const PassCtx &c, const Workspace &ws, const dsdf_camera *ca
     hipStream_t st = c.st;
     for (int i = 0; i < nv; ++i)
         VB.v[i] = make_view_args(cams[v0 + i], c.W, c.H, c.spp, c.offsets ? c.offsets + (size_t)(v0 + i) * c.nl * 2 : nullptr,
-                                 c.seeds ? c.seeds[v0 + i] : 0u, c.integrator, c.flags,
+                                 c.seeds ? c.seeds[v0 + i] : 0u, c.integrator, c.flags, c.pp,
                                  c.emitter_u ? c.emitter_u + (size_t)(v0 + i) * c.nl * 2 : nullptr,
                                  c.bsdf_u ? c.bsdf_u + (size_t)(v0 + i) * c.nl * 2 : nullptr);
     const size_t nch = (size_t)film_channels(c.integrator), npix = c.Wb * c.Hb;
@@ -1408,7 +1411,7 @@ int dsdf_grad_backward(const float *padded, int rx, int ry, int rz, const dsdf_p
     ViewBatch VB;
     for (int i = 0; i < n_views; ++i)
         VB.v[i] = make_view_args(cams[i], width, height, spp, offsets ? offsets + (size_t)i * c.nl * 2 : nullptr, seeds ? seeds[i] : 0u,
-                                 integrator, flags, c.emitter_u ? c.emitter_u + (size_t)i * c.nl * 2 : nullptr,
+                                 integrator, flags, c.pp, c.emitter_u ? c.emitter_u + (size_t)i * c.nl * 2 : nullptr,
                                  c.bsdf_u ? c.bsdf_u + (size_t)i * c.nl * 2 : nullptr);
     const dim3 adj_grid((unsigned)((c.Wb * c.Hb + 255) / 256), n_views);
     if (c.direct) hipLaunchKernelGGL(k_develop_adjoint_rgb, adj_grid, dim3(256), 0, st, film_total, grad_image, width, height, ws.block_adj);

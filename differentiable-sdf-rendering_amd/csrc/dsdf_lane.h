@@ -19,6 +19,8 @@ struct ViewArgs {
     const float *offsets;   // per-lane (r0,r1) or nullptr -> built-in sampler
     const float *emitter_u; // sdf_direct_reparam: per-lane emitter sample or nullptr -> built-in sampler
     const float *bsdf_u;    // sdf_direct_reparam, use_mis: per-lane BSDF sample (next_2d) or nullptr -> built-in sampler
+    // sdf_simple_shading_reparam.py:20: the fixed light direction normalize(1,1,1), in the SDF's frame (dsdf_params.light_dir)
+    float light[3] = {0.57735026918962576f, 0.57735026918962576f, 0.57735026918962576f};
 };
 
 // Scene-side inputs of sdf_direct_reparam (shared by all views of a call).
@@ -58,7 +60,7 @@ DSDF_HD Lane lane_setup(const ViewArgs &A, const dsdf_params &P, uint32_t lane) 
     return L;
 }
 
-DSDF_HD V3 light_dir() { const float s = 0.57735026918962576f; return mk(s, s, s); }
+DSDF_HD V3 light_dir(const ViewArgs &A) { return mk(A.light[0], A.light[1], A.light[2]); }
 
 // Value of the `sample()` body given the trace result.
 DSDF_HD float shade_value(const GridView &G, const ViewArgs &A, const Lane &L, float its_t) {
@@ -69,7 +71,7 @@ DSDF_HD float shade_value(const GridView &G, const ViewArgs &A, const Lane &L, f
     float v; V3 g; float H[6];
     eval_cubic<1>(G, fma3(its_t, L.ray.d, L.ray.o), v, g, H);
     V3 n = g * rsqf(dot(g, g));
-    return fmaxf(dot(n, light_dir()), 0.f);
+    return fmaxf(dot(n, light_dir(A)), 0.f);
 }
 
 // ImageBlock::put for one lane: 4x4 window of the radius-2 Gaussian around
@@ -197,7 +199,7 @@ DSDF_HD bool lane_forward_tangent(const GridView &G, const float *tangent, V3 dp
             eval_cubic<2>(G, phit, vhit, ghit, Hhit);
             const float gl = sqrtf(dot(ghit, ghit));
             const V3 n = ghit * (1.f / gl);
-            const V3 l = light_dir();
+            const V3 l = light_dir(A);
             const float ndl = dot(n, l);
             out.val = fmaxf(ndl, 0.f);
             float tv = 0.f; V3 tg = mk(0.f, 0.f, 0.f); float tH[6];
@@ -408,7 +410,7 @@ DSDF_HD bool lane_backward(const GridView &G, const dsdf_params &P, const ViewAr
             phit = fma3(tr.its_t, d, o);
             eval_cubic<2>(G, phit, vhit, ghit, Hhit);
             float gl = sqrtf(dot(ghit, ghit));
-            val = fmaxf(dot(ghit, light_dir()) / gl, 0.f);
+            val = fmaxf(dot(ghit, light_dir(A)) / gl, 0.f);
         }
     }
     float a_val = 0.f, a_w = 0.f, u_bar = 0.f, v_bar = 0.f;
@@ -462,7 +464,7 @@ DSDF_HD bool lane_backward(const GridView &G, const dsdf_params &P, const ViewAr
         float g2 = dot(ghit, ghit);
         float gl = sqrtf(g2);
         V3 n = ghit * (1.f / gl);
-        V3 l = light_dir();
+        V3 l = light_dir(A);
         float ndl = dot(n, l);
         float s_bar = (ndl > 0.f) ? a_val : 0.f;                  // d max(n.l,0); a_val = sum over rgb handled in develop adjoint
         V3 G_bar = (s_bar / gl) * (l - ndl * n);                  // (I - n n^T) l / |g|
@@ -666,7 +668,7 @@ DSDF_HD bool lane_backward_coef(const GridView &G, const dsdf_params &P, const V
         float vhit; V3 ghit; float Hhit[6];
         eval_cubic<2>(G, phit, vhit, ghit, Hhit);
         const float gl = sqrtf(dot(ghit, ghit));
-        const V3 n = ghit * (1.f / gl), l = light_dir();
+        const V3 n = ghit * (1.f / gl), l = light_dir(A);
         const float ndl = dot(n, l);
         c.val = fmaxf(ndl, 0.f);
         if (ndl > 0.f) {

@@ -27,7 +27,7 @@ class DsdfParams(C.Structure):
                 ('sil_weight_epsilon', C.c_float), ('bbox_delta', C.c_float), ('edge_eps', C.c_float),
                 ('clamping_thresh', C.c_float), ('near_clip', C.c_float), ('far_clip', C.c_float),
                 ('sdf_p', C.c_float * 3), ('weight_strategy', C.c_int), ('refine_steps', C.c_int),
-                ('reserved', C.c_int * 2)]
+                ('light_dir', C.c_float * 3)]
 
 
 class DsdfShading(C.Structure):

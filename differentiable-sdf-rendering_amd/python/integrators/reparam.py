@@ -86,21 +86,27 @@ class ReparamIntegrator:
         if props.get('antithetic_sampling', False) or props.get('use_aovs', False):
             raise NotImplementedError("antithetic_sampling / use_aovs are outside the supported path")
         fn = props.get('sdf_filename', '')
-        self.sdf = Grid3d(fn) if fn else props.get('sdf', None)
+        self.sdf = Grid3d(fn, transform=props.get('sdf_to_world', None)) if fn else props.get('sdf', None)   # reparam.py:21-29
         self.warp_field = None
 
     # -- helpers -------------------------------------------------------------------------
     def _sensors(self, scene, sensor):
+        """The requested sensors, seen from the SDF's own frame (Grid3d.local_sensor; the identity without a transform)."""
         if isinstance(sensor, int):
-            return [scene.sensors()[sensor]]
-        return list(sensor) if isinstance(sensor, (list, tuple)) else [sensor]
+            sens = [scene.sensors()[sensor]]
+        else:
+            sens = list(sensor) if isinstance(sensor, (list, tuple)) else [sensor]
+        return [self.sdf.local_sensor(s) for s in sens] if self.sdf is not None else sens
 
     def _configured(self):
         if self.sdf is None:
             raise ValueError("integrator has no SDF (sdf_filename / props['sdf'])")
         wf = self.warp_field if self.warp_field is not None else DummyWarpField(self.sdf)
         wf.apply(self.sdf.grid.params)
-        self.sdf.grid.set_translation(self.sdf.p)
+        self.sdf._sync()
+        sh = self.shading()
+        if self.sdf.has_transform and sh is not None and isinstance(sh.albedo, torch.Tensor) and tuple(sh.albedo.shape[:3]) != (1, 1, 1):
+            raise NotImplementedError("an albedo VOLUME lives in world space: it cannot be combined with sdf_to_world")
         return wf.reparameterize
 
     # -- plugin API ----------------------------------------------------------------------
@@ -134,7 +140,7 @@ class ReparamIntegrator:
         if want_a:
             at.grad = ga if at.grad is None else at.grad + ga
         if want_p:
-            gp = gp.to(device=pt.device, dtype=pt.dtype).reshape(pt.shape)
+            gp = self.sdf.to_world_covectors(gp[None])[0].to(device=pt.device, dtype=pt.dtype).reshape(pt.shape)
             pt.grad = gp if pt.grad is None else pt.grad + gp
 
     def render_forward(self, scene, params, sensor=0, seed=0, spp=0):
@@ -147,6 +153,8 @@ class ReparamIntegrator:
         pt = params[SDF_DEFAULT_KEY_P] if SDF_DEFAULT_KEY_P in params else None
         td = data.grad if isinstance(data, torch.Tensor) and data.grad is not None else None
         tp = pt.grad if isinstance(pt, torch.Tensor) and pt.grad is not None else None
+        if tp is not None and self.sdf.has_transform:
+            tp = self.sdf.to_local_vectors(tp.reshape(1, 3).to(torch.float64))[0].to(tp.dtype)
         if td is None and tp is None:
             raise ValueError("render_forward: set the tangent of sdf.data and / or sdf.p through their .grad fields")
         g = dsdf.render_forward_grad(self.sdf.grid, sens, spp or 4, tangent_data=td, tangent_p=tp,

@@ -16,13 +16,40 @@ def atleast_4d(t):
     return t[..., None] if t.dim() == 3 else t
 
 
+def _rigid_parts(transform):
+    """4x4 `to_world` -> (to_world, A, b) with to_local(x) = A x + b, all float64 numpy.  Accepted: a translation combined with
+    an AXIS-ALIGNED rotation (a signed permutation of the axes, det +1).  Then the reference's computation -- march through the
+    world AABB of the transformed cube, distances to that AABB in the boundary fade of the trace weights (python/shapes.py:393-403,
+    86-87) -- is the same computation in the cube's own frame, which is where the library works.  Any other rotation makes
+    the reference's AABB larger than the cube (gradients differ by percents: measured 4.9 % at 25 degrees), scale / shear /
+    mirror change the march itself: those raise."""
+    tw = np.asarray(transform.matrix if hasattr(transform, 'matrix') else transform, np.float64).reshape(4, 4)
+    if not np.allclose(tw[3], [0, 0, 0, 1], atol=1e-12):
+        raise NotImplementedError("Grid3d(transform=...): projective transforms are not supported")
+    R = tw[:3, :3]
+    if not np.allclose(R.T @ R, np.eye(3), atol=1e-5) or np.linalg.det(R) < 0:
+        raise NotImplementedError("Grid3d(transform=...): scale / shear / mirror are not supported (DESIGN.md section 9)")
+    if not np.allclose(np.abs(R), np.round(np.abs(R)), atol=1e-6):
+        raise NotImplementedError("Grid3d(transform=...): only axis-aligned rotations (+ translation) reproduce the reference, "
+                                  "whose traced box is the world AABB of the rotated cube (DESIGN.md section 9)")
+    R = np.round(R)
+    tw = tw.copy()
+    tw[:3, :3] = R
+    A = R.T
+    return tw, A, -A @ tw[:3, 3]
+
+
 class Grid3d:
-    """Grid-based SDF (python/shapes.py:375-483): a (Z,Y,X[,1]) fp32 tensor interpreted
-    as a tricubic B-spline texture over the unit cube.  `transform` is not supported."""
+    """Grid-based SDF (python/shapes.py:375-483): a (Z,Y,X[,1]) fp32 tensor interpreted as a tricubic B-spline texture
+    over the unit cube.  `transform` (python/shapes.py:378-403, integrator property `sdf_to_world`): a 4x4 `to_world` made of a
+    translation and an axis-aligned rotation (`_rigid_parts`).  The library always works in the cube's own frame: points, rays
+    and sensors are taken there with `to_local` (`local_sensor`), scalars (t, weights, images) are frame-independent and
+    vectors come back through to_local^T like the reference's gradients (:426-427, 446-448)."""
 
     def __init__(self, data, transform=None):
-        if transform is not None:
-            raise NotImplementedError("Grid3d(transform=...) is outside the supported path (DESIGN.md section 9)")
+        self.has_transform = transform is not None
+        if self.has_transform:
+            self.to_world, self._A, self._b = _rigid_parts(transform)
         if isinstance(data, str):
             from util import read_vol
             data = redistancing.redistance(read_vol(data))
@@ -32,40 +59,101 @@ class Grid3d:
         # SDFBase defaults, python/shapes.py:28-39 (held by the library's dsdf_params)
         self.refine_intersection = True
 
+    # --- change of frame (python/shapes.py:408-414) -------------------------------------
+    def _mat(self, like):
+        return torch.as_tensor(self._A, dtype=like.dtype, device=like.device), torch.as_tensor(self._b, dtype=like.dtype, device=like.device)
+
+    def to_local_points(self, x):
+        """to_local @ x for (n,3) points.  (`sdf.p` is applied by the library: lookups at x_local - to_local3 @ p.)"""
+        if not self.has_transform:
+            return x
+        A, b = self._mat(x)
+        return x @ A.T + b
+
+    def to_local_vectors(self, d):
+        if not self.has_transform:
+            return d
+        return d @ self._mat(d)[0].T
+
+    def to_world_covectors(self, g):
+        """to_local3^T g: how gradients (and derivatives w.r.t. a world-space direction) come back."""
+        if not self.has_transform:
+            return g
+        return g @ self._mat(g)[0]
+
+    def local_translation(self, p=None):
+        """`sdf.p` in the cube's frame: to_local @ (x - p) = to_local @ x - to_local3 @ p."""
+        p = self.p if p is None else p
+        vals = np.asarray(p.detach().cpu().tolist() if isinstance(p, torch.Tensor) else p, np.float64)
+        return (self._A @ vals).tolist() if self.has_transform else vals.tolist()
+
+    def local_sensor(self, sensor):
+        """The sensor seen from the cube's frame: a rigid map takes the look-at frame to the look-at frame of the mapped
+        origin / target / up, so the camera rays are the mapped camera rays."""
+        if not self.has_transform:
+            return sensor
+        return dsdf.Sensor(self._A @ sensor.origin + self._b, self._A @ sensor.target + self._b, self._A @ sensor.up,
+                           fov=sensor.fov, resx=sensor.resx, resy=sensor.resy)
+
+    def _sync(self):
+        """Frame-dependent fields of the library's parameter block: `sdf.p` and the fixed light of
+        sdf_simple_shading_reparam (normalize(1,1,1) in WORLD space, sdf_simple_shading_reparam.py:20), both in the cube's frame."""
+        self.grid.set_translation(self.local_translation())
+        if self.has_transform:
+            l = self._A @ (np.ones(3) / np.sqrt(3.0))
+            for k in range(3):
+                self.grid.params.light_dir[k] = float(l[k])
+
     # --- texture protocol -------------------------------------------------------------
     def eval(self, x, detached=False):
-        return dsdf.eval_cubic(self.grid, x, 0)[0]
+        self._sync()
+        return dsdf.eval_cubic(self.grid, self.to_local_points(x), 0)[0]
 
     def eval_grad(self, x, detached=False):
-        return dsdf.eval_cubic(self.grid, x, 1)[1]
+        self._sync()
+        return self.to_world_covectors(dsdf.eval_cubic(self.grid, self.to_local_points(x), 1)[1])
 
     def eval_and_grad(self, x, detached=False):
-        v, g, _ = dsdf.eval_cubic(self.grid, x, 1)
-        return v, g
+        self._sync()
+        v, g, _ = dsdf.eval_cubic(self.grid, self.to_local_points(x), 1)
+        return v, self.to_world_covectors(g)
 
     def eval_all(self, x, detach_w=False):
         """-> (v, v_detached, g, g_detached, H[n,3,3]) like python/shapes.py:438-450."""
-        v, g, h = dsdf.eval_cubic(self.grid, x, 2)
+        self._sync()
+        v, g, h = dsdf.eval_cubic(self.grid, self.to_local_points(x), 2)
         H = torch.stack([torch.stack([h[:, 0], h[:, 3], h[:, 4]], -1),
                          torch.stack([h[:, 3], h[:, 1], h[:, 5]], -1),
                          torch.stack([h[:, 4], h[:, 5], h[:, 2]], -1)], -2)
+        if self.has_transform:
+            A = self._mat(g)[0]
+            g = g @ A
+            H = A.T @ H @ A
         return v, v, g, g, H
 
     def bbox(self, expand=True):
+        """python/shapes.py:393-403, 416-418: AABB of the transformed cube corners (+- 0.05)."""
         d = 0.05 if expand else 0.0
+        if self.has_transform:
+            c = np.array([[x, y, z] for x in (0.0, 1.0) for y in (0.0, 1.0) for z in (0.0, 1.0)])
+            w = c @ self.to_world[:3, :3].T + self.to_world[:3, 3]
+            return torch.tensor(w.min(0) - d, dtype=torch.float32), torch.tensor(w.max(0) + d, dtype=torch.float32)
         return torch.full((3,), -d), torch.full((3,), 1.0 + d)
 
     # --- tracing (python/shapes.py:115-339) ---------------------------------------------
     def ray_intersect(self, ray_o, ray_d, maxt, warp=None, active=True, extra_outputs=None):
         """-> (its_t, warp_t, warp_t_d, warp_weight, warp_weight_d); `warp=None` takes the
         non-differentiable path exactly like the reference (:116-118)."""
-        out = dsdf.trace(self.grid, ray_o, ray_d, maxt, differentiable=warp is not None)
+        self._sync()
+        out = dsdf.trace(self.grid, self.to_local_points(ray_o), self.to_local_vectors(ray_d), maxt,
+                         differentiable=warp is not None)
         if extra_outputs is not None:
             extra_outputs['i'] = out['steps']
         if warp is None:
             z = torch.zeros_like(out['its_t'])
             return out['its_t'], z, torch.zeros_like(ray_o), None, None
-        return out['its_t'], out['warp_t'], out['warp_t_d'], out['warp_weight'], out['warp_weight_d']
+        return (out['its_t'], out['warp_t'], self.to_world_covectors(out['warp_t_d']), out['warp_weight'],
+                self.to_world_covectors(out['warp_weight_d']))
 
     def ray_intersect_non_diff(self, ray_o, ray_d, maxt, active=True):
         return self.ray_intersect(ray_o, ray_d, maxt, warp=None)

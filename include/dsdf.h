@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define DSDF_VERSION 300   /* 300: stats rows of DSDF_STAT_SLOTS (16) counters; tail hand-off on library-owned helper streams */
+#define DSDF_VERSION 301   /* 300: stats rows of DSDF_STAT_SLOTS (16) counters; tail hand-off on library-owned helper streams */
 #define DSDF_STAT_SLOTS 16
 
 enum dsdf_status {
@@ -79,7 +79,8 @@ typedef struct dsdf_params {
     float sdf_p[3];           /* `sdf.p` translation (shapes.py:389, 412) */
     int   weight_strategy;    /* configs.py:30  6 -> eps = edge_eps * t (warp.py:41-45) */
     int   refine_steps;       /* shapes.py:245-257  10 (0 disables refinement) */
-    int   reserved[2];
+    float light_dir[3];       /* sdf_simple_shading_reparam.py:20  normalize(1,1,1): the fixed light of the debug integrator, in the
+                                 SDF's frame (a caller that renders a rigidly transformed SDF rotates it, python/shapes.py Grid3d) */
 } dsdf_params;
 
 /* Scene-side inputs of sdf_direct_reparam (python/integrators/sdf_direct_reparam.py:16-111).  The reference takes BSDF and emitter from scene files it does not ship; this library

@@ -144,30 +144,51 @@ def eval_cubic(data, p, order=2):
 
 
 class Grid3d:
-    """shapes.py:375-483 without `to_world` (identity); `p` is the translation
-    parameter `sdf.p` (shapes.py:389, 412)."""
+    """shapes.py:375-483; `p` is the translation parameter `sdf.p` (shapes.py:389, 412), `to_world` the optional 4x4
+    transform of the unit cube (shapes.py:378-403): lookups happen at to_local @ (x - p) (call_wrap, :408-414), gradients
+    come back as to_local^T g and Hessians as to_local^T H to_local (:426-427, 446-448), the traced box is the AABB of
+    the eight transformed corners (:393-403, 416-418)."""
 
-    def __init__(self, data, p=None):
+    def __init__(self, data, p=None, to_world=None):
         self.data = data
         self.p = p if p is not None else torch.zeros(3, dtype=data.dtype)
+        self.has_transform = to_world is not None
+        if self.has_transform:
+            tw = torch.as_tensor(to_world, dtype=torch.float64).reshape(4, 4)
+            tl = torch.linalg.inv(tw)
+            self.to_world = tw.to(data.dtype)
+            self.A = tl[:3, :3].to(data.dtype)               # linear part of to_local
+            self.b = tl[:3, 3].to(data.dtype)
+            c = torch.tensor([[x, y, z] for x in (0.0, 1.0) for y in (0.0, 1.0) for z in (0.0, 1.0)], dtype=torch.float64)
+            w = c @ tw[:3, :3].T + tw[:3, 3]
+            self.aabb = (w.min(0).values.to(data.dtype), w.max(0).values.to(data.dtype))
+
+    def local(self, x):                                  # shapes.py:408-414
+        x = x - self.p
+        return x @ self.A.T + self.b if self.has_transform else x
 
     def bbox(self):                                      # shapes.py:416-418
+        if self.has_transform:
+            return self.aabb[0] - BBOX_DELTA, self.aabb[1] + BBOX_DELTA
         lo = torch.full((3,), -BBOX_DELTA, dtype=self.data.dtype)
         hi = torch.full((3,), 1.0 + BBOX_DELTA, dtype=self.data.dtype)
         return lo, hi
 
     def eval(self, x):                                   # shapes.py:420-421
-        return eval_cubic(self.data, x - self.p, 0)[0]
+        return eval_cubic(self.data, self.local(x), 0)[0]
 
     def eval_and_grad(self, x):                          # shapes.py:430-436
-        v, g, _ = eval_cubic(self.data, x - self.p, 1)
-        return v, g
+        v, g, _ = eval_cubic(self.data, self.local(x), 1)
+        return v, (g @ self.A if self.has_transform else g)
 
     def eval_grad(self, x):                              # shapes.py:423-428
-        return eval_cubic(self.data, x - self.p, 1)[1]
+        return self.eval_and_grad(x)[1]
 
     def eval_all(self, x):                               # shapes.py:438-450
-        v, g, H = eval_cubic(self.data, x - self.p, 2)
+        v, g, H = eval_cubic(self.data, self.local(x), 2)
+        if self.has_transform:
+            g = g @ self.A                                # to_local3^T g
+            H = self.A.T @ H @ self.A
         return v, v.detach(), g, g.detach(), H
 
 
@@ -836,7 +857,7 @@ def lane_positions(W, H, spp, offsets):
 
 def render(sdf, cam, W, H, spp, offsets, integrator=SILHOUETTE, reparam=True,
            return_aux=False, chunk=1 << 17, albedo=None, emitter_u=None, env=1.0, hide_emitters=False, rows=None,
-           return_block=False, use_mis=False, bsdf_u=None, detach_indirect_si=False, decouple_reparam=False):
+           return_block=False, use_mis=False, bsdf_u=None, detach_indirect_si=False, decouple_reparam=False, light_dir=None):
     """One view.  offsets: (Wb*Hb*spp, 2) in [0,1) (the sampler's next_2d per
     lane).  Returns image (H,W,3), differentiable w.r.t. sdf.data / sdf.p when
     they require grad.  `reparam=False` gives the DummyWarpField path
@@ -854,7 +875,8 @@ def render(sdf, cam, W, H, spp, offsets, integrator=SILHOUETTE, reparam=True,
             bsdf_u = bsdf_u[lo:hi]
     block = torch.zeros(Hb * Wb * 4, dtype=dt)
     aux = dict(steps=0, lanes=0, bbox=0, hits=0, refine=0, warp_active=0)
-    light = torch.tensor([1.0, 1.0, 1.0], dtype=dt) / math.sqrt(3.0)
+    # sdf_simple_shading_reparam.py:20 fixes normalize(1,1,1); `light_dir` only serves the change-of-frame test (tests/test_to_world.py)
+    light = torch.tensor([1.0, 1.0, 1.0], dtype=dt) / math.sqrt(3.0) if light_dir is None else torch.as_tensor(light_dir, dtype=dt)
     for s in range(0, pos_all.shape[0], chunk):
         pos = pos_all[s:s + chunk]
         o, d, maxt = cam.sample_ray(pos, W, H)                           # reparam.py:92-94
@@ -918,7 +940,7 @@ def render_backward(sdf, cam, W, H, spp, offsets, grad_in, integrator=SILHOUETTE
     Returns dL/d(sdf.data) (and accumulates into .grad of any leaf)."""
     data = sdf.data
     leaf = data.detach().clone().requires_grad_(True)
-    s2 = Grid3d(leaf, sdf.p)
+    s2 = Grid3d(leaf, sdf.p, sdf.to_world if getattr(sdf, 'has_transform', False) else None)
     img = render(s2, cam, W, H, spp, offsets, integrator, reparam)
     if not img.requires_grad:
         return torch.zeros_like(leaf)

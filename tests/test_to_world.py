@@ -1,0 +1,171 @@
+"""`Grid3d(data, transform)` / integrator property `sdf_to_world` (/root/reference/python/shapes.py:378-450,
+integrators/reparam.py:21-29).
+
+The oracle restates the reference literally: lookups at to_local @ (x - p), gradients back through to_local^T, Hessians
+through to_local^T H to_local, the traced box = AABB of the transformed corners.  The product works in the cube's own
+frame (sensors / rays mapped by to_local) and accepts the transforms for which that is the SAME computation: translation +
+axis-aligned rotation (the AABB is then the cube itself).  CPU: the two views agree inside the oracle; GPU: the HIP path through `shapes.Grid3d(transform=...)` against the oracle
+with the transform.
+"""
+import numpy as np
+import pytest
+import torch
+
+import sdf_oracle as O
+from cases import make_case
+
+FWD_TOL = 1e-4
+
+
+def rot(axis, deg):
+    a = np.radians(deg)
+    c, s = np.cos(a), np.sin(a)
+    i, j = [(1, 2), (2, 0), (0, 1)][axis]
+    R = np.eye(3)
+    R[i, i], R[i, j], R[j, i], R[j, j] = c, -s, s, c
+    return R
+
+
+def about_centre(R, shift=(0.0, 0.0, 0.0)):
+    """4x4 to_world: rotate the unit cube about its centre, then translate."""
+    T = np.eye(4)
+    T[:3, :3] = R
+    T[:3, 3] = np.array([0.5, 0.5, 0.5]) - R @ np.array([0.5, 0.5, 0.5]) + np.asarray(shift)
+    return T
+
+
+AXIS_ALIGNED = about_centre(rot(1, 90) @ rot(0, 180), (0.02, -0.015, 0.01))
+GENERAL = about_centre(rot(1, 25) @ rot(2, -10), (0.01, 0.0, -0.02))
+
+
+def local_camera(T, origin):
+    A = T[:3, :3].T
+    b = -A @ T[:3, 3]
+    return O.Camera(A @ np.asarray(origin) + b, A @ np.array([0.5, 0.5, 0.5]) + b, A @ np.array([0.0, 1.0, 0.0]))
+
+
+def test_oracle_transform_is_a_change_of_frame():
+    """Axis-aligned rigid transform: rendering the transformed SDF with the world camera == rendering the plain SDF with the
+    camera taken to the cube's frame -- image and dL/d(data) -- inside the fp64 oracle."""
+    case = make_case('sphere16')
+    data = O.blob_grid(16, n=4, seed=5)
+    offs = case['offsets'].double()
+    W, H, spp = case['W'], case['H'], case['spp']
+    p = torch.tensor([0.01, -0.02, 0.015], dtype=torch.float64)
+    A = torch.tensor(AXIS_ALIGNED[:3, :3].T)
+    light = A @ (torch.ones(3, dtype=torch.float64) / 3.0 ** 0.5)       # the world-space light of simple shading, in the cube's frame
+    gi = case['grad_image'].double()
+    for integ in (O.SILHOUETTE, O.SIMPLE_SHADING):
+        da = data.clone().requires_grad_(True)
+        db = data.clone().requires_grad_(True)
+        a = O.render(O.Grid3d(da, p, AXIS_ALIGNED), O.Camera(case['origin']), W, H, spp, offs, integ, True)
+        b = O.render(O.Grid3d(db, A @ p), local_camera(AXIS_ALIGNED, case['origin']), W, H, spp, offs, integ, True, light_dir=light)
+        assert float((a - b).abs().max()) < 1e-9
+        (a * gi).sum().backward()
+        (b * gi).sum().backward()
+        assert float(db.grad.abs().max()) > 0
+        assert float((da.grad - db.grad).abs().max()) <= 1e-8 * float(db.grad.abs().max())
+
+
+def test_oracle_transform_gradients_follow_the_reference():
+    """eval_grad / eval_all of the transformed grid are the derivatives of eval w.r.t. the WORLD point (autograd)."""
+    data = O.blob_grid(16, n=4, seed=5)
+    sdf = O.Grid3d(data, torch.tensor([0.01, 0.0, -0.01], dtype=torch.float64), GENERAL)
+    x = (torch.rand(50, 3, dtype=torch.float64, generator=torch.Generator().manual_seed(3)) * 0.6 + 0.2).requires_grad_(True)
+    v, _, g, _, Hm = sdf.eval_all(x)
+    ga = torch.autograd.grad(v.sum(), x, create_graph=True)[0]
+    assert torch.allclose(g, ga, atol=1e-10)
+    for k in range(3):
+        hk = torch.autograd.grad(ga[:, k].sum(), x, retain_graph=True)[0]
+        assert torch.allclose(Hm[:, k, :], hk, atol=1e-8)
+    lo, hi = sdf.bbox()
+    assert float(lo.min()) < -0.05 and float(hi.max()) > 1.05           # a rotated cube's AABB is larger than the cube
+
+
+def test_rigid_parts_and_local_sensor():
+    import shapes
+    import dsdf
+    with pytest.raises(NotImplementedError):
+        shapes._rigid_parts(np.diag([2.0, 2.0, 2.0, 1.0]))
+    with pytest.raises(NotImplementedError):
+        shapes._rigid_parts(np.diag([1.0, -1.0, 1.0, 1.0]))
+    with pytest.raises(NotImplementedError):
+        shapes._rigid_parts(GENERAL)                      # the reference's box is the world AABB: not the same computation
+    tw, A, b = shapes._rigid_parts(AXIS_ALIGNED)
+    assert np.allclose(A @ tw[:3, :3], np.eye(3)) and np.allclose(A @ tw[:3, 3] + b, 0)
+    # the look-at frame of the mapped sensor is the mapped look-at frame
+    s = dsdf.get_regular_cameras(5, resx=20, resy=12)[3]
+    g = shapes.Grid3d.__new__(shapes.Grid3d)
+    g.has_transform, g.to_world, g._A, g._b = True, tw, A, b
+    ls = g.local_sensor(s)
+    for u, v in zip(s.frame(), ls.frame()):
+        assert np.allclose(A @ u, v, atol=1e-12)
+    assert np.allclose(ls.origin, A @ s.origin + b) and (ls.resx, ls.resy, ls.fov) == (s.resx, s.resy, s.fov)
+    assert np.allclose(g.local_translation([0.1, 0.2, 0.3]), A @ np.array([0.1, 0.2, 0.3]))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('T,exact', [(AXIS_ALIGNED, True), (about_centre(rot(2, -90), (0.0, 0.03, 0.0)), True)])
+def test_transformed_grid_render_gpu(built, T, exact):
+    """The HIP path with `Grid3d(data, transform=T)` and the WORLD sensor against the oracle with the same transform: image and
+    dL/d(data), dL/d(sdf.p); protocol methods (eval_all, ray_intersect) against the oracle's."""
+    import configs
+    import dsdf
+    import shapes
+    import integrators  # noqa: F401  (plugin registration)
+    from integrators.reparam import Scene, create_integrator, traverse
+    from constants import SDF_DEFAULT_KEY, SDF_DEFAULT_KEY_P
+    dsdf.load()
+    case = make_case('blob32')
+    W, H, spp = case['W'], case['H'], case['spp']
+    data = case['grid'].float()
+    sdf = shapes.Grid3d(data.cuda(), transform=T)
+    p0 = torch.tensor([0.01, -0.02, 0.015])
+    sdf.p = p0.clone()
+    osdf = O.Grid3d(data.double(), p0.double(), T)
+    sensor = dsdf.Sensor(case['origin'], resx=W, resy=H)
+    cam = O.Camera(case['origin'])
+    seed = 9
+    offs = torch.tensor(O.independent_sampler_2d(seed, (W + 4) * (H + 4) * spp)).double()
+    for name, integ in (('sdf_silhouette_reparam', O.SILHOUETTE), ('sdf_simple_shading_reparam', O.SIMPLE_SHADING)):
+        it = create_integrator(name, {'sdf': sdf})
+        scene = Scene([sensor], it)
+        it.warp_field = configs.get_config('warp').get_warpfield(it.sdf)
+        img = it.render(scene, 0, seed=seed, spp=spp).cpu().double()
+        ref = O.render(osdf, cam, W, H, spp, offs, integ, True)
+        e = float(torch.linalg.norm(img - ref) / torch.linalg.norm(ref))
+        # (a general rotation: the reference also marches through the corners of the world AABB outside the cube, where it
+        # reads the clamped texture -- empty space, no hits, vanishing weights)
+        assert e < (FWD_TOL if exact else 5e-4), (name, e)
+        params = traverse(scene)
+        leaf = data.cuda().clone().requires_grad_(True)
+        pl = p0.clone().requires_grad_(True)
+        params[SDF_DEFAULT_KEY], params[SDF_DEFAULT_KEY_P] = leaf, pl
+        params.update()
+        gi = case['grad_image']
+        it.render_backward(scene, params, gi.cuda(), 0, seed=seed, spp=spp)
+        d2 = data.double().clone().requires_grad_(True)
+        p2 = p0.double().clone().requires_grad_(True)
+        (O.render(O.Grid3d(d2, p2, T), cam, W, H, spp, offs, integ, True) * gi.double()).sum().backward()
+        eg = float(torch.linalg.norm(leaf.grad.cpu().double().reshape(d2.shape) - d2.grad) / torch.linalg.norm(d2.grad))
+        ep = float(torch.linalg.norm(pl.grad.double() - p2.grad) / torch.linalg.norm(p2.grad))
+        assert eg < (5e-3 if exact else 2e-2), (name, eg)
+        assert ep < (5e-3 if exact else 2e-2), (name, ep)
+    # protocol methods, world-space arguments
+    sdf.p = p0.clone()
+    gen = torch.Generator().manual_seed(1)
+    x = torch.rand(200, 3, generator=gen) * 0.5 + 0.25
+    v, _, g, _, Hm = sdf.eval_all(x.cuda())
+    vo, _, go, _, Ho = osdf.eval_all(x.double())
+    assert torch.allclose(v.cpu().double(), vo, atol=2e-6) and torch.allclose(g.cpu().double(), go, atol=2e-4)
+    assert torch.allclose(Hm.cpu().double(), Ho, atol=3e-2, rtol=1e-3)
+    o, d, maxt = cam.sample_ray(torch.rand(300, 2, generator=gen).double() * torch.tensor([W, H]), W, H)
+    out = sdf.ray_intersect(o.float().cuda(), d.float().cuda(), maxt.float().cuda(), warp=True)
+    tr = O.ray_intersect(osdf, o, d, maxt)
+    hit = torch.isfinite(tr['its_t'])
+    assert bool((torch.isfinite(out[0].cpu()) == hit).all()) or not exact
+    both = hit & torch.isfinite(out[0].cpu())
+    assert torch.allclose(out[0].cpu().double()[both], tr['its_t'][both], atol=1e-4)
+    if exact:
+        m = tr['warp_weight'] > 1e-3
+        assert torch.allclose(out[1].cpu().double()[m], tr['warp_t'][m], rtol=2e-3, atol=1e-4)
