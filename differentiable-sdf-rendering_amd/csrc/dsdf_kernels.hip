@@ -592,6 +592,7 @@ __global__ __launch_bounds__(64, DIRECT ? 1 : DSDF_BWD_MINWAVES) void k_backward
                 n_did += lane_backward_direct(G, P, A, S, L, lane, tr, trs, trb, block_adj, req, areq) ? 1 : 0;
                 // the albedo volume is small and its adjoint 24 floats per lit sample: plain atomics
                 if (areq.on && S.grad_albedo) scatter_trilinear(S.albedo, S.grad_albedo, areq.x, areq.a_bar, AtomicAdd());
+                if (areq.on && S.grad_rough && areq.r_bar != 0.f) scatter_trilinear1(S.rough, S.grad_rough, areq.x, areq.r_bar, AtomicAdd());
             } else {
                 n_did += lane_backward(G, P, A, L, tr, block_adj, req) ? 1 : 0;
             }
@@ -834,6 +835,9 @@ static ShadeArgs make_shade_args(const dsdf_shading *sh, bool with_grad) {
         S.hide_emitters = sh->hide_emitters;
         S.use_mis = sh->use_mis != 0; S.variant = sh->variant;
         S.grad_albedo = with_grad ? sh->grad_albedo : nullptr;
+        S.bsdf = sh->bsdf;
+        S.rough.data = sh->roughness; S.rough.rx = sh->rax; S.rough.ry = sh->ray; S.rough.rz = sh->raz;
+        S.grad_rough = with_grad ? sh->grad_roughness : nullptr;
     }
     return S;
 }
@@ -858,6 +862,12 @@ static int check_render_args(const float *padded, int rx, int ry, int rz, const 
         return fail(DSDF_ERR_INVALID_ARG, "sdf_direct_reparam needs a dsdf_shading with an albedo volume");
     if (integrator == DSDF_DIRECT && (shading->variant < 0 || shading->variant > 2))
         return fail(DSDF_ERR_INVALID_ARG, "dsdf_shading.variant must be 0, 1 (detach_indirect_si) or 2 (decouple_reparam)");
+    if (integrator == DSDF_DIRECT && shading->bsdf != 0) {
+        if (shading->bsdf != 1) return fail(DSDF_ERR_INVALID_ARG, "dsdf_shading.bsdf must be 0 (diffuse) or 1 (principled)");
+        if (!shading->roughness || shading->rax < 1 || shading->ray < 1 || shading->raz < 1)
+            return fail(DSDF_ERR_INVALID_ARG, "the principled BSDF needs dsdf_shading.roughness (raz,ray,rax,1)");
+        if (shading->use_mis) return fail(DSDF_ERR_INVALID_ARG, "the principled BSDF is evaluated, not sampled: use_mis must be 0");
+    }
     size_t nl = (size_t)(W + 2 * DSDF_BORDER) * (H + 2 * DSDF_BORDER) * (size_t)spp;
     // reparam.py:48-50 wavefront-size limit
     if (nl > 0x40000000ull) return fail(DSDF_ERR_INVALID_ARG, "wavefront size exceeds 0x40000000 lanes");
@@ -1292,6 +1302,8 @@ int dsdf_render_forward_grad(const float *padded, int rx, int ry, int rz, const 
     if (rc) return rc;
     if (!grad_image_out) return fail(DSDF_ERR_INVALID_ARG, "dsdf_render_forward_grad: grad_image_out is null");
     if (!tangent_padded && !tangent_p) return fail(DSDF_ERR_INVALID_ARG, "dsdf_render_forward_grad: need a tangent");
+    if (integrator == DSDF_DIRECT && shading->bsdf != 0)
+        return fail(DSDF_ERR_INVALID_ARG, "dsdf_render_forward_grad: forward mode knows the diffuse BSDF only");
     if (!offsets && !seeds) return fail(DSDF_ERR_INVALID_ARG, "dsdf_render_forward_grad: need offsets or seeds");
     const PassCtx c = make_ctx(padded, rx, ry, rz, prm, width, height, spp, offsets, seeds, integrator, flags, shading, stream);
     hipStream_t st = c.st;

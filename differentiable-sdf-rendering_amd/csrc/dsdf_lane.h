@@ -8,6 +8,7 @@
 // Dr.Jit AD; the adjoint below is derived by hand (DESIGN.md "Backward").
 #pragma once
 #include "dsdf_math.h"
+#include "dsdf_bsdf.h"
 
 namespace dsdf {
 
@@ -31,6 +32,9 @@ struct ShadeArgs {
     int use_mis;            // reparam.py:17 / sdf_direct_reparam.py:77-105: emitter sampling + BSDF sampling, power heuristic
     int variant;            // 1 = detach_indirect_si, 2 = decouple_reparam (sdf_direct_reparam.py:13-14, 44-47)
     float *grad_albedo;     // dL/d(albedo) accumulator (gradient pass) or nullptr
+    int bsdf;               // 0 `diffuse` (albedo = reflectance), 1 `principled` (albedo = base_color, plus the roughness volume)
+    AlbedoView rough;       // 'main-bsdf.roughness.volume.data' (Z,Y,X,1)
+    float *grad_rough;      // dL/d(roughness) accumulator (gradient pass) or nullptr
 };
 
 // Film block channels: value(s) + weight.  Silhouette / simple shading emit R=G=B -> one value channel.
@@ -321,11 +325,23 @@ DSDF_HD BsdfRay bsdf_setup(const ViewArgs &A, const Lane &L, uint32_t lane, cons
     return b;
 }
 
-// factors of alb * env in the two terms: emitter sampling 4 cos_o [* mis weight], BSDF sampling (wo.z / pi) / pdf * mis weight
-DSDF_HD float emitter_factor(const ShadeArgs &S, const DirectHit &h, float &we) {
+// The emitter-sampling term of a lit sample:  rgb_e,c = env_c (a_c ke + ks)  [x det_e x det].
+//   diffuse:     ke = 4 cos_o [* mis weight], ks = 0         (bsdf a / pi cos_o, emitter_val / pdf = env 4 pi)
+//   principled:  ke = 4 pi Kd, ks = 4 pi Ks  (dsdf_bsdf.h) with x = n . wi, y = n . d_s, u = wi . d_s, r = roughness(p); wi = -d
+// (the BSDF-sampling term of use_mis -- diffuse only -- has the factor (wo.z / pi) / pdf * mis weight, bsdf_factor below)
+struct EmitterTerm { float ke, ks, we; PrincipledTerms T; V3 wi; V3 rg; };
+DSDF_HD void emitter_term(const ShadeArgs &S, const DirectHit &h, V3 d, EmitterTerm &e) {
     const float cos_o = dot(h.n, h.sr.d);
-    we = S.use_mis ? mis_weight(DSDF_INV_4PI, cos_o * DSDF_INV_PI) : 1.f;
-    return 4.f * cos_o * we;
+    e.ks = 0.f; e.we = 1.f; e.wi = -d; e.rg = mk(0.f, 0.f, 0.f);
+    if (S.bsdf == 1) {
+        float r;
+        eval_trilinear1(S.rough, h.p, r, e.rg);
+        e.T = principled_terms(dot(h.n, e.wi), cos_o, dot(e.wi, h.sr.d), r);
+        e.ke = 12.566370614359172f * e.T.kd; e.ks = 12.566370614359172f * e.T.ks;
+        return;
+    }
+    e.we = S.use_mis ? mis_weight(DSDF_INV_4PI, cos_o * DSDF_INV_PI) : 1.f;
+    e.ke = 4.f * cos_o * e.we;
 }
 DSDF_HD float bsdf_factor(const BsdfRay &b) { return b.woz * DSDF_INV_PI / b.pdf * mis_weight(b.pdf, DSDF_INV_4PI); }
 
@@ -351,7 +367,7 @@ DSDF_HD int direct_value(const GridView &G, const dsdf_params &P, const ViewArgs
     dsdf_params Ps = P;
     Ps.refine_steps = 0;                                               // ray_test consumes only isfinite(its_t)
     int lit = 0;
-    float ke = 0.f, kb = 0.f;
+    float ke = 0.f, ks = 0.f, kb = 0.f;
     if (front) {
         if (diff) trace_diff(G, Ps, h.sr.o, h.sr.d, h.sr.maxt, trs);
         else {
@@ -362,7 +378,7 @@ DSDF_HD int direct_value(const GridView &G, const dsdf_params &P, const ViewArgs
             ReuseFetch F;
             trace_plain(G, Ps, h.sr.o, h.sr.d, h.sr.maxt, trs, F);
         }
-        if (!(trs.its_t < INFINITY)) { float we; ke = emitter_factor(S, h, we); lit |= 1; }
+        if (!(trs.its_t < INFINITY)) { EmitterTerm e; emitter_term(S, h, L.ray.d, e); ke = e.ke; ks = e.ks; lit |= 1; }
     }
     if (S.use_mis) {
         const BsdfRay b = bsdf_setup(A, L, lane, h);
@@ -376,7 +392,7 @@ DSDF_HD int direct_value(const GridView &G, const dsdf_params &P, const ViewArgs
     float alb[3]; V3 ag[3];
     eval_trilinear(S.albedo, h.p, alb, ag);
 #pragma unroll
-    for (int c = 0; c < 3; ++c) rgb[c] = alb[c] * ke * S.env[c] + alb[c] * kb * S.env[c];
+    for (int c = 0; c < 3; ++c) rgb[c] = (alb[c] * ke + ks) * S.env[c] + alb[c] * kb * S.env[c];
     return lit;
 }
 
@@ -384,7 +400,7 @@ DSDF_HD int direct_value(const GridView &G, const dsdf_params &P, const ViewArgs
 // p_bar: the same site's contribution to dL/d(sdf.p) -- the grid is looked up at x - p, so
 // dv = -g.dp and dg = -H dp:  p_bar = -(cv * g + H cg).
 struct ScatterReq { bool on; V3 x; float cv; V3 cg; V3 p_bar; };
-struct AlbedoReq { bool on; V3 x; float a_bar[3]; };     // 8-tap x 3-channel scatter into dL/d(albedo)
+struct AlbedoReq { bool on; V3 x; float a_bar[3]; float r_bar; };     // 8-tap x 3-channel scatter into dL/d(albedo) [+ 1 channel: roughness]
 
 // Adjoint of one gradient-pass sample.  `tr` holds the (detached) trace outputs,
 // block_adj the adjoint of the 2-channel film block.  Produces up to two scatter
@@ -516,12 +532,14 @@ DSDF_HD bool lane_backward_direct(const GridView &G, const dsdf_params &P, const
     BsdfRay br;
     br.active = false;
     int lit = 0;
-    float alb[3] = {0.f, 0.f, 0.f}; V3 ag[3]; float ke = 0.f, kb = 0.f, we = 1.f;
+    float alb[3] = {0.f, 0.f, 0.f}; V3 ag[3]; float ke = 0.f, kb = 0.f;
+    EmitterTerm et;
+    et.ke = 0.f; et.ks = 0.f; et.we = 1.f;
     if (!hit) {
         if (!S.hide_emitters) { rgb[0] = S.env[0]; rgb[1] = S.env[1]; rgb[2] = S.env[2]; }
     } else {
         const bool front = direct_setup(G, A, L, lane, tr.its_t, h);
-        if (front && !(trs.its_t < INFINITY)) { ke = emitter_factor(S, h, we); lit |= 1; }
+        if (front && !(trs.its_t < INFINITY)) { emitter_term(S, h, d, et); ke = et.ke; lit |= 1; }
         if (S.use_mis) {
             br = bsdf_setup(A, L, lane, h);
             if (br.active && !(trb.its_t < INFINITY)) { kb = bsdf_factor(br); lit |= 2; }
@@ -529,7 +547,7 @@ DSDF_HD bool lane_backward_direct(const GridView &G, const dsdf_params &P, const
         if (lit) {
             eval_trilinear(S.albedo, h.p, alb, ag);
 #pragma unroll
-            for (int c = 0; c < 3; ++c) { rgb_e[c] = alb[c] * ke * S.env[c]; rgb_b[c] = alb[c] * kb * S.env[c]; rgb[c] = rgb_e[c] + rgb_b[c]; }
+            for (int c = 0; c < 3; ++c) { rgb_e[c] = (alb[c] * ke + et.ks) * S.env[c]; rgb_b[c] = alb[c] * kb * S.env[c]; rgb[c] = rgb_e[c] + rgb_b[c]; }
         }
     }
     float a_c[3] = {0.f, 0.f, 0.f}, a_w = 0.f, u_bar = 0.f, v_bar = 0.f;
@@ -581,17 +599,31 @@ DSDF_HD bool lane_backward_direct(const GridView &G, const dsdf_params &P, const
         const float gl = sqrtf(dot(ghit, ghit));
         const V3 n = ghit * (1.f / gl);
         V3 p_bar = mk(0.f, 0.f, 0.f), p_sh = mk(0.f, 0.f, 0.f);
-        float cos_bar = 0.f, dot_e = 0.f, dot_b = 0.f;
-        areq.on = true; areq.x = h.p;
+        float cos_bar = 0.f, dot_e = 0.f, dot_b = 0.f, ke_bar = 0.f, ks_bar = 0.f;
+        areq.on = true; areq.x = h.p; areq.r_bar = 0.f;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             const float abar = S.env[c] * a_c[c] * (ke + kb);
             areq.a_bar[c] = abar;
             p_bar = fma3(abar, ag[c], p_bar);
-            if (lit & 1) cos_bar = fmaf(4.f * we * S.env[c] * a_c[c], alb[c], cos_bar);
+            if (lit & 1) {
+                cos_bar = fmaf(4.f * et.we * S.env[c] * a_c[c], alb[c], cos_bar);
+                ke_bar = fmaf(S.env[c] * a_c[c], alb[c], ke_bar); ks_bar += S.env[c] * a_c[c];
+            }
             dot_e = fmaf(rgb_e[c], a_c[c], dot_e); dot_b = fmaf(rgb_b[c], a_c[c], dot_b);
         }
-        const V3 n_bar = cos_bar * h.sr.d, sd_bar = cos_bar * n;
+        V3 n_bar = cos_bar * h.sr.d, sd_bar = cos_bar * n;
+        if (S.bsdf == 1 && (lit & 1)) {
+            // principled: ke = 4 pi Kd(x, y, u, r), ks = 4 pi Ks(x, y, u, r) with x = n . wi, y = n . d_s', u = wi . d_s', wi = -d'
+            const float fp = 12.566370614359172f;
+            const float x_bar = fp * (ke_bar * et.T.dkd[0] + ks_bar * et.T.dks[0]), y_bar = fp * (ke_bar * et.T.dkd[1] + ks_bar * et.T.dks[1]);
+            const float uu_bar = fp * (ke_bar * et.T.dkd[2] + ks_bar * et.T.dks[2]), r_bar = fp * (ke_bar * et.T.dkd[3] + ks_bar * et.T.dks[3]);
+            n_bar = x_bar * et.wi + y_bar * h.sr.d;
+            sd_bar = y_bar * n + uu_bar * et.wi;
+            dir_bar = dir_bar - (x_bar * n + uu_bar * h.sr.d);                 // wi = -d'
+            areq.r_bar = r_bar;
+            p_bar = fma3(r_bar, et.rg, p_bar);
+        }
         const V3 G_bar = (n_bar - dot(n, n_bar) * n) * (1.f / gl);
         if (A.flags & DSDF_REPARAM) {
             WarpCoef ws;
@@ -805,7 +837,7 @@ DSDF_HD bool lane_forward_tangent_direct(const GridView &G, const float *tangent
         br.active = false;
         int lit = 0;
         float ke = 0.f, kb = 0.f, we = 1.f;
-        if (front && !(trs.its_t < INFINITY)) { ke = emitter_factor(S, h, we); lit |= 1; }
+        if (front && !(trs.its_t < INFINITY)) { EmitterTerm et; emitter_term(S, h, d, et); ke = et.ke; we = et.we; lit |= 1; }   // (diffuse only: the entry point refuses principled)
         if (S.use_mis) {
             br = bsdf_setup(A, L, lane, h);
             if (br.active && !(trb.its_t < INFINITY)) { kb = bsdf_factor(br); lit |= 2; }

@@ -906,6 +906,39 @@ DSDF_HD void eval_trilinear(const AlbedoView &A, V3 p, float val[3], V3 grad[3])
                 }
             }
 }
+// the same lookup for a one-channel volume (Z,Y,X,1): the `principled` BSDF's roughness
+DSDF_HD void eval_trilinear1(const AlbedoView &A, V3 p, float &val, V3 &grad) {
+    TrilinearCell c = trilinear_cell(A, p);
+    val = 0.f;
+    grad = mk(0.f, 0.f, 0.f);
+#pragma unroll
+    for (int dz = 0; dz < 2; ++dz)
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 2; ++dx) {
+                int ix = iclamp(c.i0[0] + dx, 0, A.rx - 1), iy = iclamp(c.i0[1] + dy, 0, A.ry - 1), iz = iclamp(c.i0[2] + dz, 0, A.rz - 1);
+                float wx = dx ? c.a[0] : 1.f - c.a[0], wy = dy ? c.a[1] : 1.f - c.a[1], wz = dz ? c.a[2] : 1.f - c.a[2];
+                float sx = dx ? 1.f : -1.f, sy = dy ? 1.f : -1.f, sz = dz ? 1.f : -1.f;
+                const float t = A.data[((size_t)iz * A.ry + iy) * A.rx + ix];
+                val = fmaf(wx * wy * wz, t, val);
+                grad = fma3(t, mk(sx * wy * wz * (float)A.rx, wx * sy * wz * (float)A.ry, wx * wy * sz * (float)A.rz), grad);
+            }
+}
+template <class Adder>
+DSDF_HD void scatter_trilinear1(const AlbedoView &A, float *grad_vol, V3 p, float r_bar, Adder add) {
+    TrilinearCell c = trilinear_cell(A, p);
+#pragma unroll
+    for (int dz = 0; dz < 2; ++dz)
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 2; ++dx) {
+                int ix = iclamp(c.i0[0] + dx, 0, A.rx - 1), iy = iclamp(c.i0[1] + dy, 0, A.ry - 1), iz = iclamp(c.i0[2] + dz, 0, A.rz - 1);
+                float w = (dx ? c.a[0] : 1.f - c.a[0]) * (dy ? c.a[1] : 1.f - c.a[1]) * (dz ? c.a[2] : 1.f - c.a[2]);
+                add(grad_vol + ((size_t)iz * A.ry + iy) * A.rx + ix, w * r_bar);
+            }
+}
 template <class Adder>
 DSDF_HD void scatter_trilinear(const AlbedoView &A, float *grad_albedo, V3 p, const float a_bar[3], Adder add) {
     TrilinearCell c = trilinear_cell(A, p);

@@ -136,18 +136,24 @@ class Shading:
     BSDF's reflectance volume `albedo` (Z,Y,X,3) -- 'main-bsdf.reflectance.volume.data',
     python/opt_configs.py:286 -- and a constant environment emitter (include/dsdf.h: dsdf_shading).
     use_mis (reparam.py:17): emitter sampling + BSDF sampling with the power heuristic; detach_indirect_si /
-    decouple_reparam: the integrator properties of the same names (sdf_direct_reparam.py:13-14, 44-47)."""
+    decouple_reparam: the integrator properties of the same names (sdf_direct_reparam.py:13-14, 44-47).
+    roughness (Z,Y,X,1): switches the BSDF to `principled` at the plugin defaults -- `albedo` is then its base_color volume and
+    `roughness` 'main-bsdf.roughness.volume.data' (python/opt_configs.py:288-299); a gradient call accumulates dL/d(roughness)
+    into `grad_roughness` (a tensor shaped like roughness, set on the object) next to grad_albedo."""
 
     def __init__(self, albedo, env_radiance=(1.0, 1.0, 1.0), hide_emitters=False, use_mis=False, detach_indirect_si=False,
-                 decouple_reparam=False):
+                 decouple_reparam=False, roughness=None):
         self.albedo = albedo
+        self.roughness = roughness
+        self.grad_roughness = None
         self.env_radiance = (float(env_radiance),) * 3 if isinstance(env_radiance, (int, float)) else tuple(env_radiance)
         self.hide_emitters = bool(hide_emitters)
         self.use_mis = bool(use_mis)
         self.detach_indirect_si, self.decouple_reparam = bool(detach_indirect_si), bool(decouple_reparam)
 
     def with_albedo(self, albedo):
-        return Shading(albedo, self.env_radiance, self.hide_emitters, self.use_mis, self.detach_indirect_si, self.decouple_reparam)
+        return Shading(albedo, self.env_radiance, self.hide_emitters, self.use_mis, self.detach_indirect_si, self.decouple_reparam,
+                       self.roughness)
 
     def to_struct(self, n_views, n_lanes, emitter_samples=None, grad_albedo=None, bsdf_samples=None):
         a = self.albedo.detach()
@@ -175,6 +181,24 @@ class Shading:
                 raise _lib.DsdfError("grad_albedo must be a contiguous tensor shaped like albedo")
             _require_dev(grad_albedo, 'grad_albedo')
             st.grad_albedo = grad_albedo.data_ptr()
+        if self.roughness is not None:
+            r = self.roughness.detach()
+            if r.dim() == 3:
+                r = r[..., None]
+            if r.dim() != 4 or r.shape[3] != 1:
+                raise _lib.DsdfError(f"roughness must be (Z,Y,X,1), got {tuple(self.roughness.shape)}")
+            r = _require_dev(r, 'roughness')
+            st.bsdf = 1
+            st.roughness = r.data_ptr()
+            st.raz, st.ray, st.rax = (int(v) for v in r.shape[:3])
+            keep.append(r)
+            gr = self.grad_roughness
+            if grad_albedo is not None and gr is not None:
+                if gr.numel() != r.numel() or not gr.is_contiguous():
+                    raise _lib.DsdfError("grad_roughness must be a contiguous tensor shaped like roughness")
+                _require_dev(gr, 'grad_roughness')
+                st.grad_roughness = gr.data_ptr()
+                keep.append(gr)
         return st, keep
 
 

@@ -131,14 +131,22 @@ class ReparamIntegrator:
         sh = self.shading()
         at = sh.albedo if sh is not None else None
         want_a = isinstance(at, torch.Tensor) and at.requires_grad
+        rt = sh.roughness if sh is not None else None
+        want_r = isinstance(rt, torch.Tensor) and rt.requires_grad
+        if want_r and not want_a:                                       # (the library scatters both volumes in one gradient call)
+            want_a = True
         ga = torch.zeros_like(at.detach(), dtype=torch.float32).contiguous() if want_a else None
+        if want_r:
+            sh.grad_roughness = torch.zeros_like(rt.detach(), dtype=torch.float32).contiguous()
         g = dsdf.render_backward(self.sdf.grid, sens, spp or 4, grad_in.reshape(len(sens), *grad_in.shape[-3:]).contiguous(),
                                  seeds=[seed + i for i in range(len(sens))], integrator=self.integrator_id, reparam=reparam,
                                  grad_p=gp, shading=sh, grad_albedo=ga)
         g = g.reshape(data.shape)
         data.grad = g if data.grad is None else data.grad + g
-        if want_a:
+        if want_a and at.requires_grad:
             at.grad = ga if at.grad is None else at.grad + ga
+        if want_r:
+            rt.grad = sh.grad_roughness if rt.grad is None else rt.grad + sh.grad_roughness
         if want_p:
             gp = self.sdf.to_world_covectors(gp[None])[0].to(device=pt.device, dtype=pt.dtype).reshape(pt.shape)
             pt.grad = gp if pt.grad is None else pt.grad + gp
@@ -183,7 +191,7 @@ class ReparamIntegrator:
 
 class _RenderOp(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, data, albedo, scene, sensors, seed, spp, seed_grad, spp_grad):
+    def forward(ctx, data, albedo, roughness, scene, sensors, seed, spp, seed_grad, spp_grad):
         integ = scene.integrator()
         ctx.args = (scene, sensors, seed_grad, spp_grad, data.shape)
         integ.sdf.set_data(data.detach())
@@ -196,12 +204,16 @@ class _RenderOp(torch.autograd.Function):
         scene, sensors, seed_grad, spp_grad, shape = ctx.args
         integ = scene.integrator()
         sh = integ.shading()
-        want_a = sh is not None and ctx.needs_input_grad[1]
+        want_r = sh is not None and sh.roughness is not None and ctx.needs_input_grad[2]
+        want_a = sh is not None and (ctx.needs_input_grad[1] or want_r)
         ga = torch.zeros_like(sh.albedo.detach(), dtype=torch.float32).contiguous() if want_a else None
+        if want_r:
+            sh.grad_roughness = torch.zeros_like(sh.roughness.detach(), dtype=torch.float32).contiguous()
         g = dsdf.render_backward(integ.sdf.grid, sensors, spp_grad, grad_out.contiguous(),
                                  seeds=[seed_grad + i for i in range(len(sensors))], integrator=integ.integrator_id,
                                  reparam=integ._configured(), shading=sh, grad_albedo=ga)
-        return g.reshape(shape) if ctx.needs_input_grad[0] else None, ga, None, None, None, None, None, None
+        return (g.reshape(shape) if ctx.needs_input_grad[0] else None, ga if ctx.needs_input_grad[1] else None,
+                sh.grad_roughness.reshape(sh.roughness.shape) if want_r else None, None, None, None, None, None, None)
 
 
 def render(scene, params=None, sensor=0, seed=0, spp=4, seed_grad=0, spp_grad=None, integrator=None):
@@ -214,9 +226,11 @@ def render(scene, params=None, sensor=0, seed=0, spp=4, seed_grad=0, spp_grad=No
     data = params[SDF_DEFAULT_KEY] if params is not None and SDF_DEFAULT_KEY in params else None
     sh = integ.shading()
     albedo = sh.albedo if sh is not None else None
-    attached = (data is not None and data.requires_grad) or (isinstance(albedo, torch.Tensor) and albedo.requires_grad)
+    rough = sh.roughness if sh is not None else None
+    attached = (data is not None and data.requires_grad) or (isinstance(albedo, torch.Tensor) and albedo.requires_grad) \
+        or (isinstance(rough, torch.Tensor) and rough.requires_grad)
     if data is not None and attached and torch.is_grad_enabled():
-        img = _RenderOp.apply(data, albedo, scene, sens, int(seed), int(spp), int(seed_grad), int(spp_grad or spp))
+        img = _RenderOp.apply(data, albedo, rough, scene, sens, int(seed), int(spp), int(seed_grad), int(spp_grad or spp))
     else:
         with torch.no_grad():
             if data is not None:

@@ -4,7 +4,9 @@ configs (python/configs.py:17): direct illumination by emitter sampling through 
 The reference reads BSDF and emitter from scene files that are not part of its repository; here they are
 fixed as a Mitsuba `diffuse` BSDF over a trilinear reflectance volume -- the optimised parameter
 'main-bsdf.reflectance.volume.data' (python/opt_configs.py:286) -- and a `constant` environment emitter
-(include/dsdf.h: dsdf_shading).  Properties as in the reference: `hide_emitters`, `use_mis` (BSDF sampling + power heuristic,
+(include/dsdf.h: dsdf_shading).  With a `roughness` (or `base_color`) property the BSDF is Mitsuba's `principled` at the plugin
+defaults instead, and the published parameters are 'main-bsdf.base_color.volume.data' / 'main-bsdf.roughness.volume.data'
+(the principled-* configs, python/opt_configs.py:288-299).  Properties as in the reference: `hide_emitters`, `use_mis` (BSDF sampling + power heuristic,
 sdf_direct_reparam.py:77-105; read by the base class, reparam.py:17), `detach_indirect_si`, `decouple_reparam` (:13-14, 44-47)."""
 import torch
 
@@ -14,6 +16,8 @@ from util import default_device
 from .reparam import ReparamIntegrator, register_integrator
 
 REFLECTANCE_KEY = 'main-bsdf.reflectance.volume.data'
+BASE_COLOR_KEY = 'main-bsdf.base_color.volume.data'
+ROUGHNESS_KEY = 'main-bsdf.roughness.volume.data'
 
 
 class SdfDirectReparamIntegrator(ReparamIntegrator):
@@ -27,22 +31,38 @@ class SdfDirectReparamIntegrator(ReparamIntegrator):
         self.decouple_reparam = bool(props.get('decouple_reparam', False))      # sdf_direct_reparam.py:14
         self.hide_emitters = bool(props.get('hide_emitters', False))          # sdf_direct_reparam.py:12
         self.env_radiance = props.get('env_radiance', 1.0)
-        refl = props.get('reflectance', 0.5)
+        self.principled = 'roughness' in props or 'base_color' in props
+        refl = props.get('base_color', 0.5) if self.principled else props.get('reflectance', 0.5)
         if not isinstance(refl, torch.Tensor):
             refl = torch.full((16, 16, 16, 3), float(refl), device=default_device())
-        self.reflectance = refl
+        self.reflectance = refl                                             # diffuse: reflectance; principled: base_color
+        self.roughness = None
+        if self.principled:
+            if self.use_mis:
+                raise NotImplementedError("the principled BSDF is evaluated, not sampled: use_mis is not available with it")
+            rough = props.get('roughness', 0.5)
+            if not isinstance(rough, torch.Tensor):
+                rough = torch.full((16, 16, 16, 1), float(rough), device=default_device())
+            self.roughness = rough
 
     def shading(self):
         return dsdf.Shading(self.reflectance, self.env_radiance, self.hide_emitters, self.use_mis, self.detach_indirect_si,
-                            self.decouple_reparam)
+                            self.decouple_reparam, self.roughness)
 
     def traverse(self, cb):
         super().traverse(cb)
-        cb.put_scene_parameter(REFLECTANCE_KEY, self.reflectance)
+        if self.principled:
+            cb.put_scene_parameter(BASE_COLOR_KEY, self.reflectance)
+            cb.put_scene_parameter(ROUGHNESS_KEY, self.roughness)
+        else:
+            cb.put_scene_parameter(REFLECTANCE_KEY, self.reflectance)
 
     def scene_parameters_changed(self, params):
-        if REFLECTANCE_KEY in params:
-            self.reflectance = params[REFLECTANCE_KEY]
+        key = BASE_COLOR_KEY if self.principled else REFLECTANCE_KEY
+        if key in params:
+            self.reflectance = params[key]
+        if self.principled and ROUGHNESS_KEY in params:
+            self.roughness = params[ROUGHNESS_KEY]
 
     def to_string(self):
         return 'SdfDirectReparamIntegrator'

@@ -34,7 +34,11 @@ def render_reference_images(scene_config, config, ref_spp=1024, force=False, ver
             target = load_target_sdf(scene_config.scene, res=max(128, 2 * 64))
             props = {'sdf': Grid3d(target)}
             if config.integrator == 'sdf_direct_reparam':
-                props['reflectance'] = load_target_albedo(scene_config.scene)
+                if any(k.endswith('roughness.volume.data') for k in scene_config.param_keys):    # principled-* configs
+                    props['base_color'] = load_target_albedo(scene_config.scene)
+                    props['roughness'] = 0.4
+                else:
+                    props['reflectance'] = load_target_albedo(scene_config.scene)
             scene = Scene(scene_config.sensors, create_integrator(config.integrator, props))
         with torch.no_grad():
             # 64-sample waves: round the reference spp up to a multiple of 64

@@ -35,7 +35,10 @@ def load_ref_images(paths, multiscale=False, device='cuda'):
 def build_scene(scene_config, config, device='cuda'):
     """Stands in for mi.load_file(scene.xml, shape_file='dummysdf.xml', sdf_filename=..., integrator=...)."""
     init = create_sphere_sdf([16, 16, 16], device=device)
-    integ = create_integrator(config.integrator, {'sdf': Grid3d(init)})
+    props = {'sdf': Grid3d(init)}
+    if any(k.endswith('roughness.volume.data') or k.endswith('base_color.volume.data') for k in scene_config.param_keys):
+        props.update(base_color=0.5, roughness=0.5)                    # principled-* configs: the scene's BSDF is `principled`
+    integ = create_integrator(config.integrator, props)
     return Scene(scene_config.sensors, integ)
 
 
@@ -52,7 +55,7 @@ def optimize_shape(scene_config, mts_args, ref_image_paths, output_dir, config, 
     missing = [k for k in scene_config.param_keys if k not in params]
     if missing:
         raise NotImplementedError(f"parameters {missing} are not published by integrator '{config.integrator}' "
-                                  f"(reflectance volumes need sdf_direct_reparam; base_color/roughness are unsupported)")
+                                  f"(reflectance / base_color / roughness volumes need sdf_direct_reparam)")
     opt = Adam(lr=config.learning_rate, params=params, mask_updates=config.mask_optimizer)
     n_iter = config.n_iter
     scene_config.initialize(opt, sdf_scene)

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define DSDF_VERSION 301   /* 300: stats rows of DSDF_STAT_SLOTS (16) counters; tail hand-off on library-owned helper streams */
+#define DSDF_VERSION 302   /* 300: stats rows of DSDF_STAT_SLOTS (16) counters; tail hand-off on library-owned helper streams */
 #define DSDF_STAT_SLOTS 16
 
 enum dsdf_status {
@@ -100,6 +100,12 @@ typedef struct dsdf_shading {
                                      2 = decouple_reparam */
     const float *bsdf_samples;    /* device, like emitter_samples: the lane's `next_2d()` of bsdf.sample (sdf_direct_reparam.py:90-91),
                                      or NULL for the built-in sampler; only read when use_mis */
+    int   bsdf;                   /* 0 = `diffuse` (albedo is its reflectance volume), 1 = `principled` with every parameter at the plugin
+                                     default except base_color (= albedo) and roughness (below): the principled-* configs,
+                                     python/opt_configs.py:288-299.  Emitter sampling only (use_mis must be 0), no forward mode */
+    const float *roughness;       /* device, (rz_,ry_,rx_,1) fp32: 'main-bsdf.roughness.volume.data'; read when bsdf == 1 */
+    int   rax, ray, raz;
+    float *grad_roughness;        /* device, like roughness: dL/d(roughness) accumulator of dsdf_render_backward, or NULL */
 } dsdf_shading;
 
 int         dsdf_version(void);

@@ -555,13 +555,90 @@ def warped_ray(sdf, o, d, maxt, reparam):
     return tr['its_t'], d_att, det
 
 
+# --------------------------------------------------------------------------
+# `principled` BSDF (configs principled-*: opt_configs.py:288-299 optimise 'main-bsdf.base_color.volume.data' and
+# 'main-bsdf.roughness.volume.data', variables.py:118-121 clamps them).  The plugin is THIRD-PARTY and absent from
+# /root/reference: Mitsuba 3 (pip `mitsuba`, unpinned in the reference's README) src/bsdfs/principled.cpp with
+# principled_helpers.h, microfacet.h, fresnel.h -- restated here from the published algorithm [3P-mem], PARITY UNPINNED.
+# The reference's scene files are not shipped either, so the parameters the configs do not optimise are fixed at the plugin's
+# defaults as this repo's spec: metallic 0, specular 0.5 (eta = 1.5), spec_tint 0, spec_trans 0, anisotropic 0, sheen 0,
+# clearcoat 0, flatness 0.  Only the lobes that survive those defaults are restated: diffuse + retro-reflection and the main
+# specular reflection (GGX, separable Smith, dielectric Fresnel).
+# --------------------------------------------------------------------------
+PRINCIPLED_ETA = 2.0 / (1.0 - math.sqrt(0.08 * 0.5)) - 1.0     # principled.cpp: m_eta from specular = 0.5 -> 1.5
+
+
+def fresnel_dielectric(cos_theta_i, eta):
+    """mitsuba fresnel.h `fresnel(cos_theta_i, eta)` -> F (unpolarised)."""
+    outside = cos_theta_i >= 0
+    rcp_eta = 1.0 / eta
+    eta_it = torch.where(outside, torch.full_like(cos_theta_i, eta), torch.full_like(cos_theta_i, rcp_eta))
+    eta_ti = torch.where(outside, torch.full_like(cos_theta_i, rcp_eta), torch.full_like(cos_theta_i, eta))
+    cos_theta_t_sqr = 1.0 - (1.0 - cos_theta_i * cos_theta_i) * eta_ti * eta_ti
+    ci = cos_theta_i.abs()
+    ct = torch.sqrt(torch.clamp(cos_theta_t_sqr, min=0.0))
+    a_s = (ci - eta_it * ct) / (ci + eta_it * ct)
+    a_p = (ct - eta_it * ci) / (ct + eta_it * ci)
+    r = 0.5 * (a_s * a_s + a_p * a_p)
+    return torch.where(ci == 0, torch.ones_like(r), r)
+
+
+def ggx_eval(m, alpha_u, alpha_v):
+    """microfacet.h MicrofacetDistribution(GGX).eval(m)."""
+    res = 1.0 / (math.pi * alpha_u * alpha_v * ((m[:, 0] / alpha_u) ** 2 + (m[:, 1] / alpha_v) ** 2 + m[:, 2] ** 2) ** 2)
+    return torch.where(res * m[:, 2] > 1e-20, res, torch.zeros_like(res))
+
+
+def ggx_smith_g1(v, m, alpha_u, alpha_v):
+    """microfacet.h smith_g1(v, m), GGX."""
+    xy_alpha_2 = (alpha_u * v[:, 0]) ** 2 + (alpha_v * v[:, 1]) ** 2
+    tan_theta_alpha_2 = xy_alpha_2 / (v[:, 2] ** 2)
+    res = 2.0 / (1.0 + torch.sqrt(1.0 + tan_theta_alpha_2))
+    res = torch.where(xy_alpha_2 == 0, torch.ones_like(res), res)
+    return torch.where(dot(v, m) * v[:, 2] <= 0, torch.zeros_like(res), res)
+
+
+def principled_eval(base_color, roughness, wi, wo):
+    """principled.cpp Principled::eval for local directions wi, wo (N,3), base_color (N,3), roughness (N,) with the defaults
+    above -> bsdf value x |cos theta_o| (N,3)."""
+    cos_theta_i, cos_theta_o = wi[:, 2], wo[:, 2]
+    active = cos_theta_i > 0                                           # no transmission: the back side is black
+    reflect = cos_theta_i * cos_theta_o > 0
+    front_side = cos_theta_i > 0
+    a = torch.clamp(roughness * roughness, min=0.001)                  # calc_dist_params without anisotropy
+    wh = wi + wo                                                        # reflect: eta-free halfway vector
+    wh = wh / torch.linalg.norm(wh, dim=-1, keepdim=True)
+    wh = wh * torch.where(wh[:, 2:3] >= 0, torch.ones_like(wh[:, 2:3]), -torch.ones_like(wh[:, 2:3]))   # mulsign(wh, cos_theta(wh))
+    F = fresnel_dielectric(dot(wi, wh), PRINCIPLED_ETA)                 # principled_fresnel: metallic 0, spec_tint 0, front side
+    compat = (dot(wi, wh) * cos_theta_i > 0) & (dot(wo, wh) * cos_theta_o > 0)       # mac_mic_compatibility
+    spec_active = active & reflect & compat & (F > 0)
+    diffuse_active = active & reflect & front_side
+    D = ggx_eval(wh, a, a)
+    Gs = ggx_smith_g1(wi, wh, a, a) * ggx_smith_g1(wo, wh, a, a)
+    value = torch.zeros_like(base_color)
+    spec = F * D * Gs / (4.0 * cos_theta_i.abs())
+    value = value + torch.where(spec_active, spec, torch.zeros_like(spec))[:, None]
+    Fo = (1.0 - cos_theta_o.abs()) ** 5                                 # schlick_weight
+    Fi = (1.0 - cos_theta_i.abs()) ** 5
+    f_diff = (1.0 - 0.5 * Fi) * (1.0 - 0.5 * Fo)
+    cos_theta_d = dot(wh, wo)
+    Rr = 2.0 * roughness * cos_theta_d * cos_theta_d
+    f_retro = Rr * (Fo + Fi + Fo * Fi * (Rr - 1.0))
+    diff = (cos_theta_o.abs() * (1.0 / math.pi) * (f_diff + f_retro))[:, None] * base_color
+    return value + torch.where(diffuse_active[:, None], diff, torch.zeros_like(diff))
+
+
 def direct_radiance(sdf, albedo, o, d_att, its_t, emitter_u, reparam, env=1.0, hide_emitters=False, use_mis=False,
-                    bsdf_u=None, detach_indirect_si=False, decouple_reparam=False, d_det=None):
+                    bsdf_u=None, detach_indirect_si=False, decouple_reparam=False, d_det=None, roughness=None):
     """sdf_direct_reparam.py:29-105 for the hit lanes + the environment term of the others (without the
     primary determinant, which the caller multiplies in).  -> rgb (N,3).
     use_mis: emitter sampling weighted by the power heuristic plus the BSDF-sampling branch (:77-105) with `bsdf_u` (N,2) as
     its next_2d() (the next_1d() before it selects a lobe: unused by `diffuse`).  detach_indirect_si / decouple_reparam
-    (:44-47): the shadow ray starts from the detached hit / from the hit of the un-warped ray (si_d0)."""
+    (:44-47): the shadow ray starts from the detached hit / from the hit of the un-warped ray (si_d0).
+    roughness: a (Z,Y,X,1) volume switches the BSDF from `diffuse` (albedo = reflectance) to `principled` (albedo = base_color);
+    emitter sampling only."""
+    if roughness is not None and use_mis:
+        raise NotImplementedError("principled + use_mis: Principled::sample is not restated")
     N = o.shape[0]
     dt = o.dtype
     hit = torch.isfinite(its_t)
@@ -593,7 +670,15 @@ def direct_radiance(sdf, albedo, o, d_att, its_t, emitter_u, reparam, env=1.0, h
         vis = (~torch.isfinite(s_t)).to(dt)
         cos_o = dot(n[fsel], sd_att)                                    # wo = si.to_local(shadow_ray.d)
         a = eval_trilinear(albedo, p[fsel])                           # reflectance volume lives on the unit cube
-        bsdf = a * (cos_o / math.pi)[:, None]
+        if roughness is None:
+            bsdf = a * (cos_o / math.pi)[:, None]
+        else:                                                           # bsdf.eval(ctx, si, wo): si.wi = to_local(-ray.d), wo = to_local(shadow_ray.d)
+            nf = n[fsel]
+            sf, tf = coordinate_system(nf)
+            wi_w = -dh[fsel]
+            wi_l = torch.stack([dot(sf, wi_w), dot(tf, wi_w), dot(nf, wi_w)], -1)
+            wo_l = torch.stack([dot(sf, sd_att), dot(tf, sd_att), dot(nf, sd_att)], -1)
+            bsdf = principled_eval(a, eval_trilinear(roughness, p[fsel])[:, 0], wi_l, wo_l)
         contrib = bsdf * (env * 4.0 * math.pi) * (vis * det_e)[:, None]   # emitter_val / ds.pdf ; * det_e (:84)
         if use_mis:                                                     # :78-79 mis_weight(ds.pdf, detach(bsdf_pdf))
             contrib = contrib * mis_weight(torch.full_like(cos_o, inv_4pi), (cos_o / math.pi).detach())[:, None]
@@ -857,7 +942,8 @@ def lane_positions(W, H, spp, offsets):
 
 def render(sdf, cam, W, H, spp, offsets, integrator=SILHOUETTE, reparam=True,
            return_aux=False, chunk=1 << 17, albedo=None, emitter_u=None, env=1.0, hide_emitters=False, rows=None,
-           return_block=False, use_mis=False, bsdf_u=None, detach_indirect_si=False, decouple_reparam=False, light_dir=None):
+           return_block=False, use_mis=False, bsdf_u=None, detach_indirect_si=False, decouple_reparam=False, light_dir=None,
+           roughness=None):
     """One view.  offsets: (Wb*Hb*spp, 2) in [0,1) (the sampler's next_2d per
     lane).  Returns image (H,W,3), differentiable w.r.t. sdf.data / sdf.p when
     they require grad.  `reparam=False` gives the DummyWarpField path
@@ -905,7 +991,7 @@ def render(sdf, cam, W, H, spp, offsets, integrator=SILHOUETTE, reparam=True,
                 aux['warp_active'] += int(keep.numel())
         if integrator == DIRECT:                                         # sdf_direct_reparam.py:16-111
             rgb = direct_radiance(sdf, albedo, o, d_att, its_t, emitter_u[s:s + chunk], reparam, env, hide_emitters, use_mis,
-                                  None if bsdf_u is None else bsdf_u[s:s + chunk], detach_indirect_si, decouple_reparam, d) * div[:, None]
+                                  None if bsdf_u is None else bsdf_u[s:s + chunk], detach_indirect_si, decouple_reparam, d, roughness) * div[:, None]
         elif integrator == SILHOUETTE:                                   # sdf_silhouette_reparam.py:20-22
             val = hit.to(dt) * div
         else:                                                            # sdf_simple_shading_reparam.py:20-22

@@ -136,7 +136,8 @@ class HostHarness:
         return out
 
     def render_direct_forward(self, grid, cam, W, H, spp, offsets, emitter_u, albedo, env=(1.0, 1.0, 1.0), hide_emitters=False,
-                              reparam=True, diff=False, seed=0, bsdf_u=None, use_mis=None, variant=0):
+                              reparam=True, diff=False, seed=0, bsdf_u=None, use_mis=None, variant=0, roughness=None):
+        self._principled(roughness)
         grid = np.ascontiguousarray(grid, np.float32)
         offsets = None if offsets is None else np.ascontiguousarray(offsets, np.float32)
         emitter_u = None if emitter_u is None else np.ascontiguousarray(emitter_u, np.float32)
@@ -150,10 +151,12 @@ class HostHarness:
                                           self._p(albedo), ax, ay, az, self._p(env), int(hide_emitters), self._p(img),
                                           int(bsdf_u is not None if use_mis is None else use_mis),
                                           self._p(None if bsdf_u is None else np.ascontiguousarray(bsdf_u, np.float32)), int(variant))
+        self._principled(None)
         return img
 
     def render_direct_backward(self, grid, cam, W, H, spp, offsets, emitter_u, albedo, grad_image, env=(1.0, 1.0, 1.0),
-                               hide_emitters=False, reparam=True, seed=0, bsdf_u=None, use_mis=None, variant=0):
+                               hide_emitters=False, reparam=True, seed=0, bsdf_u=None, use_mis=None, variant=0, roughness=None):
+        self._principled(roughness, with_grad=True)
         grid = np.ascontiguousarray(grid, np.float32)
         offsets = None if offsets is None else np.ascontiguousarray(offsets, np.float32)
         emitter_u = None if emitter_u is None else np.ascontiguousarray(emitter_u, np.float32)
@@ -172,6 +175,8 @@ class HostHarness:
                                            self._p(gg), self._p(ga), self._p(gp), self._p(img),
                                            int(bsdf_u is not None if use_mis is None else use_mis),
                                            self._p(None if bsdf_u is None else np.ascontiguousarray(bsdf_u, np.float32)), int(variant))
+        self.last_grad_roughness = self._grad_rough
+        self._principled(None)
         return gg, ga, gp, img
 
     def render_direct_forward_grad(self, grid, cam, W, H, spp, offsets, emitter_u, albedo, env=(1.0, 1.0, 1.0), hide_emitters=False,
@@ -191,6 +196,22 @@ class HostHarness:
                                                self._p(offsets), self._p(emitter_u), C.c_uint(seed), int(reparam), self._p(albedo), ax, ay, az,
                                                self._p(env), int(hide_emitters), int(bu is not None), self._p(bu), int(variant),
                                                self._p(t), self._p(tp), self._p(out))
+        return out
+
+    def _principled(self, roughness, with_grad=False):
+        """roughness (Z,Y,X[,1]) switches the next hh_render_direct_* call to the principled BSDF (None: diffuse)."""
+        self._rough = None if roughness is None else np.ascontiguousarray(roughness, np.float32)
+        self._grad_rough = np.zeros(self._rough.shape, np.float32) if (with_grad and self._rough is not None) else None
+        if self._rough is None:
+            self.lib.hh_set_principled(None, 0, 0, 0, None)
+        else:
+            raz, ray, rax = self._rough.shape[:3]
+            self.lib.hh_set_principled(self._p(self._rough), rax, ray, raz, self._p(self._grad_rough))
+
+    def principled_terms(self, xyur):
+        xyur = np.ascontiguousarray(xyur, np.float32)
+        out = np.zeros((xyur.shape[0], 10), np.float32)
+        self.lib.hh_principled_terms(C.c_long(xyur.shape[0]), self._p(xyur), self._p(out))
         return out
 
     def sampler_bsdf(self, seed, n):

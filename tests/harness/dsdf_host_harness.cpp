@@ -245,11 +245,31 @@ void hh_render_forward_grad(const float *data, int rx, int ry, int rz, const dsd
 }
 
 // ---- sdf_direct_reparam (4-channel film block) -----------------------------------------------
+// principled BSDF: the roughness volume of the next hh_render_direct_* calls (null = diffuse)
+static const float *g_rough = nullptr;
+static int g_rough_dims[3] = {0, 0, 0};
+static float *g_grad_rough = nullptr;
+void hh_set_principled(const float *rough, int rax, int ray, int raz, float *grad_rough) {
+    g_rough = rough; g_rough_dims[0] = rax; g_rough_dims[1] = ray; g_rough_dims[2] = raz; g_grad_rough = grad_rough;
+}
+// Kd, Ks and their partials w.r.t. (x, y, u, r) -> out[10] = kd, ks, dkd[4], dks[4]
+void hh_principled_terms(long n, const float *xyur, float *out) {
+    for (long i = 0; i < n; ++i) {
+        PrincipledTerms T = principled_terms(xyur[4 * i], xyur[4 * i + 1], xyur[4 * i + 2], xyur[4 * i + 3]);
+        float *o = out + 10 * i;
+        o[0] = T.kd; o[1] = T.ks;
+        for (int k = 0; k < 4; ++k) { o[2 + k] = T.dkd[k]; o[6 + k] = T.dks[k]; }
+    }
+}
+
 static ShadeArgs shade_args(const float *albedo, int ax, int ay, int az, const float *env, int hide, float *grad_albedo) {
     ShadeArgs S;
     S.albedo.data = albedo; S.albedo.rx = ax; S.albedo.ry = ay; S.albedo.rz = az;
     S.env[0] = env[0]; S.env[1] = env[1]; S.env[2] = env[2];
     S.hide_emitters = hide; S.grad_albedo = grad_albedo; S.use_mis = 0; S.variant = 0;
+    S.bsdf = g_rough ? 1 : 0;
+    S.rough.data = g_rough; S.rough.rx = g_rough_dims[0]; S.rough.ry = g_rough_dims[1]; S.rough.rz = g_rough_dims[2];
+    S.grad_rough = g_grad_rough;
     return S;
 }
 
@@ -335,6 +355,7 @@ void hh_render_direct_backward(const float *data, int rx, int ry, int rz, const 
                 if (grad_p) { grad_p[0] += req[r].p_bar.x; grad_p[1] += req[r].p_bar.y; grad_p[2] += req[r].p_bar.z; }
             }
         if (areq.on && grad_albedo) scatter_trilinear(S.albedo, grad_albedo, areq.x, areq.a_bar, PlainAdd());
+        if (areq.on && S.grad_rough && areq.r_bar != 0.f) scatter_trilinear1(S.rough, S.grad_rough, areq.x, areq.r_bar, PlainAdd());
     }
 }
 

@@ -1,0 +1,137 @@
+"""GPU parity of the `principled` BSDF path of sdf_direct_reparam (principled-* configs,
+/root/reference/python/opt_configs.py:288-299; base_color + roughness volumes) through the C-ABI against the oracle's
+restatement of Mitsuba's plugin (oracle/sdf_oracle.py principled_eval; third-party, PARITY UNPINNED) and its autograd.
+"""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+import sdf_oracle as O
+from cases import make_case
+import precision as P
+from conftest import rel_l2
+from test_principled_host import _oracle, _principled_inputs
+
+pytestmark = pytest.mark.gpu
+
+FWD_TOL = 1e-4
+
+
+@pytest.fixture(scope='module')
+def dsdf(built):
+    import dsdf as m
+    m.load()
+    assert torch.cuda.is_available()
+    return m
+
+
+def setup(dsdf, case, ex):
+    grid = dsdf.SdfGrid(case['grid'].float().cuda())
+    sen = dsdf.get_regular_cameras(case['ncam'], resx=case['W'], resy=case['H'])[case['icam']]
+    sh = dsdf.Shading(ex['albedo'].cuda(), ex['env'], roughness=ex['roughness'].cuda())
+    return grid, sen, sh
+
+
+@pytest.mark.parametrize('name', ['sphere16', 'blob32', 'blob32_spp64', 'blob48_rect'])
+def test_principled_forward_gpu(dsdf, name):
+    case = make_case(name)
+    ex = _principled_inputs(case)
+    ref = _oracle(case, ex, torch.float64, reparam=False, grads=False)
+    grid, sen, sh = setup(dsdf, case, ex)
+    for skip in (True, False):
+        img = dsdf.render_forward(grid, sen, case['spp'], offsets=case['offsets'].cuda(), integrator='sdf_direct_reparam',
+                                  shading=sh, emitter_samples=ex['emitter_u'].cuda(), empty_space_skip=skip)[0]
+        assert rel_l2(img.cpu(), ref) < FWD_TOL
+
+
+@pytest.mark.parametrize('name', ['sphere16', 'blob32', 'blob32_spp64', 'blob48_rect'])
+@pytest.mark.parametrize('reparam', [True, False])
+def test_principled_backward_gpu(dsdf, name, reparam):
+    case = make_case(name)
+    ex = _principled_inputs(case)
+    (img_ref, gd, ga, gr), tols = P.torch_gate(lambda dt: _oracle(case, ex, dt, reparam=reparam))
+    grid, sen, sh = setup(dsdf, case, ex)
+    galb = torch.zeros_like(sh.albedo)
+    sh.grad_roughness = torch.zeros_like(sh.roughness)
+    gg, img = dsdf.render_backward(grid, sen, case['spp'], case['grad_image'].cuda()[None], offsets=case['offsets'].cuda(),
+                                   integrator='sdf_direct_reparam', reparam=reparam, return_image=True, shading=sh,
+                                   emitter_samples=ex['emitter_u'].cuda(), grad_albedo=galb)
+    assert rel_l2(img[0].cpu(), img_ref) < FWD_TOL
+    assert torch.isfinite(gg).all() and torch.isfinite(galb).all() and torch.isfinite(sh.grad_roughness).all()
+    ea, er = rel_l2(galb.cpu(), ga), rel_l2(sh.grad_roughness.cpu(), gr)
+    P.record('grad_principled', case=name, reparam=reparam, err_base_color=ea, err_roughness=er, tol_base_color=tols[2], tol_roughness=tols[3])
+    assert ea < tols[2], (ea, tols[2])
+    assert er < tols[3], (er, tols[3])
+    if reparam or float(np.abs(gd).max()) > 0:
+        ed = rel_l2(gg.cpu(), gd)
+        assert ed < tols[1], (ed, tols[1])
+
+
+def test_principled_rejections(dsdf):
+    case = make_case('sphere16')
+    ex = _principled_inputs(case)
+    grid, sen, _ = setup(dsdf, case, ex)
+    sh = dsdf.Shading(ex['albedo'].cuda(), ex['env'], use_mis=True, roughness=ex['roughness'].cuda())
+    with pytest.raises(dsdf.DsdfError):
+        dsdf.render_forward(grid, sen, 4, seeds=[1], integrator='sdf_direct_reparam', shading=sh)
+    sh = dsdf.Shading(ex['albedo'].cuda(), ex['env'], roughness=ex['roughness'].cuda())
+    with pytest.raises(dsdf.DsdfError):
+        dsdf.render_forward_grad(grid, sen, 4, tangent_p=torch.tensor([1.0, 0.0, 0.0]), seeds=[1], integrator='sdf_direct_reparam',
+                                 shading=sh)
+
+
+def test_principled_plugin_and_render_op(dsdf):
+    """The plugin with a `roughness` property publishes base_color / roughness (the keys python/opt_configs.py:291 optimises) and
+    its render op attaches sdf.data and both volumes."""
+    import configs
+    import shapes
+    from constants import SDF_DEFAULT_KEY
+    from integrators.reparam import Scene, create_integrator, render, traverse
+    from integrators.sdf_direct_reparam import BASE_COLOR_KEY, ROUGHNESS_KEY
+    data = O.blob_grid(32, n=6, seed=1).float().cuda()
+    base = torch.rand(8, 8, 8, 3, device='cuda') * 0.6 + 0.2
+    rough = torch.rand(4, 4, 4, 1, device='cuda') * 0.7 + 0.1
+    sens = dsdf.get_regular_cameras(3, resx=24, resy=24)
+    integ = create_integrator('sdf_direct_reparam', {'sdf': shapes.Grid3d(data.clone()), 'base_color': base, 'roughness': rough,
+                                                     'hide_emitters': True})
+    scene = Scene(sens, integ)
+    integ.warp_field = configs.get_config('warp').get_warpfield(integ.sdf)
+    params = traverse(scene)
+    assert set(params) == {SDF_DEFAULT_KEY, 'SamplingIntegrator.sdf.p', BASE_COLOR_KEY, ROUGHNESS_KEY}
+    sh = dsdf.Shading(base, 1.0, hide_emitters=True, roughness=rough)
+    img = integ.render(scene, sensor=1, seed=5, spp=64)
+    ref = dsdf.render_forward(dsdf.SdfGrid(data), sens[1], 64, seeds=[5], integrator='sdf_direct_reparam', shading=sh)[0]
+    assert rel_l2(img.cpu(), ref.cpu()) < 1e-6
+    p = params[SDF_DEFAULT_KEY].clone().requires_grad_(True)
+    a, r = base.clone().requires_grad_(True), rough.clone().requires_grad_(True)
+    params[SDF_DEFAULT_KEY], params[BASE_COLOR_KEY], params[ROUGHNESS_KEY] = p, a, r
+    params.update()
+    out = render(scene, params, sensor=[sens[0], sens[2]], seed=3, spp=64, seed_grad=9, spp_grad=64)
+    out.sum().backward()
+    ga = torch.zeros_like(base)
+    sh.grad_roughness = torch.zeros_like(rough)
+    gref = dsdf.render_backward(dsdf.SdfGrid(data), [sens[0], sens[2]], 64, torch.ones(2, 24, 24, 3, device='cuda'),
+                                seeds=[9, 10], integrator='sdf_direct_reparam', shading=sh, grad_albedo=ga)
+    assert rel_l2(p.grad[..., 0].cpu(), gref.cpu()) < 1e-5 and rel_l2(a.grad.cpu(), ga.cpu()) < 1e-5
+    assert rel_l2(r.grad.cpu(), sh.grad_roughness.cpu()) < 1e-5 and float(r.grad.abs().max()) > 0
+    with pytest.raises(NotImplementedError):
+        create_integrator('sdf_direct_reparam', {'sdf': shapes.Grid3d(data.clone()), 'roughness': rough, 'use_mis': True})
+
+
+def test_optimize_cli_principled(dsdf, tmp_path, monkeypatch):
+    """`python optimize.py sphere --optconfig principled-6`: shape, base colour and roughness volumes optimised jointly."""
+    import optimize
+    import util
+    monkeypatch.setattr(optimize, 'RENDER_DIR', str(tmp_path / 'renders'))
+    args = ['sphere', '--optconfig', 'principled-6', '--configs', 'warp', '--outputdir', str(tmp_path / 'out'), '--refspp', '128',
+            '--n_iter=40', '--spp=64', '--sdf_res=32', '--resx=48', '--resy=48']
+    optimize.main(args)
+    out = tmp_path / 'out' / 'sphere' / 'principled-6' / 'warp'
+    lv = json.load(open(out / 'metadata.json'))['loss_values']
+    assert len(lv) == 40 and np.mean(lv[-5:]) < 0.7 * np.mean(lv[:3]), lv
+    base = util.read_vol(str(out / 'params' / 'main-bsdf-base_color-volume-data-final.vol'))
+    rough = util.read_vol(str(out / 'params' / 'main-bsdf-roughness-volume-data-final.vol'))
+    assert base.shape[-1] == 3 and float(base.min()) >= 1e-5 and float(base.max()) <= 1.0 and float(base.std()) > 1e-3
+    assert float(rough.min()) >= 0.1 - 1e-6 and float(rough.max()) <= 0.8 + 1e-6                 # variables.py:121
