@@ -1302,8 +1302,6 @@ int dsdf_render_forward_grad(const float *padded, int rx, int ry, int rz, const 
     if (rc) return rc;
     if (!grad_image_out) return fail(DSDF_ERR_INVALID_ARG, "dsdf_render_forward_grad: grad_image_out is null");
     if (!tangent_padded && !tangent_p) return fail(DSDF_ERR_INVALID_ARG, "dsdf_render_forward_grad: need a tangent");
-    if (integrator == DSDF_DIRECT && shading->bsdf != 0)
-        return fail(DSDF_ERR_INVALID_ARG, "dsdf_render_forward_grad: forward mode knows the diffuse BSDF only");
     if (!offsets && !seeds) return fail(DSDF_ERR_INVALID_ARG, "dsdf_render_forward_grad: need offsets or seeds");
     const PassCtx c = make_ctx(padded, rx, ry, rz, prm, width, height, spp, offsets, seeds, integrator, flags, shading, stream);
     hipStream_t st = c.st;

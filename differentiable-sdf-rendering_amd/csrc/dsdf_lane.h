@@ -837,7 +837,9 @@ DSDF_HD bool lane_forward_tangent_direct(const GridView &G, const float *tangent
         br.active = false;
         int lit = 0;
         float ke = 0.f, kb = 0.f, we = 1.f;
-        if (front && !(trs.its_t < INFINITY)) { EmitterTerm et; emitter_term(S, h, d, et); ke = et.ke; we = et.we; lit |= 1; }   // (diffuse only: the entry point refuses principled)
+        EmitterTerm et;
+        et.ks = 0.f;
+        if (front && !(trs.its_t < INFINITY)) { emitter_term(S, h, d, et); ke = et.ke; we = et.we; lit |= 1; }
         if (S.use_mis) {
             br = bsdf_setup(A, L, lane, h);
             if (br.active && !(trb.its_t < INFINITY)) { kb = bsdf_factor(br); lit |= 2; }
@@ -876,11 +878,21 @@ DSDF_HD bool lane_forward_tangent_direct(const GridView &G, const float *tangent
                 }
             }
             const float d_cos = (lit & 1) ? dot(dn, h.sr.d) + dot(n, d_sdir) : 0.f;
+            float d_ke = 4.f * we * d_cos, d_ks = 0.f;
+            if (S.bsdf == 1 && (lit & 1)) {
+                // principled: ke = 4 pi Kd, ks = 4 pi Ks of (x, y, u, r) = (n . wi, n . d_s', wi . d_s', roughness(p)), wi = -d'
+                const V3 dwi = -d_dir;
+                const float dq[4] = {dot(dn, et.wi) + dot(n, dwi), d_cos, dot(dwi, h.sr.d) + dot(et.wi, d_sdir), dot(et.rg, dpos)};
+                d_ke = 0.f;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { d_ke = fmaf(et.T.dkd[q], dq[q], d_ke); d_ks = fmaf(et.T.dks[q], dq[q], d_ks); }
+                d_ke *= 12.566370614359172f; d_ks *= 12.566370614359172f;
+            }
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
-                const float re = alb[c] * ke * S.env[c], rb = alb[c] * kb * S.env[c];
+                const float re = (alb[c] * ke + et.ks) * S.env[c], rb = alb[c] * kb * S.env[c];
                 out.val[c] = re + rb;
-                out.d_val[c] = S.env[c] * (ke + kb) * dot(ag[c], dpos) + alb[c] * S.env[c] * 4.f * we * d_cos + re * d_det_e + rb * d_det_b;
+                out.d_val[c] = S.env[c] * ((ke + kb) * dot(ag[c], dpos) + alb[c] * d_ke + d_ks) + re * d_det_e + rb * d_det_b;
             }
             did = true;
         }

@@ -102,7 +102,7 @@ typedef struct dsdf_shading {
                                      or NULL for the built-in sampler; only read when use_mis */
     int   bsdf;                   /* 0 = `diffuse` (albedo is its reflectance volume), 1 = `principled` with every parameter at the plugin
                                      default except base_color (= albedo) and roughness (below): the principled-* configs,
-                                     python/opt_configs.py:288-299.  Emitter sampling only (use_mis must be 0), no forward mode */
+                                     python/opt_configs.py:288-299.  Emitter sampling only (use_mis must be 0) */
     const float *roughness;       /* device, (rz_,ry_,rx_,1) fp32: 'main-bsdf.roughness.volume.data'; read when bsdf == 1 */
     int   rax, ray, raz;
     float *grad_roughness;        /* device, like roughness: dL/d(roughness) accumulator of dsdf_render_backward, or NULL */

@@ -180,7 +180,8 @@ class HostHarness:
         return gg, ga, gp, img
 
     def render_direct_forward_grad(self, grid, cam, W, H, spp, offsets, emitter_u, albedo, env=(1.0, 1.0, 1.0), hide_emitters=False,
-                                   reparam=True, seed=0, bsdf_u=None, variant=0, tangent=None, tangent_p=None):
+                                   reparam=True, seed=0, bsdf_u=None, variant=0, tangent=None, tangent_p=None, roughness=None):
+        self._principled(roughness)
         grid = np.ascontiguousarray(grid, np.float32)
         offsets = None if offsets is None else np.ascontiguousarray(offsets, np.float32)
         emitter_u = None if emitter_u is None else np.ascontiguousarray(emitter_u, np.float32)
@@ -196,6 +197,7 @@ class HostHarness:
                                                self._p(offsets), self._p(emitter_u), C.c_uint(seed), int(reparam), self._p(albedo), ax, ay, az,
                                                self._p(env), int(hide_emitters), int(bu is not None), self._p(bu), int(variant),
                                                self._p(t), self._p(tp), self._p(out))
+        self._principled(None)
         return out
 
     def _principled(self, roughness, with_grad=False):

@@ -76,10 +76,29 @@ def test_principled_rejections(dsdf):
     sh = dsdf.Shading(ex['albedo'].cuda(), ex['env'], use_mis=True, roughness=ex['roughness'].cuda())
     with pytest.raises(dsdf.DsdfError):
         dsdf.render_forward(grid, sen, 4, seeds=[1], integrator='sdf_direct_reparam', shading=sh)
-    sh = dsdf.Shading(ex['albedo'].cuda(), ex['env'], roughness=ex['roughness'].cuda())
-    with pytest.raises(dsdf.DsdfError):
-        dsdf.render_forward_grad(grid, sen, 4, tangent_p=torch.tensor([1.0, 0.0, 0.0]), seeds=[1], integrator='sdf_direct_reparam',
-                                 shading=sh)
+
+
+def test_principled_forward_mode_gpu(dsdf):
+    """`render_forward` (integrators/reparam.py:192-196) with the principled BSDF through the C-ABI: the transpose identity against
+    dsdf_render_backward on the same samples, tangents on sdf.data and on sdf.p."""
+    R, W, H = 48, 32, 32
+    data = O.blob_grid(R, n=10, seed=3).float().cuda()
+    grid = dsdf.SdfGrid(data)
+    sens = dsdf.get_regular_cameras(6, resx=W, resy=H)[:2]
+    torch.manual_seed(2)
+    sh = dsdf.Shading(torch.rand(6, 5, 4, 3, device='cuda') * 0.6 + 0.2, (1.0, 0.9, 0.8),
+                      roughness=torch.rand(3, 4, 5, 1, device='cuda') * 0.7 + 0.1)
+    gi = torch.randn(2, H, W, 3, device='cuda')
+    gp = torch.zeros(3, device='cuda')
+    gg = dsdf.render_backward(grid, sens, 64, gi, seeds=[4, 5], integrator='sdf_direct_reparam', shading=sh, grad_p=gp)
+    tdata = torch.randn_like(data)
+    tpv = [0.3, -0.2, 0.5]
+    jd = dsdf.render_forward_grad(grid, sens, 64, tangent_data=tdata, seeds=[4, 5], integrator='sdf_direct_reparam', shading=sh)
+    jp = dsdf.render_forward_grad(grid, sens, 64, tangent_p=tpv, seeds=[4, 5], integrator='sdf_direct_reparam', shading=sh)
+    lhs_d, rhs_d = float((jd.double() * gi).sum()), float((tdata.double() * gg).sum())
+    lhs_p, rhs_p = float((jp.double() * gi).sum()), float(sum(a * float(b) for a, b in zip(tpv, gp)))
+    assert abs(lhs_d - rhs_d) <= 5e-3 * max(abs(rhs_d), 1e-6), (lhs_d, rhs_d)
+    assert abs(lhs_p - rhs_p) <= 5e-3 * max(abs(rhs_p), 1e-6), (lhs_p, rhs_p)
 
 
 def test_principled_plugin_and_render_op(dsdf):

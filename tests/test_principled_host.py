@@ -131,3 +131,25 @@ def test_principled_translation_gradient_host(harness):
                                                  ex['albedo'].numpy(), case['grad_image'].numpy(), ex['env'],
                                                  roughness=ex['roughness'].numpy())
     assert rel_l2(gp, gp_ref) < tol, (rel_l2(gp, gp_ref), tol)
+
+
+def test_principled_forward_mode_is_transpose_of_backward_host(harness):
+    """`render_forward` with the principled BSDF: <J dtheta, G> = <dtheta, J^T G> for tangents on sdf.data and sdf.p."""
+    case = make_case('blob32')
+    ex = _principled_inputs(case)
+    a = (case['grid'].float().numpy(), cam_params(case), case['W'], case['H'], case['spp'], case['offsets'].numpy(), ex['emitter_u'].numpy(),
+         ex['albedo'].numpy())
+    gi = case['grad_image'].numpy()
+    rough = ex['roughness'].numpy()
+    gg, _, gp, _ = harness.render_direct_backward(*a, gi, ex['env'], roughness=rough)
+    rng = np.random.default_rng(5)
+    tdata = rng.standard_normal(gg.shape).astype(np.float32)
+    tp = np.array([0.3, -0.2, 0.5], np.float32)
+    jd = harness.render_direct_forward_grad(*a, ex['env'], tangent=tdata, roughness=rough)
+    jp = harness.render_direct_forward_grad(*a, ex['env'], tangent_p=tp, roughness=rough)
+    lhs_d, rhs_d = float((jd.astype(np.float64) * gi).sum()), float((tdata.astype(np.float64) * gg).sum())
+    lhs_p, rhs_p = float((jp.astype(np.float64) * gi).sum()), float((tp.astype(np.float64) * gp).sum())
+    assert abs(lhs_d - rhs_d) <= 2e-3 * max(abs(rhs_d), 1e-6), (lhs_d, rhs_d)
+    assert abs(lhs_p - rhs_p) <= 2e-3 * max(abs(rhs_p), 1e-6), (lhs_p, rhs_p)
+    jdd = harness.render_direct_forward_grad(*a, ex['env'], tangent=tdata)          # (the diffuse tangent is another image)
+    assert rel_l2(jd, jdd) > 1e-3
