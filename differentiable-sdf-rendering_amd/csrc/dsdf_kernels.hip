@@ -1089,6 +1089,28 @@ static void timing_mark(int which, hipStream_t st) {
     else { if (hipEventRecord(g_time_ev[1], st) == hipSuccess) g_time_state = 2; }
 }
 
+// ---- pixel-skip flags shared by the calls of one step (dsdf_share_pixel_skip, include/dsdf.h).  The primal render and the
+// gradient sweep of an optimisation step see the same grid, sensors and film size, and k_pixel_skip writes the flags of BOTH
+// passes (bits 0 / 1): between a share(buffer) and the share(NULL) that ends the bracket, the first call of the calling thread
+// computes them into the caller's buffer and records an event, a later call with the same inputs waits for that event on its own
+// stream and reads them (two 12-view proofs beside each other take 0.67 / 1.06 ms, one alone 0.53: profiles/r03_step_timeline.md).
+struct SkipShare {
+    unsigned char *buf = nullptr;
+    size_t bytes = 0;
+    bool valid = false;
+    hipEvent_t ready = nullptr;
+    const float *padded = nullptr;
+    int rx = 0, ry = 0, rz = 0, W = 0, H = 0, nv = 0;
+    dsdf_params prm;
+    dsdf_camera cams[DSDF_MAX_BATCH];
+};
+static thread_local SkipShare t_share;
+
+static bool skip_share_matches(const SkipShare &h, const PassCtx &c, const dsdf_camera *cams, int nv) {
+    return h.valid && h.padded == c.padded && h.rx == c.rx && h.ry == c.ry && h.rz == c.rz && h.W == c.W && h.H == c.H && h.nv == nv &&
+           memcmp(&h.prm, c.prm, sizeof(dsdf_params)) == 0 && memcmp(h.cams, cams, (size_t)nv * sizeof(dsdf_camera)) == 0;
+}
+
 template <bool DIFF>
 static int run_pass(const PassCtx &c, const Workspace &ws, const dsdf_camera *cams, int v0, int nv, ViewBatch &VB, Queue q,
                     int64_t *stats) {
@@ -1107,12 +1129,26 @@ static int run_pass(const PassCtx &c, const Workspace &ws, const dsdf_camera *ca
     const int level = (c.flags & DSDF_NO_SKIP) ? -1 : skip_level(cams + v0, nv, c.W, c.rx, c.ry, c.rz, step);
     const unsigned char *skip = nullptr;
     if (level >= 0) {
-        hipLaunchKernelGGL(k_pixel_skip, dim3((unsigned)((npix + 255) / 256), nv), dim3(256), 0, st,
-                           device_view(c.padded, c.rx, c.ry, c.rz, *c.prm, level), c.pp, VB, ws.skip, step);
-        if ((rc = check_launch("k_pixel_skip"))) return rc;
-        hipLaunchKernelGGL(k_skip_dilate, dim3((unsigned)((npix + 255) / 256), nv), dim3(256), 0, st, VB, ws.skip);
-        if ((rc = check_launch("k_skip_dilate"))) return rc;
-        skip = ws.skip;
+        SkipShare &sh = t_share;
+        const bool can_share = sh.buf && sh.ready && sh.bytes >= (size_t)nv * npix;
+        if (can_share && skip_share_matches(sh, c, cams + v0, nv)) {
+            if (hipStreamWaitEvent(st, sh.ready, 0) != hipSuccess) return fail(DSDF_ERR_LAUNCH, "hipStreamWaitEvent(shared skip flags) failed");
+            skip = sh.buf;
+        } else {
+            unsigned char *dst = (can_share && !sh.valid) ? sh.buf : ws.skip;       // (a second, different batch keeps its own flags)
+            hipLaunchKernelGGL(k_pixel_skip, dim3((unsigned)((npix + 255) / 256), nv), dim3(256), 0, st,
+                               device_view(c.padded, c.rx, c.ry, c.rz, *c.prm, level), c.pp, VB, dst, step);
+            if ((rc = check_launch("k_pixel_skip"))) return rc;
+            hipLaunchKernelGGL(k_skip_dilate, dim3((unsigned)((npix + 255) / 256), nv), dim3(256), 0, st, VB, dst);
+            if ((rc = check_launch("k_skip_dilate"))) return rc;
+            if (dst == sh.buf) {
+                if (hipEventRecord(sh.ready, st) != hipSuccess) return fail(DSDF_ERR_LAUNCH, "hipEventRecord(shared skip flags) failed");
+                sh.valid = true; sh.padded = c.padded; sh.rx = c.rx; sh.ry = c.ry; sh.rz = c.rz; sh.W = c.W; sh.H = c.H; sh.nv = nv;
+                sh.prm = *c.prm;
+                memcpy(sh.cams, cams + v0, (size_t)nv * sizeof(dsdf_camera));
+            }
+            skip = dst;
+        }
     }
     const GridView G = device_view(c.padded, c.rx, c.ry, c.rz, *c.prm);
     const ShadeArgs S = make_shade_args(c.shading, DIFF);
@@ -1439,6 +1475,16 @@ int dsdf_grad_backward(const float *padded, int rx, int ry, int rz, const dsdf_p
 }  // extern "C"
 
 extern "C" {
+
+int dsdf_share_pixel_skip(void *buffer, size_t bytes) {
+    SkipShare &sh = t_share;
+    sh.valid = false;
+    sh.buf = (unsigned char *)buffer;
+    sh.bytes = buffer ? bytes : 0;
+    if (buffer && !sh.ready && hipEventCreateWithFlags(&sh.ready, hipEventDisableTiming) != hipSuccess)
+        return fail(DSDF_ERR_LAUNCH, "dsdf_share_pixel_skip: hipEventCreate failed");
+    return DSDF_OK;
+}
 
 int dsdf_kernel_timing_arm(void) {
     for (int k = 0; k < 2; ++k)

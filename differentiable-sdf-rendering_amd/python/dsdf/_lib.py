@@ -47,6 +47,7 @@ _lib = None
 # name -> (restype, argtypes); every symbol include/dsdf.h declares
 SYMBOLS = {
     'dsdf_version': (C.c_int, []),
+    'dsdf_share_pixel_skip': (C.c_int, [C.c_void_p, C.c_size_t]),
     'dsdf_kernel_timing_arm': (C.c_int, []),
     'dsdf_kernel_timing_read': (C.c_int, [C.POINTER(C.c_float)]),
     'dsdf_last_error': (C.c_char_p, []),

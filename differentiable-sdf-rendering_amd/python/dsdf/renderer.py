@@ -9,6 +9,8 @@ from an independent (seed_grad, spp_grad) re-render
 """
 import ctypes as C
 
+import os
+
 import torch
 
 from . import _lib
@@ -530,6 +532,7 @@ class _GradSweepParts(GradSweep):
 
 
 _side_streams = {}
+_skip_buffers = {}
 
 
 def render_step(grid, sensors, spp, spp_grad, loss_grad, grad_grid, seeds, seeds_grad, integrator=DSDF_SILHOUETTE, reparam=True,
@@ -555,6 +558,23 @@ def render_step(grid, sensors, spp, spp_grad, loss_grad, grad_grid, seeds, seeds
         # (a handful of 1000-step rays) runs beside the bulk of the primal pass instead of after it
         side = _side_streams[dev] = torch.cuda.Stream(dev, priority=-1)
     side.wait_stream(main)                                    # the grid (and whatever produced it) is ready
+    # one empty-space proof for both passes (dsdf_share_pixel_skip): the sweep writes the flags, the primal render reads them
+    lib = _lib.load()
+    nflag = len(sensors) * (W + 4) * (H + 4)
+    flags = _skip_buffers.get(dev)
+    if flags is None or flags.numel() < nflag:
+        flags = _skip_buffers[dev] = torch.empty(nflag, dtype=torch.uint8, device=dev)
+    if os.environ.get('DSDF_SHARE_SKIP', '1') != '0':          # (A/B switch, tools/ab_step.py)
+        _lib.check(lib.dsdf_share_pixel_skip(_ptr(flags), flags.numel()))
+    try:
+        return _render_step_shared(grid, sensors, spp, spp_grad, loss_grad, grad_grid, seeds, seeds_grad, integrator, reparam, shading,
+                                   grad_albedo, grad_p, main, side, W, H, dev)
+    finally:
+        lib.dsdf_share_pixel_skip(None, 0)
+
+
+def _render_step_shared(grid, sensors, spp, spp_grad, loss_grad, grad_grid, seeds, seeds_grad, integrator, reparam, shading,
+                        grad_albedo, grad_p, main, side, W, H, dev):
     with torch.cuda.stream(side):
         sweep = GradSweep(grid, sensors, spp_grad, (0, H + 4), seeds=seeds_grad, integrator=integrator, reparam=reparam,
                           shading=shading, grad_albedo=grad_albedo, workspace=_sweep_workspaces.get(dev))

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define DSDF_VERSION 302   /* 300: stats rows of DSDF_STAT_SLOTS (16) counters; tail hand-off on library-owned helper streams */
+#define DSDF_VERSION 303   /* 300: stats rows of DSDF_STAT_SLOTS (16) counters; tail hand-off on library-owned helper streams */
 #define DSDF_STAT_SLOTS 16
 
 enum dsdf_status {
@@ -276,6 +276,15 @@ int dsdf_redistance(const float *phi, int rx, int ry, int rz, float *out,
  * *status: 0 = the relaxation reached its fixed point, 1 = the launch budget ran out while values were still moving.
  * The library never synchronises: read it whenever the caller synchronises anyway. */
 int dsdf_redistance_status(const void *workspace, int rx, int ry, int rz, int32_t *status, void *stream);
+
+/* Pixel-skip flags shared by the calls of one step.  The primal render and the gradient sweep of an optimisation step
+ * (python/shape_opt.py:77-83: one `mi.render` = a primal and a gradient launch) see the same grid, sensors and film size, and the
+ * empty-space proof the library runs in front of every pass produces the flags of both.  After dsdf_share_pixel_skip(buffer,
+ * bytes) -- a device buffer of at least n_views * (W+4) * (H+4) bytes -- the next render call of the calling thread writes its
+ * flags there, and later calls with identical grid pointer, sizes, parameters and sensors read them (ordered by an event, on
+ * whatever stream they run) instead of running the proof again.  dsdf_share_pixel_skip(NULL, 0) ends the bracket; the caller
+ * must not update the grid inside it.  (No reference counterpart: Dr.Jit has no empty-space proof.) */
+int dsdf_share_pixel_skip(void *buffer, size_t bytes);
 
 /* Measurement hook: after dsdf_kernel_timing_arm() the next render call of the calling thread (dsdf_render_forward /
  * _backward / _film / dsdf_grad_sweep ...) brackets ITS RENDER KERNEL -- k_render_items / k_render_pass alone, without the list

@@ -576,3 +576,39 @@ def test_two_stream_step_equals_sequential(dsdf):
             ib = dsdf.render_step(grid, sens, 64, 64, lg, gb, seeds, seeds_g, integrator=integ, overlap=False)
             torch.cuda.synchronize()
             assert rel_l2(ia.cpu(), ib.cpu()) < 1e-6 and rel_l2(ga.cpu(), gb.cpu()) < 1e-5
+
+
+def test_shared_pixel_skip_flags(dsdf, monkeypatch):
+    """dsdf_share_pixel_skip: inside dsdf.render_step the gradient sweep writes the empty-space flags and the primal render reads
+    them -- same image and dL/dsdf as without sharing and as the sequential step, at a size where the proof is active, and after
+    the grid changed between two steps (the flags of the previous grid must not survive the bracket)."""
+    import bench
+    data = bench.synth_grid(128, torch.device('cuda'))
+    grid = dsdf.SdfGrid(data)
+    sens = dsdf.get_regular_cameras(12, resx=192, resy=192)[2:5]
+    tgt = torch.rand(3, 192, 192, 3, device='cuda')
+    lg = lambda im: 2.0 * (im - tgt)
+    traced = []
+    for skip in (True, False):
+        stats = dsdf.new_stats('cuda')
+        dsdf.render_forward(grid, sens, 64, seeds=[1, 2, 3], stats=stats, empty_space_skip=skip)
+        traced.append(dsdf.stats_dict(stats)['bbox_lanes'])
+    assert traced[0] < 0.9 * traced[1]                                 # the proof removes work here
+    for it in range(2):
+        if it == 1:                                                     # another shape in the same buffers
+            data = torch.roll(data, 9, dims=2).contiguous()
+            grid.update(data)
+        seeds, seeds_g = [5 + it, 6 + it, 7 + it], [50 + it, 60 + it, 70 + it]
+        out = []
+        for share, overlap in (('1', True), ('0', True), ('1', False)):
+            monkeypatch.setenv('DSDF_SHARE_SKIP', share)
+            g = torch.zeros(grid.shape, device='cuda')
+            img = dsdf.render_step(grid, sens, 64, 64, lg, g, seeds, seeds_g, overlap=overlap)
+            torch.cuda.synchronize()
+            out.append((img.cpu(), g.cpu()))
+        for img, g in out[1:]:
+            assert rel_l2(out[0][0], img) < 1e-6 and rel_l2(out[0][1], g) < 1e-5
+    # a call outside a bracket runs its own proof
+    a = dsdf.render_forward(grid, sens, 64, seeds=[1, 2, 3])
+    b = dsdf.render_forward(grid, sens, 64, seeds=[1, 2, 3], empty_space_skip=False)
+    assert rel_l2(a.cpu(), b.cpu()) < 1e-6
