@@ -32,23 +32,34 @@ def main():
             f.write(f"{short(r['Name'])[:70]},{r['Calls']},{r['TotalDurationNs']},{float(r['AverageNs']):.0f},"
                     f"{r['Percentage']},{r['MinNs']},{r['MaxNs']}\n")
     d = collections.defaultdict(list)
-    for r in csv.DictReader(open(trace)):
-        if short(r['Kernel_Name']).startswith('k_'):
-            key = f"{short(r['Kernel_Name'])} grid={r['Grid_Size_X']}x{r.get('Grid_Size_Y', '1')}"
-            d[key].append((int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e6)
+    ev = [(int(r['Start_Timestamp']), int(r['End_Timestamp']), short(r['Kernel_Name']), r) for r in csv.DictReader(open(trace))]
+    renders = [(a, b) for a, b, n, _ in ev if n.startswith('k_render_items')]
+    for a, b, n, r in ev:
+        if n.startswith('k_'):
+            key = f"{n} grid={r['Grid_Size_X']}x{r.get('Grid_Size_Y', '1')}"
+            # a render / tail kernel that shares the chip with ANOTHER render kernel for more than a tenth of its run time (the
+            # two-stream step: primal render beside gradient sweep) is stretched by it: such dispatches get their own rows
+            shared = 0
+            if n.startswith(('k_render_items', 'k_tail_trace')):
+                shared = sum(max(0, min(b, d1) - max(a, c1)) for c1, d1 in renders if (c1, d1) != (a, b))
+            d[key].append(((b - a) / 1e6, shared > 0.1 * (b - a)))
     with open(os.path.join(HERE, f'{tag}_dispatches.csv'), 'w') as f:
         f.write('kernel,dispatches,median_ms,min_ms,max_ms\n')
-        for k, v in d.items():
-            s = sorted(v)
-            f.write(f"{k},{len(v)},{s[len(s) // 2]:.3f},{s[0]:.3f},{s[-1]:.3f}\n")
-            # the persistent-worker kernels have ONE grid for every workload (bench launches of 12 views x 256 spp and the
-            # single-view 64-spp target renders of the set-up share a row above): split the dispatches where consecutive
-            # sorted durations jump by more than 3x, so that each workload has its own line
-            cuts = [i for i in range(1, len(s)) if s[i] > 3.0 * s[i - 1]]
-            if cuts:
-                for a, b in zip([0] + cuts, cuts + [len(s)]):
-                    c = s[a:b]
-                    f.write(f"{k} [durations {c[0]:.2f}-{c[-1]:.2f} ms],{len(c)},{c[len(c) // 2]:.3f},{c[0]:.3f},{c[-1]:.3f}\n")
+        for k, vv in d.items():
+            for label, v in (('', [x for x, sh in vv if not sh]), (' [beside another render kernel]', [x for x, sh in vv if sh])):
+                if not v:
+                    continue
+                s = sorted(v)
+                kk = k + label
+                f.write(f"{kk},{len(v)},{s[len(s) // 2]:.3f},{s[0]:.3f},{s[-1]:.3f}\n")
+                # the persistent-worker kernels have ONE grid for every workload (bench launches of 12 views x 256 spp and the
+                # single-view 64-spp target renders of the set-up share a row above): split the dispatches where consecutive
+                # sorted durations jump by more than 3x, so that each workload has its own line
+                cuts = [i for i in range(1, len(s)) if s[i] > 3.0 * s[i - 1]]
+                if cuts:
+                    for a, b in zip([0] + cuts, cuts + [len(s)]):
+                        c = s[a:b]
+                        f.write(f"{kk} [durations {c[0]:.2f}-{c[-1]:.2f} ms],{len(c)},{c[len(c) // 2]:.3f},{c[0]:.3f},{c[-1]:.3f}\n")
     if len(sys.argv) >= 6:
         out = {}
         for col, path in (('FETCH_SIZE', sys.argv[4]), ('WRITE_SIZE', sys.argv[5])):
