@@ -13,10 +13,14 @@ for p in (ROOT, os.path.join(ROOT, 'oracle'), os.path.join(ROOT, 'differentiable
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "convergence: end-to-end optimiser runs (stochastic); always collected LAST so that "
+                                       "`pytest -x` cannot hide a parity test behind one of them")
 
 
 def pytest_collection_modifyitems(config, items):
-    """`gpu` tests need a real MI355X: skipped (not failed) on a host without one, so that a plain `pytest tests` works."""
+    """`gpu` tests need a real MI355X: skipped (not failed) on a host without one, so that a plain `pytest tests` works.
+    `convergence` tests run after everything else (stable partition: the order inside both groups is kept)."""
+    items[:] = [it for it in items if 'convergence' not in it.keywords] + [it for it in items if 'convergence' in it.keywords]
     try:
         import torch
         have = torch.cuda.is_available()

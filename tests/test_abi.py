@@ -85,3 +85,33 @@ def test_product_never_imports_oracle():
                 src = open(os.path.join(d, f)).read()
                 assert 'sdf_oracle' not in src and 'oracle/' not in src, os.path.join(d, f)
                 assert 'host_harness' not in src, os.path.join(d, f)
+
+
+def test_build_staleness_covers_every_source(tmp_path):
+    """__graft_entry__ decides whether libdsdf.so / the host harness are up to date from EVERY file of csrc/ (VERDICT r3 weak #9:
+    a hand-written list had missed dsdf_bsdf.h, so editing the BSDF did not rebuild the library)."""
+    import __graft_entry__ as g
+    csrc = os.path.join(g.PKG, 'csrc')
+    lib, har = set(g.lib_sources()), set(g.harness_sources())
+    for f in os.listdir(csrc):
+        assert os.path.join(csrc, f) in lib, f
+        if f.endswith('.h'):
+            assert os.path.join(csrc, f) in har, f
+    assert os.path.join(g.ROOT, 'include', 'dsdf.h') in lib
+    # _newer() turns false as soon as ANY listed source is younger than the target
+    tgt = tmp_path / 'target.so'
+    tgt.write_bytes(b'x')
+    old = os.path.getmtime(tgt) - 100
+    srcs = []
+    for i in range(3):
+        s = tmp_path / f's{i}.h'
+        s.write_text('x')
+        os.utime(s, (old, old))
+        srcs.append(str(s))
+    assert g._newer(str(tgt), srcs)
+    for s in srcs:
+        os.utime(s, None)
+        os.utime(s, (os.path.getmtime(tgt) + 10,) * 2)
+        assert not g._newer(str(tgt), srcs), s
+        os.utime(s, (old, old))
+    assert not g._newer(str(tmp_path / 'missing.so'), srcs)

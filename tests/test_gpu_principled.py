@@ -137,20 +137,3 @@ def test_principled_plugin_and_render_op(dsdf):
     assert rel_l2(r.grad.cpu(), sh.grad_roughness.cpu()) < 1e-5 and float(r.grad.abs().max()) > 0
     with pytest.raises(NotImplementedError):
         create_integrator('sdf_direct_reparam', {'sdf': shapes.Grid3d(data.clone()), 'roughness': rough, 'use_mis': True})
-
-
-def test_optimize_cli_principled(dsdf, tmp_path, monkeypatch):
-    """`python optimize.py sphere --optconfig principled-6`: shape, base colour and roughness volumes optimised jointly."""
-    import optimize
-    import util
-    monkeypatch.setattr(optimize, 'RENDER_DIR', str(tmp_path / 'renders'))
-    args = ['sphere', '--optconfig', 'principled-6', '--configs', 'warp', '--outputdir', str(tmp_path / 'out'), '--refspp', '128',
-            '--n_iter=40', '--spp=64', '--sdf_res=32', '--resx=48', '--resy=48']
-    optimize.main(args)
-    out = tmp_path / 'out' / 'sphere' / 'principled-6' / 'warp'
-    lv = json.load(open(out / 'metadata.json'))['loss_values']
-    assert len(lv) == 40 and np.mean(lv[-5:]) < 0.7 * np.mean(lv[:3]), lv
-    base = util.read_vol(str(out / 'params' / 'main-bsdf-base_color-volume-data-final.vol'))
-    rough = util.read_vol(str(out / 'params' / 'main-bsdf-roughness-volume-data-final.vol'))
-    assert base.shape[-1] == 3 and float(base.min()) >= 1e-5 and float(base.max()) <= 1.0 and float(base.std()) > 1e-3
-    assert float(rough.min()) >= 0.1 - 1e-6 and float(rough.max()) <= 0.8 + 1e-6                 # variables.py:121
