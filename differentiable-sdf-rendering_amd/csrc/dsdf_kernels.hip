@@ -16,8 +16,7 @@
 //                              of a pixel per ticket, one tile per XCD at a time; DIFF = 0 value-only march through the wave
 //                              cell cache, DIFF = 1 Hessian march with the warp accumulators + backward-queue compaction;
 //                              both hand the last few rays of a wave to a tail queue                         [dsdf_tail.h]
-//   k_tail_trace_plain/diff    persistent waves that resume the handed-off rays (on helper streams, beside the next
-//                              view group's render kernel)
+//   k_tail_trace_plain/diff    persistent waves that resume the handed-off rays, per-XCD queues (dsdf_tail.h)
 //   k_render_pass<DIFF,DIRECT> any spp: one lane per sample; for spp < 64 a wave = a pixel tile with an LDS film window
 //   k_develop*, k_develop_adjoint*, k_develop_tangent   HDRFilm.develop, its adjoint and tangent              [dsdf_film.h]
 //   k_backward<DIRECT>         per queued sample: film-adjoint gather, warp / shading adjoint, transposed 64-tap LDS
@@ -192,6 +191,7 @@ __device__ __forceinline__ void load_record(const float *r, size_t c, TraceOut &
 }
 
 #include "dsdf_film.h"
+#include "dsdf_proof.h"
 #include "dsdf_skip.h"
 #include "dsdf_tail.h"
 
@@ -346,6 +346,7 @@ void k_render_items(GridView G, dsdf_params P, ViewBatch VB, float *__restrict__
     // pre-assigned).  A worker whose share is exhausted moves on to the next XCD's.
     const uint32_t sub = (blockIdx.x >> 3) & 7u, first = gridDim.x / DSDF_TICKETS;
     uint32_t share = blockIdx.x & 7u, hops = 0;
+    const uint32_t my_subq = tail_subq();        // tail hand-off queue of this worker: (the XCD it runs on, its ticket counter)
     auto item_of = [&](uint32_t sh, uint32_t j) { return ((j / DSDF_ITEM_SEG) * 8u + sh) * DSDF_ITEM_SEG + j % DSDF_ITEM_SEG; };
     auto draw = [&](uint32_t sh) {            // lane 0: the next item of share sh (one round trip ahead of its use)
         return item_of(sh, sub + 8u * (first + atomicAdd(items + 16 + 16 * (sh * 8u + sub), 1u)));
@@ -368,27 +369,31 @@ void k_render_items(GridView G, dsdf_params P, ViewBatch VB, float *__restrict__
         float *__restrict__ block = blocks + (size_t)view * NCH * npix;
         const int py = (int)(pix / (uint32_t)A.Wb), px = (int)(pix - (uint32_t)py * (uint32_t)A.Wb);
         // empty-space proof of this pixel: the result of tracing is known -- a miss with no warp -- so the loop is skipped
-        const bool skip_trace = skip && (__builtin_amdgcn_readfirstlane((int)skip[e]) & (DIFF ? 2 : 1));
+        const unsigned proof = skip ? (unsigned)__builtin_amdgcn_readfirstlane((int)skip[e]) : 0u;
+        const bool skip_trace = (proof & (DIFF ? DSDF_PX_EMPTY_G : DSDF_PX_EMPTY)) != 0;
+        // hit proof of this pixel (silhouette primal): every sample hits, and only the hit flag is consumed
+        const bool known_hit = !DIFF && !DIRECT && (proof & DSDF_PX_HIT) && A.integrator == DSDF_SILHOUETTE;
         const uint32_t unit = pix * chunks + item % chunks;
         const uint32_t lane = unit * 64u + (uint32_t)lid;
         TraceOut tr, trs, trb;
         clear_trace(tr);
         int lit = 0;
         const Lane L = lane_setup(A, P, lane);
-        if (!skip_trace) {
+        if (known_hit) tr.its_t = 0.f;
+        else if (!skip_trace) {
             // (the last few rays of the wave are handed to the tail queue: dsdf_tail.h)
             if (DIFF) {
                 DirectFetch F;
                 if (!DIRECT && tq.state) {
                     HandOff ho;
-                    ho.tq = tq; ho.sub = item % DSDF_TAIL_SUBQ; ho.view = view; ho.lane = lane;
+                    ho.tq = tq; ho.sub = my_subq; ho.view = view; ho.lane = lane;
                     trace_diff(G, P, L.ray.o, L.ray.d, L.ray.maxt, tr, F, ho);
                 } else trace_diff(G, P, L.ray.o, L.ray.d, L.ray.maxt, tr, F);
             } else {
                 WaveCellCache F; F.taps = wave_lds; F.lid = lid;
                 if (!DIRECT && tq.state) {
                     PlainHandOff ho;
-                    ho.tq = tq; ho.sub = item % DSDF_TAIL_SUBQ; ho.view = view; ho.lane = lane;
+                    ho.tq = tq; ho.sub = my_subq; ho.view = view; ho.lane = lane;
                     trace_plain(G, P, L.ray.o, L.ray.d, L.ray.maxt, tr, F, ho);
                 } else trace_plain(G, P, L.ray.o, L.ray.d, L.ray.maxt, tr, F);
             }
@@ -469,14 +474,15 @@ __global__ __launch_bounds__(DSDF_BLOCK) void k_render_pass(GridView G, dsdf_par
     clear_trace(tr);
     // empty-space proof for this sample's pixel.  skip_trace: a miss with no warp is known; far: nothing this sample does
     // can reach an output (k_skip_dilate), so it is not generated.
-    bool skip_trace = false, far = false;
+    bool skip_trace = false, far = false, known_hit = false;
     {
         int px, py;
         lane_pixel(A, lane, px, py);
         if (skip) {
             const unsigned f = skip[(size_t)blockIdx.y * A.Wb * A.Hb + (size_t)py * A.Wb + px];
-            skip_trace = (f & (DIFF ? 2u : 1u)) != 0;
-            far = (f & (DIFF ? 8u : 4u)) != 0 && !(DIRECT && !S.hide_emitters);   // (a visible environment is not zero)
+            skip_trace = (f & (DIFF ? DSDF_PX_EMPTY_G : DSDF_PX_EMPTY)) != 0;
+            far = (f & (DIFF ? DSDF_PX_FAR_G : DSDF_PX_FAR)) != 0 && !(DIRECT && !S.hide_emitters);   // (a visible environment is not zero)
+            known_hit = !DIFF && !DIRECT && (f & DSDF_PX_HIT) && A.integrator == DSDF_SILHOUETTE;      // (hit proof, dsdf_proof.h)
         }
         if (py < M.row0 || py >= M.row1) { far = true; valid = false; }         // outside this call's row window
     }
@@ -486,7 +492,8 @@ __global__ __launch_bounds__(DSDF_BLOCK) void k_render_pass(GridView G, dsdf_par
     if (windowed) tile_window_clear<NCH>(TW, lid);
     if (!far) {
         L = lane_setup(A, P, lane);
-        if (!skip_trace) {
+        if (known_hit) tr.its_t = 0.f;
+        else if (!skip_trace) {
             if (DIFF) trace_diff(G, P, L.ray.o, L.ray.d, L.ray.maxt, tr);
             else if (!DIRECT) {
                 // the pass ends with its longest rays, a few lanes sliding along a surface in sub-voxel steps: they keep the
@@ -891,7 +898,7 @@ void dsdf_default_params(dsdf_params *p) {
 size_t dsdf_padded_size(int rx, int ry, int rz) {
     size_t n = padded_floats(rx, ry, rz);
     for (int l = 0; l < DSDF_COARSE_LEVELS; ++l) n += 2 * coarse_cells(rx, ry, rz, l);
-    return n;
+    return n + 2 * hit_cells(rx, ry, rz);
 }
 
 int dsdf_pad_grid(const float *data, int rx, int ry, int rz, float *padded, void *stream) {
@@ -901,19 +908,28 @@ int dsdf_pad_grid(const float *data, int rx, int ry, int rz, float *padded, void
     hipLaunchKernelGGL(k_pad_grid, dim3(grid), dim3(256), 0, (hipStream_t)stream, data, rx, ry, rz, padded);
     int rc = check_launch("k_pad_grid");
     if (rc) return rc;
-    // conservative min-grids for the empty-space proof
+    // conservative min-grids for the empty-space proof, max-grid for the hit proof
     float *c0 = padded + n;
     for (int l = 0; l < DSDF_COARSE_LEVELS; ++l) {
         int cx, cy, cz;
         coarse_dims(rx, ry, rz, l, cx, cy, cz);
         int nc = cx * cy * cz;
         float *c1 = c0 + nc;
-        hipLaunchKernelGGL(k_coarse_min, dim3((nc + 63) / 64), dim3(64), 0, (hipStream_t)stream, data, rx, ry, rz, c0, cx, cy, cz,
+        hipLaunchKernelGGL(k_coarse_reduce<false>, dim3((nc + 63) / 64), dim3(64), 0, (hipStream_t)stream, data, rx, ry, rz, c0, cx, cy, cz,
                            1 << DSDF_COARSE_SHIFT(l));
-        hipLaunchKernelGGL(k_coarse_dilate, dim3((nc + 63) / 64), dim3(64), 0, (hipStream_t)stream, c0, c1, cx, cy, cz);
+        hipLaunchKernelGGL(k_coarse_dilate<false>, dim3((nc + 63) / 64), dim3(64), 0, (hipStream_t)stream, c0, c1, cx, cy, cz, 1);
         c0 = c1 + nc;
     }
-    return check_launch("k_coarse_min/dilate");
+    {
+        int cx, cy, cz;
+        hit_dims(rx, ry, rz, cx, cy, cz);
+        int nc = cx * cy * cz;
+        float *c1 = c0 + nc;
+        hipLaunchKernelGGL(k_coarse_reduce<true>, dim3((nc + 255) / 256), dim3(256), 0, (hipStream_t)stream, data, rx, ry, rz, c0, cx, cy, cz,
+                           1 << DSDF_HIT_SHIFT);
+        hipLaunchKernelGGL(k_coarse_dilate<true>, dim3((nc + 255) / 256), dim3(256), 0, (hipStream_t)stream, c0, c1, cx, cy, cz, DSDF_HIT_RADIUS);
+    }
+    return check_launch("k_coarse_reduce/dilate");
 }
 
 int dsdf_eval_cubic(const float *padded, int rx, int ry, int rz, const dsdf_params *prm, const float *points,
@@ -1101,6 +1117,7 @@ struct SkipShare {
     hipEvent_t ready = nullptr;
     const float *padded = nullptr;
     int rx = 0, ry = 0, rz = 0, W = 0, H = 0, nv = 0;
+    int hit_proof = 0;     // the flags carry DSDF_PX_HIT (silhouette integrator, hit proof not disabled)
     dsdf_params prm;
     dsdf_camera cams[DSDF_MAX_BATCH];
 };
@@ -1108,6 +1125,7 @@ static thread_local SkipShare t_share;
 
 static bool skip_share_matches(const SkipShare &h, const PassCtx &c, const dsdf_camera *cams, int nv) {
     return h.valid && h.padded == c.padded && h.rx == c.rx && h.ry == c.ry && h.rz == c.rz && h.W == c.W && h.H == c.H && h.nv == nv &&
+           h.hit_proof == (int)(c.integrator == DSDF_SILHOUETTE && !(c.flags & DSDF_NO_HIT_PROOF)) &&
            memcmp(&h.prm, c.prm, sizeof(dsdf_params)) == 0 && memcmp(h.cams, cams, (size_t)nv * sizeof(dsdf_camera)) == 0;
 }
 
@@ -1136,14 +1154,18 @@ static int run_pass(const PassCtx &c, const Workspace &ws, const dsdf_camera *ca
             skip = sh.buf;
         } else {
             unsigned char *dst = (can_share && !sh.valid) ? sh.buf : ws.skip;       // (a second, different batch keeps its own flags)
+            // (the hit proof serves the silhouette integrator, which consumes nothing but the hit flag of a sample)
+            const float hstep = (c.integrator == DSDF_SILHOUETTE && !(c.flags & DSDF_NO_HIT_PROOF)) ? hit_step(cams + v0, nv, c.W, c.rx, c.ry, c.rz) : 0.f;
             hipLaunchKernelGGL(k_pixel_skip, dim3((unsigned)((npix + 255) / 256), nv), dim3(256), 0, st,
-                               device_view(c.padded, c.rx, c.ry, c.rz, *c.prm, level), c.pp, VB, dst, step);
+                               device_view(c.padded, c.rx, c.ry, c.rz, *c.prm), min_bounds(c.padded, c.rx, c.ry, c.rz, level),
+                               max_bounds(c.padded, c.rx, c.ry, c.rz), c.pp, VB, dst, step, hstep);
             if ((rc = check_launch("k_pixel_skip"))) return rc;
             hipLaunchKernelGGL(k_skip_dilate, dim3((unsigned)((npix + 255) / 256), nv), dim3(256), 0, st, VB, dst);
             if ((rc = check_launch("k_skip_dilate"))) return rc;
             if (dst == sh.buf) {
                 if (hipEventRecord(sh.ready, st) != hipSuccess) return fail(DSDF_ERR_LAUNCH, "hipEventRecord(shared skip flags) failed");
                 sh.valid = true; sh.padded = c.padded; sh.rx = c.rx; sh.ry = c.ry; sh.rz = c.rz; sh.W = c.W; sh.H = c.H; sh.nv = nv;
+                sh.hit_proof = (int)(c.integrator == DSDF_SILHOUETTE && !(c.flags & DSDF_NO_HIT_PROOF));
                 sh.prm = *c.prm;
                 memcpy(sh.cams, cams + v0, (size_t)nv * sizeof(dsdf_camera));
             }
@@ -1156,7 +1178,7 @@ static int run_pass(const PassCtx &c, const Workspace &ws, const dsdf_camera *ca
     if (c.spp % 64 == 0) {
         // persistent workers over the compacted list of pixels that must be sampled
         // (sdf_direct_reparam with a visible environment: the background is not zero, every pixel is sampled)
-        const unsigned far_bit = (c.direct && !S.hide_emitters) ? 0u : (DIFF ? 8u : 4u);
+        const unsigned far_bit = (c.direct && !S.hide_emitters) ? 0u : (DIFF ? DSDF_PX_FAR_G : DSDF_PX_FAR);
         if (hipMemsetAsync(ws.items, 0, (size_t)DSDF_MAX_GROUPS * DSDF_ITEM_HDR * sizeof(uint32_t), st) != hipSuccess)
             return fail(DSDF_ERR_LAUNCH, "hipMemsetAsync(work list) failed");
         // tile-major order: a tile = DSDF_ITEM_SEG chunks of 64 samples (16 x 16 pixels at 256 spp, 32 x 32 at 64 spp)

@@ -74,8 +74,6 @@ struct GridView {
     float frx, fry, frz;   // the resolution as floats (kernel arguments: they stay in SGPRs; converting in the kernel made
                            // them VGPR values that were spilled and re-loaded inside the march loop)
     float tx, ty, tz;   // sdf.p translation
-    const float *coarse;   // (cz,cy,cx) dilated block minima of ONE level (device only; nullptr = absent)
-    int cx, cy, cz, cshift;   // blocks per axis, log2(voxels per block)
 };
 
 DSDF_HD GridView make_view(const float *padded, int rx, int ry, int rz, const dsdf_params &prm) {
@@ -84,8 +82,6 @@ DSDF_HD GridView make_view(const float *padded, int rx, int ry, int rz, const ds
     g.sx = rx + 2 * DSDF_APRON; g.sxy = g.sx * (ry + 2 * DSDF_APRON);
     g.frx = (float)rx; g.fry = (float)ry; g.frz = (float)rz;
     g.tx = prm.sdf_p[0]; g.ty = prm.sdf_p[1]; g.tz = prm.sdf_p[2];
-    g.cx = g.cy = g.cz = 0; g.cshift = 0;
-    g.coarse = nullptr;
     return g;
 }
 

@@ -12,9 +12,14 @@
 // diff_march_step; bit-identical to the closed loops, tests/test_kernel_math_host.py), adds the sample's film value and, in
 // the gradient pass, appends it to the backward queue.
 //
-// A tail kernel is bound by the LATENCY of its longest rays (1000+ dependent steps on an otherwise empty chip), so the
-// host side (run_pass, dsdf_kernels.hip) cuts a launch into view groups and runs the tail kernel of group g on a helper
-// stream beside the main kernel of group g + 1; only the last group's tail is exposed.
+// A tail kernel is bound by the LATENCY of its longest rays (1000+ dependent steps on an otherwise empty chip).  Round 3's
+// counters (profiles/r03_sq.json) showed what made every one of those steps slow: sub-queue = work-list index % 64 meant that a
+// tail wave drained rays of all 8 tiles in flight (one per XCD) and of all views -- 51 % L2 misses, 9.95 GB fetched per launch,
+// where the render kernel keeps ONE tile per XCD in its L2.  The sub-queues are now per XCD: a render wave appends to queue
+// (its XCC_ID, its ticket counter), i.e. in the order in which its XCD walks the tiles, and a tail block drains the queues of
+// the XCD it runs on first (then helps the others: every queue is drained whatever the block -> XCD mapping is).
+// (The host side can still cut a launch into view groups with the tail kernel of group g on a helper stream beside the render
+// kernel of group g + 1 -- DSDF_GROUPS; measured slower than one group, profiles/r03a_tail_ab.md.)
 #pragma once
 
 #ifndef DSDF_TAIL_HANDOFF
@@ -29,7 +34,7 @@
 #ifndef DSDF_PTAIL_GRACE
 #define DSDF_PTAIL_GRACE 4
 #endif
-#define DSDF_TAIL_SUBQ 64           /* sub-queues per launch: spreads the reservation atomics */
+#define DSDF_TAIL_SUBQ 64           /* sub-queues per launch: 8 per XCD (one per ticket counter of the render kernel's XCD share) */
 #define DSDF_TAIL_REFILL 24         /* idle lanes that trigger a refill in the tail kernels */
 #ifndef DSDF_TAIL_BLOCKS_PER_SUBQ
 #define DSDF_TAIL_BLOCKS_PER_SUBQ 16   /* x 4 waves: 4096 persistent tail waves */
@@ -38,41 +43,76 @@
 #define DSDF_PTAIL_WORDS 3          /* primal: view, sample id, t (everything else follows from the sample id) */
 #define DSDF_TAIL_HANDOFF_MAX (DSDF_TAIL_HANDOFF > DSDF_PTAIL_HANDOFF ? DSDF_TAIL_HANDOFF : DSDF_PTAIL_HANDOFF)
 
+// The XCD this wave runs on (gfx942 / gfx950: XCC_ID, bits 3:0).  Producers and consumers index the tail queues with it, so
+// rays are resumed under the L2 that holds their part of the grid.
+__device__ __forceinline__ uint32_t xcc_id() {
+    uint32_t v;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
+    return v & 7u;
+}
+// sub-queue of a render worker / first sub-queue of a tail block: (XCD, blockIdx.x / 8 mod 8)
+__device__ __forceinline__ uint32_t tail_subq() { return (xcc_id() << 3) | ((blockIdx.x >> 3) & 7u); }
+// k-th sub-queue a tail block visits: the 8 queues of its own XCD first, then the other XCDs'
+__device__ __forceinline__ uint32_t tail_hop(uint32_t first, uint32_t k) {
+    return ((((first >> 3) + (k >> 3)) & 7u) << 3) | ((first + k) & 7u);
+}
+
 struct TailQueue {
     uint32_t *count;   // [DSDF_TAIL_SUBQ][2]: {queued, claimed}
     float *state;      // [DSDF_TAIL_SUBQ][cap_sub][words] march states
     uint32_t cap_sub;
 };
 
-// one reservation per wave in sub-queue `sub`; returns this lane's entry index (valid for the lanes of `m`)
-__device__ __forceinline__ uint32_t tail_reserve(const TailQueue &tq, uint32_t sub, uint64_t m) {
-    uint32_t base = 0;
+// One reservation per wave in sub-queue `sub`: `n` consecutive entries, or nothing when they do not fit (compare-and-swap, so a
+// failed attempt leaves the counter untouched and the reserved ranges stay contiguous below the capacity).  A per-XCD queue
+// has no a-priori bound on its share of the hand-offs (workers help other XCDs' shares), hence the check; capacity is the
+// worst case of an even split (8 rays per chunk) while 1-4 % of that is used.  Returns true and the first entry in `base`.
+__device__ __forceinline__ bool tail_reserve(const TailQueue &tq, uint32_t sub, uint64_t m, uint32_t &base) {
     const int leader = __builtin_ctzll(m);
-    if (lane_id() == leader) base = atomicAdd(tq.count + 2 * sub, (uint32_t)__popcll(m));
-    base = (uint32_t)__builtin_amdgcn_readlane((int)base, leader);
-    return base + mask_prefix(m);
+    const uint32_t n = (uint32_t)__popcll(m);
+    uint32_t b = 0;
+    int ok = 0;
+    if (lane_id() == leader) {
+        uint32_t *p = tq.count + 2 * sub;
+        uint32_t old = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        while (old + n <= tq.cap_sub) {
+            const uint32_t prev = atomicCAS(p, old, old + n);
+            if (prev == old) { ok = 1; break; }
+            old = prev;
+        }
+        b = old;
+    }
+    base = (uint32_t)__builtin_amdgcn_readlane((int)b, leader);
+    return __builtin_amdgcn_readlane(ok, leader) != 0;
 }
 
 // Loop control of trace_diff / trace_plain (dsdf_math.h): stop when at most HANDOFF rays of the wave are still marching and
-// GRACE more iterations have passed; export the state of the rays that are still active at once -- one reservation per wave
-// -- so that the words die before the refinement loop of the finished rays.
+// GRACE more iterations have passed; the entries are reserved at that moment (a wave whose queue is full marches on to the end
+// instead), and the state of the rays that are still active is exported right after the loop -- so that the words die before
+// the refinement loop of the finished rays.
 template <int HANDOFF, int GRACE>
 struct HandOffCtl {
     TailQueue tq;
     uint32_t sub, view, lane;
     int low = 0;       // iterations spent at or below the threshold (wave-uniform)
+    bool full = false; // the reservation failed: no hand-off for this wave
+    uint32_t base = 0; // first reserved entry (valid once more() has returned false with active rays left)
     template <class Fetch> __device__ __forceinline__ bool more(const Fetch &, bool active) {
-        const int n = __popcll(__ballot(active));
+        const uint64_t m = __ballot(active);
+        const int n = __popcll(m);
         if (n > HANDOFF) return true;
-        return n != 0 && low++ < GRACE;
+        if (n == 0) return false;
+        if (full || low++ < GRACE) return true;
+        if (tail_reserve(tq, sub, m, base)) return false;
+        full = true;
+        return true;
     }
     __device__ __forceinline__ void leftover(bool active, float t, float warp_t, float prev_sd, float wsum, float ews, V3 t_d,
                                              V3 prev_gc, V3 mixed, V3 wdsum, V3 ews_d, int i) const {
         const uint64_t m = __ballot(active);
         if (m == 0) return;
-        const uint32_t idx = tail_reserve(tq, sub, m);
         if (active) {
-            float *e = tq.state + ((size_t)sub * tq.cap_sub + idx) * DSDF_TAIL_WORDS;
+            float *e = tq.state + ((size_t)sub * tq.cap_sub + (base + mask_prefix(m))) * DSDF_TAIL_WORDS;
             e[0] = __uint_as_float(view); e[1] = __uint_as_float(lane);
             e[2] = t; e[3] = warp_t; e[4] = prev_sd; e[5] = wsum; e[6] = ews;
             e[7] = t_d.x; e[8] = t_d.y; e[9] = t_d.z;
@@ -86,9 +126,8 @@ struct HandOffCtl {
     __device__ __forceinline__ void leftover_plain(bool active, float t) const {
         const uint64_t m = __ballot(active);
         if (m == 0) return;
-        const uint32_t idx = tail_reserve(tq, sub, m);
         if (active) {
-            float *e = tq.state + ((size_t)sub * tq.cap_sub + idx) * DSDF_PTAIL_WORDS;
+            float *e = tq.state + ((size_t)sub * tq.cap_sub + (base + mask_prefix(m))) * DSDF_PTAIL_WORDS;
             e[0] = __uint_as_float(view); e[1] = __uint_as_float(lane); e[2] = t;
         }
     }
@@ -122,11 +161,22 @@ __device__ __forceinline__ void tail_stats(unsigned long long *stats, int lane_s
 // Resumes the queued rays of the gradient sweep and finishes their samples: value splat, backward-queue entry.
 __global__ __launch_bounds__(256) void k_tail_trace_diff(GridView G, dsdf_params P, ViewBatch VB, float *__restrict__ blocks,
                                                          TailQueue tq, Queue qall, unsigned long long *stats) {
-    const uint32_t sub = blockIdx.x % DSDF_TAIL_SUBQ;
-    uint32_t *cnt = tq.count + 2 * sub;
-    const float *ent = tq.state + (size_t)sub * tq.cap_sub * DSDF_TAIL_WORDS;
-    const uint32_t total = cnt[0];
-    if (total == 0) return;
+    const uint32_t first = tail_subq();
+    uint32_t hop = 0, total = 0;
+    uint32_t *cnt = nullptr;
+    const float *ent = nullptr;
+    // opens the next non-empty sub-queue; false when all DSDF_TAIL_SUBQ have been visited
+    auto open_next = [&]() {
+        while (hop < DSDF_TAIL_SUBQ) {
+            const uint32_t sub = tail_hop(first, hop++);
+            cnt = tq.count + 2 * sub;
+            ent = tq.state + (size_t)sub * tq.cap_sub * DSDF_TAIL_WORDS;
+            total = (uint32_t)__builtin_amdgcn_readfirstlane((int)cnt[0]);
+            if (total != 0) return true;
+        }
+        return false;
+    };
+    if (!open_next()) return;
     DiffMarch m;
     m.active = false;
     Lane L;
@@ -137,9 +187,11 @@ __global__ __launch_bounds__(256) void k_tail_trace_diff(GridView G, dsdf_params
     while (true) {
         const uint64_t idle = __ballot(!m.active);
         if (!exhausted && __popcll(idle) >= DSDF_TAIL_REFILL) {
-            const uint32_t idx = tail_claim(cnt, total, idle, !m.active, exhausted);
+            bool drained = false;
+            const uint32_t idx = tail_claim(cnt, total, idle, !m.active, drained);
+            const float *e = ent + (size_t)idx * DSDF_TAIL_WORDS;       // (read below, before the queue is switched)
+            if (drained) exhausted = !open_next();                       // this queue is done: the next refill takes the next one
             if (idx != ~0u) {
-                const float *e = ent + (size_t)idx * DSDF_TAIL_WORDS;
                 view = __float_as_uint(e[0]);
                 sample = __float_as_uint(e[1]);
                 const ViewArgs &A = VB.v[view];
@@ -204,11 +256,21 @@ __global__ __launch_bounds__(256) void k_tail_trace_diff(GridView G, dsdf_params
 // gathers only on entering another cell -- the step is then a dependent ALU chain without a memory round trip.
 __global__ __launch_bounds__(256) void k_tail_trace_plain(GridView G, dsdf_params P, ViewBatch VB, float *__restrict__ blocks,
                                                           TailQueue tq, unsigned long long *stats) {
-    const uint32_t sub = blockIdx.x % DSDF_TAIL_SUBQ;
-    uint32_t *cnt = tq.count + 2 * sub;
-    const float *ent = tq.state + (size_t)sub * tq.cap_sub * DSDF_PTAIL_WORDS;
-    const uint32_t total = cnt[0];
-    if (total == 0) return;
+    const uint32_t first = tail_subq();
+    uint32_t hop = 0, total = 0;
+    uint32_t *cnt = nullptr;
+    const float *ent = nullptr;
+    auto open_next = [&]() {
+        while (hop < DSDF_TAIL_SUBQ) {
+            const uint32_t sub = tail_hop(first, hop++);
+            cnt = tq.count + 2 * sub;
+            ent = tq.state + (size_t)sub * tq.cap_sub * DSDF_PTAIL_WORDS;
+            total = (uint32_t)__builtin_amdgcn_readfirstlane((int)cnt[0]);
+            if (total != 0) return true;
+        }
+        return false;
+    };
+    if (!open_next()) return;
     PlainMarch m;
     m.active = false;
     Lane L;
@@ -220,9 +282,11 @@ __global__ __launch_bounds__(256) void k_tail_trace_plain(GridView G, dsdf_param
     while (true) {
         const uint64_t idle = __ballot(!m.active);
         if (!exhausted && __popcll(idle) >= DSDF_TAIL_REFILL) {
-            const uint32_t idx = tail_claim(cnt, total, idle, !m.active, exhausted);
+            bool drained = false;
+            const uint32_t idx = tail_claim(cnt, total, idle, !m.active, drained);
+            const float *e = ent + (size_t)idx * DSDF_PTAIL_WORDS;      // (read below, before the queue is switched)
+            if (drained) exhausted = !open_next();
             if (idx != ~0u) {
-                const float *e = ent + (size_t)idx * DSDF_PTAIL_WORDS;
                 view = __float_as_uint(e[0]);
                 L = lane_setup(VB.v[view], P, __float_as_uint(e[1]));
                 m = plain_march_begin(P, L.ray.o, L.ray.d, L.ray.maxt);

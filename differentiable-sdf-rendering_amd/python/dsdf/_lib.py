@@ -15,6 +15,7 @@ DSDF_SIMPLE_SHADING = 1
 DSDF_DIRECT = 2
 DSDF_REPARAM = 1
 DSDF_NO_SKIP = 2
+DSDF_NO_HIT_PROOF = 4
 
 
 class DsdfCamera(C.Structure):

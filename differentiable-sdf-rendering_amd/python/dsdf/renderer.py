@@ -14,7 +14,7 @@ import os
 import torch
 
 from . import _lib
-from ._lib import (DSDF_DIRECT, DSDF_NO_SKIP, DSDF_REPARAM, DSDF_SILHOUETTE, DSDF_SIMPLE_SHADING, DsdfCamera,
+from ._lib import (DSDF_DIRECT, DSDF_NO_HIT_PROOF, DSDF_NO_SKIP, DSDF_REPARAM, DSDF_SILHOUETTE, DSDF_SIMPLE_SHADING, DsdfCamera,
                    DsdfShading)
 
 INTEGRATORS = {'sdf_silhouette_reparam': DSDF_SILHOUETTE, 'sdf_simple_shading_reparam': DSDF_SIMPLE_SHADING,
@@ -26,6 +26,13 @@ STAT_NAMES = ('lanes', 'bbox_lanes', 'steps', 'hits', 'refine_steps', 'warp_acti
 STAT_SLOTS = 16          # include/dsdf.h: DSDF_STAT_SLOTS
 
 _workspaces = {}
+
+
+def _proof_flags(empty_space_skip):
+    """True: both per-pixel proofs (csrc/dsdf_proof.h); 'empty-only': without the hit proof of the silhouette primal; False: none."""
+    if empty_space_skip == 'empty-only':
+        return DSDF_NO_HIT_PROOF
+    return 0 if empty_space_skip else DSDF_NO_SKIP
 
 # Views traced by one kernel launch (bounded by the workspace: the backward queue of a GRADIENT pass holds 40 B per
 # sample and view -- 16 views x 512^2 x 64 spp = 11 GB, cheap in 288 GB of HBM; a primal render carries no queue).
@@ -320,7 +327,7 @@ def render_forward(grid, sensors, spp, seeds=None, offsets=None, integrator=DSDF
     with torch.cuda.device(dev):
         _lib.check(lib.dsdf_render_forward(_ptr(grid.padded), grid.rx, grid.ry, grid.rz, C.byref(grid.params), cams, nv,
                                            W, H, int(spp), _ptr(offsets), cseeds, INTEGRATORS[integrator],
-                                           (DSDF_REPARAM if reparam else 0) | (0 if empty_space_skip else DSDF_NO_SKIP),
+                                           (DSDF_REPARAM if reparam else 0) | _proof_flags(empty_space_skip),
                                            sh, _ptr(img), _ptr(ws), wsb, _ptr(stats), _stream()))
     return img
 
@@ -358,7 +365,7 @@ def render_backward(grid, sensors, spp, grad_image, grad_grid=None, seeds=None, 
     with torch.cuda.device(dev):
         _lib.check(lib.dsdf_render_backward(_ptr(grid.padded), grid.rx, grid.ry, grid.rz, C.byref(grid.params), cams, nv,
                                             W, H, int(spp), _ptr(offsets), cseeds, INTEGRATORS[integrator],
-                                            (DSDF_REPARAM if reparam else 0) | (0 if empty_space_skip else DSDF_NO_SKIP),
+                                            (DSDF_REPARAM if reparam else 0) | _proof_flags(empty_space_skip),
                                             sh, _ptr(grad_image), _ptr(grad_grid), _ptr(grad_p),
                                             _ptr(img), _ptr(ws), wsb, _ptr(stats), _stream()))
     return (grad_grid, img) if return_image else grad_grid
@@ -396,7 +403,7 @@ def render_forward_grad(grid, sensors, spp, tangent_data=None, tangent_p=None, s
     with torch.cuda.device(dev):
         _lib.check(lib.dsdf_render_forward_grad(_ptr(grid.padded), grid.rx, grid.ry, grid.rz, C.byref(grid.params), cams, nv,
                                                 W, H, int(spp), _ptr(offsets), cseeds, INTEGRATORS[integrator],
-                                                (DSDF_REPARAM if reparam else 0) | (0 if empty_space_skip else DSDF_NO_SKIP), sh,
+                                                (DSDF_REPARAM if reparam else 0) | _proof_flags(empty_space_skip), sh,
                                                 _ptr(tpad), tp, _ptr(out), _ptr(img), _ptr(ws), wsb, _stream()))
     return (out, img) if return_image else out
 
@@ -427,7 +434,7 @@ def render_film(grid, sensors, spp, film, rows, seeds=None, offsets=None, integr
     with torch.cuda.device(dev):
         _lib.check(lib.dsdf_render_film(_ptr(grid.padded), grid.rx, grid.ry, grid.rz, C.byref(grid.params), cams, nv, W, H, int(spp),
                                         _ptr(offsets), cseeds, INTEGRATORS[integrator],
-                                        (DSDF_REPARAM if reparam else 0) | (0 if empty_space_skip else DSDF_NO_SKIP), sh,
+                                        (DSDF_REPARAM if reparam else 0) | _proof_flags(empty_space_skip), sh,
                                         int(rows[0]), int(rows[1]), _ptr(film), _ptr(ws), ws.numel(), _ptr(stats), _stream()))
     return film
 
@@ -468,7 +475,7 @@ class GradSweep:
         n_lanes = (self.W + 4) * (self.H + 4) * self.spp
         self.offsets, self.cseeds = _sampler_args(self.nv, seeds, offsets, n_lanes)
         self.integrator = INTEGRATORS[integrator]
-        self.flags = (DSDF_REPARAM if reparam else 0) | (0 if empty_space_skip else DSDF_NO_SKIP)
+        self.flags = (DSDF_REPARAM if reparam else 0) | _proof_flags(empty_space_skip)
         self.rows = (int(rows[0]), int(rows[1]))
         self.sh, self._keep = _shading_arg(integrator, shading, self.nv, n_lanes, emitter_samples, grad_albedo)
         wsb = int(self.lib.dsdf_render_workspace_size(self.W, self.H, self.spp, self.nv, self.integrator))

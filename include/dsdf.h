@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define DSDF_VERSION 303   /* 300: stats rows of DSDF_STAT_SLOTS (16) counters; tail hand-off on library-owned helper streams */
+#define DSDF_VERSION 304   /* 300: stats rows of DSDF_STAT_SLOTS (16) counters; tail hand-off on library-owned helper streams */
 #define DSDF_STAT_SLOTS 16
 
 enum dsdf_status {
@@ -49,7 +49,8 @@ enum dsdf_integrator {
  * without it the DummyWarpField path is taken (python/warp.py:179-196). */
 enum dsdf_flags {
     DSDF_REPARAM = 1,
-    DSDF_NO_SKIP = 2   /* disable the exact per-pixel empty-space proof (A/B and testing) */
+    DSDF_NO_SKIP = 2,        /* disable the exact per-pixel proofs (empty space and hit; A/B and testing) */
+    DSDF_NO_HIT_PROOF = 4    /* keep the empty-space proof, disable the hit proof of the silhouette primal (csrc/dsdf_proof.h) */
 };
 
 /* Perspective sensor as built by python/util.py:115-138 (`get_regular_cameras`):

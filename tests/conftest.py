@@ -230,6 +230,23 @@ class HostHarness:
         self.lib.hh_sampler_emitter(C.c_uint(seed), C.c_long(n), self._p(out))
         return out
 
+    def pixel_proof(self, grid, cam, W, H):
+        """flags (H+4, W+4) of dsdf_proof.h for every film-block pixel + (empty-proof step, hit-proof step, coarse level)."""
+        grid = np.ascontiguousarray(grid, np.float32)
+        flags = np.zeros((H + 4, W + 4), np.uint8)
+        info = np.zeros(3, np.float32)
+        rz, ry, rx = grid.shape
+        self.lib.hh_pixel_proof(self._p(grid), rx, ry, rz, C.byref(self.params), self._p(cam), W, H, self._p(flags), self._p(info))
+        return flags, info
+
+    def trace_hits(self, grid, cam, W, H, spp, seed=0):
+        """hit flag of every film sample (H+4, W+4, spp) as the value-only march finds it."""
+        grid = np.ascontiguousarray(grid, np.float32)
+        hits = np.zeros((H + 4, W + 4, spp), np.uint8)
+        rz, ry, rx = grid.shape
+        self.lib.hh_trace_hits(self._p(grid), rx, ry, rz, C.byref(self.params), self._p(cam), W, H, spp, C.c_uint(seed), self._p(hits))
+        return hits
+
     def sampler(self, seed, n):
         out = np.zeros((n, 2), np.float32)
         self.lib.hh_sampler(C.c_uint(seed), C.c_long(n), self._p(out))

@@ -430,6 +430,41 @@ def test_empty_space_skip_is_exact(dsdf, integ, R, W):
     assert rel_l2(c.cpu(), d.cpu()) < 1e-6
 
 
+@pytest.mark.parametrize('spp', [4, 64, 256])
+def test_hit_proof_is_exact(dsdf, spp):
+    """The hit proof of the silhouette primal (csrc/dsdf_proof.h: pixels whose every sample provably hits are not marched) must not
+    change any result: the SAME number of hits and the same image as with the empty-space proof alone and as without any proof
+    -- through the work-list kernel (spp 64 / 256) and the general pass (spp 4) -- while far fewer steps are traced.  The other
+    integrators consume the hit distance and must not be affected at all."""
+    R, W = 96, 256
+    lin = torch.linspace(0, 1, R)
+    z, y, x = torch.meshgrid(lin, lin, lin, indexing='ij')
+    blob = torch.minimum(torch.sqrt((x - .45) ** 2 + (y - .5) ** 2 + (z - .5) ** 2) - 0.25,
+                         torch.sqrt((x - .68) ** 2 + (y - .42) ** 2 + (z - .55) ** 2) - 0.12)
+    grid = dsdf.SdfGrid(blob.float().cuda())
+    sens = dsdf.get_regular_cameras(6, resx=W, resy=W)[1:4]
+    seeds = [7, 8, 9]
+    st = {m: dsdf.new_stats('cuda') for m in ('all', 'empty', 'none')}
+    a = dsdf.render_forward(grid, sens, spp, seeds=seeds, stats=st['all'])
+    b = dsdf.render_forward(grid, sens, spp, seeds=seeds, stats=st['empty'], empty_space_skip='empty-only')
+    c = dsdf.render_forward(grid, sens, spp, seeds=seeds, stats=st['none'], empty_space_skip=False)
+    d = {m: dsdf.stats_dict(v) for m, v in st.items()}
+    assert d['all']['hits'] == d['empty']['hits'] == d['none']['hits'] > 0
+    assert d['all']['lanes'] == d['empty']['lanes']
+    assert rel_l2(a.cpu(), b.cpu()) < 1e-6 and rel_l2(a.cpu(), c.cpu()) < 1e-6
+    assert d['all']['all_steps'] < 0.6 * d['empty']['all_steps'], (d['all']['all_steps'], d['empty']['all_steps'])
+    # simple shading needs the hit distance: identical step counts with and without the flag
+    sa, sb = dsdf.new_stats('cuda'), dsdf.new_stats('cuda')
+    e = dsdf.render_forward(grid, sens, spp, seeds=seeds, integrator=O.SIMPLE_SHADING, stats=sa)
+    f = dsdf.render_forward(grid, sens, spp, seeds=seeds, integrator=O.SIMPLE_SHADING, stats=sb, empty_space_skip='empty-only')
+    assert dsdf.stats_dict(sa)['all_steps'] == dsdf.stats_dict(sb)['all_steps'] and rel_l2(e.cpu(), f.cpu()) < 1e-6
+    # the gradient pass is untouched by the proof (it needs the warp of every traced sample)
+    gi = torch.randn(3, W, W, 3, device='cuda')
+    ga = dsdf.render_backward(grid, sens, spp, gi, seeds=seeds)
+    gb = dsdf.render_backward(grid, sens, spp, gi, seeds=seeds, empty_space_skip='empty-only')
+    assert rel_l2(ga.cpu(), gb.cpu()) < 1e-5
+
+
 def test_maximum_grid_size_512(dsdf):
     """BASELINE.json's largest grid (512^3 = 537 MB padded): indexing stays in range, and the image
     of an analytic sphere agrees with the same sphere sampled at 128^3 (the half-voxel convention shifts
