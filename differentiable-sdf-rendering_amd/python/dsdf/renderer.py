@@ -450,7 +450,7 @@ def develop(film, W, H, integrator=DSDF_SILHOUETTE):
     return img
 
 
-_sweep_workspaces = {}
+_sweep_workspaces = {}        # device -> {'ws': uint8 tensor, 'leased': bool}  (step_begin / step_finish)
 
 
 class GradSweep:
@@ -469,6 +469,8 @@ class GradSweep:
                  empty_space_skip=True, shading=None, emitter_samples=None, grad_albedo=None, workspace=None):
         self.lib = _lib.load()
         self.grid = grid
+        # the parameter block as it is NOW (sdf.p, warp settings): backward() may run after the caller touched grid.params
+        self.params = type(grid.params).from_buffer_copy(grid.params)
         self.sensors, self.cams, self.W, self.H = _views(sensors)
         self.nv = len(self.sensors)
         self.spp = int(spp)
@@ -487,7 +489,7 @@ class GradSweep:
 
     def _args(self):
         g = self.grid
-        return (_ptr(g.padded), g.rx, g.ry, g.rz, C.byref(g.params), self.cams, self.nv, self.W, self.H, self.spp,
+        return (_ptr(g.padded), g.rx, g.ry, g.rz, C.byref(self.params), self.cams, self.nv, self.W, self.H, self.spp,
                 _ptr(self.offsets), self.cseeds, self.integrator, self.flags, self.sh)
 
     def sweep(self, film):
@@ -542,22 +544,35 @@ _side_streams = {}
 _skip_buffers = {}
 
 
-def render_step(grid, sensors, spp, spp_grad, loss_grad, grad_grid, seeds, seeds_grad, integrator=DSDF_SILHOUETTE, reparam=True,
-                shading=None, grad_albedo=None, grad_p=None, overlap=True):
-    """One differentiable render step (python/shape_opt.py:77-83 for a batch of views): primal render at `spp`, image
-    gradient `loss_grad(images)`, gradient pass at `spp_grad` accumulating into `grad_grid` -- the same three library calls as
-    render_forward + render_backward, scheduled on TWO HIP streams: the forward sweep of the gradient pass (tracing, film,
-    backward queue: dsdf_grad_sweep) does not depend on the image gradient, so it runs on a side stream concurrently with the
-    primal render; only the backward proper (dsdf_grad_backward) waits for both.  The latency-bound ends of the two passes
-    (a handful of 1000-step grazing rays each) then overlap with the other pass' bulk.  Returns the images."""
+class StepHandle:
+    """What step_begin leaves for step_finish: the gradient sweep (its workspace holds the backward queue and the adjoint
+    coefficients), its film, and the streams to join."""
+
+    def __init__(self, sweep, film_g, main, side, lease):
+        self.sweep, self.film_g, self.main, self.side, self.lease = sweep, film_g, main, side, lease
+        self.done = False
+
+
+def _lease_sweep_workspace(dev):
+    """The cached sweep workspace of `dev` unless a step that has begun and not yet finished still owns its queue."""
+    ent = _sweep_workspaces.get(dev)
+    if ent is None or ent['leased']:
+        return None, None
+    ent['leased'] = True
+    return ent['ws'], ent
+
+
+def step_begin(grid, sensors, spp, spp_grad, seeds, seeds_grad, integrator=DSDF_SILHOUETTE, reparam=True, shading=None,
+               grad_albedo=None):
+    """Forward half of one differentiable render step (python/shape_opt.py:77-80: `mi.render(..., seed, spp, seed_grad, spp_grad)`):
+    returns (images, handle).  The forward sweep of the gradient pass (tracing, film, backward queue, the image-independent half
+    of the adjoint: dsdf_grad_sweep) does not depend on the image gradient, so it is enqueued on a high-priority side stream
+    beside the primal render; both passes share one empty-space / hit proof (dsdf_share_pixel_skip).  step_finish(handle,
+    grad_image, ...) then runs what is left of the backward (dsdf_grad_backward).  This is the autograd boundary of the render
+    op: torch's forward() calls step_begin, backward() calls step_finish."""
     sensors = list(sensors) if isinstance(sensors, (list, tuple)) else [sensors]
     W, H = sensors[0].film_size()
     dev = grid.device
-    if not overlap:
-        img = render_forward(grid, sensors, spp, seeds=seeds, integrator=integrator, reparam=reparam, shading=shading)
-        render_backward(grid, sensors, spp_grad, loss_grad(img), grad_grid=grad_grid, seeds=seeds_grad, integrator=integrator,
-                        reparam=reparam, shading=shading, grad_albedo=grad_albedo, grad_p=grad_p)
-        return img
     main = torch.cuda.current_stream(dev)
     side = _side_streams.get(dev)
     if side is None:
@@ -565,34 +580,61 @@ def render_step(grid, sensors, spp, spp_grad, loss_grad, grad_grid, seeds, seeds
         # (a handful of 1000-step rays) runs beside the bulk of the primal pass instead of after it
         side = _side_streams[dev] = torch.cuda.Stream(dev, priority=-1)
     side.wait_stream(main)                                    # the grid (and whatever produced it) is ready
-    # one empty-space proof for both passes (dsdf_share_pixel_skip): the sweep writes the flags, the primal render reads them
+    # one per-pixel proof for both passes (dsdf_share_pixel_skip): the sweep writes the flags, the primal render reads them
     lib = _lib.load()
     nflag = len(sensors) * (W + 4) * (H + 4)
     flags = _skip_buffers.get(dev)
     if flags is None or flags.numel() < nflag:
         flags = _skip_buffers[dev] = torch.empty(nflag, dtype=torch.uint8, device=dev)
-    if os.environ.get('DSDF_SHARE_SKIP', '1') != '0':          # (A/B switch, tools/ab_step.py)
-        _lib.check(lib.dsdf_share_pixel_skip(_ptr(flags), flags.numel()))
-    try:
-        return _render_step_shared(grid, sensors, spp, spp_grad, loss_grad, grad_grid, seeds, seeds_grad, integrator, reparam, shading,
-                                   grad_albedo, grad_p, main, side, W, H, dev)
-    finally:
-        lib.dsdf_share_pixel_skip(None, 0)
+    with torch.cuda.device(dev):
+        if os.environ.get('DSDF_SHARE_SKIP', '1') != '0':          # (A/B switch, tools/ab_step.py)
+            _lib.check(lib.dsdf_share_pixel_skip(_ptr(flags), flags.numel()))
+        try:
+            ws, lease = _lease_sweep_workspace(dev)
+            with torch.cuda.stream(side):
+                sweep = GradSweep(grid, sensors, spp_grad, (0, H + 4), seeds=seeds_grad, integrator=integrator, reparam=reparam,
+                                  shading=shading, grad_albedo=grad_albedo, workspace=ws)
+                if sweep.ws is not None and sweep.ws is not ws:
+                    if lease is not None:
+                        lease['leased'] = False
+                    # (a larger / first buffer: it becomes the cached one, owned by this step until step_finish)
+                    lease = _sweep_workspaces[dev] = {'ws': sweep.ws, 'leased': True}
+                film_g = sweep.sweep(new_film(len(sensors), W, H, integrator, dev))
+            img = render_forward(grid, sensors, spp, seeds=seeds, integrator=integrator, reparam=reparam, shading=shading)
+        finally:
+            lib.dsdf_share_pixel_skip(None, 0)
+    return img, StepHandle(sweep, film_g, main, side, lease)
 
 
-def _render_step_shared(grid, sensors, spp, spp_grad, loss_grad, grad_grid, seeds, seeds_grad, integrator, reparam, shading,
-                        grad_albedo, grad_p, main, side, W, H, dev):
-    with torch.cuda.stream(side):
-        sweep = GradSweep(grid, sensors, spp_grad, (0, H + 4), seeds=seeds_grad, integrator=integrator, reparam=reparam,
-                          shading=shading, grad_albedo=grad_albedo, workspace=_sweep_workspaces.get(dev))
-        if sweep.ws is not None:
-            _sweep_workspaces[dev] = sweep.ws              # re-used by the next step's sweep (stream-ordered after this backward)
-        film_g = sweep.sweep(new_film(len(sensors), W, H, integrator, dev))
-    img = render_forward(grid, sensors, spp, seeds=seeds, integrator=integrator, reparam=reparam, shading=shading)
-    gi = loss_grad(img)
-    main.wait_stream(side)
-    film_g.record_stream(main); sweep.record_stream(main)
-    sweep.backward(film_g, gi.contiguous(), grad_grid, grad_p)
+def step_finish(handle, grad_image, grad_grid, grad_p=None):
+    """Backward half of the step: waits for the side stream and back-propagates the queued samples of the sweep against
+    `grad_image` (n,H,W,3) into grad_grid (and grad_p, and the albedo / roughness gradients the sweep was built with)."""
+    if handle.done:
+        raise _lib.DsdfError("step_finish: this step's backward queue was already consumed (retain_graph is not supported)")
+    cur = torch.cuda.current_stream(grad_grid.device)
+    cur.wait_stream(handle.side)
+    handle.film_g.record_stream(cur); handle.sweep.record_stream(cur)
+    handle.sweep.backward(handle.film_g, grad_image.contiguous(), grad_grid, grad_p)
+    handle.done = True
+    if handle.lease is not None:
+        handle.lease['leased'] = False        # (the next sweep is stream-ordered after this backward)
+    return grad_grid
+
+
+def render_step(grid, sensors, spp, spp_grad, loss_grad, grad_grid, seeds, seeds_grad, integrator=DSDF_SILHOUETTE, reparam=True,
+                shading=None, grad_albedo=None, grad_p=None, overlap=True):
+    """One differentiable render step (python/shape_opt.py:77-83 for a batch of views): primal render at `spp`, image
+    gradient `loss_grad(images)`, gradient pass at `spp_grad` accumulating into `grad_grid` -- the same three library calls as
+    render_forward + render_backward, scheduled on TWO HIP streams (step_begin / step_finish): only the backward proper
+    (dsdf_grad_backward) waits for both the primal image and the sweep.  Returns the images."""
+    sensors = list(sensors) if isinstance(sensors, (list, tuple)) else [sensors]
+    if not overlap:
+        img = render_forward(grid, sensors, spp, seeds=seeds, integrator=integrator, reparam=reparam, shading=shading)
+        render_backward(grid, sensors, spp_grad, loss_grad(img), grad_grid=grad_grid, seeds=seeds_grad, integrator=integrator,
+                        reparam=reparam, shading=shading, grad_albedo=grad_albedo, grad_p=grad_p)
+        return img
+    img, h = step_begin(grid, sensors, spp, spp_grad, seeds, seeds_grad, integrator, reparam, shading, grad_albedo)
+    step_finish(h, loss_grad(img), grad_grid, grad_p)
     return img
 
 
@@ -661,16 +703,15 @@ def stats_dict(stats):
 
 
 class _RenderOp(torch.autograd.Function):
-    """`mi.render`'s custom op: primal (seed, spp) without AD, backward via an
-    independent (seed_grad, spp_grad) gradient pass."""
+    """`mi.render`'s custom op: primal (seed, spp) without AD, backward via an independent (seed_grad, spp_grad) gradient
+    pass -- split at the autograd boundary like dsdf.render_step: forward() enqueues the primal render AND the image-independent
+    sweep of the gradient pass (two streams, step_begin), backward() only what needs the image gradient (step_finish)."""
 
     @staticmethod
     def forward(ctx, data, grid, sensors, spp, seed, spp_grad, seed_grad, integrator, reparam, p=None, albedo=None,
-                shading=None):
+                shading=None, roughness=None):
         if albedo is not None:
             shading = shading.with_albedo(albedo)
-        ctx.cfg = (grid, sensors, spp_grad, seed_grad, integrator, reparam)
-        ctx.shading = shading
         ctx.data_shape = data.shape
         ctx.p_meta = None if p is None else (p.shape, p.dtype, p.device)
         if not grid.in_sync_with(data):                      # the caller stepped `data` without grid.update(): rebuild the padded copy
@@ -678,25 +719,30 @@ class _RenderOp(torch.autograd.Function):
         if p is not None:
             grid.set_translation(p)
         n = len(sensors)
-        return render_forward(grid, sensors, spp, seeds=[seed + i for i in range(n)], integrator=integrator,
-                              reparam=reparam, shading=shading)
+        sh = shading
+        want_r = sh is not None and sh.roughness is not None and roughness is not None and ctx.needs_input_grad[12]
+        want_a = sh is not None and (ctx.needs_input_grad[10] or want_r)         # (the library scatters both volumes in one call)
+        ctx.ga = torch.zeros_like(sh.albedo.detach(), dtype=torch.float32).contiguous() if want_a else None
+        ctx.gr = None
+        if want_r:
+            ctx.gr = sh.grad_roughness = torch.zeros_like(sh.roughness.detach(), dtype=torch.float32).contiguous()
+        ctx.gp = torch.zeros(3, dtype=torch.float32, device=grid.device) if (p is not None and ctx.needs_input_grad[9]) else None
+        img, ctx.step = step_begin(grid, sensors, spp, spp_grad, [seed + i for i in range(n)], [seed_grad + i for i in range(n)],
+                                   integrator, reparam, sh, ctx.ga)
+        ctx.grid = grid
+        return img
 
     @staticmethod
     def backward(ctx, grad_out):
-        grid, sensors, spp_grad, seed_grad, integrator, reparam = ctx.cfg
-        n = len(sensors)
-        want_p = ctx.p_meta is not None and ctx.needs_input_grad[9]
-        gp = torch.zeros(3, dtype=torch.float32, device=grid.device) if want_p else None
-        sh = ctx.shading
-        want_a = sh is not None and ctx.needs_input_grad[10]
-        ga = torch.zeros_like(sh.albedo, dtype=torch.float32).contiguous() if want_a else None
-        g = render_backward(grid, sensors, spp_grad, grad_out.contiguous(), seeds=[seed_grad + i for i in range(n)],
-                            integrator=integrator, reparam=reparam, grad_p=gp, shading=sh, grad_albedo=ga)
-        if want_p:
+        g = torch.zeros(ctx.grid.shape, dtype=torch.float32, device=ctx.grid.device)
+        step_finish(ctx.step, grad_out, g, ctx.gp)
+        gp = ctx.gp
+        if gp is not None:
             shape, dtype, dev = ctx.p_meta
             gp = gp.to(device=dev, dtype=dtype).reshape(shape)
         return (g.reshape(ctx.data_shape) if ctx.needs_input_grad[0] else None, None, None, None, None, None, None,
-                None, None, gp, ga, None)
+                None, None, gp, ctx.ga if ctx.needs_input_grad[10] else None, None,
+                None if ctx.gr is None else ctx.gr)
 
 
 def render(data, grid, sensors, spp, seed=0, spp_grad=None, seed_grad=0, integrator=DSDF_SILHOUETTE, reparam=True,
@@ -706,5 +752,15 @@ def render(data, grid, sensors, spp, seed=0, spp_grad=None, seed_grad=0, integra
     translation `p` (3,) (`SamplingIntegrator.sdf.p`)."""
     sensors = list(sensors) if isinstance(sensors, (list, tuple)) else [sensors]
     albedo = shading.albedo if shading is not None else None      # attached when it requires grad (sdf_direct_reparam)
+    rough = shading.roughness if shading is not None else None    # ... and the principled roughness volume
+    attached = any(isinstance(t, torch.Tensor) and t.requires_grad for t in (data, p, albedo, rough))
+    if not (attached and torch.is_grad_enabled()):
+        # nothing to differentiate: a plain primal render (no gradient sweep is enqueued)
+        if not grid.in_sync_with(data):
+            grid.update(data)
+        if p is not None:
+            grid.set_translation(p)
+        return render_forward(grid, sensors, int(spp), seeds=[int(seed) + i for i in range(len(sensors))], integrator=integrator,
+                              reparam=reparam, shading=shading)
     return _RenderOp.apply(data, grid, sensors, int(spp), int(seed), int(spp_grad or spp), int(seed_grad),
-                           integrator, reparam, p, albedo, shading)
+                           integrator, reparam, p, albedo, shading, rough)

@@ -90,12 +90,16 @@ class ReparamIntegrator:
         self.warp_field = None
 
     # -- helpers -------------------------------------------------------------------------
+    @staticmethod
+    def _world_sensors(scene, sensor):
+        """The requested sensors as the scene holds them (world space): an index, a sensor or a list of either."""
+        items = list(sensor) if isinstance(sensor, (list, tuple)) else [sensor]
+        return [scene.sensors()[s] if isinstance(s, int) else s for s in items]
+
     def _sensors(self, scene, sensor):
-        """The requested sensors, seen from the SDF's own frame (Grid3d.local_sensor; the identity without a transform)."""
-        if isinstance(sensor, int):
-            sens = [scene.sensors()[sensor]]
-        else:
-            sens = list(sensor) if isinstance(sensor, (list, tuple)) else [sensor]
+        """The requested sensors, seen from the SDF's own frame (Grid3d.local_sensor; the identity without a transform).
+        Takes WORLD-space sensors: mapping a sensor that is already local would transform it twice."""
+        sens = self._world_sensors(scene, sensor)
         return [self.sdf.local_sensor(s) for s in sens] if self.sdf is not None else sens
 
     def _configured(self):
@@ -190,30 +194,35 @@ class ReparamIntegrator:
 
 
 class _RenderOp(torch.autograd.Function):
+    """The op behind `mi.render(scene, params, ...)`: forward() = primal render AND the image-independent sweep of the gradient
+    pass on two streams (dsdf.step_begin), backward() = the rest of the adjoint once the image gradient exists (dsdf.step_finish)
+    -- the schedule of dsdf.render_step, split at the autograd boundary (python/shape_opt.py:77-83: mi.render + dr.backward)."""
+
     @staticmethod
     def forward(ctx, data, albedo, roughness, scene, sensors, seed, spp, seed_grad, spp_grad):
         integ = scene.integrator()
-        ctx.args = (scene, sensors, seed_grad, spp_grad, data.shape)
         integ.sdf.set_data(data.detach())
         reparam = integ._configured()
-        return dsdf.render_forward(integ.sdf.grid, sensors, spp, seeds=[seed + i for i in range(len(sensors))],
-                                   integrator=integ.integrator_id, reparam=reparam, shading=integ.shading())
+        sh = integ.shading()
+        want_r = sh is not None and sh.roughness is not None and ctx.needs_input_grad[2]
+        want_a = sh is not None and (ctx.needs_input_grad[1] or want_r)          # (the library scatters both volumes in one call)
+        ctx.ga = torch.zeros_like(sh.albedo.detach(), dtype=torch.float32).contiguous() if want_a else None
+        ctx.gr = None
+        if want_r:
+            ctx.gr = sh.grad_roughness = torch.zeros_like(sh.roughness.detach(), dtype=torch.float32).contiguous()
+        n = len(sensors)
+        img, ctx.step = dsdf.step_begin(integ.sdf.grid, sensors, spp, spp_grad, [seed + i for i in range(n)],
+                                        [seed_grad + i for i in range(n)], integ.integrator_id, reparam, sh, ctx.ga)
+        ctx.meta = (data.shape, integ.sdf.grid)
+        return img
 
     @staticmethod
     def backward(ctx, grad_out):
-        scene, sensors, seed_grad, spp_grad, shape = ctx.args
-        integ = scene.integrator()
-        sh = integ.shading()
-        want_r = sh is not None and sh.roughness is not None and ctx.needs_input_grad[2]
-        want_a = sh is not None and (ctx.needs_input_grad[1] or want_r)
-        ga = torch.zeros_like(sh.albedo.detach(), dtype=torch.float32).contiguous() if want_a else None
-        if want_r:
-            sh.grad_roughness = torch.zeros_like(sh.roughness.detach(), dtype=torch.float32).contiguous()
-        g = dsdf.render_backward(integ.sdf.grid, sensors, spp_grad, grad_out.contiguous(),
-                                 seeds=[seed_grad + i for i in range(len(sensors))], integrator=integ.integrator_id,
-                                 reparam=integ._configured(), shading=sh, grad_albedo=ga)
-        return (g.reshape(shape) if ctx.needs_input_grad[0] else None, ga if ctx.needs_input_grad[1] else None,
-                sh.grad_roughness.reshape(sh.roughness.shape) if want_r else None, None, None, None, None, None, None)
+        shape, grid = ctx.meta
+        g = torch.zeros(grid.shape, dtype=torch.float32, device=grid.device)
+        dsdf.step_finish(ctx.step, grad_out, g)
+        return (g.reshape(shape) if ctx.needs_input_grad[0] else None, ctx.ga if ctx.needs_input_grad[1] else None,
+                None if ctx.gr is None else ctx.gr.reshape(ctx.gr.shape), None, None, None, None, None, None)
 
 
 def render(scene, params=None, sensor=0, seed=0, spp=4, seed_grad=0, spp_grad=None, integrator=None):
@@ -222,7 +231,6 @@ def render(scene, params=None, sensor=0, seed=0, spp=4, seed_grad=0, spp_grad=No
     result is attached to it and its backward runs an independent (seed_grad, spp_grad) gradient pass."""
     integ = scene.integrator()
     single = not isinstance(sensor, (list, tuple))
-    sens = integ._sensors(scene, sensor)
     data = params[SDF_DEFAULT_KEY] if params is not None and SDF_DEFAULT_KEY in params else None
     sh = integ.shading()
     albedo = sh.albedo if sh is not None else None
@@ -230,10 +238,13 @@ def render(scene, params=None, sensor=0, seed=0, spp=4, seed_grad=0, spp_grad=No
     attached = (data is not None and data.requires_grad) or (isinstance(albedo, torch.Tensor) and albedo.requires_grad) \
         or (isinstance(rough, torch.Tensor) and rough.requires_grad)
     if data is not None and attached and torch.is_grad_enabled():
-        img = _RenderOp.apply(data, albedo, rough, scene, sens, int(seed), int(spp), int(seed_grad), int(spp_grad or spp))
+        # (the op takes the sensors in the SDF's own frame; `integ.render` below maps its world-space sensors itself -- each
+        # consumer maps exactly once)
+        img = _RenderOp.apply(data, albedo, rough, scene, integ._sensors(scene, sensor), int(seed), int(spp), int(seed_grad),
+                              int(spp_grad or spp))
     else:
         with torch.no_grad():
             if data is not None:
                 integ.sdf.set_data(data.detach())
-            img = integ.render(scene, sens, seed=seed, spp=spp)
+            img = integ.render(scene, integ._world_sensors(scene, sensor), seed=seed, spp=spp)
     return img[0] if single else img

@@ -137,6 +137,17 @@ def test_transformed_grid_render_gpu(built, T, exact):
         # (a general rotation: the reference also marches through the corners of the world AABB outside the cube, where it
         # reads the clamped texture -- empty space, no hits, vanishing weights)
         assert e < (FWD_TOL if exact else 5e-4), (name, e)
+        # the module-level render() (mi.render) maps the WORLD sensor exactly once on both of its branches: primal-only
+        # (params without grad / no_grad) and attached (the primal-only branch used to transform it twice)
+        from integrators.reparam import render as mi_render
+        with torch.no_grad():
+            img_plain = mi_render(scene, None, sensor=0, seed=seed, spp=spp)
+        assert float(torch.linalg.norm(img_plain.cpu().double() - img) / torch.linalg.norm(img)) < 1e-6, name
+        att = traverse(scene)
+        att[SDF_DEFAULT_KEY] = data.cuda().clone().requires_grad_(True)
+        att.update()
+        img_att = mi_render(scene, att, sensor=[sensor], seed=seed, spp=spp, seed_grad=seed, spp_grad=spp)[0]
+        assert float(torch.linalg.norm(img_att.detach().cpu().double() - img) / torch.linalg.norm(img)) < 1e-6, name
         params = traverse(scene)
         leaf = data.cuda().clone().requires_grad_(True)
         pl = p0.clone().requires_grad_(True)
