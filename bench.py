@@ -308,13 +308,19 @@ def main():
     nv = len(sensors)
     # two gradient buffers, used alternately: the RCCL all-reduce of step i is issued non-blocking and overlaps the rendering of
     # step i + 1, which accumulates into the other buffer
-    grads = [torch.zeros_like(data), torch.zeros_like(data)]
+    # (each a parallel.GradBucket: dL/dsdf and, for C5, dL/d(albedo) are views into ONE persistent flat buffer, so the all-reduce
+    # moves that buffer as it is -- no per-step torch.cat / copy-back)
     # BASELINE.json C5 (--integrator sdf_direct_reparam): a 3-channel albedo volume of the grid's resolution is optimised too
     shade, galbs = {}, [None, None]
+    shapes = [tuple(data.shape)]
     if args.integrator == 'sdf_direct_reparam':
         albedo = torch.rand(args.res, args.res, args.res, 3, device=dev) * 0.6 + 0.2
         shade = {'shading': dsdf.Shading(albedo, 1.0, hide_emitters=False)}
-        galbs = [torch.zeros_like(albedo), torch.zeros_like(albedo)]
+        shapes.append(tuple(albedo.shape))
+    buckets = [parallel.GradBucket(shapes, dev), parallel.GradBucket(shapes, dev)]
+    grads = [b.views[0] for b in buckets]
+    if len(shapes) > 1:
+        galbs = [b.views[1] for b in buckets]
     # target images (outside the timed region) -> L1 image gradient sign(img - target)/(H*W*3)
     tgt = torch.cat([dsdf.render_forward(target, s, 64, seeds=[1000 + i]) for i, s in zip(mine, sensors)]) if nv else None
     scale = 1.0 / (args.img * args.img * 3)

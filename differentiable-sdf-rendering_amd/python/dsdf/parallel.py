@@ -228,40 +228,107 @@ class HipOps:
         handle.backward(film_total, grad_image, grad_grid)
 
 
+class GradBucket:
+    """Gradient tensors as VIEWS into one persistent flat buffer: the all-reduce of a step then moves that buffer as it is --
+    no per-step torch.cat into a fresh bucket and no copy back (round 3 built a new flat tensor every step: 256 MiB at
+    BASELINE's configs[4]).  `views[i]` has shapes[i]; zero_() clears all of them with one memset."""
+
+    def __init__(self, shapes, device, dtype=None):
+        import math
+        dtype = dtype or torch.float32
+        sizes = [int(math.prod(s)) for s in shapes]
+        self.flat = torch.zeros(sum(sizes), dtype=dtype, device=device)
+        self.views, off = [], 0
+        for s, n in zip(shapes, sizes):
+            self.views.append(self.flat[off:off + n].view(*s))
+            off += n
+
+    def zero_(self):
+        self.flat.zero_()
+        return self
+
+    def all_reduce(self, group=None, async_op=False, force=False):
+        return all_reduce_gradients([self.flat], group, async_op=async_op, force=force)
+
+
+def _as_one_buffer(tensors):
+    """The flat tensor that covers `tensors` when they are consecutive contiguous views of ONE storage (a GradBucket), else None."""
+    t0 = tensors[0]
+    if not all(t.is_contiguous() and t.dtype == t0.dtype and t.device == t0.device for t in tensors):
+        return None
+    try:
+        base = t0.untyped_storage().data_ptr()
+        if any(t.untyped_storage().data_ptr() != base for t in tensors):
+            return None
+    except Exception:
+        return None
+    off = t0.storage_offset()
+    for t in tensors:
+        if t.storage_offset() != off:
+            return None
+        off += t.numel()
+    return torch.as_strided(t0, (off - t0.storage_offset(),), (1,), t0.storage_offset())
+
+
+_BIG = 1 << 20            # elements: a tensor this large is reduced in place on its own (bandwidth-bound either way)
+_small_buckets = {}       # (device, dtype, numel) -> persistent flat buffer for the small tensors of a call
+
+
 def all_reduce_gradients(tensors, group=None, async_op=False, force=False):
-    """Sums the given gradient tensors over all ranks in place with ONE collective.  async_op: the collective is issued
-    non-blocking and a handle with .wait() is returned (None when there is nothing to reduce); several tensors are then
-    copied back from the flat bucket by wait().  force: issue the collective even in a world of one rank (exercises the
-    transport on a single GPU)."""
+    """Sums the given gradient tensors over all ranks in place.  Tensors that are consecutive views of one buffer (GradBucket)
+    go out as that buffer -- one collective, no copy.  Otherwise every large tensor (>= 2^20 elements) is reduced in place by
+    its own collective and the small ones share ONE persistent bucket (copied in and out; no per-step allocation).  async_op:
+    the collectives are issued non-blocking and a handle with .wait() is returned (None when there is nothing to reduce).
+    force: issue them even in a world of one rank (exercises the transport on a single GPU)."""
     import torch.distributed as dist
     tensors = list(tensors)
-    if not dist.is_available() or not dist.is_initialized() or (dist.get_world_size(group) == 1 and not force):
+    if not tensors or not dist.is_available() or not dist.is_initialized() or (dist.get_world_size(group) == 1 and not force):
         return None if async_op else tensors
-    if len(tensors) == 1 and tensors[0].is_contiguous():
-        w = dist.all_reduce(tensors[0], op=dist.ReduceOp.SUM, group=group, async_op=async_op)
-        return w if async_op else tensors
-    flat = torch.cat([t.reshape(-1) for t in tensors])
-    w = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
-
-    def unpack():
+    one = _as_one_buffer(tensors)
+    if one is not None:
+        w = dist.all_reduce(one, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
+        return _BucketWork([w], None) if async_op else tensors
+    works, small = [], []
+    for t in tensors:
+        if t.numel() >= _BIG and t.is_contiguous():
+            works.append(dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group, async_op=async_op))
+        else:
+            small.append(t)
+    unpack = None
+    if small:
+        n = sum(t.numel() for t in small)
+        key = (small[0].device, small[0].dtype, n)
+        flat = _small_buckets.get(key)
+        if flat is None:
+            flat = _small_buckets[key] = torch.empty(n, dtype=small[0].dtype, device=small[0].device)
         off = 0
-        for t in tensors:
-            n = t.numel()
-            t.copy_(flat[off:off + n].view_as(t))
-            off += n
+        for t in small:
+            flat[off:off + t.numel()].copy_(t.reshape(-1))
+            off += t.numel()
+        works.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group, async_op=async_op))
+
+        def unpack():
+            o = 0
+            for t in small:
+                t.copy_(flat[o:o + t.numel()].view_as(t))
+                o += t.numel()
     if not async_op:
-        unpack()
+        if unpack:
+            unpack()
         return tensors
-    return _BucketWork(w, unpack)
+    return _BucketWork(works, unpack)
 
 
 class _BucketWork:
-    def __init__(self, work, unpack):
-        self.work, self.unpack = work, unpack
+    def __init__(self, works, unpack):
+        self.works, self.unpack = works, unpack
 
     def wait(self):
-        self.work.wait()
-        self.unpack()
+        for w in self.works:
+            if w is not None:
+                w.wait()
+        if self.unpack:
+            self.unpack()
 
 
 def broadcast_parameters(tensors, src=0, group=None):

@@ -102,8 +102,16 @@ def optimize_shape(scene_config, mts_args, ref_image_paths, output_dir, config, 
                 (reg_loss / world).backward()
                 loss = loss.detach() + reg_loss.detach() / world
             if world > 1:
+                # gradients are reduced where autograd put them (a large tensor by its own in-place collective, small ones
+                # through one persistent bucket); the scalar loss goes separately -- appending it to the list used to force a
+                # copy of everything into a fresh flat bucket every iteration
                 grads = [p.grad if p.grad is not None else torch.zeros_like(p) for _, p in opt.items()]
-                parallel.all_reduce_gradients(grads + [loss.detach()])
+                loss = loss.detach().reshape(1).clone()
+                work = parallel.all_reduce_gradients(grads, async_op=True)
+                parallel.all_reduce_gradients([loss])
+                if work is not None:
+                    work.wait()
+                loss = loss[0]
                 for (_, p), g in zip(opt.items(), grads):
                     p.grad = g
             if rank == 0:

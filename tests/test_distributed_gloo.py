@@ -41,6 +41,25 @@ def _worker(rank, world, port, out):
     if rank == 0:
         full = sum(view_grad(i) for i in range(n_views))
         out.put((float((g - full).abs().max()), float(full.abs().max()), float(tex[0, 0]), mine))
+    # GradBucket: the tensors are views of ONE persistent buffer -> reduced as that buffer (no cat, no copy back); and the
+    # split policy of a plain list: a large tensor in place by its own collective, the small ones through a cached bucket
+    bucket = parallel.GradBucket([(R, R, R), (4, 4, 3)], 'cpu', torch.float64)
+    bucket.views[0].copy_(torch.full((R, R, R), float(rank + 1), dtype=torch.float64))
+    bucket.views[1].fill_(10.0 * (rank + 1))
+    flat_ptr = bucket.flat.data_ptr()
+    assert parallel._as_one_buffer(bucket.views) is not None and parallel._as_one_buffer([g, tex]) is None
+    work = parallel.all_reduce_gradients(bucket.views, async_op=True)
+    work.wait()
+    tot = sum(range(1, world + 1))
+    assert bucket.flat.data_ptr() == flat_ptr and float(bucket.views[0][1, 2, 3]) == tot and float(bucket.views[1][0, 0, 0]) == 10.0 * tot
+    big = torch.full(((1 << 20) + 5,), float(rank + 1))
+    small_a, small_b = torch.full((7,), float(rank)), torch.full((2, 3), 2.0 * rank)
+    n_cached = len(parallel._small_buckets)
+    for _ in range(2):                                            # twice: the second call re-uses the cached small bucket
+        big.fill_(float(rank + 1)); small_a.fill_(float(rank)); small_b.fill_(2.0 * rank)
+        parallel.all_reduce_gradients([big, small_a, small_b])
+        assert float(big[-1]) == tot and float(small_a[0]) == tot - world and float(small_b[1, 2]) == 2.0 * (tot - world)
+    assert len(parallel._small_buckets) == n_cached + 1
     w = torch.full((3,), float(rank))
     parallel.broadcast_parameters([w], src=1)
     assert float(w[0]) == 1.0
