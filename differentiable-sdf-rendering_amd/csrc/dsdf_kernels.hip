@@ -386,14 +386,14 @@ void k_render_items(GridView G, dsdf_params P, ViewBatch VB, float *__restrict__
                 DirectFetch F;
                 if (!DIRECT && tq.state) {
                     HandOff ho;
-                    ho.tq = tq; ho.sub = my_subq; ho.view = view; ho.lane = lane;
+                    ho.tq = tq; ho.sub = tq.per_xcd ? my_subq : item % DSDF_TAIL_SUBQ; ho.view = view; ho.lane = lane;
                     trace_diff(G, P, L.ray.o, L.ray.d, L.ray.maxt, tr, F, ho);
                 } else trace_diff(G, P, L.ray.o, L.ray.d, L.ray.maxt, tr, F);
             } else {
                 WaveCellCache F; F.taps = wave_lds; F.lid = lid;
                 if (!DIRECT && tq.state) {
                     PlainHandOff ho;
-                    ho.tq = tq; ho.sub = my_subq; ho.view = view; ho.lane = lane;
+                    ho.tq = tq; ho.sub = tq.per_xcd ? my_subq : item % DSDF_TAIL_SUBQ; ho.view = view; ho.lane = lane;
                     trace_plain(G, P, L.ray.o, L.ray.d, L.ray.maxt, tr, F, ho);
                 } else trace_plain(G, P, L.ray.o, L.ray.d, L.ray.maxt, tr, F);
             }
@@ -898,7 +898,7 @@ void dsdf_default_params(dsdf_params *p) {
 size_t dsdf_padded_size(int rx, int ry, int rz) {
     size_t n = padded_floats(rx, ry, rz);
     for (int l = 0; l < DSDF_COARSE_LEVELS; ++l) n += 2 * coarse_cells(rx, ry, rz, l);
-    return n + 2 * hit_cells(rx, ry, rz);
+    return n + 2 * hit_cells(rx, ry, rz) + 2 * (size_t)rx * ry * rz;      // (+ fine window maxima and their scratch)
 }
 
 int dsdf_pad_grid(const float *data, int rx, int ry, int rz, float *padded, void *stream) {
@@ -928,6 +928,14 @@ int dsdf_pad_grid(const float *data, int rx, int ry, int rz, float *padded, void
         hipLaunchKernelGGL(k_coarse_reduce<true>, dim3((nc + 255) / 256), dim3(256), 0, (hipStream_t)stream, data, rx, ry, rz, c0, cx, cy, cz,
                            1 << DSDF_HIT_SHIFT);
         hipLaunchKernelGGL(k_coarse_dilate<true>, dim3((nc + 255) / 256), dim3(256), 0, (hipStream_t)stream, c0, c1, cx, cy, cz, DSDF_HIT_RADIUS);
+    }
+    {   // fine window maxima: x pass (data -> F), y pass (F -> scratch), z pass (scratch -> F)
+        float *F = fine_buffer(padded, rx, ry, rz), *T = F + (size_t)rx * ry * rz;
+        const size_t total = (size_t)rx * ry * rz;
+        const dim3 g((unsigned)((total + 255) / 256)), b(256);
+        hipLaunchKernelGGL(k_window_max, g, b, 0, (hipStream_t)stream, data, F, total, rx, (size_t)1, DSDF_FINE_LO, DSDF_FINE_HI);
+        hipLaunchKernelGGL(k_window_max, g, b, 0, (hipStream_t)stream, (const float *)F, T, total, ry, (size_t)rx, DSDF_FINE_LO, DSDF_FINE_HI);
+        hipLaunchKernelGGL(k_window_max, g, b, 0, (hipStream_t)stream, (const float *)T, F, total, rz, (size_t)rx * ry, DSDF_FINE_LO, DSDF_FINE_HI);
     }
     return check_launch("k_coarse_reduce/dilate");
 }
@@ -1042,6 +1050,7 @@ static std::mutex g_helper_mutex;
 static std::vector<TailStreams> g_helpers;
 static std::vector<hipEvent_t> g_events;
 static size_t g_next_event = 0;
+static int g_events_device = -1;
 
 static int env_int(const char *name, int dflt) {
     const char *v = getenv(name);
@@ -1050,6 +1059,14 @@ static int env_int(const char *name, int dflt) {
 
 // DSDF_BWD_SPLIT=0: dsdf_grad_backward runs the fused k_backward instead of k_backward_coef (in dsdf_grad_sweep) + k_backward_apply
 static bool backward_split() { static const int v = env_int("DSDF_BWD_SPLIT", 1); return v != 0; }
+// DSDF_TAIL_QUEUES=xcd: tail sub-queue = (XCD of the producing worker, its ticket counter), drained by the blocks of that XCD
+// first; default `item`: sub-queue = work-list index % 64 -- measured (profiles/r04_tail_ab.md): the per-XCD queues keep the L2
+// policy of the render kernel but put a hard tile's long rays on an eighth of the tail waves, and the tail kernels are bound by
+// exactly those rays.  DSDF_PRIMAL_HANDOFF=0: the value-only march keeps its last rays (no primal tail kernel).
+static int tail_per_xcd() { static const char *v = getenv("DSDF_TAIL_QUEUES"); return (v && !strcmp(v, "xcd")) ? 1 : 0; }
+// DSDF_FINE_HIT_PROOF=0: hit proof from the block maxima only (A/B)
+static bool fine_hit_proof() { static const int v = env_int("DSDF_FINE_HIT_PROOF", 1); return v != 0; }
+static bool primal_handoff() { static const int v = env_int("DSDF_PRIMAL_HANDOFF", 1); return v != 0; }
 static int tail_streams_enabled() { static int v = env_int("DSDF_TAIL_STREAMS", 1); return v; }
 // blocks (4 waves) per sub-queue of a tail kernel: DSDF_TAIL_BLOCKS overrides the built-in value
 static unsigned tail_blocks() {
@@ -1084,6 +1101,13 @@ static bool helper_streams(hipStream_t owner, hipStream_t out[2]) {
 
 static hipEvent_t next_event() {
     std::lock_guard<std::mutex> lock(g_helper_mutex);
+    // the ring holds events of ONE device: a process that drives another GPU later starts a new ring
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    if (dev != g_events_device) {
+        for (hipEvent_t e : g_events) (void)hipEventDestroy(e);
+        g_events.clear(); g_next_event = 0; g_events_device = dev;
+    }
     if (g_events.size() < 256) {
         hipEvent_t e;
         if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
@@ -1115,6 +1139,7 @@ struct SkipShare {
     size_t bytes = 0;
     bool valid = false;
     hipEvent_t ready = nullptr;
+    int device = -1;       // the device `ready` was created on (an event must be recorded on a stream of its own device)
     const float *padded = nullptr;
     int rx = 0, ry = 0, rz = 0, W = 0, H = 0, nv = 0;
     int hit_proof = 0;     // the flags carry DSDF_PX_HIT (silhouette integrator, hit proof not disabled)
@@ -1155,10 +1180,20 @@ static int run_pass(const PassCtx &c, const Workspace &ws, const dsdf_camera *ca
         } else {
             unsigned char *dst = (can_share && !sh.valid) ? sh.buf : ws.skip;       // (a second, different batch keeps its own flags)
             // (the hit proof serves the silhouette integrator, which consumes nothing but the hit flag of a sample)
-            const float hstep = (c.integrator == DSDF_SILHOUETTE && !(c.flags & DSDF_NO_HIT_PROOF)) ? hit_step(cams + v0, nv, c.W, c.rx, c.ry, c.rz) : 0.f;
+            const bool want_hit = c.integrator == DSDF_SILHOUETTE && !(c.flags & DSDF_NO_HIT_PROOF);
+            const float hstep = want_hit ? hit_step(cams + v0, nv, c.W, c.rx, c.ry, c.rz) : 0.f;
+            const float fstep = (want_hit && fine_hit_proof()) ? hit_step_fine(cams + v0, nv, c.W, c.rx, c.ry, c.rz) : 0.f;
+            // the pixels neither proof settles are listed in the (not yet built) work-list area of this workspace for the second
+            // stage of the hit proof: [DSDF_MAX_GROUPS * DSDF_ITEM_HDR ..) holds one entry per film-block pixel and view
+            uint32_t *und = fstep > 0.f ? ws.items + (size_t)DSDF_MAX_GROUPS * DSDF_ITEM_HDR - DSDF_UNDECIDED_HDR : nullptr;
+            if (und && hipMemsetAsync(und, 0, sizeof(uint32_t), st) != hipSuccess) return fail(DSDF_ERR_LAUNCH, "hipMemsetAsync(undecided list) failed");
             hipLaunchKernelGGL(k_pixel_skip, dim3((unsigned)((npix + 255) / 256), nv), dim3(256), 0, st,
                                device_view(c.padded, c.rx, c.ry, c.rz, *c.prm), min_bounds(c.padded, c.rx, c.ry, c.rz, level),
-                               max_bounds(c.padded, c.rx, c.ry, c.rz), c.pp, VB, dst, step, hstep);
+                               max_bounds(c.padded, c.rx, c.ry, c.rz), c.pp, VB, dst, step, hstep, und);
+            if (und)
+                hipLaunchKernelGGL(k_pixel_hit_fine, dim3((unsigned)((npix * nv + 255) / 256)), dim3(256), 0, st,
+                                   device_view(c.padded, c.rx, c.ry, c.rz, *c.prm), fine_bounds(c.padded, c.rx, c.ry, c.rz), c.pp, VB, dst,
+                                   (const uint32_t *)und, (const uint32_t *)(und + DSDF_UNDECIDED_HDR), fstep);
             if ((rc = check_launch("k_pixel_skip"))) return rc;
             hipLaunchKernelGGL(k_skip_dilate, dim3((unsigned)((npix + 255) / 256), nv), dim3(256), 0, st, VB, dst);
             if ((rc = check_launch("k_skip_dilate"))) return rc;
@@ -1196,7 +1231,7 @@ static int run_pass(const PassCtx &c, const Workspace &ws, const dsdf_camera *ca
         if (DIFF && hipMemsetAsync(ws.count, 0, (size_t)nv * ws.nunits * sizeof(uint32_t), st) != hipSuccess)
             return fail(DSDF_ERR_LAUNCH, "hipMemsetAsync(queue counts) failed");
         // view groups: render kernel g on the caller's stream, tail kernel g on a helper stream beside render kernel g + 1
-        const bool handoff = ws.tail != nullptr;
+        const bool handoff = ws.tail != nullptr && (DIFF || primal_handoff());
         const size_t cnt_bytes = align_up((size_t)DSDF_MAX_GROUPS * DSDF_TAIL_SUBQ * 2 * sizeof(uint32_t), 256);
         const size_t grp_bytes = align_up((size_t)DSDF_TAIL_SUBQ * ws.tail_cap_sub * ws.tail_words * sizeof(float), 256);
         if (handoff && hipMemsetAsync(ws.tail, 0, cnt_bytes, st) != hipSuccess)
@@ -1228,6 +1263,7 @@ static int run_pass(const PassCtx &c, const Workspace &ws, const dsdf_camera *ca
             memset(&tq, 0, sizeof(tq));
             if (handoff) {
                 tq.cap_sub = ws.tail_cap_sub * (uint32_t)kreg;
+                tq.per_xcd = (uint32_t)tail_per_xcd();
                 tq.count = (uint32_t *)ws.tail + (size_t)g * DSDF_TAIL_SUBQ * 2;
                 tq.state = (float *)(ws.tail + cnt_bytes + (size_t)g * kreg * grp_bytes);
             }
@@ -1503,8 +1539,15 @@ int dsdf_share_pixel_skip(void *buffer, size_t bytes) {
     sh.valid = false;
     sh.buf = (unsigned char *)buffer;
     sh.bytes = buffer ? bytes : 0;
-    if (buffer && !sh.ready && hipEventCreateWithFlags(&sh.ready, hipEventDisableTiming) != hipSuccess)
-        return fail(DSDF_ERR_LAUNCH, "dsdf_share_pixel_skip: hipEventCreate failed");
+    if (buffer) {
+        // the event belongs to the CURRENT device: a thread that moves on to another GPU gets a new one
+        int dev = -1;
+        if (hipGetDevice(&dev) != hipSuccess) return fail(DSDF_ERR_LAUNCH, "dsdf_share_pixel_skip: hipGetDevice failed");
+        if (sh.ready && sh.device != dev) { (void)hipEventDestroy(sh.ready); sh.ready = nullptr; }
+        if (!sh.ready && hipEventCreateWithFlags(&sh.ready, hipEventDisableTiming) != hipSuccess)
+            return fail(DSDF_ERR_LAUNCH, "dsdf_share_pixel_skip: hipEventCreate failed");
+        sh.device = dev;
+    }
     return DSDF_OK;
 }
 

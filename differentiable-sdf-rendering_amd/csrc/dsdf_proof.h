@@ -27,12 +27,13 @@ namespace dsdf {
 struct BoundGrid {
     const float *b;          // (cz,cy,cx) dilated block minima (empty-space proof) or maxima (hit proof)
     int cx, cy, cz, shift;   // blocks per axis, log2(voxels per block)
+    float off;               // 0: blocks of voxels, index = floor(x * res) >> shift;  0.5: B-spline cells, index = floor(x * res - 0.5)
 };
 
 DSDF_HD float bound_at(const BoundGrid &B, const GridView &G, V3 x) {
-    int bx = iclamp((int)floorf((x.x - G.tx) * G.frx) >> B.shift, 0, B.cx - 1);
-    int by = iclamp((int)floorf((x.y - G.ty) * G.fry) >> B.shift, 0, B.cy - 1);
-    int bz = iclamp((int)floorf((x.z - G.tz) * G.frz) >> B.shift, 0, B.cz - 1);
+    int bx = iclamp((int)floorf((x.x - G.tx) * G.frx - B.off) >> B.shift, 0, B.cx - 1);
+    int by = iclamp((int)floorf((x.y - G.ty) * G.fry - B.off) >> B.shift, 0, B.cy - 1);
+    int bz = iclamp((int)floorf((x.z - G.tz) * G.frz - B.off) >> B.shift, 0, B.cz - 1);
     return B.b[((size_t)bz * B.cy + by) * B.cx + bx];
 }
 
@@ -146,6 +147,24 @@ static int skip_level(const dsdf_camera *cams, int nv, int W, int rx, int ry, in
     }
     step = 0.f;
     return -1;
+}
+
+// The FINE bound of the hit proof (second stage, for the pixels the block maxima leave undecided): per B-spline cell c the
+// maximum over the taps [c - 2, c + 3]^3 -- every tap of every lookup within ONE voxel of a point of cell c -- at full
+// resolution (k_window_max, dsdf_skip.h).  A 6^3-voxel window instead of the 10^3 of the block maxima: shapes a few voxels
+// thick and pixels close to the silhouette still prove.  Step of its march, or 0 when lateral deviation + half a step exceed
+// that one voxel (or the box argument of pixel_hit_proof fails).
+#define DSDF_FINE_LO (-2)
+#define DSDF_FINE_HI 3
+static float hit_step_fine(const dsdf_camera *cams, int nv, int W, int rx, int ry, int rz) {
+    int rmax = rx > ry ? (rx > rz ? rx : rz) : (ry > rz ? ry : rz);
+    int rmin = rx < ry ? (rx < rz ? rx : rz) : (ry < rz ? ry : rz);
+    const float worst = pixel_spread_voxels(cams, nv, W, rmax);
+    if (worst / (float)rmin > 0.5f * DSDF_PROOF_GROW) return 0.f;
+    float step_vox = 2.f * (1.f - worst) - 0.02f;            // (0.01 voxel of slack on either side for the rounding of x * res)
+    if (step_vox < 0.25f) return 0.f;
+    if (step_vox > 1.f) step_vox = 1.f;
+    return step_vox / (float)rmax;
 }
 
 // March step (world units) of the hit proof, or 0 when its margins are not covered: the dilation (DSDF_HIT_RADIUS blocks of

@@ -38,19 +38,68 @@ __global__ void k_coarse_dilate(const float *__restrict__ c0, float *__restrict_
     c[i] = m;
 }
 
+// Sliding-window maximum along one axis (stride `st` elements, extent n): out[i] = max(in[clamp(i + lo .. i + hi)]).  Three passes
+// (x, y, z) build the fine bound of the hit proof (dsdf_proof.h: hit_step_fine) from sdf.data.
+__global__ void k_window_max(const float *__restrict__ in, float *__restrict__ out, size_t total, int n, size_t st, int lo, int hi) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int a = (int)((i / st) % (size_t)n);
+    float m = -INFINITY;
+    for (int o = lo; o <= hi; ++o) {
+        const int b = min(max(a + o, 0), n - 1);
+        m = fmaxf(m, in[i + (size_t)(b - a) * st]);     // (b - a may be negative: size_t wrap-around adds up correctly)
+    }
+    out[i] = m;
+}
+
 // flags[view][Hb*Wb]: DSDF_PX_EMPTY / _EMPTY_G / _HIT of every film-block pixel (dsdf_proof.h).  step == 0: no empty-space
 // proof, hstep == 0: no hit proof (margins not covered, or the integrator consumes more than the hit flag).
-__global__ void k_pixel_skip(GridView G, BoundGrid Bmin, BoundGrid Bmax, dsdf_params P, ViewBatch VB, unsigned char *__restrict__ flags,
-                             float step, float hstep) {
+// `undecided` (optional): [0] = counter (zeroed by the caller), entries from [DSDF_UNDECIDED_HDR]: view * Wb * Hb + pixel of every
+// pixel neither proof settled -- the work list of k_pixel_hit_fine.
+#define DSDF_UNDECIDED_HDR 16
+__global__ void k_pixel_skip(GridView G, BoundGrid Bmin, BoundGrid Bmax, dsdf_params P, ViewBatch VB,
+                             unsigned char *__restrict__ flags, float step, float hstep, uint32_t *__restrict__ undecided) {
     const ViewArgs &A = VB.v[blockIdx.y];
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= A.Wb * A.Hb) return;
-    int py = i / A.Wb, px = i - py * A.Wb;
-    CamRay r = camera_ray(A.cam, P, (float)(px - DSDF_BORDER) + 0.5f, (float)(py - DSDF_BORDER) + 0.5f, A.W, A.H);
-    V3 d = r.d * rsqf(dot(r.d, r.d));
-    unsigned f = step > 0.f ? pixel_empty_proof(G, Bmin, P, r.o, d, step) : 0u;
-    if (hstep > 0.f && !(f & DSDF_PX_EMPTY)) f |= pixel_hit_proof(G, Bmax, P, r.o, d, hstep);
-    flags[(size_t)blockIdx.y * A.Wb * A.Hb + i] = (unsigned char)f;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x, npix = A.Wb * A.Hb;
+    const bool valid = i < npix;
+    unsigned f = DSDF_PX_EMPTY;
+    if (valid) {
+        int py = i / A.Wb, px = i - py * A.Wb;
+        CamRay r = camera_ray(A.cam, P, (float)(px - DSDF_BORDER) + 0.5f, (float)(py - DSDF_BORDER) + 0.5f, A.W, A.H);
+        V3 d = r.d * rsqf(dot(r.d, r.d));
+        f = step > 0.f ? pixel_empty_proof(G, Bmin, P, r.o, d, step) : 0u;
+        if (hstep > 0.f && !(f & DSDF_PX_EMPTY)) f |= pixel_hit_proof(G, Bmax, P, r.o, d, hstep);
+        flags[(size_t)blockIdx.y * npix + i] = (unsigned char)f;
+    }
+    if (undecided) {
+        const bool open = valid && !(f & (DSDF_PX_EMPTY | DSDF_PX_HIT));
+        const uint64_t m = __ballot(open);
+        if (m != 0) {
+            const int leader = __builtin_ctzll(m);
+            uint32_t base = 0;
+            if (lane_id() == leader) base = atomicAdd(undecided, (uint32_t)__popcll(m));
+            base = (uint32_t)__builtin_amdgcn_readlane((int)base, leader);
+            if (open) undecided[DSDF_UNDECIDED_HDR + base + mask_prefix(m)] = (uint32_t)blockIdx.y * (uint32_t)npix + (uint32_t)i;
+        }
+    }
+}
+
+// Second stage of the hit proof on the pixels k_pixel_skip left undecided: pixel_hit_proof (dsdf_proof.h) over the
+// full-resolution window maxima -- ~600 samples half a voxel apart per ray.  Inside k_pixel_skip that loop cost 1.2 ms per
+// 12-view step: a few undecided pixels per wave, each a serial chain on an otherwise idle wave; a wave-cooperative form (64
+// samples of one pixel per wave iteration, prefix maxima by shuffles) did MORE work, 1.7 ms.  So the undecided pixels are
+// COMPACTED (k_pixel_skip appends them to a list, one reservation per wave) and a dense launch runs the serial form, one pixel
+// per lane, every wave full.
+__global__ __launch_bounds__(256) void k_pixel_hit_fine(GridView G, BoundGrid B, dsdf_params P, ViewBatch VB, unsigned char *__restrict__ flags,
+                                                        const uint32_t *__restrict__ count, const uint32_t *__restrict__ list, float step) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= *count) return;
+    const uint32_t e = list[i], npix = (uint32_t)(VB.v[0].Wb * VB.v[0].Hb), view = e / npix, pix = e - view * npix;
+    const ViewArgs &A = VB.v[view];
+    const int py = (int)(pix / (uint32_t)A.Wb), px = (int)(pix - (uint32_t)py * (uint32_t)A.Wb);
+    const CamRay r = camera_ray(A.cam, P, (float)(px - DSDF_BORDER) + 0.5f, (float)(py - DSDF_BORDER) + 0.5f, A.W, A.H);
+    const V3 d = r.d * rsqf(dot(r.d, r.d));
+    if (pixel_hit_proof(G, B, P, r.o, d, step)) flags[e] |= (unsigned char)DSDF_PX_HIT;
 }
 
 // Bits 2/3 (DSDF_PX_FAR / _FAR_G): every film pixel within +-4 of this one carries bit 0 / bit 1.  A sample only splats into
@@ -87,6 +136,7 @@ static BoundGrid min_bounds(const float *padded, int rx, int ry, int rz, int lev
     BoundGrid B;
     coarse_dims(rx, ry, rz, level, B.cx, B.cy, B.cz);
     B.shift = DSDF_COARSE_SHIFT(level);
+    B.off = 0.f;
     B.b = c + coarse_cells(rx, ry, rz, level);
     return B;
 }
@@ -96,6 +146,19 @@ static BoundGrid max_bounds(const float *padded, int rx, int ry, int rz) {
     BoundGrid B;
     hit_dims(rx, ry, rz, B.cx, B.cy, B.cz);
     B.shift = DSDF_HIT_SHIFT;
+    B.off = 0.f;
     B.b = c + hit_cells(rx, ry, rz);
+    return B;
+}
+// [.. | block maxima, dilated | fine window maxima (rz,ry,rx) | scratch of the same size]
+static float *fine_buffer(const float *padded, int rx, int ry, int rz) {
+    const float *c = padded + padded_floats(rx, ry, rz);
+    for (int l = 0; l < DSDF_COARSE_LEVELS; ++l) c += 2 * coarse_cells(rx, ry, rz, l);
+    return const_cast<float *>(c) + 2 * hit_cells(rx, ry, rz);
+}
+static BoundGrid fine_bounds(const float *padded, int rx, int ry, int rz) {
+    BoundGrid B;
+    B.cx = rx; B.cy = ry; B.cz = rz; B.shift = 0; B.off = 0.5f;
+    B.b = fine_buffer(padded, rx, ry, rz);
     return B;
 }

@@ -37,7 +37,7 @@
 #define DSDF_TAIL_SUBQ 64           /* sub-queues per launch: 8 per XCD (one per ticket counter of the render kernel's XCD share) */
 #define DSDF_TAIL_REFILL 24         /* idle lanes that trigger a refill in the tail kernels */
 #ifndef DSDF_TAIL_BLOCKS_PER_SUBQ
-#define DSDF_TAIL_BLOCKS_PER_SUBQ 16   /* x 4 waves: 4096 persistent tail waves */
+#define DSDF_TAIL_BLOCKS_PER_SUBQ 4    /* x 4 waves x 64 sub-queues: 1024 persistent tail waves = one per SIMD.  A tail kernel is the chain of its longest rays (2000+ steps); every further resident wave per SIMD slows that chain down (step: 47.2 / 44.4 / 44.0 / 46.0 / 46.6 ms at 1 / 2 / 4 / 8 / 16 blocks, profiles/r04_tail_ab.md) */
 #endif
 #define DSDF_TAIL_WORDS 23          /* gradient sweep: view, sample id, t, warp_t, prev_sd, wsum, ews, 5 x V3, step counter */
 #define DSDF_PTAIL_WORDS 3          /* primal: view, sample id, t (everything else follows from the sample id) */
@@ -52,15 +52,16 @@ __device__ __forceinline__ uint32_t xcc_id() {
 }
 // sub-queue of a render worker / first sub-queue of a tail block: (XCD, blockIdx.x / 8 mod 8)
 __device__ __forceinline__ uint32_t tail_subq() { return (xcc_id() << 3) | ((blockIdx.x >> 3) & 7u); }
-// k-th sub-queue a tail block visits: the 8 queues of its own XCD first, then the other XCDs'
-__device__ __forceinline__ uint32_t tail_hop(uint32_t first, uint32_t k) {
-    return ((((first >> 3) + (k >> 3)) & 7u) << 3) | ((first + k) & 7u);
+// k-th sub-queue a tail block visits.  per XCD: the 8 queues of its own XCD first, then the other XCDs'; else round the ring
+__device__ __forceinline__ uint32_t tail_hop(uint32_t first, uint32_t k, uint32_t per_xcd) {
+    return per_xcd ? (((((first >> 3) + (k >> 3)) & 7u) << 3) | ((first + k) & 7u)) : ((first + k) & (DSDF_TAIL_SUBQ - 1u));
 }
 
 struct TailQueue {
     uint32_t *count;   // [DSDF_TAIL_SUBQ][2]: {queued, claimed}
     float *state;      // [DSDF_TAIL_SUBQ][cap_sub][words] march states
     uint32_t cap_sub;
+    uint32_t per_xcd;  // 1: sub-queue = (XCD of the producer, ticket counter); 0: sub-queue = work-list index % DSDF_TAIL_SUBQ
 };
 
 // One reservation per wave in sub-queue `sub`: `n` consecutive entries, or nothing when they do not fit (compare-and-swap, so a
@@ -161,14 +162,14 @@ __device__ __forceinline__ void tail_stats(unsigned long long *stats, int lane_s
 // Resumes the queued rays of the gradient sweep and finishes their samples: value splat, backward-queue entry.
 __global__ __launch_bounds__(256) void k_tail_trace_diff(GridView G, dsdf_params P, ViewBatch VB, float *__restrict__ blocks,
                                                          TailQueue tq, Queue qall, unsigned long long *stats) {
-    const uint32_t first = tail_subq();
+    const uint32_t first = tq.per_xcd ? tail_subq() : blockIdx.x % DSDF_TAIL_SUBQ;
     uint32_t hop = 0, total = 0;
     uint32_t *cnt = nullptr;
     const float *ent = nullptr;
     // opens the next non-empty sub-queue; false when all DSDF_TAIL_SUBQ have been visited
     auto open_next = [&]() {
         while (hop < DSDF_TAIL_SUBQ) {
-            const uint32_t sub = tail_hop(first, hop++);
+            const uint32_t sub = tail_hop(first, hop++, tq.per_xcd);
             cnt = tq.count + 2 * sub;
             ent = tq.state + (size_t)sub * tq.cap_sub * DSDF_TAIL_WORDS;
             total = (uint32_t)__builtin_amdgcn_readfirstlane((int)cnt[0]);
@@ -256,13 +257,13 @@ __global__ __launch_bounds__(256) void k_tail_trace_diff(GridView G, dsdf_params
 // gathers only on entering another cell -- the step is then a dependent ALU chain without a memory round trip.
 __global__ __launch_bounds__(256) void k_tail_trace_plain(GridView G, dsdf_params P, ViewBatch VB, float *__restrict__ blocks,
                                                           TailQueue tq, unsigned long long *stats) {
-    const uint32_t first = tail_subq();
+    const uint32_t first = tq.per_xcd ? tail_subq() : blockIdx.x % DSDF_TAIL_SUBQ;
     uint32_t hop = 0, total = 0;
     uint32_t *cnt = nullptr;
     const float *ent = nullptr;
     auto open_next = [&]() {
         while (hop < DSDF_TAIL_SUBQ) {
-            const uint32_t sub = tail_hop(first, hop++);
+            const uint32_t sub = tail_hop(first, hop++, tq.per_xcd);
             cnt = tq.count + 2 * sub;
             ent = tq.state + (size_t)sub * tq.cap_sub * DSDF_PTAIL_WORDS;
             total = (uint32_t)__builtin_amdgcn_readfirstlane((int)cnt[0]);

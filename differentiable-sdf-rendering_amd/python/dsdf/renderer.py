@@ -130,7 +130,18 @@ class SdfGrid:
         """`sdf.p` (python/shapes.py:389, 412): lookups happen at x - p.  A tensor is ALWAYS read back (3 floats): its
         address and in-place version do not identify its contents -- a temporary (`p0 + eps * e` in a finite-difference
         loop) is freed and re-allocated at the same address with version 0."""
-        vals = p.detach().cpu().tolist() if isinstance(p, torch.Tensor) else p
+        if isinstance(p, torch.Tensor):
+            # ... but the SAME tensor object at the same in-place version holds what was read last time: no second
+            # device-to-host read-back (a blocking sync per call when sdf.p lives on the GPU, ADVICE r3).  The object is
+            # held, so its storage cannot be recycled for another tensor meanwhile.
+            src = getattr(self, '_p_src', None)
+            if src is not None and src[0] is p and src[1] == p._version:
+                return self
+            vals = p.detach().cpu().tolist()
+            self._p_src = (p, p._version)
+        else:
+            vals = p
+            self._p_src = None
         px, py, pz = (float(v) for v in vals)
         self.params.sdf_p[0], self.params.sdf_p[1], self.params.sdf_p[2] = px, py, pz
         return self

@@ -84,7 +84,15 @@ class Grid3d:
     def local_translation(self, p=None):
         """`sdf.p` in the cube's frame: to_local @ (x - p) = to_local @ x - to_local3 @ p."""
         p = self.p if p is None else p
-        vals = np.asarray(p.detach().cpu().tolist() if isinstance(p, torch.Tensor) else p, np.float64)
+        if isinstance(p, torch.Tensor):
+            # one read-back per (tensor object, in-place version): `_sync` runs before every eval / trace / render call, and a
+            # device tensor would otherwise cost a blocking device-to-host sync each time (ADVICE r3)
+            c = getattr(self, '_p_read', None)
+            if c is None or c[0] is not p or c[1] != p._version:
+                c = self._p_read = (p, p._version, np.asarray(p.detach().cpu().tolist(), np.float64))
+            vals = c[2]
+        else:
+            vals = np.asarray(p, np.float64)
         return (self._A @ vals).tolist() if self.has_transform else vals.tolist()
 
     def local_sensor(self, sensor):

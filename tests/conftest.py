@@ -230,13 +230,15 @@ class HostHarness:
         self.lib.hh_sampler_emitter(C.c_uint(seed), C.c_long(n), self._p(out))
         return out
 
-    def pixel_proof(self, grid, cam, W, H):
-        """flags (H+4, W+4) of dsdf_proof.h for every film-block pixel + (empty-proof step, hit-proof step, coarse level)."""
+    def pixel_proof(self, grid, cam, W, H, stages=3):
+        """flags (H+4, W+4) of dsdf_proof.h for every film-block pixel + (empty-proof step, hit-proof step, coarse level, step of
+        the fine hit proof).  stages: bit 0 = hit proof from the block maxima, bit 1 = second stage on the window maxima."""
         grid = np.ascontiguousarray(grid, np.float32)
         flags = np.zeros((H + 4, W + 4), np.uint8)
-        info = np.zeros(3, np.float32)
+        info = np.zeros(4, np.float32)
         rz, ry, rx = grid.shape
-        self.lib.hh_pixel_proof(self._p(grid), rx, ry, rz, C.byref(self.params), self._p(cam), W, H, self._p(flags), self._p(info))
+        self.lib.hh_pixel_proof(self._p(grid), rx, ry, rz, C.byref(self.params), self._p(cam), W, H, self._p(flags), self._p(info),
+                                int(stages))
         return flags, info
 
     def trace_hits(self, grid, cam, W, H, spp, seed=0):

@@ -441,24 +441,50 @@ static std::vector<float> block_bounds(const float *data, int rx, int ry, int rz
     return c;
 }
 
+// Sliding-window maxima as k_window_max builds them (dsdf_skip.h): max over [i + lo, i + hi] (clamped) along x, then y, then z.
+static std::vector<float> window_max(const float *data, int rx, int ry, int rz, int lo, int hi) {
+    const size_t total = (size_t)rx * ry * rz;
+    std::vector<float> a(data, data + total), b(total);
+    const int n[3] = {rx, ry, rz};
+    const size_t st[3] = {1, (size_t)rx, (size_t)rx * ry};
+    for (int ax = 0; ax < 3; ++ax) {
+        for (size_t i = 0; i < total; ++i) {
+            const int c = (int)((i / st[ax]) % (size_t)n[ax]);
+            float m = -INFINITY;
+            for (int o = lo; o <= hi; ++o) {
+                const int q = std::min(std::max(c + o, 0), n[ax] - 1);
+                m = fmaxf(m, a[i + (size_t)(q - c) * st[ax]]);
+            }
+            b[i] = m;
+        }
+        a.swap(b);
+    }
+    return a;
+}
+
 // The per-pixel proofs of dsdf_proof.h for every film-block pixel of one view (what k_pixel_skip computes), with the margins
 // the library would choose (skip_level / hit_step).  flags: (H+4) x (W+4) bytes; info[0] = empty-proof step, info[1] = hit-proof
 // step, info[2] = coarse level (0 where a proof is not available for this camera / grid).
 void hh_pixel_proof(const float *data, int rx, int ry, int rz, const dsdf_params *prm, const dsdf_camera *cam, int W, int H,
-                    unsigned char *flags, float *info) {
+                    unsigned char *flags, float *info, int stages) {
     std::vector<float> p = pad(data, rx, ry, rz);
     GridView G = make_view(p.data(), rx, ry, rz, *prm);
     float step = 0.f;
     const int level = skip_level(cam, 1, W, rx, ry, rz, step);
-    const float hstep = hit_step(cam, 1, W, rx, ry, rz);
-    BoundGrid Bmin, Bmax;
-    std::vector<float> cmin, cmax;
+    const float hstep = (stages & 1) ? hit_step(cam, 1, W, rx, ry, rz) : 0.f;
+    const float fstep = (stages & 2) ? hit_step_fine(cam, 1, W, rx, ry, rz) : 0.f;
+    BoundGrid Bmin, Bmax, Bfine;
+    std::vector<float> cmin, cmax, fine;
+    if (fstep > 0.f) {
+        fine = window_max(data, rx, ry, rz, DSDF_FINE_LO, DSDF_FINE_HI);
+        Bfine.b = fine.data(); Bfine.cx = rx; Bfine.cy = ry; Bfine.cz = rz; Bfine.shift = 0; Bfine.off = 0.5f;
+    }
     if (level >= 0) {
         cmin = block_bounds(data, rx, ry, rz, 1 << DSDF_COARSE_SHIFT(level), 1, false, Bmin.cx, Bmin.cy, Bmin.cz);
-        Bmin.b = cmin.data(); Bmin.shift = DSDF_COARSE_SHIFT(level);
+        Bmin.b = cmin.data(); Bmin.shift = DSDF_COARSE_SHIFT(level); Bmin.off = 0.f;
     }
     cmax = block_bounds(data, rx, ry, rz, 1 << DSDF_HIT_SHIFT, DSDF_HIT_RADIUS, true, Bmax.cx, Bmax.cy, Bmax.cz);
-    Bmax.b = cmax.data(); Bmax.shift = DSDF_HIT_SHIFT;
+    Bmax.b = cmax.data(); Bmax.shift = DSDF_HIT_SHIFT; Bmax.off = 0.f;
     const int Wb = W + 2 * DSDF_BORDER, Hb = H + 2 * DSDF_BORDER;
     for (int py = 0; py < Hb; ++py)
         for (int px = 0; px < Wb; ++px) {
@@ -466,9 +492,10 @@ void hh_pixel_proof(const float *data, int rx, int ry, int rz, const dsdf_params
             V3 d = r.d * rsqf(dot(r.d, r.d));
             unsigned f = (level >= 0 && step > 0.f) ? pixel_empty_proof(G, Bmin, *prm, r.o, d, step) : 0u;
             if (level >= 0 && hstep > 0.f && !(f & DSDF_PX_EMPTY)) f |= pixel_hit_proof(G, Bmax, *prm, r.o, d, hstep);
+            if (level >= 0 && fstep > 0.f && !(f & (DSDF_PX_EMPTY | DSDF_PX_HIT))) f |= pixel_hit_proof(G, Bfine, *prm, r.o, d, fstep);
             flags[(size_t)py * Wb + px] = (unsigned char)f;
         }
-    info[0] = step; info[1] = hstep; info[2] = (float)level;
+    info[0] = step; info[1] = hstep; info[2] = (float)level; info[3] = fstep;
 }
 
 // Hit flag of every film sample of one view as the value-only march finds it (trace_plain): hits[lane] for lane = pixel * spp + s.

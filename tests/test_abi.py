@@ -34,9 +34,10 @@ def test_default_params_and_sizes(built):
     assert abs(p.trace_eps - 1e-6) < 1e-12 and abs(p.edge_eps - 0.01) < 1e-9 and p.weight_strategy == 6
     assert p.refine_steps == 10 and abs(p.clamping_thresh - 0.05) < 1e-9
     assert C.sizeof(dsdf.DsdfParams) == 68 and abs(p.light_dir[0] - 3 ** -0.5) < 1e-7 and C.sizeof(dsdf.DsdfCamera) == 64
-    # padded copy + coarse min-grids (8^3 and 4^3 blocks) + the hit proof's max-grid (2^3 blocks), each raw and dilated
-    assert lib.dsdf_padded_size(256, 256, 256) == 262 ** 3 + 2 * 32 ** 3 + 2 * 64 ** 3 + 2 * 128 ** 3
-    assert lib.dsdf_padded_size(4, 5, 6) == 10 * 11 * 12 + 2 + 2 * (1 * 2 * 2) + 2 * (2 * 3 * 3)
+    # padded copy + coarse min-grids (8^3 and 4^3 blocks) + the hit proof's max-grid (2^3 blocks), each raw and dilated,
+    # + the fine window maxima of the hit proof at full resolution and their scratch
+    assert lib.dsdf_padded_size(256, 256, 256) == 262 ** 3 + 2 * 32 ** 3 + 2 * 64 ** 3 + 2 * 128 ** 3 + 2 * 256 ** 3
+    assert lib.dsdf_padded_size(4, 5, 6) == 10 * 11 * 12 + 2 + 2 * (1 * 2 * 2) + 2 * (2 * 3 * 3) + 2 * (4 * 5 * 6)
     ws = lib.dsdf_render_workspace_size(512, 512, 64, 1, 0)
     assert ws >= 516 * 516 * 64 * 40 and lib.dsdf_render_workspace_size(0, 4, 4, 1, 0) == 0
     assert lib.dsdf_render_workspace_size(512, 512, 64, 4, 0) >= 4 * 516 * 516 * 64 * 40
