@@ -293,7 +293,7 @@ __global__ __launch_bounds__(256) void k_build_items(ViewBatch VB, int view0, in
         const int px = (int)((tx << O.tw_log2) + (in & ((1u << O.tw_log2) - 1u))), py = (int)((ty << O.th_log2) + (in >> O.tw_log2));
         if (px >= A.Wb || py >= A.Hb || py < row0 || py >= row1) return ~0u;     // (rows: this call's window of the film block)
         const uint32_t e = view * npix + (uint32_t)py * (uint32_t)A.Wb + (uint32_t)px;
-        return (skip && (skip[e] & far_bit)) ? ~0u : e;
+        return (skip && (skip[e] & far_bit)) ? ~0u : e;      // (far_bit: a MASK -- far pixels and, for the silhouette primal, deep ones)
     };
     auto live = [&](uint32_t i) { return entry(i) != ~0u; };
     // pass 1: live pixels of the region
@@ -431,7 +431,7 @@ void k_render_items(GridView G, dsdf_params P, ViewBatch VB, float *__restrict__
 // For spp < 64 (a power of two) a wave takes a tile_w x tile_h PIXEL TILE (64 / spp pixels) instead of 64 / spp consecutive
 // pixels of a row: its rays stay within a few voxels of each other (coherent row gathers, far fewer divergent march
 // lengths).  tile_w == 0: linear order.
-struct LaneMap { int tile_w, tile_h; uint32_t n_lanes; int row0, row1; };   // rows: film-block row window of the call
+struct LaneMap { int tile_w, tile_h; uint32_t n_lanes; int row0, row1; unsigned deep_mask; };   // rows: film-block row window of the call
 
 __device__ __forceinline__ uint32_t thread_lane(const ViewArgs &A, const LaneMap &M, uint32_t t, bool &valid) {
     if (M.tile_w == 0) {
@@ -482,6 +482,8 @@ __global__ __launch_bounds__(DSDF_BLOCK) void k_render_pass(GridView G, dsdf_par
             const unsigned f = skip[(size_t)blockIdx.y * A.Wb * A.Hb + (size_t)py * A.Wb + px];
             skip_trace = (f & (DIFF ? DSDF_PX_EMPTY_G : DSDF_PX_EMPTY)) != 0;
             far = (f & (DIFF ? DSDF_PX_FAR_G : DSDF_PX_FAR)) != 0 && !(DIRECT && !S.hide_emitters);   // (a visible environment is not zero)
+            // (hit proof: the samples of a deep pixel only reach film pixels that develop to 1 anyway; M.deep_mask = DSDF_PX_DEEP or 0)
+            if (!DIFF && !DIRECT && (f & M.deep_mask) && A.integrator == DSDF_SILHOUETTE) far = true;
             known_hit = !DIFF && !DIRECT && (f & DSDF_PX_HIT) && A.integrator == DSDF_SILHOUETTE;      // (hit proof, dsdf_proof.h)
         }
         if (py < M.row0 || py >= M.row1) { far = true; valid = false; }         // outside this call's row window
@@ -1066,6 +1068,8 @@ static bool backward_split() { static const int v = env_int("DSDF_BWD_SPLIT", 1)
 static int tail_per_xcd() { static const char *v = getenv("DSDF_TAIL_QUEUES"); return (v && !strcmp(v, "xcd")) ? 1 : 0; }
 // DSDF_FINE_HIT_PROOF=0: hit proof from the block maxima only (A/B)
 static bool fine_hit_proof() { static const int v = env_int("DSDF_FINE_HIT_PROOF", 1); return v != 0; }
+// DSDF_DEEP_SKIP=0: the samples of deep pixels are generated (and only their march is skipped)
+static bool deep_skip_enabled() { static const int v = env_int("DSDF_DEEP_SKIP", 1); return v != 0; }
 static bool primal_handoff() { static const int v = env_int("DSDF_PRIMAL_HANDOFF", 1); return v != 0; }
 static int tail_streams_enabled() { static int v = env_int("DSDF_TAIL_STREAMS", 1); return v; }
 // blocks (4 waves) per sub-queue of a tail kernel: DSDF_TAIL_BLOCKS overrides the built-in value
@@ -1187,9 +1191,12 @@ static int run_pass(const PassCtx &c, const Workspace &ws, const dsdf_camera *ca
             // stage of the hit proof: [DSDF_MAX_GROUPS * DSDF_ITEM_HDR ..) holds one entry per film-block pixel and view
             uint32_t *und = fstep > 0.f ? ws.items + (size_t)DSDF_MAX_GROUPS * DSDF_ITEM_HDR - DSDF_UNDECIDED_HDR : nullptr;
             if (und && hipMemsetAsync(und, 0, sizeof(uint32_t), st) != hipSuccess) return fail(DSDF_ERR_LAUNCH, "hipMemsetAsync(undecided list) failed");
+            // (when the proof runs on the finer min-grid, the coarser one gets a first, cheaper try)
+            const float step0 = level > 0 ? skip_step(cams + v0, nv, c.W, c.rx, c.ry, c.rz, level - 1) : 0.f;
             hipLaunchKernelGGL(k_pixel_skip, dim3((unsigned)((npix + 255) / 256), nv), dim3(256), 0, st,
-                               device_view(c.padded, c.rx, c.ry, c.rz, *c.prm), min_bounds(c.padded, c.rx, c.ry, c.rz, level),
-                               max_bounds(c.padded, c.rx, c.ry, c.rz), c.pp, VB, dst, step, hstep, und);
+                               device_view(c.padded, c.rx, c.ry, c.rz, *c.prm), min_bounds(c.padded, c.rx, c.ry, c.rz, level > 0 ? level - 1 : 0),
+                               min_bounds(c.padded, c.rx, c.ry, c.rz, level), max_bounds(c.padded, c.rx, c.ry, c.rz), c.pp, VB, dst,
+                               step0, step, hstep, und);
             if (und)
                 hipLaunchKernelGGL(k_pixel_hit_fine, dim3((unsigned)((npix * nv + 255) / 256)), dim3(256), 0, st,
                                    device_view(c.padded, c.rx, c.ry, c.rz, *c.prm), fine_bounds(c.padded, c.rx, c.ry, c.rz), c.pp, VB, dst,
@@ -1210,10 +1217,17 @@ static int run_pass(const PassCtx &c, const Workspace &ws, const dsdf_camera *ca
     const GridView G = device_view(c.padded, c.rx, c.ry, c.rz, *c.prm);
     const ShadeArgs S = make_shade_args(c.shading, DIFF);
     unsigned long long *st64 = (unsigned long long *)stats;
+    // hit proof, second half: the samples of deep pixels are not generated; the film pixels that receive hits only get (1, 1)
+    const bool deep_skip = !DIFF && skip && c.integrator == DSDF_SILHOUETTE && !(c.flags & DSDF_NO_HIT_PROOF) && deep_skip_enabled();
+    if (deep_skip) {
+        hipLaunchKernelGGL(k_film_ones, dim3((unsigned)((npix + 255) / 256), nv), dim3(256), 0, st, VB, skip, film, c.row0, c.row1, st64);
+        if ((rc = check_launch("k_film_ones"))) return rc;
+    }
     if (c.spp % 64 == 0) {
         // persistent workers over the compacted list of pixels that must be sampled
         // (sdf_direct_reparam with a visible environment: the background is not zero, every pixel is sampled)
-        const unsigned far_bit = (c.direct && !S.hide_emitters) ? 0u : (DIFF ? DSDF_PX_FAR_G : DSDF_PX_FAR);
+        // (for the silhouette primal also the pixels whose samples only reach film pixels of value 1: DSDF_PX_DEEP, k_skip_dilate)
+        const unsigned far_bit = (c.direct && !S.hide_emitters) ? 0u : (DIFF ? DSDF_PX_FAR_G : (DSDF_PX_FAR | (deep_skip ? DSDF_PX_DEEP : 0u)));
         if (hipMemsetAsync(ws.items, 0, (size_t)DSDF_MAX_GROUPS * DSDF_ITEM_HDR * sizeof(uint32_t), st) != hipSuccess)
             return fail(DSDF_ERR_LAUNCH, "hipMemsetAsync(work list) failed");
         // tile-major order: a tile = DSDF_ITEM_SEG chunks of 64 samples (16 x 16 pixels at 256 spp, 32 x 32 at 64 spp)
@@ -1302,7 +1316,7 @@ static int run_pass(const PassCtx &c, const Workspace &ws, const dsdf_camera *ca
         LaneMap M;
         size_t nunits;
         pass_shape(c.W, c.H, c.spp, M.tile_w, M.tile_h, nunits);
-        M.n_lanes = c.nl; M.row0 = c.row0; M.row1 = c.row1;
+        M.n_lanes = c.nl; M.row0 = c.row0; M.row1 = c.row1; M.deep_mask = deep_skip ? DSDF_PX_DEEP : 0u;
         const dim3 grid((unsigned)(nunits / 4), nv), blk(DSDF_BLOCK);
         timing_mark(0, st);
         if (c.direct) hipLaunchKernelGGL((k_render_pass<DIFF, true>), grid, blk, 0, st, G, c.pp, VB, film, q, st64, M, skip, S);

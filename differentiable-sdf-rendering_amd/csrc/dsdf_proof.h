@@ -19,6 +19,8 @@
 #define DSDF_PX_FAR 4u         /* (k_skip_dilate) every pixel within +-4 carries bit 0: the samples reach no output */
 #define DSDF_PX_FAR_G 8u       /* ... bit 1 */
 #define DSDF_PX_HIT 16u        /* every sample of the pixel hits the surface */
+#define DSDF_PX_DEEP 32u       /* (k_skip_dilate) every pixel within +-4 carries bit 4: the samples reach only film pixels of value 1 */
+#define DSDF_PX_ONE 64u        /* (k_skip_dilate) every pixel within +-2 carries bit 4: this FILM pixel receives hits only */
 #define DSDF_PX_KEEP (DSDF_PX_EMPTY | DSDF_PX_EMPTY_G | DSDF_PX_HIT)
 
 namespace dsdf {
@@ -75,15 +77,24 @@ DSDF_HD unsigned pixel_hit_proof(const GridView &G, const BoundGrid &B, const ds
     const float i0 = fmaxf(in.mint, 0.f), i1 = in.maxt;
     float J = -INFINITY, Jrun = 0.f;
     bool in_run = false;
-    for (float t = t0; t < t1 + step; t += step) {
-        const float tc = fminf(t, t1);
-        const float U = bound_at(B, G, fma3(tc, d, o));
-        const bool neg = U < 0.f && tc - half >= i0 && tc + half <= i1;
-        if (neg) {
-            if (!in_run) { in_run = true; Jrun = J; }             // (the samples of the run itself take no step: every evaluation hits)
-            if (tc + half >= Jrun + 1e-4f) return DSDF_PX_HIT;
-        } else in_run = false;
-        J = fmaxf(J, tc + half + U);
+    // (four samples per round: their bounds are fetched together -- the loads do not depend on each other, the decisions do)
+    for (float tb = t0; tb < t1 + step; tb += 4.f * step) {
+        float tc[4], U[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            tc[k] = fminf(tb + (float)k * step, t1);
+            U[k] = bound_at(B, G, fma3(tc[k], d, o));
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (!(tb + (float)k * step < t1 + step)) break;
+            const bool neg = U[k] < 0.f && tc[k] - half >= i0 && tc[k] + half <= i1;
+            if (neg) {
+                if (!in_run) { in_run = true; Jrun = J; }         // (the samples of the run itself take no step: every evaluation hits)
+                if (tc[k] + half >= Jrun + 1e-4f) return DSDF_PX_HIT;
+            } else in_run = false;
+            J = fmaxf(J, tc[k] + half + U[k]);
+        }
     }
     return 0u;
 }

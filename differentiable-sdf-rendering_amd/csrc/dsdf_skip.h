@@ -57,8 +57,10 @@ __global__ void k_window_max(const float *__restrict__ in, float *__restrict__ o
 // `undecided` (optional): [0] = counter (zeroed by the caller), entries from [DSDF_UNDECIDED_HDR]: view * Wb * Hb + pixel of every
 // pixel neither proof settled -- the work list of k_pixel_hit_fine.
 #define DSDF_UNDECIDED_HDR 16
-__global__ void k_pixel_skip(GridView G, BoundGrid Bmin, BoundGrid Bmax, dsdf_params P, ViewBatch VB,
-                             unsigned char *__restrict__ flags, float step, float hstep, uint32_t *__restrict__ undecided) {
+// step0 > 0: a first, cheaper attempt at the empty-space proof on the next-coarser level Bmin0 (blocks twice as large, steps twice
+// as long): most pixels of a silhouette view pass far from the shape and are settled there.
+__global__ void k_pixel_skip(GridView G, BoundGrid Bmin0, BoundGrid Bmin, BoundGrid Bmax, dsdf_params P, ViewBatch VB,
+                             unsigned char *__restrict__ flags, float step0, float step, float hstep, uint32_t *__restrict__ undecided) {
     const ViewArgs &A = VB.v[blockIdx.y];
     const int i = blockIdx.x * blockDim.x + threadIdx.x, npix = A.Wb * A.Hb;
     const bool valid = i < npix;
@@ -67,7 +69,9 @@ __global__ void k_pixel_skip(GridView G, BoundGrid Bmin, BoundGrid Bmax, dsdf_pa
         int py = i / A.Wb, px = i - py * A.Wb;
         CamRay r = camera_ray(A.cam, P, (float)(px - DSDF_BORDER) + 0.5f, (float)(py - DSDF_BORDER) + 0.5f, A.W, A.H);
         V3 d = r.d * rsqf(dot(r.d, r.d));
-        f = step > 0.f ? pixel_empty_proof(G, Bmin, P, r.o, d, step) : 0u;
+        if (step0 > 0.f) f = pixel_empty_proof(G, Bmin0, P, r.o, d, step0);
+        else f = 0u;
+        if (f != (DSDF_PX_EMPTY | DSDF_PX_EMPTY_G) && step > 0.f) f |= pixel_empty_proof(G, Bmin, P, r.o, d, step);
         if (hstep > 0.f && !(f & DSDF_PX_EMPTY)) f |= pixel_hit_proof(G, Bmax, P, r.o, d, hstep);
         flags[(size_t)blockIdx.y * npix + i] = (unsigned char)f;
     }
@@ -108,17 +112,44 @@ __global__ __launch_bounds__(256) void k_pixel_hit_fine(GridView G, BoundGrid B,
 // samples of a pixel with bit 2 (3) set cannot influence any output of the primal (gradient) pass and are
 // not generated at all.  (In place: writers only add bits 2/3, readers only look at bits 0/1.)
 #define DSDF_FAR_RADIUS 4
+// Bits 5/6 (DSDF_PX_DEEP / _ONE), the same argument for the hit proof of the silhouette primal: a film pixel all of whose
+// contributors (the pixels within +-2) carry DSDF_PX_HIT receives only samples of value 1, so its value channel EQUALS its
+// weight channel and it develops to 1 whatever the samples are (bit 6); a pixel whose whole +-4 neighbourhood carries
+// DSDF_PX_HIT only ever feeds such film pixels, so its samples are not generated (bit 5) -- k_film_ones adds (1, 1) to every
+// bit-6 film pixel instead, which leaves value == weight where samples still arrive and gives 1 / 1 where none does.
 __global__ void k_skip_dilate(ViewBatch VB, unsigned char *__restrict__ flags) {
     const ViewArgs &A = VB.v[blockIdx.y];
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= A.Wb * A.Hb) return;
     unsigned char *f = flags + (size_t)blockIdx.y * A.Wb * A.Hb;
     int py = i / A.Wb, px = i - py * A.Wb;
-    unsigned m = 3u;
+    unsigned m = 3u | DSDF_PX_HIT, near = DSDF_PX_HIT;
     for (int y = max(py - DSDF_FAR_RADIUS, 0); y <= min(py + DSDF_FAR_RADIUS, A.Hb - 1); ++y)
-        for (int x = max(px - DSDF_FAR_RADIUS, 0); x <= min(px + DSDF_FAR_RADIUS, A.Wb - 1); ++x)
-            m &= f[y * A.Wb + x];
-    f[i] = (unsigned char)((f[i] & DSDF_PX_KEEP) | (m << 2));
+        for (int x = max(px - DSDF_FAR_RADIUS, 0); x <= min(px + DSDF_FAR_RADIUS, A.Wb - 1); ++x) {
+            const unsigned v = f[y * A.Wb + x];
+            m &= v;
+            if (abs(y - py) <= 2 && abs(x - px) <= 2) near &= v;
+        }
+    f[i] = (unsigned char)((f[i] & DSDF_PX_KEEP) | ((m & 3u) << 2) | ((m & DSDF_PX_HIT) ? DSDF_PX_DEEP : 0u) | (near ? DSDF_PX_ONE : 0u));
+}
+
+// (1, 1) for the film pixels of the call's row window that receive hits only (bit 6): see k_skip_dilate.  The samples of the
+// deep pixels (bit 5) are proven hits that nobody generates: the caller's statistics count them as hits all the same.
+__global__ void k_film_ones(ViewBatch VB, const unsigned char *__restrict__ flags, float *__restrict__ blocks, int row0, int row1,
+                            unsigned long long *stats) {
+    const ViewArgs &A = VB.v[blockIdx.y];
+    const int i = blockIdx.x * blockDim.x + threadIdx.x, npix = A.Wb * A.Hb;
+    const int py = i < npix ? i / A.Wb : -1;
+    const unsigned f = (py >= row0 && py < row1) ? flags[(size_t)blockIdx.y * npix + i] : 0u;
+    if (f & DSDF_PX_ONE) {
+        float *b = blocks + ((size_t)blockIdx.y * npix + i) * 2;
+        atomicAdd(b, 1.f);
+        atomicAdd(b + 1, 1.f);
+    }
+    if (stats) {
+        const int n = wave_sum_i32((f & DSDF_PX_DEEP) ? A.spp : 0);
+        if (n && lane_id() == 0) atomicAdd(stats + (size_t)(blockIdx.x & 63u) * DSDF_STAT_SLOTS + 3, (unsigned long long)n);
+    }
 }
 
 // ---- host side: layout of the coarse levels behind the padded grid, level selection

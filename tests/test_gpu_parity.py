@@ -450,7 +450,8 @@ def test_hit_proof_is_exact(dsdf, spp):
     c = dsdf.render_forward(grid, sens, spp, seeds=seeds, stats=st['none'], empty_space_skip=False)
     d = {m: dsdf.stats_dict(v) for m, v in st.items()}
     assert d['all']['hits'] == d['empty']['hits'] == d['none']['hits'] > 0
-    assert d['all']['lanes'] == d['empty']['lanes']
+    # (deep pixels -- whole +-4 neighbourhood proven -- are not even sampled: fewer generated lanes, their samples counted as hits)
+    assert d['all']['lanes'] < d['empty']['lanes']
     assert rel_l2(a.cpu(), b.cpu()) < 1e-6 and rel_l2(a.cpu(), c.cpu()) < 1e-6
     assert d['all']['all_steps'] < 0.95 * d['empty']['all_steps'], (d['all']['all_steps'], d['empty']['all_steps'])   # (a 10^3-voxel window on a 96^3 grid: the core of the blob only)
     # simple shading needs the hit distance: identical step counts with and without the flag
