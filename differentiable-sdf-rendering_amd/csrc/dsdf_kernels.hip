@@ -656,9 +656,21 @@ __global__ __launch_bounds__(64) void k_backward_coef(GridView G, dsdf_params P,
     }
 }
 
+// DSDF_APPLY_HALF_TILE (default 1): the scatter of k_backward_apply goes through the 9 KB half tile (wave_scatter_half), 0: the 17 KB
+// tile of the fused kernel.
+#ifndef DSDF_APPLY_HALF_TILE
+#define DSDF_APPLY_HALF_TILE 1
+#endif
+#if DSDF_APPLY_HALF_TILE
+#define DSDF_APPLY_TILE_FLOATS DSDF_SCATH_FLOATS
+#define DSDF_APPLY_SCATTER wave_scatter_half
+#else
+#define DSDF_APPLY_TILE_FLOATS DSDF_SCAT_FLOATS
+#define DSDF_APPLY_SCATTER wave_scatter_t
+#endif
 __global__ __launch_bounds__(64) void k_backward_apply(GridView G, dsdf_params P, ViewBatch VB, Queue qall,
                                                        const float *__restrict__ block_adjs, float *__restrict__ grad_grid) {
-    __shared__ __attribute__((aligned(16))) float tile[DSDF_SCAT_FLOATS];
+    __shared__ __attribute__((aligned(16))) float tile[DSDF_APPLY_TILE_FLOATS];
     const ViewArgs &A = VB.v[blockIdx.y];
     const float *__restrict__ block_adj = block_adjs + (size_t)blockIdx.y * 2 * A.Wb * A.Hb;
     const Queue q = view_queue(qall, blockIdx.y);
@@ -689,8 +701,8 @@ __global__ __launch_bounds__(64) void k_backward_apply(GridView G, dsdf_params P
             const Lane L = lane_setup(A, P, lane);
             lane_backward_apply(P, A, L, tr, c, block_adj, req);
         }
-        wave_scatter_t(G, grad_grid, req[0], tile, lid);
-        if (A.integrator != DSDF_SILHOUETTE) wave_scatter_t(G, grad_grid, req[1], tile, lid);
+        DSDF_APPLY_SCATTER(G, grad_grid, req[0], tile, lid);
+        if (A.integrator != DSDF_SILHOUETTE) DSDF_APPLY_SCATTER(G, grad_grid, req[1], tile, lid);
     }
 }
 

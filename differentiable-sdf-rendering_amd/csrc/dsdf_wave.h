@@ -112,6 +112,68 @@ __device__ __forceinline__ void wave_scatter_t(const GridView &G, float *__restr
     wave_lds_sync();
 }
 
+// The same scatter through HALF the tile: the z taps {0, 1} and then {2, 3}, 32 contributions per lane and pass in a 64 x 36
+// tile (9 KB instead of 17 KB).  k_backward_apply is a latency-bound kernel whose occupancy was set by the tile (9 single-wave
+// blocks per CU = 2.25 waves per SIMD); at 9 KB twice as many fit.  Lane k < 32 owns tap (z = 2 * pass + k / 16, y, x) of the pass.
+#define DSDF_SCATH_STRIDE 36  /* floats per row: 16-byte aligned, the rows of 8 consecutive lanes on disjoint banks */
+#define DSDF_SCATH_FLOATS (64 * DSDF_SCATH_STRIDE)
+__device__ __forceinline__ void wave_scatter_half(const GridView &G, float *__restrict__ grad, const ScatterReq &rq,
+                                                  float *T, int lid) {
+    const bool on = rq.on;
+    const uint64_t all = __ballot(on);
+    if (!all) return;
+    CubicSetup s = cubic_setup(G, on ? rq.x : mk(0.f, 0.f, 0.f));
+    const int bx = iclamp(s.ix, -DSDF_APRON, G.rx - 1), by = iclamp(s.iy, -DSDF_APRON, G.ry - 1), bz = iclamp(s.iz, -DSDF_APRON, G.rz - 1);
+    float wx[4], wy[4], wz[4], dwx[4], dwy[4], dwz[4];
+    bspline_w(s.ax, wx); bspline_w(s.ay, wy); bspline_w(s.az, wz);
+    bspline_dw(s.ax, dwx); bspline_dw(s.ay, dwy); bspline_dw(s.az, dwz);
+    const float gx = rq.cg.x * G.frx, gy = rq.cg.y * G.fry, gz = rq.cg.z * G.frz;
+    const uint64_t key = ((uint64_t)(uint32_t)(bz + DSDF_APRON) << 42) | ((uint64_t)(uint32_t)(by + DSDF_APRON) << 21) | (uint64_t)(uint32_t)(bx + DSDF_APRON);
+    const uint32_t klo = (uint32_t)key, khi = (uint32_t)(key >> 32);
+    const int tk = lid >> 4, tj = (lid >> 2) & 3, ti = lid & 3;          // (lanes 0..31: tk in {0, 1})
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        if (on) {
+            float4 *row = reinterpret_cast<float4 *>(T + lid * DSDF_SCATH_STRIDE);
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                const int k = 2 * pass + kk;
+                const float azv = wz[k], azd = dwz[k] * gz;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float c0 = azv * wy[j] * rq.cv + azd * wy[j] + azv * dwy[j] * gy;
+                    const float c1 = azv * wy[j] * gx;
+                    row[kk * 4 + j] = make_float4(fmaf(c0, wx[0], c1 * dwx[0]), fmaf(c0, wx[1], c1 * dwx[1]),
+                                                  fmaf(c0, wx[2], c1 * dwx[2]), fmaf(c0, wx[3], c1 * dwx[3]));
+                }
+            }
+        }
+        wave_lds_sync();
+        uint64_t todo = all;
+        while (todo != 0) {
+            const int leader = __builtin_ctzll(todo);
+            const uint32_t llo = (uint32_t)__builtin_amdgcn_readlane((int)klo, leader), lhi = (uint32_t)__builtin_amdgcn_readlane((int)khi, leader);
+            const uint64_t grp = __ballot(on && klo == llo && khi == lhi);
+            todo &= ~grp;
+            const int gbx = __builtin_amdgcn_readlane(bx, leader), gby = __builtin_amdgcn_readlane(by, leader), gbz = __builtin_amdgcn_readlane(bz, leader);
+            if (lid < 32) {
+                float sum = 0.f;
+                uint64_t m = grp;
+                while (m != 0) {                                   // wave-uniform: lanes of this cell
+                    const int l = __builtin_ctzll(m);
+                    m &= m - 1;
+                    sum += T[l * DSDF_SCATH_STRIDE + lid];
+                }
+                if (sum != 0.f) {
+                    const int zi = iclamp(gbz + 2 * pass + tk, 0, G.rz - 1), yi = iclamp(gby + tj, 0, G.ry - 1), xi = iclamp(gbx + ti, 0, G.rx - 1);
+                    atomicAdd(grad + ((size_t)zi * G.ry + yi) * G.rx + xi, sum);
+                }
+            }
+        }
+        wave_lds_sync();
+    }
+}
+
 // ------------------------------------------------------------------ wave cell cache
 // The 64 lanes of a wave are samples of ONE pixel, so at every trace step they sit in a
 // handful of B-spline cells (measured: 5 distinct cells on average, <= 8 in 87 % and <= 16
