@@ -545,23 +545,27 @@ __global__ __launch_bounds__(DSDF_BLOCK) void k_render_pass(GridView G, dsdf_par
 #define DSDF_BWD_UNITS 16
 #endif
 struct UnitGather {
-    uint32_t c[DSDF_BWD_UNITS], total, unit0;
-    __device__ __forceinline__ void init(const Queue &q, uint32_t group) {
+    uint32_t c[DSDF_BWD_UNITS], lo[DSDF_BWD_UNITS], total, unit0;
+    // the queued samples [from[u], count[u]) of the group's units (from == nullptr: all of them)
+    __device__ __forceinline__ void init(const Queue &q, uint32_t group, const uint32_t *from = nullptr) {
         unit0 = group * (uint32_t)DSDF_BWD_UNITS;
         total = 0;
 #pragma unroll
         for (int k = 0; k < DSDF_BWD_UNITS; ++k) {
-            c[k] = (unit0 + k < q.nunits) ? (uint32_t)__builtin_amdgcn_readfirstlane((int)q.count[unit0 + k]) : 0u;
+            const bool in = unit0 + k < q.nunits;
+            const uint32_t n = in ? (uint32_t)__builtin_amdgcn_readfirstlane((int)q.count[unit0 + k]) : 0u;
+            lo[k] = (in && from) ? (uint32_t)__builtin_amdgcn_readfirstlane((int)from[unit0 + k]) : 0u;
+            c[k] = n - (lo[k] < n ? lo[k] : n);
             total += c[k];
         }
     }
     // queue slot of the s-th queued sample of the group
     __device__ __forceinline__ uint32_t slot(uint32_t s) const {
-        uint32_t u = 0, r = s;
+        uint32_t u = 0, r = s, base = lo[0];
 #pragma unroll
         for (int k = 0; k < DSDF_BWD_UNITS - 1; ++k)
-            if (u == (uint32_t)k && r >= c[k]) { r -= c[k]; u = k + 1; }
-        return (unit0 + u) * 64u + r;
+            if (u == (uint32_t)k && r >= c[k]) { r -= c[k]; u = k + 1; base = lo[k + 1]; }
+        return (unit0 + u) * 64u + base + r;
     }
 };
 
@@ -632,11 +636,20 @@ __global__ __launch_bounds__(64, DIRECT ? 1 : DSDF_BWD_MINWAVES) void k_backward
 // on the sweep's stream while the primal pass is still busy -- and k_backward_apply once the image gradient exists: film-adjoint
 // gather, 30 FMAs, transposed scatter (lane_backward_coef / _apply, dsdf_lane.h).  (The fused k_backward is 3.5 ms of dependent
 // chains at 1.4 waves/SIMD, exposed at the end of every step.)
-__global__ __launch_bounds__(64) void k_backward_coef(GridView G, dsdf_params P, ViewBatch VB, Queue qall) {
+// Two launches per sweep: the FIRST right behind the render kernel, for the samples it queued itself (`mark` receives the
+// count of every unit as it stood) -- it runs while the primal workers still have the chip, ahead of the tail kernel, which on
+// the step's critical path only needs the time of its longest rays once the primal kernel is gone; the SECOND after the tail
+// kernel, for the few samples that appended (`from` = the marks).  (One launch behind the tail kernel: +1.1-1.5 ms at the end of
+// every step, profiles/r04_step_timeline.md.)
+__global__ __launch_bounds__(64) void k_backward_coef(GridView G, dsdf_params P, ViewBatch VB, Queue qall, const uint32_t *__restrict__ from,
+                                                      uint32_t *__restrict__ mark) {
     const ViewArgs &A = VB.v[blockIdx.y];
     const Queue q = view_queue(qall, blockIdx.y);
+    const size_t voff = (size_t)blockIdx.y * q.nunits;
     UnitGather ug;
-    ug.init(q, blockIdx.x);
+    ug.init(q, blockIdx.x, from ? from + voff : nullptr);
+    if (mark && threadIdx.x < DSDF_BWD_UNITS && ug.unit0 + threadIdx.x < q.nunits)
+        mark[voff + ug.unit0 + threadIdx.x] = q.count[ug.unit0 + threadIdx.x];
     for (uint32_t si = threadIdx.x; si < ug.total; si += 64) {
         const uint32_t slot = ug.slot(si), lane = q.lane[slot];
         TraceOut tr;
@@ -777,6 +790,7 @@ struct Workspace {
     float *block, *block_adj;
     uint32_t *count, *qlane;
     float *qrec, *qcoef;   // qcoef: DSDF_COEF_WORDS rows per queue slot (split backward; not for sdf_direct_reparam)
+    uint32_t *count0;      // per unit: the queue length when the render kernel was done (k_backward_coef's two launches)
     unsigned char *skip;
     uint32_t *items;       // work lists of the persistent render kernel: DSDF_MAX_GROUPS headers, then one entry per film-block pixel and view
     char *tail;            // tail hand-off queues: DSDF_MAX_GROUPS x (counters | march states)
@@ -801,7 +815,7 @@ static Workspace carve(void *base, int W, int H, int spp, int nv, int integrator
     ws.block = (float *)(p + off); off += align_up(nv * Wb * Hb * nch * sizeof(float), 256);
     ws.skip = (unsigned char *)(p + off); off += align_up(nv * Wb * Hb, 256);
     ws.items = (uint32_t *)(p + off); off += align_up((DSDF_MAX_GROUPS * DSDF_ITEM_HDR + nv * Wb * Hb) * sizeof(uint32_t), 256);
-    ws.block_adj = nullptr; ws.count = nullptr; ws.qlane = nullptr; ws.qrec = nullptr; ws.qcoef = nullptr; ws.coef_rows = 0;
+    ws.block_adj = nullptr; ws.count = nullptr; ws.qlane = nullptr; ws.qrec = nullptr; ws.qcoef = nullptr; ws.coef_rows = 0; ws.count0 = nullptr;
     ws.tail = nullptr; ws.tail_bytes = 0; ws.tail_cap_sub = 0; ws.tail_words = 0;
     ws.group_views = (uint32_t)((nv + DSDF_MAX_GROUPS - 1) / DSDF_MAX_GROUPS);
     if (diff) {
@@ -812,6 +826,7 @@ static Workspace carve(void *base, int W, int H, int spp, int nv, int integrator
         if (integrator != DSDF_DIRECT) {
             ws.coef_rows = integrator == DSDF_SILHOUETTE ? 8 : DSDF_COEF_WORDS;         // (the silhouette integrator uses the first 8 rows)
             ws.qcoef = (float *)(p + off); off += align_up(nv * cap * ws.coef_rows * sizeof(float), 256);
+            ws.count0 = (uint32_t *)(p + off); off += align_up(nv * nunits * sizeof(uint32_t), 256);
         }
     }
     if (integrator != DSDF_DIRECT && spp % 64 == 0) {
@@ -1021,6 +1036,8 @@ struct PassCtx {
     int row0, row1;        // film-block rows of this call (multi-GPU pixel-tile split; the whole film by default)
     float *film;           // caller-owned film block to ACCUMULATE into (tile calls), or nullptr: the workspace's, zeroed
     hipStream_t st;
+    bool coef_early;       // gradient sweep: launch k_backward_coef for the render kernel's own samples AHEAD of the tail kernel
+    bool coef_done_early;  // (set by run_pass when it did)
 };
 
 static PassCtx make_ctx(const float *padded, int rx, int ry, int rz, const dsdf_params *prm, int W, int H, int spp,
@@ -1034,6 +1051,7 @@ static PassCtx make_ctx(const float *padded, int rx, int ry, int rz, const dsdf_
     c.Wb = W + 2 * DSDF_BORDER; c.Hb = H + 2 * DSDF_BORDER; c.nl = (uint32_t)(c.Wb * c.Hb * spp);
     c.row0 = 0; c.row1 = (int)c.Hb; c.film = nullptr;
     c.st = (hipStream_t)stream;
+    c.coef_early = false; c.coef_done_early = false;
     return c;
 }
 
@@ -1082,6 +1100,11 @@ static int tail_per_xcd() { static const char *v = getenv("DSDF_TAIL_QUEUES"); r
 static bool fine_hit_proof() { static const int v = env_int("DSDF_FINE_HIT_PROOF", 1); return v != 0; }
 // DSDF_DEEP_SKIP=0: the samples of deep pixels are generated (and only their march is skipped)
 static bool deep_skip_enabled() { static const int v = env_int("DSDF_DEEP_SKIP", 1); return v != 0; }
+// DSDF_COEF_EARLY=1: k_backward_coef for the render kernel's own samples AHEAD of the tail kernel + a second launch for what the
+// tail appended.  Measured (profiles/r04_tail_ab.md): the early launch is starved by the primal workers just like the tail kernel
+// (15 ms resident), and the tail kernel then starts later: step 42.5 vs 40.8 ms.  Default: one launch behind the tail kernel.
+static bool coef_early_enabled() { static const int v = env_int("DSDF_COEF_EARLY", 0); return v != 0; }
+static int hit_proof_min_spp() { static const int v = env_int("DSDF_HIT_PROOF_MIN_SPP", 16); return v; }
 static bool primal_handoff() { static const int v = env_int("DSDF_PRIMAL_HANDOFF", 1); return v != 0; }
 static int tail_streams_enabled() { static int v = env_int("DSDF_TAIL_STREAMS", 1); return v; }
 // blocks (4 waves) per sub-queue of a tail kernel: DSDF_TAIL_BLOCKS overrides the built-in value
@@ -1166,12 +1189,12 @@ static thread_local SkipShare t_share;
 
 static bool skip_share_matches(const SkipShare &h, const PassCtx &c, const dsdf_camera *cams, int nv) {
     return h.valid && h.padded == c.padded && h.rx == c.rx && h.ry == c.ry && h.rz == c.rz && h.W == c.W && h.H == c.H && h.nv == nv &&
-           h.hit_proof == (int)(c.integrator == DSDF_SILHOUETTE && !(c.flags & DSDF_NO_HIT_PROOF)) &&
+           h.hit_proof <= (int)(c.integrator == DSDF_SILHOUETTE && !(c.flags & DSDF_NO_HIT_PROOF)) &&      // (flags WITHOUT hit bits serve any call)
            memcmp(&h.prm, c.prm, sizeof(dsdf_params)) == 0 && memcmp(h.cams, cams, (size_t)nv * sizeof(dsdf_camera)) == 0;
 }
 
 template <bool DIFF>
-static int run_pass(const PassCtx &c, const Workspace &ws, const dsdf_camera *cams, int v0, int nv, ViewBatch &VB, Queue q,
+static int run_pass(PassCtx &c, const Workspace &ws, const dsdf_camera *cams, int v0, int nv, ViewBatch &VB, Queue q,
                     int64_t *stats) {
     int rc;
     hipStream_t st = c.st;
@@ -1196,7 +1219,9 @@ static int run_pass(const PassCtx &c, const Workspace &ws, const dsdf_camera *ca
         } else {
             unsigned char *dst = (can_share && !sh.valid) ? sh.buf : ws.skip;       // (a second, different batch keeps its own flags)
             // (the hit proof serves the silhouette integrator, which consumes nothing but the hit flag of a sample)
-            const bool want_hit = c.integrator == DSDF_SILHOUETTE && !(c.flags & DSDF_NO_HIT_PROOF);
+            // (the hit proof costs 0.4 + 0.6 ms per 12-view call and saves marching in proportion to the samples per pixel: below
+            // DSDF_HIT_PROOF_MIN_SPP samples -- of THIS call: in a shared bracket the gradient sweep's -- it does not pay)
+            const bool want_hit = c.integrator == DSDF_SILHOUETTE && !(c.flags & DSDF_NO_HIT_PROOF) && c.spp >= hit_proof_min_spp();
             const float hstep = want_hit ? hit_step(cams + v0, nv, c.W, c.rx, c.ry, c.rz) : 0.f;
             const float fstep = (want_hit && fine_hit_proof()) ? hit_step_fine(cams + v0, nv, c.W, c.rx, c.ry, c.rz) : 0.f;
             // the pixels neither proof settles are listed in the (not yet built) work-list area of this workspace for the second
@@ -1219,7 +1244,7 @@ static int run_pass(const PassCtx &c, const Workspace &ws, const dsdf_camera *ca
             if (dst == sh.buf) {
                 if (hipEventRecord(sh.ready, st) != hipSuccess) return fail(DSDF_ERR_LAUNCH, "hipEventRecord(shared skip flags) failed");
                 sh.valid = true; sh.padded = c.padded; sh.rx = c.rx; sh.ry = c.ry; sh.rz = c.rz; sh.W = c.W; sh.H = c.H; sh.nv = nv;
-                sh.hit_proof = (int)(c.integrator == DSDF_SILHOUETTE && !(c.flags & DSDF_NO_HIT_PROOF));
+                sh.hit_proof = (int)want_hit;
                 sh.prm = *c.prm;
                 memcpy(sh.cams, cams + v0, (size_t)nv * sizeof(dsdf_camera));
             }
@@ -1277,7 +1302,11 @@ static int run_pass(const PassCtx &c, const Workspace &ws, const dsdf_camera *ca
         const bool forked = handoff && ngroups > 1 && tail_streams_enabled() && helper_streams(st, hs);
         hipEvent_t joins[DSDF_MAX_BATCH];
         int njoin = 0;
-        const dim3 grid(worker_blocks()), blk(64);
+        // (DSDF_PRIMAL_WORKERS / DSDF_SWEEP_WORKERS: persistent workers per SIMD of the two render kernels -- A/B switch; the
+        // default fills every wave slot of the device, workers that find no slot start when others retire)
+        static const int w_primal = env_int("DSDF_PRIMAL_WORKERS", 0), w_sweep = env_int("DSDF_SWEEP_WORKERS", 0);
+        const int w_mine = DIFF ? w_sweep : w_primal;
+        const dim3 grid(w_mine > 0 ? (worker_blocks() / 8u) * (unsigned)w_mine : worker_blocks()), blk(64);
         for (int g = 0; g < ngroups; ++g) {
             const int a = g * per, b = (a + per) < nv ? (a + per) : nv;
             uint32_t *hdr = ws.items + (size_t)g * DSDF_ITEM_HDR;
@@ -1303,6 +1332,13 @@ static int run_pass(const PassCtx &c, const Workspace &ws, const dsdf_camera *ca
             }
             if ((rc = check_launch("k_render_items"))) return rc;
             if (g == ngroups - 1) timing_mark(1, st);
+            if (DIFF && handoff && c.coef_early && ngroups == 1 && ws.count0) {
+                // the coefficients of what the render kernel queued itself, ahead of the tail kernel (k_backward_coef's comment)
+                const dim3 cgrid((ws.nunits + DSDF_BWD_UNITS - 1) / DSDF_BWD_UNITS, nv);
+                hipLaunchKernelGGL(k_backward_coef, cgrid, dim3(64), 0, st, G, c.pp, VB, q, (const uint32_t *)nullptr, ws.count0);
+                if ((rc = check_launch("k_backward_coef"))) return rc;
+                c.coef_done_early = true;
+            }
             if (handoff) {
                 hipStream_t ts = st;
                 if (forked) {
@@ -1364,7 +1400,7 @@ int dsdf_render_forward(const float *padded, int rx, int ry, int rz, const dsdf_
     if (rc) return rc;
     if (!image_out) return fail(DSDF_ERR_INVALID_ARG, "dsdf_render_forward: image_out is null");
     if (!offsets && !seeds) return fail(DSDF_ERR_INVALID_ARG, "dsdf_render_forward: need offsets or seeds");
-    const PassCtx c = make_ctx(padded, rx, ry, rz, prm, width, height, spp, offsets, seeds, integrator, flags, shading, stream);
+    PassCtx c = make_ctx(padded, rx, ry, rz, prm, width, height, spp, offsets, seeds, integrator, flags, shading, stream);
     const int nb = batch_size(width, height, spp, n_views, integrator, workspace_bytes, false);
     const Workspace ws = carve(workspace, width, height, spp, nb, integrator, false);
     const Queue q = make_queue(ws, c.direct);
@@ -1387,7 +1423,7 @@ int dsdf_render_backward(const float *padded, int rx, int ry, int rz, const dsdf
     if (rc) return rc;
     if (!grad_image || !grad_grid) return fail(DSDF_ERR_INVALID_ARG, "dsdf_render_backward: null gradient buffer");
     if (!offsets && !seeds) return fail(DSDF_ERR_INVALID_ARG, "dsdf_render_backward: need offsets or seeds");
-    const PassCtx c = make_ctx(padded, rx, ry, rz, prm, width, height, spp, offsets, seeds, integrator, flags, shading, stream);
+    PassCtx c = make_ctx(padded, rx, ry, rz, prm, width, height, spp, offsets, seeds, integrator, flags, shading, stream);
     hipStream_t st = c.st;
     const int nb = batch_size(width, height, spp, n_views, integrator, workspace_bytes, true);
     const Workspace ws = carve(workspace, width, height, spp, nb, integrator, true);
@@ -1423,7 +1459,7 @@ int dsdf_render_forward_grad(const float *padded, int rx, int ry, int rz, const 
     if (!grad_image_out) return fail(DSDF_ERR_INVALID_ARG, "dsdf_render_forward_grad: grad_image_out is null");
     if (!tangent_padded && !tangent_p) return fail(DSDF_ERR_INVALID_ARG, "dsdf_render_forward_grad: need a tangent");
     if (!offsets && !seeds) return fail(DSDF_ERR_INVALID_ARG, "dsdf_render_forward_grad: need offsets or seeds");
-    const PassCtx c = make_ctx(padded, rx, ry, rz, prm, width, height, spp, offsets, seeds, integrator, flags, shading, stream);
+    PassCtx c = make_ctx(padded, rx, ry, rz, prm, width, height, spp, offsets, seeds, integrator, flags, shading, stream);
     hipStream_t st = c.st;
     const int nb = batch_size(width, height, spp, n_views, integrator, workspace_bytes, true);
     const Workspace ws = carve(workspace, width, height, spp, nb, integrator, true);
@@ -1511,13 +1547,16 @@ int dsdf_grad_sweep(const float *padded, int rx, int ry, int rz, const dsdf_para
     const Workspace ws = carve(workspace, width, height, spp, n_views, integrator, true);
     ViewBatch VB;
     const Queue q = make_queue(ws, c.direct);
+    c.coef_early = q.coef && backward_split() && coef_early_enabled();
     int rc2 = run_pass<true>(c, ws, cams, 0, n_views, VB, q, nullptr);
     if (rc2) return rc2;
     if (q.coef && backward_split()) {
         // the image-independent half of the adjoint of the queued samples, now: the caller has the primal pass to run (or
-        // running on another stream) before it can hand over the image gradient
+        // running on another stream) before it can hand over the image gradient.  (If run_pass already did the render kernel's
+        // own samples, only what the tail kernel appended is left.)
         const dim3 grid((ws.nunits + DSDF_BWD_UNITS - 1) / DSDF_BWD_UNITS, n_views);
-        hipLaunchKernelGGL(k_backward_coef, grid, dim3(64), 0, c.st, device_view(padded, rx, ry, rz, *prm), c.pp, VB, q);
+        hipLaunchKernelGGL(k_backward_coef, grid, dim3(64), 0, c.st, device_view(padded, rx, ry, rz, *prm), c.pp, VB, q,
+                           (const uint32_t *)(c.coef_done_early ? ws.count0 : nullptr), (uint32_t *)nullptr);
         return check_launch("k_backward_coef");
     }
     return DSDF_OK;
@@ -1534,7 +1573,7 @@ int dsdf_grad_backward(const float *padded, int rx, int ry, int rz, const dsdf_p
     if (!film_total || !grad_image || !grad_grid) return fail(DSDF_ERR_INVALID_ARG, "dsdf_grad_backward: null buffer");
     if (batch_size(width, height, spp, n_views, integrator, workspace_bytes, true) < n_views)
         return fail(DSDF_ERR_WORKSPACE, "dsdf_grad_backward: the workspace must be the one dsdf_grad_sweep filled");
-    const PassCtx c = make_ctx(padded, rx, ry, rz, prm, width, height, spp, offsets, seeds, integrator, flags, shading, stream);
+    PassCtx c = make_ctx(padded, rx, ry, rz, prm, width, height, spp, offsets, seeds, integrator, flags, shading, stream);
     hipStream_t st = c.st;
     const Workspace ws = carve(workspace, width, height, spp, n_views, integrator, true);
     const Queue q = make_queue(ws, c.direct);

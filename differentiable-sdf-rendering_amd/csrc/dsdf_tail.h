@@ -34,6 +34,14 @@
 #ifndef DSDF_PTAIL_GRACE
 #define DSDF_PTAIL_GRACE 4
 #endif
+// Issue priority of the tail waves (s_setprio, 0..3).  A tail kernel is ONE dependent chain per wave; beside the persistent
+// workers of a render kernel (6-8 VALU-bound waves per SIMD, round-robin issue) it gets a sixth of the issue slots and crawls
+// (profiles/r04_step_timeline.md: k_tail_trace_diff resident for 20 ms).  With a raised priority the SIMD issues the tail wave
+// whenever it is ready -- it can use at most every fifth slot or so -- and the chain runs at single-wave speed under the
+// render kernel instead of after it.
+#ifndef DSDF_TAIL_PRIO
+#define DSDF_TAIL_PRIO 3
+#endif
 #define DSDF_TAIL_SUBQ 64           /* sub-queues per launch: 8 per XCD (one per ticket counter of the render kernel's XCD share) */
 #define DSDF_TAIL_REFILL 24         /* idle lanes that trigger a refill in the tail kernels */
 #ifndef DSDF_TAIL_BLOCKS_PER_SUBQ
@@ -162,6 +170,7 @@ __device__ __forceinline__ void tail_stats(unsigned long long *stats, int lane_s
 // Resumes the queued rays of the gradient sweep and finishes their samples: value splat, backward-queue entry.
 __global__ __launch_bounds__(256) void k_tail_trace_diff(GridView G, dsdf_params P, ViewBatch VB, float *__restrict__ blocks,
                                                          TailQueue tq, Queue qall, unsigned long long *stats) {
+    __builtin_amdgcn_s_setprio(DSDF_TAIL_PRIO);
     const uint32_t first = tq.per_xcd ? tail_subq() : blockIdx.x % DSDF_TAIL_SUBQ;
     uint32_t hop = 0, total = 0;
     uint32_t *cnt = nullptr;
@@ -257,6 +266,7 @@ __global__ __launch_bounds__(256) void k_tail_trace_diff(GridView G, dsdf_params
 // gathers only on entering another cell -- the step is then a dependent ALU chain without a memory round trip.
 __global__ __launch_bounds__(256) void k_tail_trace_plain(GridView G, dsdf_params P, ViewBatch VB, float *__restrict__ blocks,
                                                           TailQueue tq, unsigned long long *stats) {
+    __builtin_amdgcn_s_setprio(DSDF_TAIL_PRIO);
     const uint32_t first = tq.per_xcd ? tail_subq() : blockIdx.x % DSDF_TAIL_SUBQ;
     uint32_t hop = 0, total = 0;
     uint32_t *cnt = nullptr;

@@ -430,7 +430,7 @@ def test_empty_space_skip_is_exact(dsdf, integ, R, W):
     assert rel_l2(c.cpu(), d.cpu()) < 1e-6
 
 
-@pytest.mark.parametrize('spp', [4, 64, 256])
+@pytest.mark.parametrize('spp', [4, 16, 64, 256])
 def test_hit_proof_is_exact(dsdf, spp):
     """The hit proof of the silhouette primal (csrc/dsdf_proof.h: pixels whose every sample provably hits are not marched) must not
     change any result: the SAME number of hits and the same image as with the empty-space proof alone and as without any proof
@@ -450,10 +450,14 @@ def test_hit_proof_is_exact(dsdf, spp):
     c = dsdf.render_forward(grid, sens, spp, seeds=seeds, stats=st['none'], empty_space_skip=False)
     d = {m: dsdf.stats_dict(v) for m, v in st.items()}
     assert d['all']['hits'] == d['empty']['hits'] == d['none']['hits'] > 0
-    # (deep pixels -- whole +-4 neighbourhood proven -- are not even sampled: fewer generated lanes, their samples counted as hits)
-    assert d['all']['lanes'] < d['empty']['lanes']
     assert rel_l2(a.cpu(), b.cpu()) < 1e-6 and rel_l2(a.cpu(), c.cpu()) < 1e-6
-    assert d['all']['all_steps'] < 0.95 * d['empty']['all_steps'], (d['all']['all_steps'], d['empty']['all_steps'])   # (a 10^3-voxel window on a 96^3 grid: the core of the blob only)
+    if spp < 16:
+        # below DSDF_HIT_PROOF_MIN_SPP (16) samples per pixel the proof costs more than the marching it saves: not computed
+        assert d['all']['lanes'] == d['empty']['lanes'] and d['all']['all_steps'] == d['empty']['all_steps']
+    else:
+        # (deep pixels -- whole +-4 neighbourhood proven -- are not even sampled: fewer generated lanes, their samples counted as hits)
+        assert d['all']['lanes'] < d['empty']['lanes']
+        assert d['all']['all_steps'] < 0.9 * d['empty']['all_steps'], (d['all']['all_steps'], d['empty']['all_steps'])
     # simple shading needs the hit distance: identical step counts with and without the flag
     sa, sb = dsdf.new_stats('cuda'), dsdf.new_stats('cuda')
     e = dsdf.render_forward(grid, sens, spp, seeds=seeds, integrator=O.SIMPLE_SHADING, stats=sa)
