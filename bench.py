@@ -135,6 +135,24 @@ def cpu_baseline(args, target_seconds=15.0):
                       f"{args.res}^3 grid; {tp + tg:.1f}s measured, scaled linearly in spp and views"}
 
 
+def side_roofline(model_key, kernel_name, kernel_ms, stats):
+    """VALU-issue roofline of the primal render kernel of a side block (low_spp, direct): measured VALU instructions per wave
+    iteration of THAT kernel (profiles/valu_model.json, written by the PMC passes of tools/pmc_workload.py --low --direct) x the
+    wave iterations counted live, over the kernel's own launch time (dsdf_kernel_timing_arm / _read)."""
+    model = load_valu_model()
+    if not model or model_key not in model or not kernel_ms:
+        return None
+    m = model[model_key]
+    valu = m['valu_per_wave_step'] * stats['wave_steps']
+    achieved = valu / (kernel_ms * 1e-3)
+    evals = stats['steps'] + stats['refine_steps']
+    lane_util = evals / max(64.0 * stats['wave_steps'], 1.0)
+    return {"bound": "valu", "kernel": kernel_name, "unit": "G wave-instr/s", "peak": VALU_PEAK / 1e9, "achieved": achieved / 1e9,
+            "frac": achieved / VALU_PEAK, "frac_lane_weighted": achieved / VALU_PEAK * lane_util, "lane_utilisation": lane_util,
+            "avg_launch_ms": kernel_ms, "wave_steps_per_launch": stats['wave_steps'], "valu_per_wave_step": m['valu_per_wave_step'],
+            "traffic": m.get('hbm_bytes_per_launch'), "calibration": f"profiles/valu_model.json[{model_key}] (tag {model.get('tag')})"}
+
+
 def direct_block(args, dev, grid, sensors, steps=4):
     """BASELINE.json configs[4] sizes on one GPU: sdf_direct_reparam with a 256^3 x 3 albedo volume, the same two-stream step."""
     import dsdf
@@ -165,7 +183,9 @@ def direct_block(args, dev, grid, sensors, steps=4):
     torch.cuda.synchronize()
     e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
     e0.record()
+    dsdf.kernel_timing_arm()
     img = dsdf.render_forward(grid, sensors, args.spp_primal, seeds=list(range(nv)), integrator='sdf_direct_reparam', shading=sh)
+    kern_ms = dsdf.kernel_timing_read()
     e1.record()
     dsdf.render_backward(grid, sensors, args.spp_grad, torch.sign(img - tgt) * scale, grad_grid=grad, seeds=list(range(50, 50 + nv)),
                          integrator='sdf_direct_reparam', shading=sh, grad_albedo=galb)
@@ -176,6 +196,10 @@ def direct_block(args, dev, grid, sensors, steps=4):
            "grad_l1": float(grad.double().abs().sum()), "grad_albedo_l1": float(galb.double().abs().sum()),
            "config": {"workload": f"diffuse-12-hqq sizes (BASELINE.json configs[4]) on ONE GPU: {args.res}^3 SDF + {args.res}^3 x 3 albedo, "
                                   f"{nv} views x {args.img}^2, sdf_direct_reparam (emitter sampling), spp {args.spp_primal}/{args.spp_grad}"}}
+    st = dsdf.new_stats(dev)
+    dsdf.render_forward(grid, sensors, args.spp_primal, seeds=list(range(nv)), integrator='sdf_direct_reparam', shading=sh, stats=st)
+    out["roofline"] = side_roofline('direct_primal', 'k_render_items<false, true, false> (primal render kernel of sdf_direct_reparam)', kern_ms,
+                                    dsdf.stats_dict(st))
     del albedo, galb, grad, tgt
     return out
 
@@ -449,6 +473,15 @@ def main():
         if lp:
             low["primal_ms_per_launch"] = sum(a.elapsed_time(b) for a, b in lp) / len(lp)
             low["grad_ms_per_launch"] = sum(a.elapsed_time(b) for a, b in lg) / len(lg)
+        if nv and not tiled:
+            lk = []
+            for k in range(3):
+                dsdf.kernel_timing_arm()
+                dsdf.render_forward(grid, sensors, 4, seeds=[(11 * k + i) * 2 for i in range(nv)], integrator=args.integrator, **shade)
+                lk.append(dsdf.kernel_timing_read())
+            lst = dsdf.new_stats(dev)
+            dsdf.render_forward(grid, sensors, 4, seeds=list(range(nv)), integrator=args.integrator, stats=lst, **shade)
+            low["roofline"] = side_roofline('low_primal', 'k_render_pass<false, false> (general pass, 4 spp)', sum(lk) / len(lk), dsdf.stats_dict(lst))
 
     # per-launch statistics (untimed; same launch shape as the timed ones)
     out_cfg, roof = {}, None
@@ -485,10 +518,17 @@ def main():
                                    "note": "SURVEY 8(d) tap-byte model; taps are LDS/L1-resident, so this is not a bound"}}
         if model and 'primal' in model:
             m = model['primal']
-            valu = m['valu_per_wave_step'] * sp['wave_steps']
+            if 'valu_per_wave_iteration' in m:
+                # (the hit proof removes the march of whole chunks but not their set-up / film code: VALU = a x wave iterations + b x chunks of
+                # 64 generated samples, both coefficients measured -- profiles/summarize_pmc.py)
+                valu = m['valu_per_wave_iteration'] * sp['wave_steps'] + m['valu_per_chunk'] * sp['lanes'] / 64.0
+            else:
+                valu = m['valu_per_wave_step'] * sp['wave_steps']
             achieved = valu / (kern_avg * 1e-3)
             roof.update({"achieved": achieved / 1e9, "frac": achieved / VALU_PEAK, "frac_lane_weighted": achieved / VALU_PEAK * lane_util,
-                         "valu_insts_per_launch": valu, "valu_per_wave_step": m['valu_per_wave_step'],
+                         "valu_insts_per_launch": valu, "valu_per_wave_step": valu / max(sp['wave_steps'], 1),
+                         "valu_per_wave_iteration": m.get('valu_per_wave_iteration'), "valu_per_chunk": m.get('valu_per_chunk'),
+                         "chunks_per_launch": sp['lanes'] / 64.0,
                          "calibration": f"profiles/valu_model.json (tag {model.get('tag')}): SQ_INSTS_VALU {m.get('valu_insts_per_launch')} / "
                                         f"{m.get('wave_steps_per_launch')} wave iterations of tools/pmc_workload.py",
                          "traffic": m.get('hbm_bytes_per_launch'), "traffic_unit": "bytes per launch (2 x FETCH_SIZE + WRITE_SIZE, separate PMC passes)",

@@ -378,7 +378,7 @@ void k_render_items(GridView G, dsdf_params P, ViewBatch VB, float *__restrict__
         TraceOut tr, trs, trb;
         clear_trace(tr);
         int lit = 0;
-        const Lane L = lane_setup(A, P, lane);
+        const Lane L = lane_setup(A, P, lane, px, py);
         if (known_hit) tr.its_t = 0.f;
         else if (!skip_trace) {
             // (the last few rays of the wave are handed to the tail queue: dsdf_tail.h)

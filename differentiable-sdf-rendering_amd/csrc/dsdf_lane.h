@@ -51,10 +51,17 @@ DSDF_HD void lane_pixel(const ViewArgs &A, uint32_t lane, int &px, int &py) {
     px = (int)(pix - (uint32_t)py * (uint32_t)A.Wb);
 }
 
-// lane -> pixel, jitter, camera ray (reparam.py:140-171, 90-95)
+// lane -> pixel, jitter, camera ray (reparam.py:140-171, 90-95).  The second form takes the pixel from the caller: the work-list
+// kernel knows it (wave-uniform), and lane_pixel's two divisions by run-time values are ~50 instructions per chunk.
+DSDF_HD Lane lane_setup(const ViewArgs &A, const dsdf_params &P, uint32_t lane, int px, int py);
 DSDF_HD Lane lane_setup(const ViewArgs &A, const dsdf_params &P, uint32_t lane) {
+    int px, py;
+    lane_pixel(A, lane, px, py);
+    return lane_setup(A, P, lane, px, py);
+}
+DSDF_HD Lane lane_setup(const ViewArgs &A, const dsdf_params &P, uint32_t lane, int px, int py) {
     Lane L;
-    lane_pixel(A, lane, L.px, L.py);
+    L.px = px; L.py = py;
     float r0, r1;
     if (A.offsets) { r0 = A.offsets[2 * (size_t)lane]; r1 = A.offsets[2 * (size_t)lane + 1]; }
     else sampler_next_2d(A.seed, lane, r0, r1);
