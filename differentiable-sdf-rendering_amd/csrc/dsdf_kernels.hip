@@ -1091,11 +1091,12 @@ static int env_int(const char *name, int dflt) {
 
 // DSDF_BWD_SPLIT=0: dsdf_grad_backward runs the fused k_backward instead of k_backward_coef (in dsdf_grad_sweep) + k_backward_apply
 static bool backward_split() { static const int v = env_int("DSDF_BWD_SPLIT", 1); return v != 0; }
-// DSDF_TAIL_QUEUES=xcd: tail sub-queue = (XCD of the producing worker, its ticket counter), drained by the blocks of that XCD
-// first; default `item`: sub-queue = work-list index % 64 -- measured (profiles/r04_tail_ab.md): the per-XCD queues keep the L2
-// policy of the render kernel but put a hard tile's long rays on an eighth of the tail waves, and the tail kernels are bound by
-// exactly those rays.  DSDF_PRIMAL_HANDOFF=0: the value-only march keeps its last rays (no primal tail kernel).
-static int tail_per_xcd() { static const char *v = getenv("DSDF_TAIL_QUEUES"); return (v && !strcmp(v, "xcd")) ? 1 : 0; }
+// DSDF_TAIL_QUEUES=xcd (default): tail sub-queue = (XCD of the producing worker, its ticket counter), drained by the blocks of that
+// XCD first; `item`: sub-queue = work-list index % 64 (round 3).  Measured (profiles/r04_tail_ab.md, profiles/r04_sq.json vs
+// r04_item_sq.json): with 4096 tail waves the per-XCD queues were SLOWER (a hard tile's long rays on an eighth of the waves: 4.4 ->
+// 6.1 ms), with ONE tail wave per SIMD -- what the longest chain wants anyway -- they win a little: k_tail_trace_plain L2 misses
+// 44 % -> 18 %, 2.6 -> 0.8 GB fetched, 3.1-3.5 -> 2.7-2.9 ms; step 41.0 -> 40.6 ms (three runs each).
+static int tail_per_xcd() { static const char *v = getenv("DSDF_TAIL_QUEUES"); return (v && !strcmp(v, "item")) ? 0 : 1; }
 // DSDF_FINE_HIT_PROOF=0: hit proof from the block maxima only (A/B)
 static bool fine_hit_proof() { static const int v = env_int("DSDF_FINE_HIT_PROOF", 1); return v != 0; }
 // DSDF_DEEP_SKIP=0: the samples of deep pixels are generated (and only their march is skipped)

@@ -12,14 +12,16 @@
 // diff_march_step; bit-identical to the closed loops, tests/test_kernel_math_host.py), adds the sample's film value and, in
 // the gradient pass, appends it to the backward queue.
 //
-// A tail kernel is bound by the LATENCY of its longest rays (1000+ dependent steps on an otherwise empty chip).  Round 3's
-// counters (profiles/r03_sq.json) showed what made every one of those steps slow: sub-queue = work-list index % 64 meant that a
-// tail wave drained rays of all 8 tiles in flight (one per XCD) and of all views -- 51 % L2 misses, 9.95 GB fetched per launch,
-// where the render kernel keeps ONE tile per XCD in its L2.  The sub-queues are now per XCD: a render wave appends to queue
-// (its XCC_ID, its ticket counter), i.e. in the order in which its XCD walks the tiles, and a tail block drains the queues of
-// the XCD it runs on first (then helps the others: every queue is drained whatever the block -> XCD mapping is).
+// A tail kernel is bound by the LATENCY of its longest rays (2000+ dependent steps of ~1.8 us on an otherwise empty chip), so it
+// runs ONE wave per SIMD (DSDF_TAIL_BLOCKS_PER_SUBQ): every further resident wave slows that chain down.  Round 3's counters
+// (profiles/r03_sq.json) showed what the memory system saw: sub-queue = work-list index % 64 meant that a tail wave drained
+// rays of all 8 tiles in flight (one per XCD) and of all views -- 51 % L2 misses, 9.95 GB fetched per launch.  The sub-queues are
+// per XCD now: a render wave appends to queue (its XCC_ID, its ticket counter), i.e. in the order in which its XCD walks the
+// tiles, and a tail block drains the queues of the XCD it runs on first (then helps the others: every queue is drained
+// whatever the block -> XCD mapping is): 18 % misses, 0.8 GB, and -- with one wave per SIMD -- 0.4 ms off the step
+// (profiles/r04_tail_ab.md; with 4096 tail waves the same mapping was slower: a hard tile's rays land on an eighth of the waves).
 // (The host side can still cut a launch into view groups with the tail kernel of group g on a helper stream beside the render
-// kernel of group g + 1 -- DSDF_GROUPS; measured slower than one group, profiles/r03a_tail_ab.md.)
+// kernel of group g + 1 -- DSDF_GROUPS; measured slower than one group, profiles/r03a_tail_ab.md, r04_tail_ab.md.)
 #pragma once
 
 #ifndef DSDF_TAIL_HANDOFF
