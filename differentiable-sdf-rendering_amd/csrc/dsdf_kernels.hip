@@ -573,7 +573,10 @@ struct UnitGather {
 #define DSDF_BWD_MINWAVES 1
 #endif
 template <bool DIRECT>
-__global__ __launch_bounds__(64, DIRECT ? 1 : DSDF_BWD_MINWAVES) void k_backward(GridView G, dsdf_params P, ViewBatch VB, Queue qall,
+#ifndef DSDF_BWD_DIRECT_MINWAVES
+#define DSDF_BWD_DIRECT_MINWAVES 3   /* 168 VGPRs + 1 KB of scratch per lane, 3 waves per SIMD instead of 413 registers and ONE: a kernel at 5 % VALU and 83 % L2 misses wants the waves (gradient call of C5: 98.2 -> 93.7 ms, checksums equal; profiles/r04_tail_ab.md) */
+#endif
+__global__ __launch_bounds__(64, DIRECT ? DSDF_BWD_DIRECT_MINWAVES : DSDF_BWD_MINWAVES) void k_backward(GridView G, dsdf_params P, ViewBatch VB, Queue qall,
                                                  const float *__restrict__ block_adjs,
                                                  float *__restrict__ grad_grid, float *__restrict__ grad_p,
                                                  unsigned long long *stats, ShadeArgs S) {
