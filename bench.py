@@ -46,7 +46,7 @@ sys.path.insert(0, os.path.join(ROOT, 'differentiable-sdf-rendering_amd', 'pytho
 import torch
 
 VALU_PEAK = 1024 * 2.4e9 / 2.0        # wave64 VALU instructions / s: 256 CUs x 4 SIMD-32, 2 clk per instruction
-FP32_VECTOR_PEAK = 157.3e12           # MI355X_MICROARCH.md: fp32 vector peak (packed FMA)
+FP32_VECTOR_PEAK = 157.3e12           # MI355X_MICROARCH.md: fp32 vector peak = 1024 SIMD-32 x 32 lanes x 2 flop (FMA) x 2.4 GHz (scalar v_fma_f32 at full rate; not a packed-math figure)
 SPLINE_FLOP_PER_EVAL = 168.0          # 64 + 16 + 4 FMAs of one value-only tricubic lookup
 
 
