@@ -533,6 +533,24 @@ def main():
                                         f"{m.get('wave_steps_per_launch')} wave iterations of tools/pmc_workload.py",
                          "traffic": m.get('hbm_bytes_per_launch'), "traffic_unit": "bytes per launch (2 x FETCH_SIZE + WRITE_SIZE, separate PMC passes)",
                          "traffic_from": model.get('source')})
+        # the gradient sweep has its own VALU-issue figure (since the hit proof halved the primal march the two render kernels take the same time)
+        if model and 'sweep' in model and kern_g:
+            ms = model['sweep']
+            kg = sum(kern_g) / len(kern_g)
+            g_evals = sg['steps'] + sg['refine_steps']
+            g_util = g_evals / max(64.0 * sg['wave_steps'], 1.0)
+            g_valu = ms['valu_per_wave_step'] * sg['wave_steps']
+            sweep = {"bound": "valu", "kernel": "k_render_items<true, false, false> (gradient sweep)", "unit": "G wave-instr/s", "peak": VALU_PEAK / 1e9,
+                     "achieved": g_valu / (kg * 1e-3) / 1e9, "frac": g_valu / (kg * 1e-3) / VALU_PEAK,
+                     "frac_lane_weighted": g_valu / (kg * 1e-3) / VALU_PEAK * g_util, "traffic": ms.get('hbm_bytes_per_launch'),
+                     "avg_launch_ms": kg, "wave_steps_per_launch": sg['wave_steps'], "lane_utilisation": g_util,
+                     "valu_insts_per_launch": g_valu, "valu_per_wave_step": ms['valu_per_wave_step'],
+                     "calibration": f"profiles/valu_model.json[sweep] (tag {model.get('tag')})"}
+            # (`roofline` stays the primal render kernel, as in every round; the sweep -- as long as the primal kernel since the hit
+            # proof -- is listed beside it, and both together as one figure: their instructions over their summed launch times)
+            roof["other_kernel"] = sweep
+            if roof.get("valu_insts_per_launch"):
+                roof["render_kernels_combined_frac"] = (roof["valu_insts_per_launch"] + g_valu) / ((kern_avg + kg) * 1e-3) / VALU_PEAK
         out_cfg = {"mean_steps_per_bbox_lane": (sp['steps'] + sp['tail_steps']) / max(sp['bbox_lanes'], 1),
                    "hit_fraction": sp['hits'] / total_lanes, "traced_fraction": sp['bbox_lanes'] / total_lanes,
                    "generated_fraction": sp['lanes'] / total_lanes, "handed_off_fraction": sp['tail_rays'] / max(sp['bbox_lanes'], 1),
