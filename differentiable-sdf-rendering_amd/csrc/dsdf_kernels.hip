@@ -644,7 +644,10 @@ __global__ __launch_bounds__(64, DIRECT ? DSDF_BWD_DIRECT_MINWAVES : DSDF_BWD_MI
 // the step's critical path only needs the time of its longest rays once the primal kernel is gone; the SECOND after the tail
 // kernel, for the few samples that appended (`from` = the marks).  (One launch behind the tail kernel: +1.1-1.5 ms at the end of
 // every step, profiles/r04_step_timeline.md.)
-__global__ __launch_bounds__(64) void k_backward_coef(GridView G, dsdf_params P, ViewBatch VB, Queue qall, const uint32_t *__restrict__ from,
+#ifndef DSDF_COEF_MINWAVES
+#define DSDF_COEF_MINWAVES 1
+#endif
+__global__ __launch_bounds__(64, DSDF_COEF_MINWAVES) void k_backward_coef(GridView G, dsdf_params P, ViewBatch VB, Queue qall, const uint32_t *__restrict__ from,
                                                       uint32_t *__restrict__ mark) {
     const ViewArgs &A = VB.v[blockIdx.y];
     const Queue q = view_queue(qall, blockIdx.y);
