@@ -67,3 +67,48 @@ def test_hit_proof_rejects_shapes_at_the_box_wall(harness):
     hits = harness.trace_hits(slab, cam, 176, 176, spp=4, seed=5)
     assert hits[(flags & PX_HIT) != 0].all()
     assert not hits[(flags & PX_EMPTY) != 0].any()
+
+
+def _check(harness, grid, cam, W, H, spp=4, seed=3):
+    flags, info = harness.pixel_proof(grid, cam, W, H)
+    hits = harness.trace_hits(grid, cam, W, H, spp=spp, seed=seed)
+    hit_px, empty_px = (flags & PX_HIT) != 0, (flags & PX_EMPTY) != 0
+    assert hits[hit_px].all(), f"{(~hits[hit_px].all(-1)).sum()} pixels flagged 'every sample hits' hold a missing sample"
+    assert not hits[empty_px].any(), "a pixel flagged empty holds a hitting sample"
+    return flags, info, hits
+
+
+def test_proofs_on_a_non_cubic_grid_and_a_translated_one(harness):
+    """Voxel sizes that differ per axis (the margins are taken on the finest axis) and sdf.p != 0 (the bounds are looked up at x - p like
+    the SDF itself): flagged pixels still agree with traced rays."""
+    lz, ly, lx = np.linspace(0, 1, 48), np.linspace(0, 1, 64), np.linspace(0, 1, 80)
+    z, y, x = np.meshgrid(lz, ly, lx, indexing='ij')
+    grid = (np.sqrt((x - .5) ** 2 + (y - .48) ** 2 + (z - .52) ** 2) - 0.28).astype(np.float32)
+    cam = O.Camera(O.regular_camera_origins(5)[3]).params()
+    flags, info, hits = _check(harness, grid, cam, 224, 224)
+    assert info[1] > 0 and ((flags & PX_HIT) != 0).sum() > 0.3 * hits.all(-1).sum()
+    old = [harness.params.sdf_p[k] for k in range(3)]
+    try:
+        harness.params.sdf_p[0], harness.params.sdf_p[1], harness.params.sdf_p[2] = 0.06, -0.05, 0.04
+        flags2, _, hits2 = _check(harness, grid, cam, 224, 224)
+        assert (flags2 != flags).any() and ((flags2 & PX_HIT) != 0).sum() > 0.3 * hits2.all(-1).sum()     # (the shape moved in the image)
+    finally:
+        harness.params.sdf_p[0], harness.params.sdf_p[1], harness.params.sdf_p[2] = old
+
+
+def test_proofs_with_the_sensor_inside_the_box(harness):
+    """Rays that start inside the traced box (b.inside: the march starts at t = 0) and even inside the shape."""
+    grid = _grids()['sphere64']
+    for origin in ([0.5, 0.5, 0.02], [0.5, 0.5, 0.3]):                       # inside the box, outside / inside the sphere
+        cam = O.Camera(np.array(origin), target=(0.5, 0.5, 0.9)).params()
+        _check(harness, grid, cam, 200, 200)
+
+
+def test_hit_proof_survives_a_noisy_field(harness):
+    """A field that is nowhere a distance: a sphere plus +-0.05 of voxel-scale noise (steps overshoot and undershoot at random).  The
+    proof makes no assumption about the field beyond the tap bounds, so whatever it flags must hold."""
+    rng = np.random.default_rng(4)
+    grid = (_grids()['sphere64'] + rng.uniform(-0.05, 0.05, (64, 64, 64))).astype(np.float32)
+    cam = O.Camera(O.regular_camera_origins(5)[1]).params()
+    flags, info, hits = _check(harness, grid, cam, 176, 176, spp=6)
+    print(f"noisy sphere: {((flags & PX_HIT) != 0).sum()} of {hits.all(-1).sum()} all-hit pixels proven")
