@@ -927,6 +927,7 @@ void dsdf_default_params(dsdf_params *p) {
     p->trace_eps = 1e-6f; p->extra_thresh = 0.05f; p->sil_weight_offset = 0.05f; p->sil_weight_epsilon = 1e-6f;
     p->bbox_delta = 0.05f; p->edge_eps = 0.01f; p->clamping_thresh = 0.05f; p->near_clip = 1e-2f; p->far_clip = 1e4f;
     p->weight_strategy = 6; p->refine_steps = 10;
+    p->normalize_warp_field = 1; p->max_reparam_depth = -1;
     p->light_dir[0] = p->light_dir[1] = p->light_dir[2] = 0.57735026918962576f;
 }
 

@@ -352,6 +352,15 @@ DSDF_HD void emitter_term(const ShadeArgs &S, const DirectHit &h, V3 d, EmitterT
 }
 DSDF_HD float bsdf_factor(const BsdfRay &b) { return b.woz * DSDF_INV_PI / b.pdf * mis_weight(b.pdf, DSDF_INV_4PI); }
 
+// warp.py:103: `reparam and (max_reparam_depth < 0 or depth <= max_reparam_depth)` for the depth-1 rays of sdf_direct_reparam
+// (:52 shadow ray, :95 BSDF-sampled ray).  With `warpprimary` (configs.py:63-75) they keep their direction and det = 1: the
+// differentiable trace still decides visibility (warp.py:105), its warp outputs are dropped -- every consumer
+// (warp_weight_positive, warp_coefficients) reads "no warp" from warp_t = inf.
+DSDF_HD bool reparam_depth1(const dsdf_params &P) { return P.max_reparam_depth < 0 || P.max_reparam_depth >= 1; }
+DSDF_HD void drop_warp(TraceOut &t) {
+    t.warp_t = INFINITY; t.warp_weight = 0.f; t.warp_t_d = mk(0.f, 0.f, 0.f); t.warp_weight_d = mk(0.f, 0.f, 0.f);
+}
+
 DSDF_HD void clear_trace_out(TraceOut &t, float its_t) {
     t.its_t = its_t; t.warp_t = INFINITY; t.warp_weight = 0.f; t.weight_sum = 0.f;
     t.warp_t_d = mk(0.f, 0.f, 0.f); t.warp_weight_d = mk(0.f, 0.f, 0.f); t.steps = 0; t.refine_steps = 0;
@@ -376,7 +385,7 @@ DSDF_HD int direct_value(const GridView &G, const dsdf_params &P, const ViewArgs
     int lit = 0;
     float ke = 0.f, ks = 0.f, kb = 0.f;
     if (front) {
-        if (diff) trace_diff(G, Ps, h.sr.o, h.sr.d, h.sr.maxt, trs);
+        if (diff) { trace_diff(G, Ps, h.sr.o, h.sr.d, h.sr.maxt, trs); if (!reparam_depth1(P)) drop_warp(trs); }
         else {
             // shadow rays dwell in the cell they start in (Mitsuba's offset_p starts them 1.8e-4 off the surface and their steps
             // grow geometrically): the value-only march keeps the 64 taps of its current cell in registers and gathers only
@@ -390,7 +399,7 @@ DSDF_HD int direct_value(const GridView &G, const dsdf_params &P, const ViewArgs
     if (S.use_mis) {
         const BsdfRay b = bsdf_setup(A, L, lane, h);
         if (b.active) {
-            if (diff) trace_diff(G, Ps, b.o, b.d, 1e30f, trb);
+            if (diff) { trace_diff(G, Ps, b.o, b.d, 1e30f, trb); if (!reparam_depth1(P)) drop_warp(trb); }
             else { ReuseFetch F; trace_plain(G, Ps, b.o, b.d, 1e30f, trb, F); }
             if (!(trb.its_t < INFINITY)) { kb = bsdf_factor(b); lit |= 2; }   // escaped: the environment, emitter pdf 1/(4 pi)
         }

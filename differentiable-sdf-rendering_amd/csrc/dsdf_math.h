@@ -1026,7 +1026,8 @@ DSDF_HD bool warp_coefficients(const GridView &G, const dsdf_params &P, V3 o, V3
     float v; V3 g; float H[6];
     eval_cubic<2>(G, x, v, g, H);
     float g2 = dot(g, g);
-    V3 n_ = g * (1.f / g2);                                          // normalize_sqr, math_util.py:13-17
+    const bool unit = P.normalize_warp_field != 0;                   // warp.py:56-62 (0: `warpnotnormalized`, configs.py:96-109)
+    V3 n_ = unit ? g * (1.f / g2) : g;                               // normalize_sqr, math_util.py:13-17 | the raw gradient
     // weight(), warp.py:25-39
     float edge_eps = (P.weight_strategy == 6) ? P.edge_eps * t : P.edge_eps;
     V3 bd_d;
@@ -1064,6 +1065,10 @@ DSDF_HD bool warp_coefficients(const GridView &G, const dsdf_params &P, V3 o, V3
     float tr_JHP = (trH - dHd) / g2 - 2.f * (gHg - dg * gHd) / (g2 * g2);
     // (Pq)^T J_n H d = Pq.Hd/g2 - 2 (Pq.g)(g.Hd)/g2^2
     float pq_JHd = dot(Pq, Hd) / g2 - 2.f * dot(Pq, g) * gHd / (g2 * g2);
+    if (!unit) {                                                     // n' = g, J_n = I (warp.py:60-62): tr(H A) = tr(H P) + Pq.Hd
+        tr_JHP = trH - dHd;
+        pq_JHd = dot(Pq, Hd);
+    }
     float tr_JHA = tr_JHP + pq_JHd;
     // a = -(grad w)^T A n' - w tr(J_n H A) ;  (grad w)^T A n' = w_d.Pn + (w_d.d)(Pq.n')
     float a = -(dot(w_d, Pn) + dot(w_d, d) * dot(Pq, n_)) - w * tr_JHA;

@@ -28,7 +28,7 @@ class DsdfParams(C.Structure):
                 ('sil_weight_epsilon', C.c_float), ('bbox_delta', C.c_float), ('edge_eps', C.c_float),
                 ('clamping_thresh', C.c_float), ('near_clip', C.c_float), ('far_clip', C.c_float),
                 ('sdf_p', C.c_float * 3), ('weight_strategy', C.c_int), ('refine_steps', C.c_int),
-                ('light_dir', C.c_float * 3)]
+                ('light_dir', C.c_float * 3), ('normalize_warp_field', C.c_int), ('max_reparam_depth', C.c_int)]
 
 
 class DsdfShading(C.Structure):
@@ -44,6 +44,7 @@ class DsdfError(RuntimeError):
 
 
 _lib = None
+ABI_VERSION = 305          # DSDF_VERSION of include/dsdf.h these ctypes mirrors were written against
 
 # name -> (restype, argtypes); every symbol include/dsdf.h declares
 SYMBOLS = {
@@ -113,6 +114,9 @@ def load():
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
+    if lib.dsdf_version() != ABI_VERSION:                # a stale .so would read the structs above with another layout
+        raise DsdfError(f"{LIB_PATH} is version {lib.dsdf_version()}, the binding expects {ABI_VERSION}: rebuild "
+                        f"(`python -c 'import __graft_entry__ as g; g.build()'`)")
     _lib = lib
     return lib
 

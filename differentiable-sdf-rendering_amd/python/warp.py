@@ -18,11 +18,13 @@ class WarpField2D:
 
     def apply(self, params):
         """Writes this field's settings into a DsdfParams struct."""
-        if not self.normalize_warp_field or self.return_aovs:
-            raise NotImplementedError("normalize_warp_field=False / return_aovs are outside the supported path")
+        if self.return_aovs:
+            raise NotImplementedError("return_aovs is outside the supported path (DESIGN.md section 9)")
         params.edge_eps = float(self.edge_eps)
         params.weight_strategy = int(self.weight_strategy)
         params.clamping_thresh = float(self.clamping_thresh)
+        params.normalize_warp_field = int(bool(self.normalize_warp_field))          # python/warp.py:56-62
+        params.max_reparam_depth = int(self.max_reparam_depth)                      # python/warp.py:103
         return params
 
 

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define DSDF_VERSION 304   /* 300: stats rows of DSDF_STAT_SLOTS (16) counters; tail hand-off on library-owned helper streams; 304: DSDF_NO_HIT_PROOF, the grid buffer carries the bounds of the hit proof (dsdf_padded_size) */
+#define DSDF_VERSION 305   /* 300: stats rows of DSDF_STAT_SLOTS (16) counters; tail hand-off on library-owned helper streams; 304: DSDF_NO_HIT_PROOF, the grid buffer carries the bounds of the hit proof (dsdf_padded_size); 305: dsdf_params grows by normalize_warp_field, max_reparam_depth */
 #define DSDF_STAT_SLOTS 16
 
 enum dsdf_status {
@@ -82,6 +82,10 @@ typedef struct dsdf_params {
     int   refine_steps;       /* shapes.py:245-257  10 (0 disables refinement) */
     float light_dir[3];       /* sdf_simple_shading_reparam.py:20  normalize(1,1,1): the fixed light of the debug integrator, in the
                                  SDF's frame (a caller that renders a rigidly transformed SDF rotates it, python/shapes.py Grid3d) */
+    int   normalize_warp_field; /* warp.py:20, 56-62  1: V = -g/|g|^2 v; 0 (configs.py:96-109 `warpnotnormalized`): V = -g v */
+    int   max_reparam_depth;  /* warp.py:11, 103  -1: every ray is reparameterised; 0 (configs.py:63-75 `warpprimary`): primary
+                                 rays only -- the depth-1 rays of sdf_direct_reparam (shadow ray :52, BSDF-sampled ray :95) keep
+                                 det = 1 and their un-warped direction */
 } dsdf_params;
 
 /* Scene-side inputs of sdf_direct_reparam (python/integrators/sdf_direct_reparam.py:16-111).  The reference takes BSDF and emitter from scene files it does not ship; this library

@@ -451,15 +451,21 @@ def warp_weight_fn(sdf, x, v, g, edge_eps):                           # warp.py:
     return w, w_d, eps_d
 
 
-def warp_eval(sdf, x, ray_d, t, dt_dx, ww, ww_d, active):             # warp.py:47-96
+def warp_eval(sdf, x, ray_d, t, dt_dx, ww, ww_d, active, normalize=True):   # warp.py:47-96
     """Returns (warp_dir with value ray_d, div with analytic value) -- attached
-    to the grid through v and g at x (x itself is constant for primary rays)."""
+    to the grid through v and g at x (x itself is constant for primary rays).
+    normalize=False: WarpField2D.normalize_warp_field = False (warp.py:59-62; the `warpnotnormalized` method, configs.py:96-109)."""
     active = active & torch.isfinite(t)
     v, _, g, g_det, H = sdf.eval_all(x)
     H = H.detach()
-    n_, jn = normalize_sqr(g_det)                                      # :55
-    warp = -n_ * v[:, None]
-    jac = -torch.matmul(jn, H) * v[:, None, None] - outer(n_, g)      # :57
+    if normalize:
+        n_, jn = normalize_sqr(g_det)                                  # :57
+        warp = -n_ * v[:, None]
+        jac = -torch.matmul(jn, H) * v[:, None, None] - outer(n_, g)  # :59
+    else:
+        n_ = g_det                                                     # :61
+        warp = -n_ * v[:, None]
+        jac = -H * v[:, None, None] - outer(n_, g)                     # :63
     w, w_grad, eps_grad = warp_weight_fn(sdf, x.detach(), v.detach(), g.detach(), EDGE_EPS * t.detach())
     w_grad = w_grad + eps_grad[:, None] * ray_d * EDGE_EPS            # :70
     w_grad = w_grad * ww[:, None] + w[:, None] * ww_d                 # :73
@@ -534,9 +540,10 @@ def spawn_ray_to(p, n, target):
     return o, dv / dist[:, None], dist * (1.0 - SHADOW_EPSILON)
 
 
-def warped_ray(sdf, o, d, maxt, reparam):
+def warped_ray(sdf, o, d, maxt, reparam, normalize=True):
     """WarpField2D.ray_intersect (warp.py:99-117) for a batch of rays whose origin may be attached:
-    trace under suspend_grad, then eval the warp at ray(warp_t).  -> (its_t, d_attached, det)."""
+    trace under suspend_grad, then eval the warp at ray(warp_t).  -> (its_t, d_attached, det).
+    `reparam` is the caller's flag AFTER the depth rule of warp.py:103."""
     tr = ray_intersect(sdf, o.detach(), d.detach(), maxt)
     N = o.shape[0]
     d_att = d
@@ -547,7 +554,7 @@ def warped_ray(sdf, o, d, maxt, reparam):
             tw = tr['warp_t'][sel]
             x = o[sel] + tw[:, None] * d[sel].detach()
             wdir, dv, wact = warp_eval(sdf, x, d[sel].detach(), tw, tr['warp_t_d'][sel], tr['warp_weight'][sel],
-                                       tr['warp_weight_d'][sel], torch.ones_like(tw, dtype=torch.bool))
+                                       tr['warp_weight_d'][sel], torch.ones_like(tw, dtype=torch.bool), normalize)
             keep = wact.nonzero()[:, 0]
             sel = sel[keep]
             d_att = d.index_put((sel,), wdir[keep])
@@ -629,14 +636,16 @@ def principled_eval(base_color, roughness, wi, wo):
 
 
 def direct_radiance(sdf, albedo, o, d_att, its_t, emitter_u, reparam, env=1.0, hide_emitters=False, use_mis=False,
-                    bsdf_u=None, detach_indirect_si=False, decouple_reparam=False, d_det=None, roughness=None):
+                    bsdf_u=None, detach_indirect_si=False, decouple_reparam=False, d_det=None, roughness=None,
+                    normalize_warp_field=True):
     """sdf_direct_reparam.py:29-105 for the hit lanes + the environment term of the others (without the
     primary determinant, which the caller multiplies in).  -> rgb (N,3).
     use_mis: emitter sampling weighted by the power heuristic plus the BSDF-sampling branch (:77-105) with `bsdf_u` (N,2) as
     its next_2d() (the next_1d() before it selects a lobe: unused by `diffuse`).  detach_indirect_si / decouple_reparam
     (:44-47): the shadow ray starts from the detached hit / from the hit of the un-warped ray (si_d0).
     roughness: a (Z,Y,X,1) volume switches the BSDF from `diffuse` (albedo = reflectance) to `principled` (albedo = base_color);
-    emitter sampling only."""
+    emitter sampling only.  `reparam` here is the flag of the DEPTH-1 rays (shadow ray :52, BSDF-sampled ray :95): the caller has
+    applied warp.py:103 (False under `warpprimary`, max_reparam_depth = 0)."""
     if roughness is not None and use_mis:
         raise NotImplementedError("principled + use_mis: Principled::sample is not restated")
     N = o.shape[0]
@@ -666,7 +675,7 @@ def direct_radiance(sdf, albedo, o, d_att, its_t, emitter_u, reparam, env=1.0, h
     contrib_all = torch.zeros(hsel.numel(), 3, dtype=dt)
     inv_4pi = 1.0 / (4.0 * math.pi)
     if fsel.numel() > 0:
-        s_t, sd_att, det_e = warped_ray(sdf, so[fsel], sd[fsel], smaxt[fsel], reparam)   # :54 ray_test
+        s_t, sd_att, det_e = warped_ray(sdf, so[fsel], sd[fsel], smaxt[fsel], reparam, normalize_warp_field)   # :54 ray_test
         vis = (~torch.isfinite(s_t)).to(dt)
         cos_o = dot(n[fsel], sd_att)                                    # wo = si.to_local(shadow_ray.d)
         a = eval_trilinear(albedo, p[fsel])                           # reflectance volume lives on the unit cube
@@ -697,7 +706,7 @@ def direct_radiance(sdf, albedo, o, d_att, its_t, emitter_u, reparam, env=1.0, h
             mag = (1.0 + pb.detach().abs().max(dim=-1).values) * RAY_EPSILON     # si.spawn_ray -> offset_p (attached to p only)
             sgn = torch.where(dot(nb, db) >= 0, torch.ones_like(mag), -torch.ones_like(mag))
             ob = pb + (mag * sgn)[:, None] * nb
-            b_t, _, det_b = warped_ray(sdf, ob, db, torch.full_like(mag, 1e30), reparam)    # :95-96 ray_intersect, depth 1
+            b_t, _, det_b = warped_ray(sdf, ob, db, torch.full_like(mag, 1e30), reparam, normalize_warp_field)    # :95-96 ray_intersect, depth 1
             escaped = ~torch.isfinite(b_t)                              # si_bsdf invalid -> the environment emitter
             ab = eval_trilinear(albedo, pb)
             bsdf_val = ab * (wob[:, 2] / math.pi)[:, None]              # :97 bsdf.eval(ctx, si, bs.wo): local wo, cos detached
@@ -943,14 +952,17 @@ def lane_positions(W, H, spp, offsets):
 def render(sdf, cam, W, H, spp, offsets, integrator=SILHOUETTE, reparam=True,
            return_aux=False, chunk=1 << 17, albedo=None, emitter_u=None, env=1.0, hide_emitters=False, rows=None,
            return_block=False, use_mis=False, bsdf_u=None, detach_indirect_si=False, decouple_reparam=False, light_dir=None,
-           roughness=None):
+           roughness=None, normalize_warp_field=True, max_reparam_depth=-1):
     """One view.  offsets: (Wb*Hb*spp, 2) in [0,1) (the sampler's next_2d per
     lane).  Returns image (H,W,3), differentiable w.r.t. sdf.data / sdf.p when
     they require grad.  `reparam=False` gives the DummyWarpField path
     (warp.py:179-196).  rows = (row0, row1): only the samples of the film-BLOCK rows [row0, row1) are generated
-    (multi-GPU pixel-tile split; they keep their lane index); return_block: the un-developed film block (Hb, Wb, 4)."""
+    (multi-GPU pixel-tile split; they keep their lane index); return_block: the un-developed film block (Hb, Wb, 4).
+    normalize_warp_field / max_reparam_depth: the two WarpField2D settings the method configs change (warp.py:11, 20;
+    configs.py:63-75 `warpprimary`, :96-109 `warpnotnormalized`)."""
     Wb, Hb = W + 2 * BORDER, H + 2 * BORDER
     dt = offsets.dtype
+    reparam1 = reparam and (max_reparam_depth < 0 or 1 <= max_reparam_depth)      # warp.py:103 for the depth-1 rays
     pos_all = lane_positions(W, H, spp, offsets)
     if rows is not None:
         lo, hi = rows[0] * Wb * spp, rows[1] * Wb * spp          # lanes are pixel-major, pixels row-major
@@ -983,15 +995,16 @@ def render(sdf, cam, W, H, spp, offsets, integrator=SILHOUETTE, reparam=True,
                 tw = tr['warp_t'][sel]
                 x = o[sel] + tw[:, None] * d[sel]
                 wdir, dv, wact = warp_eval(sdf, x, d[sel], tw, tr['warp_t_d'][sel], tr['warp_weight'][sel],
-                                           tr['warp_weight_d'][sel], torch.ones_like(tw, dtype=torch.bool))
+                                           tr['warp_weight_d'][sel], torch.ones_like(tw, dtype=torch.bool), normalize_warp_field)
                 keep = wact.nonzero()[:, 0]
                 sel = sel[keep]
                 d_att = d.index_put((sel,), wdir[keep])                  # warp.py:114
                 div = div.index_put((sel,), replace_grad(torch.ones_like(dv[keep]), dv[keep]))   # warp.py:115
                 aux['warp_active'] += int(keep.numel())
         if integrator == DIRECT:                                         # sdf_direct_reparam.py:16-111
-            rgb = direct_radiance(sdf, albedo, o, d_att, its_t, emitter_u[s:s + chunk], reparam, env, hide_emitters, use_mis,
-                                  None if bsdf_u is None else bsdf_u[s:s + chunk], detach_indirect_si, decouple_reparam, d, roughness) * div[:, None]
+            rgb = direct_radiance(sdf, albedo, o, d_att, its_t, emitter_u[s:s + chunk], reparam1, env, hide_emitters, use_mis,
+                                  None if bsdf_u is None else bsdf_u[s:s + chunk], detach_indirect_si, decouple_reparam, d, roughness,
+                                  normalize_warp_field) * div[:, None]
         elif integrator == SILHOUETTE:                                   # sdf_silhouette_reparam.py:20-22
             val = hit.to(dt) * div
         else:                                                            # sdf_simple_shading_reparam.py:20-22

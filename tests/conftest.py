@@ -55,6 +55,22 @@ class HostHarness:
     def _p(a):
         return a.ctypes.data_as(C.c_void_p) if a is not None else None
 
+    def settings(self, **fields):
+        """Context manager: dsdf_params fields (e.g. normalize_warp_field=0, max_reparam_depth=0) for the calls inside."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def cm():
+            old = {k: getattr(self.params, k) for k in fields}
+            try:
+                for k, v in fields.items():
+                    setattr(self.params, k, v)
+                yield self
+            finally:
+                for k, v in old.items():
+                    setattr(self.params, k, v)
+        return cm()
+
     def eval_cubic(self, grid, pts, order=2):
         grid = np.ascontiguousarray(grid, np.float32); pts = np.ascontiguousarray(pts, np.float32)
         n = pts.shape[0]

@@ -192,7 +192,7 @@ class _LeafSdf:
         return self.v, self.v.detach(), self.g, self.g.detach(), self.H
 
 
-def oracle_warp_coefficients(case, o, d, tr, dtype=torch.float64):
+def oracle_warp_coefficients(case, o, d, tr, dtype=torch.float64, normalize=True):
     """python/warp.py:47-96 through oracle/sdf_oracle.py:warp_eval with autograd: per-ray active flag, cdir = d(dir)/dv,
     a = d(div)/dv, b = d(div)/dg and the value of div.  o, d: (n,3) tensors; tr: dict of per-ray trace outputs (tensors)."""
     o = o.to(dtype); d = d.to(dtype)
@@ -203,7 +203,7 @@ def oracle_warp_coefficients(case, o, d, tr, dtype=torch.float64):
     sdf = O.Grid3d(case['grid'].float().to(dtype))
     leaf = _LeafSdf(sdf, x)
     wdir, div, active = O.warp_eval(leaf, x, d, tt, tr['warp_t_d'].to(dtype), tr['warp_weight'].to(dtype),
-                                    tr['warp_weight_d'].to(dtype), fin)
+                                    tr['warp_weight_d'].to(dtype), fin, normalize)
     a, b = torch.autograd.grad(div.sum(), (leaf.v, leaf.g), retain_graph=True, allow_unused=True)
     cols = []
     for k in range(3):
@@ -224,11 +224,11 @@ def silhouette_rays(case, n=6000, seed=7):
     return o32, d32, m32, tr
 
 
-def check_warp_coefficients(tag, case, o32, d32, tr32, out):
+def check_warp_coefficients(tag, case, o32, d32, tr32, out, normalize=True):
     """Per-ray A9 outputs (dict of numpy arrays: active, cdir, a, b, div) against the oracle's autograd linearisation of
     WarpField2D.eval; gates = max(2 x the torch oracle's own fp32-vs-fp64 difference, 1e-4) per output."""
-    ref = oracle_warp_coefficients(case, o32, d32, tr32)
-    r32 = oracle_warp_coefficients(case, o32, d32, tr32, dtype=torch.float32)
+    ref = oracle_warp_coefficients(case, o32, d32, tr32, normalize=normalize)
+    r32 = oracle_warp_coefficients(case, o32, d32, tr32, dtype=torch.float32, normalize=normalize)
     act = np.asarray(out['active']) != 0
     assert (act != ref['active']).mean() < 2e-3, (act.sum(), ref['active'].sum())
     m = act & ref['active'] & r32['active']
@@ -237,7 +237,7 @@ def check_warp_coefficients(tag, case, o32, d32, tr32, out):
     for k in ('cdir', 'a', 'b', 'div'):
         e, f = rel_l2(np.asarray(out[k])[m], ref[k][m]), rel_l2(r32[k][m], ref[k][m])
         tol = max(FLOOR_FACTOR * f, NORTH_STAR)
-        record('warp_eval', tag=tag, case=case['name'], output=k, err=e, floor=f, tol=tol, rays=int(m.sum()))
+        record('warp_eval' if normalize else 'warp_eval_not_normalized', tag=tag, case=case['name'], output=k, err=e, floor=f, tol=tol, rays=int(m.sum()))
         msgs.append((k, e, tol))
     bad = [x for x in msgs if not x[1] <= x[2]]
     assert not bad, msgs

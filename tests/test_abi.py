@@ -24,7 +24,7 @@ def test_every_header_symbol_exported(built):
     for s in syms:
         assert hasattr(lib, s), f"{s} declared in include/dsdf.h but not exported"
     assert set(syms) == set(dsdf._lib.SYMBOLS), "ctypes prototypes out of sync with the header"
-    assert lib.dsdf_version() == 304
+    assert lib.dsdf_version() == 305 == dsdf._lib.ABI_VERSION
 
 
 def test_default_params_and_sizes(built):
@@ -33,7 +33,7 @@ def test_default_params_and_sizes(built):
     p = dsdf.default_params()
     assert abs(p.trace_eps - 1e-6) < 1e-12 and abs(p.edge_eps - 0.01) < 1e-9 and p.weight_strategy == 6
     assert p.refine_steps == 10 and abs(p.clamping_thresh - 0.05) < 1e-9
-    assert C.sizeof(dsdf.DsdfParams) == 68 and abs(p.light_dir[0] - 3 ** -0.5) < 1e-7 and C.sizeof(dsdf.DsdfCamera) == 64
+    assert C.sizeof(dsdf.DsdfParams) == 76 and p.normalize_warp_field == 1 and p.max_reparam_depth == -1 and abs(p.light_dir[0] - 3 ** -0.5) < 1e-7 and C.sizeof(dsdf.DsdfCamera) == 64
     # padded copy + coarse min-grids (8^3 and 4^3 blocks) + the hit proof's max-grid (2^3 blocks), each raw and dilated,
     # + the fine window maxima of the hit proof at full resolution and their scratch
     assert lib.dsdf_padded_size(256, 256, 256) == 262 ** 3 + 2 * 32 ** 3 + 2 * 64 ** 3 + 2 * 128 ** 3 + 2 * 256 ** 3

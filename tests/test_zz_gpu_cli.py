@@ -45,13 +45,13 @@ def ball_scene(tmp_path, monkeypatch):
     return 'ball'
 
 
-def _run(tmp_path, monkeypatch, scene, optconfig, n_iter, extra=()):
+def _run(tmp_path, monkeypatch, scene, optconfig, n_iter, extra=(), config='warp'):
     import optimize
     monkeypatch.setattr(optimize, 'RENDER_DIR', str(tmp_path / 'renders'))
-    args = [scene, '--optconfig', optconfig, '--configs', 'warp', '--outputdir', str(tmp_path / 'out'), '--refspp', '128',
+    args = [scene, '--optconfig', optconfig, '--configs', config, '--outputdir', str(tmp_path / 'out'), '--refspp', '128',
             f'--n_iter={n_iter}', '--spp=64', '--sdf_res=32'] + list(extra)
     optimize.main(args)
-    out = tmp_path / 'out' / scene / optconfig / 'warp'
+    out = tmp_path / 'out' / scene / optconfig / config
     lv = json.load(open(out / 'metadata.json'))['loss_values']
     assert len(lv) == n_iter and all(np.isfinite(lv)), lv
     return out, lv
@@ -95,3 +95,12 @@ def test_optimize_cli_principled(dsdf, tmp_path, monkeypatch, ball_scene):
     got = base.reshape(-1, 3).mean(0).cpu().numpy()
     assert np.abs(got - np.array(BALL_COLOUR)).max() < 0.12, got
     assert float(rough.min()) >= 0.1 - 1e-6 and float(rough.max()) <= 0.8 + 1e-6                 # variables.py:121
+
+
+@pytest.mark.parametrize('config', ['warpprimary', 'warpnotnormalized'])
+def test_optimize_cli_method_configs(dsdf, tmp_path, monkeypatch, ball_scene, config):
+    """`--configs warpprimary` (python/configs.py:63-75: only the primary ray is reparameterised) and `--configs warpnotnormalized`
+    (:96-109: V = -g v) run end to end through sdf_direct_reparam and optimise (parity of the two estimators:
+    tests/test_gpu_warp_settings.py)."""
+    out, lv = _run(tmp_path, monkeypatch, ball_scene, 'diffuse-6', 40, ['--resx=48', '--resy=48'], config=config)
+    assert np.mean(lv[-5:]) < 0.6 * np.mean(lv[:3]), lv
