@@ -1,29 +1,43 @@
 #!/usr/bin/env python3
-"""REFERENCE-SIDE fixture generator: runs the real stack (Mitsuba 3 + Dr.Jit + rgl-epfl/differentiable-sdf-rendering's python/)
-on the seeded inputs of tests/cases.py and writes tests/golden/ref_<case>.npz in the layout tests/test_golden.py reads.
+"""REFERENCE-SIDE fixture generator: executes rgl-epfl/differentiable-sdf-rendering's OWN python/ files on the seeded inputs of
+tests/cases.py and writes golden files in the layout tests/test_golden.py reads.  Two ways to run it:
 
-It CANNOT run in this repository's build container (no mitsuba / drjit, no network) and has never been run by the authors of
-this repository: it is written against the reference's sources (file:line cited at every call) so that a maintainer with the
-reference's environment can pin the in-repo oracle -- and through it the HIP path -- to the reference itself:
+(1) the real stack (Mitsuba 3 + Dr.Jit; not available in this repository's build container, never run by its authors):
 
-    pip install mitsuba fastsweep                       # the reference's README.md:48
-    python tools/make_reference_fixtures.py --reference /path/to/differentiable-sdf-rendering [--variant llvm_ad_rgb]
-    python -m pytest tests/test_golden.py -k reference  # oracle (CPU) and HIP (GPU) against the new files
+        pip install mitsuba fastsweep                       # the reference's README.md:48
+        python tools/make_reference_fixtures.py --reference /path/to/differentiable-sdf-rendering [--variant llvm_ad_rgb]
+        -> tests/golden/ref_<case>.npz                      # pins oracle and HIP path to the reference AND its dependencies
 
-Until such a file exists `tests/test_golden.py::test_*_reference_fixture` SKIP loudly and DESIGN.md keeps saying "parity unpinned".
+(2) `--shim`: the same reference files, imported from --reference (default /root/reference), run on top of tools/refshim/ -- a
+    torch-backed stand-in for the subset of Dr.Jit / Mitsuba 3 they use (tools/refshim/_core.py says exactly what is restated):
 
-What is dumped, per case (sphere16, blob32 of tests/cases.py; the grid itself is stored, so the two sides cannot drift):
-  * `sampler_2d`          first `next_2d()` of Mitsuba's `independent` sampler seeded like ReparamIntegrator.prepare
-                          (python/integrators/reparam.py:37-54)                       -> pins oracle.independent_sampler_2d
-  * `ri_*`                SDFBase.ray_intersect(ray, warp=WarpField2D) for the camera rays of `ray_pos`
-                          (python/shapes.py:115-288): its_t, warp_t, warp_t_d, warp_weight, warp_weight_d
-  * `ri_plain_its_t`      SDFBase.ray_intersect_non_diff (python/shapes.py:290-339)
-  * `we_dir`, `we_div`    WarpField2D.eval at those rays (python/warp.py:47-96): warped direction (primal) and divergence
+        python tools/make_reference_fixtures.py --shim
+        -> tests/golden/refshim_<case>.npz                  # COMMITTED: pins the oracle to the reference's first-party code
+
+    What (2) pins: python/shapes.py (SDFBase.ray_intersect, eval_trace_weight, ray_intersect_non_diff, the refinement loop,
+    compute_surface_interaction, Grid3d.eval*), python/warp.py (WarpField2D.weight / eval / ray_intersect), python/math_util.py,
+    python/integrators/reparam.py (prepare, render, eval_sample, render_backward, ray_intersect / ray_test),
+    sdf_silhouette_reparam.py, sdf_simple_shading_reparam.py, sdf_direct_reparam.py and python/configs.py (the `warp` settings)
+    run LITERALLY.  What it does not pin: the third-party layer underneath (arrays, AD, loops, cubic texture, sensor, film,
+    sampler, BSDF, emitter), which the stand-in restates like the oracle does.  It runs in fp64 (REFSHIM_DTYPE=float32 for the
+    reference's own precision), so the comparison with the fp64 oracle is sharp: ~1e-9 instead of the fp32 floor.
+
+What is dumped, per case (sphere16, blob32 of tests/cases.py; the grid and the fp32 sensor record are stored, so the two sides
+cannot drift):
+  * `sampler_2d`          first `next_2d()` of the `independent` sampler seeded like ReparamIntegrator.prepare
+                          (python/integrators/reparam.py:37-54)
   * `eval_*`              Grid3d.eval_all at random points (python/shapes.py:438-450): value, gradient, Hessian
-  * per integrator tag (sil, shade): `img_<tag>` = integrator.render (python/integrators/reparam.py:120-185),
-    `grad_<tag>` = d(sum(img * grad_image))/d(sdf.data) and `gradp_<tag>` = .../d(sdf.p) through render_backward (:187-190)
+  * `ri_*`                SDFBase.ray_intersect(ray, warp=WarpField2D) for camera rays (python/shapes.py:115-288): its_t, warp_t,
+                          warp_t_d, warp_weight, warp_weight_d;  `ri_plain_its_t`: ray_intersect_non_diff (python/shapes.py:290-339)
+  * `we_dir`, `we_div`    WarpField2D.eval at those rays (python/warp.py:47-96); with --shim also `we_a`, `we_b`, `we_cdir`:
+                          d(div)/dv, d(div)/dg, d(dir)/dv by AD through the reference's eval
+  * `si_p`, `si_n`        compute_surface_interaction for the hit rays (python/shapes.py:347-366)
+  * per integrator tag (sil, shade[, direct, direct_mis]): `img_<tag>` = integrator.render (python/integrators/reparam.py:120-185),
+    `grad_<tag>` = d(sum(img * grad_image))/d(sdf.data), `gradp_<tag>` = .../d(sdf.p) through render_backward (:187-190)
+    [`galb_<tag>` = .../d(reflectance volume)]
 """
 import argparse
+import inspect
 import os
 import sys
 
@@ -34,9 +48,9 @@ ROOT = os.path.dirname(HERE)
 
 
 def case_inputs(name):
-    """The seeded inputs of tests/cases.py WITHOUT importing the in-repo oracle for anything but the grids' closed forms
-    (numpy only: sphere_grid / blob_grid are restated here so that this script depends on nothing of this repository)."""
-    import torch                                                    # (only for the seeded generator that tests/cases.py uses)
+    """The seeded inputs of tests/cases.py WITHOUT the product: grids from the oracle's closed forms, the rest from torch's
+    seeded generator exactly as tests/cases.py draws it."""
+    import torch
     cfg = {'sphere16': (16, 1, 0, 16, 16, 4, 1), 'blob32': (32, 3, 1, 24, 24, 8, 2)}[name]
     R, ncam, icam, W, H, spp, seed = cfg
     sys.path.insert(0, os.path.join(ROOT, 'oracle'))
@@ -46,17 +60,40 @@ def case_inputs(name):
     torch.rand((W + 4) * (H + 4) * spp, 2, generator=gen, dtype=torch.float32)      # (cases.py draws the explicit offsets first)
     grad_image = torch.randn(H, W, 3, generator=gen, dtype=torch.float32).numpy()
     origin = np.asarray(O.regular_camera_origins(ncam)[icam], np.float64)
-    return dict(name=name, grid=grid, W=W, H=H, spp=spp, origin=origin, grad_image=grad_image, render_seed=40 + seed)
+    cam16 = O.Camera(origin).params()                               # the fp32 sensor record the C-ABI receives (include/dsdf.h)
+    gen2 = torch.Generator().manual_seed(11)                        # tests/cases.py: direct_inputs
+    albedo = (torch.rand(6, 5, 4, 3, generator=gen2, dtype=torch.float32) * 0.6 + 0.2).numpy()
+    return dict(name=name, grid=grid, W=W, H=H, spp=spp, origin=origin, cam16=cam16, grad_image=grad_image, render_seed=40 + seed,
+                albedo=albedo, env=tuple(float(np.float32(e)) for e in (1.0, 0.9, 0.8)))   # (fp32 values: what the C-ABI receives)
+
+
+def cols(a, k):
+    """A k-vector array of the stack as (n, k) numpy."""
+    arr = np.array(a)
+    if arr.ndim == 2 and arr.shape[0] == k and arr.shape[1] != k:
+        arr = arr.T
+    return np.ascontiguousarray(arr.reshape(-1, k))
+
+
+def mat33(m, mi):
+    arr = np.array(m)
+    if arr.ndim == 3 and arr.shape[-2:] == (3, 3):
+        return arr
+    return np.array([[np.array(m[i, j]) for j in range(3)] for i in range(3)]).transpose(2, 0, 1)
 
 
 def main():
     ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
-    ap.add_argument('--reference', required=True, help="checkout of rgl-epfl/differentiable-sdf-rendering (its python/ is imported)")
+    ap.add_argument('--reference', default='/root/reference', help="checkout of rgl-epfl/differentiable-sdf-rendering (its python/ is imported)")
+    ap.add_argument('--shim', action='store_true', help="run the reference's files on tools/refshim instead of Mitsuba 3 / Dr.Jit")
     ap.add_argument('--variant', default='llvm_ad_rgb', help="Mitsuba variant; the reference's CPU path is llvm_ad_rgb")
     ap.add_argument('--out', default=os.path.join(ROOT, 'tests', 'golden'))
     ap.add_argument('--cases', nargs='*', default=['sphere16', 'blob32'])
+    ap.add_argument('--tags', nargs='*', default=None, help='subset of the integrator runs (default: all)')
     args = ap.parse_args()
 
+    if args.shim:
+        sys.path.insert(0, os.path.join(HERE, 'refshim'))           # `import drjit`, `import mitsuba`, `import fastsweep` -> the stand-in
     import drjit as dr
     import mitsuba as mi
     mi.set_variant(args.variant)
@@ -64,19 +101,29 @@ def main():
     import configs                                                  # registers the integrators (python/configs.py:4-7)
     from shapes import Grid3d                                       # python/shapes.py:375
     from constants import SDF_DEFAULT_KEY, SDF_DEFAULT_KEY_P        # python/constants.py:18-19
+    prefix = 'refshim' if args.shim else 'ref'
 
     for name in args.cases:
         c = case_inputs(name)
         W, H, spp, seed = c['W'], c['H'], c['spp'], c['render_seed']
-        out = dict(grid=c['grid'], origin=c['origin'], W=np.int64(W), H=np.int64(H), spp=np.int64(spp), seed=np.int64(seed),
-                   grad_image=c['grad_image'], mitsuba_version=np.bytes_(mi.__version__), variant=np.bytes_(args.variant))
+        out = dict(grid=c['grid'], origin=c['origin'], cam16=c['cam16'], W=np.int64(W), H=np.int64(H), spp=np.int64(spp),
+                   seed=np.int64(seed), grad_image=c['grad_image'], albedo=c['albedo'], env=np.asarray(c['env'], np.float32),
+                   mitsuba_version=np.bytes_(mi.__version__), variant=np.bytes_(args.variant))
 
-        # ---- sensor: exactly python/util.py:115-138 (get_regular_cameras builds the same dict for its ring origins)
+        # ---- sensor: python/util.py:115-138 (get_regular_cameras builds the same dict for its ring origins).  With --shim the
+        # frame comes from the fp32 record (left, up, dir, origin: what look_at returns, rounded) so that both sides of the fp64
+        # comparison see bit-identical inputs (the estimator amplifies a 6e-8 input rounding to 1e-4)
         o = c['origin']
+        to_world = mi.ScalarTransform4f.look_at(mi.ScalarPoint3f(float(o[0]), float(o[1]), float(o[2])), [0.5, 0.5, 0.5], [0, 1, 0])
+        fov = 39.0
+        if args.shim:
+            r = c['cam16'].astype(np.float64)
+            frame = mi.ScalarTransform4f.from_frame(r[3:6], r[6:9], r[9:12], r[0:3])       # (stand-in only) look_at's result, rounded
+            assert np.abs(np.asarray(frame.matrix) - np.asarray(to_world.matrix)).max() < 1e-6
+            to_world = frame
+            fov = float(np.degrees(2.0 * np.arctan(r[12])))
         sensor = mi.load_dict({
-            'type': 'perspective', 'fov': 39.0,
-            'to_world': mi.ScalarTransform4f.look_at(mi.ScalarPoint3f(float(o[0]), float(o[1]), float(o[2])), [0.5, 0.5, 0.5], [0, 1, 0]),
-            'sampler': {'type': 'independent'},
+            'type': 'perspective', 'fov': fov, 'to_world': to_world, 'sampler': {'type': 'independent'},
             'film': {'type': 'hdrfilm', 'width': W, 'height': H, 'pixel_format': 'rgb', 'pixel_filter': {'type': 'gaussian'},
                      'sample_border': True}})
 
@@ -86,7 +133,7 @@ def main():
         smp.set_sample_count(spp)
         smp.set_samples_per_wavefront(spp)
         smp.seed(seed, n_lanes)
-        out['sampler_2d'] = np.array(smp.next_2d()).T.astype(np.float32).reshape(n_lanes, 2)
+        out['sampler_2d'] = cols(smp.next_2d(), 2).astype(np.float32)
 
         # ---- the SDF object on the raw tensor (a str argument would redistance it: python/shapes.py:384-386)
         def make_sdf():
@@ -99,8 +146,7 @@ def main():
         rng = np.random.default_rng(7)
         pts = rng.uniform(0.1, 0.9, (256, 3)).astype(np.float32)
         v, _, g, _, Hm = sdf.eval_all(mi.Point3f(pts[:, 0], pts[:, 1], pts[:, 2]))
-        out.update(eval_pts=pts, eval_v=np.array(v), eval_g=np.array(g).T.reshape(-1, 3),
-                   eval_H=np.array([[np.array(Hm[i, j]) for j in range(3)] for i in range(3)]).transpose(2, 0, 1))
+        out.update(eval_pts=pts, eval_v=np.array(v), eval_g=cols(g, 3), eval_H=mat33(Hm, mi))
 
         # ---- A2 / A4 / A9: per-ray outputs for camera rays at random film positions
         pos = rng.uniform(0.0, 1.0, (512, 2)).astype(np.float32)
@@ -112,39 +158,106 @@ def main():
         rayn.d = dr.normalize(rayn.d)
         warp_dir, div = wf.eval(rayn(warp_t), rayn.d, t=warp_t, dt_dx=warp_t_d, active=True,      # python/warp.py:47
                                 warp_weight=ww, warp_weight_d=ww_d)
-        as3 = lambda a: np.array(a).T.reshape(-1, 3)
-        out.update(ray_pos=pos, ray_o=as3(ray.o), ray_d=as3(ray.d), ray_maxt=np.array(ray.maxt),
-                   ri_its_t=np.array(its_t), ri_warp_t=np.array(warp_t), ri_warp_t_d=as3(warp_t_d), ri_warp_weight=np.array(ww),
-                   ri_warp_weight_d=as3(ww_d), ri_plain_its_t=np.array(plain if not isinstance(plain, tuple) else plain[0]),
-                   we_dir=as3(dr.detach(warp_dir)), we_div=np.array(dr.detach(div)))
+        out.update(ray_pos=pos, ray_o=cols(ray.o, 3), ray_d=cols(ray.d, 3), ray_maxt=np.array(ray.maxt),
+                   ri_its_t=np.array(its_t), ri_warp_t=np.array(warp_t), ri_warp_t_d=cols(warp_t_d, 3), ri_warp_weight=np.array(ww),
+                   ri_warp_weight_d=cols(ww_d, 3), ri_plain_its_t=np.array(plain if not isinstance(plain, tuple) else plain[0]),
+                   we_dir=cols(dr.detach(warp_dir), 3), we_div=np.array(dr.detach(div)))
+        with dr.suspend_grad():
+            si = sdf.compute_surface_interaction(ray, its_t)                                      # python/shapes.py:347
+        out.update(si_p=cols(si.p, 3), si_n=cols(si.n, 3))
+        if args.shim:
+            out.update(warp_coefficients_by_ad(dr, mi, sdf, wf, rayn, warp_t, warp_t_d, ww, ww_d))
 
-        # ---- A12-A17: image and gradients of the two primary-ray integrators
-        for integ_name, tag in (('sdf_silhouette_reparam', 'sil'), ('sdf_simple_shading_reparam', 'shade')):
-            # one placeholder shape whose id contains '_sdf_' (python/integrators/reparam.py:66-76); with a single shape the
-            # integrator never calls into Embree / OptiX (use_optix = len(shapes) > 1)
-            scene = mi.load_dict({'type': 'scene', 'integrator': {'type': integ_name}, 'sensor': sensor,
-                                  'placeholder_sdf_shape': {'type': 'sphere', 'center': [100, 100, 100], 'radius': 1e-3,
-                                                            'bsdf': {'type': 'diffuse'}}})
+        # ---- A12-A17: image and gradients of the integrators
+        runs = [('sdf_silhouette_reparam', 'sil', {}, 'warp'), ('sdf_simple_shading_reparam', 'shade', {}, 'warp')]
+        if args.shim:
+            D = 'sdf_direct_reparam'
+            runs += [(D, 'direct', {}, 'warp'), (D, 'direct_mis', {'use_mis': True}, 'warp'),
+                     # the integrator's own properties (sdf_direct_reparam.py:12-14) ...
+                     (D, 'direct_hide', {'hide_emitters': True}, 'warp'), (D, 'direct_detach', {'detach_indirect_si': True}, 'warp'),
+                     (D, 'direct_decouple', {'decouple_reparam': True}, 'warp'),
+                     (D, 'direct_mis_decouple', {'use_mis': True, 'decouple_reparam': True}, 'warp'),
+                     # ... and the method configs that change the warp field (python/configs.py:63-75, 96-109, 112-125)
+                     (D, 'direct_primary', {}, 'warpprimary'), (D, 'direct_mis_primary', {'use_mis': True}, 'warpprimary'),
+                     (D, 'direct_notnorm', {}, 'warpnotnormalized'), ('sdf_silhouette_reparam', 'sil_notnorm', {}, 'warpnotnormalized'),
+                     ('sdf_simple_shading_reparam', 'shade_notnorm', {}, 'warpnotnormalized'), (D, 'direct_onlyshading', {}, 'onlyshadinggrad')]
+        for integ_name, tag, props, method in runs:
+            if args.tags is not None and tag not in args.tags:
+                continue
+            # one placeholder shape whose id contains '_sdf_' (python/integrators/reparam.py:66-76) carries the BSDF; with a
+            # single shape the integrator never calls into Embree / OptiX (use_optix = len(shapes) > 1)
+            scene_dict = {'type': 'scene', 'integrator': dict({'type': integ_name}, **props), 'sensor': sensor,
+                          'placeholder_sdf_shape': {'type': 'sphere', 'center': [100, 100, 100], 'radius': 1e-3,
+                                                    'bsdf': {'type': 'diffuse'}}}
+            direct = tag.startswith('direct')
+            if direct:                                              # this repository's spec of the scene side (oracle/sdf_oracle.py header)
+                scene_dict['placeholder_sdf_shape']['bsdf'] = {'type': 'diffuse', 'reflectance': {'type': 'gridvolume',
+                                                                                                  'data': mi.TensorXf(c['albedo'])}}
+                scene_dict['emitter'] = {'type': 'constant', 'radiance': list(c['env'])}
+            scene = mi.load_dict(scene_dict)
             integ = scene.integrator()
             integ.sdf = make_sdf()
-            integ.warp_field = configs.get_config('warp').get_warpfield(integ.sdf)
+            integ.warp_field = configs.get_config(method).get_warpfield(integ.sdf)
+            if len(inspect.signature(integ.sample).parameters) == 5:
+                # python/integrators/sdf_simple_shading_reparam.py:16 still has the 5-argument signature of an older base
+                # class, ReparamIntegrator.eval_sample (reparam.py:94) passes 8: the body is run through this argument adapter
+                body = integ.sample
+                integ.sample = lambda mode, scene_, sampler, ray_, dL, state_in, reparam, active, **kw: body(scene_, sampler, ray_, None, active)
+                out[f'adapter_{tag}'] = np.int64(1)
             with dr.suspend_grad():
                 img = mi.render(scene, sensor=sensor, seed=seed, spp=spp)                       # python/shape_opt.py:61-63
-            out[f'img_{tag}'] = np.array(img)[..., :3].astype(np.float32)
+            out[f'img_{tag}'] = np.array(img)[..., :3].astype(np.float64 if args.shim else np.float32)
             params = mi.traverse(scene)
-            params.keep([SDF_DEFAULT_KEY, SDF_DEFAULT_KEY_P])
-            dr.enable_grad(params[SDF_DEFAULT_KEY]); dr.enable_grad(params[SDF_DEFAULT_KEY_P])
+            keys = [SDF_DEFAULT_KEY, SDF_DEFAULT_KEY_P] + [k for k in params if k.endswith('reflectance.volume.data')]
+            params.keep(keys)
+            for k in keys:
+                dr.enable_grad(params[k])
             params.update()
             # the SAME samples for the primal image and the gradient pass: seed_grad = seed, spp_grad = spp (the in-repo tests
             # compare a gradient pass on given samples; python/shape_opt.py:78-80 uses independent ones)
             img = mi.render(scene, params=params, sensor=sensor, seed=seed, spp=spp, seed_grad=seed, spp_grad=spp)
             dr.backward(img * mi.TensorXf(c['grad_image']))
-            out[f'grad_{tag}'] = np.array(dr.grad(params[SDF_DEFAULT_KEY])).reshape(c['grid'].shape).astype(np.float32)
-            out[f'gradp_{tag}'] = np.array(dr.grad(params[SDF_DEFAULT_KEY_P])).reshape(3).astype(np.float32)
+            ft = np.float64 if args.shim else np.float32
+            out[f'grad_{tag}'] = np.array(dr.grad(params[SDF_DEFAULT_KEY])).reshape(c['grid'].shape).astype(ft)
+            out[f'gradp_{tag}'] = np.array(dr.grad(params[SDF_DEFAULT_KEY_P])).reshape(3).astype(ft)
+            if direct:
+                out[f'galb_{tag}'] = np.array(dr.grad(params[keys[2]])).reshape(c['albedo'].shape).astype(ft)
 
-        fn = os.path.join(args.out, f'ref_{name}.npz')
+        fn = os.path.join(args.out, f'{prefix}_{name}.npz')
         np.savez_compressed(fn, **out)
         print(fn, {k: (getattr(v, 'shape', None) or v) for k, v in out.items()})
+
+
+def warp_coefficients_by_ad(dr, mi, sdf, wf, rayn, warp_t, warp_t_d, ww, ww_d):
+    """d(div)/dv, d(div)/dg and d(dir)/dv of WarpField2D.eval (python/warp.py:47-96) by AD through the reference's own eval: the SDF
+    handed to it returns value and gradient as AD leaves (Hessian and the detached copies from the real grid), which is exactly
+    the linearisation the HIP path's k_warp_eval reports (--shim only: uses torch autograd directly)."""
+    import torch
+    x = rayn(warp_t)
+    with dr.suspend_grad():
+        v0, _, g0, _, H0 = sdf.eval_all(x)
+    fin = np.isfinite(np.array(warp_t))
+    v = mi.Float(np.where(fin, np.array(v0), 0.0)); g = mi.Vector3f(np.where(fin[:, None], cols(g0, 3), 1.0))
+    dr.enable_grad(v, g)
+
+    class Leaf:
+        bbox = sdf.bbox
+
+        def eval_all(self, x_):
+            return v, dr.detach(v), g, dr.detach(g), H0
+    saved = wf.sdf
+    wf.sdf = Leaf()
+    try:
+        wdir, div = wf.eval(x, rayn.d, t=warp_t, dt_dx=warp_t_d, active=True, warp_weight=ww, warp_weight_d=ww_d)
+    finally:
+        wf.sdf = saved
+    a, b = torch.autograd.grad(div.v.sum(), (v.v, g.v), retain_graph=True, allow_unused=True)
+    cd = []
+    for k in range(3):
+        (ck,) = torch.autograd.grad(wdir.v[:, k].sum(), (v.v,), retain_graph=True, allow_unused=True)
+        cd.append(torch.zeros_like(v.v) if ck is None else ck)
+    z = lambda q, like: torch.zeros_like(like) if q is None else q
+    return dict(we_a=z(a, v.v).numpy(), we_b=z(b, g.v).numpy(), we_cdir=torch.stack(cd, -1).numpy())
 
 
 if __name__ == '__main__':
