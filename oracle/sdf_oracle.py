@@ -8,16 +8,26 @@ Dr.Jit reverse-mode AD; this oracle obtains them from torch autograd applied to
 the same forward program with the same detach / replace_grad structure, so the
 backward here is *not* hand-derived (the product's HIP backward is).
 
-PARITY UNPINNED: the reference has no tests, golden vectors or fixtures, and
-Mitsuba 3 / Dr.Jit (un-vendored, unversioned `pip install mitsuba`,
-README.md:48) cannot be imported in the build container.  The third-party
-conventions on the path -- Dr.Jit `Texture3f` cubic B-spline lookups, Mitsuba's
-perspective sensor, Gaussian reconstruction filter, `ImageBlock.put`,
-`HDRFilm.develop`, `BoundingBox3f.ray_intersect` -- are restated below from their
-published algorithms (see each docstring) and are this repository's own spec.
-What IS pinned: the in-repo closed forms (`SphereSDF`, shapes.py:494-514),
-B-spline identities, the primal-invariance property of the estimator, and
-finite differences in the style of figures/result_utils.py:126-161 (see tests/).
+PARITY -- what is pinned and what is not.  The reference has no tests, golden vectors or fixtures, and Mitsuba 3 / Dr.Jit
+(un-vendored, unversioned `pip install mitsuba`, README.md:48) cannot be imported in the build container.
+  * PINNED to the reference's own code (round 4): tools/make_reference_fixtures.py --shim imports the reference's python/
+    files (shapes.py, warp.py, math_util.py, configs.py, integrators/*.py) and runs them UNCHANGED on tools/refshim/, a torch
+    stand-in for the Dr.Jit / Mitsuba subset they use; the committed fixtures tests/golden/refshim_*.npz hold what that code
+    returned -- per-ray outputs, images and gradients of the three integrators under the method configs warp / warpprimary /
+    warpnotnormalized / onlyshadinggrad and the integrator properties -- and this oracle reproduces them to 1e-9 .. 1e-16 in fp64
+    (tests/test_refshim_fixture.py).  So every function below that restates FIRST-PARTY logic is checked against that logic itself.
+  * UNPINNED: the third-party layer -- Dr.Jit `Texture3f` cubic B-spline lookups, Mitsuba's perspective sensor, Gaussian
+    reconstruction filter, `ImageBlock.put`, `HDRFilm.develop`, `BoundingBox3f.ray_intersect`, the independent sampler, the
+    `diffuse` / `principled` BSDFs, the `constant` emitter.  They are restated below from their published algorithms (see each
+    docstring) -- and restated a second time, independently written, in tools/refshim (e.g. the sensor: matrices there, closed
+    form here; the two agree to 1e-16) -- and are this repository's own spec.  A fixture from the real stack
+    (tools/make_reference_fixtures.py without --shim -> tests/golden/ref_*.npz) would pin these too; none can be made here.
+  * Also pinned: the in-repo closed forms (`SphereSDF`, shapes.py:494-514), B-spline identities, the primal-invariance property
+    of the estimator, and finite differences in the style of figures/result_utils.py:126-161 (see tests/).
+  * Masked lanes: Dr.Jit's AD propagates a ZERO adjoint as zero across an edge whose weight is inf / NaN (drjit autodiff,
+    `mul_accum`: "v1 == 0 implies v1 * v2 == 0, even if multiplication by v2 would produce a NaN"), so lanes removed by a
+    `dr.select` contribute nothing.  torch would produce 0 * NaN there; this file therefore SKIPS masked lanes instead of
+    evaluating-then-masking them (same result as the rule; the stand-in implements the rule itself).
 
 Only `tests/`, `__graft_entry__.smoke()` and `bench.py`'s cpu_baseline leg may
 import this file.
