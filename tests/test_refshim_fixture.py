@@ -107,7 +107,7 @@ def test_oracle_matches_reference_code_per_ray(name):
     tr32 = {k: tr[k] for k in ('warp_t', 'warp_t_d', 'warp_weight', 'warp_weight_d')}
     oc = P.oracle_warp_coefficients(dict(grid=x['grid']), o, d / torch.linalg.norm(d, dim=-1, keepdim=True), tr32)
     act = oc['active']
-    assert act.sum() > 100 and np.array_equal(act, ref['we_div'] != 0) or (act != (ref['we_div'] != 0)).mean() < 0.01
+    assert act.sum() >= 20 and (act != (ref['we_div'] != 0)).mean() < 0.01       # (92 / 24 of the 512 fixture rays carry a warp)
     assert rel_l2(oc['div'][act], ref['we_div'][act]) < 1e-9
     assert rel_l2(oc['a'][act], ref['we_a'][act]) < 1e-9 and rel_l2(oc['b'][act], ref['we_b'][act]) < 1e-9
     assert rel_l2(oc['cdir'][act], ref['we_cdir'][act]) < 1e-9
@@ -200,6 +200,39 @@ def test_kernel_math_matches_reference_code(harness, name, tag):
     check_fp32_gradient('refshim_host', name, tag, gg, ref[f'grad_{tag}'], gates[1])
 
 
+def _check_per_ray(trace, warp_eval, ref):
+    """The per-ray gates shared by the host build of the kernel arithmetic and the HIP path (fp32 against the fp64 fixture)."""
+    o, d, maxt = (ref[k].astype(np.float32) for k in ('ray_o', 'ray_d', 'ray_maxt'))
+    out = trace(o, d, maxt, True)
+    hit, fin = np.isfinite(ref['ri_its_t']), np.isfinite(ref['ri_warp_t'])
+    its = out['its_t']
+    assert (np.isfinite(its) == hit).mean() > 0.995                             # (a grazing ray may flip between fp32 and fp64)
+    both = hit & np.isfinite(its)
+    assert rel_l2(its[both], ref['ri_its_t'][both]) < 1e-5
+    m = fin & np.isfinite(out['warp_t']) & (ref['ri_warp_weight'] > 1e-3)
+    assert m.sum() > 100
+    for k, tol in (('warp_t', 1e-4), ('warp_weight', 1e-3), ('warp_t_d', 2e-2), ('warp_weight_d', 2e-2)):   # (1 / denom^3 weights)
+        assert rel_l2(out[k][m], ref['ri_' + k][m]) < tol, k
+    plain = trace(o, d, maxt, False)['its_t']
+    assert rel_l2(plain[both], ref['ri_plain_its_t'][both]) < 1e-5
+    # WarpField2D.eval on the REFERENCE's trace outputs: isolates the warp field from the trace
+    we = warp_eval(o, d, {k: ref['ri_' + k].astype(np.float32) for k in ('warp_t', 'warp_t_d', 'warp_weight', 'warp_weight_d')})
+    act = (we['active'] != 0) & (ref['we_div'] != 0)
+    assert act.sum() >= 20 and ((we['active'] != 0) != (ref['we_div'] != 0)).mean() < 0.01   # (92 / 24 of the 512 fixture rays carry a warp)
+    for k, rk in (('div', 'we_div'), ('a', 'we_a'), ('b', 'we_b'), ('cdir', 'we_cdir')):
+        assert rel_l2(we[k][act], ref[rk][act]) < 2e-3, k                        # (fp32 evaluation of 1 / |g|^4 terms; per-ray gates: test_gpu_parity.py)
+    return both
+
+
+@pytest.mark.parametrize('name', ['sphere16', 'blob32'])
+def test_kernel_math_matches_reference_code_per_ray(harness, name):
+    """Host build of trace_diff / trace_plain / warp_coefficients against what the reference's shapes.py / warp.py returned --
+    the same gates as the HIP test below, so that a gate the GPU box would trip over is tripped over here first."""
+    ref = load(name)
+    _check_per_ray(lambda o, d, maxt, diff: harness.trace(ref['grid'], o, d, maxt, diff=diff),
+                   lambda o, d, tr: harness.warp_eval(ref['grid'], o, d, tr), ref)
+
+
 # ---------------------------------------------------------------------------------------------------------------- HIP path
 @pytest.fixture(scope='module')
 def dsdf(built):
@@ -214,26 +247,11 @@ def test_gpu_matches_reference_code_per_ray(dsdf, name):
     """dsdf_trace / dsdf_warp_eval / dsdf_surface_interaction against what the reference's shapes.py / warp.py returned."""
     ref = load(name)
     g = dsdf.SdfGrid(torch.from_numpy(ref['grid']).cuda())
-    o, d, maxt = (torch.from_numpy(ref[k]).float().cuda() for k in ('ray_o', 'ray_d', 'ray_maxt'))
-    out = dsdf.trace(g, o, d, maxt)
-    hit, fin = np.isfinite(ref['ri_its_t']), np.isfinite(ref['ri_warp_t'])
-    its = out['its_t'].cpu().numpy()
-    assert (np.isfinite(its) == hit).mean() > 0.995                             # (a grazing ray may flip between fp32 and fp64)
-    both = hit & np.isfinite(its)
-    assert rel_l2(its[both], ref['ri_its_t'][both]) < 1e-5
-    m = fin & np.isfinite(out['warp_t'].cpu().numpy()) & (ref['ri_warp_weight'] > 1e-3)
-    assert m.sum() > 100
-    for k, tol in (('warp_t', 1e-4), ('warp_weight', 1e-3), ('warp_t_d', 2e-2), ('warp_weight_d', 2e-2)):   # (1 / denom^3 weights)
-        assert rel_l2(out[k].cpu().numpy()[m], ref['ri_' + k][m]) < tol, k
-    plain = dsdf.trace(g, o, d, maxt, differentiable=False)['its_t'].cpu().numpy()
-    assert rel_l2(plain[both], ref['ri_plain_its_t'][both]) < 1e-5
-    # WarpField2D.eval on the REFERENCE's trace outputs: isolates the warp field from the trace
-    tr = {k: torch.from_numpy(ref['ri_' + k]).float().cuda() for k in ('warp_t', 'warp_t_d', 'warp_weight', 'warp_weight_d')}
-    we = {k: v.cpu().numpy() for k, v in dsdf.warp_eval(g, o, d, tr).items()}
-    act = (we['active'] != 0) & (ref['we_div'] != 0)
-    assert act.sum() > 100 and ((we['active'] != 0) != (ref['we_div'] != 0)).mean() < 0.01
-    for k, rk in (('div', 'we_div'), ('a', 'we_a'), ('b', 'we_b'), ('cdir', 'we_cdir')):
-        assert rel_l2(we[k][act], ref[rk][act]) < 2e-3, k                        # (fp32 evaluation of 1 / |g|^4 terms; per-ray gates: test_gpu_parity.py)
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).float().cuda()
+    host = lambda r: {k: v.cpu().numpy() for k, v in r.items()}
+    both = _check_per_ray(lambda o, d, maxt, diff: host(dsdf.trace(g, dev(o), dev(d), dev(maxt), differentiable=diff)),
+                          lambda o, d, tr: host(dsdf.warp_eval(g, dev(o), dev(d), {k: dev(v) for k, v in tr.items()})), ref)
+    o, d = dev(ref['ray_o']), dev(ref['ray_d'])
     si = dsdf.surface_interaction(g, o[torch.from_numpy(both).cuda()], d[torch.from_numpy(both).cuda()],
                                   torch.from_numpy(ref['ri_its_t'][both]).float().cuda())
     assert rel_l2(si['p'].cpu().numpy(), ref['si_p'][both]) < 1e-5 and rel_l2(si['n'].cpu().numpy(), ref['si_n'][both]) < 1e-3
