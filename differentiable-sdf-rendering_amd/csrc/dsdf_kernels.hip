@@ -18,6 +18,7 @@
 //                              both hand the last few rays of a wave to a tail queue                         [dsdf_tail.h]
 //   k_tail_trace_plain/diff    persistent waves that resume the handed-off rays, per-XCD queues (dsdf_tail.h)
 //   k_render_pass<DIFF,DIRECT> any spp: one lane per sample; for spp < 64 a wave = a pixel tile with an LDS film window
+//   k_render_aovs, k_develop_aov   debug images `i` / `weight_sum` of use_aovs + return_aovs (one lane per sample)
 //   k_develop*, k_develop_adjoint*, k_develop_tangent   HDRFilm.develop, its adjoint and tangent              [dsdf_film.h]
 //   k_backward<DIRECT>         per queued sample: film-adjoint gather, warp / shading adjoint, transposed 64-tap LDS
 //                              scatter into dL/dsdf                                                           [dsdf_wave.h]
@@ -535,6 +536,34 @@ __global__ __launch_bounds__(DSDF_BLOCK) void k_render_pass(GridView G, dsdf_par
         add_stats(wst, tr, valid && !far, need);          // (`lanes` counts the samples that are generated)
         flush_stats(stats, wst, blockIdx.x, lid);
     }
+}
+
+// Debug images of `use_aovs` + `WarpField2D.return_aovs` (integrators/reparam.py:160-165, 263-267; warp.py:105-106): the film gets
+// eleven more channels, and the two that any code path of the reference fills are the loop state of the primary ray's
+// differentiable trace -- the iteration count `i` and the un-clamped `weight_sum` (shapes.py:240-242), splatted and developed like
+// every other channel.  One lane per sample in the reference's lane order, every sample traced (no proofs, no hand-off: a debug
+// path).  Film block: (i, weight_sum, weight) per pixel.
+__global__ __launch_bounds__(DSDF_BLOCK) void k_render_aovs(GridView G, dsdf_params P, ViewBatch VB, float *__restrict__ blocks, uint32_t n_lanes) {
+    const ViewArgs &A = VB.v[blockIdx.y];
+    float *__restrict__ block = blocks + (size_t)blockIdx.y * 3 * A.Wb * A.Hb;
+    const uint32_t lane = blockIdx.x * DSDF_BLOCK + threadIdx.x;
+    if (lane >= n_lanes) return;
+    const Lane L = lane_setup(A, P, lane);
+    TraceOut tr;
+    trace_diff(G, P, L.ray.o, L.ray.d, L.ray.maxt, tr);
+    const Reproj rp = reproject(A.cam, P, L.ray.o + L.ray.d, A.W, A.H);
+    splat_lane_aov(block, A.Wb, A.Hb, rp.u, rp.v, (float)tr.steps, tr.weight_sum, AtomicAdd());
+}
+
+// HDRFilm.develop of that block: crop the border, (i, weight_sum) / (weight == 0 ? 1 : weight).
+__global__ void k_develop_aov(const float *__restrict__ blocks, int W, int H, float *__restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= W * H) return;
+    const int y = i / W, x = i - y * W, Wb = W + 2 * DSDF_BORDER, Hb = H + 2 * DSDF_BORDER;
+    const float *b = blocks + ((size_t)blockIdx.y * Wb * Hb + (size_t)(y + DSDF_BORDER) * Wb + x + DSDF_BORDER) * 3;
+    const float w = b[2] == 0.f ? 1.f : b[2];
+    float *o = out + ((size_t)blockIdx.y * W * H + i) * 2;
+    o[0] = b[0] / w; o[1] = b[1] / w;
 }
 
 // Backward sweep: one single-wave block per DSDF_BWD_UNITS consecutive units of a view (a unit = 64 samples: one pixel at
@@ -1536,6 +1565,46 @@ int dsdf_develop(const float *film, int n_views, int width, int height, int inte
     if (integrator == DSDF_DIRECT) hipLaunchKernelGGL(k_develop_rgb, grid, dim3(256), 0, (hipStream_t)stream, film, width, height, image_out);
     else hipLaunchKernelGGL(k_develop, grid, dim3(256), 0, (hipStream_t)stream, film, width, height, image_out);
     return check_launch("k_develop");
+}
+
+size_t dsdf_aov_workspace_size(int width, int height, int n_views) {
+    if (width < 1 || height < 1 || n_views < 1) return 0;
+    return (size_t)(n_views < DSDF_MAX_BATCH ? n_views : DSDF_MAX_BATCH) * (width + 2 * DSDF_BORDER) * (height + 2 * DSDF_BORDER) * 3 * sizeof(float);
+}
+
+int dsdf_render_aovs(const float *padded, int rx, int ry, int rz, const dsdf_params *prm, const dsdf_camera *cams,
+                     int n_views, int width, int height, int spp, const float *offsets, const uint32_t *seeds,
+                     float *aov_out, void *workspace, size_t workspace_bytes, void *stream) {
+    if (!padded || !prm || !cams || !aov_out || !workspace) return fail(DSDF_ERR_INVALID_ARG, "dsdf_render_aovs: null pointer argument");
+    if (rx < 1 || ry < 1 || rz < 1 || n_views < 1 || width < 1 || height < 1 || spp < 1)
+        return fail(DSDF_ERR_INVALID_ARG, "dsdf_render_aovs: non-positive size argument");
+    if (!offsets && !seeds) return fail(DSDF_ERR_INVALID_ARG, "dsdf_render_aovs: need offsets or seeds");
+    const size_t Wb = width + 2 * DSDF_BORDER, Hb = height + 2 * DSDF_BORDER, nl = Wb * Hb * (size_t)spp;
+    if (nl > 0x40000000ull) return fail(DSDF_ERR_INVALID_ARG, "wavefront size exceeds 0x40000000 lanes");
+    const size_t per_view = Wb * Hb * 3 * sizeof(float);
+    if (workspace_bytes < per_view) return fail(DSDF_ERR_WORKSPACE, "dsdf_render_aovs: workspace too small (dsdf_aov_workspace_size)");
+    int nb = (int)(workspace_bytes / per_view);
+    nb = nb < DSDF_MAX_BATCH ? nb : DSDF_MAX_BATCH;
+    hipStream_t st = (hipStream_t)stream;
+    const GridView G = device_view(padded, rx, ry, rz, *prm);
+    float *blocks = (float *)workspace;
+    for (int v0 = 0; v0 < n_views; v0 += nb) {
+        const int nv = (n_views - v0) < nb ? (n_views - v0) : nb;
+        ViewBatch VB;
+        // (the trace runs with the caller's parameters as they are: `i` counts the march, the refinement loop has its own counter)
+        for (int i = 0; i < nv; ++i)
+            VB.v[i] = make_view_args(cams[v0 + i], width, height, spp, offsets ? offsets + (size_t)(v0 + i) * nl * 2 : nullptr,
+                                     seeds ? seeds[v0 + i] : 0u, DSDF_SILHOUETTE, DSDF_REPARAM, *prm);
+        if (hipMemsetAsync(blocks, 0, nv * per_view, st) != hipSuccess) return fail(DSDF_ERR_LAUNCH, "hipMemsetAsync(AOV film block) failed");
+        hipLaunchKernelGGL(k_render_aovs, dim3((unsigned)((nl + DSDF_BLOCK - 1) / DSDF_BLOCK), nv), dim3(DSDF_BLOCK), 0, st, G, *prm, VB,
+                           blocks, (uint32_t)nl);
+        int rc = check_launch("k_render_aovs");
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_develop_aov, dim3((width * height + 255) / 256, nv), dim3(256), 0, st, (const float *)blocks, width, height,
+                           aov_out + (size_t)v0 * width * height * 2);
+        if ((rc = check_launch("k_develop_aov"))) return rc;
+    }
+    return DSDF_OK;
 }
 
 int dsdf_grad_sweep(const float *padded, int rx, int ry, int rz, const dsdf_params *prm, const dsdf_camera *cams,

@@ -135,6 +135,35 @@ DSDF_HD void splat_value_lane(float *block, int Wb, int Hb, float u, float v, fl
     }
 }
 
+// The 3-channel (i, weight_sum, weight) block of the AOV debug render (reparam.py:117-118: `block.put(position_sample, aovs + aovs_)`).
+template <class Adder>
+DSDF_HD void splat_lane_aov(float *block, int Wb, int Hb, float u, float v, float a0, float a1, Adder add) {
+    float pfx = u + (DSDF_BORDER - 0.5f), pfy = v + (DSDF_BORDER - 0.5f);
+    int x0 = (int)ceilf(pfx - DSDF_FILTER_RADIUS), y0 = (int)ceilf(pfy - DSDF_FILTER_RADIUS);
+    float wx[4], wy[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        wx[i] = gauss_f((float)(x0 + i) - pfx);
+        wy[i] = gauss_f((float)(y0 + i) - pfy);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        int qy = y0 + j;
+        if (qy < 0 || qy >= Hb) continue;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int qx = x0 + i;
+            if (qx < 0 || qx >= Wb) continue;
+            float f = wx[i] * wy[j];
+            if (f == 0.f) continue;
+            float *dst = block + 3 * ((size_t)qy * Wb + qx);
+            if (a0 != 0.f) add(dst, f * a0);
+            if (a1 != 0.f) add(dst + 1, f * a1);
+            add(dst + 2, f);
+        }
+    }
+}
+
 // Same for the 4-channel (r,g,b,weight) block of sdf_direct_reparam.
 template <class Adder>
 DSDF_HD void splat_lane_rgb(float *block, int Wb, int Hb, float u, float v, const float rgb[3], Adder add) {

@@ -44,7 +44,7 @@ class DsdfError(RuntimeError):
 
 
 _lib = None
-ABI_VERSION = 305          # DSDF_VERSION of include/dsdf.h these ctypes mirrors were written against
+ABI_VERSION = 306          # DSDF_VERSION of include/dsdf.h these ctypes mirrors were written against
 
 # name -> (restype, argtypes); every symbol include/dsdf.h declares
 SYMBOLS = {
@@ -79,6 +79,9 @@ SYMBOLS = {
     'dsdf_render_film': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(DsdfParams), C.POINTER(DsdfCamera), C.c_int, C.c_int,
                                    C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_uint32), C.c_int, C.c_int, C.POINTER(DsdfShading), C.c_int,
                                    C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
+    'dsdf_aov_workspace_size': (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    'dsdf_render_aovs': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(DsdfParams), C.POINTER(DsdfCamera), C.c_int, C.c_int,
+                                   C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_uint32), C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     'dsdf_develop': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     'dsdf_grad_sweep': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(DsdfParams), C.POINTER(DsdfCamera), C.c_int, C.c_int,
                                   C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_uint32), C.c_int, C.c_int, C.POINTER(DsdfShading), C.c_int,

@@ -343,6 +343,30 @@ def render_forward(grid, sensors, spp, seeds=None, offsets=None, integrator=DSDF
     return img
 
 
+AOV_NAMES = ['sdf_value', 'warp_t', 'vx', 'vy', 'div', 'i', 'weight_sum', 'weight', 'warp_t_dx', 'warp_t_dy', 'warp_t_dz']   # reparam.py:265
+
+
+def render_aovs(grid, sensors, spp, seeds=None, offsets=None):
+    """The debug channels of `use_aovs` + `WarpField2D.return_aovs` (python/integrators/reparam.py:160-165, 263-267) for a batch of
+    views -> (n_views, H, W, 11) in the order of AOV_NAMES.  The reference writes two of them, the loop state of the primary
+    ray's differentiable trace (`i`, `weight_sum`: python/shapes.py:240-242; dsdf_render_aovs); the other nine are zero there too."""
+    lib = _lib.load()
+    sensors, cams, W, H = _views(sensors)
+    nv = len(sensors)
+    n_lanes = (W + 4) * (H + 4) * int(spp)
+    offsets, cseeds = _sampler_args(nv, seeds, offsets, n_lanes)
+    dev = grid.device
+    two = torch.empty(nv, H, W, 2, dtype=torch.float32, device=dev)
+    ws = _workspace(dev, lib.dsdf_aov_workspace_size(W, H, min(nv, MAX_VIEWS_PER_LAUNCH)), lib.dsdf_aov_workspace_size(W, H, 1))
+    with torch.cuda.device(dev):
+        _lib.check(lib.dsdf_render_aovs(_ptr(grid.padded), grid.rx, grid.ry, grid.rz, C.byref(grid.params), cams, nv, W, H, int(spp),
+                                        _ptr(offsets), cseeds, _ptr(two), _ptr(ws), ws.numel(), _stream()))
+    out = torch.zeros(nv, H, W, len(AOV_NAMES), dtype=torch.float32, device=dev)
+    out[..., AOV_NAMES.index('i')] = two[..., 0]
+    out[..., AOV_NAMES.index('weight_sum')] = two[..., 1]
+    return out
+
+
 def render_backward(grid, sensors, spp, grad_image, grad_grid=None, seeds=None, offsets=None,
                     integrator=DSDF_SILHOUETTE, reparam=True, stats=None, return_image=False, empty_space_skip=True,
                     grad_p=None, shading=None, emitter_samples=None, grad_albedo=None, bsdf_samples=None):

@@ -83,8 +83,10 @@ class ReparamIntegrator:
         self.max_depth = props.get('max_depth', 4)
         if props.get('weight_by_spp', False):
             raise AssertionError("Not supported")                       # python/integrators/reparam.py:16
-        if props.get('antithetic_sampling', False) or props.get('use_aovs', False):
-            raise NotImplementedError("antithetic_sampling / use_aovs are outside the supported path")
+        if props.get('antithetic_sampling', False):
+            raise NotImplementedError("antithetic_sampling is outside the supported path (no reference config or file sets it)")
+        # sdf_silhouette_reparam.py:10, sdf_simple_shading_reparam.py:14, sdf_direct_reparam.py:11: every integrator on the path reads it
+        self.use_aovs = bool(props.get('use_aovs', False))
         fn = props.get('sdf_filename', '')
         self.sdf = Grid3d(fn, transform=props.get('sdf_to_world', None)) if fn else props.get('sdf', None)   # reparam.py:21-29
         self.warp_field = None
@@ -115,13 +117,23 @@ class ReparamIntegrator:
 
     # -- plugin API ----------------------------------------------------------------------
     def render(self, scene, sensor=0, seed=0, spp=0, develop=True, evaluate=True, mode=None):
-        """python/integrators/reparam.py:120-185 -> image(s) (n,H,W,3) (a single sensor gives (H,W,3))."""
+        """python/integrators/reparam.py:120-185 -> image(s) (n,H,W,3) (a single sensor gives (H,W,3)).  With the property
+        `use_aovs` the film carries the channels of aov_names() behind RGB (reparam.py:130, 263-267): (n,H,W,14); they are filled
+        when the warp field has `return_aovs` set (reparam.py:163-165, warp.py:105-106) and zero otherwise, like in the reference."""
         if not develop:
             raise Exception("Must use develop=True for this AD integrator")
         sens = self._sensors(scene, sensor)
         reparam = self._configured()
-        img = dsdf.render_forward(self.sdf.grid, sens, spp or 4, seeds=[seed + i for i in range(len(sens))],
+        seeds = [seed + i for i in range(len(sens))]
+        img = dsdf.render_forward(self.sdf.grid, sens, spp or 4, seeds=seeds,
                                   integrator=self.integrator_id, reparam=reparam, shading=self.shading())
+        if self.use_aovs:
+            wf = self.warp_field
+            if wf is not None and reparam and getattr(wf, 'return_aovs', False):
+                aov = dsdf.render_aovs(self.sdf.grid, sens, spp or 4, seeds=seeds)        # (the primary ray: depth 0 passes warp.py:103 for any max_reparam_depth)
+            else:
+                aov = torch.zeros(*img.shape[:-1], len(dsdf.AOV_NAMES), dtype=img.dtype, device=img.device)
+            img = torch.cat([img, aov], -1)
         return img[0] if len(sens) == 1 and not isinstance(sensor, (list, tuple)) else img
 
     def render_backward(self, scene, params, grad_in, sensor=0, seed=0, spp=0):
@@ -190,7 +202,7 @@ class ReparamIntegrator:
             self.sdf.parameters_changed(keys)
 
     def aov_names(self):
-        return []
+        return list(dsdf.AOV_NAMES) if self.use_aovs else []                    # reparam.py:263-267
 
 
 class _RenderOp(torch.autograd.Function):

@@ -18,8 +18,8 @@ class WarpField2D:
 
     def apply(self, params):
         """Writes this field's settings into a DsdfParams struct."""
-        if self.return_aovs:
-            raise NotImplementedError("return_aovs is outside the supported path (DESIGN.md section 9)")
+        # (return_aovs, python/warp.py:17, 105-106, is read by ReparamIntegrator.render: the debug channels are a render of
+        # their own, dsdf_render_aovs, and change nothing in the parameters of the passes)
         params.edge_eps = float(self.edge_eps)
         params.weight_strategy = int(self.weight_strategy)
         params.clamping_thresh = float(self.clamping_thresh)

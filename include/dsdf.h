@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define DSDF_VERSION 305   /* 300: stats rows of DSDF_STAT_SLOTS (16) counters; tail hand-off on library-owned helper streams; 304: DSDF_NO_HIT_PROOF, the grid buffer carries the bounds of the hit proof (dsdf_padded_size); 305: dsdf_params grows by normalize_warp_field, max_reparam_depth */
+#define DSDF_VERSION 306   /* 300: stats rows of DSDF_STAT_SLOTS (16) counters; tail hand-off on library-owned helper streams; 304: DSDF_NO_HIT_PROOF, the grid buffer carries the bounds of the hit proof (dsdf_padded_size); 305: dsdf_params grows by normalize_warp_field, max_reparam_depth; 306: dsdf_render_aovs, dsdf_aov_workspace_size */
 #define DSDF_STAT_SLOTS 16
 
 enum dsdf_status {
@@ -238,6 +238,24 @@ int dsdf_render_forward_grad(const float *padded, int rx, int ry, int rz, const 
                              const float *tangent_padded, const float *tangent_p,
                              float *grad_image_out, float *image_out,
                              void *workspace, size_t workspace_bytes, void *stream);
+
+/* Debug images of `use_aovs` (integrator property, python/integrators/sdf_silhouette_reparam.py:10, sdf_simple_shading_reparam.py:14,
+ * sdf_direct_reparam.py:11) together with `WarpField2D.return_aovs` (python/warp.py:17): `ReparamIntegrator.render` then prepares
+ * the film with the eleven channels of `aov_names()` (python/integrators/reparam.py:130, 263-267) behind R, G, B and renders with the
+ * reparameterisation on (reparam.py:163-165).  Of the eleven names only two are ever written by the reference -- the loop state
+ * of the PRIMARY ray's differentiable trace, `extra_outputs['i']` and `['weight_sum']` (python/shapes.py:240-242; WarpField2D.eval
+ * takes `extra_output` and never stores into it, python/warp.py:47-96) -- the other nine develop to 0.  This entry point renders
+ * those two: every sample of n_views sensors is traced with `SDFBase.ray_intersect` (python/shapes.py:115-288), (i, weight_sum) are
+ * splatted with the film's reconstruction filter like any channel (`block.put`, reparam.py:117-118) and developed
+ * (`HDRFilm.develop`: divided by the filter-weight sum).
+ *   aov_out   : n_views x H x W x 2 = {`i`, `weight_sum`}
+ *   workspace : >= dsdf_aov_workspace_size(width, height, 1) bytes (one (H+4) x (W+4) x 3 film block per view of a batch)
+ * Sampler rules as in dsdf_render_forward (same offsets / seeds give the samples of the RGB image). */
+size_t dsdf_aov_workspace_size(int width, int height, int n_views);
+int dsdf_render_aovs(const float *padded, int rx, int ry, int rz, const dsdf_params *prm,
+                     const dsdf_camera *cams, int n_views, int width, int height, int spp,
+                     const float *offsets, const uint32_t *seeds,
+                     float *aov_out, void *workspace, size_t workspace_bytes, void *stream);
 
 /* ---- multi-GPU pixel-tile split of a view ("pixel tiles within a view when N > views-per-iteration") --------
  * The reference is single-device; these four entry points split `ReparamIntegrator.render` / `render_backward`

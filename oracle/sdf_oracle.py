@@ -937,13 +937,16 @@ def block_put(block, uv, values, Wb, Hb):
     return block.index_add(0, idx, contrib)
 
 
+AOV_NAMES = ['sdf_value', 'warp_t', 'vx', 'vy', 'div', 'i', 'weight_sum', 'weight', 'warp_t_dx', 'warp_t_dy', 'warp_t_dz']   # reparam.py:265
+
+
 def develop(block, W, H):
-    """HDRFilm::develop: crop border, rgb / (W==0 ? 1 : W)."""
+    """HDRFilm::develop: crop border, rgb / (W==0 ? 1 : W); AOV channels (behind the weight) are normalised the same way."""
     Wb, Hb = W + 2 * BORDER, H + 2 * BORDER
-    b = block.reshape(Hb, Wb, 4)[BORDER:BORDER + H, BORDER:BORDER + W]
+    b = block.reshape(Hb, Wb, -1)[BORDER:BORDER + H, BORDER:BORDER + W]
     wgt = b[..., 3:4]
     wgt = torch.where(wgt == 0, torch.ones_like(wgt), wgt)
-    return b[..., :3] / wgt
+    return torch.cat([b[..., :3], b[..., 4:]], -1) / wgt
 
 
 # --------------------------------------------------------------------------
@@ -962,16 +965,22 @@ def lane_positions(W, H, spp, offsets):
 def render(sdf, cam, W, H, spp, offsets, integrator=SILHOUETTE, reparam=True,
            return_aux=False, chunk=1 << 17, albedo=None, emitter_u=None, env=1.0, hide_emitters=False, rows=None,
            return_block=False, use_mis=False, bsdf_u=None, detach_indirect_si=False, decouple_reparam=False, light_dir=None,
-           roughness=None, normalize_warp_field=True, max_reparam_depth=-1):
+           roughness=None, normalize_warp_field=True, max_reparam_depth=-1, aovs=False):
     """One view.  offsets: (Wb*Hb*spp, 2) in [0,1) (the sampler's next_2d per
     lane).  Returns image (H,W,3), differentiable w.r.t. sdf.data / sdf.p when
     they require grad.  `reparam=False` gives the DummyWarpField path
     (warp.py:179-196).  rows = (row0, row1): only the samples of the film-BLOCK rows [row0, row1) are generated
     (multi-GPU pixel-tile split; they keep their lane index); return_block: the un-developed film block (Hb, Wb, 4).
     normalize_warp_field / max_reparam_depth: the two WarpField2D settings the method configs change (warp.py:11, 20;
-    configs.py:63-75 `warpprimary`, :96-109 `warpnotnormalized`)."""
+    configs.py:63-75 `warpprimary`, :96-109 `warpnotnormalized`).
+    aovs: the integrator property `use_aovs` together with `warp_field.return_aovs` (reparam.py:263-267, 160-165; warp.py:105-106):
+    the film gets the 11 channels of AOV_NAMES behind RGB and the image is (H, W, 14).  The only two any code path of the reference
+    fills are the loop state of the primary ray's trace, `i` and `weight_sum` (shapes.py:240-242) -- WarpField2D.eval accepts
+    `extra_output` and never writes to it (warp.py:47-96), and sdf_direct_reparam.py:58-60 looks for a key the shadow ray's
+    dictionary cannot hold; without reparameterisation (DummyWarpField, warp.py:185) all eleven stay 0."""
     Wb, Hb = W + 2 * BORDER, H + 2 * BORDER
     dt = offsets.dtype
+    C = 4 + (len(AOV_NAMES) if aovs else 0)
     reparam1 = reparam and (max_reparam_depth < 0 or 1 <= max_reparam_depth)      # warp.py:103 for the depth-1 rays
     pos_all = lane_positions(W, H, spp, offsets)
     if rows is not None:
@@ -981,7 +990,7 @@ def render(sdf, cam, W, H, spp, offsets, integrator=SILHOUETTE, reparam=True,
             emitter_u = emitter_u[lo:hi]
         if bsdf_u is not None:
             bsdf_u = bsdf_u[lo:hi]
-    block = torch.zeros(Hb * Wb * 4, dtype=dt)
+    block = torch.zeros(Hb * Wb * C, dtype=dt)
     aux = dict(steps=0, lanes=0, bbox=0, hits=0, refine=0, warp_active=0)
     # sdf_simple_shading_reparam.py:20 fixes normalize(1,1,1); `light_dir` only serves the change-of-frame test (tests/test_to_world.py)
     light = torch.tensor([1.0, 1.0, 1.0], dtype=dt) / math.sqrt(3.0) if light_dir is None else torch.as_tensor(light_dir, dtype=dt)
@@ -1032,12 +1041,19 @@ def render(sdf, cam, W, H, spp, offsets, integrator=SILHOUETTE, reparam=True,
         rwn = replace_grad(torch.ones_like(rwn), rwn)
         rgb = rwn[:, None] * rgb
         wch = replace_grad(torch.ones(N, dtype=dt), div * rwn)           # reparam.py:115
-        block = block_put(block, uv, torch.cat([rgb, wch[:, None]], 1), Wb, Hb)
+        chans = [rgb, wch[:, None]]
+        if aovs:                                                         # reparam.py:117: `aovs + aovs_`
+            extra = torch.zeros(N, len(AOV_NAMES), dtype=dt)
+            if reparam:                                                  # warp.py:105-106: `extra_outputs if (reparam and self.return_aovs)`
+                extra[:, AOV_NAMES.index('i')] = tr['steps'].to(dt)      # shapes.py:241
+                extra[:, AOV_NAMES.index('weight_sum')] = tr['weight_sum']   # shapes.py:242
+            chans.append(extra)
+        block = block_put(block, uv, torch.cat(chans, 1), Wb, Hb)
         aux['steps'] += int(tr['steps'].sum()); aux['lanes'] += N
         aux['bbox'] += int((tr['steps'] > 0).sum()); aux['hits'] += int(hit.sum())
         aux['refine'] += int(tr['refine_steps'].sum())
     if return_block:
-        return block.reshape(Hb, Wb, 4)
+        return block.reshape(Hb, Wb, C)
     img = develop(block, W, H)
     if return_aux:
         return img, aux

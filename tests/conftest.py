@@ -130,6 +130,16 @@ class HostHarness:
                                    self._p(offsets), C.c_uint(seed), integrator, int(reparam), int(diff), self._p(img))
         return img
 
+    def render_aovs(self, grid, cam, W, H, spp, offsets, seed=0):
+        """(H, W, 2) = developed (`i`, `weight_sum`) of the AOV debug render (hh_render_aovs = k_render_aovs' statements)."""
+        grid = np.ascontiguousarray(grid, np.float32)
+        offs = None if offsets is None else np.ascontiguousarray(offsets, np.float32)
+        out = np.zeros((H, W, 2), np.float32)
+        rz, ry, rx = grid.shape
+        self.lib.hh_render_aovs(self._p(grid), rx, ry, rz, C.byref(self.params), self._p(cam), W, H, spp, self._p(offs),
+                                C.c_uint(seed), self._p(out))
+        return out
+
     def render_backward(self, grid, cam, W, H, spp, offsets, grad_image, integrator, reparam=True, seed=0, split=False):
         grid = np.ascontiguousarray(grid, np.float32)
         offsets = None if offsets is None else np.ascontiguousarray(offsets, np.float32)

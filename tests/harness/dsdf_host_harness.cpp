@@ -127,6 +127,29 @@ void hh_render_forward(const float *data, int rx, int ry, int rz, const dsdf_par
     develop(block, W, H, image);
 }
 
+// the statements of k_render_aovs / k_develop_aov of the HIP library: (i, weight_sum) of the primary ray's differentiable trace
+void hh_render_aovs(const float *data, int rx, int ry, int rz, const dsdf_params *prm, const dsdf_camera *cam,
+                    int W, int H, int spp, const float *offsets, unsigned seed, float *aov /* H x W x 2 */) {
+    std::vector<float> p = pad(data, rx, ry, rz);
+    GridView G = make_view(p.data(), rx, ry, rz, *prm);
+    ViewArgs A = view_args(cam, W, H, spp, offsets, seed, DSDF_SILHOUETTE, DSDF_REPARAM);
+    std::vector<float> block((size_t)3 * A.Wb * A.Hb, 0.f);
+    long n = (long)A.Wb * A.Hb * spp;
+    for (long lane = 0; lane < n; ++lane) {
+        Lane L = lane_setup(A, *prm, (uint32_t)lane);
+        TraceOut t;
+        trace_diff(G, *prm, L.ray.o, L.ray.d, L.ray.maxt, t);
+        Reproj rp = reproject(A.cam, *prm, L.ray.o + L.ray.d, W, H);
+        splat_lane_aov(block.data(), A.Wb, A.Hb, rp.u, rp.v, (float)t.steps, t.weight_sum, PlainAdd());
+    }
+    for (int y = 0; y < H; ++y)
+        for (int x = 0; x < W; ++x) {
+            const float *b = block.data() + ((size_t)(y + DSDF_BORDER) * A.Wb + x + DSDF_BORDER) * 3;
+            const float w = b[2] == 0.f ? 1.f : b[2];
+            aov[((size_t)y * W + x) * 2] = b[0] / w; aov[((size_t)y * W + x) * 2 + 1] = b[1] / w;
+        }
+}
+
 void hh_render_backward(const float *data, int rx, int ry, int rz, const dsdf_params *prm, const dsdf_camera *cam,
                         int W, int H, int spp, const float *offsets, unsigned seed, int integrator, int flags,
                         const float *grad_image, float *grad_grid, float *image, float *grad_p) {

@@ -35,6 +35,8 @@ cannot drift):
   * per integrator tag (sil, shade[, direct, direct_mis]): `img_<tag>` = integrator.render (python/integrators/reparam.py:120-185),
     `grad_<tag>` = d(sum(img * grad_image))/d(sdf.data), `gradp_<tag>` = .../d(sdf.p) through render_backward (:187-190)
     [`galb_<tag>` = .../d(reflectance volume)]
+  * `aov_<tag>` (sil_aovs, direct_aovs, sil_aovs_noreparam): the (H, W, 14) image of integrator.render with `use_aovs` and
+    `warp_field.return_aovs` (python/integrators/reparam.py:160-165, 263-267)
 """
 import argparse
 import inspect
@@ -180,7 +182,11 @@ def main():
                      # ... and the method configs that change the warp field (python/configs.py:63-75, 96-109, 112-125)
                      (D, 'direct_primary', {}, 'warpprimary'), (D, 'direct_mis_primary', {'use_mis': True}, 'warpprimary'),
                      (D, 'direct_notnorm', {}, 'warpnotnormalized'), ('sdf_silhouette_reparam', 'sil_notnorm', {}, 'warpnotnormalized'),
-                     ('sdf_simple_shading_reparam', 'shade_notnorm', {}, 'warpnotnormalized'), (D, 'direct_onlyshading', {}, 'onlyshadinggrad')]
+                     ('sdf_simple_shading_reparam', 'shade_notnorm', {}, 'warpnotnormalized'), (D, 'direct_onlyshading', {}, 'onlyshadinggrad'),
+                     # ... and the debug images: `use_aovs` on the integrator + `return_aovs` on the warp field (reparam.py:160-165,
+                     # 263-267; warp.py:105-106; shapes.py:240-242) -> (H, W, 3 + 11) images, stored whole as `aov_<tag>`
+                     ('sdf_silhouette_reparam', 'sil_aovs', {'use_aovs': True}, 'warp'), (D, 'direct_aovs', {'use_aovs': True}, 'warp'),
+                     ('sdf_silhouette_reparam', 'sil_aovs_noreparam', {'use_aovs': True}, 'onlyshadinggrad')]
         for integ_name, tag, props, method in runs:
             if args.tags is not None and tag not in args.tags:
                 continue
@@ -204,6 +210,13 @@ def main():
                 body = integ.sample
                 integ.sample = lambda mode, scene_, sampler, ray_, dL, state_in, reparam, active, **kw: body(scene_, sampler, ray_, None, active)
                 out[f'adapter_{tag}'] = np.int64(1)
+            if 'use_aovs' in props:
+                integ.warp_field.return_aovs = True                                             # python/warp.py:17 (set by hand there too)
+                with dr.suspend_grad():
+                    img = mi.render(scene, sensor=sensor, seed=seed, spp=spp)
+                out[f'aov_{tag}'] = np.array(img).astype(np.float64 if args.shim else np.float32)
+                assert out[f'aov_{tag}'].shape == (H, W, 3 + len(integ.aov_names())), out[f'aov_{tag}'].shape
+                continue
             with dr.suspend_grad():
                 img = mi.render(scene, sensor=sensor, seed=seed, spp=spp)                       # python/shape_opt.py:61-63
             out[f'img_{tag}'] = np.array(img)[..., :3].astype(np.float64 if args.shim else np.float32)
