@@ -19,6 +19,7 @@
 //   k_tail_trace_plain/diff    persistent waves that resume the handed-off rays, per-XCD queues (dsdf_tail.h)
 //   k_render_pass<DIFF,DIRECT> any spp: one lane per sample; for spp < 64 a wave = a pixel tile with an LDS film window
 //   k_render_aovs, k_develop_aov   debug images `i` / `weight_sum` of use_aovs + return_aovs (one lane per sample)
+//   k_sampler_2d               the film offsets of the built-in sampler (or their mirror images: antithetic_sampling)
 //   k_develop*, k_develop_adjoint*, k_develop_tangent   HDRFilm.develop, its adjoint and tangent              [dsdf_film.h]
 //   k_backward<DIRECT>         per queued sample: film-adjoint gather, warp / shading adjoint, transposed 64-tap LDS
 //                              scatter into dL/dsdf                                                           [dsdf_wave.h]
@@ -536,6 +537,16 @@ __global__ __launch_bounds__(DSDF_BLOCK) void k_render_pass(GridView G, dsdf_par
         add_stats(wst, tr, valid && !far, need);          // (`lanes` counts the samples that are generated)
         flush_stats(stats, wst, blockIdx.x, lid);
     }
+}
+
+// `sampler.next_2d()` of the `independent` sampler as ReparamIntegrator.prepare seeds it (reparam.py:37-51, 169): the film offsets r of
+// every lane of a view, or -- mirror -- 1 - r, the offsets of the antithetic pair (reparam.py:173: position_sample2 = pos - r + 1).
+__global__ void k_sampler_2d(uint32_t seed, uint32_t n_lanes, int mirror, float2 *__restrict__ out) {
+    const uint32_t lane = blockIdx.x * blockDim.x + threadIdx.x;
+    if (lane >= n_lanes) return;
+    float r0, r1;
+    sampler_next_2d(seed, lane, r0, r1);
+    out[lane] = mirror ? make_float2(1.f - r0, 1.f - r1) : make_float2(r0, r1);
 }
 
 // Debug images of `use_aovs` + `WarpField2D.return_aovs` (integrators/reparam.py:160-165, 263-267; warp.py:105-106): the film gets
@@ -1565,6 +1576,16 @@ int dsdf_develop(const float *film, int n_views, int width, int height, int inte
     if (integrator == DSDF_DIRECT) hipLaunchKernelGGL(k_develop_rgb, grid, dim3(256), 0, (hipStream_t)stream, film, width, height, image_out);
     else hipLaunchKernelGGL(k_develop, grid, dim3(256), 0, (hipStream_t)stream, film, width, height, image_out);
     return check_launch("k_develop");
+}
+
+int dsdf_sampler_2d(const uint32_t *seeds, int n_views, int width, int height, int spp, int mirror, float *offsets_out, void *stream) {
+    if (!seeds || !offsets_out || n_views < 1 || width < 1 || height < 1 || spp < 1) return fail(DSDF_ERR_INVALID_ARG, "dsdf_sampler_2d: bad argument");
+    const size_t nl = (size_t)(width + 2 * DSDF_BORDER) * (height + 2 * DSDF_BORDER) * (size_t)spp;
+    if (nl > 0x40000000ull) return fail(DSDF_ERR_INVALID_ARG, "wavefront size exceeds 0x40000000 lanes");
+    for (int v = 0; v < n_views; ++v)
+        hipLaunchKernelGGL(k_sampler_2d, dim3((unsigned)((nl + 255) / 256)), dim3(256), 0, (hipStream_t)stream, seeds[v], (uint32_t)nl, mirror,
+                           reinterpret_cast<float2 *>(offsets_out) + (size_t)v * nl);
+    return check_launch("k_sampler_2d");
 }
 
 size_t dsdf_aov_workspace_size(int width, int height, int n_views) {

@@ -79,6 +79,7 @@ SYMBOLS = {
     'dsdf_render_film': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(DsdfParams), C.POINTER(DsdfCamera), C.c_int, C.c_int,
                                    C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_uint32), C.c_int, C.c_int, C.POINTER(DsdfShading), C.c_int,
                                    C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
+    'dsdf_sampler_2d': (C.c_int, [C.POINTER(C.c_uint32), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     'dsdf_aov_workspace_size': (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     'dsdf_render_aovs': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(DsdfParams), C.POINTER(DsdfCamera), C.c_int, C.c_int,
                                    C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_uint32), C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),

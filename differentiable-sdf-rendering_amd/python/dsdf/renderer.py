@@ -306,18 +306,38 @@ def _views(sensors):
 
 
 def _sampler_args(n_views, seeds, offsets, n_lanes):
+    """(offsets, seeds) of a render call.  Explicit offsets replace the FILM sample of every lane; seeds given next to them still
+    seed the later dimensions of the lane's stream (emitter / BSDF samples of sdf_direct_reparam: include/dsdf.h)."""
+    cseeds = None
+    if seeds is not None:
+        seeds = [seeds] * n_views if isinstance(seeds, int) else list(seeds)
+        if len(seeds) != n_views:
+            raise _lib.DsdfError("one seed per view is required")
+        cseeds = (C.c_uint32 * n_views)(*[int(s) & 0xffffffff for s in seeds])
     if offsets is not None:
         offsets = _require_dev(offsets, 'offsets')
         if offsets.numel() != n_views * n_lanes * 2:
             raise _lib.DsdfError(f"offsets must hold n_views*(W+4)*(H+4)*spp*2 = {n_views * n_lanes * 2} floats, "
                                  f"got {offsets.numel()}")
-        return offsets, None
-    if seeds is None:
+        return offsets, cseeds
+    if cseeds is None:
         raise _lib.DsdfError("either seeds or offsets is required")
-    seeds = [seeds] * n_views if isinstance(seeds, int) else list(seeds)
-    if len(seeds) != n_views:
-        raise _lib.DsdfError("one seed per view is required")
-    return None, (C.c_uint32 * n_views)(*[int(s) & 0xffffffff for s in seeds])
+    return None, cseeds
+
+
+def sampler_offsets(sensors, spp, seeds, mirror=False, device=None):
+    """`sampler.next_2d()` of the built-in `independent` sampler for every lane of every view -> (n_views, (W+4)(H+4)spp, 2); mirror:
+    1 - r, the film offsets of the antithetic pair (python/integrators/reparam.py:167-178; dsdf_sampler_2d)."""
+    lib = _lib.load()
+    sensors, _, W, H = _views(sensors)
+    nv = len(sensors)
+    n_lanes = (W + 4) * (H + 4) * int(spp)
+    _, cseeds = _sampler_args(nv, seeds, None, n_lanes)
+    dev = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
+    out = torch.empty(nv, n_lanes, 2, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(lib.dsdf_sampler_2d(cseeds, nv, W, H, int(spp), int(bool(mirror)), _ptr(out), _stream()))
+    return out
 
 
 def render_forward(grid, sensors, spp, seeds=None, offsets=None, integrator=DSDF_SILHOUETTE, reparam=True, stats=None,

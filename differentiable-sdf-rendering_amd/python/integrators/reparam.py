@@ -83,8 +83,8 @@ class ReparamIntegrator:
         self.max_depth = props.get('max_depth', 4)
         if props.get('weight_by_spp', False):
             raise AssertionError("Not supported")                       # python/integrators/reparam.py:16
-        if props.get('antithetic_sampling', False):
-            raise NotImplementedError("antithetic_sampling is outside the supported path (no reference config or file sets it)")
+        # reparam.py:19, 167-178: every lane is evaluated a second time at the mirrored film position with a clone of its sampler
+        self.antithetic_sampling = bool(props.get('antithetic_sampling', False))
         # sdf_silhouette_reparam.py:10, sdf_simple_shading_reparam.py:14, sdf_direct_reparam.py:11: every integrator on the path reads it
         self.use_aovs = bool(props.get('use_aovs', False))
         fn = props.get('sdf_filename', '')
@@ -115,6 +115,35 @@ class ReparamIntegrator:
             raise NotImplementedError("an albedo VOLUME lives in world space: it cannot be combined with sdf_to_world")
         return wf.reparameterize
 
+    # -- antithetic pairs (python/integrators/reparam.py:167-178) --------------------------
+    # `position_sample2 = pos - r + 1.0` with `sampler2 = sampler.clone()`: the second sample of a lane differs from the first in
+    # its film offset only (1 - r: dsdf_sampler_2d), every later dimension of its stream is the same, and both go into ONE film
+    # block.  The film-level entry points render exactly that: two passes over one film (the second with explicit offsets next to
+    # the view's seeds), developed once; in the gradient pass two sweeps with a backward queue each, both back-propagated against
+    # the summed film -- the protocol of the multi-GPU split (dsdf/parallel.py) with the two sample sets in the role of two ranks.
+    def _pair_passes(self, sens, spp, seeds):
+        mirror = dsdf.sampler_offsets(sens, spp, seeds, mirror=True, device=self.sdf.grid.device)
+        return [dict(seeds=seeds), dict(seeds=seeds, offsets=mirror)]
+
+    def _render_pair(self, sens, spp, seeds, reparam):
+        W, H = sens[0].film_size()
+        film = dsdf.new_film(len(sens), W, H, self.integrator_id, self.sdf.grid.device)
+        for kw in self._pair_passes(sens, spp, seeds):
+            dsdf.render_film(self.sdf.grid, sens, spp, film, (0, H + 4), integrator=self.integrator_id, reparam=reparam,
+                             shading=self.shading(), **kw)
+        return dsdf.develop(film, W, H, self.integrator_id)
+
+    def _backward_pair(self, sens, spp, seeds, reparam, grad_in, grad_grid, grad_p, sh, ga):
+        W, H = sens[0].film_size()
+        film = dsdf.new_film(len(sens), W, H, self.integrator_id, self.sdf.grid.device)
+        sweeps = [dsdf.GradSweep(self.sdf.grid, sens, spp, (0, H + 4), integrator=self.integrator_id, reparam=reparam, shading=sh,
+                                 grad_albedo=ga, **kw) for kw in self._pair_passes(sens, spp, seeds)]
+        for sw in sweeps:
+            sw.sweep(film)
+        for sw in sweeps:
+            sw.backward(film, grad_in, grad_grid, grad_p)
+        return grad_grid
+
     # -- plugin API ----------------------------------------------------------------------
     def render(self, scene, sensor=0, seed=0, spp=0, develop=True, evaluate=True, mode=None):
         """python/integrators/reparam.py:120-185 -> image(s) (n,H,W,3) (a single sensor gives (H,W,3)).  With the property
@@ -125,9 +154,14 @@ class ReparamIntegrator:
         sens = self._sensors(scene, sensor)
         reparam = self._configured()
         seeds = [seed + i for i in range(len(sens))]
-        img = dsdf.render_forward(self.sdf.grid, sens, spp or 4, seeds=seeds,
-                                  integrator=self.integrator_id, reparam=reparam, shading=self.shading())
+        if self.antithetic_sampling:
+            img = self._render_pair(sens, spp or 4, seeds, reparam)
+        else:
+            img = dsdf.render_forward(self.sdf.grid, sens, spp or 4, seeds=seeds,
+                                      integrator=self.integrator_id, reparam=reparam, shading=self.shading())
         if self.use_aovs:
+            if self.antithetic_sampling:
+                raise NotImplementedError("use_aovs together with antithetic_sampling: the debug channels are rendered for one sample set")
             wf = self.warp_field
             if wf is not None and reparam and getattr(wf, 'return_aovs', False):
                 aov = dsdf.render_aovs(self.sdf.grid, sens, spp or 4, seeds=seeds)        # (the primary ray: depth 0 passes warp.py:103 for any max_reparam_depth)
@@ -154,9 +188,14 @@ class ReparamIntegrator:
         ga = torch.zeros_like(at.detach(), dtype=torch.float32).contiguous() if want_a else None
         if want_r:
             sh.grad_roughness = torch.zeros_like(rt.detach(), dtype=torch.float32).contiguous()
-        g = dsdf.render_backward(self.sdf.grid, sens, spp or 4, grad_in.reshape(len(sens), *grad_in.shape[-3:]).contiguous(),
-                                 seeds=[seed + i for i in range(len(sens))], integrator=self.integrator_id, reparam=reparam,
-                                 grad_p=gp, shading=sh, grad_albedo=ga)
+        gi = grad_in.reshape(len(sens), *grad_in.shape[-3:]).contiguous()
+        if self.antithetic_sampling:
+            g = torch.zeros(self.sdf.grid.shape, dtype=torch.float32, device=self.sdf.grid.device)
+            self._backward_pair(sens, spp or 4, [seed + i for i in range(len(sens))], reparam, gi, g, gp, sh, ga)
+        else:
+            g = dsdf.render_backward(self.sdf.grid, sens, spp or 4, gi,
+                                     seeds=[seed + i for i in range(len(sens))], integrator=self.integrator_id, reparam=reparam,
+                                     grad_p=gp, shading=sh, grad_albedo=ga)
         g = g.reshape(data.shape)
         data.grad = g if data.grad is None else data.grad + g
         if want_a and at.requires_grad:
@@ -171,6 +210,8 @@ class ReparamIntegrator:
         """python/integrators/reparam.py:192-196: forward-mode gradient image.  Dr.Jit seeds the tangent with
         `dr.set_grad` / `dr.forward(param)`; here the tangent of a parameter is its `.grad` field (sdf.data: a tensor
         of the same shape; sdf.p: 3 floats, e.g. (1,0,0) for `dr.forward(p.x)`, figures/result_utils.py:126-161)."""
+        if self.antithetic_sampling:
+            raise NotImplementedError("render_forward with antithetic_sampling: the forward-mode entry point has no film-level split")
         sens = self._sensors(scene, sensor)
         reparam = self._configured()
         data = params[SDF_DEFAULT_KEY] if SDF_DEFAULT_KEY in params else None
@@ -237,6 +278,36 @@ class _RenderOp(torch.autograd.Function):
                 None if ctx.gr is None else ctx.gr.reshape(ctx.gr.shape), None, None, None, None, None, None)
 
 
+class _PairRenderOp(torch.autograd.Function):
+    """`mi.render` for an integrator with `antithetic_sampling`: primal pair in forward(), gradient-pass pair in backward() (sequential:
+    the two-stream schedule of _RenderOp serves the default path)."""
+
+    @staticmethod
+    def forward(ctx, data, albedo, roughness, scene, sensors, seed, spp, seed_grad, spp_grad):
+        integ = scene.integrator()
+        integ.sdf.set_data(data.detach())
+        reparam = integ._configured()
+        n = len(sensors)
+        ctx.args = (scene, sensors, [seed_grad + i for i in range(n)], spp_grad, reparam, data.shape)
+        ctx.want = (ctx.needs_input_grad[1], ctx.needs_input_grad[2])
+        return integ._render_pair(sensors, spp, [seed + i for i in range(n)], reparam)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        scene, sensors, seeds, spp, reparam, shape = ctx.args
+        integ = scene.integrator()
+        sh = integ.shading()
+        want_r = sh is not None and sh.roughness is not None and ctx.want[1]
+        want_a = sh is not None and (ctx.want[0] or want_r)
+        ga = torch.zeros_like(sh.albedo.detach(), dtype=torch.float32).contiguous() if want_a else None
+        gr = None
+        if want_r:
+            gr = sh.grad_roughness = torch.zeros_like(sh.roughness.detach(), dtype=torch.float32).contiguous()
+        g = torch.zeros(integ.sdf.grid.shape, dtype=torch.float32, device=integ.sdf.grid.device)
+        integ._backward_pair(sensors, spp, seeds, reparam, grad_out.contiguous(), g, None, sh, ga)
+        return (g.reshape(shape) if ctx.needs_input_grad[0] else None, ga if ctx.want[0] else None, gr, None, None, None, None, None, None)
+
+
 def render(scene, params=None, sensor=0, seed=0, spp=4, seed_grad=0, spp_grad=None, integrator=None):
     """`mi.render(scene, params, sensor, seed, spp, seed_grad, spp_grad)` (python/shape_opt.py:78-80):
     primal image from (seed, spp) without AD; if `params` holds a tensor that requires grad the
@@ -252,8 +323,9 @@ def render(scene, params=None, sensor=0, seed=0, spp=4, seed_grad=0, spp_grad=No
     if data is not None and attached and torch.is_grad_enabled():
         # (the op takes the sensors in the SDF's own frame; `integ.render` below maps its world-space sensors itself -- each
         # consumer maps exactly once)
-        img = _RenderOp.apply(data, albedo, rough, scene, integ._sensors(scene, sensor), int(seed), int(spp), int(seed_grad),
-                              int(spp_grad or spp))
+        op = _PairRenderOp if integ.antithetic_sampling else _RenderOp
+        img = op.apply(data, albedo, rough, scene, integ._sensors(scene, sensor), int(seed), int(spp), int(seed_grad),
+                       int(spp_grad or spp))
     else:
         with torch.no_grad():
             if data is not None:

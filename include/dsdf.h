@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define DSDF_VERSION 306   /* 300: stats rows of DSDF_STAT_SLOTS (16) counters; tail hand-off on library-owned helper streams; 304: DSDF_NO_HIT_PROOF, the grid buffer carries the bounds of the hit proof (dsdf_padded_size); 305: dsdf_params grows by normalize_warp_field, max_reparam_depth; 306: dsdf_render_aovs, dsdf_aov_workspace_size */
+#define DSDF_VERSION 306   /* 300: stats rows of DSDF_STAT_SLOTS (16) counters; tail hand-off on library-owned helper streams; 304: DSDF_NO_HIT_PROOF, the grid buffer carries the bounds of the hit proof (dsdf_padded_size); 305: dsdf_params grows by normalize_warp_field, max_reparam_depth; 306: dsdf_render_aovs, dsdf_aov_workspace_size, dsdf_sampler_2d */
 #define DSDF_STAT_SLOTS 16
 
 enum dsdf_status {
@@ -190,7 +190,8 @@ size_t dsdf_forward_workspace_size(int width, int height, int spp, int n_views, 
  *               reference's lane order (reparam.py:140-155), or NULL to use the
  *               built-in `independent` sampler (PCG32 seeded by sample_tea_32)
  *               with seed = seeds[view]
- *   seeds     : n_views uint32 (HOST memory; ignored when offsets != NULL)
+ *   seeds     : n_views uint32 (HOST memory).  With offsets != NULL they still seed the LATER dimensions of a lane's stream
+ *               (sdf_direct_reparam: emitter / BSDF samples when dsdf_shading supplies none); NULL = seed 0 for those
  *   image_out : n_views x H x W x 3
  *   stats     : optional device int64[64][DSDF_STAT_SLOTS] accumulators -- 64 interleaved copies (to
  *               spread the atomics; sum over the first axis) of {lanes, bbox_lanes,
@@ -256,6 +257,16 @@ int dsdf_render_aovs(const float *padded, int rx, int ry, int rz, const dsdf_par
                      const dsdf_camera *cams, int n_views, int width, int height, int spp,
                      const float *offsets, const uint32_t *seeds,
                      float *aov_out, void *workspace, size_t workspace_bytes, void *stream);
+
+/* The film offsets of the built-in sampler: `sampler.next_2d()` of Mitsuba's `independent` sampler seeded like
+ * `ReparamIntegrator.prepare` (python/integrators/reparam.py:37-51, 169) -- what the render calls draw for a lane when they are given
+ * `seeds` instead of `offsets`.  offsets_out: n_views x (W+4)(H+4)*spp x 2 floats in the reference's lane order; mirror != 0 writes
+ * 1 - r instead, the offsets of the ANTITHETIC pair (integrator property `antithetic_sampling`, reparam.py:19, 167-178: a second
+ * eval_sample at `pos - r + 1` with a clone of the sampler -- the same emitter / BSDF samples -- into the same film block).  A host
+ * renders the pair as two film-level calls over one film (dsdf_render_film; dsdf_grad_sweep / dsdf_grad_backward), the second with
+ * these offsets AND the view's seeds: explicit offsets replace only the film sample of a lane, the later dimensions of its stream
+ * still come from seeds[view].  seeds: n_views uint32 (HOST memory). */
+int dsdf_sampler_2d(const uint32_t *seeds, int n_views, int width, int height, int spp, int mirror, float *offsets_out, void *stream);
 
 /* ---- multi-GPU pixel-tile split of a view ("pixel tiles within a view when N > views-per-iteration") --------
  * The reference is single-device; these four entry points split `ReparamIntegrator.render` / `render_backward`

@@ -965,7 +965,7 @@ def lane_positions(W, H, spp, offsets):
 def render(sdf, cam, W, H, spp, offsets, integrator=SILHOUETTE, reparam=True,
            return_aux=False, chunk=1 << 17, albedo=None, emitter_u=None, env=1.0, hide_emitters=False, rows=None,
            return_block=False, use_mis=False, bsdf_u=None, detach_indirect_si=False, decouple_reparam=False, light_dir=None,
-           roughness=None, normalize_warp_field=True, max_reparam_depth=-1, aovs=False):
+           roughness=None, normalize_warp_field=True, max_reparam_depth=-1, aovs=False, antithetic=False):
     """One view.  offsets: (Wb*Hb*spp, 2) in [0,1) (the sampler's next_2d per
     lane).  Returns image (H,W,3), differentiable w.r.t. sdf.data / sdf.p when
     they require grad.  `reparam=False` gives the DummyWarpField path
@@ -977,7 +977,10 @@ def render(sdf, cam, W, H, spp, offsets, integrator=SILHOUETTE, reparam=True,
     the film gets the 11 channels of AOV_NAMES behind RGB and the image is (H, W, 14).  The only two any code path of the reference
     fills are the loop state of the primary ray's trace, `i` and `weight_sum` (shapes.py:240-242) -- WarpField2D.eval accepts
     `extra_output` and never writes to it (warp.py:47-96), and sdf_direct_reparam.py:58-60 looks for a key the shadow ray's
-    dictionary cannot hold; without reparameterisation (DummyWarpField, warp.py:185) all eleven stay 0."""
+    dictionary cannot hold; without reparameterisation (DummyWarpField, warp.py:185) all eleven stay 0.
+    antithetic: the integrator property `antithetic_sampling` (reparam.py:19, 167-178): every lane is evaluated a second time at the
+    mirrored film position `pos - r + 1` with a CLONE of its sampler taken after `next_2d` -- i.e. with the same emitter / BSDF
+    samples -- and both samples go into the same film block."""
     Wb, Hb = W + 2 * BORDER, H + 2 * BORDER
     dt = offsets.dtype
     C = 4 + (len(AOV_NAMES) if aovs else 0)
@@ -994,8 +997,15 @@ def render(sdf, cam, W, H, spp, offsets, integrator=SILHOUETTE, reparam=True,
     aux = dict(steps=0, lanes=0, bbox=0, hits=0, refine=0, warp_active=0)
     # sdf_simple_shading_reparam.py:20 fixes normalize(1,1,1); `light_dir` only serves the change-of-frame test (tests/test_to_world.py)
     light = torch.tensor([1.0, 1.0, 1.0], dtype=dt) / math.sqrt(3.0) if light_dir is None else torch.as_tensor(light_dir, dtype=dt)
-    for s in range(0, pos_all.shape[0], chunk):
-        pos = pos_all[s:s + chunk]
+    passes = [pos_all]
+    if antithetic:                                                       # reparam.py:173: position_sample2 = pos - r + 1.0
+        pix = lane_positions(W, H, spp, torch.zeros_like(offsets))
+        if rows is not None:
+            pix = pix[lo:hi]
+        passes.append(pix - (pos_all - pix) + 1.0)
+    # (chunks never straddle the two passes: the per-lane emitter / BSDF samples are indexed by the lane, not by the pass)
+    for pos_pass, s in [(p_, s_) for p_ in passes for s_ in range(0, p_.shape[0], chunk)]:
+        pos = pos_pass[s:s + chunk]
         o, d, maxt = cam.sample_ray(pos, W, H)                           # reparam.py:92-94
         tr = ray_intersect(sdf, o, d, maxt)                              # warp.py:104-107
         its_t = tr['its_t']

@@ -140,7 +140,8 @@ class HostHarness:
                                 C.c_uint(seed), self._p(out))
         return out
 
-    def render_backward(self, grid, cam, W, H, spp, offsets, grad_image, integrator, reparam=True, seed=0, split=False):
+    def render_backward(self, grid, cam, W, H, spp, offsets, grad_image, integrator, reparam=True, seed=0, split=False, offsets2=None):
+        """offsets2: a second sample set per lane into the same film (the antithetic pair of reparam.py:167-178)."""
         grid = np.ascontiguousarray(grid, np.float32)
         offsets = None if offsets is None else np.ascontiguousarray(offsets, np.float32)
         gi = np.ascontiguousarray(grad_image, np.float32)
@@ -148,9 +149,16 @@ class HostHarness:
         img = np.zeros((H, W, 3), np.float32)
         self.last_grad_p = np.zeros(3, np.float32)
         rz, ry, rx = grid.shape
-        self.lib.hh_render_backward(self._p(grid), rx, ry, rz, C.byref(self.params), self._p(cam), W, H, spp,
-                                    self._p(offsets), C.c_uint(seed), integrator, int(reparam) | (0x1000 if split else 0), self._p(gi),
-                                    self._p(gg), self._p(img), self._p(self.last_grad_p))
+        fl = int(reparam) | (0x1000 if split else 0)
+        if offsets2 is None:
+            self.lib.hh_render_backward(self._p(grid), rx, ry, rz, C.byref(self.params), self._p(cam), W, H, spp,
+                                        self._p(offsets), C.c_uint(seed), integrator, fl, self._p(gi),
+                                        self._p(gg), self._p(img), self._p(self.last_grad_p))
+        else:
+            o2 = np.ascontiguousarray(offsets2, np.float32)
+            self.lib.hh_render_backward_pair(self._p(grid), rx, ry, rz, C.byref(self.params), self._p(cam), W, H, spp,
+                                             self._p(offsets), self._p(o2), C.c_uint(seed), integrator, fl, self._p(gi),
+                                             self._p(gg), self._p(img), self._p(self.last_grad_p))
         return gg, img
 
     def render_forward_grad(self, grid, cam, W, H, spp, offsets, integrator, tangent=None, tangent_p=None, reparam=True, seed=0):

@@ -150,47 +150,68 @@ void hh_render_aovs(const float *data, int rx, int ry, int rz, const dsdf_params
         }
 }
 
-void hh_render_backward(const float *data, int rx, int ry, int rz, const dsdf_params *prm, const dsdf_camera *cam,
-                        int W, int H, int spp, const float *offsets, unsigned seed, int integrator, int flags,
-                        const float *grad_image, float *grad_grid, float *image, float *grad_p) {
+// offsets2 != null: the antithetic pair (reparam.py:167-178) -- every lane a second time with the offsets of offsets2 (the host of
+// the product passes 1 - r), both samples into the same film block, both back-propagated against the developed sum
+static void render_backward_sets(const float *data, int rx, int ry, int rz, const dsdf_params *prm, const dsdf_camera *cam,
+                                 int W, int H, int spp, const float *offsets, const float *offsets2, unsigned seed, int integrator, int flags,
+                                 const float *grad_image, float *grad_grid, float *image, float *grad_p) {
     std::vector<float> p = pad(data, rx, ry, rz);
     GridView G = make_view(p.data(), rx, ry, rz, *prm);
     const bool split = (flags & 0x1000) != 0;          // harness-only: the two-half adjoint (lane_backward_coef / _apply)
-    ViewArgs A = view_args(cam, W, H, spp, offsets, seed, integrator, flags & 0xfff);
-    std::vector<float> block((size_t)2 * A.Wb * A.Hb, 0.f), badj((size_t)2 * A.Wb * A.Hb, 0.f);
-    long n = (long)A.Wb * A.Hb * spp;
-    std::vector<TraceOut> tr(n);
-    for (long lane = 0; lane < n; ++lane) {
-        Lane L = lane_setup(A, *prm, (uint32_t)lane);
-        trace_diff(G, *prm, L.ray.o, L.ray.d, L.ray.maxt, tr[lane]);
-        float val = shade_value(G, A, L, tr[lane].its_t);
-        Reproj rp = reproject(A.cam, *prm, L.ray.o + L.ray.d, W, H);
-        splat_lane(block.data(), A.Wb, A.Hb, rp.u, rp.v, val, PlainAdd());
-    }
+    const int nsets = offsets2 ? 2 : 1;
+    ViewArgs As[2] = {view_args(cam, W, H, spp, offsets, seed, integrator, flags & 0xfff),
+                      view_args(cam, W, H, spp, offsets2 ? offsets2 : offsets, seed, integrator, flags & 0xfff)};
+    const ViewArgs &A0 = As[0];
+    std::vector<float> block((size_t)2 * A0.Wb * A0.Hb, 0.f), badj((size_t)2 * A0.Wb * A0.Hb, 0.f);
+    long n = (long)A0.Wb * A0.Hb * spp;
+    std::vector<TraceOut> tr(n * nsets);
+    for (int s = 0; s < nsets; ++s)
+        for (long lane = 0; lane < n; ++lane) {
+            const ViewArgs &A = As[s];
+            Lane L = lane_setup(A, *prm, (uint32_t)lane);
+            trace_diff(G, *prm, L.ray.o, L.ray.d, L.ray.maxt, tr[s * n + lane]);
+            float val = shade_value(G, A, L, tr[s * n + lane].its_t);
+            Reproj rp = reproject(A.cam, *prm, L.ray.o + L.ray.d, W, H);
+            splat_lane(block.data(), A.Wb, A.Hb, rp.u, rp.v, val, PlainAdd());
+        }
     if (image) develop(block, W, H, image);
     for (int y = 0; y < H; ++y)
         for (int x = 0; x < W; ++x) {
-            size_t q = (size_t)(y + DSDF_BORDER) * A.Wb + x + DSDF_BORDER;
+            size_t q = (size_t)(y + DSDF_BORDER) * A0.Wb + x + DSDF_BORDER;
             const float *gi = grad_image + 3 * ((size_t)y * W + x);
             float gs = gi[0] + gi[1] + gi[2];
-            float w = block[2 * q + 1], s = block[2 * q];
+            float w = block[2 * q + 1], sv = block[2 * q];
             if (w == 0.f) { badj[2 * q] = gs; badj[2 * q + 1] = 0.f; }
-            else { badj[2 * q] = gs / w; badj[2 * q + 1] = -gs * s / (w * w); }
+            else { badj[2 * q] = gs / w; badj[2 * q + 1] = -gs * sv / (w * w); }
         }
-    for (long lane = 0; lane < n; ++lane) {
-        Lane L = lane_setup(A, *prm, (uint32_t)lane);
-        ScatterReq req[2];
-        if (split) {
-            BackCoef bc;
-            req[0].on = req[1].on = false;
-            if (lane_backward_coef(G, *prm, A, L, tr[lane], bc)) lane_backward_apply(*prm, A, L, tr[lane], bc, badj.data(), req);
-        } else lane_backward(G, *prm, A, L, tr[lane], badj.data(), req);
-        for (int r = 0; r < 2; ++r)
-            if (req[r].on) {
-                scatter_cubic(G, grad_grid, req[r].x, req[r].cv, req[r].cg, PlainAdd());
-                if (grad_p) { grad_p[0] += req[r].p_bar.x; grad_p[1] += req[r].p_bar.y; grad_p[2] += req[r].p_bar.z; }
-            }
-    }
+    for (int s = 0; s < nsets; ++s)
+        for (long lane = 0; lane < n; ++lane) {
+            const ViewArgs &A = As[s];
+            Lane L = lane_setup(A, *prm, (uint32_t)lane);
+            ScatterReq req[2];
+            if (split) {
+                BackCoef bc;
+                req[0].on = req[1].on = false;
+                if (lane_backward_coef(G, *prm, A, L, tr[s * n + lane], bc)) lane_backward_apply(*prm, A, L, tr[s * n + lane], bc, badj.data(), req);
+            } else lane_backward(G, *prm, A, L, tr[s * n + lane], badj.data(), req);
+            for (int r = 0; r < 2; ++r)
+                if (req[r].on) {
+                    scatter_cubic(G, grad_grid, req[r].x, req[r].cv, req[r].cg, PlainAdd());
+                    if (grad_p) { grad_p[0] += req[r].p_bar.x; grad_p[1] += req[r].p_bar.y; grad_p[2] += req[r].p_bar.z; }
+                }
+        }
+}
+
+void hh_render_backward(const float *data, int rx, int ry, int rz, const dsdf_params *prm, const dsdf_camera *cam,
+                        int W, int H, int spp, const float *offsets, unsigned seed, int integrator, int flags,
+                        const float *grad_image, float *grad_grid, float *image, float *grad_p) {
+    render_backward_sets(data, rx, ry, rz, prm, cam, W, H, spp, offsets, nullptr, seed, integrator, flags, grad_image, grad_grid, image, grad_p);
+}
+
+void hh_render_backward_pair(const float *data, int rx, int ry, int rz, const dsdf_params *prm, const dsdf_camera *cam,
+                             int W, int H, int spp, const float *offsets, const float *offsets2, unsigned seed, int integrator, int flags,
+                             const float *grad_image, float *grad_grid, float *image, float *grad_p) {
+    render_backward_sets(data, rx, ry, rz, prm, cam, W, H, spp, offsets, offsets2, seed, integrator, flags, grad_image, grad_grid, image, grad_p);
 }
 
 // Tail hand-off (dsdf_tail.h): stop the differentiable march after `split` steps, export the state in the tail-queue

@@ -186,7 +186,11 @@ def main():
                      # ... and the debug images: `use_aovs` on the integrator + `return_aovs` on the warp field (reparam.py:160-165,
                      # 263-267; warp.py:105-106; shapes.py:240-242) -> (H, W, 3 + 11) images, stored whole as `aov_<tag>`
                      ('sdf_silhouette_reparam', 'sil_aovs', {'use_aovs': True}, 'warp'), (D, 'direct_aovs', {'use_aovs': True}, 'warp'),
-                     ('sdf_silhouette_reparam', 'sil_aovs_noreparam', {'use_aovs': True}, 'onlyshadinggrad')]
+                     ('sdf_silhouette_reparam', 'sil_aovs_noreparam', {'use_aovs': True}, 'onlyshadinggrad'),
+                     # ... and the antithetic pair of every sample (reparam.py:19, 167-178: a second eval_sample at the mirrored film
+                     # position `pos - r + 1` with a clone of the sampler, into the same block)
+                     ('sdf_silhouette_reparam', 'sil_anti', {'antithetic_sampling': True}, 'warp'),
+                     (D, 'direct_anti', {'antithetic_sampling': True}, 'warp')]
         for integ_name, tag, props, method in runs:
             if args.tags is not None and tag not in args.tags:
                 continue
