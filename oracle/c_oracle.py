@@ -9,12 +9,14 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB = os.path.join(HERE, '_build', 'libdsdf_oracle.so')
 LIB64 = os.path.join(HERE, '_build', 'libdsdf_oracle64.so')
+LIB64X = os.path.join(HERE, '_build', 'libdsdf_oracle64x.so')     # fp64 with fp64-VALUED literals (oracle/Makefile)
 
 
 def load(double=False):
     """fp32 build (the reference's arithmetic type; the timed CPU baseline) or, with double=True, the fp64 build of
-    the same statements (checker at config sizes / yardstick of the fp32 noise floor)."""
-    path = LIB64 if double else LIB
+    the same statements (checker at config sizes / yardstick of the fp32 noise floor); double='exact': the fp64 build whose
+    literals are fp64-valued too (0.05 instead of 0.05f) -- the program the fp64 fixtures of the reference's own code were made with."""
+    path = LIB64X if double == 'exact' else (LIB64 if double else LIB)
     src = os.path.join(HERE, 'dsdf_oracle.c')
     if not os.path.isfile(path) or os.path.getmtime(path) < os.path.getmtime(src):
         subprocess.check_call(['make', '-C', HERE])

@@ -140,6 +140,44 @@ def test_method_configs_are_different_estimators():
     assert rel_l2(ref16['grad_direct_onlyshading'], ref16['grad_direct']) > 1e-2
 
 
+# ---------------------------------------------------------------------------------------------------------------- C oracle (fp64 build)
+@pytest.mark.parametrize('name', ['sphere16', 'blob32'])
+def test_c64_oracle_matches_reference_code(name):
+    """The plain-C restatement with the HAND-WRITTEN adjoint (oracle/dsdf_oracle.c: the checker at BASELINE.json config sizes, where
+    the torch oracle is too slow) DIRECTLY against what the reference's own files produced -- not only through the torch oracle it
+    is otherwise compared with (tests/test_c_oracle.py).
+      * the fp64 build with fp64-valued literals (libdsdf_oracle64x.so: the same source, `f` suffixes removed) is the program the
+        fixtures were made with: images to 1e-14, gradients to 1e-8 -- a code that shares no line with the reference's or the torch
+        oracle's, and derives its backward by hand;
+      * the regular fp64 build keeps the fp32 VALUES of its constants (0.05f: "the fp32 program in exact arithmetic", the yardstick
+        of the kernels' rounding).  That 1.5e-8 relative change of a few constants moves ONE heavy-tailed sample of the blob32
+        `direct` case by 5e-4 and the whole gradient by 1.4e-5 -- the conditioning of the estimator, measured
+        here between two fp64 programs; every other output stays below 1e-6."""
+    import c_oracle
+    ref = load(name)
+    x = inputs(ref)
+    grid, cam, W, H, spp, offs, gi = ref['grid'], ref['cam16'], x['W'], x['H'], x['spp'], ref['sampler_2d'], ref['grad_image']
+    eu, bu = x['emitter_u'].numpy(), x['bsdf_u'].numpy()
+    direct = [(t, kw) for t, kw in (('direct', {}), ('direct_mis', dict(bsdf_u=bu)), ('direct_hide', dict(hide_emitters=True)),
+                                    ('direct_detach', dict(variant=1)), ('direct_decouple', dict(variant=2)),
+                                    ('direct_mis_decouple', dict(bsdf_u=bu, variant=2)), ('direct_onlyshading', dict(reparam=False)))
+              if f'img_{t}' in ref.files]
+    worst = {}
+    for kind, gate_img, gate_g in (('exact', 1e-14, 1e-8), (True, 2e-7, 1e-4)):
+        lib = c_oracle.load(kind)
+        for tag, integ in (('sil', O.SILHOUETTE), ('shade', O.SIMPLE_SHADING)):
+            gg, img = c_oracle.render_backward(lib, grid, cam, W, H, spp, offs, gi, integ, True)
+            e = (rel_l2(img, ref[f'img_{tag}']), rel_l2(gg, ref[f'grad_{tag}']))
+            assert e[0] < gate_img and e[1] < gate_g, (kind, tag, e)
+            worst[kind] = max(worst.get(kind, 0.0), e[1])
+        for tag, kw in direct:
+            gg, galb, img = c_oracle.render_direct_backward(lib, grid, cam, W, H, spp, offs, eu, ref['albedo'], gi, tuple(ref['env']), **kw)
+            e = (rel_l2(img, ref[f'img_{tag}']), rel_l2(gg, ref[f'grad_{tag}']), rel_l2(galb, ref[f'galb_{tag}']))
+            assert e[0] < gate_img and e[1] < gate_g and e[2] < max(gate_g, 1e-6), (kind, tag, e)
+            worst[kind] = max(worst.get(kind, 0.0), e[1])
+    print(f"C oracle vs reference-code fixture {name}: worst gradient rel-L2 {worst['exact']:.2e} (fp64 literals), {worst[True]:.2e} (fp32-valued literals)")
+
+
 # ---------------------------------------------------------------------------------------------------------------- kernel arithmetic (host build)
 def _settings(tag):
     kw = TAGS[tag][1]
