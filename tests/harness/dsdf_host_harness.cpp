@@ -87,8 +87,11 @@ void hh_warp_eval(const float *data, int rx, int ry, int rz, const dsdf_params *
 }
 
 static ViewArgs view_args(const dsdf_camera *cam, int W, int H, int spp, const float *offsets, unsigned seed,
-                          int integrator, int flags) {
+                          int integrator, int flags, const dsdf_params *prm = nullptr) {
     ViewArgs A;
+    // (the library's make_view_args: the fixed light of sdf_simple_shading_reparam comes from dsdf_params.light_dir)
+    if (prm && (prm->light_dir[0] != 0.f || prm->light_dir[1] != 0.f || prm->light_dir[2] != 0.f))
+        for (int k = 0; k < 3; ++k) A.light[k] = prm->light_dir[k];
     A.cam = *cam; A.W = W; A.H = H; A.Wb = W + 2 * DSDF_BORDER; A.Hb = H + 2 * DSDF_BORDER; A.spp = spp;
     A.integrator = integrator; A.flags = flags; A.seed = seed; A.offsets = offsets; A.emitter_u = nullptr; A.bsdf_u = nullptr;
     return A;
@@ -112,7 +115,7 @@ void hh_render_forward(const float *data, int rx, int ry, int rz, const dsdf_par
                        int diff, float *image) {
     std::vector<float> p = pad(data, rx, ry, rz);
     GridView G = make_view(p.data(), rx, ry, rz, *prm);
-    ViewArgs A = view_args(cam, W, H, spp, offsets, seed, integrator, flags);
+    ViewArgs A = view_args(cam, W, H, spp, offsets, seed, integrator, flags, prm);
     std::vector<float> block((size_t)2 * A.Wb * A.Hb, 0.f);
     long n = (long)A.Wb * A.Hb * spp;
     for (long lane = 0; lane < n; ++lane) {
@@ -159,8 +162,8 @@ static void render_backward_sets(const float *data, int rx, int ry, int rz, cons
     GridView G = make_view(p.data(), rx, ry, rz, *prm);
     const bool split = (flags & 0x1000) != 0;          // harness-only: the two-half adjoint (lane_backward_coef / _apply)
     const int nsets = offsets2 ? 2 : 1;
-    ViewArgs As[2] = {view_args(cam, W, H, spp, offsets, seed, integrator, flags & 0xfff),
-                      view_args(cam, W, H, spp, offsets2 ? offsets2 : offsets, seed, integrator, flags & 0xfff)};
+    ViewArgs As[2] = {view_args(cam, W, H, spp, offsets, seed, integrator, flags & 0xfff, prm),
+                      view_args(cam, W, H, spp, offsets2 ? offsets2 : offsets, seed, integrator, flags & 0xfff, prm)};
     const ViewArgs &A0 = As[0];
     std::vector<float> block((size_t)2 * A0.Wb * A0.Hb, 0.f), badj((size_t)2 * A0.Wb * A0.Hb, 0.f);
     long n = (long)A0.Wb * A0.Hb * spp;
@@ -265,7 +268,7 @@ void hh_render_forward_grad(const float *data, int rx, int ry, int rz, const dsd
     std::vector<float> tp;
     if (tangent) tp = pad(tangent, rx, ry, rz);
     GridView G = make_view(p.data(), rx, ry, rz, *prm);
-    ViewArgs A = view_args(cam, W, H, spp, offsets, seed, integrator, flags);
+    ViewArgs A = view_args(cam, W, H, spp, offsets, seed, integrator, flags, prm);
     V3 dp = tangent_p ? mk(tangent_p[0], tangent_p[1], tangent_p[2]) : mk(0.f, 0.f, 0.f);
     std::vector<float> block((size_t)2 * A.Wb * A.Hb, 0.f), dblock((size_t)2 * A.Wb * A.Hb, 0.f);
     long n = (long)A.Wb * A.Hb * spp;

@@ -82,6 +82,45 @@ def test_oracle_transform_gradients_follow_the_reference():
     assert float(lo.min()) < -0.05 and float(hi.max()) > 1.05           # a rotated cube's AABB is larger than the cube
 
 
+def _ref16():
+    import os
+    return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'refshim_sphere16.npz'))
+
+
+@pytest.mark.parametrize('key', ['tf_general', 'tf_axis'])
+def test_oracle_transform_matches_reference_code(key):
+    """The oracle's `Grid3d(data, p, to_world)` against the REFERENCE'S OWN python/shapes.py with a transform (run on the torch
+    stand-in, tools/make_reference_fixtures.py --shim: the `tf_*` keys of tests/golden/refshim_sphere16.npz): eval_all, per-ray
+    outputs of ray_intersect, image and gradients of both scene-free integrators -- for a rotation that is NOT axis-aligned (the
+    traced box is the world AABB of the rotated cube, shapes.py:393-403) and for the axis-aligned one the product accepts.  This
+    is what the product's transform test below is measured against."""
+    from test_refshim_fixture import inputs
+    ref = _ref16()
+    x = inputs(ref)
+    assert np.allclose(ref['tf_general_matrix'], GENERAL) and np.allclose(ref['tf_axis_matrix'], AXIS_ALIGNED)
+    M, p0 = ref[f'{key}_matrix'], torch.from_numpy(ref['tf_p'])
+    sdf = O.Grid3d(x['grid'], p0, M)
+    v, _, g, _, Hm = sdf.eval_all(torch.from_numpy(ref['eval_pts']).double())
+    rel = lambda a, b: float(np.linalg.norm(np.asarray(a) - b) / np.linalg.norm(b))
+    assert rel(v.numpy(), ref[f'{key}_eval_v']) < 1e-12 and rel(g.numpy(), ref[f'{key}_eval_g']) < 1e-12 and rel(Hm.numpy(), ref[f'{key}_eval_H']) < 1e-12
+    o, d, maxt = (torch.from_numpy(ref[k]).double() for k in ('ray_o', 'ray_d', 'ray_maxt'))
+    tr = O.ray_intersect(sdf, o, d, maxt)
+    hit, fin = np.isfinite(ref[f'{key}_ri_its_t']), np.isfinite(ref[f'{key}_ri_warp_t'])
+    assert hit.sum() > 50 and fin.sum() > 200
+    assert np.array_equal(np.isfinite(tr['its_t'].numpy()), hit) and np.array_equal(np.isfinite(tr['warp_t'].numpy()), fin)
+    assert rel(tr['its_t'].numpy()[hit], ref[f'{key}_ri_its_t'][hit]) < 1e-12
+    for k, tol in (('warp_t', 1e-12), ('warp_weight', 1e-11), ('warp_t_d', 1e-9), ('warp_weight_d', 1e-11)):
+        assert rel(tr[k].numpy()[fin], ref[f'{key}_ri_{k}'][fin]) < tol, k
+    for tag, integ in (('sil', O.SILHOUETTE), ('shade', O.SIMPLE_SHADING)):
+        data, p = x['grid'].clone().requires_grad_(True), p0.clone().requires_grad_(True)
+        img = O.render(O.Grid3d(data, p, M), x['cam'], x['W'], x['H'], x['spp'], x['offs'], integ, True)
+        (img * x['gi']).sum().backward()
+        assert rel(img.detach().numpy(), ref[f'{key}_img_{tag}']) < 1e-12
+        assert rel(data.grad.numpy(), ref[f'{key}_grad_{tag}']) < 1e-9 and rel(p.grad.numpy(), ref[f'{key}_gradp_{tag}']) < 1e-9
+    # the transform matters: neither image is the un-transformed one
+    assert rel(ref[f'{key}_img_sil'], ref['img_sil']) > 1e-3
+
+
 def test_rigid_parts_and_local_sensor():
     import shapes
     import dsdf
@@ -180,3 +219,95 @@ def test_transformed_grid_render_gpu(built, T, exact):
     if exact:
         m = tr['warp_weight'] > 1e-3
         assert torch.allclose(out[1].cpu().double()[m], tr['warp_t'][m], rtol=2e-3, atol=1e-4)
+
+
+def _fp32_floor_tf(x, ref, tag, integ):
+    """The oracle run in fp32 with the transform against the fp64 fixture: (dL/d data, dL/d p) rel-L2."""
+    rel = lambda a, b: float(np.linalg.norm(np.asarray(a, np.float64) - b) / np.linalg.norm(b))
+    cam32 = O.Camera.from_params(x['cam'].params(), dtype=torch.float32)
+    d32, p32 = x['grid'].float().clone().requires_grad_(True), torch.from_numpy(ref['tf_p']).float().requires_grad_(True)
+    i32 = O.render(O.Grid3d(d32, p32, AXIS_ALIGNED), cam32, x['W'], x['H'], x['spp'], x['offs'].float(), integ, True)
+    (i32 * x['gi'].float()).sum().backward()
+    return rel(d32.grad.numpy(), ref[f'tf_axis_grad_{tag}']), rel(p32.grad.numpy(), ref[f'tf_axis_gradp_{tag}'])
+
+
+@pytest.mark.parametrize('tag,integ', [('sil', O.SILHOUETTE), ('shade', O.SIMPLE_SHADING)])
+def test_change_of_frame_kernel_math_matches_reference_code(harness, tag, integ):
+    """The product's route for `Grid3d(data, transform)` on the host: the mirror's change of frame (shapes.Grid3d.local_sensor /
+    local_translation / the light direction of simple shading taken to the cube's frame, dL/dp back through to_local^T) around
+    the host build of the kernel arithmetic, against what the reference's own code produced in WORLD space with the axis-aligned
+    transform (`tf_axis_*`).  The GPU test below runs the same route through the library."""
+    import dsdf
+    import shapes
+    from test_refshim_fixture import inputs, check_fp32_gradient
+    import precision as P
+    ref = _ref16()
+    x = inputs(ref)
+    rel = lambda a, b: float(np.linalg.norm(np.asarray(a, np.float64) - b) / np.linalg.norm(b))
+    g = shapes.Grid3d.__new__(shapes.Grid3d)                              # (the constructor wants a device tensor: frame fields only)
+    g.has_transform = True
+    g.to_world, g._A, g._b = shapes._rigid_parts(AXIS_ALIGNED)
+    ls = g.local_sensor(dsdf.Sensor(ref['origin'], resx=x['W'], resy=x['H']))
+    s = ls.to_struct()
+    cam = np.array(list(s.origin) + list(s.left) + list(s.up) + list(s.dir) + [s.tan_half_fov, 0, 0, 0], np.float32)
+    pl = g.local_translation(ref['tf_p'])
+    light = g._A @ (np.ones(3) / np.sqrt(3.0))
+    old = [harness.params.sdf_p[k] for k in range(3)], [harness.params.light_dir[k] for k in range(3)]
+    try:
+        for k in range(3):
+            harness.params.sdf_p[k] = float(pl[k]); harness.params.light_dir[k] = float(light[k])
+        gg, img = harness.render_backward(ref['grid'], cam, x['W'], x['H'], x['spp'], ref['sampler_2d'], ref['grad_image'], integ)
+        gp = g._A.T @ harness.last_grad_p.astype(np.float64)             # to_local3^T: back to the world frame
+    finally:
+        for k in range(3):
+            harness.params.sdf_p[k] = old[0][k]; harness.params.light_dir[k] = old[1][k]
+    assert rel(img, ref[f'tf_axis_img_{tag}']) < 1e-4
+    fg, fp = _fp32_floor_tf(x, ref, tag, integ)
+    e = check_fp32_gradient('refshim_host', 'sphere16', f'tf_axis_{tag}', gg, ref[f'tf_axis_grad_{tag}'], max(P.FLOOR_FACTOR * fg, P.NORTH_STAR))
+    ep = rel(gp, ref[f'tf_axis_gradp_{tag}'])
+    print(f"host tf_axis {tag}: dL/d data {e:.3e} (fp32 oracle {fg:.3e}), dL/d p {ep:.3e} (fp32 oracle {fp:.3e})")
+    assert ep < max(P.FLOOR_FACTOR * fp, 2 * e, P.NORTH_STAR), (ep, fp, e)
+
+
+@pytest.mark.gpu
+def test_transformed_grid_matches_reference_code_gpu(built):
+    """The HIP path with `Grid3d(data, transform=AXIS_ALIGNED)`, sdf.p and the WORLD sensor against what the reference's own
+    shapes.py / reparam.py produced with that transform (`tf_axis_*` of the sphere16 fixture): image, dL/d(data), dL/d(sdf.p).
+    Gates: max(2 x the oracle's own fp32-vs-fixture error, 1e-4), like every other fp32 comparison of the suite."""
+    import configs
+    import dsdf
+    import shapes
+    import integrators  # noqa: F401
+    from integrators.reparam import Scene, create_integrator, traverse
+    from constants import SDF_DEFAULT_KEY, SDF_DEFAULT_KEY_P
+    from test_refshim_fixture import inputs
+    dsdf.load()
+    ref = _ref16()
+    x = inputs(ref)
+    W, H, spp, seed = x['W'], x['H'], x['spp'], x['seed']
+    rel = lambda a, b: float(np.linalg.norm(np.asarray(a, np.float64) - b) / np.linalg.norm(b))
+    sensor = dsdf.Sensor(ref['origin'], resx=W, resy=H)
+    gi = torch.from_numpy(ref['grad_image']).cuda()
+    p0 = torch.from_numpy(ref['tf_p']).float()
+    import precision as P
+    from test_refshim_fixture import check_fp32_gradient
+    for name, tag, integ in (('sdf_silhouette_reparam', 'sil', O.SILHOUETTE), ('sdf_simple_shading_reparam', 'shade', O.SIMPLE_SHADING)):
+        floor_g, floor_p = _fp32_floor_tf(x, ref, tag, integ)
+        sdf = shapes.Grid3d(torch.from_numpy(ref['grid']).cuda(), transform=AXIS_ALIGNED)
+        sdf.p = p0.clone()
+        it = create_integrator(name, {'sdf': sdf})
+        scene = Scene([sensor], it)
+        it.warp_field = configs.get_config('warp').get_warpfield(it.sdf)
+        img = it.render(scene, 0, seed=seed, spp=spp).cpu().numpy()
+        assert rel(img, ref[f'tf_axis_img_{tag}']) < 1e-4, tag
+        params = traverse(scene)
+        leaf = torch.from_numpy(ref['grid']).cuda().clone().requires_grad_(True)
+        pl = p0.clone().requires_grad_(True)
+        params[SDF_DEFAULT_KEY], params[SDF_DEFAULT_KEY_P] = leaf, pl
+        params.update()
+        it.render_backward(scene, params, gi, 0, seed=seed, spp=spp)
+        eg = check_fp32_gradient('refshim_gpu', 'sphere16', f'tf_axis_{tag}', leaf.grad.cpu().numpy().reshape(ref['grid'].shape),
+                                 ref[f'tf_axis_grad_{tag}'], max(P.FLOOR_FACTOR * floor_g, P.NORTH_STAR))
+        ep = rel(pl.grad.numpy(), ref[f'tf_axis_gradp_{tag}'])
+        print(f"gpu tf_axis {tag}: dL/d data {eg:.3e} (fp32 oracle {floor_g:.3e}), dL/d p {ep:.3e} (fp32 oracle {floor_p:.3e})")
+        assert ep < max(P.FLOOR_FACTOR * floor_p, 2 * eg, P.NORTH_STAR), (tag, ep, floor_p, eg)

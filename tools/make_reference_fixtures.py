@@ -35,6 +35,8 @@ cannot drift):
   * per integrator tag (sil, shade[, direct, direct_mis]): `img_<tag>` = integrator.render (python/integrators/reparam.py:120-185),
     `grad_<tag>` = d(sum(img * grad_image))/d(sdf.data), `gradp_<tag>` = .../d(sdf.p) through render_backward (:187-190)
     [`galb_<tag>` = .../d(reflectance volume)]
+  * `tf_general_*`, `tf_axis_*`: Grid3d(data, transform) (python/shapes.py:378-450) with a non-axis-aligned and an axis-aligned `to_world` and
+    sdf.p = `tf_p`: eval_all at `eval_pts`, ray_intersect on the camera rays, image / gradients of the two scene-free integrators
   * `aov_<tag>` (sil_aovs, direct_aovs, sil_aovs_noreparam): the (H, W, 14) image of integrator.render with `use_aovs` and
     `warp_field.return_aovs` (python/integrators/reparam.py:160-165, 263-267)
 """
@@ -69,6 +71,26 @@ def case_inputs(name):
                 albedo=albedo, env=tuple(float(np.float32(e)) for e in (1.0, 0.9, 0.8)))   # (fp32 values: what the C-ABI receives)
 
 
+def transforms():
+    """The two `to_world` matrices of the transform fixtures (the same as tests/test_to_world.py: GENERAL, AXIS_ALIGNED): a rotation
+    of the unit cube about its centre followed by a translation."""
+    def rot(axis, deg):
+        a = np.radians(deg)
+        c, s = np.cos(a), np.sin(a)
+        i, j = [(1, 2), (2, 0), (0, 1)][axis]
+        R = np.eye(3)
+        R[i, i], R[i, j], R[j, i], R[j, j] = c, -s, s, c
+        return R
+
+    def about_centre(R, shift):
+        T = np.eye(4)
+        T[:3, :3] = R
+        T[:3, 3] = np.array([0.5, 0.5, 0.5]) - R @ np.array([0.5, 0.5, 0.5]) + np.asarray(shift)
+        return T
+    return {'tf_general': about_centre(rot(1, 25) @ rot(2, -10), (0.01, 0.0, -0.02)),
+            'tf_axis': about_centre(rot(1, 90) @ rot(0, 180), (0.02, -0.015, 0.01))}
+
+
 def cols(a, k):
     """A k-vector array of the stack as (n, k) numpy."""
     arr = np.array(a)
@@ -92,6 +114,7 @@ def main():
     ap.add_argument('--out', default=os.path.join(ROOT, 'tests', 'golden'))
     ap.add_argument('--cases', nargs='*', default=['sphere16', 'blob32'])
     ap.add_argument('--tags', nargs='*', default=None, help='subset of the integrator runs (default: all)')
+    ap.add_argument('--tf-cases', nargs='*', default=['sphere16'], help='cases that also get the Grid3d(transform) section (slow on the stand-in)')
     args = ap.parse_args()
 
     if args.shim:
@@ -239,6 +262,51 @@ def main():
             out[f'gradp_{tag}'] = np.array(dr.grad(params[SDF_DEFAULT_KEY_P])).reshape(3).astype(ft)
             if direct:
                 out[f'galb_{tag}'] = np.array(dr.grad(params[keys[2]])).reshape(c['albedo'].shape).astype(ft)
+
+        # ---- Grid3d(data, transform) / integrator property `sdf_to_world` (python/shapes.py:378-450, integrators/reparam.py:21-29):
+        # lookups at to_local @ (x - p), gradients back through to_local^T, the traced box = world AABB of the transformed cube.
+        # `tf_general`: a rotation that is NOT axis-aligned (the AABB outgrows the cube); `tf_axis`: translation + axis-aligned
+        # rotation, the transforms this repository's product accepts (tests/test_to_world.py holds the same two matrices)
+        if name in args.tf_cases and (args.tags is None or any(t.startswith('tf_') for t in args.tags)):
+            p0 = [0.01, -0.02, 0.015]
+            out['tf_p'] = np.asarray(p0, np.float64)
+            for key, T in transforms().items():
+                if args.tags is not None and key not in args.tags:
+                    continue
+                def make_sdf_t():
+                    s_ = Grid3d(mi.TensorXf(c['grid'][..., None]), transform=mi.ScalarTransform4f(T))
+                    s_.p = mi.Vector3f(*p0)
+                    return s_
+                sdf_t = make_sdf_t()
+                out[f'{key}_matrix'] = np.asarray(T, np.float64)
+                v, _, g, _, Hm = sdf_t.eval_all(mi.Point3f(pts[:, 0], pts[:, 1], pts[:, 2]))                 # python/shapes.py:438-450
+                out.update({f'{key}_eval_v': np.array(v), f'{key}_eval_g': cols(g, 3), f'{key}_eval_H': mat33(Hm, mi)})
+                wf_t = configs.get_config('warp').get_warpfield(sdf_t)
+                with dr.suspend_grad():
+                    its_t, warp_t, warp_t_d, ww, ww_d = sdf_t.ray_intersect(ray, warp=wf_t)                  # python/shapes.py:115
+                out.update({f'{key}_ri_its_t': np.array(its_t), f'{key}_ri_warp_t': np.array(warp_t), f'{key}_ri_warp_t_d': cols(warp_t_d, 3),
+                            f'{key}_ri_warp_weight': np.array(ww), f'{key}_ri_warp_weight_d': cols(ww_d, 3)})
+                for integ_name, tag in (('sdf_silhouette_reparam', 'sil'), ('sdf_simple_shading_reparam', 'shade')):
+                    scene = mi.load_dict({'type': 'scene', 'integrator': {'type': integ_name}, 'sensor': sensor,
+                                          'placeholder_sdf_shape': {'type': 'sphere', 'center': [100, 100, 100], 'radius': 1e-3,
+                                                                    'bsdf': {'type': 'diffuse'}}})
+                    integ = scene.integrator()
+                    integ.sdf = make_sdf_t()
+                    integ.warp_field = configs.get_config('warp').get_warpfield(integ.sdf)
+                    if len(inspect.signature(integ.sample).parameters) == 5:                                 # (see above: argument adapter)
+                        body = integ.sample
+                        integ.sample = lambda mode, scene_, sampler, ray_, dL, state_in, reparam, active, **kw: body(scene_, sampler, ray_, None, active)
+                    params = mi.traverse(scene)
+                    params.keep([SDF_DEFAULT_KEY, SDF_DEFAULT_KEY_P])
+                    for k in (SDF_DEFAULT_KEY, SDF_DEFAULT_KEY_P):
+                        dr.enable_grad(params[k])
+                    params.update()
+                    img = mi.render(scene, params=params, sensor=sensor, seed=seed, spp=spp, seed_grad=seed, spp_grad=spp)
+                    dr.backward(img * mi.TensorXf(c['grad_image']))
+                    ft = np.float64 if args.shim else np.float32
+                    out[f'{key}_img_{tag}'] = np.array(img)[..., :3].astype(ft)
+                    out[f'{key}_grad_{tag}'] = np.array(dr.grad(params[SDF_DEFAULT_KEY])).reshape(c['grid'].shape).astype(ft)
+                    out[f'{key}_gradp_{tag}'] = np.array(dr.grad(params[SDF_DEFAULT_KEY_P])).reshape(3).astype(ft)
 
         fn = os.path.join(args.out, f'{prefix}_{name}.npz')
         np.savez_compressed(fn, **out)

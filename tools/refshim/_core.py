@@ -853,7 +853,9 @@ class Ray3f(Struct):
         self.wavelengths = wavelengths if wavelengths is not None else Color3f(0.0)
 
     def __call__(self, t):
-        return fma(self.d, t, self.o) if isinstance(self.o, Point3f) else Point3f._wrap((self.d * t + self.o).v)
+        # Ray::operator()(t) returns a POINT (mitsuba/core/ray.h): Transform4f @ ray(t) must apply the translation (Grid3d.call_wrap,
+        # python/shapes.py:408-414, with a `to_world`)
+        return Point3f._wrap(fma(self.d, t, self.o).v)
 
     def scale_differential(self, s):
         pass
