@@ -71,6 +71,65 @@ def case_inputs(name):
                 albedo=albedo, env=tuple(float(np.float32(e)) for e in (1.0, 0.9, 0.8)))   # (fp32 values: what the C-ABI receives)
 
 
+def _plain(v):
+    """JSON form of a configuration attribute: numbers / strings as they are, callables and classes by name, arrays as lists."""
+    if v is None or isinstance(v, (bool, int, float, str)):
+        return v
+    if callable(v):
+        return getattr(v, '__name__', type(v).__name__)
+    if isinstance(v, (list, tuple)):
+        return [_plain(x) for x in v]
+    a = np.asarray(v.cpu() if hasattr(v, 'cpu') else v)
+    return a.tolist() if a.size <= 16 else {'shape': list(a.shape), 'sum': float(a.astype(np.float64).sum()), 'abs_sum': float(np.abs(a.astype(np.float64)).sum()),
+                                            'min': float(a.min()), 'max': float(a.max())}
+
+
+def sensor_record(s):
+    """(origin, fov) of a sensor: a Mitsuba / stand-in perspective sensor or this repository's dsdf.Sensor.  (The film size is not
+    part of the record: the reference builds every sensor at 128 x 128 and sets the render resolution per iteration from the
+    config's resx / resy / init_res -- set_sensor_res, python/util.py -- the mirror's sensors are built at the config's size.)"""
+    if hasattr(s, 'origin'):
+        return [float(x) for x in s.origin] + [float(s.fov)]
+    m = np.asarray(s.to_world.matrix if hasattr(s, 'to_world') else s.world_transform().matrix, np.float64).reshape(4, 4)
+    return [float(x) for x in m[:3, 3]] + [float(getattr(s, 'fov', 39.0))]
+
+
+def opt_config_record(c):
+    """Every attribute of a resolved opt-config (python/opt_configs.py: SceneConfig / SdfConfig and the Variable objects of
+    python/variables.py) in JSON form -- works on the reference's objects and on the mirror's."""
+    rec = {k: _plain(v) for k, v in vars(c).items() if k not in ('sensors', 'variables', 'device')}
+    rec['sensors'] = [sensor_record(s) for s in c.sensors]
+    rec['variables'] = [dict({k: _plain(v) for k, v in vars(var).items() if k != 'device'}, cls=type(var).__name__) for var in c.variables]
+    return rec
+
+
+def method_config_record(cfg):
+    rec = {k: _plain(v) for k, v in vars(cfg).items()}
+    wf = cfg.get_warpfield(None) if type(cfg).__name__.lower() not in ('finitedifferences',) else None
+    rec['warpfield'] = None if wf is None else dict({k: _plain(v) for k, v in vars(wf).items() if k in
+                                                      ('max_reparam_depth', 'edge_eps', 'weight_strategy', 'clamping_thresh', 'normalize_warp_field')},
+                                                     cls=type(wf).__name__)
+    return rec
+
+
+def config_table():
+    """All named opt-configs that need no scene file (82 of the 85: `torus-shadow-1`, `mirror-opt-1`, `mirror-opt-hq` read their
+    sensors from an XML scene, python/opt_configs.py:215-230) and all method configs whose warp field is on the path."""
+    import configs
+    import opt_configs
+    out = {'opt': {}, 'skipped': [], 'method': {}}
+    for name in opt_configs.SCENE_CONFIGS:
+        try:
+            c = opt_configs.get_opt_config(name)
+        except (AttributeError, FileNotFoundError, OSError) as e:
+            out['skipped'].append(name)
+            continue
+        out['opt'][name] = opt_config_record(c[0] if isinstance(c, tuple) else c)
+    for name in ('warp', 'warpprimary', 'warpnotnormalized', 'onlyshadinggrad', 'finitedifferences'):
+        out['method'][name] = method_config_record(configs.get_config(name))
+    return out
+
+
 def transforms():
     """The two `to_world` matrices of the transform fixtures (the same as tests/test_to_world.py: GENERAL, AXIS_ALIGNED): a rotation
     of the unit cube about its centre followed by a translation."""
@@ -114,6 +173,8 @@ def main():
     ap.add_argument('--out', default=os.path.join(ROOT, 'tests', 'golden'))
     ap.add_argument('--cases', nargs='*', default=['sphere16', 'blob32'])
     ap.add_argument('--tags', nargs='*', default=None, help='subset of the integrator runs (default: all)')
+    ap.add_argument('--config-table', action='store_true', help="dump python/opt_configs.py and python/configs.py (every named configuration, "
+                    "resolved) to <out>/<prefix>_config_table.json instead of the render fixtures")
     ap.add_argument('--tf-cases', nargs='*', default=['sphere16'], help='cases that also get the Grid3d(transform) section (slow on the stand-in)')
     args = ap.parse_args()
 
@@ -127,6 +188,13 @@ def main():
     from shapes import Grid3d                                       # python/shapes.py:375
     from constants import SDF_DEFAULT_KEY, SDF_DEFAULT_KEY_P        # python/constants.py:18-19
     prefix = 'refshim' if args.shim else 'ref'
+    if args.config_table:
+        import json
+        fn = os.path.join(args.out, f'{prefix}_config_table.json')
+        with open(fn, 'w') as f:
+            json.dump(config_table(), f, indent=0, sort_keys=True)
+        print(fn)
+        return
 
     for name in args.cases:
         c = case_inputs(name)

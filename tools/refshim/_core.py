@@ -616,9 +616,10 @@ def linspace(cls, a, b, n, endpoint=True):
     return cls._wrap(torch.as_tensor(np.linspace(float(a), float(b), int(n), endpoint=endpoint), dtype=FDT))
 
 
-def meshgrid(a, b):
-    x, y = torch.meshgrid(a.v, b.v, indexing='xy')
-    return Float._wrap(x.reshape(-1)), Float._wrap(y.reshape(-1))
+def meshgrid(*args, indexing='xy'):
+    """drjit.meshgrid: NumPy's semantics ('xy' cartesian by default, 'ij' matrix indexing), every output flattened."""
+    out = torch.meshgrid(*[a.v for a in args], indexing=indexing)
+    return tuple(type(a)._wrap(o.reshape(-1)) for a, o in zip(args, out))
 
 
 def log2i(x):

@@ -16,7 +16,7 @@ Mask = Bool
 Spectrum = Color3f
 UnpolarizedSpectrum = Color3f
 ScalarFloat = float
-ScalarPoint2u = ScalarVector2u = lambda *a: __import__('numpy').asarray(a if len(a) > 1 else a[0], 'int64')
+ScalarPoint2u = ScalarVector2u = ScalarPoint2i = ScalarVector2i = lambda *a: __import__('numpy').asarray(a if len(a) > 1 else a[0], 'int64')
 _variant = ['llvm_ad_rgb']
 
 
