@@ -40,6 +40,14 @@
 
 using namespace dsdf;
 
+#if DSDF_XF
+// the transform of an XF build (csrc/dsdf_math.h): device copy for the kernels, host copy for the host-side uses of the same inline functions
+namespace dsdf {
+__constant__ XfState g_xf_dev;
+XfState g_xf_host = {{1.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 1.f}, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, {1.f, 1.f, 1.f}};
+}
+#endif
+
 #define DSDF_BLOCK 256    /* threads per block of the general (any spp) render pass */
 #define DSDF_TSTRIDE 68   /* 64 + 4: rows 16-byte aligned, ds_read_b128 conflict-free across lanes */
 #define DSDF_TROWS 13     /* film transpose processes the 25 window slots in two chunks of <= 13 rows */
@@ -1093,6 +1101,9 @@ static PassCtx make_ctx(const float *padded, int rx, int ry, int rz, const dsdf_
     PassCtx c;
     c.padded = padded; c.rx = rx; c.ry = ry; c.rz = rz; c.prm = prm; c.pp = pass_params(*prm, integrator);
     c.W = W; c.H = H; c.spp = spp; c.integrator = integrator; c.flags = flags; c.direct = integrator == DSDF_DIRECT;
+#if DSDF_XF
+    c.flags |= DSDF_NO_SKIP | DSDF_NO_HIT_PROOF;        // the per-pixel proofs reason in the cube's own frame: not in a world-space build
+#endif
     c.offsets = offsets; c.seeds = seeds; c.shading = shading; c.emitter_u = c.direct ? shading->emitter_samples : nullptr;
     c.bsdf_u = (c.direct && shading->use_mis) ? shading->bsdf_samples : nullptr;
     c.Wb = W + 2 * DSDF_BORDER; c.Hb = H + 2 * DSDF_BORDER; c.nl = (uint32_t)(c.Wb * c.Hb * spp);
@@ -1696,6 +1707,32 @@ int dsdf_grad_backward(const float *padded, int rx, int ry, int rz, const dsdf_p
 }  // extern "C"
 
 extern "C" {
+
+int dsdf_has_grid_transform(void) { return DSDF_XF; }
+
+int dsdf_set_grid_transform(const float *to_local, const float *aabb_lo, const float *aabb_hi, void *stream) {
+#if DSDF_XF
+    if (!to_local || !aabb_lo || !aabb_hi) return fail(DSDF_ERR_INVALID_ARG, "dsdf_set_grid_transform: null pointer argument");
+    // (source of an asynchronous copy from pageable memory: a slot of a small ring, not the stack)
+    static thread_local XfState ring[32];
+    static thread_local unsigned next = 0;
+    XfState &st = ring[next++ % 32u];
+    for (int r = 0; r < 3; ++r) {
+        for (int c = 0; c < 3; ++c) st.A[3 * r + c] = to_local[4 * r + c];
+        st.b[r] = to_local[4 * r + 3];
+        st.lo[r] = aabb_lo[r]; st.hi[r] = aabb_hi[r];
+        if (!(aabb_lo[r] < aabb_hi[r])) return fail(DSDF_ERR_INVALID_ARG, "dsdf_set_grid_transform: empty bounding box");
+    }
+    g_xf_host = st;
+    // (stream-ordered like every launch of the library: calls enqueued before it keep the transform they were enqueued with)
+    if (hipMemcpyToSymbolAsync(HIP_SYMBOL(g_xf_dev), &st, sizeof(st), 0, hipMemcpyHostToDevice, (hipStream_t)stream) != hipSuccess)
+        return fail(DSDF_ERR_LAUNCH, "dsdf_set_grid_transform: hipMemcpyToSymbolAsync failed");
+    return DSDF_OK;
+#else
+    (void)to_local; (void)aabb_lo; (void)aabb_hi; (void)stream;
+    return fail(DSDF_ERR_INVALID_ARG, "dsdf_set_grid_transform: this build has no general transform (lib/variants/libdsdf_xf.so, -DDSDF_XF=1, has)");
+#endif
+}
 
 int dsdf_share_pixel_skip(void *buffer, size_t bytes) {
     SkipShare &sh = t_share;

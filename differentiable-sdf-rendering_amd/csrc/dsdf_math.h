@@ -112,6 +112,73 @@ DSDF_HD void bspline_ddw(float a, float w[4]) {
     w[0] = 1.f - a; w[1] = 3.f * a - 2.f; w[2] = 1.f - 3.f * a; w[3] = a;
 }
 
+// ---------------------------------------------------------------------------
+// General `Grid3d(data, transform)` (shapes.py:378-450) -- ONLY in builds with -DDSDF_XF=1 (the default library and its kernels
+// contain none of it: the hooks below compile to the statements they replace).  The reference keeps rays, positions and the
+// traced box in WORLD space and goes through `to_local @ (x - p)` for every texture lookup, bringing gradients back through
+// to_local3^T and Hessians through to_local3^T H to_local3 (:408-450); its box is the world AABB of the transformed cube
+// (:393-403, 416-418).  An XF build does exactly that:
+//   to_grid(G, x)          A (x - p) + b                       (cubic_setup / cubic_cell: position -> texture coordinates)
+//   eval_cubic_rows        g <- A^T g,  H <- A^T H A           (every lookup's outputs are world-space derivatives)
+//   scatter                cg <- A cg                          (adjoint of g_world = A^T g_local)
+//   box_lo / box_hi        aabb -+ delta per axis              (instead of -delta, 1 + delta)
+// The transform is library state of such a build (DSDF_XF_STATE: a __constant__ block on the device, a global in the host build).
+// ---------------------------------------------------------------------------
+#ifndef DSDF_XF
+#define DSDF_XF 0
+#endif
+#if DSDF_XF
+struct XfState { float A[9], b[3], lo[3], hi[3]; };          // to_local (row-major 3x3 + translation), world AABB of the cube
+#if defined(__HIP_DEVICE_COMPILE__)
+extern __constant__ XfState g_xf_dev;
+#define DSDF_XF_STATE g_xf_dev
+#else
+extern XfState g_xf_host;
+#define DSDF_XF_STATE g_xf_host
+#endif
+DSDF_HD V3 xf_apply(V3 q) {                                     // to_local3 q
+    const XfState &s = DSDF_XF_STATE;
+    return mk(s.A[0] * q.x + s.A[1] * q.y + s.A[2] * q.z, s.A[3] * q.x + s.A[4] * q.y + s.A[5] * q.z, s.A[6] * q.x + s.A[7] * q.y + s.A[8] * q.z);
+}
+DSDF_HD V3 xf_apply_t(V3 q) {                                   // to_local3^T q
+    const XfState &s = DSDF_XF_STATE;
+    return mk(s.A[0] * q.x + s.A[3] * q.y + s.A[6] * q.z, s.A[1] * q.x + s.A[4] * q.y + s.A[7] * q.z, s.A[2] * q.x + s.A[5] * q.y + s.A[8] * q.z);
+}
+DSDF_HD V3 xf_col(int j) { const XfState &s = DSDF_XF_STATE; return mk(s.A[j], s.A[3 + j], s.A[6 + j]); }   // column j of to_local3
+typedef V3 BoxBound;
+DSDF_HD BoxBound box_lo(const dsdf_params &P) { const XfState &s = DSDF_XF_STATE; return mk(s.lo[0] - P.bbox_delta, s.lo[1] - P.bbox_delta, s.lo[2] - P.bbox_delta); }
+DSDF_HD BoxBound box_hi(const dsdf_params &P) { const XfState &s = DSDF_XF_STATE; return mk(s.hi[0] + P.bbox_delta, s.hi[1] + P.bbox_delta, s.hi[2] + P.bbox_delta); }
+#else
+typedef float BoxBound;
+DSDF_HD BoxBound box_lo(const dsdf_params &P) { return -P.bbox_delta; }
+DSDF_HD BoxBound box_hi(const dsdf_params &P) { return 1.f + P.bbox_delta; }
+#endif
+// per-axis view of a box bound: the same scalar three times for the unit cube, a component of the world AABB in an XF build
+DSDF_HD float bx(float b) { return b; }
+DSDF_HD float by(float b) { return b; }
+DSDF_HD float bz(float b) { return b; }
+DSDF_HD float bx(V3 b) { return b.x; }
+DSDF_HD float by(V3 b) { return b.y; }
+DSDF_HD float bz(V3 b) { return b.z; }
+// position -> the frame of the texture: x - p, or to_local @ (x - p) (shapes.py:412)
+DSDF_HD V3 to_grid(const GridView &G, V3 x) {
+    V3 q = mk(x.x - G.tx, x.y - G.ty, x.z - G.tz);
+#if DSDF_XF
+    const XfState &s = DSDF_XF_STATE;
+    q = xf_apply(q) + mk(s.b[0], s.b[1], s.b[2]);
+#endif
+    return q;
+}
+
+// adjoint of g_world = to_local3^T g_local: the gradient coefficient of a scatter request goes to the texture frame with to_local3
+DSDF_HD V3 grad_coef_to_grid(V3 cg) {
+#if DSDF_XF
+    return xf_apply(cg);
+#else
+    return cg;
+#endif
+}
+
 struct CubicSetup {
     int ix, iy, iz;      // unclamped base tap index (floor(pf) - 1)
     float ax, ay, az;    // fractional offsets
@@ -127,9 +194,10 @@ DSDF_HD int iclamp(int v, int lo, int hi) {
 
 DSDF_HD CubicSetup cubic_setup(const GridView &G, V3 x) {
     // pf = (x - p) * res - 0.5 ; shapes.py:412 + Dr.Jit texel-centre convention
-    float pfx = fmaf(x.x - G.tx, G.frx, -0.5f);
-    float pfy = fmaf(x.y - G.ty, G.fry, -0.5f);
-    float pfz = fmaf(x.z - G.tz, G.frz, -0.5f);
+    const V3 q = to_grid(G, x);
+    float pfx = fmaf(q.x, G.frx, -0.5f);
+    float pfy = fmaf(q.y, G.fry, -0.5f);
+    float pfz = fmaf(q.z, G.frz, -0.5f);
     float fx = floorf(pfx), fy = floorf(pfy), fz = floorf(pfz);
     CubicSetup s;
     s.ax = pfx - fx; s.ay = pfy - fy; s.az = pfz - fz;
@@ -161,7 +229,8 @@ DSDF_HD CubicCell cubic_cell(const GridView &G, V3 x) {
     // swallowed like before) + an integer med3, and v_fract_f32 for the offset: 3 instead of 4 instructions per axis.  v_fract
     // returns x - floor(x) clamped below 1, which differs from the subtraction only for |x| < 2^-25 below an integer
     // (0.99999994 instead of 1.0 in the cell below -- the same spline value to 1e-7).
-    const float pfx = fmaf(x.x - G.tx, G.frx, -0.5f), pfy = fmaf(x.y - G.ty, G.fry, -0.5f), pfz = fmaf(x.z - G.tz, G.frz, -0.5f);
+    const V3 q = to_grid(G, x);
+    const float pfx = fmaf(q.x, G.frx, -0.5f), pfy = fmaf(q.y, G.fry, -0.5f), pfz = fmaf(q.z, G.frz, -0.5f);
     CubicCell cc;
     cc.ax = __builtin_amdgcn_fractf(pfx); cc.ay = __builtin_amdgcn_fractf(pfy); cc.az = __builtin_amdgcn_fractf(pfz);
     int qx, qy, qz;
@@ -287,6 +356,15 @@ DSDF_HD void eval_cubic_rows(const GridView &G, const CubicCell &c, const Rows &
         H[0] = axx * fx * fx; H[1] = ayy * fy * fy; H[2] = azz * fz * fz;
         H[3] = axy * fx * fy; H[4] = axz * fx * fz; H[5] = ayz * fy * fz;
     }
+#if DSDF_XF
+    // shapes.py:426-427, 445-448: gradient through to_local3^T, Hessian through to_local3^T H to_local3
+    if (ORDER >= 2) {
+        // column j of A^T H A is A^T (H col_j(A))
+        const V3 c0 = xf_apply_t(symmul(H, xf_col(0))), c1 = xf_apply_t(symmul(H, xf_col(1))), c2 = xf_apply_t(symmul(H, xf_col(2)));
+        H[0] = c0.x; H[1] = c1.y; H[2] = c2.z; H[3] = c1.x; H[4] = c2.x; H[5] = c2.y;
+    }
+    g = xf_apply_t(g);
+#endif
 }
 
 template <int ORDER>
@@ -364,6 +442,7 @@ DSDF_HD void scatter_cubic(const GridView &G, float *grad, V3 x, float cv, V3 cg
     float wx[4], wy[4], wz[4], dwx[4], dwy[4], dwz[4];
     bspline_w(s.ax, wx); bspline_w(s.ay, wy); bspline_w(s.az, wz);
     bspline_dw(s.ax, dwx); bspline_dw(s.ay, dwy); bspline_dw(s.az, dwz);
+    cg = grad_coef_to_grid(cg);
     float gx = cg.x * G.frx, gy = cg.y * G.fry, gz = cg.z * G.frz;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -397,12 +476,13 @@ DSDF_HD V3 closest_axis(V3 m) {
     return n;
 }
 
-DSDF_HD float bbox_distance_inside_d(V3 x, float lo, float hi, V3 &dd) {
-    float mlo = fminf(fminf(x.x - lo, x.y - lo), x.z - lo);
-    float mhi = fminf(fminf(hi - x.x, hi - x.y), hi - x.z);
+template <class B>      // B: float (the unit cube -+ delta) or V3 (per-axis bounds: the world AABB of an XF build)
+DSDF_HD float bbox_distance_inside_d(V3 x, B lo, B hi, V3 &dd) {
+    float mlo = fminf(fminf(x.x - bx(lo), x.y - by(lo)), x.z - bz(lo));
+    float mhi = fminf(fminf(bx(hi) - x.x, by(hi) - x.y), bz(hi) - x.z);
     float dist = fmaxf(0.f, fminf(mlo, mhi));
-    V3 dmax = mk(fabsf(hi - x.x), fabsf(hi - x.y), fabsf(hi - x.z));
-    V3 dmin = mk(fabsf(lo - x.x), fabsf(lo - x.y), fabsf(lo - x.z));
+    V3 dmax = mk(fabsf(bx(hi) - x.x), fabsf(by(hi) - x.y), fabsf(bz(hi) - x.z));
+    V3 dmin = mk(fabsf(bx(lo) - x.x), fabsf(by(lo) - x.y), fabsf(bz(lo) - x.z));
     V3 n = closest_axis(mk(fminf(dmin.x, dmax.x), fminf(dmin.y, dmax.y), fminf(dmin.z, dmax.z)));
     if (dist > 0.f)
         dd = mk(n.x * drsign(dmax.x - dmin.x), n.y * drsign(dmax.y - dmin.y), n.z * drsign(dmax.z - dmin.z));
@@ -413,25 +493,33 @@ DSDF_HD float bbox_distance_inside_d(V3 x, float lo, float hi, V3 &dd) {
 
 struct BoxHit { bool hit, inside; float mint, maxt; };
 
-DSDF_HD BoxHit bbox_ray_intersect(float lo, float hi, V3 o, V3 d) {
+template <class B>
+DSDF_HD BoxHit bbox_ray_intersect(B lo, B hi, V3 o, V3 d) {
     BoxHit b;
-    bool ok = (d.x != 0.f || o.x > lo || o.x < hi) && (d.y != 0.f || o.y > lo || o.y < hi) &&
-              (d.z != 0.f || o.z > lo || o.z < hi);
+    bool ok = (d.x != 0.f || o.x > bx(lo) || o.x < bx(hi)) && (d.y != 0.f || o.y > by(lo) || o.y < by(hi)) &&
+              (d.z != 0.f || o.z > bz(lo) || o.z < bz(hi));
     float rx = rcpf(d.x), ry = rcpf(d.y), rz = rcpf(d.z);
-    float t1x = (lo - o.x) * rx, t2x = (hi - o.x) * rx;
-    float t1y = (lo - o.y) * ry, t2y = (hi - o.y) * ry;
-    float t1z = (lo - o.z) * rz, t2z = (hi - o.z) * rz;
+    float t1x = (bx(lo) - o.x) * rx, t2x = (bx(hi) - o.x) * rx;
+    float t1y = (by(lo) - o.y) * ry, t2y = (by(hi) - o.y) * ry;
+    float t1z = (bz(lo) - o.z) * rz, t2z = (bz(hi) - o.z) * rz;
     b.mint = fmaxf(fmaxf(fminf(t1x, t2x), fminf(t1y, t2y)), fminf(t1z, t2z));
     b.maxt = fminf(fminf(fmaxf(t1x, t2x), fmaxf(t1y, t2y)), fmaxf(t1z, t2z));
     b.hit = ok && (b.maxt >= b.mint);
-    b.inside = o.x >= lo && o.x <= hi && o.y >= lo && o.y <= hi && o.z >= lo && o.z <= hi;
+    b.inside = o.x >= bx(lo) && o.x <= bx(hi) && o.y >= by(lo) && o.y <= by(hi) && o.z >= bz(lo) && o.z <= bz(hi);
     return b;
+}
+// distance of a point on the box surface to the nearest face, per axis (shapes.py:156-157)
+template <class B>
+DSDF_HD V3 box_face_distance(B lo, B hi, V3 pb) {
+    return mk(fminf(fabsf(bx(lo) - pb.x), fabsf(bx(hi) - pb.x)), fminf(fabsf(by(lo) - pb.y), fabsf(by(hi) - pb.y)),
+              fminf(fabsf(bz(lo) - pb.z), fabsf(bz(hi) - pb.z)));
 }
 
 // ---------------------------------------------------------------------------
 // A3: SDFBase.eval_trace_weight (shapes.py:68-113), analytic-gradient branch.
 // ---------------------------------------------------------------------------
-DSDF_HD float eval_trace_weight(const dsdf_params &P, V3 d, int i, float lo, float hi, V3 x,
+template <class B>
+DSDF_HD float eval_trace_weight(const dsdf_params &P, V3 d, int i, B lo, B hi, V3 x,
                                 float v, V3 g, const float H[6], V3 &weight_d) {
     float n_dot_d = dot(g, d);
     float n_dot_n = dot(g, g);
@@ -487,7 +575,7 @@ DSDF_HD PlainMarch plain_march_begin(const dsdf_params &P, V3 o, V3 d_in, float 
     float inv = rsqf(dot(d_in, d_in));
     m.o = o;
     m.d = d_in * inv;
-    float lo = -P.bbox_delta, hi = 1.f + P.bbox_delta;
+    const BoxBound lo = box_lo(P), hi = box_hi(P);
     BoxHit b = bbox_ray_intersect(lo, hi, o, m.d);
     m.active = b.hit && (b.mint > 0.f || b.inside);
     m.maxt = fminf(b.maxt, ray_maxt);
@@ -545,7 +633,7 @@ template <class Fetch, class Ctl>
 DSDF_HD void trace_diff(const GridView &G, const dsdf_params &P, V3 o, V3 d_in, float ray_maxt, TraceOut &out, Fetch &F, Ctl &C) {
     float invn = rsqf(dot(d_in, d_in));
     V3 d = d_in * invn;                                              // :124
-    float lo = -P.bbox_delta, hi = 1.f + P.bbox_delta;
+    const BoxBound lo = box_lo(P), hi = box_hi(P);
     BoxHit b = bbox_ray_intersect(lo, hi, o, d);
     bool hit_box = b.hit && (b.mint > 0.f || b.inside);              // :132
     bool active = hit_box;
@@ -558,8 +646,7 @@ DSDF_HD void trace_diff(const GridView &G, const dsdf_params &P, V3 o, V3 d_in, 
     int i = 0;
     // entry-face derivative of t (:156-164)
     V3 pb = fma3(t, d, o);
-    V3 n = closest_axis(mk(fminf(fabsf(lo - pb.x), fabsf(hi - pb.x)), fminf(fabsf(lo - pb.y), fabsf(hi - pb.y)),
-                           fminf(fabsf(lo - pb.z), fabsf(hi - pb.z))));
+    V3 n = closest_axis(box_face_distance(lo, hi, pb));
     float ddn = dot(d, n);
     V3 t_d = mk(0.f, 0.f, 0.f);
     if (!b.inside && fabsf(ddn) > 0.f) t_d = n * (-t / ddn);
@@ -645,7 +732,7 @@ DSDF_HD DiffMarch diff_march_begin(const dsdf_params &P, V3 o, V3 d_in, float ra
     float invn = rsqf(dot(d_in, d_in));
     m.o = o;
     m.d = d_in * invn;                                               // :124
-    float lo = -P.bbox_delta, hi = 1.f + P.bbox_delta;
+    const BoxBound lo = box_lo(P), hi = box_hi(P);
     BoxHit b = bbox_ray_intersect(lo, hi, o, m.d);
     m.hit_box = b.hit && (b.mint > 0.f || b.inside);                 // :132
     m.active = m.hit_box;
@@ -658,8 +745,7 @@ DSDF_HD DiffMarch diff_march_begin(const dsdf_params &P, V3 o, V3 d_in, float ra
     m.i = 0;
     // entry-face derivative of t (:156-164)
     V3 pb = fma3(m.t, m.d, o);
-    V3 n = closest_axis(mk(fminf(fabsf(lo - pb.x), fabsf(hi - pb.x)), fminf(fabsf(lo - pb.y), fabsf(hi - pb.y)),
-                           fminf(fabsf(lo - pb.z), fabsf(hi - pb.z))));
+    V3 n = closest_axis(box_face_distance(lo, hi, pb));
     float ddn = dot(m.d, n);
     m.t_d = mk(0.f, 0.f, 0.f);
     if (!b.inside && fabsf(ddn) > 0.f) m.t_d = n * (-m.t / ddn);
@@ -668,7 +754,7 @@ DSDF_HD DiffMarch diff_march_begin(const dsdf_params &P, V3 o, V3 d_in, float ra
 
 // consumes value / gradient / Hessian of the SDF at x = o + t d of an active march
 DSDF_HD void diff_march_step(const dsdf_params &P, DiffMarch &m, V3 x, float v, V3 g, const float H[6]) {
-    const float lo = -P.bbox_delta, hi = 1.f + P.bbox_delta;
+    const BoxBound lo = box_lo(P), hi = box_hi(P);
     const V3 d = m.d;
     const float t = m.t;
     bool hit = v < m.trace_eps;                                      // :185
@@ -1010,7 +1096,7 @@ DSDF_HD bool warp_weight_positive(const GridView &G, const dsdf_params &P, V3 o,
     float v = eval_value(G, x);
     float edge_eps = (P.weight_strategy == 6) ? P.edge_eps * t : P.edge_eps;
     V3 bd_d;
-    float bd = bbox_distance_inside_d(x, -P.bbox_delta, 1.f + P.bbox_delta, bd_d);
+    float bd = bbox_distance_inside_d(x, box_lo(P), box_hi(P), bd_d);
     float eps = fminf(edge_eps, bd);
     float fac = 1.f - fabsf(v) * (1.f / eps);
     return fmaxf(fac, 0.f) * tr.warp_weight > 0.f;
@@ -1021,7 +1107,7 @@ struct WarpCoef { V3 cdir; float a; V3 b; float div; V3 g; float H[6]; };   // g
 DSDF_HD bool warp_coefficients(const GridView &G, const dsdf_params &P, V3 o, V3 d, const TraceOut &tr, WarpCoef &wc) {
     float t = tr.warp_t;
     if (!(fabsf(t) < INFINITY)) return false;                        // warp.py:52 (NaN fails too)
-    float lo = -P.bbox_delta, hi = 1.f + P.bbox_delta;
+    const BoxBound lo = box_lo(P), hi = box_hi(P);
     V3 x = fma3(t, d, o);
     float v; V3 g; float H[6];
     eval_cubic<2>(G, x, v, g, H);

@@ -71,7 +71,8 @@ __device__ __forceinline__ void wave_scatter_t(const GridView &G, float *__restr
         float wx[4], wy[4], wz[4], dwx[4], dwy[4], dwz[4];
         bspline_w(s.ax, wx); bspline_w(s.ay, wy); bspline_w(s.az, wz);
         bspline_dw(s.ax, dwx); bspline_dw(s.ay, dwy); bspline_dw(s.az, dwz);
-        const float gx = rq.cg.x * G.frx, gy = rq.cg.y * G.fry, gz = rq.cg.z * G.frz;
+        const V3 cgl = grad_coef_to_grid(rq.cg);
+        const float gx = cgl.x * G.frx, gy = cgl.y * G.fry, gz = cgl.z * G.frz;
         float4 *row = reinterpret_cast<float4 *>(T + lid * DSDF_SCAT_STRIDE);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -127,7 +128,8 @@ __device__ __forceinline__ void wave_scatter_half(const GridView &G, float *__re
     float wx[4], wy[4], wz[4], dwx[4], dwy[4], dwz[4];
     bspline_w(s.ax, wx); bspline_w(s.ay, wy); bspline_w(s.az, wz);
     bspline_dw(s.ax, dwx); bspline_dw(s.ay, dwy); bspline_dw(s.az, dwz);
-    const float gx = rq.cg.x * G.frx, gy = rq.cg.y * G.fry, gz = rq.cg.z * G.frz;
+    const V3 cgl = grad_coef_to_grid(rq.cg);
+    const float gx = cgl.x * G.frx, gy = cgl.y * G.fry, gz = cgl.z * G.frz;
     const uint64_t key = ((uint64_t)(uint32_t)(bz + DSDF_APRON) << 42) | ((uint64_t)(uint32_t)(by + DSDF_APRON) << 21) | (uint64_t)(uint32_t)(bx + DSDF_APRON);
     const uint32_t klo = (uint32_t)key, khi = (uint32_t)(key >> 32);
     const int tk = lid >> 4, tj = (lid >> 2) & 3, ti = lid & 3;          // (lanes 0..31: tk in {0, 1})

@@ -79,6 +79,8 @@ SYMBOLS = {
     'dsdf_render_film': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(DsdfParams), C.POINTER(DsdfCamera), C.c_int, C.c_int,
                                    C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_uint32), C.c_int, C.c_int, C.POINTER(DsdfShading), C.c_int,
                                    C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
+    'dsdf_has_grid_transform': (C.c_int, []),
+    'dsdf_set_grid_transform': (C.c_int, [C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_void_p]),
     'dsdf_sampler_2d': (C.c_int, [C.POINTER(C.c_uint32), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     'dsdf_aov_workspace_size': (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     'dsdf_render_aovs': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(DsdfParams), C.POINTER(DsdfCamera), C.c_int, C.c_int,
@@ -102,32 +104,50 @@ SYMBOLS = {
 }
 
 
-def load():
-    """Loads libdsdf.so once; raises DsdfError if the HIP extension is absent."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.isfile(LIB_PATH):
-        raise DsdfError(f"HIP extension not built: {LIB_PATH} is missing "
+def _open(path):
+    if not os.path.isfile(path):
+        raise DsdfError(f"HIP extension not built: {path} is missing "
                         f"(run `python -c 'import __graft_entry__ as g; g.build()'`). No CPU fallback exists.")
     try:
-        lib = C.CDLL(LIB_PATH)
+        lib = C.CDLL(path)
     except OSError as e:
-        raise DsdfError(f"cannot load {LIB_PATH}: {e}") from e
+        raise DsdfError(f"cannot load {path}: {e}") from e
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
     if lib.dsdf_version() != ABI_VERSION:                # a stale .so would read the structs above with another layout
-        raise DsdfError(f"{LIB_PATH} is version {lib.dsdf_version()}, the binding expects {ABI_VERSION}: rebuild "
+        raise DsdfError(f"{path} is version {lib.dsdf_version()}, the binding expects {ABI_VERSION}: rebuild "
                         f"(`python -c 'import __graft_entry__ as g; g.build()'`)")
-    _lib = lib
     return lib
 
 
-def check(rc):
+def load():
+    """Loads libdsdf.so once; raises DsdfError if the HIP extension is absent."""
+    global _lib
+    if _lib is None:
+        _lib = _open(LIB_PATH)
+    return _lib
+
+
+_variants = {}
+XF_LIB_PATH = os.path.normpath(os.path.join(_HERE, '..', '..', 'lib', 'variants', 'libdsdf_xf.so'))
+
+
+def load_xf():
+    """The WORLD-SPACE build of the same sources (lib/variants/libdsdf_xf.so, -DDSDF_XF=1) that serves a general
+    `Grid3d(data, transform)` (include/dsdf.h: dsdf_set_grid_transform)."""
+    if 'xf' not in _variants:
+        lib = _open(XF_LIB_PATH)
+        if not lib.dsdf_has_grid_transform():
+            raise DsdfError(f"{XF_LIB_PATH} was not built with -DDSDF_XF=1")
+        _variants['xf'] = lib
+    return _variants['xf']
+
+
+def check(rc, lib=None):
     if rc != 0:
-        raise DsdfError(f"libdsdf error {rc}: {load().dsdf_last_error().decode()}")
+        raise DsdfError(f"libdsdf error {rc}: {(lib or load()).dsdf_last_error().decode()}")
 
 
 def default_params():

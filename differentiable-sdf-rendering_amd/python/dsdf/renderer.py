@@ -90,10 +90,38 @@ class SdfGrid:
     Mirrors what `Grid3d.__init__/update/parameters_changed` do with the Dr.Jit
     texture (python/shapes.py:378-403, 473-479)."""
 
-    def __init__(self, data, params=None):
+    def __init__(self, data, params=None, to_world=None):
         self.params = params if params is not None else _lib.default_params()
         self.padded = None
+        self.transform = None
+        if to_world is not None:
+            self.set_to_world(to_world)
         self.update(data)
+
+    def set_to_world(self, to_world):
+        """A GENERAL `to_world` (4x4, affine: any rotation, scale) for this grid (python/shapes.py:378-403): its calls go to the
+        world-space build of the library (lib/variants/libdsdf_xf.so, include/dsdf.h: dsdf_set_grid_transform) with
+        to_local = to_world^-1 and the world AABB of the transformed cube; rays, sensors and `sdf.p` stay in world space."""
+        import numpy as np
+        tw = np.asarray(to_world, np.float64).reshape(4, 4)
+        if not np.allclose(tw[3], [0, 0, 0, 1], atol=1e-12):
+            raise _lib.DsdfError("to_world must be affine")
+        inv = np.linalg.inv(tw)
+        corners = np.array([[x, y, z] for x in (0.0, 1.0) for y in (0.0, 1.0) for z in (0.0, 1.0)])
+        w = corners @ tw[:3, :3].T + tw[:3, 3]
+        f = lambda a: (C.c_float * len(a))(*[float(v) for v in a])
+        self.transform = (f(inv[:3, :].reshape(-1)), f(w.min(0)), f(w.max(0)))
+        return self
+
+    def lib(self):
+        """The library this grid's calls go to; for a grid with a general transform the world-space build, with the transform
+        (re-)applied in stream order (it is state of that library instance)."""
+        if self.transform is None:
+            return _lib.load()
+        lib = _lib.load_xf()
+        with torch.cuda.device(self.device):
+            _lib.check(lib.dsdf_set_grid_transform(self.transform[0], self.transform[1], self.transform[2], _stream()), lib)
+        return lib
 
     def update(self, data):
         lib = _lib.load()
@@ -233,7 +261,7 @@ def _shading_arg(integrator, shading, n_views, n_lanes, emitter_samples=None, gr
 
 def eval_cubic(grid, points, order=2):
     """A1. points (n,3) -> v (n,), g (n,3), H (n,6: xx,yy,zz,xy,xz,yz)."""
-    lib = _lib.load()
+    lib = grid.lib()
     points = _require_dev(points, 'points')
     n = points.shape[0]
     dev = points.device
@@ -248,7 +276,7 @@ def eval_cubic(grid, points, order=2):
 
 def trace(grid, rays_o, rays_d, maxt, differentiable=True):
     """A2/A4/A5: per-ray sphere tracing. Returns dict of per-ray outputs."""
-    lib = _lib.load()
+    lib = grid.lib()
     rays_o = _require_dev(rays_o, 'rays_o'); rays_d = _require_dev(rays_d, 'rays_d'); maxt = _require_dev(maxt, 'maxt')
     n = rays_o.shape[0]
     dev = rays_o.device
@@ -266,7 +294,7 @@ def trace(grid, rays_o, rays_d, maxt, differentiable=True):
 def warp_eval(grid, rays_o, rays_d, trace_out):
     """A9 per ray: `WarpField2D.eval` (python/warp.py:47-96) as its linearisation in (v, g) at x = o + warp_t d.
     trace_out: the dict returned by trace(..., differentiable=True).  Returns dict(active, cdir, a, b, div)."""
-    lib = _lib.load()
+    lib = grid.lib()
     rays_o = _require_dev(rays_o, 'rays_o'); rays_d = _require_dev(rays_d, 'rays_d')
     n = rays_o.shape[0]
     dev = rays_o.device
@@ -282,7 +310,7 @@ def warp_eval(grid, rays_o, rays_d, trace_out):
 
 def surface_interaction(grid, rays_o, rays_d, t):
     """A6 per ray: `SDFBase.compute_surface_interaction` (python/shapes.py:347-366) -> dict(p, n, grad, t_coef)."""
-    lib = _lib.load()
+    lib = grid.lib()
     rays_o = _require_dev(rays_o, 'rays_o'); rays_d = _require_dev(rays_d, 'rays_d'); t = _require_dev(t, 't')
     n = rays_o.shape[0]
     dev = rays_o.device
@@ -344,7 +372,7 @@ def render_forward(grid, sensors, spp, seeds=None, offsets=None, integrator=DSDF
                    empty_space_skip=True, shading=None, emitter_samples=None, bsdf_samples=None):
     """`ReparamIntegrator.render` for a batch of views -> (n_views, H, W, 3).  `shading` (dsdf.Shading) and the
     optional per-lane `emitter_samples` belong to sdf_direct_reparam."""
-    lib = _lib.load()
+    lib = grid.lib()
     sensors, cams, W, H = _views(sensors)
     nv = len(sensors)
     n_lanes = (W + 4) * (H + 4) * int(spp)
@@ -370,7 +398,7 @@ def render_aovs(grid, sensors, spp, seeds=None, offsets=None):
     """The debug channels of `use_aovs` + `WarpField2D.return_aovs` (python/integrators/reparam.py:160-165, 263-267) for a batch of
     views -> (n_views, H, W, 11) in the order of AOV_NAMES.  The reference writes two of them, the loop state of the primary
     ray's differentiable trace (`i`, `weight_sum`: python/shapes.py:240-242; dsdf_render_aovs); the other nine are zero there too."""
-    lib = _lib.load()
+    lib = grid.lib()
     sensors, cams, W, H = _views(sensors)
     nv = len(sensors)
     n_lanes = (W + 4) * (H + 4) * int(spp)
@@ -393,7 +421,7 @@ def render_backward(grid, sensors, spp, grad_image, grad_grid=None, seeds=None, 
     """`ReparamIntegrator.render_backward`: accumulates dL/dsdf into grad_grid (Z,Y,X) and, if given,
     dL/d(sdf.p) into grad_p (3 floats on the device; `sdf.p`, python/shapes.py:471) and, for
     sdf_direct_reparam, dL/d(albedo) into grad_albedo (shaped like shading.albedo)."""
-    lib = _lib.load()
+    lib = grid.lib()
     sensors, cams, W, H = _views(sensors)
     nv = len(sensors)
     n_lanes = (W + 4) * (H + 4) * int(spp)
@@ -431,7 +459,7 @@ def render_forward_grad(grid, sensors, spp, tangent_data=None, tangent_p=None, s
                         emitter_samples=None, bsdf_samples=None):
     """`ReparamIntegrator.render_forward` (python/integrators/reparam.py:192-196): forward-mode gradient image(s)
     (n_views,H,W,3) for a tangent on sdf.data (tensor shaped like the grid) and / or on sdf.p (3 floats)."""
-    lib = _lib.load()
+    lib = grid.lib()
     sensors, cams, W, H = _views(sensors)
     nv = len(sensors)
     n_lanes = (W + 4) * (H + 4) * int(spp)
@@ -476,7 +504,7 @@ def new_film(n_views, W, H, integrator, device):
 def render_film(grid, sensors, spp, film, rows, seeds=None, offsets=None, integrator=DSDF_SILHOUETTE, reparam=True,
                 empty_space_skip=True, shading=None, emitter_samples=None, stats=None):
     """Primal samples of the film-block rows [rows[0], rows[1]) of every view, ACCUMULATED into `film`."""
-    lib = _lib.load()
+    lib = grid.lib()
     sensors, cams, W, H = _views(sensors)
     nv = len(sensors)
     n_lanes = (W + 4) * (H + 4) * int(spp)
@@ -522,7 +550,7 @@ class GradSweep:
 
     def __init__(self, grid, sensors, spp, rows, seeds=None, offsets=None, integrator=DSDF_SILHOUETTE, reparam=True,
                  empty_space_skip=True, shading=None, emitter_samples=None, grad_albedo=None, workspace=None):
-        self.lib = _lib.load()
+        self.lib = grid.lib()
         self.grid = grid
         # the parameter block as it is NOW (sdf.p, warp settings): backward() may run after the caller touched grid.params
         self.params = type(grid.params).from_buffer_copy(grid.params)
@@ -549,12 +577,14 @@ class GradSweep:
 
     def sweep(self, film):
         _require_dev(film, 'film')
+        self.lib = self.grid.lib()                            # (re-applies a general transform: state of the library instance)
         with torch.cuda.device(self.grid.device):
             _lib.check(self.lib.dsdf_grad_sweep(*self._args(), self.rows[0], self.rows[1], _ptr(film), _ptr(self.ws), self.ws.numel(), _stream()))
         return film
 
     def backward(self, film_total, grad_image, grad_grid, grad_p=None):
         _require_dev(film_total, 'film_total'); grad_image = _require_dev(grad_image, 'grad_image'); _require_dev(grad_grid, 'grad_grid')
+        self.lib = self.grid.lib()
         with torch.cuda.device(self.grid.device):
             _lib.check(self.lib.dsdf_grad_backward(*self._args(), _ptr(film_total), _ptr(grad_image), _ptr(grad_grid), _ptr(grad_p),
                                                    _ptr(self.ws), self.ws.numel(), _stream()))
@@ -636,7 +666,7 @@ def step_begin(grid, sensors, spp, spp_grad, seeds, seeds_grad, integrator=DSDF_
         side = _side_streams[dev] = torch.cuda.Stream(dev, priority=-1)
     side.wait_stream(main)                                    # the grid (and whatever produced it) is ready
     # one per-pixel proof for both passes (dsdf_share_pixel_skip): the sweep writes the flags, the primal render reads them
-    lib = _lib.load()
+    lib = grid.lib()
     nflag = len(sensors) * (W + 4) * (H + 4)
     flags = _skip_buffers.get(dev)
     if flags is None or flags.numel() < nflag:

@@ -111,8 +111,10 @@ class ReparamIntegrator:
         wf.apply(self.sdf.grid.params)
         self.sdf._sync()
         sh = self.shading()
-        if self.sdf.has_transform and sh is not None and isinstance(sh.albedo, torch.Tensor) and tuple(sh.albedo.shape[:3]) != (1, 1, 1):
-            raise NotImplementedError("an albedo VOLUME lives in world space: it cannot be combined with sdf_to_world")
+        if self.sdf.has_transform and not self.sdf._world and sh is not None and isinstance(sh.albedo, torch.Tensor) \
+                and tuple(sh.albedo.shape[:3]) != (1, 1, 1):
+            raise NotImplementedError("an albedo VOLUME lives in world space: it cannot be combined with the change-of-frame route of "
+                                      "sdf_to_world (a general transform -- the world-space build -- can)")
         return wf.reparameterize
 
     # -- antithetic pairs (python/integrators/reparam.py:167-178) --------------------------

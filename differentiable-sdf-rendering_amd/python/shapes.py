@@ -46,15 +46,30 @@ class Grid3d:
     and sensors are taken there with `to_local` (`local_sensor`), scalars (t, weights, images) are frame-independent and
     vectors come back through to_local^T like the reference's gradients (:426-427, 446-448)."""
 
+    _world = False
+
     def __init__(self, data, transform=None):
         self.has_transform = transform is not None
+        # `_world`: a transform that is NOT a change of frame (any other rotation, a scale).  Such a grid is served by the
+        # world-space build of the library (lib/variants/libdsdf_xf.so; dsdf.SdfGrid(to_world=...)): sensors, rays and `sdf.p`
+        # stay in world space and the library returns world-space derivatives, exactly the reference's formulation
+        # (python/shapes.py:408-450) -- without the per-pixel proofs and the tuned schedule of the default build.
+        self._world = False
         if self.has_transform:
-            self.to_world, self._A, self._b = _rigid_parts(transform)
+            try:
+                self.to_world, self._A, self._b = _rigid_parts(transform)
+            except NotImplementedError:
+                tw = np.asarray(transform.matrix if hasattr(transform, 'matrix') else transform, np.float64).reshape(4, 4)
+                if not np.allclose(tw[3], [0, 0, 0, 1], atol=1e-12) or abs(np.linalg.det(tw[:3, :3])) < 1e-12:
+                    raise
+                self.to_world, self._world = tw, True
+                inv = np.linalg.inv(tw)
+                self._A, self._b = inv[:3, :3], inv[:3, 3]
         if isinstance(data, str):
             from util import read_vol
             data = redistancing.redistance(read_vol(data))
         self.data = atleast_4d(data)
-        self.grid = dsdf.SdfGrid(self.data)
+        self.grid = dsdf.SdfGrid(self.data, to_world=self.to_world if self._world else None)
         self.p = torch.zeros(3)
         # SDFBase defaults, python/shapes.py:28-39 (held by the library's dsdf_params)
         self.refine_intersection = True
@@ -65,19 +80,19 @@ class Grid3d:
 
     def to_local_points(self, x):
         """to_local @ x for (n,3) points.  (`sdf.p` is applied by the library: lookups at x_local - to_local3 @ p.)"""
-        if not self.has_transform:
+        if not self.has_transform or self._world:
             return x
         A, b = self._mat(x)
         return x @ A.T + b
 
     def to_local_vectors(self, d):
-        if not self.has_transform:
+        if not self.has_transform or self._world:
             return d
         return d @ self._mat(d)[0].T
 
     def to_world_covectors(self, g):
         """to_local3^T g: how gradients (and derivatives w.r.t. a world-space direction) come back."""
-        if not self.has_transform:
+        if not self.has_transform or self._world:
             return g
         return g @ self._mat(g)[0]
 
@@ -93,12 +108,12 @@ class Grid3d:
             vals = c[2]
         else:
             vals = np.asarray(p, np.float64)
-        return (self._A @ vals).tolist() if self.has_transform else vals.tolist()
+        return (self._A @ vals).tolist() if (self.has_transform and not self._world) else vals.tolist()
 
     def local_sensor(self, sensor):
         """The sensor seen from the cube's frame: a rigid map takes the look-at frame to the look-at frame of the mapped
         origin / target / up, so the camera rays are the mapped camera rays."""
-        if not self.has_transform:
+        if not self.has_transform or self._world:
             return sensor
         return dsdf.Sensor(self._A @ sensor.origin + self._b, self._A @ sensor.target + self._b, self._A @ sensor.up,
                            fov=sensor.fov, resx=sensor.resx, resy=sensor.resy)
@@ -107,7 +122,7 @@ class Grid3d:
         """Frame-dependent fields of the library's parameter block: `sdf.p` and the fixed light of
         sdf_simple_shading_reparam (normalize(1,1,1) in WORLD space, sdf_simple_shading_reparam.py:20), both in the cube's frame."""
         self.grid.set_translation(self.local_translation())
-        if self.has_transform:
+        if self.has_transform and not self._world:
             l = self._A @ (np.ones(3) / np.sqrt(3.0))
             for k in range(3):
                 self.grid.params.light_dir[k] = float(l[k])
@@ -133,7 +148,7 @@ class Grid3d:
         H = torch.stack([torch.stack([h[:, 0], h[:, 3], h[:, 4]], -1),
                          torch.stack([h[:, 3], h[:, 1], h[:, 5]], -1),
                          torch.stack([h[:, 4], h[:, 5], h[:, 2]], -1)], -2)
-        if self.has_transform:
+        if self.has_transform and not self._world:
             A = self._mat(g)[0]
             g = g @ A
             H = A.T @ H @ A

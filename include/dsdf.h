@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define DSDF_VERSION 306   /* 300: stats rows of DSDF_STAT_SLOTS (16) counters; tail hand-off on library-owned helper streams; 304: DSDF_NO_HIT_PROOF, the grid buffer carries the bounds of the hit proof (dsdf_padded_size); 305: dsdf_params grows by normalize_warp_field, max_reparam_depth; 306: dsdf_render_aovs, dsdf_aov_workspace_size, dsdf_sampler_2d */
+#define DSDF_VERSION 306   /* 300: stats rows of DSDF_STAT_SLOTS (16) counters; tail hand-off on library-owned helper streams; 304: DSDF_NO_HIT_PROOF, the grid buffer carries the bounds of the hit proof (dsdf_padded_size); 305: dsdf_params grows by normalize_warp_field, max_reparam_depth; 306: dsdf_render_aovs, dsdf_aov_workspace_size, dsdf_sampler_2d, dsdf_set_grid_transform / dsdf_has_grid_transform */
 #define DSDF_STAT_SLOTS 16
 
 enum dsdf_status {
@@ -318,6 +318,20 @@ int dsdf_redistance(const float *phi, int rx, int ry, int rz, float *out,
  * tests/test_gpu_optimize.py::test_redistance_matches_c_oracle gates).
  * The library never synchronises: read it whenever the caller synchronises anyway. */
 int dsdf_redistance_status(const void *workspace, int rx, int ry, int rz, int32_t *status, void *stream);
+
+/* General `Grid3d(data, transform)` / integrator property `sdf_to_world` (python/shapes.py:378-450, python/integrators/reparam.py:21-29).
+ * The default library works in the cube's own frame and serves the transforms that are a change of frame (translation +
+ * axis-aligned rotation: the host maps sensors and `sdf.p`, differentiable-sdf-rendering_amd/python/shapes.py).  Any other rotation
+ * or a scale is the business of the WORLD-SPACE build of the same sources, lib/variants/libdsdf_xf.so (-DDSDF_XF=1): rays, `sdf.p`
+ * and the traced box stay in world space like in the reference, every texture lookup goes through to_local @ (x - p), gradients come
+ * back through to_local3^T, Hessians through to_local3^T H to_local3, and the box is the world AABB of the transformed cube -+
+ * bbox_delta (shapes.py:393-418).  The per-pixel proofs are off in that build (they reason in the cube's frame).
+ *   to_local : 12 floats, rows of the 3 x 4 matrix [A | b] of `to_world.inverse()`;  aabb_lo / aabb_hi : 3 floats each, the AABB of the
+ *   eight transformed cube corners (`Grid3d.update_bbox`, WITHOUT the 0.05 expansion).  HOST pointers.
+ * The transform is state of the library instance, applied in stream order to every later call until it is set again.
+ * dsdf_has_grid_transform(): 1 in the world-space build, 0 in the default one, whose dsdf_set_grid_transform returns an error. */
+int dsdf_has_grid_transform(void);
+int dsdf_set_grid_transform(const float *to_local, const float *aabb_lo, const float *aabb_hi, void *stream);
 
 /* Pixel-skip flags shared by the calls of one step.  The primal render and the gradient sweep of an optimisation step
  * (python/shape_opt.py:77-83: one `mi.render` = a primal and a gradient launch) see the same grid, sensors and film size, and the

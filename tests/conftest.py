@@ -294,6 +294,23 @@ def harness(built):
     return HostHarness(built.build_harness())
 
 
+@pytest.fixture(scope='session')
+def harness_xf(built):
+    """The host build of the kernel arithmetic with -DDSDF_XF=1: the world-space formulation of a general Grid3d(data, transform)."""
+    h = HostHarness(built.build_harness(xf=True))
+    assert h.lib.hh_has_transform() == 1
+
+    def set_transform(to_world):
+        tw = np.asarray(to_world, np.float64).reshape(4, 4)
+        inv = np.linalg.inv(tw)
+        corners = np.array([[x, y, z] for x in (0.0, 1.0) for y in (0.0, 1.0) for z in (0.0, 1.0)])
+        w = corners @ tw[:3, :3].T + tw[:3, 3]
+        tl, lo, hi = (np.ascontiguousarray(a, np.float32) for a in (inv[:3, :].reshape(-1), w.min(0), w.max(0)))
+        h.lib.hh_set_transform(h._p(tl), h._p(lo), h._p(hi))
+    h.set_transform = set_transform
+    return h
+
+
 def rel_l2(a, b):
     a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
     return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300))

@@ -15,6 +15,21 @@ using namespace dsdf;
 
 struct PlainAdd { void operator()(float *p, float v) const { *p += v; } };
 
+#if DSDF_XF
+// the transform state of an XF build (csrc/dsdf_math.h): hh_set_transform fills it like dsdf_set_grid_transform does in the library
+namespace dsdf { XfState g_xf_host = {{1, 0, 0, 0, 1, 0, 0, 0, 1}, {0, 0, 0}, {0, 0, 0}, {1, 1, 1}}; }
+extern "C" int hh_has_transform() { return 1; }
+extern "C" void hh_set_transform(const float *to_local12, const float *lo, const float *hi) {
+    for (int r = 0; r < 3; ++r) {
+        for (int c = 0; c < 3; ++c) g_xf_host.A[3 * r + c] = to_local12[4 * r + c];
+        g_xf_host.b[r] = to_local12[4 * r + 3];
+        g_xf_host.lo[r] = lo[r]; g_xf_host.hi[r] = hi[r];
+    }
+}
+#else
+extern "C" int hh_has_transform() { return 0; }
+#endif
+
 static std::vector<float> pad(const float *data, int rx, int ry, int rz) {
     int sx = rx + 6, sy = ry + 6, sz = rz + 6;
     std::vector<float> out((size_t)sx * sy * sz);

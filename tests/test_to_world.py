@@ -121,6 +121,31 @@ def test_oracle_transform_matches_reference_code(key):
     assert rel(ref[f'{key}_img_sil'], ref['img_sil']) > 1e-3
 
 
+def test_world_space_build_and_grid_state(built):
+    """lib/variants/libdsdf_xf.so loads, reports the transform capability the default build lacks, and dsdf.SdfGrid turns a
+    `to_world` into to_local + world AABB the way Grid3d.__init__ / update_bbox do (python/shapes.py:390-403).  No device needed."""
+    import ctypes as C
+    import dsdf
+    from dsdf import _lib
+    built.build_variant('xf', built.VARIANTS['xf'])
+    xf, default = _lib.load_xf(), _lib.load()
+    assert xf.dsdf_has_grid_transform() == 1 and default.dsdf_has_grid_transform() == 0
+    assert xf.dsdf_version() == default.dsdf_version()
+    z = (C.c_float * 12)(*([0.0] * 12))
+    assert default.dsdf_set_grid_transform(z, z, z, None) != 0 and b'DSDF_XF' in default.dsdf_last_error()
+    g = dsdf.SdfGrid.__new__(dsdf.SdfGrid)
+    g.transform = None
+    g.set_to_world(GENERAL)
+    tl, lo, hi = (np.array(list(a), np.float64) for a in g.transform)
+    inv = np.linalg.inv(GENERAL)
+    assert np.allclose(tl.reshape(3, 4), inv[:3, :], atol=1e-6)
+    osdf = O.Grid3d(O.sphere_grid(8), None, GENERAL)
+    blo, bhi = osdf.bbox()                                          # (the oracle's box carries the 0.05 expansion)
+    assert np.allclose(lo - 0.05, blo.numpy(), atol=1e-6) and np.allclose(hi + 0.05, bhi.numpy(), atol=1e-6)
+    with pytest.raises(dsdf.DsdfError):
+        g.set_to_world(np.diag([1.0, 1.0, 1.0, 2.0]))
+
+
 def test_rigid_parts_and_local_sensor():
     import shapes
     import dsdf
@@ -269,6 +294,59 @@ def test_change_of_frame_kernel_math_matches_reference_code(harness, tag, integ)
     assert ep < max(P.FLOOR_FACTOR * fp, 2 * e, P.NORTH_STAR), (ep, fp, e)
 
 
+def _fp32_floor(x, ref, key, tag, integ):
+    rel = lambda a, b: float(np.linalg.norm(np.asarray(a, np.float64) - b) / np.linalg.norm(b))
+    cam32 = O.Camera.from_params(x['cam'].params(), dtype=torch.float32)
+    d32, p32 = x['grid'].float().clone().requires_grad_(True), torch.from_numpy(ref['tf_p']).float().requires_grad_(True)
+    i32 = O.render(O.Grid3d(d32, p32, ref[f'{key}_matrix']), cam32, x['W'], x['H'], x['spp'], x['offs'].float(), integ, True)
+    (i32 * x['gi'].float()).sum().backward()
+    return rel(d32.grad.numpy(), ref[f'{key}_grad_{tag}']), rel(p32.grad.numpy(), ref[f'{key}_gradp_{tag}'])
+
+
+@pytest.mark.parametrize('key', ['tf_general', 'tf_axis'])
+def test_world_space_kernel_math_matches_reference_code(harness_xf, key):
+    """The -DDSDF_XF=1 build of the kernel arithmetic (host): WORLD-space rays, sensor and sdf.p, every lookup through
+    to_local @ (x - p), derivatives back through to_local3^T (csrc/dsdf_math.h: to_grid, xf_apply_t, box_lo) -- against the
+    reference's own shapes.py / reparam.py run with the same `to_world`: a rotation that is not axis-aligned, and the axis-aligned
+    one (which the default build serves by a change of frame: both routes must agree with the same fixture)."""
+    from test_refshim_fixture import inputs, check_fp32_gradient
+    import precision as P
+    ref = _ref16()
+    x = inputs(ref)
+    rel = lambda a, b: float(np.linalg.norm(np.asarray(a, np.float64) - b) / np.linalg.norm(b))
+    h = harness_xf
+    h.set_transform(ref[f'{key}_matrix'])
+    old = [h.params.sdf_p[k] for k in range(3)]
+    try:
+        for k in range(3):
+            h.params.sdf_p[k] = float(ref['tf_p'][k])
+        v, g, H = h.eval_cubic(ref['grid'], ref['eval_pts'], 2)
+        Hr = ref[f'{key}_eval_H']
+        H6 = np.stack([Hr[:, 0, 0], Hr[:, 1, 1], Hr[:, 2, 2], Hr[:, 0, 1], Hr[:, 0, 2], Hr[:, 1, 2]], -1)
+        assert rel(v, ref[f'{key}_eval_v']) < 1e-6 and rel(g, ref[f'{key}_eval_g']) < 1e-6 and rel(H, H6) < 1e-5
+        out = h.trace(ref['grid'], ref['ray_o'], ref['ray_d'], ref['ray_maxt'])
+        hit, fin = np.isfinite(ref[f'{key}_ri_its_t']), np.isfinite(ref[f'{key}_ri_warp_t'])
+        assert (np.isfinite(out['its_t']) == hit).mean() > 0.995
+        both = hit & np.isfinite(out['its_t'])
+        assert rel(out['its_t'][both], ref[f'{key}_ri_its_t'][both]) < 1e-5
+        m = fin & np.isfinite(out['warp_t']) & (ref[f'{key}_ri_warp_weight'] > 1e-3)
+        assert m.sum() > 100
+        for k, tol in (('warp_t', 1e-4), ('warp_weight', 1e-3), ('warp_t_d', 2e-2), ('warp_weight_d', 2e-2)):
+            assert rel(out[k][m], ref[f'{key}_ri_{k}'][m]) < tol, k
+        for tag, integ in (('sil', O.SILHOUETTE), ('shade', O.SIMPLE_SHADING)):
+            gg, img = h.render_backward(ref['grid'], ref['cam16'], x['W'], x['H'], x['spp'], ref['sampler_2d'], ref['grad_image'], integ)
+            assert rel(img, ref[f'{key}_img_{tag}']) < 1e-4
+            fg, fp = _fp32_floor(x, ref, key, tag, integ)
+            e = check_fp32_gradient('refshim_host_xf', 'sphere16', f'{key}_{tag}', gg, ref[f'{key}_grad_{tag}'], max(P.FLOOR_FACTOR * fg, P.NORTH_STAR))
+            ep = rel(h.last_grad_p, ref[f'{key}_gradp_{tag}'])
+            print(f"host xf {key} {tag}: dL/d data {e:.3e} (fp32 oracle {fg:.3e}), dL/d p {ep:.3e} (fp32 oracle {fp:.3e})")
+            assert ep < max(P.FLOOR_FACTOR * fp, 2 * e, P.NORTH_STAR), (ep, fp, e)
+    finally:
+        for k in range(3):
+            h.params.sdf_p[k] = old[k]
+        h.set_transform(np.eye(4))
+
+
 @pytest.mark.gpu
 def test_transformed_grid_matches_reference_code_gpu(built):
     """The HIP path with `Grid3d(data, transform=AXIS_ALIGNED)`, sdf.p and the WORLD sensor against what the reference's own
@@ -311,3 +389,71 @@ def test_transformed_grid_matches_reference_code_gpu(built):
         ep = rel(pl.grad.numpy(), ref[f'tf_axis_gradp_{tag}'])
         print(f"gpu tf_axis {tag}: dL/d data {eg:.3e} (fp32 oracle {floor_g:.3e}), dL/d p {ep:.3e} (fp32 oracle {floor_p:.3e})")
         assert ep < max(P.FLOOR_FACTOR * floor_p, 2 * eg, P.NORTH_STAR), (tag, ep, floor_p, eg)
+
+
+@pytest.mark.gpu
+def test_general_transform_matches_reference_code_gpu(built):
+    """A `to_world` that is NOT a change of frame (25 / -10 degrees: the reference's traced box, the world AABB of the rotated cube,
+    outgrows the cube) through `shapes.Grid3d(data, transform)` -> dsdf.SdfGrid(to_world) -> the world-space build of the library
+    (lib/variants/libdsdf_xf.so, dsdf_set_grid_transform), against what the reference's own shapes.py / reparam.py produced
+    (`tf_general_*`): eval_all, ray_intersect, image, dL/d(data), dL/d(sdf.p) of both scene-free integrators.
+    The gradient statistic of this configuration is ONE sample's footprint (99.9998 % of the squared fp32 error of the oracle's own
+    fp32 run sits in 64 voxels; the host build of the same arithmetic measures 1.5 x that run's error): gate 3 x the fp32 floor."""
+    import configs
+    import dsdf
+    import shapes
+    import integrators  # noqa: F401
+    from integrators.reparam import Scene, create_integrator, traverse
+    from constants import SDF_DEFAULT_KEY, SDF_DEFAULT_KEY_P
+    from test_refshim_fixture import inputs
+    dsdf.load()
+    ref = _ref16()
+    x = inputs(ref)
+    key = 'tf_general'
+    W, H, spp, seed = x['W'], x['H'], x['spp'], x['seed']
+    rel = lambda a, b: float(np.linalg.norm(np.asarray(a, np.float64) - b) / np.linalg.norm(b))
+    p0 = torch.from_numpy(ref['tf_p']).float()
+    sdf = shapes.Grid3d(torch.from_numpy(ref['grid']).cuda(), transform=GENERAL)
+    assert sdf._world and sdf.grid.transform is not None
+    sdf.p = p0.clone()
+    # protocol methods, world-space arguments and results
+    v, _, g, _, Hm = sdf.eval_all(torch.from_numpy(ref['eval_pts']).float().cuda())
+    assert rel(v.cpu().numpy(), ref[f'{key}_eval_v']) < 1e-6 and rel(g.cpu().numpy(), ref[f'{key}_eval_g']) < 1e-6
+    assert rel(Hm.cpu().numpy(), ref[f'{key}_eval_H']) < 1e-5
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).float().cuda()
+    out = sdf.ray_intersect(dev(ref['ray_o']), dev(ref['ray_d']), dev(ref['ray_maxt']), warp=True)
+    its = out[0].cpu().numpy()
+    hit = np.isfinite(ref[f'{key}_ri_its_t'])
+    assert (np.isfinite(its) == hit).mean() > 0.995
+    both = hit & np.isfinite(its)
+    assert rel(its[both], ref[f'{key}_ri_its_t'][both]) < 1e-5
+    m = np.isfinite(ref[f'{key}_ri_warp_t']) & np.isfinite(out[1].cpu().numpy()) & (ref[f'{key}_ri_warp_weight'] > 1e-3)
+    assert m.sum() > 100 and rel(out[1].cpu().numpy()[m], ref[f'{key}_ri_warp_t'][m]) < 1e-4
+    assert rel(out[2].cpu().numpy()[m], ref[f'{key}_ri_warp_t_d'][m]) < 2e-2
+    # integrators: WORLD sensor, nothing mapped
+    sensor = dsdf.Sensor(ref['origin'], resx=W, resy=H)
+    gi = torch.from_numpy(ref['grad_image']).cuda()
+    for name, tag, integ in (('sdf_silhouette_reparam', 'sil', O.SILHOUETTE), ('sdf_simple_shading_reparam', 'shade', O.SIMPLE_SHADING)):
+        floor_g, floor_p = _fp32_floor(x, ref, key, tag, integ)
+        it = create_integrator(name, {'sdf': sdf})
+        scene = Scene([sensor], it)
+        it.warp_field = configs.get_config('warp').get_warpfield(it.sdf)
+        sdf.p = p0.clone()
+        img = it.render(scene, 0, seed=seed, spp=spp).cpu().numpy()
+        assert rel(img, ref[f'{key}_img_{tag}']) < 1e-4, tag
+        params = traverse(scene)
+        leaf = torch.from_numpy(ref['grid']).cuda().clone().requires_grad_(True)
+        pl = p0.clone().requires_grad_(True)
+        params[SDF_DEFAULT_KEY], params[SDF_DEFAULT_KEY_P] = leaf, pl
+        params.update()
+        it.render_backward(scene, params, gi, 0, seed=seed, spp=spp)
+        eg = rel(leaf.grad.cpu().numpy().reshape(ref['grid'].shape), ref[f'{key}_grad_{tag}'])
+        ep = rel(pl.grad.numpy(), ref[f'{key}_gradp_{tag}'])
+        print(f"gpu xf {key} {tag}: dL/d data {eg:.3e} (fp32 oracle {floor_g:.3e}), dL/d p {ep:.3e} (fp32 oracle {floor_p:.3e})")
+        assert eg < max(3 * floor_g, 1e-4) and ep < max(3 * floor_p, 2 * eg, 1e-4), (tag, eg, floor_g, ep, floor_p)
+    # the default library is untouched by all of this: a plain grid still renders through it
+    plain = shapes.Grid3d(torch.from_numpy(ref['grid']).cuda())
+    it = create_integrator('sdf_silhouette_reparam', {'sdf': plain})
+    it.warp_field = configs.get_config('warp').get_warpfield(plain)
+    img = it.render(Scene([sensor], it), 0, seed=seed, spp=spp).cpu().numpy()
+    assert rel(img, ref['img_sil']) < 1e-4
