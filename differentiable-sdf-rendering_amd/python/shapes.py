@@ -22,7 +22,7 @@ def _rigid_parts(transform):
     world AABB of the transformed cube, distances to that AABB in the boundary fade of the trace weights (python/shapes.py:393-403,
     86-87) -- is the same computation in the cube's own frame, which is where the library works.  Any other rotation makes
     the reference's AABB larger than the cube (gradients differ by percents: measured 4.9 % at 25 degrees), scale / shear /
-    mirror change the march itself: those raise."""
+    mirror change the march itself: those raise HERE and Grid3d falls back to the world-space build of the library for them."""
     tw = np.asarray(transform.matrix if hasattr(transform, 'matrix') else transform, np.float64).reshape(4, 4)
     if not np.allclose(tw[3], [0, 0, 0, 1], atol=1e-12):
         raise NotImplementedError("Grid3d(transform=...): projective transforms are not supported")
@@ -41,10 +41,12 @@ def _rigid_parts(transform):
 
 class Grid3d:
     """Grid-based SDF (python/shapes.py:375-483): a (Z,Y,X[,1]) fp32 tensor interpreted as a tricubic B-spline texture
-    over the unit cube.  `transform` (python/shapes.py:378-403, integrator property `sdf_to_world`): a 4x4 `to_world` made of a
-    translation and an axis-aligned rotation (`_rigid_parts`).  The library always works in the cube's own frame: points, rays
-    and sensors are taken there with `to_local` (`local_sensor`), scalars (t, weights, images) are frame-independent and
-    vectors come back through to_local^T like the reference's gradients (:426-427, 446-448)."""
+    over the unit cube.  `transform` (python/shapes.py:378-403, integrator property `sdf_to_world`): a 4x4 affine `to_world`.
+      * translation + axis-aligned rotation (`_rigid_parts`): a change of frame.  The default library works in the cube's own
+        frame: points, rays and sensors are taken there with `to_local` (`local_sensor`), scalars (t, weights, images) are
+        frame-independent and vectors come back through to_local^T like the reference's gradients (:426-427, 446-448);
+      * anything else (a general rotation, a scale): `_world` -- the grid is served by the world-space build of the library
+        (dsdf.SdfGrid(to_world=...), lib/variants/libdsdf_xf.so), nothing is mapped on the host."""
 
     _world = False
 

@@ -2,10 +2,11 @@
 integrators/reparam.py:21-29).
 
 The oracle restates the reference literally: lookups at to_local @ (x - p), gradients back through to_local^T, Hessians
-through to_local^T H to_local, the traced box = AABB of the transformed corners.  The product works in the cube's own
-frame (sensors / rays mapped by to_local) and accepts the transforms for which that is the SAME computation: translation +
-axis-aligned rotation (the AABB is then the cube itself).  CPU: the two views agree inside the oracle; GPU: the HIP path through `shapes.Grid3d(transform=...)` against the oracle
-with the transform.
+through to_local^T H to_local, the traced box = AABB of the transformed corners -- and is pinned to the reference's OWN code run
+with a general and an axis-aligned `to_world` (`tf_*` keys of tests/golden/refshim_sphere16.npz).  The product has two routes:
+translation + axis-aligned rotation is a change of frame served by the default library (sensors / rays / sdf.p mapped by to_local);
+any other affine transform goes to the world-space build of the same sources (lib/variants/libdsdf_xf.so, -DDSDF_XF=1).  Both are
+checked against the reference-code fixtures on the host build of the kernel arithmetic and on the GPU.
 """
 import numpy as np
 import pytest
