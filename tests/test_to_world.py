@@ -348,6 +348,64 @@ def test_world_space_kernel_math_matches_reference_code(harness_xf, key):
         h.set_transform(np.eye(4))
 
 
+def _fp32_floor_direct(x, ref, key):
+    rel = lambda a, b: float(np.linalg.norm(np.asarray(a, np.float64) - b) / np.linalg.norm(b))
+    cam32 = O.Camera.from_params(x['cam'].params(), dtype=torch.float32)
+    d32, p32 = x['grid'].float().clone().requires_grad_(True), torch.from_numpy(ref['tf_p']).float().requires_grad_(True)
+    a32 = x['albedo'].float().clone().requires_grad_(True)
+    i32 = O.render(O.Grid3d(d32, p32, ref[f'{key}_matrix']), cam32, x['W'], x['H'], x['spp'], x['offs'].float(), O.DIRECT, True,
+                   albedo=a32, emitter_u=x['emitter_u'].float(), env=x['env'].float())
+    (i32 * x['gi'].float()).sum().backward()
+    return (rel(d32.grad.numpy(), ref[f'{key}_grad_direct']), rel(p32.grad.numpy(), ref[f'{key}_gradp_direct']),
+            rel(a32.grad.numpy(), ref[f'{key}_galb_direct']))
+
+
+def test_oracle_direct_with_transform_matches_reference_code():
+    """sdf_direct_reparam (the default integrator of the method configs) with the general `to_world`: shadow rays, the attached
+    shadow-ray warp and the WORLD-space reflectance volume through the transformed grid -- oracle against the reference's own code."""
+    from test_refshim_fixture import inputs
+    ref = _ref16()
+    x = inputs(ref)
+    key = 'tf_general'
+    rel = lambda a, b: float(np.linalg.norm(np.asarray(a) - b) / np.linalg.norm(b))
+    data, p = x['grid'].clone().requires_grad_(True), torch.from_numpy(ref['tf_p']).clone().requires_grad_(True)
+    alb = x['albedo'].clone().requires_grad_(True)
+    img = O.render(O.Grid3d(data, p, ref[f'{key}_matrix']), x['cam'], x['W'], x['H'], x['spp'], x['offs'], O.DIRECT, True, albedo=alb,
+                   emitter_u=x['emitter_u'], env=x['env'])
+    (img * x['gi']).sum().backward()
+    assert rel(img.detach().numpy(), ref[f'{key}_img_direct']) < 1e-12
+    assert rel(data.grad.numpy(), ref[f'{key}_grad_direct']) < 1e-9 and rel(p.grad.numpy(), ref[f'{key}_gradp_direct']) < 1e-9
+    assert rel(alb.grad.numpy(), ref[f'{key}_galb_direct']) < 1e-9
+
+
+def test_world_space_kernel_math_direct_matches_reference_code(harness_xf):
+    """The same run through the -DDSDF_XF=1 host build of the kernel arithmetic (lane_backward_direct and its shadow-ray trace)."""
+    from test_refshim_fixture import inputs, check_fp32_gradient
+    import precision as P
+    ref = _ref16()
+    x = inputs(ref)
+    key = 'tf_general'
+    rel = lambda a, b: float(np.linalg.norm(np.asarray(a, np.float64) - b) / np.linalg.norm(b))
+    h = harness_xf
+    h.set_transform(ref[f'{key}_matrix'])
+    old = [h.params.sdf_p[k] for k in range(3)]
+    try:
+        for k in range(3):
+            h.params.sdf_p[k] = float(ref['tf_p'][k])
+        gg, galb, gp, img = h.render_direct_backward(ref['grid'], ref['cam16'], x['W'], x['H'], x['spp'], ref['sampler_2d'], x['emitter_u'].numpy(),
+                                                     ref['albedo'], ref['grad_image'], tuple(ref['env']))
+    finally:
+        for k in range(3):
+            h.params.sdf_p[k] = old[k]
+        h.set_transform(np.eye(4))
+    fg, fp, fa = _fp32_floor_direct(x, ref, key)
+    assert rel(img, ref[f'{key}_img_direct']) < 1e-4
+    e = check_fp32_gradient('refshim_host_xf', 'sphere16', f'{key}_direct', gg, ref[f'{key}_grad_direct'], max(P.FLOOR_FACTOR * fg, P.NORTH_STAR))
+    ep, ea = rel(gp, ref[f'{key}_gradp_direct']), rel(galb, ref[f'{key}_galb_direct'])
+    print(f"host xf {key} direct: dL/d data {e:.3e} (fp32 oracle {fg:.3e}), dL/d p {ep:.3e} ({fp:.3e}), dL/d albedo {ea:.3e} ({fa:.3e})")
+    assert ep < max(P.FLOOR_FACTOR * fp, 2 * e, P.NORTH_STAR) and ea < max(P.FLOOR_FACTOR * fa, P.NORTH_STAR), (ep, fp, ea, fa)
+
+
 @pytest.mark.gpu
 def test_transformed_grid_matches_reference_code_gpu(built):
     """The HIP path with `Grid3d(data, transform=AXIS_ALIGNED)`, sdf.p and the WORLD sensor against what the reference's own
@@ -452,6 +510,28 @@ def test_general_transform_matches_reference_code_gpu(built):
         ep = rel(pl.grad.numpy(), ref[f'{key}_gradp_{tag}'])
         print(f"gpu xf {key} {tag}: dL/d data {eg:.3e} (fp32 oracle {floor_g:.3e}), dL/d p {ep:.3e} (fp32 oracle {floor_p:.3e})")
         assert eg < max(3 * floor_g, 1e-4) and ep < max(3 * floor_p, 2 * eg, 1e-4), (tag, eg, floor_g, ep, floor_p)
+    # sdf_direct_reparam with a WORLD-space reflectance volume (the change-of-frame route cannot take one, this build can)
+    if f'{key}_img_direct' in ref.files:
+        fg, fp, fa = _fp32_floor_direct(x, ref, key)
+        it = create_integrator('sdf_direct_reparam', {'sdf': sdf, 'reflectance': torch.from_numpy(ref['albedo']).cuda(),
+                                                      'env_radiance': tuple(float(e) for e in ref['env'])})
+        scene = Scene([sensor], it)
+        it.warp_field = configs.get_config('warp').get_warpfield(it.sdf)
+        sdf.p = p0.clone()
+        img = it.render(scene, 0, seed=seed, spp=spp).cpu().numpy()
+        assert rel(img, ref[f'{key}_img_direct']) < 1e-4
+        params = traverse(scene)
+        leaf = torch.from_numpy(ref['grid']).cuda().clone().requires_grad_(True)
+        pl = p0.clone().requires_grad_(True)
+        params[SDF_DEFAULT_KEY], params[SDF_DEFAULT_KEY_P] = leaf, pl
+        akey = [k for k in params if k.endswith('reflectance.volume.data')][0]
+        params[akey] = torch.from_numpy(ref['albedo']).cuda().clone().requires_grad_(True)
+        params.update()
+        it.render_backward(scene, params, gi, 0, seed=seed, spp=spp)
+        eg = rel(leaf.grad.cpu().numpy().reshape(ref['grid'].shape), ref[f'{key}_grad_direct'])
+        ep, ea = rel(pl.grad.numpy(), ref[f'{key}_gradp_direct']), rel(params[akey].grad.cpu().numpy(), ref[f'{key}_galb_direct'])
+        print(f"gpu xf {key} direct: dL/d data {eg:.3e} (fp32 oracle {fg:.3e}), dL/d p {ep:.3e} ({fp:.3e}), dL/d albedo {ea:.3e} ({fa:.3e})")
+        assert eg < max(3 * fg, 1e-4) and ep < max(3 * fp, 2 * eg, 1e-4) and ea < max(3 * fa, 1e-4), (eg, fg, ep, fp, ea, fa)
     # the default library is untouched by all of this: a plain grid still renders through it
     plain = shapes.Grid3d(torch.from_numpy(ref['grid']).cuda())
     it = create_integrator('sdf_silhouette_reparam', {'sdf': plain})

@@ -354,10 +354,16 @@ def main():
                     its_t, warp_t, warp_t_d, ww, ww_d = sdf_t.ray_intersect(ray, warp=wf_t)                  # python/shapes.py:115
                 out.update({f'{key}_ri_its_t': np.array(its_t), f'{key}_ri_warp_t': np.array(warp_t), f'{key}_ri_warp_t_d': cols(warp_t_d, 3),
                             f'{key}_ri_warp_weight': np.array(ww), f'{key}_ri_warp_weight_d': cols(ww_d, 3)})
-                for integ_name, tag in (('sdf_silhouette_reparam', 'sil'), ('sdf_simple_shading_reparam', 'shade')):
-                    scene = mi.load_dict({'type': 'scene', 'integrator': {'type': integ_name}, 'sensor': sensor,
-                                          'placeholder_sdf_shape': {'type': 'sphere', 'center': [100, 100, 100], 'radius': 1e-3,
-                                                                    'bsdf': {'type': 'diffuse'}}})
+                tf_runs = [('sdf_silhouette_reparam', 'sil'), ('sdf_simple_shading_reparam', 'shade')]
+                if args.shim and key == 'tf_general':
+                    tf_runs.append(('sdf_direct_reparam', 'direct'))          # (the albedo volume stays in WORLD space: a Mitsuba gridvolume)
+                for integ_name, tag in tf_runs:
+                    sd = {'type': 'scene', 'integrator': {'type': integ_name}, 'sensor': sensor,
+                          'placeholder_sdf_shape': {'type': 'sphere', 'center': [100, 100, 100], 'radius': 1e-3, 'bsdf': {'type': 'diffuse'}}}
+                    if tag == 'direct':
+                        sd['placeholder_sdf_shape']['bsdf'] = {'type': 'diffuse', 'reflectance': {'type': 'gridvolume', 'data': mi.TensorXf(c['albedo'])}}
+                        sd['emitter'] = {'type': 'constant', 'radiance': list(c['env'])}
+                    scene = mi.load_dict(sd)
                     integ = scene.integrator()
                     integ.sdf = make_sdf_t()
                     integ.warp_field = configs.get_config('warp').get_warpfield(integ.sdf)
@@ -365,8 +371,9 @@ def main():
                         body = integ.sample
                         integ.sample = lambda mode, scene_, sampler, ray_, dL, state_in, reparam, active, **kw: body(scene_, sampler, ray_, None, active)
                     params = mi.traverse(scene)
-                    params.keep([SDF_DEFAULT_KEY, SDF_DEFAULT_KEY_P])
-                    for k in (SDF_DEFAULT_KEY, SDF_DEFAULT_KEY_P):
+                    tkeys = [SDF_DEFAULT_KEY, SDF_DEFAULT_KEY_P] + [k for k in params if k.endswith('reflectance.volume.data')]
+                    params.keep(tkeys)
+                    for k in tkeys:
                         dr.enable_grad(params[k])
                     params.update()
                     img = mi.render(scene, params=params, sensor=sensor, seed=seed, spp=spp, seed_grad=seed, spp_grad=spp)
@@ -375,6 +382,8 @@ def main():
                     out[f'{key}_img_{tag}'] = np.array(img)[..., :3].astype(ft)
                     out[f'{key}_grad_{tag}'] = np.array(dr.grad(params[SDF_DEFAULT_KEY])).reshape(c['grid'].shape).astype(ft)
                     out[f'{key}_gradp_{tag}'] = np.array(dr.grad(params[SDF_DEFAULT_KEY_P])).reshape(3).astype(ft)
+                    if len(tkeys) > 2:
+                        out[f'{key}_galb_{tag}'] = np.array(dr.grad(params[tkeys[2]])).reshape(c['albedo'].shape).astype(ft)
 
         fn = os.path.join(args.out, f'{prefix}_{name}.npz')
         np.savez_compressed(fn, **out)
