@@ -69,3 +69,75 @@ DSDF_HD PrincipledTerms principled_terms(float x, float y, float u, float r) {
     T.dks[3] = T.ks * (dlnD_da2 + dlnGx_da2 + dlnGy_da2) * da2_dr;
     return T;
 }
+
+#if DSDF_XF
+// ---------------------------------------------------------------------------------------------------------------------------
+// `use_mis` with the principled BSDF (sdf_direct_reparam.py:77-105 over the principled-* configs) -- only in the extended build
+// (-DDSDF_XF=1, lib/variants/libdsdf_xf.so).  Principled::pdf and Principled::sample at the plugin defaults, restated from the
+// published plugin like eval above [third-party, parity unpinned]: main_specular_sampling_rate = diffuse_reflectance_sampling_rate
+// = 1 and no transmission / clearcoat leave two lobes chosen with probability 1/2 each --
+//   sample1 <  1/2 : wo = square_to_cosine_hemisphere(sample2)
+//   sample1 >= 1/2 : wo = reflect(wi, m), m a VISIBLE GGX normal (MicrofacetDistribution(GGX, alpha, sample_visible).sample:
+//                    stretch wi, sample_visible_11 in its projected-disk form, rotate, unstretch, normalise) from the SAME sample2
+//   pdf(wo) = 1/2 D(h) G1(wi, h) |wi.h| / |cos_i| / (4 |wo.h|)  +  1/2 cos_o / pi      (both directions on the front side)
+// The oracle checks that the two are consistent (the pdf integrates to the accepted fraction of the samples, E[cos / pdf] = pi).
+// ---------------------------------------------------------------------------------------------------------------------------
+DSDF_HD float principled_pdf(float x, float y, float u, float r) {
+    const float inv_pi = 0.3183098861837907f;
+    const float alpha = fmaxf(r * r, 0.001f), a2 = alpha * alpha;
+    const float c = sqrtf(fmaxf(0.5f * (1.f + u), 1e-12f));             // wi . h = wo . h
+    const float ch = (x + y) / (2.f * c);                                // n . h
+    const float s = 1.f - ch * ch + a2 * ch * ch;
+    const float D = a2 * inv_pi / (s * s);
+    const float qx = sqrtf(1.f + a2 * (1.f / (x * x) - 1.f));
+    const float Gx = 2.f / (1.f + qx);
+    return 0.5f * D * Gx / (4.f * x) + 0.5f * y * inv_pi;
+}
+
+// mitsuba warp.h square_to_uniform_disk_concentric
+DSDF_HD void concentric_disk(float u0, float u1, float &dx, float &dy) {
+    const float x = 2.f * u0 - 1.f, y = 2.f * u1 - 1.f;
+    const bool zero = x == 0.f && y == 0.f, q13 = fabsf(x) < fabsf(y);
+    const float rr = q13 ? y : x, rp = q13 ? x : y;
+    float phi = zero ? 0.f : 0.7853981633974483f * rp / rr;
+    if (q13) phi = 1.5707963267948966f - phi;
+    if (zero) phi = 0.f;
+    dx = rr * cosf(phi); dy = rr * sinf(phi);
+}
+
+// Principled::sample in the local shading frame (wi.z = cos_i > 0).  Returns false when the sample is rejected.
+DSDF_HD bool principled_sample(float wix, float wiy, float wiz, float r, float u1, float ua, float ub, float &wox, float &woy, float &woz) {
+    if (!(wiz > 0.f)) return false;
+    float dx, dy;
+    concentric_disk(ua, ub, dx, dy);
+    if (u1 < 0.5f) {
+        wox = dx; woy = dy; woz = sqrtf(fmaxf(1.f - dx * dx - dy * dy, 0.f));
+        return woz > 0.f;
+    }
+    const float alpha = fmaxf(r * r, 0.001f);
+    float px = alpha * wix, py = alpha * wiy, pz = wiz;                  // step 1: stretch wi
+    const float inl = 1.f / sqrtf(px * px + py * py + pz * pz);
+    px *= inl; py *= inl; pz *= inl;
+    const float st2 = 1.f - pz * pz;
+    float cos_phi = 1.f, sin_phi = 0.f;
+    if (fabsf(st2) > 4.f * 1.1920929e-7f) {
+        const float is = 1.f / sqrtf(st2);
+        cos_phi = fminf(fmaxf(px * is, -1.f), 1.f); sin_phi = fminf(fmaxf(py * is, -1.f), 1.f);
+    }
+    // step 2: sample_visible_11(cos_theta = pz, sample)
+    const float sfac = 0.5f * (1.f + pz);
+    const float qy = sqrtf(fmaxf(1.f - dx * dx, 0.f)) * (1.f - sfac) + dy * sfac;
+    const float qz = sqrtf(fmaxf(1.f - dx * dx - qy * qy, 0.f));
+    const float sin_t = sqrtf(fmaxf(1.f - pz * pz, 0.f));
+    const float norm = 1.f / (sin_t * qy + pz * qz);
+    const float slx = (pz * qy - sin_t * qz) * norm, sly = dx * norm;
+    // step 3: rotate & unstretch; step 4: normal
+    const float sx = (cos_phi * slx - sin_phi * sly) * alpha, sy = (sin_phi * slx + cos_phi * sly) * alpha;
+    const float iml = 1.f / sqrtf(sx * sx + sy * sy + 1.f);
+    const float mx = -sx * iml, my = -sy * iml, mz = iml;
+    const float wim = wix * mx + wiy * my + wiz * mz;
+    wox = 2.f * wim * mx - wix; woy = 2.f * wim * my - wiy; woz = 2.f * wim * mz - wiz;
+    const float wom = wox * mx + woy * my + woz * mz;
+    return woz > 0.f && wim > 0.f && wom > 0.f;                          // reflect && mac_mic_compatibility
+}
+#endif

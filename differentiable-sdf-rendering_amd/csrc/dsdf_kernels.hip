@@ -908,8 +908,13 @@ static int batch_size(int W, int H, int spp, int n_views, int integrator, size_t
 
 static ViewArgs make_view_args(const dsdf_camera &cam, int W, int H, int spp, const float *offsets, uint32_t seed,
                                int integrator, int flags, const dsdf_params &prm, const float *emitter_u = nullptr,
-                               const float *bsdf_u = nullptr) {
+                               const float *bsdf_u = nullptr, const float *lobe_u = nullptr) {
     ViewArgs A;
+#if DSDF_XF
+    A.lobe_u = lobe_u;
+#else
+    (void)lobe_u;
+#endif
     for (int k = 0; k < 3; ++k) A.light[k] = prm.light_dir[k];
     A.cam = cam; A.W = W; A.H = H; A.Wb = W + 2 * DSDF_BORDER; A.Hb = H + 2 * DSDF_BORDER; A.spp = spp;
     A.integrator = integrator; A.flags = flags; A.seed = seed; A.offsets = offsets; A.emitter_u = emitter_u; A.bsdf_u = bsdf_u;
@@ -956,7 +961,11 @@ static int check_render_args(const float *padded, int rx, int ry, int rz, const 
         if (shading->bsdf != 1) return fail(DSDF_ERR_INVALID_ARG, "dsdf_shading.bsdf must be 0 (diffuse) or 1 (principled)");
         if (!shading->roughness || shading->rax < 1 || shading->ray < 1 || shading->raz < 1)
             return fail(DSDF_ERR_INVALID_ARG, "the principled BSDF needs dsdf_shading.roughness (raz,ray,rax,1)");
-        if (shading->use_mis) return fail(DSDF_ERR_INVALID_ARG, "the principled BSDF is evaluated, not sampled: use_mis must be 0");
+#if !DSDF_XF
+        if (shading->use_mis)
+            return fail(DSDF_ERR_INVALID_ARG, "the principled BSDF is evaluated, not sampled, in this build: use_mis needs the extended build "
+                                              "(lib/variants/libdsdf_xf.so, -DDSDF_XF=1)");
+#endif
     }
     size_t nl = (size_t)(W + 2 * DSDF_BORDER) * (H + 2 * DSDF_BORDER) * (size_t)spp;
     // reparam.py:48-50 wavefront-size limit
@@ -1086,7 +1095,7 @@ size_t dsdf_forward_workspace_size(int width, int height, int spp, int n_views, 
 struct PassCtx {
     const float *padded; int rx, ry, rz; const dsdf_params *prm; dsdf_params pp;
     int W, H, spp, integrator, flags; bool direct;
-    const float *offsets, *emitter_u, *bsdf_u; const uint32_t *seeds; const dsdf_shading *shading;
+    const float *offsets, *emitter_u, *bsdf_u, *lobe_u; const uint32_t *seeds; const dsdf_shading *shading;
     size_t Wb, Hb; uint32_t nl;
     int row0, row1;        // film-block rows of this call (multi-GPU pixel-tile split; the whole film by default)
     float *film;           // caller-owned film block to ACCUMULATE into (tile calls), or nullptr: the workspace's, zeroed
@@ -1106,6 +1115,7 @@ static PassCtx make_ctx(const float *padded, int rx, int ry, int rz, const dsdf_
 #endif
     c.offsets = offsets; c.seeds = seeds; c.shading = shading; c.emitter_u = c.direct ? shading->emitter_samples : nullptr;
     c.bsdf_u = (c.direct && shading->use_mis) ? shading->bsdf_samples : nullptr;
+    c.lobe_u = (c.direct && shading->use_mis && shading->bsdf == 1) ? shading->bsdf_lobe_samples : nullptr;   // (n_views x lanes x 1)
     c.Wb = W + 2 * DSDF_BORDER; c.Hb = H + 2 * DSDF_BORDER; c.nl = (uint32_t)(c.Wb * c.Hb * spp);
     c.row0 = 0; c.row1 = (int)c.Hb; c.film = nullptr;
     c.st = (hipStream_t)stream;
@@ -1261,7 +1271,8 @@ static int run_pass(PassCtx &c, const Workspace &ws, const dsdf_camera *cams, in
         VB.v[i] = make_view_args(cams[v0 + i], c.W, c.H, c.spp, c.offsets ? c.offsets + (size_t)(v0 + i) * c.nl * 2 : nullptr,
                                  c.seeds ? c.seeds[v0 + i] : 0u, c.integrator, c.flags, c.pp,
                                  c.emitter_u ? c.emitter_u + (size_t)(v0 + i) * c.nl * 2 : nullptr,
-                                 c.bsdf_u ? c.bsdf_u + (size_t)(v0 + i) * c.nl * 2 : nullptr);
+                                 c.bsdf_u ? c.bsdf_u + (size_t)(v0 + i) * c.nl * 2 : nullptr,
+                                 c.lobe_u ? c.lobe_u + (size_t)(v0 + i) * c.nl : nullptr);
     const size_t nch = (size_t)film_channels(c.integrator), npix = c.Wb * c.Hb;
     float *film = c.film ? c.film + (size_t)v0 * npix * nch : ws.block;
     if (!c.film && hipMemsetAsync(ws.block, 0, nv * npix * nch * sizeof(float), st) != hipSuccess)
@@ -1516,6 +1527,8 @@ int dsdf_render_forward_grad(const float *padded, int rx, int ry, int rz, const 
                                workspace_bytes, true);
     if (rc) return rc;
     if (!grad_image_out) return fail(DSDF_ERR_INVALID_ARG, "dsdf_render_forward_grad: grad_image_out is null");
+    if (integrator == DSDF_DIRECT && shading->bsdf == 1 && shading->use_mis)
+        return fail(DSDF_ERR_INVALID_ARG, "dsdf_render_forward_grad: forward mode is not provided for the principled BSDF with use_mis");
     if (!tangent_padded && !tangent_p) return fail(DSDF_ERR_INVALID_ARG, "dsdf_render_forward_grad: need a tangent");
     if (!offsets && !seeds) return fail(DSDF_ERR_INVALID_ARG, "dsdf_render_forward_grad: need offsets or seeds");
     PassCtx c = make_ctx(padded, rx, ry, rz, prm, width, height, spp, offsets, seeds, integrator, flags, shading, stream);
@@ -1690,7 +1703,7 @@ int dsdf_grad_backward(const float *padded, int rx, int ry, int rz, const dsdf_p
     for (int i = 0; i < n_views; ++i)
         VB.v[i] = make_view_args(cams[i], width, height, spp, offsets ? offsets + (size_t)i * c.nl * 2 : nullptr, seeds ? seeds[i] : 0u,
                                  integrator, flags, c.pp, c.emitter_u ? c.emitter_u + (size_t)i * c.nl * 2 : nullptr,
-                                 c.bsdf_u ? c.bsdf_u + (size_t)i * c.nl * 2 : nullptr);
+                                 c.bsdf_u ? c.bsdf_u + (size_t)i * c.nl * 2 : nullptr, c.lobe_u ? c.lobe_u + (size_t)i * c.nl : nullptr);
     const dim3 adj_grid((unsigned)((c.Wb * c.Hb + 255) / 256), n_views);
     if (c.direct) hipLaunchKernelGGL(k_develop_adjoint_rgb, adj_grid, dim3(256), 0, st, film_total, grad_image, width, height, ws.block_adj);
     else hipLaunchKernelGGL(k_develop_adjoint, adj_grid, dim3(256), 0, st, film_total, grad_image, width, height, ws.block_adj);

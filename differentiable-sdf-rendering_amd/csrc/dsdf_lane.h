@@ -20,6 +20,9 @@ struct ViewArgs {
     const float *offsets;   // per-lane (r0,r1) or nullptr -> built-in sampler
     const float *emitter_u; // sdf_direct_reparam: per-lane emitter sample or nullptr -> built-in sampler
     const float *bsdf_u;    // sdf_direct_reparam, use_mis: per-lane BSDF sample (next_2d) or nullptr -> built-in sampler
+#if DSDF_XF
+    const float *lobe_u = nullptr;   // ... and the next_1d before it (the lobe selector of `principled`), or nullptr -> built-in sampler
+#endif
     // sdf_simple_shading_reparam.py:20: the fixed light direction normalize(1,1,1), in the SDF's frame (dsdf_params.light_dir)
     float light[3] = {0.57735026918962576f, 0.57735026918962576f, 0.57735026918962576f};
 };
@@ -329,7 +332,12 @@ DSDF_HD bool direct_setup(const GridView &G, const ViewArgs &A, const Lane &L, u
 // hit point (interaction.h spawn_ray / offset_p), power-heuristic weights (mitsuba.ad.integrators.common.mis_weight, detached).
 #define DSDF_INV_4PI 0.07957747154594767f
 #define DSDF_INV_PI 0.3183098861837907f
-struct BsdfRay { bool active; V3 o, d; float woz, pdf; };
+struct BsdfRay {
+    bool active; V3 o, d; float woz, pdf;
+#if DSDF_XF
+    V3 wo, sv, tv;          // principled: the sampled LOCAL direction and the frame it was taken to the world with
+#endif
+};
 
 DSDF_HD float mis_weight(float a, float b) { return a > 0.f ? a * a / (b * b + a * a) : 0.f; }
 
@@ -361,6 +369,54 @@ DSDF_HD BsdfRay bsdf_setup(const ViewArgs &A, const Lane &L, uint32_t lane, cons
     return b;
 }
 
+#if DSDF_XF
+// bsdf.sample(ctx, si_d, next_1d, next_2d) of the principled BSDF (sdf_direct_reparam.py:88-94): everything detached; the ray
+// leaves the attached hit point like the diffuse one (si.spawn_ray).
+DSDF_HD BsdfRay bsdf_setup_principled(const ViewArgs &A, const ShadeArgs &S, const Lane &L, uint32_t lane, const DirectHit &h) {
+    float u0, u1;
+    bsdf_sample(A, lane, u0, u1);
+    const float ul = A.lobe_u ? A.lobe_u[lane] : sampler_bsdf_1d(A.seed, lane);
+    const V3 n = h.n, wi = -L.ray.d;
+    const float sign = n.z >= 0.f ? 1.f : -1.f, a = -1.f / (sign + n.z), bb = n.x * n.y * a;
+    BsdfRay b;
+    b.sv = mk(sign * (n.x * n.x * a) + 1.f, sign * bb, -sign * n.x); b.tv = mk(bb, n.y * (n.y * a) + sign, -n.y);
+    float r; V3 rg;
+    eval_trilinear1(S.rough, h.p, r, rg);
+    float wx = 0.f, wy = 0.f, wz = 0.f;
+    const bool ok = principled_sample(dot(b.sv, wi), dot(b.tv, wi), dot(n, wi), r, ul, u0, u1, wx, wy, wz);
+    b.wo = mk(wx, wy, wz);
+    b.d = b.sv * wx + b.tv * wy + n * wz;
+    float mag = (1.f + fmaxf(fabsf(h.p.x), fmaxf(fabsf(h.p.y), fabsf(h.p.z)))) * DSDF_RAY_EPSILON;
+    if (dot(n, b.d) < 0.f) mag = -mag;
+    b.o = fma3(mag, n, h.p);
+    b.woz = wz;
+    b.pdf = ok ? principled_pdf(dot(n, wi), wz, dot(wi, b.d), r) : 0.f;
+    b.active = ok && b.pdf > 0.f;
+    return b;
+}
+// bsdf.eval(ctx, si, bs.wo) / bs.pdf * mis_weight(bs.pdf, emitter_pdf) of an escaped BSDF-sampled ray: the terms Kd, Ks (and their
+// partials) at x = n . wi, y = wo.z, u = wi_local . wo_local = wi . d_b, scaled by that factor
+DSDF_HD PrincipledTerms bsdf_terms_principled(const ShadeArgs &S, const DirectHit &h, const BsdfRay &b, V3 d, V3 &rg) {
+    float r;
+    eval_trilinear1(S.rough, h.p, r, rg);
+    const V3 wi = -d;
+    PrincipledTerms T = principled_terms(dot(h.n, wi), b.woz, dot(wi, b.d), r);
+    const float f = mis_weight(b.pdf, DSDF_INV_4PI) / b.pdf;
+    T.kd *= f; T.ks *= f;
+    for (int k = 0; k < 4; ++k) { T.dkd[k] *= f; T.dks[k] *= f; }
+    return T;
+}
+// d(u)/dn for u = (s . wi) wo.x + (t . wi) wo.y + (n . wi) wo.z with (s, t) = coordinate_system(n) (Duff et al.; the ATTACHED frame
+// of si: initialize_sh_frame), wi and the local wo held fixed
+DSDF_HD V3 frame_dot_dn(V3 n, V3 wi, V3 wo) {
+    const float sign = n.z >= 0.f ? 1.f : -1.f, a = -1.f / (sign + n.z), a2 = a * a;
+    const V3 ds = mk(sign * (2.f * n.x * a * wi.x + n.y * a * wi.y) - sign * wi.z, sign * n.x * a * wi.y,
+                     sign * a2 * (n.x * n.x * wi.x + n.x * n.y * wi.y));
+    const V3 dt = mk(n.y * a * wi.x, n.x * a * wi.x + 2.f * n.y * a * wi.y - wi.z, a2 * (n.x * n.y * wi.x + n.y * n.y * wi.y));
+    return wo.x * ds + wo.y * dt + wo.z * wi;
+}
+#endif
+
 // The emitter-sampling term of a lit sample:  rgb_e,c = env_c (a_c ke + ks)  [x det_e x det].
 //   diffuse:     ke = 4 cos_o [* mis weight], ks = 0         (bsdf a / pi cos_o, emitter_val / pdf = env 4 pi)
 //   principled:  ke = 4 pi Kd, ks = 4 pi Ks  (dsdf_bsdf.h) with x = n . wi, y = n . d_s, u = wi . d_s, r = roughness(p); wi = -d
@@ -373,6 +429,13 @@ DSDF_HD void emitter_term(const ShadeArgs &S, const DirectHit &h, V3 d, EmitterT
         float r;
         eval_trilinear1(S.rough, h.p, r, e.rg);
         e.T = principled_terms(dot(h.n, e.wi), cos_o, dot(e.wi, h.sr.d), r);
+#if DSDF_XF
+        if (S.use_mis) {                                              // :78-79 mis_weight(ds.pdf, detach(bsdf_pdf)): a constant factor
+            e.we = mis_weight(DSDF_INV_4PI, principled_pdf(dot(h.n, e.wi), cos_o, dot(e.wi, h.sr.d), r));
+            e.T.kd *= e.we; e.T.ks *= e.we;
+            for (int k = 0; k < 4; ++k) { e.T.dkd[k] *= e.we; e.T.dks[k] *= e.we; }
+        }
+#endif
         e.ke = 12.566370614359172f * e.T.kd; e.ks = 12.566370614359172f * e.T.ks;
         return;
     }
@@ -425,19 +488,37 @@ DSDF_HD int direct_value(const GridView &G, const dsdf_params &P, const ViewArgs
         }
         if (!(trs.its_t < INFINITY)) { EmitterTerm e; emitter_term(S, h, L.ray.d, e); ke = e.ke; ks = e.ks; lit |= 1; }
     }
+#if DSDF_XF
+    float kbs = 0.f;
+#endif
     if (S.use_mis) {
+#if DSDF_XF
+        const BsdfRay b = S.bsdf == 1 ? bsdf_setup_principled(A, S, L, lane, h) : bsdf_setup(A, L, lane, h);
+#else
         const BsdfRay b = bsdf_setup(A, L, lane, h);
+#endif
         if (b.active) {
             if (diff) { trace_diff(G, Ps, b.o, b.d, 1e30f, trb); if (!reparam_depth1(P)) drop_warp(trb); }
             else { ReuseFetch F; trace_plain(G, Ps, b.o, b.d, 1e30f, trb, F); }
-            if (!(trb.its_t < INFINITY)) { kb = bsdf_factor(b); lit |= 2; }   // escaped: the environment, emitter pdf 1/(4 pi)
+            if (!(trb.its_t < INFINITY)) {                                     // escaped: the environment, emitter pdf 1/(4 pi)
+#if DSDF_XF
+                if (S.bsdf == 1) { V3 rg; const PrincipledTerms Tb = bsdf_terms_principled(S, h, b, L.ray.d, rg); kb = Tb.kd; kbs = Tb.ks; }
+                else
+#endif
+                kb = bsdf_factor(b);
+                lit |= 2;
+            }
         }
     }
     if (!lit) return 0;
     float alb[3]; V3 ag[3];
     eval_trilinear(S.albedo, h.p, alb, ag);
 #pragma unroll
+#if DSDF_XF
+    for (int c = 0; c < 3; ++c) rgb[c] = (alb[c] * ke + ks) * S.env[c] + (alb[c] * kb + kbs) * S.env[c];
+#else
     for (int c = 0; c < 3; ++c) rgb[c] = (alb[c] * ke + ks) * S.env[c] + alb[c] * kb * S.env[c];
+#endif
     return lit;
 }
 
@@ -578,6 +659,12 @@ DSDF_HD bool lane_backward_direct(const GridView &G, const dsdf_params &P, const
     br.active = false;
     int lit = 0;
     float alb[3] = {0.f, 0.f, 0.f}; V3 ag[3]; float ke = 0.f, kb = 0.f;
+#if DSDF_XF
+    float kbs = 0.f;
+    PrincipledTerms Tb; V3 rgb_rough = mk(0.f, 0.f, 0.f);            // principled + use_mis: the BSDF-sampled term's Kd, Ks (x mis / pdf)
+    Tb.kd = 0.f; Tb.ks = 0.f;
+    for (int k = 0; k < 4; ++k) { Tb.dkd[k] = 0.f; Tb.dks[k] = 0.f; }
+#endif
     EmitterTerm et;
     et.ke = 0.f; et.ks = 0.f; et.we = 1.f;
     if (!hit) {
@@ -586,13 +673,26 @@ DSDF_HD bool lane_backward_direct(const GridView &G, const dsdf_params &P, const
         const bool front = direct_setup(G, A, L, lane, tr.its_t, h);
         if (front && !(trs.its_t < INFINITY)) { emitter_term(S, h, d, et); ke = et.ke; lit |= 1; }
         if (S.use_mis) {
+#if DSDF_XF
+            br = S.bsdf == 1 ? bsdf_setup_principled(A, S, L, lane, h) : bsdf_setup(A, L, lane, h);
+            if (br.active && !(trb.its_t < INFINITY)) {
+                if (S.bsdf == 1) { Tb = bsdf_terms_principled(S, h, br, d, rgb_rough); kb = Tb.kd; kbs = Tb.ks; }
+                else kb = bsdf_factor(br);
+                lit |= 2;
+            }
+#else
             br = bsdf_setup(A, L, lane, h);
             if (br.active && !(trb.its_t < INFINITY)) { kb = bsdf_factor(br); lit |= 2; }
+#endif
         }
         if (lit) {
             eval_trilinear(S.albedo, h.p, alb, ag);
 #pragma unroll
+#if DSDF_XF
+            for (int c = 0; c < 3; ++c) { rgb_e[c] = (alb[c] * ke + et.ks) * S.env[c]; rgb_b[c] = (alb[c] * kb + kbs) * S.env[c]; rgb[c] = rgb_e[c] + rgb_b[c]; }
+#else
             for (int c = 0; c < 3; ++c) { rgb_e[c] = (alb[c] * ke + et.ks) * S.env[c]; rgb_b[c] = alb[c] * kb * S.env[c]; rgb[c] = rgb_e[c] + rgb_b[c]; }
+#endif
         }
     }
     float a_c[3] = {0.f, 0.f, 0.f}, a_w = 0.f, u_bar = 0.f, v_bar = 0.f;
@@ -669,6 +769,22 @@ DSDF_HD bool lane_backward_direct(const GridView &G, const dsdf_params &P, const
             areq.r_bar = r_bar;
             p_bar = fma3(r_bar, et.rg, p_bar);
         }
+#if DSDF_XF
+        if (S.bsdf == 1 && (lit & 2)) {
+            // BSDF-sampled term (a_c Kd_b + Ks_b) env_c with the LOCAL wo fixed: x = n . wi, u = wi_local . wo_local through the attached
+            // frame, r = roughness(p); y = wo.z is a constant (sdf_direct_reparam.py:97: bsdf.eval(ctx, si, bs.wo))
+            float kd_bar = 0.f, ks_b_bar = 0.f;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { kd_bar = fmaf(S.env[c] * a_c[c], alb[c], kd_bar); ks_b_bar += S.env[c] * a_c[c]; }
+            const float xb = kd_bar * Tb.dkd[0] + ks_b_bar * Tb.dks[0], ub = kd_bar * Tb.dkd[2] + ks_b_bar * Tb.dks[2];
+            const float rb = kd_bar * Tb.dkd[3] + ks_b_bar * Tb.dks[3];
+            const V3 wi = -d;
+            n_bar = n_bar + xb * wi + ub * frame_dot_dn(n, wi, br.wo);
+            dir_bar = dir_bar - (xb * n + ub * br.d);                           // wi = -d'
+            areq.r_bar += rb;
+            p_bar = fma3(rb, rgb_rough, p_bar);
+        }
+#endif
         const V3 G_bar = (n_bar - dot(n, n_bar) * n) * (1.f / gl);
         if (A.flags & DSDF_REPARAM) {
             WarpCoef ws;

@@ -960,6 +960,19 @@ DSDF_HD void sampler_bsdf_2d(uint32_t seed, uint32_t lane, float &b0, float &b1)
     b1 = pcg32_float(r);
 }
 
+// bsdf.sample's `next_1d()` (sdf_direct_reparam.py:90: the lobe selector of `principled`): float 5 of the lane's stream
+DSDF_HD float sampler_bsdf_1d(uint32_t seed, uint32_t lane) {
+    uint32_t v0, v1;
+    sample_tea_32(seed, lane, v0, v1);
+    Pcg32 r;
+    r.state = 0; r.inc = ((uint64_t)v1 << 1u) | 1u;
+    pcg32_next(r);
+    r.state += (uint64_t)v0;
+    pcg32_next(r);
+    for (int k = 0; k < 5; ++k) pcg32_next(r);
+    return pcg32_float(r);
+}
+
 // ---------------------------------------------------------------------------
 // sdf_direct_reparam (integrators/sdf_direct_reparam.py:16-75) building blocks.  The BSDF and the emitter
 // come from scene files the reference does not ship; this repo fixes them as Mitsuba `diffuse` over a

@@ -36,7 +36,7 @@ class DsdfShading(C.Structure):
                 ('env_radiance', C.c_float * 3), ('hide_emitters', C.c_int), ('emitter_samples', C.c_void_p),
                 ('grad_albedo', C.c_void_p), ('use_mis', C.c_int), ('variant', C.c_int), ('bsdf_samples', C.c_void_p),
                 ('bsdf', C.c_int), ('roughness', C.c_void_p), ('rax', C.c_int), ('ray', C.c_int), ('raz', C.c_int),
-                ('grad_roughness', C.c_void_p)]
+                ('grad_roughness', C.c_void_p), ('bsdf_lobe_samples', C.c_void_p)]
 
 
 class DsdfError(RuntimeError):

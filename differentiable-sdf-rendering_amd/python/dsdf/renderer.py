@@ -247,6 +247,13 @@ class Shading:
                 _require_dev(gr, 'grad_roughness')
                 st.grad_roughness = gr.data_ptr()
                 keep.append(gr)
+        lobe = getattr(self, 'lobe_samples', None)       # explicit next_1d() of bsdf.sample (principled + use_mis; tests): (n_views, lanes)
+        if lobe is not None and self.roughness is not None and self.use_mis:
+            lobe = _require_dev(lobe, 'lobe_samples')
+            if lobe.numel() != n_views * n_lanes:
+                raise _lib.DsdfError(f"lobe_samples must hold n_views*(W+4)*(H+4)*spp = {n_views * n_lanes} floats")
+            st.bsdf_lobe_samples = lobe.data_ptr()
+            keep.append(lobe)
         return st, keep
 
 

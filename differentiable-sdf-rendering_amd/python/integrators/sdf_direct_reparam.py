@@ -6,7 +6,7 @@ fixed as a Mitsuba `diffuse` BSDF over a trilinear reflectance volume -- the opt
 'main-bsdf.reflectance.volume.data' (python/opt_configs.py:286) -- and a `constant` environment emitter
 (include/dsdf.h: dsdf_shading).  With a `roughness` (or `base_color`) property the BSDF is Mitsuba's `principled` at the plugin
 defaults instead, and the published parameters are 'main-bsdf.base_color.volume.data' / 'main-bsdf.roughness.volume.data'
-(the principled-* configs, python/opt_configs.py:288-299).  Properties as in the reference: `hide_emitters`, `use_mis` (BSDF sampling + power heuristic,
+(the principled-* configs, python/opt_configs.py:288-299; `use_mis` with it runs in the extended build of the library).  Properties as in the reference: `hide_emitters`, `use_mis` (BSDF sampling + power heuristic,
 sdf_direct_reparam.py:77-105; read by the base class, reparam.py:17), `detach_indirect_si`, `decouple_reparam` (:13-14, 44-47)."""
 import torch
 
@@ -38,12 +38,18 @@ class SdfDirectReparamIntegrator(ReparamIntegrator):
         self.reflectance = refl                                             # diffuse: reflectance; principled: base_color
         self.roughness = None
         if self.principled:
-            if self.use_mis:
-                raise NotImplementedError("the principled BSDF is evaluated, not sampled: use_mis is not available with it")
             rough = props.get('roughness', 0.5)
             if not isinstance(rough, torch.Tensor):
                 rough = torch.full((16, 16, 16, 1), float(rough), device=default_device())
             self.roughness = rough
+
+    def _configured(self):
+        # `use_mis` with the principled BSDF (Principled::sample / ::pdf) exists in the extended build of the library only
+        # (lib/variants/libdsdf_xf.so): a grid without a transform is routed there with the identity (include/dsdf.h)
+        if self.principled and self.use_mis and self.sdf is not None and self.sdf.grid.transform is None:
+            import numpy as np
+            self.sdf.grid.set_to_world(np.eye(4))
+        return super()._configured()
 
     def shading(self):
         return dsdf.Shading(self.reflectance, self.env_radiance, self.hide_emitters, self.use_mis, self.detach_indirect_si,

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define DSDF_VERSION 306   /* 300: stats rows of DSDF_STAT_SLOTS (16) counters; tail hand-off on library-owned helper streams; 304: DSDF_NO_HIT_PROOF, the grid buffer carries the bounds of the hit proof (dsdf_padded_size); 305: dsdf_params grows by normalize_warp_field, max_reparam_depth; 306: dsdf_render_aovs, dsdf_aov_workspace_size, dsdf_sampler_2d, dsdf_set_grid_transform / dsdf_has_grid_transform */
+#define DSDF_VERSION 306   /* 300: stats rows of DSDF_STAT_SLOTS (16) counters; tail hand-off on library-owned helper streams; 304: DSDF_NO_HIT_PROOF, the grid buffer carries the bounds of the hit proof (dsdf_padded_size); 305: dsdf_params grows by normalize_warp_field, max_reparam_depth; 306: dsdf_render_aovs, dsdf_aov_workspace_size, dsdf_sampler_2d, dsdf_set_grid_transform / dsdf_has_grid_transform, dsdf_shading.bsdf_lobe_samples */
 #define DSDF_STAT_SLOTS 16
 
 enum dsdf_status {
@@ -107,10 +107,14 @@ typedef struct dsdf_shading {
                                      or NULL for the built-in sampler; only read when use_mis */
     int   bsdf;                   /* 0 = `diffuse` (albedo is its reflectance volume), 1 = `principled` with every parameter at the plugin
                                      default except base_color (= albedo) and roughness (below): the principled-* configs,
-                                     python/opt_configs.py:288-299.  Emitter sampling only (use_mis must be 0) */
+                                     python/opt_configs.py:288-299.  Emitter sampling only in the default library (use_mis must be 0);
+                                     the extended build (-DDSDF_XF=1) also samples it: Principled::sample / ::pdf at the defaults */
     const float *roughness;       /* device, (rz_,ry_,rx_,1) fp32: 'main-bsdf.roughness.volume.data'; read when bsdf == 1 */
     int   rax, ray, raz;
     float *grad_roughness;        /* device, like roughness: dL/d(roughness) accumulator of dsdf_render_backward, or NULL */
+    const float *bsdf_lobe_samples; /* device, n_views x (W+4)(H+4)*spp: the lane's `next_1d()` of bsdf.sample (sdf_direct_reparam.py:90), which
+                                     selects the lobe of `principled`; NULL for the built-in sampler.  Read when bsdf == 1 and use_mis -- a
+                                     combination only the extended build (lib/variants/libdsdf_xf.so) renders */
 } dsdf_shading;
 
 int         dsdf_version(void);

@@ -645,9 +645,83 @@ def principled_eval(base_color, roughness, wi, wo):
     return value + torch.where(diffuse_active[:, None], diff, torch.zeros_like(diff))
 
 
+def square_to_uniform_disk_concentric(u):
+    """mitsuba warp.h (the map square_to_cosine_hemisphere below is built on)."""
+    x = 2.0 * u[:, 0] - 1.0
+    y = 2.0 * u[:, 1] - 1.0
+    is_zero = (x == 0) & (y == 0)
+    q13 = x.abs() < y.abs()
+    r = torch.where(q13, y, x)
+    rp = torch.where(q13, x, y)
+    phi = 0.25 * math.pi * rp / torch.where(is_zero, torch.ones_like(r), r)
+    phi = torch.where(q13, 0.5 * math.pi - phi, phi)
+    phi = torch.where(is_zero, torch.zeros_like(phi), phi)
+    return r * torch.cos(phi), r * torch.sin(phi)
+
+
+def ggx_sample_visible(wi, alpha, u):
+    """microfacet.h MicrofacetDistribution(GGX, alpha, alpha, sample_visible = true).sample(wi, u) -> microfacet normal m [3P-mem]:
+    stretch wi, sample_visible_11 (projected-disk form of the visible-normal distribution), rotate, unstretch, normalise."""
+    wp = torch.stack([alpha * wi[:, 0], alpha * wi[:, 1], wi[:, 2]], -1)
+    wp = wp / torch.linalg.norm(wp, dim=-1, keepdim=True)
+    st2 = 1.0 - wp[:, 2] * wp[:, 2]                                   # Frame3f::sincos_phi
+    inv = torch.rsqrt(torch.clamp(st2, min=1e-300))
+    tiny = st2.abs() <= 4.0 * torch.finfo(wi.dtype).eps
+    cos_phi = torch.where(tiny, torch.ones_like(st2), torch.clamp(wp[:, 0] * inv, -1.0, 1.0))
+    sin_phi = torch.where(tiny, torch.zeros_like(st2), torch.clamp(wp[:, 1] * inv, -1.0, 1.0))
+    cos_theta = wp[:, 2]
+    # sample_visible_11(cos_theta, u)
+    px, py = square_to_uniform_disk_concentric(u)
+    sfac = 0.5 * (1.0 + cos_theta)
+    py = torch.sqrt(torch.clamp(1.0 - px * px, min=0.0)) * (1.0 - sfac) + py * sfac      # lerp(safe_sqrt(1 - x^2), y, s)
+    pz = torch.sqrt(torch.clamp(1.0 - px * px - py * py, min=0.0))
+    sin_theta = torch.sqrt(torch.clamp(1.0 - cos_theta * cos_theta, min=0.0))
+    norm = 1.0 / (sin_theta * py + cos_theta * pz)
+    slx, sly = (cos_theta * py - sin_theta * pz) * norm, px * norm
+    # rotate & unstretch, normal
+    sx = (cos_phi * slx - sin_phi * sly) * alpha
+    sy = (sin_phi * slx + cos_phi * sly) * alpha
+    m = torch.stack([-sx, -sy, torch.ones_like(sx)], -1)
+    return m / torch.linalg.norm(m, dim=-1, keepdim=True)
+
+
+def principled_pdf(roughness, wi, wo):
+    """principled.cpp Principled::pdf at the plugin defaults [3P-mem]: main_specular_sampling_rate = diffuse_reflectance_sampling_rate
+    = 1, no transmission / clearcoat -> the specular-reflection and the diffuse lobe are chosen with probability 1/2 each;
+    specular: visible-normal pdf D G1(wi, h) |wi . h| / |cos theta_i| times the half-vector Jacobian 1 / (4 |wo . h|); diffuse:
+    cos theta_o / pi.  Zero unless both directions are on the front side."""
+    ci, co = wi[:, 2], wo[:, 2]
+    ok = (ci > 0) & (co > 0)
+    a = torch.clamp(roughness * roughness, min=0.001)
+    wh = wi + wo
+    wh = wh / torch.linalg.norm(wh, dim=-1, keepdim=True)
+    wh = wh * torch.where(wh[:, 2:3] >= 0, torch.ones_like(wh[:, 2:3]), -torch.ones_like(wh[:, 2:3]))
+    spec = ggx_eval(wh, a, a) * ggx_smith_g1(wi, wh, a, a) * dot(wi, wh).abs() / ci.abs() / (4.0 * dot(wo, wh)).abs()
+    pdf = 0.5 * spec + 0.5 * co / math.pi
+    return torch.where(ok, pdf, torch.zeros_like(pdf))
+
+
+def principled_sample(roughness, wi, u1, u2):
+    """principled.cpp Principled::sample at the defaults [3P-mem]: sample1 < 1/2 -> cosine hemisphere, else reflect wi about a
+    visible GGX normal; both from the SAME sample2.  -> (wo, pdf, active)."""
+    a = torch.clamp(roughness * roughness, min=0.001)
+    ci = wi[:, 2]
+    diffuse = u1 < 0.5
+    wo_d = square_to_cosine_hemisphere(u2)
+    m = ggx_sample_visible(wi, a, u2)
+    wo_s = 2.0 * dot(wi, m)[:, None] * m - wi                           # reflect(wi, m)
+    ok_s = (ci * wo_s[:, 2] > 0) & (dot(wi, m) * ci > 0) & (dot(wo_s, m) * ci > 0)     # reflect && mac_mic_compatibility
+    ok_d = ci * wo_d[:, 2] > 0
+    wo = torch.where(diffuse[:, None], wo_d, wo_s)
+    active = (ci > 0) & torch.where(diffuse, ok_d, ok_s)
+    pdf = principled_pdf(roughness, wi, wo)
+    active = active & (pdf > 0)
+    return wo, torch.where(active, pdf, torch.zeros_like(pdf)), active
+
+
 def direct_radiance(sdf, albedo, o, d_att, its_t, emitter_u, reparam, env=1.0, hide_emitters=False, use_mis=False,
                     bsdf_u=None, detach_indirect_si=False, decouple_reparam=False, d_det=None, roughness=None,
-                    normalize_warp_field=True):
+                    normalize_warp_field=True, lobe_u=None):
     """sdf_direct_reparam.py:29-105 for the hit lanes + the environment term of the others (without the
     primary determinant, which the caller multiplies in).  -> rgb (N,3).
     use_mis: emitter sampling weighted by the power heuristic plus the BSDF-sampling branch (:77-105) with `bsdf_u` (N,2) as
@@ -656,8 +730,8 @@ def direct_radiance(sdf, albedo, o, d_att, its_t, emitter_u, reparam, env=1.0, h
     roughness: a (Z,Y,X,1) volume switches the BSDF from `diffuse` (albedo = reflectance) to `principled` (albedo = base_color);
     emitter sampling only.  `reparam` here is the flag of the DEPTH-1 rays (shadow ray :52, BSDF-sampled ray :95): the caller has
     applied warp.py:103 (False under `warpprimary`, max_reparam_depth = 0)."""
-    if roughness is not None and use_mis:
-        raise NotImplementedError("principled + use_mis: Principled::sample is not restated")
+    if roughness is not None and use_mis and lobe_u is None:
+        raise ValueError("principled + use_mis needs `lobe_u`: bsdf.sample's next_1d() selects the lobe (sdf_direct_reparam.py:90)")
     N = o.shape[0]
     dt = o.dtype
     hit = torch.isfinite(its_t)
@@ -697,15 +771,26 @@ def direct_radiance(sdf, albedo, o, d_att, its_t, emitter_u, reparam, env=1.0, h
             wi_w = -dh[fsel]
             wi_l = torch.stack([dot(sf, wi_w), dot(tf, wi_w), dot(nf, wi_w)], -1)
             wo_l = torch.stack([dot(sf, sd_att), dot(tf, sd_att), dot(nf, sd_att)], -1)
-            bsdf = principled_eval(a, eval_trilinear(roughness, p[fsel])[:, 0], wi_l, wo_l)
+            rough_f = eval_trilinear(roughness, p[fsel])[:, 0]
+            bsdf = principled_eval(a, rough_f, wi_l, wo_l)
         contrib = bsdf * (env * 4.0 * math.pi) * (vis * det_e)[:, None]   # emitter_val / ds.pdf ; * det_e (:84)
         if use_mis:                                                     # :78-79 mis_weight(ds.pdf, detach(bsdf_pdf))
-            contrib = contrib * mis_weight(torch.full_like(cos_o, inv_4pi), (cos_o / math.pi).detach())[:, None]
+            bsdf_pdf = (cos_o / math.pi) if roughness is None else principled_pdf(rough_f, wi_l, wo_l)
+            contrib = contrib * mis_weight(torch.full_like(cos_o, inv_4pi), bsdf_pdf.detach())[:, None]
         contrib_all = contrib_all.index_put((fsel,), contrib)
     if use_mis:                                                         # ---- BSDF sampling, :86-105
-        wo = square_to_cosine_hemisphere(bsdf_u[hsel].to(dt))           # bs.wo (local frame of the detached si)
-        pdf_b = wo[:, 2] / math.pi
-        act = (cos_i > 0) & (pdf_b > 0)                                 # diffuse::sample: cos_theta_i > 0; :92 bs.pdf > 0
+        if roughness is None:
+            wo = square_to_cosine_hemisphere(bsdf_u[hsel].to(dt))       # bs.wo (local frame of the detached si)
+            pdf_b = wo[:, 2] / math.pi
+            act = (cos_i > 0) & (pdf_b > 0)                             # diffuse::sample: cos_theta_i > 0; :92 bs.pdf > 0
+        else:                                                           # bsdf.sample(ctx, si_d, next_1d, next_2d): everything detached
+            nd = n.detach()
+            sd_, td_ = coordinate_system(nd)
+            wi_d = -dh.detach()
+            wi_ld = torch.stack([dot(sd_, wi_d), dot(td_, wi_d), dot(nd, wi_d)], -1)
+            rough_d = eval_trilinear(roughness, p.detach())[:, 0].detach()
+            wo, pdf_b, act = principled_sample(rough_d, wi_ld, lobe_u[hsel].to(dt), bsdf_u[hsel].to(dt))
+            wo, pdf_b = wo.detach(), pdf_b.detach()
         bsel = act.nonzero()[:, 0]
         if bsel.numel() > 0:
             nb = n[bsel].detach()
@@ -719,7 +804,14 @@ def direct_radiance(sdf, albedo, o, d_att, its_t, emitter_u, reparam, env=1.0, h
             b_t, _, det_b = warped_ray(sdf, ob, db, torch.full_like(mag, 1e30), reparam, normalize_warp_field)    # :95-96 ray_intersect, depth 1
             escaped = ~torch.isfinite(b_t)                              # si_bsdf invalid -> the environment emitter
             ab = eval_trilinear(albedo, pb)
-            bsdf_val = ab * (wob[:, 2] / math.pi)[:, None]              # :97 bsdf.eval(ctx, si, bs.wo): local wo, cos detached
+            if roughness is None:
+                bsdf_val = ab * (wob[:, 2] / math.pi)[:, None]          # :97 bsdf.eval(ctx, si, bs.wo): local wo, cos detached
+            else:                                                       # ... with the ATTACHED si: frame (n), wi and roughness(p) carry gradients
+                na = n[bsel]
+                sa, ta = coordinate_system(na)
+                wia = -dh[bsel]
+                wi_la = torch.stack([dot(sa, wia), dot(ta, wia), dot(na, wia)], -1)
+                bsdf_val = principled_eval(ab, eval_trilinear(roughness, pb)[:, 0], wi_la, wob)
             emitter_pdf = torch.where(escaped, torch.full_like(pdf_b[bsel], inv_4pi), torch.zeros_like(pdf_b[bsel]))   # :100-102
             w = mis_weight(pdf_b[bsel], emitter_pdf)
             cb = bsdf_val / pdf_b[bsel][:, None] * (env * escaped.to(dt)[:, None]) * (w * det_b)[:, None]   # :104-105
@@ -901,6 +993,11 @@ def independent_sampler_emitter_2d(seed, n):
     return independent_sampler(seed, n, 5)[:, 3:5]
 
 
+def independent_sampler_bsdf_1d(seed, n):
+    """bsdf.sample's `next_1d()` (sdf_direct_reparam.py:90: the lobe selector of `principled`): float 5 of the lane's stream."""
+    return independent_sampler(seed, n, 6)[:, 5]
+
+
 def independent_sampler_bsdf_2d(seed, n):
     """The `next_2d()` of the BSDF-sampling branch (sdf_direct_reparam.py:90-91): after the film position (2 floats), the
     wavelength sample (1), the emitter sample (2) and bsdf.sample's next_1d (1) -- floats 6 and 7 of the lane's stream."""
@@ -965,7 +1062,7 @@ def lane_positions(W, H, spp, offsets):
 def render(sdf, cam, W, H, spp, offsets, integrator=SILHOUETTE, reparam=True,
            return_aux=False, chunk=1 << 17, albedo=None, emitter_u=None, env=1.0, hide_emitters=False, rows=None,
            return_block=False, use_mis=False, bsdf_u=None, detach_indirect_si=False, decouple_reparam=False, light_dir=None,
-           roughness=None, normalize_warp_field=True, max_reparam_depth=-1, aovs=False, antithetic=False):
+           roughness=None, normalize_warp_field=True, max_reparam_depth=-1, aovs=False, antithetic=False, lobe_u=None):
     """One view.  offsets: (Wb*Hb*spp, 2) in [0,1) (the sampler's next_2d per
     lane).  Returns image (H,W,3), differentiable w.r.t. sdf.data / sdf.p when
     they require grad.  `reparam=False` gives the DummyWarpField path
@@ -993,6 +1090,8 @@ def render(sdf, cam, W, H, spp, offsets, integrator=SILHOUETTE, reparam=True,
             emitter_u = emitter_u[lo:hi]
         if bsdf_u is not None:
             bsdf_u = bsdf_u[lo:hi]
+        if lobe_u is not None:
+            lobe_u = lobe_u[lo:hi]
     block = torch.zeros(Hb * Wb * C, dtype=dt)
     aux = dict(steps=0, lanes=0, bbox=0, hits=0, refine=0, warp_active=0)
     # sdf_simple_shading_reparam.py:20 fixes normalize(1,1,1); `light_dir` only serves the change-of-frame test (tests/test_to_world.py)
@@ -1033,7 +1132,7 @@ def render(sdf, cam, W, H, spp, offsets, integrator=SILHOUETTE, reparam=True,
         if integrator == DIRECT:                                         # sdf_direct_reparam.py:16-111
             rgb = direct_radiance(sdf, albedo, o, d_att, its_t, emitter_u[s:s + chunk], reparam1, env, hide_emitters, use_mis,
                                   None if bsdf_u is None else bsdf_u[s:s + chunk], detach_indirect_si, decouple_reparam, d, roughness,
-                                  normalize_warp_field) * div[:, None]
+                                  normalize_warp_field, None if lobe_u is None else lobe_u[s:s + chunk]) * div[:, None]
         elif integrator == SILHOUETTE:                                   # sdf_silhouette_reparam.py:20-22
             val = hit.to(dt) * div
         else:                                                            # sdf_simple_shading_reparam.py:20-22

@@ -308,6 +308,12 @@ def harness_xf(built):
         tl, lo, hi = (np.ascontiguousarray(a, np.float32) for a in (inv[:3, :].reshape(-1), w.min(0), w.max(0)))
         h.lib.hh_set_transform(h._p(tl), h._p(lo), h._p(hi))
     h.set_transform = set_transform
+
+    def set_lobe_samples(u):
+        """Explicit next_1d() of bsdf.sample (the lobe selector of `principled`) for the next render_direct_* calls; None = built-in sampler."""
+        h._lobe = None if u is None else np.ascontiguousarray(u, np.float32)
+        h.lib.hh_set_lobe_samples(h._p(h._lobe))
+    h.set_lobe_samples = set_lobe_samples
     return h
 
 

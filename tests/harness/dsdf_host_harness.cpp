@@ -19,6 +19,9 @@ struct PlainAdd { void operator()(float *p, float v) const { *p += v; } };
 // the transform state of an XF build (csrc/dsdf_math.h): hh_set_transform fills it like dsdf_set_grid_transform does in the library
 namespace dsdf { XfState g_xf_host = {{1, 0, 0, 0, 1, 0, 0, 0, 1}, {0, 0, 0}, {0, 0, 0}, {1, 1, 1}}; }
 extern "C" int hh_has_transform() { return 1; }
+// principled + use_mis: explicit next_1d() samples (the lobe selector) of the next hh_render_direct_* calls, or null = built-in sampler
+static const float *g_lobe_u = nullptr;
+extern "C" void hh_set_lobe_samples(const float *u) { g_lobe_u = u; }
 extern "C" void hh_set_transform(const float *to_local12, const float *lo, const float *hi) {
     for (int r = 0; r < 3; ++r) {
         for (int c = 0; c < 3; ++c) g_xf_host.A[3 * r + c] = to_local12[4 * r + c];
@@ -357,6 +360,9 @@ void hh_render_direct_forward(const float *data, int rx, int ry, int rz, const d
     GridView G = make_view(p.data(), rx, ry, rz, *prm);
     ViewArgs A = view_args(cam, W, H, spp, offsets, seed, DSDF_DIRECT, flags);
     A.emitter_u = emitter_u; A.bsdf_u = bsdf_u;
+#if DSDF_XF
+    A.lobe_u = g_lobe_u;
+#endif
     ShadeArgs S = shade_args(albedo, ax, ay, az, env, hide, nullptr);
     S.use_mis = use_mis; S.variant = variant;
     std::vector<float> block((size_t)4 * A.Wb * A.Hb, 0.f);
@@ -383,6 +389,9 @@ void hh_render_direct_backward(const float *data, int rx, int ry, int rz, const 
     GridView G = make_view(p.data(), rx, ry, rz, *prm);
     ViewArgs A = view_args(cam, W, H, spp, offsets, seed, DSDF_DIRECT, flags);
     A.emitter_u = emitter_u; A.bsdf_u = bsdf_u;
+#if DSDF_XF
+    A.lobe_u = g_lobe_u;
+#endif
     ShadeArgs S = shade_args(albedo, ax, ay, az, env, hide, grad_albedo);
     S.use_mis = use_mis; S.variant = variant;
     std::vector<float> block((size_t)4 * A.Wb * A.Hb, 0.f), badj((size_t)4 * A.Wb * A.Hb, 0.f);
@@ -434,6 +443,9 @@ void hh_render_direct_forward_grad(const float *data, int rx, int ry, int rz, co
     GridView G = make_view(p.data(), rx, ry, rz, *prm);
     ViewArgs A = view_args(cam, W, H, spp, offsets, seed, DSDF_DIRECT, flags);
     A.emitter_u = emitter_u; A.bsdf_u = bsdf_u;
+#if DSDF_XF
+    A.lobe_u = g_lobe_u;
+#endif
     ShadeArgs S = shade_args(albedo, ax, ay, az, env, hide, nullptr);
     S.use_mis = use_mis; S.variant = variant;
     V3 dp = tangent_p ? mk(tangent_p[0], tangent_p[1], tangent_p[2]) : mk(0.f, 0.f, 0.f);
