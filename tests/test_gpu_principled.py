@@ -170,7 +170,7 @@ def test_principled_mis_backward_gpu(dsdf, name):
     print(f"gpu principled+mis {name}: dL/d data {e[0]:.3e} (gate {tols[1]:.3e}), base_color {e[1]:.3e} ({tols[2]:.3e}), roughness {e[2]:.3e} ({tols[3]:.3e})")
     assert e[1] < tols[2] and e[2] < tols[3], (e, tols)
     from test_refshim_fixture import check_fp32_gradient          # (plain gate; one heavy-tailed sample footprint may be set aside)
-    check_fp32_gradient('principled_mis_gpu', name, 'direct_mis', gg.cpu().numpy(), gd.numpy() if hasattr(gd, 'numpy') else gd, tols[1])
+    check_fp32_gradient('principled_mis_gpu', name, 'direct_mis', gg.cpu().numpy(), gd, tols[1])
     # the default library keeps refusing the combination
     with pytest.raises(dsdf.DsdfError):
         dsdf.render_forward(dsdf.SdfGrid(case['grid'].float().cuda()), sen, 4, seeds=[1], integrator='sdf_direct_reparam', shading=sh)
