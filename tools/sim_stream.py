@@ -82,3 +82,41 @@ def stream_h(p,H=8,G=4):
 r=[stream_h(p) for p in S]
 w_sh=sum(a for a,_ in r); left2=sum(b for _,b in r)
 print('streaming + hand-off(8,4): wave-iterations',w_sh,'in-kernel utilisation',(lane-left2)/(64*w_sh),'handed off',left2/lane,'vs chunked+hand-off',w_sh/w_h.sum())
+
+
+# (e) streaming with BATCHED refills: the lane-setup code (sampler, camera ray: ~190 instructions) runs for the whole wave whenever some
+# lanes start a new sample, so lanes wait until at least `batch` of them are idle (or nothing is marching); counts wave iterations and
+# refill events per pixel
+def stream_batched(p, batch=16, H=8, G=4):
+    p = list(p)
+    nxt = 64
+    rem = p[:64]                      # remaining steps of the sample each lane holds (0 = idle)
+    it = refills = 0
+    stop_at = None
+    while True:
+        active = sum(1 for r in rem if r > 0)
+        idle = [i for i, r in enumerate(rem) if r == 0]
+        if nxt < len(p) and idle and (len(idle) >= batch or active == 0):
+            for i in idle:
+                if nxt < len(p):
+                    rem[i] = p[nxt]; nxt += 1
+            refills += 1
+            continue
+        if active == 0:
+            return it, refills, 0
+        if nxt >= len(p) and active <= H:
+            if stop_at is None:
+                stop_at = it + G
+            if it >= stop_at:
+                return it, refills, sum(rem)
+        step = 1
+        rem = [r - step if r > 0 else 0 for r in rem]
+        it += 1
+
+
+for batch in (1, 8, 16, 32, 48, 56):
+    r = [stream_batched(p, batch) for p in S[:600]]
+    wi, rf, lf = sum(a for a, _, _ in r), sum(b for _, b, _ in r), sum(c for _, _, c in r)
+    base = handoff(S[:600].reshape(-1, 4, 64))
+    print(f'batched refill >= {batch:2d} idle lanes: wave-iterations {wi} ({wi / base[0].sum():.3f} of chunked+hand-off), refill events per pixel {rf / 600:.1f} '
+          f'(chunked: 3), handed off {lf / S[:600].sum():.4f} (chunked {base[1] / S[:600].sum():.4f})')
