@@ -406,6 +406,48 @@ def test_world_space_kernel_math_direct_matches_reference_code(harness_xf):
     assert ep < max(P.FLOOR_FACTOR * fp, 2 * e, P.NORTH_STAR) and ea < max(P.FLOOR_FACTOR * fa, P.NORTH_STAR), (ep, fp, ea, fa)
 
 
+def test_world_space_kernel_math_with_scale_and_shear(harness_xf):
+    """An affine `to_world` with a non-uniform SCALE and a shear on top of the rotation (to_local3 is neither orthogonal nor
+    symmetric: the transposes in g <- A^T g, H <- A^T H A and cg <- A cg matter): the world-space host build against the oracle's
+    literal restatement of python/shapes.py:408-450 (pinned to the reference's code for rotations, matrix-generic)."""
+    from test_refshim_fixture import inputs, check_fp32_gradient
+    import precision as P
+    ref = _ref16()
+    x = inputs(ref)
+    rel = lambda a, b: float(np.linalg.norm(np.asarray(a, np.float64) - b) / np.linalg.norm(b))
+    L = rot(1, 25) @ np.diag([0.9, 1.1, 0.8]) @ np.array([[1.0, 0.15, 0.0], [0.0, 1.0, 0.0], [0.05, 0.0, 1.0]])
+    T = about_centre(L, (0.01, 0.0, -0.02))
+    p0 = torch.from_numpy(ref['tf_p'])
+    h = harness_xf
+    h.set_transform(T)
+    old = [h.params.sdf_p[k] for k in range(3)]
+    try:
+        for k in range(3):
+            h.params.sdf_p[k] = float(p0[k])
+        osdf = O.Grid3d(x['grid'], p0, T)
+        pts = ref['eval_pts']
+        v, g, H = h.eval_cubic(ref['grid'], pts, 2)
+        ov, _, og, _, oH = osdf.eval_all(torch.from_numpy(pts).double())
+        oH6 = torch.stack([oH[:, 0, 0], oH[:, 1, 1], oH[:, 2, 2], oH[:, 0, 1], oH[:, 0, 2], oH[:, 1, 2]], -1)
+        assert rel(v, ov.numpy()) < 1e-6 and rel(g, og.numpy()) < 1e-6 and rel(H, oH6.numpy()) < 1e-5
+        for tag, integ in (('sil', O.SILHOUETTE), ('shade', O.SIMPLE_SHADING)):
+            def oracle(dt):
+                d_, p_ = x['grid'].to(dt).clone().requires_grad_(True), p0.to(dt).clone().requires_grad_(True)
+                cam = O.Camera.from_params(x['cam'].params(), dtype=dt)
+                img = O.render(O.Grid3d(d_, p_, T), cam, x['W'], x['H'], x['spp'], x['offs'].to(dt), integ, True)
+                (img * x['gi'].to(dt)).sum().backward()
+                return img.detach(), d_.grad, p_.grad
+            (img_ref, gd, gp), tols = P.torch_gate(oracle)
+            gg, img = h.render_backward(ref['grid'], ref['cam16'], x['W'], x['H'], x['spp'], ref['sampler_2d'], ref['grad_image'], integ)
+            assert rel(img, img_ref) < 1e-4
+            e = check_fp32_gradient('host_xf_affine', 'sphere16', f'affine_{tag}', gg, gd, tols[1])
+            assert rel(h.last_grad_p, gp) < max(tols[2], 2 * e), (rel(h.last_grad_p, gp), tols[2], e)
+    finally:
+        for k in range(3):
+            h.params.sdf_p[k] = old[k]
+        h.set_transform(np.eye(4))
+
+
 @pytest.mark.gpu
 def test_transformed_grid_matches_reference_code_gpu(built):
     """The HIP path with `Grid3d(data, transform=AXIS_ALIGNED)`, sdf.p and the WORLD sensor against what the reference's own
