@@ -7,7 +7,11 @@ counts of the silhouette band of one bench view (every other row of the central 
     chunked + hand-off(8,4)    497 k wave iterations, in-kernel utilisation 0.75, 4.2 % of the lane-steps handed off
     streaming + hand-off(8,4)  428 k wave iterations (-14 %), utilisation 0.90, 1.5 % handed off (-65 % tail work)
 For the silhouette primal the film side needs nothing new: a sample's value is its hit flag (4 bits per lane), the four film passes
-of the pixel run after its march exactly as today.  DESIGN.md section 10 lists it as the first experiment of round 5."""
+of the pixel run after its march exactly as today.  DESIGN.md section 10 lists it as the first experiment of round 5.
+Also replayed: refills batched until N lanes are idle (a refill runs the ~190-instruction lane setup for the whole wave), and a variant
+that keeps today's chunks but lets the <= 8 leftover rays stay in their lanes while the samples those lanes would have started go to
+the tail queue as FRESH rays (+1 % march iterations, +27 % tail lane-steps, longest tail chain unchanged: not worth building -- the end
+phase is the one extremely long ray of a view, which no re-packing shortens)."""
 import os, sys, heapq, time
 import numpy as np, torch
 ROOT=os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -120,3 +124,42 @@ for batch in (1, 8, 16, 32, 48, 56):
     base = handoff(S[:600].reshape(-1, 4, 64))
     print(f'batched refill >= {batch:2d} idle lanes: wave-iterations {wi} ({wi / base[0].sum():.3f} of chunked+hand-off), refill events per pixel {rf / 600:.1f} '
           f'(chunked: 3), handed off {lf / S[:600].sum():.4f} (chunked {base[1] / S[:600].sum():.4f})')
+
+
+# (f) "hand off the FRESH sample": chunks as today, but at a chunk boundary the <= H rays still marching STAY in their lanes and the
+# samples those lanes would have started go to the tail queue as fresh rays (ordinary, short).  Only the last chunk hands off ray states.
+def carry_fresh(p, H=8, G=4):
+    c = np.asarray(p).reshape(4, 64)
+    rem = np.zeros(64, np.int64)
+    it = 0
+    tail_steps, tail_chain = 0, 0
+    for k in range(4):
+        busy = rem > 0
+        fresh_out = c[k][busy]                     # samples of busy lanes -> tail, from their start
+        tail_steps += int(fresh_out.sum()); tail_chain = max(tail_chain, int(fresh_out.max()) if fresh_out.size else 0)
+        rem = np.where(busy, rem, c[k])
+        srt = np.sort(rem)[::-1]
+        stop = min(int(srt[H]) + G, int(srt[0]))   # iterations of this chunk's loop
+        it += stop
+        rem = np.clip(rem - stop, 0, None)
+    tail_steps += int(rem.sum()); tail_chain = max(tail_chain, int(rem.max()))
+    return it, tail_steps, tail_chain
+
+
+def chunked_tail(p, H=8, G=4):
+    c = np.asarray(p).reshape(4, 64)
+    it = ts = ch = 0
+    for k in range(4):
+        srt = np.sort(c[k])[::-1]
+        stop = min(int(srt[H]) + G, int(srt[0]))
+        left = np.clip(c[k] - stop, 0, None)
+        it += stop; ts += int(left.sum()); ch = max(ch, int(left.max()))
+    return it, ts, ch
+
+
+a = np.array([chunked_tail(p) for p in S])
+b = np.array([carry_fresh(p) for p in S])
+print(f'chunked + hand-off      : wave-iterations {a[:, 0].sum()}, tail lane-steps {a[:, 1].sum()} ({a[:, 1].sum() / lane:.4f}), longest tail chain {a[:, 2].max()}, '
+      f'mean of the per-pixel longest {a[:, 2].mean():.1f}, 99th percentile {np.percentile(a[:, 2], 99):.0f}')
+print(f'carry + fresh hand-off  : wave-iterations {b[:, 0].sum()} ({b[:, 0].sum() / a[:, 0].sum():.3f}), tail lane-steps {b[:, 1].sum()} ({b[:, 1].sum() / lane:.4f}), '
+      f'longest tail chain {b[:, 2].max()}, mean of the per-pixel longest {b[:, 2].mean():.1f}, 99th percentile {np.percentile(b[:, 2], 99):.0f}')
