@@ -191,8 +191,13 @@ def main():
     if args.config_table:
         import json
         fn = os.path.join(args.out, f'{prefix}_config_table.json')
-        with open(fn, 'w') as f:
-            json.dump(config_table(), f, indent=0, sort_keys=True)
+        t = config_table()
+        with open(fn, 'w') as f:                          # one opt-config per line
+            f.write('{"method": ' + json.dumps(t['method'], sort_keys=True) + ',\n"skipped": ' + json.dumps(t['skipped']) + ',\n"opt": {\n')
+            names = sorted(t['opt'])
+            for i, n in enumerate(names):
+                f.write(json.dumps(n) + ': ' + json.dumps(t['opt'][n], sort_keys=True) + (',\n' if i + 1 < len(names) else '\n'))
+            f.write('}}\n')
         print(fn)
         return
 
