@@ -153,6 +153,8 @@ class ReparamIntegrator:
         when the warp field has `return_aovs` set (reparam.py:163-165, warp.py:105-106) and zero otherwise, like in the reference."""
         if not develop:
             raise Exception("Must use develop=True for this AD integrator")
+        if self.use_aovs and self.antithetic_sampling:
+            raise NotImplementedError("use_aovs together with antithetic_sampling: the debug channels are rendered for one sample set")
         sens = self._sensors(scene, sensor)
         reparam = self._configured()
         seeds = [seed + i for i in range(len(sens))]
@@ -162,8 +164,6 @@ class ReparamIntegrator:
             img = dsdf.render_forward(self.sdf.grid, sens, spp or 4, seeds=seeds,
                                       integrator=self.integrator_id, reparam=reparam, shading=self.shading())
         if self.use_aovs:
-            if self.antithetic_sampling:
-                raise NotImplementedError("use_aovs together with antithetic_sampling: the debug channels are rendered for one sample set")
             wf = self.warp_field
             if wf is not None and reparam and getattr(wf, 'return_aovs', False):
                 aov = dsdf.render_aovs(self.sdf.grid, sens, spp or 4, seeds=seeds)        # (the primary ray: depth 0 passes warp.py:103 for any max_reparam_depth)
