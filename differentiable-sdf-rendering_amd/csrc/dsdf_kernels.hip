@@ -220,6 +220,12 @@ __device__ __forceinline__ void load_record(const float *r, size_t c, TraceOut &
 #ifndef DSDF_DIFF_MINWAVES
 #define DSDF_DIFF_MINWAVES 1
 #endif
+#ifndef DSDF_STREAM_DEFAULT
+#define DSDF_STREAM_DEFAULT 0
+#endif
+#ifndef DSDF_SWEEP_CACHE
+#define DSDF_SWEEP_CACHE 0
+#endif
 
 __device__ __forceinline__ void clear_trace(TraceOut &tr) {
     tr.its_t = INFINITY; tr.warp_t = INFINITY; tr.warp_weight = 0.f; tr.weight_sum = 0.f;
@@ -393,7 +399,11 @@ void k_render_items(GridView G, dsdf_params P, ViewBatch VB, float *__restrict__
         else if (!skip_trace) {
             // (the last few rays of the wave are handed to the tail queue: dsdf_tail.h)
             if (DIFF) {
+#if DSDF_SWEEP_CACHE
+                WaveCellCache F; F.taps = wave_lds; F.lid = lid;     // (A/B: the wave cell cache of the primal march for the Hessian march)
+#else
                 DirectFetch F;
+#endif
                 if (!DIRECT && tq.state) {
                     HandOff ho;
                     ho.tq = tq; ho.sub = tq.per_xcd ? my_subq : item % DSDF_TAIL_SUBQ; ho.view = view; ho.lane = lane;
@@ -435,6 +445,8 @@ void k_render_items(GridView G, dsdf_params P, ViewBatch VB, float *__restrict__
     }
     if (STATS) flush_stats(stats, wst, blockIdx.x, lid);
 }
+
+#include "dsdf_stream.h"
 
 // Thread -> sample of the general pass.  The reference's lane order (lane = pixel * spp + sample, pixels row-major,
 // reparam.py:140-155) is only a convention -- the sampler is keyed by the lane index, so any thread may render any lane.
@@ -1173,7 +1185,13 @@ static bool deep_skip_enabled() { static const int v = env_int("DSDF_DEEP_SKIP",
 // tail appended.  Measured (profiles/r04_tail_ab.md): the early launch is starved by the primal workers just like the tail kernel
 // (15 ms resident), and the tail kernel then starts later: step 42.5 vs 40.8 ms.  Default: one launch behind the tail kernel.
 static bool coef_early_enabled() { static const int v = env_int("DSDF_COEF_EARLY", 0); return v != 0; }
+// DSDF_TAIL_LONG=n: a tail wave holding a ray older than n of its iterations stops refilling (dsdf_tail.h); 0: off
+static int tail_hold_after() { static const int v = env_int("DSDF_TAIL_LONG", DSDF_TAIL_LONG); return v < 0 ? 0 : v; }
 static int hit_proof_min_spp() { static const int v = env_int("DSDF_HIT_PROOF_MIN_SPP", 16); return v; }
+// DSDF_STREAM=1: the primal render of the one-channel integrators streams the samples of a pixel through one wave (k_render_stream,
+// dsdf_stream.h) instead of marching them in lock-step chunks; DSDF_STREAM_SEG_LOG2: log2 of the pixels per list segment (= tile)
+static bool stream_enabled() { static const int v = env_int("DSDF_STREAM", DSDF_STREAM_DEFAULT); return v != 0; }
+static int stream_seg_log2() { static const int v = env_int("DSDF_STREAM_SEG_LOG2", 10); return v < 4 ? 4 : (v > 14 ? 14 : v); }
 static bool primal_handoff() { static const int v = env_int("DSDF_PRIMAL_HANDOFF", 1); return v != 0; }
 static int tail_streams_enabled() { static int v = env_int("DSDF_TAIL_STREAMS", 1); return v; }
 // blocks (4 waves) per sub-queue of a tail kernel: DSDF_TAIL_BLOCKS overrides the built-in value
@@ -1338,9 +1356,11 @@ static int run_pass(PassCtx &c, const Workspace &ws, const dsdf_camera *cams, in
         if (hipMemsetAsync(ws.items, 0, (size_t)DSDF_MAX_GROUPS * DSDF_ITEM_HDR * sizeof(uint32_t), st) != hipSuccess)
             return fail(DSDF_ERR_LAUNCH, "hipMemsetAsync(work list) failed");
         // tile-major order: a tile = DSDF_ITEM_SEG chunks of 64 samples (16 x 16 pixels at 256 spp, 32 x 32 at 64 spp)
+        // (the streaming primal kernel takes whole pixels: a tile = one segment of 2^seg pixels)
+        const bool stream = !DIFF && !c.direct && stream_enabled();
         ItemOrder O;
         {
-            unsigned tile_px = DSDF_ITEM_SEG / (unsigned)(c.spp / 64);
+            unsigned tile_px = stream ? (1u << stream_seg_log2()) : DSDF_ITEM_SEG / (unsigned)(c.spp / 64);
             if (tile_px < 1) tile_px = 1;
             int lg = 0;
             while ((2u << lg) <= tile_px) ++lg;
@@ -1389,11 +1409,15 @@ static int run_pass(PassCtx &c, const Workspace &ws, const dsdf_camera *cams, in
             if (handoff) {
                 tq.cap_sub = ws.tail_cap_sub * (uint32_t)kreg;
                 tq.per_xcd = (uint32_t)tail_per_xcd();
+                tq.hold_after = (uint32_t)tail_hold_after();
                 tq.count = (uint32_t *)ws.tail + (size_t)g * DSDF_TAIL_SUBQ * 2;
                 tq.state = (float *)(ws.tail + cnt_bytes + (size_t)g * kreg * grp_bytes);
             }
             if (g == 0) timing_mark(0, st);
-            if (c.direct) {
+            if (stream) {
+                if (st64) hipLaunchKernelGGL((k_render_stream<true>), grid, blk, 0, st, G, c.pp, VB, film, st64, skip, tq, hdr, list, (uint32_t)stream_seg_log2());
+                else hipLaunchKernelGGL((k_render_stream<false>), grid, blk, 0, st, G, c.pp, VB, film, st64, skip, tq, hdr, list, (uint32_t)stream_seg_log2());
+            } else if (c.direct) {
                 if (st64) hipLaunchKernelGGL((k_render_items<DIFF, true, true>), grid, blk, 0, st, G, c.pp, VB, film, q, st64, skip, S, tq, hdr, list);
                 else hipLaunchKernelGGL((k_render_items<DIFF, true, false>), grid, blk, 0, st, G, c.pp, VB, film, q, st64, skip, S, tq, hdr, list);
             } else {

@@ -32,14 +32,20 @@ if '--shade' in sys.argv:
     out['shade_grad64'] = t(lambda: dsdf.render_backward(grid, sens, 64, gi, grad_grid=g, seeds=S, integrator=1), 3)
 if '--low' in sys.argv:
     out['step_4_1'] = t(lambda: dsdf.render_step(grid, sens, 4, 1, lambda im: gi, g, S, [s + 100 for s in S]), 20)
-a = dsdf.render_forward(grid, sens, 256, seeds=S).double()
+st = dsdf.new_stats(dev)
+a = dsdf.render_forward(grid, sens, 256, seeds=S, stats=st).double()
 cs = {'img256': [float(a.sum()), float((a * a).sum())]}
+sd = dsdf.stats_dict(st)
+out['primal_stats'] = {k: sd[k] for k in ('lanes', 'steps', 'hits', 'wave_steps', 'tail_rays', 'tail_steps', 'tail_wave_steps') if k in sd}
 g.zero_()
 dsdf.render_backward(grid, sens, 64, gi, grad_grid=g, seeds=S)
 cs['grad64'] = [float(g.double().abs().sum()), float((g.double() ** 2).sum())]
 if '--shade' in sys.argv:
-    a = dsdf.render_forward(grid, sens, 256, seeds=S, integrator=1).double()
+    st = dsdf.new_stats(dev)
+    a = dsdf.render_forward(grid, sens, 256, seeds=S, integrator=1, stats=st).double()
     cs['img256_shade'] = [float(a.sum()), float((a * a).sum())]
+    sd = dsdf.stats_dict(st)
+    out['shade_stats'] = {k: sd[k] for k in ('lanes', 'steps', 'hits', 'refine_steps', 'wave_steps', 'tail_rays') if k in sd}
     g.zero_()
     dsdf.render_backward(grid, sens, 64, gi, grad_grid=g, seeds=S, integrator=1)
     cs['grad64_shade'] = [float(g.double().abs().sum()), float((g.double() ** 2).sum())]
