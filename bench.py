@@ -204,6 +204,75 @@ def direct_block(args, dev, grid, sensors, steps=4):
     return out
 
 
+
+def scaling_prediction_block(args, dev, grid, target, ring, t1_ms, steps=3):
+    """PREDICTED strong-scaling curve from ONE GPU (no xGMI is measured here): for N = 2, 4, 8 every rank's shard of the N-way
+    split -- the partition a real run uses (parallel.strided_view_shard for whole views, parallel.work_partition / render_step
+    with pixel-row windows when N does not divide the views) -- is rendered ALONE on this GPU with the code path that rank
+    would execute, and timed.  A step of the N-GPU job takes max over ranks of that time; the one exchange (a ring all-reduce
+    of dL/dsdf, 2 (N - 1) / N x S bytes per GPU over one ~153 GB/s xGMI link per direction) is issued
+    non-blocking and overlaps the next step, so it only shows where it exceeds the compute; split views add two film
+    all-reduces (2 x views x 2 MiB) that are NOT overlapped.  `--emulate-rank r/N` runs a single (r, N)."""
+    import dsdf
+    from dsdf import parallel
+    scale = 1.0 / (args.img * args.img * 3)
+    S = 4.0 * args.res ** 3
+    link = 153e9
+    grad = torch.zeros(args.res, args.res, args.res, device=dev)
+    tgt_all = torch.cat([dsdf.render_forward(target, s, 64, seeds=[1000 + i]) for i, s in enumerate(ring)])
+
+    def rank_ms(r, N):
+        split = args.views % N != 0
+        if not split:
+            mine = parallel.strided_view_shard(list(range(args.views)), r, N)
+            sensors = [ring[i] for i in mine]
+            tgt = tgt_all[mine]
+
+            def step(it):
+                seeds = [(it * args.views + i) * 2 for i in mine]
+                grad.zero_()
+                dsdf.render_step(grid, sensors, args.spp_primal, args.spp_grad, lambda im: torch.sign(im - tgt) * scale, grad, seeds,
+                                 [x + 1 for x in seeds], integrator=args.integrator)
+        else:
+            seeds0 = [i * 2 for i in range(args.views)]
+            ops = parallel.HipOps(grid, ring, args.spp_primal, args.spp_grad, seeds0, [x + 1 for x in seeds0], args.integrator,
+                                  two_streams=bool(args.overlap))
+
+            def step(it):
+                seeds = [(it * args.views + i) * 2 for i in range(args.views)]
+                ops.set_seeds(seeds, [x + 1 for x in seeds])
+                grad.zero_()
+                parallel.render_step(ops, args.views, args.img, args.img, r, N, lambda im, views: torch.sign(im - tgt_all[views]) * scale,
+                                     grad, gather_images=False)
+        step(0)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k in range(steps):
+            step(1 + k)
+        torch.cuda.synchronize()
+        ms = 1e3 * (time.perf_counter() - t0) / steps
+        dsdf.release_workspaces()
+        return ms
+
+    if args.emulate_rank:
+        r, N = (int(x) for x in args.emulate_rank.split('/'))
+        return {"emulated_rank": r, "world": N, "ms_per_step": rank_ms(r, N)}
+    rows = []
+    for N in (2, 4, 8):
+        per = [rank_ms(r, N) for r in range(N)]
+        split = args.views % N != 0
+        ar = 1e3 * 2.0 * (N - 1) / N * S / link
+        film = 1e3 * 2.0 * (2.0 * (N - 1) / N * args.views * (args.img + 4) ** 2 * 2 * 4 / link) if split else 0.0
+        comp = max(per)
+        pred = max(comp + film, ar)
+        rows.append({"n_gpus": N, "partition": "pixel-row windows" if split else "whole views", "rank_ms": [round(x, 3) for x in per],
+                     "compute_ms_max_over_ranks": comp, "allreduce_ms_model": ar, "film_exchange_ms_model": film,
+                     "predicted_ms_per_step": pred, "predicted_speedup": t1_ms / pred, "predicted_efficiency": t1_ms / pred / N})
+    return {"label": "PREDICTED from single-GPU shard timings + a link model; no xGMI / RCCL transfer between two GPUs was measured",
+            "one_gpu_ms_per_step": t1_ms, "allreduce_model": "ring, 2 (N - 1) / N x 4 R^3 bytes per GPU at 153 GB/s per link direction, overlapped "
+            "with the next step's rendering (bench.py issues it non-blocking on alternating gradient buffers)", "rows": rows}
+
+
 def opt_iteration_block(args, dev, data0, ring, iters=6):
     """One whole optimiser iteration (python/shape_opt.py:75-105) at the headline sizes, with the host modules the CLI uses:
     a batch of 6 of the 12 views (opt_configs.py:245) rendered through the autograd op (primal 256 spp, gradient pass 64 spp),
@@ -287,6 +356,8 @@ def main():
     ap.add_argument('--no-low-spp', action='store_true')
     ap.add_argument('--no-direct', action='store_true')
     ap.add_argument('--no-opt-iteration', action='store_true')
+    ap.add_argument('--no-scaling-prediction', action='store_true')
+    ap.add_argument('--emulate-rank', default='', help="r/N: time rank r's shard of an N-GPU strong-scaling run alone on this GPU (scaling_prediction)")
     ap.add_argument('--overlap', type=int, default=1, help='1: primal pass and gradient sweep on two HIP streams (dsdf.render_step)')
     args = ap.parse_args()
 
@@ -565,6 +636,10 @@ def main():
         if not args.no_opt_iteration:
             dsdf.release_workspaces()
             opt_it = opt_iteration_block(args, dev, data, ring)
+    scaling_pred = None
+    if world == 1 and dist is None and args.scaling == 'strong' and (args.emulate_rank or not args.no_scaling_prediction):
+        dsdf.release_workspaces()
+        scaling_pred = scaling_prediction_block(args, dev, grid, target, ring, 1e3 * elapsed / args.steps)
 
     if rank == 0:
         strong = args.scaling == 'strong'
@@ -591,6 +666,8 @@ def main():
             out["direct"] = direct
         if opt_it is not None:
             out["opt_iteration"] = opt_it
+        if scaling_pred is not None:
+            out["scaling_prediction"] = scaling_pred
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args)
         print(json.dumps(out))

@@ -1750,20 +1750,31 @@ int dsdf_has_grid_transform(void) { return DSDF_XF; }
 int dsdf_set_grid_transform(const float *to_local, const float *aabb_lo, const float *aabb_hi, void *stream) {
 #if DSDF_XF
     if (!to_local || !aabb_lo || !aabb_hi) return fail(DSDF_ERR_INVALID_ARG, "dsdf_set_grid_transform: null pointer argument");
-    // (source of an asynchronous copy from pageable memory: a slot of a small ring, not the stack)
-    static thread_local XfState ring[32];
-    static thread_local unsigned next = 0;
-    XfState &st = ring[next++ % 32u];
+    XfState st;
     for (int r = 0; r < 3; ++r) {
         for (int c = 0; c < 3; ++c) st.A[3 * r + c] = to_local[4 * r + c];
         st.b[r] = to_local[4 * r + 3];
         st.lo[r] = aabb_lo[r]; st.hi[r] = aabb_hi[r];
         if (!(aabb_lo[r] < aabb_hi[r])) return fail(DSDF_ERR_INVALID_ARG, "dsdf_set_grid_transform: empty bounding box");
     }
+    // The transform is ONE __constant__ block per library instance and device: kernels of EARLIER calls, on any stream, may still be
+    // reading it.  Setting the transform it already holds is free (the common case: one transformed grid per process); a CHANGE
+    // waits for the whole device first and is written synchronously -- two grids with different transforms can therefore be used
+    // alternately from several streams or threads without a launch ever seeing the other grid's transform; they just do not
+    // overlap.  (This build serves configurations no reference config uses; it is not tuned for switching.)
+    static std::mutex mu;
+    static std::vector<std::pair<int, XfState>> current;      // per device: what g_xf_dev holds
+    std::lock_guard<std::mutex> lock(mu);
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return fail(DSDF_ERR_LAUNCH, "dsdf_set_grid_transform: hipGetDevice failed");
+    XfState *cur = nullptr;
+    for (auto &e : current) if (e.first == dev) cur = &e.second;
     g_xf_host = st;
-    // (stream-ordered like every launch of the library: calls enqueued before it keep the transform they were enqueued with)
-    if (hipMemcpyToSymbolAsync(HIP_SYMBOL(g_xf_dev), &st, sizeof(st), 0, hipMemcpyHostToDevice, (hipStream_t)stream) != hipSuccess)
-        return fail(DSDF_ERR_LAUNCH, "dsdf_set_grid_transform: hipMemcpyToSymbolAsync failed");
+    if (cur && memcmp(cur, &st, sizeof(st)) == 0) return DSDF_OK;
+    (void)stream;
+    if (hipDeviceSynchronize() != hipSuccess || hipMemcpyToSymbol(HIP_SYMBOL(g_xf_dev), &st, sizeof(st), 0, hipMemcpyHostToDevice) != hipSuccess)
+        return fail(DSDF_ERR_LAUNCH, "dsdf_set_grid_transform: hipMemcpyToSymbol failed");
+    if (cur) *cur = st; else current.push_back(std::make_pair(dev, st));
     return DSDF_OK;
 #else
     (void)to_local; (void)aabb_lo; (void)aabb_hi; (void)stream;

@@ -112,13 +112,22 @@ def _open(path):
         lib = C.CDLL(path)
     except OSError as e:
         raise DsdfError(f"cannot load {path}: {e}") from e
+    rebuild = "rebuild (`python -c 'import __graft_entry__ as g; g.build()'`)"
+    # the version FIRST: a stale .so is the one case this check exists for, and it also lacks the newer entry points
+    try:
+        ver = lib.dsdf_version
+    except AttributeError as e:
+        raise DsdfError(f"{path} does not export dsdf_version: not this library, or a stale build -- {rebuild}") from e
+    ver.restype, ver.argtypes = SYMBOLS['dsdf_version']
+    if ver() != ABI_VERSION:                             # a stale .so would read the structs above with another layout
+        raise DsdfError(f"{path} is version {ver()}, the binding expects {ABI_VERSION}: {rebuild}")
     for name, (res, args) in SYMBOLS.items():
-        fn = getattr(lib, name)
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise DsdfError(f"{path} does not export {name} although it reports ABI {ABI_VERSION}: {rebuild}") from e
         fn.restype = res
         fn.argtypes = args
-    if lib.dsdf_version() != ABI_VERSION:                # a stale .so would read the structs above with another layout
-        raise DsdfError(f"{path} is version {lib.dsdf_version()}, the binding expects {ABI_VERSION}: rebuild "
-                        f"(`python -c 'import __graft_entry__ as g; g.build()'`)")
     return lib
 
 

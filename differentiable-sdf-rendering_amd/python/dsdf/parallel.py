@@ -99,22 +99,28 @@ def render_step(ops, n_views, W, H, rank, world, loss_grad, grad_grid, group=Non
     wins = rank_windows(units)
     split = world // math.gcd(n_views, world) > 1
     mine = sorted({v for v, _, _ in units})
-    # ---- gradient-pass sweeps first: independent of the primal images (HIP: a side stream)
+    # ---- per row window: the gradient-pass sweep (independent of the primal images; HIP: a side stream) and the primal film of
+    # the same views, bracketed so that the two passes share ONE per-pixel proof (ops.begin_group / end_group: the sweep writes the
+    # flags, the film waits for them -- which also puts the film's small kernels in front of the sweep's persistent workers; without
+    # the bracket they were found waiting 2.7 ms for a wave slot, profiles/r05_ab.md)
     if hasattr(ops, 'begin_sweeps'):
         ops.begin_sweeps()
-    swept = []
+    swept, film = [], None
     for rows, views in wins:
-        f, h = ops.sweep(views, rows)
-        swept.append((views, f, h))                       # (the films are summed after join_sweeps(): they may still be in flight)
-    if hasattr(ops, 'end_sweeps'):
-        ops.end_sweeps()
-    # ---- primal films
-    film = None
-    for rows, views in wins:
-        f = ops.film(views, rows)
+        if hasattr(ops, 'begin_group'):
+            ops.begin_group(views)
+        try:
+            fg, h = ops.sweep(views, rows)
+            swept.append((views, fg, h))                  # (the films are summed after join_sweeps(): they may still be in flight)
+            f = ops.film(views, rows)
+        finally:
+            if hasattr(ops, 'end_group'):
+                ops.end_group()
         if film is None:
             film = torch.zeros((n_views,) + tuple(f.shape[1:]), dtype=f.dtype, device=f.device)
         film[views] += f
+    if hasattr(ops, 'end_sweeps'):
+        ops.end_sweeps()
     if film is None:
         film = ops.empty_film(n_views)
     if split:
@@ -186,6 +192,23 @@ class HipOps:
 
     def develop(self, film):
         return self.r.develop(film, self.W, self.H, self.integrator)
+
+    # ---- one per-pixel proof for the sweep and the film of a window group (dsdf_share_pixel_skip, as dsdf.step_begin does)
+    def begin_group(self, views):
+        import torch
+        from . import _lib
+        dev = self.grid.device
+        n = len(views) * (self.W + 4) * (self.H + 4)
+        if getattr(self, '_flags', None) is None or self._flags.numel() < n:
+            self._flags = torch.empty(n, dtype=torch.uint8, device=dev)
+        self._share_lib = self.grid.lib(self.r._needs_extended(self.kw.get('shading')))
+        with torch.cuda.device(dev):
+            _lib.check(self._share_lib.dsdf_share_pixel_skip(self.r._ptr(self._flags), self._flags.numel()))
+
+    def end_group(self):
+        import torch
+        with torch.cuda.device(self.grid.device):
+            self._share_lib.dsdf_share_pixel_skip(None, 0)
 
     # ---- sweeps: on the side stream, between begin_sweeps() and end_sweeps(); joined before the backward
     def begin_sweeps(self):
@@ -294,24 +317,33 @@ def all_reduce_gradients(tensors, group=None, async_op=False, force=False):
             works.append(dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group, async_op=async_op))
         else:
             small.append(t)
-    unpack = None
-    if small:
-        n = sum(t.numel() for t in small)
-        key = (small[0].device, small[0].dtype, n)
-        flat = _small_buckets.get(key)
-        if flat is None:
-            flat = _small_buckets[key] = torch.empty(n, dtype=small[0].dtype, device=small[0].device)
+    unpacks = []
+    by_dtype = {}
+    for t in small:                                       # (one bucket per dtype: nothing is cast)
+        by_dtype.setdefault(t.dtype, []).append(t)
+    for dtype, group_ts in by_dtype.items():
+        n = sum(t.numel() for t in group_ts)
+        if async_op:
+            # a non-blocking reduce owns its bucket until wait(): overlapping calls must not share one
+            flat = torch.empty(n, dtype=dtype, device=group_ts[0].device)
+        else:
+            key = (group_ts[0].device, dtype, n)
+            flat = _small_buckets.get(key)
+            if flat is None:
+                flat = _small_buckets[key] = torch.empty(n, dtype=dtype, device=group_ts[0].device)
         off = 0
-        for t in small:
+        for t in group_ts:
             flat[off:off + t.numel()].copy_(t.reshape(-1))
             off += t.numel()
         works.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group, async_op=async_op))
 
-        def unpack():
+        def _unpack(flat=flat, group_ts=group_ts):
             o = 0
-            for t in small:
+            for t in group_ts:
                 t.copy_(flat[o:o + t.numel()].view_as(t))
                 o += t.numel()
+        unpacks.append(_unpack)
+    unpack = (lambda: [u() for u in unpacks]) if unpacks else None
     if not async_op:
         if unpack:
             unpack()

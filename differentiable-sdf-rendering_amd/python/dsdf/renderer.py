@@ -94,6 +94,7 @@ class SdfGrid:
         self.params = params if params is not None else _lib.default_params()
         self.padded = None
         self.transform = None
+        self.version = 0                                   # counts update() calls: a gradient sweep remembers which grid it traced
         if to_world is not None:
             self.set_to_world(to_world)
         self.update(data)
@@ -113,18 +114,28 @@ class SdfGrid:
         self.transform = (f(inv[:3, :].reshape(-1)), f(w.min(0)), f(w.max(0)))
         return self
 
-    def lib(self):
+    _IDENTITY = None
+
+    def lib(self, extended=False):
         """The library this grid's calls go to; for a grid with a general transform the world-space build, with the transform
-        (re-)applied in stream order (it is state of that library instance)."""
-        if self.transform is None:
+        (re-)applied (it is state of that library instance, include/dsdf.h: dsdf_set_grid_transform).  extended=True routes THIS
+        call of a transform-free grid to that build with the identity -- `use_mis` with the principled BSDF lives there --
+        without changing the grid: its other calls keep the default library and its per-pixel proofs."""
+        if self.transform is None and not extended:
             return _lib.load()
+        tf = self.transform
+        if tf is None:
+            if SdfGrid._IDENTITY is None:
+                f = lambda a: (C.c_float * len(a))(*[float(v) for v in a])
+                SdfGrid._IDENTITY = (f([1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0]), f([0, 0, 0]), f([1, 1, 1]))
+            tf = SdfGrid._IDENTITY
         lib = _lib.load_xf()
         with torch.cuda.device(self.device):
-            _lib.check(lib.dsdf_set_grid_transform(self.transform[0], self.transform[1], self.transform[2], _stream()), lib)
+            _lib.check(lib.dsdf_set_grid_transform(tf[0], tf[1], tf[2], _stream()), lib)
         return lib
 
     def update(self, data):
-        lib = _lib.load()
+        lib = _lib.load()                                  # (dsdf_padded_size / dsdf_pad_grid know nothing of a transform: any build serves)
         if data.dim() == 4:
             if data.shape[3] != 1:
                 raise _lib.DsdfError("sdf.data must have one channel")
@@ -139,6 +150,7 @@ class SdfGrid:
         with torch.cuda.device(data.device):
             _lib.check(lib.dsdf_pad_grid(_ptr(data), self.rx, self.ry, self.rz, _ptr(self.padded), _stream()))
         self.device = data.device
+        self.version += 1
         # what the padded copy was built from: the tensor OBJECT (held, so its storage cannot be recycled for another tensor
         # while it is the key) and its in-place version
         self._src = (data, data._version)
@@ -162,11 +174,17 @@ class SdfGrid:
             # ... but the SAME tensor object at the same in-place version holds what was read last time: no second
             # device-to-host read-back (a blocking sync per call when sdf.p lives on the GPU).  The object is
             # held, so its storage cannot be recycled for another tensor meanwhile.
+            # (only for a tensor whose in-place version is tracked: inference-mode tensors have none, and writes through `.data`
+            # / `set_()` do not bump it -- a leaf that is edited that way must be passed as a list, or after any in-place op)
+            try:
+                ver = p._version
+            except (RuntimeError, AttributeError):
+                ver = None
             src = getattr(self, '_p_src', None)
-            if src is not None and src[0] is p and src[1] == p._version:
+            if ver is not None and src is not None and src[0] is p and src[1] == ver:
                 return self
             vals = p.detach().cpu().tolist()
-            self._p_src = (p, p._version)
+            self._p_src = (p, ver) if ver is not None else None
         else:
             vals = p
             self._p_src = None
@@ -177,6 +195,11 @@ class SdfGrid:
     @property
     def shape(self):
         return (self.rz, self.ry, self.rx)
+
+
+def _needs_extended(shading):
+    """`use_mis` with the principled BSDF (Principled::sample / ::pdf) exists in the extended build of the library only."""
+    return shading is not None and shading.roughness is not None and shading.use_mis
 
 
 class Shading:
@@ -379,7 +402,7 @@ def render_forward(grid, sensors, spp, seeds=None, offsets=None, integrator=DSDF
                    empty_space_skip=True, shading=None, emitter_samples=None, bsdf_samples=None):
     """`ReparamIntegrator.render` for a batch of views -> (n_views, H, W, 3).  `shading` (dsdf.Shading) and the
     optional per-lane `emitter_samples` belong to sdf_direct_reparam."""
-    lib = grid.lib()
+    lib = grid.lib(_needs_extended(shading))
     sensors, cams, W, H = _views(sensors)
     nv = len(sensors)
     n_lanes = (W + 4) * (H + 4) * int(spp)
@@ -428,7 +451,7 @@ def render_backward(grid, sensors, spp, grad_image, grad_grid=None, seeds=None, 
     """`ReparamIntegrator.render_backward`: accumulates dL/dsdf into grad_grid (Z,Y,X) and, if given,
     dL/d(sdf.p) into grad_p (3 floats on the device; `sdf.p`, python/shapes.py:471) and, for
     sdf_direct_reparam, dL/d(albedo) into grad_albedo (shaped like shading.albedo)."""
-    lib = grid.lib()
+    lib = grid.lib(_needs_extended(shading))
     sensors, cams, W, H = _views(sensors)
     nv = len(sensors)
     n_lanes = (W + 4) * (H + 4) * int(spp)
@@ -466,7 +489,7 @@ def render_forward_grad(grid, sensors, spp, tangent_data=None, tangent_p=None, s
                         emitter_samples=None, bsdf_samples=None):
     """`ReparamIntegrator.render_forward` (python/integrators/reparam.py:192-196): forward-mode gradient image(s)
     (n_views,H,W,3) for a tangent on sdf.data (tensor shaped like the grid) and / or on sdf.p (3 floats)."""
-    lib = grid.lib()
+    lib = grid.lib(_needs_extended(shading))
     sensors, cams, W, H = _views(sensors)
     nv = len(sensors)
     n_lanes = (W + 4) * (H + 4) * int(spp)
@@ -511,7 +534,7 @@ def new_film(n_views, W, H, integrator, device):
 def render_film(grid, sensors, spp, film, rows, seeds=None, offsets=None, integrator=DSDF_SILHOUETTE, reparam=True,
                 empty_space_skip=True, shading=None, emitter_samples=None, stats=None):
     """Primal samples of the film-block rows [rows[0], rows[1]) of every view, ACCUMULATED into `film`."""
-    lib = grid.lib()
+    lib = grid.lib(_needs_extended(shading))
     sensors, cams, W, H = _views(sensors)
     nv = len(sensors)
     n_lanes = (W + 4) * (H + 4) * int(spp)
@@ -557,7 +580,8 @@ class GradSweep:
 
     def __init__(self, grid, sensors, spp, rows, seeds=None, offsets=None, integrator=DSDF_SILHOUETTE, reparam=True,
                  empty_space_skip=True, shading=None, emitter_samples=None, grad_albedo=None, workspace=None):
-        self.lib = grid.lib()
+        self.extended = _needs_extended(shading)
+        self.lib = grid.lib(self.extended)
         self.grid = grid
         # the parameter block as it is NOW (sdf.p, warp settings): backward() may run after the caller touched grid.params
         self.params = type(grid.params).from_buffer_copy(grid.params)
@@ -571,6 +595,8 @@ class GradSweep:
         self.rows = (int(rows[0]), int(rows[1]))
         self.sh, self._keep = _shading_arg(integrator, shading, self.nv, n_lanes, emitter_samples, grad_albedo)
         wsb = int(self.lib.dsdf_render_workspace_size(self.W, self.H, self.spp, self.nv, self.integrator))
+        self.ws_bytes = wsb
+        self.grid_version = None                              # set by sweep(): the grid the queue in `ws` belongs to
         # the backward queue lives in this buffer between the two halves: private to the sweep unless the caller lends one
         if workspace is not None and workspace.numel() >= wsb:
             self.ws = workspace
@@ -584,14 +610,26 @@ class GradSweep:
 
     def sweep(self, film):
         _require_dev(film, 'film')
-        self.lib = self.grid.lib()                            # (re-applies a general transform: state of the library instance)
+        self.lib = self.grid.lib(self.extended)               # (re-applies a general transform: state of the library instance)
+        self.grid_version = self.grid.version
         with torch.cuda.device(self.grid.device):
             _lib.check(self.lib.dsdf_grad_sweep(*self._args(), self.rows[0], self.rows[1], _ptr(film), _ptr(self.ws), self.ws.numel(), _stream()))
         return film
 
+    def make_private(self):
+        """A workspace of its own for this sweep (a second backward of a step whose lent buffer went back to the pool)."""
+        self.ws = torch.empty(self.ws_bytes, dtype=torch.uint8, device=self.grid.device)
+
     def backward(self, film_total, grad_image, grad_grid, grad_p=None):
         _require_dev(film_total, 'film_total'); grad_image = _require_dev(grad_image, 'grad_image'); _require_dev(grad_grid, 'grad_grid')
-        self.lib = self.grid.lib()
+        if grad_image.numel() != self.nv * self.H * self.W * 3:
+            raise _lib.DsdfError(f"grad_image must be (n_views,H,W,3) = {(self.nv, self.H, self.W, 3)}, got {tuple(grad_image.shape)}")
+        if self.grid_version != self.grid.version:
+            # the padded buffer is rewritten in place by SdfGrid.update: the queued samples (warp points, records) belong to the
+            # grid that was traced, the lookups of the backward would read the new one
+            raise _lib.DsdfError("the grid was updated (SdfGrid.update / set_data) between the gradient sweep of this step and its "
+                                 "backward: back-propagate before the optimiser step, or render again")
+        self.lib = self.grid.lib(self.extended)
         with torch.cuda.device(self.grid.device):
             _lib.check(self.lib.dsdf_grad_backward(*self._args(), _ptr(film_total), _ptr(grad_image), _ptr(grad_grid), _ptr(grad_p),
                                                    _ptr(self.ws), self.ws.numel(), _stream()))
@@ -630,6 +668,10 @@ class _GradSweepParts(GradSweep):
     def record_stream(self, stream):
         for _, _, part in self.parts:
             part.ws.record_stream(stream)
+
+    def make_private(self):
+        for _, _, part in self.parts:
+            part.make_private()
 
 
 _side_streams = {}
@@ -673,7 +715,7 @@ def step_begin(grid, sensors, spp, spp_grad, seeds, seeds_grad, integrator=DSDF_
         side = _side_streams[dev] = torch.cuda.Stream(dev, priority=-1)
     side.wait_stream(main)                                    # the grid (and whatever produced it) is ready
     # one per-pixel proof for both passes (dsdf_share_pixel_skip): the sweep writes the flags, the primal render reads them
-    lib = grid.lib()
+    lib = grid.lib(_needs_extended(shading))
     nflag = len(sensors) * (W + 4) * (H + 4)
     flags = _skip_buffers.get(dev)
     if flags is None or flags.numel() < nflag:
@@ -702,14 +744,22 @@ def step_finish(handle, grad_image, grad_grid, grad_p=None):
     """Backward half of the step: waits for the side stream and back-propagates the queued samples of the sweep against
     `grad_image` (n,H,W,3) into grad_grid (and grad_p, and the albedo / roughness gradients the sweep was built with)."""
     if handle.done:
-        raise _lib.DsdfError("step_finish: this step's backward queue was already consumed (retain_graph is not supported)")
+        # a second backward of the same step (retain_graph=True, torch.autograd.grad twice): the lent workspace went back to the
+        # pool with the first one, so the sweep is traced again into a buffer of its own -- sequentially, on the caller's stream
+        sw = handle.sweep
+        sw.make_private()
+        film = sw.sweep(torch.zeros_like(handle.film_g))
+        sw.backward(film, grad_image.contiguous(), grad_grid, grad_p)
+        return grad_grid
     cur = torch.cuda.current_stream(grad_grid.device)
     cur.wait_stream(handle.side)
     handle.film_g.record_stream(cur); handle.sweep.record_stream(cur)
-    handle.sweep.backward(handle.film_g, grad_image.contiguous(), grad_grid, grad_p)
-    handle.done = True
-    if handle.lease is not None:
-        handle.lease['leased'] = False        # (the next sweep is stream-ordered after this backward)
+    try:
+        handle.sweep.backward(handle.film_g, grad_image.contiguous(), grad_grid, grad_p)
+    finally:
+        handle.done = True
+        if handle.lease is not None:
+            handle.lease['leased'] = False    # (the next sweep is stream-ordered after this backward; also when it was refused)
     return grad_grid
 
 
@@ -794,6 +844,16 @@ def stats_dict(stats):
     return d
 
 
+def eager_sweep_enabled():
+    """DSDF_EAGER_SWEEP=0: the autograd render ops do NOT enqueue the gradient sweep in forward() -- backward() then runs a plain
+    sequential gradient pass.  Default 1 (the optimiser loop's fast path).  What the eager schedule costs, so that a caller can
+    decide: a grad-enabled render that is never back-propagated (a validation image rendered without torch.no_grad()) pays a
+    gradient sweep it does not need, and every render whose backward is still outstanding keeps its backward queue (40 B per
+    gradient-pass sample and view: 8.2 GB + 6.5 GB of coefficients for 12 views x 512^2 x 64 spp) until its backward ran or
+    its graph is freed; several such renders hold a queue each (the first leases the cached buffer, the others allocate)."""
+    return os.environ.get('DSDF_EAGER_SWEEP', '1') != '0'
+
+
 class _RenderOp(torch.autograd.Function):
     """`mi.render`'s custom op: primal (seed, spp) without AD, backward via an independent (seed_grad, spp_grad) gradient
     pass -- split at the autograd boundary like dsdf.render_step: forward() enqueues the primal render AND the image-independent
@@ -819,15 +879,26 @@ class _RenderOp(torch.autograd.Function):
         if want_r:
             ctx.gr = sh.grad_roughness = torch.zeros_like(sh.roughness.detach(), dtype=torch.float32).contiguous()
         ctx.gp = torch.zeros(3, dtype=torch.float32, device=grid.device) if (p is not None and ctx.needs_input_grad[9]) else None
+        ctx.grid = grid
+        if not eager_sweep_enabled():
+            ctx.step = None
+            ctx.lazy = (list(sensors), int(spp_grad), [seed_grad + i for i in range(n)], integrator, reparam, sh, grid.version)
+            return render_forward(grid, sensors, spp, seeds=[seed + i for i in range(n)], integrator=integrator, reparam=reparam, shading=sh)
         img, ctx.step = step_begin(grid, sensors, spp, spp_grad, [seed + i for i in range(n)], [seed_grad + i for i in range(n)],
                                    integrator, reparam, sh, ctx.ga)
-        ctx.grid = grid
         return img
 
     @staticmethod
     def backward(ctx, grad_out):
         g = torch.zeros(ctx.grid.shape, dtype=torch.float32, device=ctx.grid.device)
-        step_finish(ctx.step, grad_out, g, ctx.gp)
+        if ctx.step is None:
+            sensors, spp_grad, seeds_grad, integrator, reparam, sh, ver = ctx.lazy
+            if ver != ctx.grid.version:
+                raise _lib.DsdfError("the grid was updated between this render and its backward: back-propagate before the optimiser step")
+            render_backward(ctx.grid, sensors, spp_grad, grad_out.contiguous(), grad_grid=g, seeds=seeds_grad, integrator=integrator,
+                            reparam=reparam, grad_p=ctx.gp, shading=sh, grad_albedo=ctx.ga)
+        else:
+            step_finish(ctx.step, grad_out, g, ctx.gp)
         gp = ctx.gp
         if gp is not None:
             shape, dtype, dev = ctx.p_meta

@@ -87,6 +87,10 @@ class ReparamIntegrator:
         self.antithetic_sampling = bool(props.get('antithetic_sampling', False))
         # sdf_silhouette_reparam.py:10, sdf_simple_shading_reparam.py:14, sdf_direct_reparam.py:11: every integrator on the path reads it
         self.use_aovs = bool(props.get('use_aovs', False))
+        if self.use_aovs and self.antithetic_sampling:
+            # (the reference allows the pair; here the debug channels are rendered for one sample set: refused where the
+            # integrator is configured, not at the first render)
+            raise NotImplementedError("use_aovs together with antithetic_sampling: the debug channels are rendered for one sample set")
         fn = props.get('sdf_filename', '')
         self.sdf = Grid3d(fn, transform=props.get('sdf_to_world', None)) if fn else props.get('sdf', None)   # reparam.py:21-29
         self.warp_field = None
@@ -164,13 +168,17 @@ class ReparamIntegrator:
             img = dsdf.render_forward(self.sdf.grid, sens, spp or 4, seeds=seeds,
                                       integrator=self.integrator_id, reparam=reparam, shading=self.shading())
         if self.use_aovs:
-            wf = self.warp_field
-            if wf is not None and reparam and getattr(wf, 'return_aovs', False):
-                aov = dsdf.render_aovs(self.sdf.grid, sens, spp or 4, seeds=seeds)        # (the primary ray: depth 0 passes warp.py:103 for any max_reparam_depth)
-            else:
-                aov = torch.zeros(*img.shape[:-1], len(dsdf.AOV_NAMES), dtype=img.dtype, device=img.device)
-            img = torch.cat([img, aov], -1)
+            img = torch.cat([img, self._aov_channels(sens, spp or 4, seeds, reparam, img)], -1)
         return img[0] if len(sens) == 1 and not isinstance(sensor, (list, tuple)) else img
+
+    def _aov_channels(self, sens, spp, seeds, reparam, like):
+        """The eleven channels of aov_names() for these sensors (no gradient flows through them, as in the reference: they are
+        written under suspend_grad): filled when the warp field has `return_aovs` set, zero otherwise."""
+        wf = self.warp_field
+        with torch.no_grad():
+            if wf is not None and reparam and getattr(wf, 'return_aovs', False):
+                return dsdf.render_aovs(self.sdf.grid, sens, spp, seeds=seeds)            # (the primary ray: depth 0 passes warp.py:103 for any max_reparam_depth)
+            return torch.zeros(*like.shape[:-1], len(dsdf.AOV_NAMES), dtype=like.dtype, device=like.device)
 
     def render_backward(self, scene, params, grad_in, sensor=0, seed=0, spp=0):
         """python/integrators/reparam.py:187-190: accumulates into params[key].grad."""
@@ -190,7 +198,10 @@ class ReparamIntegrator:
         ga = torch.zeros_like(at.detach(), dtype=torch.float32).contiguous() if want_a else None
         if want_r:
             sh.grad_roughness = torch.zeros_like(rt.detach(), dtype=torch.float32).contiguous()
-        gi = grad_in.reshape(len(sens), *grad_in.shape[-3:]).contiguous()
+        gi = grad_in.reshape(len(sens), *grad_in.shape[-3:])
+        if self.use_aovs and gi.shape[-1] > 3:
+            gi = gi[..., :3]                                            # (the debug channels carry no gradient: reparam.py:160-165 writes them detached)
+        gi = gi.contiguous()
         if self.antithetic_sampling:
             g = torch.zeros(self.sdf.grid.shape, dtype=torch.float32, device=self.sdf.grid.device)
             self._backward_pair(sens, spp or 4, [seed + i for i in range(len(sens))], reparam, gi, g, gp, sh, ga)
@@ -266,16 +277,28 @@ class _RenderOp(torch.autograd.Function):
         if want_r:
             ctx.gr = sh.grad_roughness = torch.zeros_like(sh.roughness.detach(), dtype=torch.float32).contiguous()
         n = len(sensors)
+        ctx.meta = (data.shape, integ.sdf.grid)
+        if not dsdf.eager_sweep_enabled():                    # DSDF_EAGER_SWEEP=0 (dsdf/renderer.py): plain gradient pass in backward()
+            ctx.step = None
+            ctx.lazy = (list(sensors), int(spp_grad), [seed_grad + i for i in range(n)], integ.integrator_id, reparam, sh, integ.sdf.grid.version)
+            return dsdf.render_forward(integ.sdf.grid, sensors, spp, seeds=[seed + i for i in range(n)], integrator=integ.integrator_id,
+                                       reparam=reparam, shading=sh)
         img, ctx.step = dsdf.step_begin(integ.sdf.grid, sensors, spp, spp_grad, [seed + i for i in range(n)],
                                         [seed_grad + i for i in range(n)], integ.integrator_id, reparam, sh, ctx.ga)
-        ctx.meta = (data.shape, integ.sdf.grid)
         return img
 
     @staticmethod
     def backward(ctx, grad_out):
         shape, grid = ctx.meta
         g = torch.zeros(grid.shape, dtype=torch.float32, device=grid.device)
-        dsdf.step_finish(ctx.step, grad_out, g)
+        if ctx.step is None:
+            sensors, spp_grad, seeds_grad, integ_id, reparam, sh, ver = ctx.lazy
+            if ver != grid.version:
+                raise dsdf.DsdfError("the grid was updated between this render and its backward: back-propagate before the optimiser step")
+            dsdf.render_backward(grid, sensors, spp_grad, grad_out.contiguous(), grad_grid=g, seeds=seeds_grad, integrator=integ_id,
+                                 reparam=reparam, shading=sh, grad_albedo=ctx.ga)
+        else:
+            dsdf.step_finish(ctx.step, grad_out, g)
         return (g.reshape(shape) if ctx.needs_input_grad[0] else None, ctx.ga if ctx.needs_input_grad[1] else None,
                 None if ctx.gr is None else ctx.gr.reshape(ctx.gr.shape), None, None, None, None, None, None)
 
@@ -326,8 +349,10 @@ def render(scene, params=None, sensor=0, seed=0, spp=4, seed_grad=0, spp_grad=No
         # (the op takes the sensors in the SDF's own frame; `integ.render` below maps its world-space sensors itself -- each
         # consumer maps exactly once)
         op = _PairRenderOp if integ.antithetic_sampling else _RenderOp
-        img = op.apply(data, albedo, rough, scene, integ._sensors(scene, sensor), int(seed), int(spp), int(seed_grad),
-                       int(spp_grad or spp))
+        sens = integ._sensors(scene, sensor)
+        img = op.apply(data, albedo, rough, scene, sens, int(seed), int(spp), int(seed_grad), int(spp_grad or spp))
+        if integ.use_aovs:                                              # (the same 14 channels as the detached path below)
+            img = torch.cat([img, integ._aov_channels(sens, int(spp), [int(seed) + i for i in range(len(sens))], integ._configured(), img)], -1)
     else:
         with torch.no_grad():
             if data is not None:

@@ -43,13 +43,9 @@ class SdfDirectReparamIntegrator(ReparamIntegrator):
                 rough = torch.full((16, 16, 16, 1), float(rough), device=default_device())
             self.roughness = rough
 
-    def _configured(self):
-        # `use_mis` with the principled BSDF (Principled::sample / ::pdf) exists in the extended build of the library only
-        # (lib/variants/libdsdf_xf.so): a grid without a transform is routed there with the identity (include/dsdf.h)
-        if self.principled and self.use_mis and self.sdf is not None and self.sdf.grid.transform is None:
-            import numpy as np
-            self.sdf.grid.set_to_world(np.eye(4))
-        return super()._configured()
+    # (`use_mis` with the principled BSDF -- Principled::sample / ::pdf -- exists in the extended build of the library only
+    # (lib/variants/libdsdf_xf.so): dsdf routes exactly the calls that carry such a Shading there, with the identity transform;
+    # the grid itself stays what it is, so its other renders keep the default library and its per-pixel proofs)
 
     def shading(self):
         return dsdf.Shading(self.reflectance, self.env_radiance, self.hide_emitters, self.use_mis, self.detach_indirect_si,

@@ -332,7 +332,9 @@ int dsdf_redistance_status(const void *workspace, int rx, int ry, int rz, int32_
  * bbox_delta (shapes.py:393-418).  The per-pixel proofs are off in that build (they reason in the cube's frame).
  *   to_local : 12 floats, rows of the 3 x 4 matrix [A | b] of `to_world.inverse()`;  aabb_lo / aabb_hi : 3 floats each, the AABB of the
  *   eight transformed cube corners (`Grid3d.update_bbox`, WITHOUT the 0.05 expansion).  HOST pointers.
- * The transform is state of the library instance, applied in stream order to every later call until it is set again.
+ * The transform is state of the library instance (one per device): it applies to every later call until it is set again.  Setting the
+ * value it already holds costs nothing; a CHANGE first waits for the device (hipDeviceSynchronize) and is written synchronously, so
+ * calls enqueued earlier -- on any stream, from any thread -- keep the transform they were enqueued with.  `stream` is unused.
  * dsdf_has_grid_transform(): 1 in the world-space build, 0 in the default one, whose dsdf_set_grid_transform returns an error. */
 int dsdf_has_grid_transform(void);
 int dsdf_set_grid_transform(const float *to_local, const float *aabb_lo, const float *aabb_hi, void *stream);

@@ -633,6 +633,39 @@ def test_forward_mode_gpu(dsdf, integ):
         dsdf.render_forward_grad(grid, sens, 64, seeds=[4, 5, 6], integrator=integ)           # no tangent
 
 
+def test_autograd_render_op_edge_cases(dsdf, monkeypatch):
+    """What the eager schedule of the render op must survive: a second backward of the same graph (the lent queue is
+    gone: the sweep is traced again), a grid update between forward and backward (refused: the queue belongs to the old grid),
+    two renders outstanding at once (a queue each), and DSDF_EAGER_SWEEP=0 (plain gradient pass in backward) giving the same
+    gradient."""
+    case = make_case('blob32')
+    data = case['grid'].float().cuda().requires_grad_(True)
+    grid = dsdf.SdfGrid(data)
+    sen = sensor(dsdf, case)
+    w = torch.rand(1, case['H'], case['W'], 3, device='cuda')
+    img = dsdf.render(data, grid, [sen], spp=64, seed=3, spp_grad=64, seed_grad=11)
+    (g1,) = torch.autograd.grad((img * w).sum(), data, retain_graph=True)
+    (g2,) = torch.autograd.grad((img * w).sum(), data)                 # second backward: re-traced into a private workspace
+    assert g1.abs().sum() > 0 and rel_l2(g2.cpu(), g1.cpu()) < 1e-5
+    # two renders before one backward
+    ia = dsdf.render(data, grid, [sen], spp=64, seed=3, spp_grad=64, seed_grad=11)
+    ib = dsdf.render(data, grid, [sen], spp=64, seed=4, spp_grad=64, seed_grad=12)
+    (gab,) = torch.autograd.grad((ia * w).sum() + (ib * w).sum(), data)
+    (gb,) = torch.autograd.grad((dsdf.render(data, grid, [sen], spp=64, seed=4, spp_grad=64, seed_grad=12) * w).sum(), data)
+    assert rel_l2((gab - gb).cpu(), g1.cpu()) < 1e-4
+    # the lazy schedule
+    monkeypatch.setenv('DSDF_EAGER_SWEEP', '0')
+    (g3,) = torch.autograd.grad((dsdf.render(data, grid, [sen], spp=64, seed=3, spp_grad=64, seed_grad=11) * w).sum(), data)
+    monkeypatch.delenv('DSDF_EAGER_SWEEP')
+    assert rel_l2(g3.cpu(), g1.cpu()) < 1e-5
+    # a grid update between forward and backward
+    img = dsdf.render(data, grid, [sen], spp=64, seed=3, spp_grad=64, seed_grad=11)
+    grid.update(data.detach() + 0.01)
+    with pytest.raises(dsdf.DsdfError, match='updated'):
+        (img * w).sum().backward()
+    grid.update(data.detach())
+
+
 def test_two_stream_step_equals_sequential(dsdf):
     """dsdf.render_step (primal pass and gradient sweep on two HIP streams, backward after both) == render_forward +
     render_backward: same image, same dL/dsdf (atomic-order noise), repeated to exercise the workspace hand-over."""

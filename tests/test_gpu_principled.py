@@ -69,12 +69,20 @@ def test_principled_backward_gpu(dsdf, name, reparam):
         assert ed < tols[1], (ed, tols[1])
 
 
-def test_principled_rejections(dsdf):
+def test_principled_mis_is_routed_per_call(dsdf, monkeypatch):
+    """`use_mis` with the principled BSDF lives in the extended build only: the DEFAULT library refuses it at the C-ABI, the Python
+    layer routes exactly the calls that carry such a Shading to lib/variants/libdsdf_xf.so (identity transform) and leaves the grid
+    what it was -- its other renders keep the default library (no permanent set_to_world(eye))."""
+    import dsdf.renderer as R
     case = make_case('sphere16')
     ex = _principled_inputs(case)
     grid, sen, _ = setup(dsdf, case, ex)
     sh = dsdf.Shading(ex['albedo'].cuda(), ex['env'], use_mis=True, roughness=ex['roughness'].cuda())
-    with pytest.raises(dsdf.DsdfError):
+    img = dsdf.render_forward(grid, sen, 4, seeds=[1], integrator='sdf_direct_reparam', shading=sh)
+    assert torch.isfinite(img).all() and float(img.abs().sum()) > 0
+    assert grid.transform is None and grid.lib().dsdf_has_grid_transform() == 0 and grid.lib(True).dsdf_has_grid_transform() == 1
+    monkeypatch.setattr(R, '_needs_extended', lambda shading: False)          # the default library's own answer
+    with pytest.raises(dsdf.DsdfError, match='extended build'):
         dsdf.render_forward(grid, sen, 4, seeds=[1], integrator='sdf_direct_reparam', shading=sh)
 
 
@@ -139,7 +147,10 @@ def test_principled_plugin_and_render_op(dsdf):
     it_mis = create_integrator('sdf_direct_reparam', {'sdf': shapes.Grid3d(data.clone()), 'roughness': rough, 'base_color': base, 'use_mis': True})
     assert it_mis.sdf.grid.transform is None
     it_mis._configured()
-    assert it_mis.sdf.grid.transform is not None and it_mis.sdf.grid.lib().dsdf_has_grid_transform() == 1
+    assert it_mis.sdf.grid.transform is None                           # (routed per call, the grid is not touched: dsdf.SdfGrid.lib)
+    it_mis.warp_field = configs.get_config('warp').get_warpfield(it_mis.sdf)
+    img_mis = it_mis.render(Scene(sens, it_mis), sensor=1, seed=5, spp=64)
+    assert torch.isfinite(img_mis).all() and it_mis.sdf.grid.transform is None
 
 
 @pytest.mark.parametrize('name', ['blob32', 'blob48_rect'])
@@ -171,6 +182,7 @@ def test_principled_mis_backward_gpu(dsdf, name):
     assert e[1] < tols[2] and e[2] < tols[3], (e, tols)
     from test_refshim_fixture import check_fp32_gradient          # (plain gate; one heavy-tailed sample footprint may be set aside)
     check_fp32_gradient('principled_mis_gpu', name, 'direct_mis', gg.cpu().numpy(), gd, tols[1])
-    # the default library keeps refusing the combination
-    with pytest.raises(dsdf.DsdfError):
-        dsdf.render_forward(dsdf.SdfGrid(case['grid'].float().cuda()), sen, 4, seeds=[1], integrator='sdf_direct_reparam', shading=sh)
+    # a transform-free grid gets the same result: the call is routed to the extended build with the identity (dsdf.SdfGrid.lib)
+    plain = dsdf.render_forward(dsdf.SdfGrid(case['grid'].float().cuda()), sen, case['spp'], offsets=case['offsets'].cuda(),
+                                integrator='sdf_direct_reparam', shading=sh, emitter_samples=ex['emitter_u'].cuda(), bsdf_samples=bu.cuda())[0]
+    assert rel_l2(plain.cpu(), prim.cpu()) < 1e-6

@@ -9,9 +9,10 @@ import dsdf
 from bench import synth_grid
 dev = torch.device('cuda')
 data = synth_grid(256, dev); grid = dsdf.SdfGrid(data)
-sens = dsdf.get_regular_cameras(12, resx=512, resy=512)
-S = list(range(12))
-gi = torch.sin(torch.arange(12 * 512 * 512 * 3, device=dev, dtype=torch.float32)).reshape(12, 512, 512, 3) * 1e-6
+NV = int(os.environ.get('AB_VIEWS', 12))                 # (AB_VIEWS=n: the first n views of the ring -- a rank's shard of a multi-GPU run)
+sens = dsdf.get_regular_cameras(12, resx=512, resy=512)[:NV]
+S = list(range(NV))
+gi = torch.sin(torch.arange(NV * 512 * 512 * 3, device=dev, dtype=torch.float32)).reshape(NV, 512, 512, 3) * 1e-6
 g = torch.zeros_like(data)
 
 

@@ -55,7 +55,8 @@ def case_inputs(name):
     """The seeded inputs of tests/cases.py WITHOUT the product: grids from the oracle's closed forms, the rest from torch's
     seeded generator exactly as tests/cases.py draws it."""
     import torch
-    cfg = {'sphere16': (16, 1, 0, 16, 16, 4, 1), 'blob32': (32, 3, 1, 24, 24, 8, 2)}[name]
+    cfg = {'sphere16': (16, 1, 0, 16, 16, 4, 1), 'blob32': (32, 3, 1, 24, 24, 8, 2),
+           'blob32_spp64': (32, 3, 2, 12, 12, 64, 3)}[name]          # (the same tuples as tests/cases.py)
     R, ncam, icam, W, H, spp, seed = cfg
     sys.path.insert(0, os.path.join(ROOT, 'oracle'))
     import sdf_oracle as O                                          # grids + camera ring: plain torch, no product code
@@ -176,7 +177,16 @@ def main():
     ap.add_argument('--config-table', action='store_true', help="dump python/opt_configs.py and python/configs.py (every named configuration, "
                     "resolved) to <out>/<prefix>_config_table.json instead of the render fixtures")
     ap.add_argument('--tf-cases', nargs='*', default=['sphere16'], help='cases that also get the Grid3d(transform) section (slow on the stand-in)')
+    ap.add_argument('--light', action='store_true', help='images and gradients of the integrator runs only (no per-ray sections)')
     args = ap.parse_args()
+    # REFSHIM_DTYPE=float32: the stand-in's arrays are fp32 -- the reference's own statements in the reference's own operation order at
+    # the precision of its CPU variant (llvm_ad_rgb, python/optimize.py:70-78) -> tests/golden/refshim32_<case>.npz: the third witness
+    # of the fp32 floor (next to the fp32 builds of the two oracles), and a direct fp32-vs-fp32 comparison for the HIP path
+    fp32 = args.shim and os.environ.get('REFSHIM_DTYPE', 'float64') == 'float32'
+    if fp32:
+        args.tf_cases = []
+        if args.tags is None:
+            args.tags = ['sil', 'shade', 'direct', 'direct_mis']
 
     if args.shim:
         sys.path.insert(0, os.path.join(HERE, 'refshim'))           # `import drjit`, `import mitsuba`, `import fastsweep` -> the stand-in
@@ -187,7 +197,7 @@ def main():
     import configs                                                  # registers the integrators (python/configs.py:4-7)
     from shapes import Grid3d                                       # python/shapes.py:375
     from constants import SDF_DEFAULT_KEY, SDF_DEFAULT_KEY_P        # python/constants.py:18-19
-    prefix = 'refshim' if args.shim else 'ref'
+    prefix = ('refshim32' if fp32 else 'refshim') if args.shim else 'ref'
     if args.config_table:
         import json
         fn = os.path.join(args.out, f'{prefix}_config_table.json')
@@ -239,32 +249,9 @@ def main():
 
         sdf = make_sdf()
         wf = configs.get_config('warp').get_warpfield(sdf)          # python/configs.py:36-40: strategy 6, edge_eps 0.01, clamp 0.05
-
-        # ---- A1: eval_all at random points (python/shapes.py:438-450)
-        rng = np.random.default_rng(7)
-        pts = rng.uniform(0.1, 0.9, (256, 3)).astype(np.float32)
-        v, _, g, _, Hm = sdf.eval_all(mi.Point3f(pts[:, 0], pts[:, 1], pts[:, 2]))
-        out.update(eval_pts=pts, eval_v=np.array(v), eval_g=cols(g, 3), eval_H=mat33(Hm, mi))
-
-        # ---- A2 / A4 / A9: per-ray outputs for camera rays at random film positions
-        pos = rng.uniform(0.0, 1.0, (512, 2)).astype(np.float32)
-        ray, _ = sensor.sample_ray_differential(0.0, 0.5, mi.Point2f(pos[:, 0], pos[:, 1]), mi.Point2f(0.5))
-        with dr.suspend_grad():
-            its_t, warp_t, warp_t_d, ww, ww_d = sdf.ray_intersect(ray, warp=wf)                  # python/shapes.py:115
-            plain = sdf.ray_intersect_non_diff(ray, True)                                         # python/shapes.py:290
-        rayn = mi.Ray3f(ray)
-        rayn.d = dr.normalize(rayn.d)
-        warp_dir, div = wf.eval(rayn(warp_t), rayn.d, t=warp_t, dt_dx=warp_t_d, active=True,      # python/warp.py:47
-                                warp_weight=ww, warp_weight_d=ww_d)
-        out.update(ray_pos=pos, ray_o=cols(ray.o, 3), ray_d=cols(ray.d, 3), ray_maxt=np.array(ray.maxt),
-                   ri_its_t=np.array(its_t), ri_warp_t=np.array(warp_t), ri_warp_t_d=cols(warp_t_d, 3), ri_warp_weight=np.array(ww),
-                   ri_warp_weight_d=cols(ww_d, 3), ri_plain_its_t=np.array(plain if not isinstance(plain, tuple) else plain[0]),
-                   we_dir=cols(dr.detach(warp_dir), 3), we_div=np.array(dr.detach(div)))
-        with dr.suspend_grad():
-            si = sdf.compute_surface_interaction(ray, its_t)                                      # python/shapes.py:347
-        out.update(si_p=cols(si.p, 3), si_n=cols(si.n, 3))
-        if args.shim:
-            out.update(warp_coefficients_by_ad(dr, mi, sdf, wf, rayn, warp_t, warp_t_d, ww, ww_d))
+        pts = ray = None
+        if not args.light:
+            pts, ray = per_ray_sections(args, dr, mi, sdf, wf, sensor, out)
 
         # ---- A12-A17: image and gradients of the integrators
         runs = [('sdf_silhouette_reparam', 'sil', {}, 'warp'), ('sdf_simple_shading_reparam', 'shade', {}, 'warp')]
@@ -340,7 +327,7 @@ def main():
         # lookups at to_local @ (x - p), gradients back through to_local^T, the traced box = world AABB of the transformed cube.
         # `tf_general`: a rotation that is NOT axis-aligned (the AABB outgrows the cube); `tf_axis`: translation + axis-aligned
         # rotation, the transforms this repository's product accepts (tests/test_to_world.py holds the same two matrices)
-        if name in args.tf_cases and (args.tags is None or any(t.startswith('tf_') for t in args.tags)):
+        if name in args.tf_cases and not args.light and (args.tags is None or any(t.startswith('tf_') for t in args.tags)):
             p0 = [0.01, -0.02, 0.015]
             out['tf_p'] = np.asarray(p0, np.float64)
             for key, T in transforms().items():
@@ -393,6 +380,36 @@ def main():
         fn = os.path.join(args.out, f'{prefix}_{name}.npz')
         np.savez_compressed(fn, **out)
         print(fn, {k: (getattr(v, 'shape', None) or v) for k, v in out.items()})
+
+
+def per_ray_sections(args, dr, mi, sdf, wf, sensor, out):
+    """A1 / A2 / A4 / A6 / A9 of SURVEY 8(a) on random points and camera rays: what the reference's shapes.py / warp.py return per ray."""
+    # ---- A1: eval_all at random points (python/shapes.py:438-450)
+    rng = np.random.default_rng(7)
+    pts = rng.uniform(0.1, 0.9, (256, 3)).astype(np.float32)
+    v, _, g, _, Hm = sdf.eval_all(mi.Point3f(pts[:, 0], pts[:, 1], pts[:, 2]))
+    out.update(eval_pts=pts, eval_v=np.array(v), eval_g=cols(g, 3), eval_H=mat33(Hm, mi))
+
+    # ---- A2 / A4 / A9: per-ray outputs for camera rays at random film positions
+    pos = rng.uniform(0.0, 1.0, (512, 2)).astype(np.float32)
+    ray, _ = sensor.sample_ray_differential(0.0, 0.5, mi.Point2f(pos[:, 0], pos[:, 1]), mi.Point2f(0.5))
+    with dr.suspend_grad():
+        its_t, warp_t, warp_t_d, ww, ww_d = sdf.ray_intersect(ray, warp=wf)                  # python/shapes.py:115
+        plain = sdf.ray_intersect_non_diff(ray, True)                                         # python/shapes.py:290
+    rayn = mi.Ray3f(ray)
+    rayn.d = dr.normalize(rayn.d)
+    warp_dir, div = wf.eval(rayn(warp_t), rayn.d, t=warp_t, dt_dx=warp_t_d, active=True,      # python/warp.py:47
+                            warp_weight=ww, warp_weight_d=ww_d)
+    out.update(ray_pos=pos, ray_o=cols(ray.o, 3), ray_d=cols(ray.d, 3), ray_maxt=np.array(ray.maxt),
+               ri_its_t=np.array(its_t), ri_warp_t=np.array(warp_t), ri_warp_t_d=cols(warp_t_d, 3), ri_warp_weight=np.array(ww),
+               ri_warp_weight_d=cols(ww_d, 3), ri_plain_its_t=np.array(plain if not isinstance(plain, tuple) else plain[0]),
+               we_dir=cols(dr.detach(warp_dir), 3), we_div=np.array(dr.detach(div)))
+    with dr.suspend_grad():
+        si = sdf.compute_surface_interaction(ray, its_t)                                      # python/shapes.py:347
+    out.update(si_p=cols(si.p, 3), si_n=cols(si.n, 3))
+    if args.shim:
+        out.update(warp_coefficients_by_ad(dr, mi, sdf, wf, rayn, warp_t, warp_t_d, ww, ww_d))
+    return pts, ray
 
 
 def warp_coefficients_by_ad(dr, mi, sdf, wf, rayn, warp_t, warp_t_d, ww, ww_d):
