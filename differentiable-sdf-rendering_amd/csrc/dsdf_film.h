@@ -66,6 +66,75 @@ __device__ __forceinline__ void film_accum_wave(int px, int py, float u, float v
     }
 }
 
+// The 5 x 5 film window of the 64 samples of one chunk from their film offsets (r0, r1) in [0, 1)^2.  A PRIMAL sample is splatted
+// where it was generated: without a reparameterisation `sensor.sample_direction(o + d)` (reparam.py:99-118) returns the film position
+// the ray was sampled at -- exactly, in real arithmetic: (near_t + 1) d_local projects to the pixel position d_local was built from --
+// so the window weights follow from the sampler's offsets alone and neither a camera ray nor a re-projection is computed for the
+// samples of a chunk whose march is proven away (dsdf_proof.h).  (Against the re-projected position of round 4 the weights move by
+// the fp32 rounding of that projection, ~1e-7: image sums agree to 7e-8.)  The the sample sits at block
+// position (px + r0 - 0.5, py + r1 - 0.5), window pixel (px - 2 + i, py - 2 + j) is (i - 1.5 - r0, j - 1.5 - r1) away.  `on`:
+// lanes that are off contribute nothing.  Same wave-level reduction as film_accum_wave (dsdf_film.h).
+__device__ __forceinline__ void film_accum_offsets(float r0, float r1, bool on, float val, float *T, int lid, float acc[2][2]) {
+    float fx[5], fy[5];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        fx[i] = on ? gauss_f(((float)i - 1.5f) - r0) : 0.f;
+        fy[i] = gauss_f(((float)i - 1.5f) - r1);
+    }
+    float f[25];
+#pragma unroll
+    for (int j = 0; j < 5; ++j)
+#pragma unroll
+        for (int i = 0; i < 5; ++i) f[j * 5 + i] = fx[i] * fy[j];
+    // (lanes that are off carry f == 0: any value gives 0; 1 keeps the all-one shortcut of hit-only events)
+    const float vv = on ? val : 1.f;
+    const bool all_one = __ballot(vv != 1.f) == 0;
+    const bool any_val = __ballot(on && vv != 0.f) != 0;
+    float wsum[2] = {0.f, 0.f};
+#pragma unroll
+    for (int cc = 0; cc < 2; ++cc) {
+        const int ch = cc == 0 ? 1 : 0;                      // weight channel first
+        const float s = ch == 0 ? vv : 1.f;
+        if (ch == 0 && all_one) {
+            if (lid < DSDF_TROWS) { acc[0][0] += wsum[0]; acc[0][1] += wsum[1]; }
+            continue;
+        }
+        if (ch == 0 && !any_val) continue;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int k0 = c * DSDF_TROWS;
+            const int nk = (25 - k0) < DSDF_TROWS ? (25 - k0) : DSDF_TROWS;
+#pragma unroll
+            for (int k = 0; k < DSDF_TROWS; ++k)
+                if (k < nk) T[k * DSDF_TSTRIDE + lid] = f[k0 + k] * s;
+            wave_lds_sync();
+            if (lid < nk) {
+                const float4 *row = reinterpret_cast<const float4 *>(T + lid * DSDF_TSTRIDE);
+                float4 a0 = row[0], a1 = row[1], a2 = row[2], a3 = row[3];
+#pragma unroll
+                for (int r = 4; r < 16; r += 4) {
+                    float4 b0 = row[r], b1 = row[r + 1], b2 = row[r + 2], b3 = row[r + 3];
+                    a0.x += b0.x; a0.y += b0.y; a0.z += b0.z; a0.w += b0.w;
+                    a1.x += b1.x; a1.y += b1.y; a1.z += b1.z; a1.w += b1.w;
+                    a2.x += b2.x; a2.y += b2.y; a2.z += b2.z; a2.w += b2.w;
+                    a3.x += b3.x; a3.y += b3.y; a3.z += b3.z; a3.w += b3.w;
+                }
+                const float sum = ((a0.x + a0.y) + (a0.z + a0.w)) + ((a1.x + a1.y) + (a1.z + a1.w)) +
+                                  (((a2.x + a2.y) + (a2.z + a2.w)) + ((a3.x + a3.y) + (a3.z + a3.w)));
+                acc[ch][c] += sum;
+                if (ch == 1) wsum[c] = sum;
+            }
+            wave_lds_sync();
+        }
+    }
+}
+
+// film offsets of sample `lane` of a view (explicit offsets or the built-in sampler): lane_setup without the camera ray
+__device__ __forceinline__ void sample_offsets(const ViewArgs &A, uint32_t lane, float &r0, float &r1) {
+    if (A.offsets) { r0 = A.offsets[2 * (size_t)lane]; r1 = A.offsets[2 * (size_t)lane + 1]; }
+    else sampler_next_2d(A.seed, lane, r0, r1);
+}
+
 template <int NCH>
 __device__ __forceinline__ void film_flush_wave(float *__restrict__ block, const ViewArgs &A, int px, int py, int lid,
                                                 const float acc[NCH][2]) {

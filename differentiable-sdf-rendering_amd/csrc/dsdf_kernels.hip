@@ -220,12 +220,6 @@ __device__ __forceinline__ void load_record(const float *r, size_t c, TraceOut &
 #ifndef DSDF_DIFF_MINWAVES
 #define DSDF_DIFF_MINWAVES 1
 #endif
-#ifndef DSDF_STREAM_DEFAULT
-#define DSDF_STREAM_DEFAULT 0
-#endif
-#ifndef DSDF_SWEEP_CACHE
-#define DSDF_SWEEP_CACHE 0
-#endif
 
 __device__ __forceinline__ void clear_trace(TraceOut &tr) {
     tr.its_t = INFINITY; tr.warp_t = INFINITY; tr.warp_weight = 0.f; tr.weight_sum = 0.f;
@@ -340,8 +334,14 @@ __global__ __launch_bounds__(256) void k_build_items(ViewBatch VB, int view0, in
     }
 }
 
+#ifndef DSDF_DIRECT_PRIMAL_MINWAVES
+#define DSDF_DIRECT_PRIMAL_MINWAVES 1
+#endif
+#ifndef DSDF_DIRECT_SWEEP_MINWAVES
+#define DSDF_DIRECT_SWEEP_MINWAVES 1
+#endif
 template <bool DIFF, bool DIRECT, bool STATS>
-__global__ __launch_bounds__(64, DIRECT ? 1 : (DIFF ? DSDF_DIFF_MINWAVES : DSDF_PRIMAL_MINWAVES))
+__global__ __launch_bounds__(64, DIRECT ? (DIFF ? DSDF_DIRECT_SWEEP_MINWAVES : DSDF_DIRECT_PRIMAL_MINWAVES) : (DIFF ? DSDF_DIFF_MINWAVES : DSDF_PRIMAL_MINWAVES))
 void k_render_items(GridView G, dsdf_params P, ViewBatch VB, float *__restrict__ blocks, Queue qall, unsigned long long *stats,
                     const unsigned char *__restrict__ skip, ShadeArgs S, TailQueue tq, uint32_t *__restrict__ items,
                     const uint32_t *__restrict__ list) {
@@ -394,16 +394,29 @@ void k_render_items(GridView G, dsdf_params P, ViewBatch VB, float *__restrict__
         TraceOut tr, trs, trb;
         clear_trace(tr);
         int lit = 0;
-        const Lane L = lane_setup(A, P, lane, px, py);
+        float acc[NCH][2];
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch) { acc[ch][0] = 0.f; acc[ch][1] = 0.f; }
+        // A primal chunk of the one-channel integrators whose march is proven away (empty-space proof: every sample misses; hit
+        // proof: every sample of the silhouette integrator hits) consists of its film weights: the sampler's offsets and the 5 x 5
+        // window -- no camera ray, no box test, no re-projection (film_accum_offsets, dsdf_film.h).  Half of the listed chunks of
+        // the bench scene.
+        const bool proven = !DIFF && !DIRECT && (known_hit || skip_trace);
+        Lane L;
+        if (proven) {
+            float r0, r1;
+            sample_offsets(A, lane, r0, r1);
+            film_accum_offsets(r0, r1, true, known_hit ? 1.f : 0.f, wave_lds, lid, acc);
+            if (known_hit) tr.its_t = 0.f;                 // (statistics: the samples count as hits)
+        } else {
+        L = lane_setup(A, P, lane, px, py);
         if (known_hit) tr.its_t = 0.f;
         else if (!skip_trace) {
             // (the last few rays of the wave are handed to the tail queue: dsdf_tail.h)
             if (DIFF) {
-#if DSDF_SWEEP_CACHE
-                WaveCellCache F; F.taps = wave_lds; F.lid = lid;     // (A/B: the wave cell cache of the primal march for the Hessian march)
-#else
+                // (the wave cell cache of the value-only march was A/B'd here in rounds 1 and 5: 125 -> 125 VGPRs, fewer VMEM instructions,
+                // gradient call 25.7 -> 27.3 ms -- the Hessian march re-reads its 16 rows too rarely for the grouping loop to pay)
                 DirectFetch F;
-#endif
                 if (!DIRECT && tq.state) {
                     HandOff ho;
                     ho.tq = tq; ho.sub = tq.per_xcd ? my_subq : item % DSDF_TAIL_SUBQ; ho.view = view; ho.lane = lane;
@@ -418,17 +431,20 @@ void k_render_items(GridView G, dsdf_params P, ViewBatch VB, float *__restrict__
                 } else trace_plain(G, P, L.ray.o, L.ray.d, L.ray.maxt, tr, F);
             }
         }
-        float acc[NCH][2];
-#pragma unroll
-        for (int ch = 0; ch < NCH; ++ch) { acc[ch][0] = 0.f; acc[ch][1] = 0.f; }
-        const Reproj rp = reproject(A.cam, P, L.ray.o + L.ray.d, A.W, A.H);
         if (DIRECT) {
+            const Reproj rp = reproject(A.cam, P, L.ray.o + L.ray.d, A.W, A.H);
             float rgb[3];
             lit = direct_value(G, P, A, S, L, lane, tr.its_t, DIFF, trs, trb, rgb);
             film_accum_wave<NCH>(px, py, rp.u, rp.v, rgb, wave_lds, lid, acc);
-        } else {
+        } else if (DIFF) {
+            const Reproj rp = reproject(A.cam, P, L.ray.o + L.ray.d, A.W, A.H);
             const float val = shade_value(G, A, L, tr.its_t);
             film_accum_wave<NCH>(px, py, rp.u, rp.v, &val, wave_lds, lid, acc);
+        } else {
+            // (primal: the sample lands where it was generated -- film_accum_offsets)
+            const float val = shade_value(G, A, L, tr.its_t);
+            film_accum_offsets(L.r0, L.r1, true, val, wave_lds, lid, reinterpret_cast<float (*)[2]>(acc));
+        }
         }
         film_flush_wave<NCH>(block, A, px, py, lid, acc);
         bool need = false;
@@ -445,8 +461,6 @@ void k_render_items(GridView G, dsdf_params P, ViewBatch VB, float *__restrict__
     }
     if (STATS) flush_stats(stats, wst, blockIdx.x, lid);
 }
-
-#include "dsdf_stream.h"
 
 // Thread -> sample of the general pass.  The reference's lane order (lane = pixel * spp + sample, pixels row-major,
 // reparam.py:140-155) is only a convention -- the sampler is keyed by the lane index, so any thread may render any lane.
@@ -632,6 +646,18 @@ struct UnitGather {
 #ifndef DSDF_BWD_MINWAVES
 #define DSDF_BWD_MINWAVES 1
 #endif
+// DSDF_BWD_HALF_TILE=1: the scatters of the fused k_backward go through the 9 KB half tile as well (wave_scatter_half): with the
+// 17 KB tile the LDS allows 9 single-wave blocks per CU = 2.25 waves per SIMD, fewer than the registers of k_backward<true> do
+#ifndef DSDF_BWD_HALF_TILE
+#define DSDF_BWD_HALF_TILE 0
+#endif
+#if DSDF_BWD_HALF_TILE
+#define DSDF_BWD_TILE_FLOATS DSDF_SCATH_FLOATS
+#define DSDF_BWD_SCATTER wave_scatter_half
+#else
+#define DSDF_BWD_TILE_FLOATS DSDF_SCAT_FLOATS
+#define DSDF_BWD_SCATTER wave_scatter_t
+#endif
 template <bool DIRECT>
 #ifndef DSDF_BWD_DIRECT_MINWAVES
 #define DSDF_BWD_DIRECT_MINWAVES 3   /* 168 VGPRs + 1 KB of scratch per lane, 3 waves per SIMD instead of 413 registers and ONE: a kernel at 5 % VALU and 83 % L2 misses wants the waves (gradient call of C5: 98.2 -> 93.7 ms, checksums equal; profiles/r04_tail_ab.md) */
@@ -640,7 +666,7 @@ __global__ __launch_bounds__(64, DIRECT ? DSDF_BWD_DIRECT_MINWAVES : DSDF_BWD_MI
                                                  const float *__restrict__ block_adjs,
                                                  float *__restrict__ grad_grid, float *__restrict__ grad_p,
                                                  unsigned long long *stats, ShadeArgs S) {
-    __shared__ __attribute__((aligned(16))) float tile[DSDF_SCAT_FLOATS];
+    __shared__ __attribute__((aligned(16))) float tile[DSDF_BWD_TILE_FLOATS];
     const ViewArgs &A = VB.v[blockIdx.y];
     constexpr int NCH = DIRECT ? 4 : 2;
     const float *__restrict__ block_adj = block_adjs + (size_t)blockIdx.y * NCH * A.Wb * A.Hb;
@@ -673,10 +699,10 @@ __global__ __launch_bounds__(64, DIRECT ? DSDF_BWD_DIRECT_MINWAVES : DSDF_BWD_MI
                 n_did += lane_backward(G, P, A, L, tr, block_adj, req) ? 1 : 0;
             }
         }
-        wave_scatter_t(G, grad_grid, req[0], tile, lid);
-        if (A.integrator != DSDF_SILHOUETTE) wave_scatter_t(G, grad_grid, req[1], tile, lid);
-        if (DIRECT) wave_scatter_t(G, grad_grid, req[2], tile, lid);
-        if (DIRECT && S.use_mis) wave_scatter_t(G, grad_grid, req[3], tile, lid);
+        DSDF_BWD_SCATTER(G, grad_grid, req[0], tile, lid);
+        if (A.integrator != DSDF_SILHOUETTE) DSDF_BWD_SCATTER(G, grad_grid, req[1], tile, lid);
+        if (DIRECT) DSDF_BWD_SCATTER(G, grad_grid, req[2], tile, lid);
+        if (DIRECT && S.use_mis) DSDF_BWD_SCATTER(G, grad_grid, req[3], tile, lid);
         if (grad_p) {
             if (req[0].on) p_bar = p_bar + req[0].p_bar;
             if (req[1].on) p_bar = p_bar + req[1].p_bar;
@@ -1185,13 +1211,7 @@ static bool deep_skip_enabled() { static const int v = env_int("DSDF_DEEP_SKIP",
 // tail appended.  Measured (profiles/r04_tail_ab.md): the early launch is starved by the primal workers just like the tail kernel
 // (15 ms resident), and the tail kernel then starts later: step 42.5 vs 40.8 ms.  Default: one launch behind the tail kernel.
 static bool coef_early_enabled() { static const int v = env_int("DSDF_COEF_EARLY", 0); return v != 0; }
-// DSDF_TAIL_LONG=n: a tail wave holding a ray older than n of its iterations stops refilling (dsdf_tail.h); 0: off
-static int tail_hold_after() { static const int v = env_int("DSDF_TAIL_LONG", DSDF_TAIL_LONG); return v < 0 ? 0 : v; }
 static int hit_proof_min_spp() { static const int v = env_int("DSDF_HIT_PROOF_MIN_SPP", 16); return v; }
-// DSDF_STREAM=1: the primal render of the one-channel integrators streams the samples of a pixel through one wave (k_render_stream,
-// dsdf_stream.h) instead of marching them in lock-step chunks; DSDF_STREAM_SEG_LOG2: log2 of the pixels per list segment (= tile)
-static bool stream_enabled() { static const int v = env_int("DSDF_STREAM", DSDF_STREAM_DEFAULT); return v != 0; }
-static int stream_seg_log2() { static const int v = env_int("DSDF_STREAM_SEG_LOG2", 10); return v < 4 ? 4 : (v > 14 ? 14 : v); }
 static bool primal_handoff() { static const int v = env_int("DSDF_PRIMAL_HANDOFF", 1); return v != 0; }
 static int tail_streams_enabled() { static int v = env_int("DSDF_TAIL_STREAMS", 1); return v; }
 // blocks (4 waves) per sub-queue of a tail kernel: DSDF_TAIL_BLOCKS overrides the built-in value
@@ -1356,11 +1376,9 @@ static int run_pass(PassCtx &c, const Workspace &ws, const dsdf_camera *cams, in
         if (hipMemsetAsync(ws.items, 0, (size_t)DSDF_MAX_GROUPS * DSDF_ITEM_HDR * sizeof(uint32_t), st) != hipSuccess)
             return fail(DSDF_ERR_LAUNCH, "hipMemsetAsync(work list) failed");
         // tile-major order: a tile = DSDF_ITEM_SEG chunks of 64 samples (16 x 16 pixels at 256 spp, 32 x 32 at 64 spp)
-        // (the streaming primal kernel takes whole pixels: a tile = one segment of 2^seg pixels)
-        const bool stream = !DIFF && !c.direct && stream_enabled();
         ItemOrder O;
         {
-            unsigned tile_px = stream ? (1u << stream_seg_log2()) : DSDF_ITEM_SEG / (unsigned)(c.spp / 64);
+            unsigned tile_px = DSDF_ITEM_SEG / (unsigned)(c.spp / 64);
             if (tile_px < 1) tile_px = 1;
             int lg = 0;
             while ((2u << lg) <= tile_px) ++lg;
@@ -1409,15 +1427,11 @@ static int run_pass(PassCtx &c, const Workspace &ws, const dsdf_camera *cams, in
             if (handoff) {
                 tq.cap_sub = ws.tail_cap_sub * (uint32_t)kreg;
                 tq.per_xcd = (uint32_t)tail_per_xcd();
-                tq.hold_after = (uint32_t)tail_hold_after();
                 tq.count = (uint32_t *)ws.tail + (size_t)g * DSDF_TAIL_SUBQ * 2;
                 tq.state = (float *)(ws.tail + cnt_bytes + (size_t)g * kreg * grp_bytes);
             }
             if (g == 0) timing_mark(0, st);
-            if (stream) {
-                if (st64) hipLaunchKernelGGL((k_render_stream<true>), grid, blk, 0, st, G, c.pp, VB, film, st64, skip, tq, hdr, list, (uint32_t)stream_seg_log2());
-                else hipLaunchKernelGGL((k_render_stream<false>), grid, blk, 0, st, G, c.pp, VB, film, st64, skip, tq, hdr, list, (uint32_t)stream_seg_log2());
-            } else if (c.direct) {
+            if (c.direct) {
                 if (st64) hipLaunchKernelGGL((k_render_items<DIFF, true, true>), grid, blk, 0, st, G, c.pp, VB, film, q, st64, skip, S, tq, hdr, list);
                 else hipLaunchKernelGGL((k_render_items<DIFF, true, false>), grid, blk, 0, st, G, c.pp, VB, film, q, st64, skip, S, tq, hdr, list);
             } else {

@@ -45,6 +45,7 @@ DSDF_HD int film_channels(int integrator) { return integrator == DSDF_DIRECT ? 4
 
 struct Lane {
     int px, py;             // block pixel (0..Wb-1, 0..Hb-1)
+    float r0, r1;           // film offsets of the sample within its pixel (sampler.next_2d, reparam.py:147)
     CamRay ray;
 };
 
@@ -68,6 +69,7 @@ DSDF_HD Lane lane_setup(const ViewArgs &A, const dsdf_params &P, uint32_t lane, 
     float r0, r1;
     if (A.offsets) { r0 = A.offsets[2 * (size_t)lane]; r1 = A.offsets[2 * (size_t)lane + 1]; }
     else sampler_next_2d(A.seed, lane, r0, r1);
+    L.r0 = r0; L.r1 = r1;
     float fx = (float)(L.px - DSDF_BORDER) + r0;
     float fy = (float)(L.py - DSDF_BORDER) + r1;
     L.ray = camera_ray(A.cam, P, fx, fy, A.W, A.H);

@@ -23,10 +23,6 @@
 #define DSDF_FAST_RCP 1
 #endif
 
-#ifndef DSDF_BBOX_FAST
-#define DSDF_BBOX_FAST 1
-#endif
-
 namespace dsdf {
 
 struct V3 { float x, y, z; };
@@ -531,34 +527,21 @@ DSDF_HD float eval_trace_weight(const dsdf_params &P, V3 d, int i, B lo, B hi, V
     float denom = P.sil_weight_epsilon + fabsf(v) + P.sil_weight_offset * n_dot_d * ratio;
     float inv_denom = rcpf(denom);
     float dist_w = inv_denom * inv_denom * inv_denom;
+    // (Round 5 measured a bit-identical short cut here -- outside the fade zone bw is exactly 1 and its gradient exactly 0, so the
+    // nearest-face logic can be skipped: 30 fewer instructions per step and 166 -> 125 VGPRs for the sweep, 3 -> 4 waves per SIMD,
+    // gradient call alone 25.6 -> 24.9 ms.  In the two-stream step it LOST 0.4 ms (39.88 vs 39.46 ms, three alternating runs each), and
+    // for sdf_direct_reparam the smaller register footprint put a third wave of incoherent shadow rays on every SIMD: gradient call
+    // 93 -> 128 ms.  Removed; profiles/r05_ab.md.)
+    V3 bd_d;
+    float bd = bbox_distance_inside_d(x, lo, hi, bd_d);
     const float bbox_eps = 0.01f;
+    float bw = i > 0 ? fminf(bd, bbox_eps) * (1.f / bbox_eps) : 1.f;
+    V3 bw_d = (i > 0 && bd < bbox_eps) ? bd_d * (1.f / bbox_eps) : mk(0.f, 0.f, 0.f);
     V3 grad = (2.f * ratio) * (d - ratio * g);
     V3 denom_d = drsign(v) * g + P.sil_weight_offset * symmul(H, grad);
     V3 dist_w_d = (-3.f * dist_w * inv_denom) * denom_d;
-#if DSDF_BBOX_FAST
-    // The fade towards the box wall (shapes.py:86-92) only acts within bbox_eps of it: elsewhere -- almost every step of almost
-    // every ray -- bw = min(bd, eps) / eps is exactly 1 (0.01f * (1.f / 0.01f) rounds to 1.f) and its gradient exactly 0, so
-    // weight_d = dist_w * 0 + 1 * dist_w_d = dist_w_d to the last bit.  The distance itself is six subtractions and five minima;
-    // the direction (nearest face, its sign) is only worked out inside the fade zone.
-    const float bd = fmaxf(0.f, fminf(fminf(fminf(x.x - bx(lo), x.y - by(lo)), x.z - bz(lo)), fminf(fminf(bx(hi) - x.x, by(hi) - x.y), bz(hi) - x.z)));
-    if (!(i > 0 && bd < bbox_eps)) {
-        weight_d = dist_w_d;
-        return dist_w;
-    }
-    V3 bd_d;
-    (void)bbox_distance_inside_d(x, lo, hi, bd_d);
-    const float bw = bd * (1.f / bbox_eps);
-    const V3 bw_d = bd_d * (1.f / bbox_eps);
     weight_d = dist_w * bw_d + bw * dist_w_d;
     return dist_w * bw;
-#else
-    V3 bd_d;
-    float bd = bbox_distance_inside_d(x, lo, hi, bd_d);
-    float bw = i > 0 ? fminf(bd, bbox_eps) * (1.f / bbox_eps) : 1.f;
-    V3 bw_d = (i > 0 && bd < bbox_eps) ? bd_d * (1.f / bbox_eps) : mk(0.f, 0.f, 0.f);
-    weight_d = dist_w * bw_d + bw * dist_w_d;
-    return dist_w * bw;
-#endif
 }
 
 struct TraceOut {

@@ -55,14 +55,6 @@
 #ifndef DSDF_TAIL_BLOCKS_PER_SUBQ
 #define DSDF_TAIL_BLOCKS_PER_SUBQ 4    /* x 4 waves x 64 sub-queues: 1024 persistent tail waves = one per SIMD.  A tail kernel is the chain of its longest rays (2000+ steps); every further resident wave per SIMD slows that chain down (step: 47.2 / 44.4 / 44.0 / 46.0 / 46.6 ms at 1 / 2 / 4 / 8 / 16 blocks, profiles/r04_tail_ab.md) */
 #endif
-// A tail wave that holds a LONG ray stops refilling (DSDF_TAIL_LONG lock-step iterations in this wave, 0 = off).  The kernels end with
-// the chains of their longest rays (2000+ steps); while such a ray shares its wave with freshly claimed ones, every iteration of
-// the wave waits for the gathers of the newcomers (a cell entered -> 16 rows from L2), i.e. the chain advances at the pace of a
-// memory round trip.  Once the wave has drained to its long rays -- which creep through one cell for dozens of steps, taps in
-// registers -- an iteration is a short ALU chain.  The queue entries it does not claim are taken by the other waves.
-#ifndef DSDF_TAIL_LONG
-#define DSDF_TAIL_LONG 0            /* default of the run-time setting (environment DSDF_TAIL_LONG) */
-#endif
 #define DSDF_TAIL_WORDS 23          /* gradient sweep: view, sample id, t, warp_t, prev_sd, wsum, ews, 5 x V3, step counter */
 #define DSDF_PTAIL_WORDS 3          /* primal: view, sample id, t (everything else follows from the sample id) */
 #define DSDF_TAIL_HANDOFF_MAX (DSDF_TAIL_HANDOFF > DSDF_PTAIL_HANDOFF ? DSDF_TAIL_HANDOFF : DSDF_PTAIL_HANDOFF)
@@ -86,7 +78,6 @@ struct TailQueue {
     float *state;      // [DSDF_TAIL_SUBQ][cap_sub][words] march states
     uint32_t cap_sub;
     uint32_t per_xcd;  // 1: sub-queue = (XCD of the producer, ticket counter); 0: sub-queue = work-list index % DSDF_TAIL_SUBQ
-    uint32_t hold_after;   // a tail wave stops refilling while it holds a ray older than this many of its iterations (0: never)
 };
 
 // One reservation per wave in sub-queue `sub`: `n` consecutive entries, or nothing when they do not fit (compare-and-swap, so a
@@ -210,15 +201,13 @@ __global__ __launch_bounds__(256) void k_tail_trace_diff(GridView G, dsdf_params
     uint32_t sample = 0, view = 0;
     bool exhausted = false;
     int n_steps = 0, n_wsteps = 0, n_rays = 0, n_hits = 0, n_need = 0;
-    int age = 0;                                                         // lock-step iterations since this lane claimed its ray
 #if DSDF_TAIL_DIFF_REUSE
     ReuseFetch RF;
 #endif
 
     while (true) {
         const uint64_t idle = __ballot(!m.active);
-        const bool hold = tq.hold_after != 0u && __ballot(m.active && age > (int)tq.hold_after) != 0;
-        if (!exhausted && !hold && __popcll(idle) >= DSDF_TAIL_REFILL) {
+        if (!exhausted && __popcll(idle) >= DSDF_TAIL_REFILL) {
             bool drained = false;
             const uint32_t idx = tail_claim(cnt, total, idle, !m.active, drained);
             const float *e = ent + (size_t)idx * DSDF_TAIL_WORDS;       // (read below, before the queue is switched)
@@ -234,7 +223,6 @@ __global__ __launch_bounds__(256) void k_tail_trace_diff(GridView G, dsdf_params
                 m.wdsum = mk(e[16], e[17], e[18]); m.ews_d = mk(e[19], e[20], e[21]);
                 m.i = __float_as_int(e[22]);
                 ++n_rays;
-                age = 0;
 #if DSDF_TAIL_DIFF_REUSE
                 RF.valid = false;
 #endif
@@ -245,7 +233,6 @@ __global__ __launch_bounds__(256) void k_tail_trace_diff(GridView G, dsdf_params
             continue;
         }
         ++n_wsteps;
-        ++age;
         if (m.active) {
             V3 x = fma3(m.t, m.d, m.o);
             float v; V3 g; float H[6];
@@ -320,12 +307,10 @@ __global__ __launch_bounds__(256) void k_tail_trace_plain(GridView G, dsdf_param
     uint32_t view = 0;
     bool exhausted = false;
     int n_steps = 0, n_wsteps = 0, n_rays = 0, n_hits = 0, n_ref = 0;
-    int age = 0;
 
     while (true) {
         const uint64_t idle = __ballot(!m.active);
-        const bool hold = tq.hold_after != 0u && __ballot(m.active && age > (int)tq.hold_after) != 0;
-        if (!exhausted && !hold && __popcll(idle) >= DSDF_TAIL_REFILL) {
+        if (!exhausted && __popcll(idle) >= DSDF_TAIL_REFILL) {
             bool drained = false;
             const uint32_t idx = tail_claim(cnt, total, idle, !m.active, drained);
             const float *e = ent + (size_t)idx * DSDF_PTAIL_WORDS;      // (read below, before the queue is switched)
@@ -337,7 +322,6 @@ __global__ __launch_bounds__(256) void k_tail_trace_plain(GridView G, dsdf_param
                 m.t = e[2];
                 F.valid = false;
                 ++n_rays;
-                age = 0;
             }
         }
         if (__ballot(m.active) == 0) {
@@ -345,7 +329,6 @@ __global__ __launch_bounds__(256) void k_tail_trace_plain(GridView G, dsdf_param
             continue;
         }
         ++n_wsteps;
-        ++age;
         if (m.active) {
             float v = 0.f; V3 gd; float Hd[6];
             F.template eval<0>(G, fma3(m.t, m.d, m.o), true, v, gd, Hd);

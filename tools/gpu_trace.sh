@@ -11,7 +11,7 @@ for spec in "$@"; do
   [ -n "$lib" ] && [ "$lib" != default ] && L=$PWD/differentiable-sdf-rendering_amd/lib/variants/libdsdf_$lib.so
   E="AB_TAG=$tag DSDF_LIB_PATH=$L"
   [ -n "$envs" ] && E="$E ${envs//,/ }"
-  env $E timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_$tag -o t -- python tools/ab_step.py $AB_ARGS > $O/trace_$tag.log 2>&1
+  env $E timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_$tag -o t -- python ${AB_SCRIPT:-tools/ab_step.py} $AB_ARGS > $O/trace_$tag.log 2>&1
   f=$(find $O/trace_$tag -name "t_kernel_stats.csv" | head -1)
   [ -n "$f" ] && cp $f $O/trace_${tag}_stats.csv && head -12 $f | cut -c1-160
   k=$(find $O/trace_$tag -name "t_kernel_trace.csv" | head -1)
