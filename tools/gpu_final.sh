@@ -25,14 +25,6 @@ $P --pmc FETCH_SIZE -d $O/pmc_f -o f -- python tools/pmc_workload.py --low --dir
 $P --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum -d $O/pmc_w -o w -- python tools/pmc_workload.py --low --direct > $O/pmc_w.log 2>&1; tail -1 $O/pmc_w.log
 find $O -name "*.db" -delete
 python profiles/summarize_pmc.py $TAG $O $O/pmc_stats.json > $O/summarize_pmc.log 2>&1; tail -4 $O/summarize_pmc.log | cut -c1-600
-# the OTHER tail-queue mapping (round 3's: sub-queue = work-list index % 64) for comparison with the per-XCD default:
-# L2 hit / miss and HBM bytes of the tail kernels -> <tag>_item_sq.json
-mkdir -p $O/item
-DSDF_TAIL_QUEUES=item $P --pmc FETCH_SIZE -d $O/item/pmc_f -o f -- python tools/pmc_workload.py > $O/item_f.log 2>&1
-DSDF_TAIL_QUEUES=item $P --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum -d $O/item/pmc_w -o w -- python tools/pmc_workload.py > $O/item_w.log 2>&1
-DSDF_TAIL_QUEUES=item $P --pmc SQ_BUSY_CU_CYCLES SQ_CYCLES SQ_INST_CYCLES_SALU SQ_THREAD_CYCLES_VALU SQ_IFETCH SQ_ACTIVE_INST_SCA GRBM_GUI_ACTIVE -d $O/item/pmc_c -o c -- python tools/pmc_workload.py > $O/item_c.log 2>&1
-find $O -name "*.db" -delete
-python profiles/summarize_pmc.py ${TAG}_item $O/item > $O/summarize_pmc_item.log 2>&1
 echo "== bench (reads profiles/valu_model.json written above)"; date
 timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err; tail -c 6000 $O/bench.json; tail -2 $O/bench.err
 timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 --overlap 0 --no-cpu-baseline --no-direct --no-opt-iteration > $O/bench_seq.json 2> $O/bench_seq.err

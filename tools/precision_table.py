@@ -63,6 +63,37 @@ def worker(cases):
     print('ROWS=' + json.dumps(rows))
 
 
+def ref32_section():
+    """The reference's OWN files at the reference's OWN precision (tests/golden/refshim32_*.npz: tools/make_reference_fixtures.py --shim
+    with REFSHIM_DTYPE=float32) next to their fp64 run (refshim_*.npz) and the HIP path: relative L2 of dL/dsdf."""
+    import numpy as np
+    import dsdf
+    import test_refshim_fixture as T
+    import __graft_entry__ as g
+    from conftest import HostHarness
+    dsdf.load()
+    hh = HostHarness(g.build_harness())
+    rel = T.rel_l2
+    print()
+    print('| case | run | lanes | reference fp32 vs reference fp64 | HIP vs reference fp64 | HIP vs reference fp32 | host build of the kernel arithmetic vs reference fp64 | image: HIP vs reference fp64 |')
+    print('|---|---|---|---|---|---|---|---|')
+    ratios, out = [], []
+    for name, tag in T.FP32_RUNS:
+        ref, r32 = T.load(name), T.load32(name)
+        x = T.inputs(ref)
+        gg = T._gpu_backward(dsdf, name, tag)
+        gh = T._host_backward(hh, ref, x, tag)
+        a64, a32 = ref[f'grad_{tag}'], r32[f'grad_{tag}']
+        f, e64, e32, h64 = rel(a32, a64), rel(gg, a64), rel(gg, a32), rel(gh, a64)
+        sen = dsdf.Sensor(ref['origin'], resx=x['W'], resy=x['H'])
+        ratios.append(e64 / f)
+        out.append(dict(case=name, tag=tag, ref32_vs_ref64=f, hip_vs_ref64=e64, hip_vs_ref32=e32, host_vs_ref64=h64))
+        print(f"| {name} | {tag} | {x['n']} | {f:8.2e} | {e64:8.2e} | {e32:8.2e} | {h64:8.2e} | - |")
+    gm = float(np.exp(np.mean(np.log(ratios))))
+    print(f"\ngeometric mean of (HIP vs reference fp64) / (reference fp32 vs reference fp64) over the {len(ratios)} runs: {gm:.2f}")
+    return dict(rows=out, geometric_mean_ratio=gm)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--worker', action='store_true')
@@ -105,6 +136,12 @@ def main():
               f"{f(e.get('grad_ieee'))} | {f(e['floor_c'])} | {f(e['floor_torch'] or None)} | {f(e.get('grad_vs_c32_fast'))} | {f(e.get('grad_trim_fast'))} | "
               f"{f(e['floor_trim'])} | {f(e.get('grad_err_trim01_fast'))} | {f(e['floor_trim01'])} | "
               f"{e.get('attr_removed_fast', '-')} / {e.get('attr_budget_fast', '-')} | {f(e.get('attr_rest_fast'))} | {f(e.get('attr_gate_fast'))} |")
+    try:
+        r32 = ref32_section()
+        d = json.load(open(args.out)); d['reference_fp32'] = r32
+        json.dump(d, open(args.out, 'w'), indent=1)
+    except Exception as e:                                   # (the main table stands on its own)
+        print(f'reference-fp32 section failed: {e!r}', file=sys.stderr)
 
 
 if __name__ == '__main__':
