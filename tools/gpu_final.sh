@@ -29,7 +29,7 @@ echo "== bench (reads profiles/valu_model.json written above)"; date
 timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err; tail -c 6000 $O/bench.json; tail -2 $O/bench.err
 timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 --overlap 0 --no-cpu-baseline --no-direct --no-opt-iteration > $O/bench_seq.json 2> $O/bench_seq.err
 echo "== kernel trace (the default bench command, without the side blocks)"; date
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o t -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-low-spp --no-direct --no-opt-iteration > $O/trace.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o t -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-low-spp --no-direct --no-opt-iteration --no-scaling-prediction > $O/trace.log 2>&1
 f=$(find $O/trace -name "t_kernel_stats.csv" | head -1); k=$(find $O/trace -name "t_kernel_trace.csv" | head -1)
 [ -n "$f" ] && python profiles/summarize.py $TAG $f $k > $O/summarize.log 2>&1
 [ -n "$k" ] && python tools/step_timeline.py $k > profiles/${TAG}_step_timeline.md 2> $O/step_timeline.err
