@@ -365,7 +365,9 @@ def test_fixture_is_what_the_reference_code_produces(tmp_path):
 # one-footprint rule, stay in force; these add the reference's own code at its own precision as the third witness.)
 REF32_RUN_FACTOR, REF32_MEAN_FACTOR = 6.0, 2.0
 FP32_RUNS = [('sphere16', 'sil'), ('sphere16', 'shade'), ('sphere16', 'direct'), ('blob32', 'sil'), ('blob32', 'shade'), ('blob32', 'direct'),
-             ('blob32', 'direct_mis'), ('blob32_spp64', 'sil'), ('blob32_spp64', 'shade')]
+             ('blob32', 'direct_mis'), ('blob32_spp64', 'sil'), ('blob32_spp64', 'shade'),
+             # BASELINE.json configs[0] sizes (64^3, 128 x 128; spp 4: 70 k lanes) -- the reference's own CPU-runnable case
+             ('c1_spp4', 'sil'), ('c1_spp4', 'shade')]
 
 
 def load32(name):
@@ -378,7 +380,7 @@ def reference_floor(name, tag):
                 gradp=rel_l2(r32[f'gradp_{tag}'], r64[f'gradp_{tag}']))
 
 
-@pytest.mark.parametrize('name', ['sphere16', 'blob32', 'blob32_spp64'])
+@pytest.mark.parametrize('name', ['sphere16', 'blob32', 'blob32_spp64', 'c1_spp4'])
 def test_reference_fp32_run_sees_the_same_inputs(name):
     r32, r64 = load32(name), load(name)
     for k in ('grid', 'cam16', 'sampler_2d', 'grad_image', 'albedo', 'env'):
@@ -394,9 +396,17 @@ def test_reference_code_fp32_floor(name, tag):
     f = reference_floor(name, tag)
     assert f['img'] < 1e-4, f
     assert 1e-5 < f['grad'] < 1e-2, f
-    x = inputs(load(name))
-    o32 = oracle_run(x, tag, torch.float32)
-    floor_oracle = rel_l2(o32[1].numpy().astype(np.float64), load(name)[f'grad_{tag}'])
+    ref = load(name)
+    if name == 'c1_spp4':
+        # (config size: the C restatement's fp32 build instead of the torch oracle's -- the same floor the config-size gates use)
+        import c_oracle
+        integ = TAGS[tag][0]
+        g32, _ = c_oracle.render_backward(c_oracle.load(False), ref['grid'], ref['cam16'], int(ref['W']), int(ref['H']), int(ref['spp']),
+                                          ref['sampler_2d'], ref['grad_image'], integ, True)
+        floor_oracle = rel_l2(g32, ref[f'grad_{tag}'])
+    else:
+        o32 = oracle_run(inputs(ref), tag, torch.float32)
+        floor_oracle = rel_l2(o32[1].numpy().astype(np.float64), ref[f'grad_{tag}'])
     assert floor_oracle / 10 < f['grad'] < floor_oracle * 10, (f, floor_oracle)
     P.record('reference_fp32_floor', case=name, tag=tag, floor_reference=f['grad'], floor_torch_oracle=floor_oracle, image=f['img'])
 

@@ -56,11 +56,14 @@ def case_inputs(name):
     seeded generator exactly as tests/cases.py draws it."""
     import torch
     cfg = {'sphere16': (16, 1, 0, 16, 16, 4, 1), 'blob32': (32, 3, 1, 24, 24, 8, 2),
-           'blob32_spp64': (32, 3, 2, 12, 12, 64, 3)}[name]          # (the same tuples as tests/cases.py)
+           'blob32_spp64': (32, 3, 2, 12, 12, 64, 3),                # (the same tuples as tests/cases.py)
+           # BASELINE.json configs[0] -- "sphere 64^3 SDF, 1 view, 128 x 128", the reference's own CPU-runnable case -- at spp 4
+           # (tests/precision.py: C1_spp4; 70 k lanes)
+           'c1_spp4': (64, 1, 0, 128, 128, 4, 21)}[name]
     R, ncam, icam, W, H, spp, seed = cfg
     sys.path.insert(0, os.path.join(ROOT, 'oracle'))
     import sdf_oracle as O                                          # grids + camera ring: plain torch, no product code
-    grid = (O.sphere_grid(16) if name == 'sphere16' else O.blob_grid(32, n=6, seed=1)).float().numpy()
+    grid = (O.sphere_grid(16) if name == 'sphere16' else (O.sphere_grid(64) if name == 'c1_spp4' else O.blob_grid(32, n=6, seed=1))).float().numpy()
     gen = torch.Generator().manual_seed(seed)
     torch.rand((W + 4) * (H + 4) * spp, 2, generator=gen, dtype=torch.float32)      # (cases.py draws the explicit offsets first)
     grad_image = torch.randn(H, W, 3, generator=gen, dtype=torch.float32).numpy()
