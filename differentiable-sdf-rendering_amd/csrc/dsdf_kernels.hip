@@ -203,6 +203,7 @@ __device__ __forceinline__ void load_record(const float *r, size_t c, TraceOut &
 #include "dsdf_film.h"
 #include "dsdf_proof.h"
 #include "dsdf_skip.h"
+#include "dsdf_coop.h"
 #include "dsdf_tail.h"
 
 // ------------------------------------------------------------------ render pass
@@ -528,10 +529,25 @@ __global__ __launch_bounds__(DSDF_BLOCK) void k_render_pass(GridView G, dsdf_par
     Lane L;
     const bool windowed = M.tile_w && __ballot(!far) != 0;       // (a wave of far pixels touches nothing)
     if (windowed) tile_window_clear<NCH>(TW, lid);
+#if DSDF_COOP
+    // the primary rays of the wave, traced at wave level (dsdf_coop.h: the last rays get 16 lanes each)
+    constexpr bool COOP = !DIRECT && ((DSDF_COOP >> (DIFF ? 1 : 0)) & 1);        // bit 0: plain traces, bit 1: differentiable traces
+    if (COOP) {
+        const bool on = !far && !known_hit && !skip_trace;
+        if (!far) L = lane_setup(A, P, lane);
+        else { L.ray.o = mk(0.f, 0.f, 0.f); L.ray.d = mk(0.f, 0.f, 1.f); L.ray.maxt = 0.f; }
+        if (__ballot(on) != 0) {
+            if (DIFF) coop_trace_diff(G, P, L.ray.o, L.ray.d, L.ray.maxt, on, tr, lid);
+            else coop_trace_plain(G, P, L.ray.o, L.ray.d, L.ray.maxt, on, tr, lid);
+        }
+    }
+#else
+    constexpr bool COOP = false;
+#endif
     if (!far) {
-        L = lane_setup(A, P, lane);
+        if (!COOP) L = lane_setup(A, P, lane);
         if (known_hit) tr.its_t = 0.f;
-        else if (!skip_trace) {
+        else if (!skip_trace && !COOP) {
             if (DIFF) trace_diff(G, P, L.ray.o, L.ray.d, L.ray.maxt, tr);
             else if (!DIRECT) {
                 // the pass ends with its longest rays, a few lanes sliding along a surface in sub-voxel steps: they keep the
@@ -621,13 +637,15 @@ __global__ void k_develop_aov(const float *__restrict__ blocks, int W, int H, fl
 struct UnitGather {
     uint32_t c[DSDF_BWD_UNITS], lo[DSDF_BWD_UNITS], total, unit0;
     // the queued samples [from[u], count[u]) of the group's units (from == nullptr: all of them)
-    __device__ __forceinline__ void init(const Queue &q, uint32_t group, const uint32_t *from = nullptr) {
+    // (`upto`: the counts to use instead of q.count -- a snapshot of them, while another kernel is still appending)
+    __device__ __forceinline__ void init(const Queue &q, uint32_t group, const uint32_t *from = nullptr, const uint32_t *upto = nullptr) {
         unit0 = group * (uint32_t)DSDF_BWD_UNITS;
         total = 0;
+        const uint32_t *cnt = upto ? upto : q.count;
 #pragma unroll
         for (int k = 0; k < DSDF_BWD_UNITS; ++k) {
             const bool in = unit0 + k < q.nunits;
-            const uint32_t n = in ? (uint32_t)__builtin_amdgcn_readfirstlane((int)q.count[unit0 + k]) : 0u;
+            const uint32_t n = in ? (uint32_t)__builtin_amdgcn_readfirstlane((int)cnt[unit0 + k]) : 0u;
             lo[k] = (in && from) ? (uint32_t)__builtin_amdgcn_readfirstlane((int)from[unit0 + k]) : 0u;
             c[k] = n - (lo[k] < n ? lo[k] : n);
             total += c[k];
@@ -734,12 +752,12 @@ __global__ __launch_bounds__(64, DIRECT ? DSDF_BWD_DIRECT_MINWAVES : DSDF_BWD_MI
 #define DSDF_COEF_MINWAVES 1
 #endif
 __global__ __launch_bounds__(64, DSDF_COEF_MINWAVES) void k_backward_coef(GridView G, dsdf_params P, ViewBatch VB, Queue qall, const uint32_t *__restrict__ from,
-                                                      uint32_t *__restrict__ mark) {
+                                                      uint32_t *__restrict__ mark, const uint32_t *__restrict__ upto) {
     const ViewArgs &A = VB.v[blockIdx.y];
     const Queue q = view_queue(qall, blockIdx.y);
     const size_t voff = (size_t)blockIdx.y * q.nunits;
     UnitGather ug;
-    ug.init(q, blockIdx.x, from ? from + voff : nullptr);
+    ug.init(q, blockIdx.x, from ? from + voff : nullptr, upto ? upto + voff : nullptr);
     if (mark && threadIdx.x < DSDF_BWD_UNITS && ug.unit0 + threadIdx.x < q.nunits)
         mark[voff + ug.unit0 + threadIdx.x] = q.count[ug.unit0 + threadIdx.x];
     for (uint32_t si = threadIdx.x; si < ug.total; si += 64) {
@@ -927,7 +945,7 @@ static Workspace carve(void *base, int W, int H, int spp, int nv, int integrator
         const size_t handoff = diff ? DSDF_TAIL_HANDOFF : DSDF_PTAIL_HANDOFF;
         ws.tail_words = diff ? DSDF_TAIL_WORDS : DSDF_PTAIL_WORDS;
         ws.tail_cap_sub = (uint32_t)((ws.group_views * Wb * Hb * (size_t)(spp / 64) + DSDF_TAIL_SUBQ - 1) / DSDF_TAIL_SUBQ * handoff);
-        ws.tail_bytes = align_up((size_t)DSDF_MAX_GROUPS * DSDF_TAIL_SUBQ * 2 * sizeof(uint32_t), 256) +
+        ws.tail_bytes = align_up((size_t)DSDF_MAX_GROUPS * DSDF_TAIL_SUBQ * DSDF_TAIL_CNT_STRIDE * sizeof(uint32_t), 256) +
                         (size_t)DSDF_MAX_GROUPS * align_up((size_t)DSDF_TAIL_SUBQ * ws.tail_cap_sub * ws.tail_words * sizeof(float), 256);
         ws.tail = p + off; off += ws.tail_bytes;
     }
@@ -1139,7 +1157,8 @@ struct PassCtx {
     float *film;           // caller-owned film block to ACCUMULATE into (tile calls), or nullptr: the workspace's, zeroed
     hipStream_t st;
     bool coef_early;       // gradient sweep: launch k_backward_coef for the render kernel's own samples AHEAD of the tail kernel
-    bool coef_done_early;  // (set by run_pass when it did)
+    bool coef_beside;      // ... or BESIDE the tail kernel, on the other helper stream, up to a snapshot of the queue lengths (DSDF_COEF_EARLY=2)
+    bool coef_done_early;  // (set by run_pass when it did either)
 };
 
 static PassCtx make_ctx(const float *padded, int rx, int ry, int rz, const dsdf_params *prm, int W, int H, int spp,
@@ -1157,7 +1176,7 @@ static PassCtx make_ctx(const float *padded, int rx, int ry, int rz, const dsdf_
     c.Wb = W + 2 * DSDF_BORDER; c.Hb = H + 2 * DSDF_BORDER; c.nl = (uint32_t)(c.Wb * c.Hb * spp);
     c.row0 = 0; c.row1 = (int)c.Hb; c.film = nullptr;
     c.st = (hipStream_t)stream;
-    c.coef_early = false; c.coef_done_early = false;
+    c.coef_early = false; c.coef_beside = false; c.coef_done_early = false;
     return c;
 }
 
@@ -1210,7 +1229,7 @@ static bool deep_skip_enabled() { static const int v = env_int("DSDF_DEEP_SKIP",
 // DSDF_COEF_EARLY=1: k_backward_coef for the render kernel's own samples AHEAD of the tail kernel + a second launch for what the
 // tail appended.  Measured (profiles/r04_tail_ab.md): the early launch is starved by the primal workers just like the tail kernel
 // (15 ms resident), and the tail kernel then starts later: step 42.5 vs 40.8 ms.  Default: one launch behind the tail kernel.
-static bool coef_early_enabled() { static const int v = env_int("DSDF_COEF_EARLY", 0); return v != 0; }
+static int coef_early_mode() { static const int v = env_int("DSDF_COEF_EARLY", 0); return v; }
 static int hit_proof_min_spp() { static const int v = env_int("DSDF_HIT_PROOF_MIN_SPP", 16); return v; }
 static bool primal_handoff() { static const int v = env_int("DSDF_PRIMAL_HANDOFF", 1); return v != 0; }
 static int tail_streams_enabled() { static int v = env_int("DSDF_TAIL_STREAMS", 1); return v; }
@@ -1266,6 +1285,7 @@ static hipEvent_t next_event() {
 // Measurement hook (include/dsdf.h: dsdf_kernel_timing_arm / _read): when armed, the next render call of this thread brackets
 // its render kernel(s) -- k_render_items / k_render_pass only, not the list build before or the tail kernel after -- with two
 // library-owned HIP events on the caller's stream.  bench.py's roofline divides by THIS duration.
+static thread_local unsigned long long *g_tail_stats = nullptr;      // dsdf_tail_stats_arm
 static thread_local hipEvent_t g_time_ev[2] = {nullptr, nullptr};
 static thread_local int g_time_state = 0;          // 0 idle, 1 armed, 2 recorded
 
@@ -1391,7 +1411,7 @@ static int run_pass(PassCtx &c, const Workspace &ws, const dsdf_camera *cams, in
             return fail(DSDF_ERR_LAUNCH, "hipMemsetAsync(queue counts) failed");
         // view groups: render kernel g on the caller's stream, tail kernel g on a helper stream beside render kernel g + 1
         const bool handoff = ws.tail != nullptr && (DIFF || primal_handoff());
-        const size_t cnt_bytes = align_up((size_t)DSDF_MAX_GROUPS * DSDF_TAIL_SUBQ * 2 * sizeof(uint32_t), 256);
+        const size_t cnt_bytes = align_up((size_t)DSDF_MAX_GROUPS * DSDF_TAIL_SUBQ * DSDF_TAIL_CNT_STRIDE * sizeof(uint32_t), 256);
         const size_t grp_bytes = align_up((size_t)DSDF_TAIL_SUBQ * ws.tail_cap_sub * ws.tail_words * sizeof(float), 256);
         if (handoff && hipMemsetAsync(ws.tail, 0, cnt_bytes, st) != hipSuccess)
             return fail(DSDF_ERR_LAUNCH, "hipMemsetAsync(tail queue) failed");
@@ -1427,7 +1447,7 @@ static int run_pass(PassCtx &c, const Workspace &ws, const dsdf_camera *cams, in
             if (handoff) {
                 tq.cap_sub = ws.tail_cap_sub * (uint32_t)kreg;
                 tq.per_xcd = (uint32_t)tail_per_xcd();
-                tq.count = (uint32_t *)ws.tail + (size_t)g * DSDF_TAIL_SUBQ * 2;
+                tq.count = (uint32_t *)ws.tail + (size_t)g * DSDF_TAIL_SUBQ * DSDF_TAIL_CNT_STRIDE;
                 tq.state = (float *)(ws.tail + cnt_bytes + (size_t)g * kreg * grp_bytes);
             }
             if (g == 0) timing_mark(0, st);
@@ -1443,9 +1463,17 @@ static int run_pass(PassCtx &c, const Workspace &ws, const dsdf_camera *cams, in
             if (DIFF && handoff && c.coef_early && ngroups == 1 && ws.count0) {
                 // the coefficients of what the render kernel queued itself, ahead of the tail kernel (k_backward_coef's comment)
                 const dim3 cgrid((ws.nunits + DSDF_BWD_UNITS - 1) / DSDF_BWD_UNITS, nv);
-                hipLaunchKernelGGL(k_backward_coef, cgrid, dim3(64), 0, st, G, c.pp, VB, q, (const uint32_t *)nullptr, ws.count0);
+                hipLaunchKernelGGL(k_backward_coef, cgrid, dim3(64), 0, st, G, c.pp, VB, q, (const uint32_t *)nullptr, ws.count0, (const uint32_t *)nullptr);
                 if ((rc = check_launch("k_backward_coef"))) return rc;
                 c.coef_done_early = true;
+            }
+            bool coef_beside = false;
+            hipStream_t chs[2] = {st, st};
+            if (DIFF && handoff && c.coef_beside && ngroups == 1 && ws.count0 && helper_streams(st, chs)) {
+                // the queue lengths as the render kernel leaves them: the tail kernel appends behind them from now on
+                if (hipMemcpyAsync(ws.count0, ws.count, (size_t)nv * ws.nunits * sizeof(uint32_t), hipMemcpyDeviceToDevice, st) != hipSuccess)
+                    return fail(DSDF_ERR_LAUNCH, "hipMemcpyAsync(queue lengths) failed");
+                coef_beside = true;
             }
             if (handoff) {
                 hipStream_t ts = st;
@@ -1456,13 +1484,29 @@ static int run_pass(PassCtx &c, const Workspace &ws, const dsdf_camera *cams, in
                         return fail(DSDF_ERR_LAUNCH, "tail stream fork failed");
                 }
                 const dim3 tgrid(DSDF_TAIL_SUBQ * tail_blocks()), tblk(256);
-                if (DIFF) hipLaunchKernelGGL(k_tail_trace_diff, tgrid, tblk, 0, ts, G, c.pp, VB, film, tq, q, st64);
-                else hipLaunchKernelGGL(k_tail_trace_plain, tgrid, tblk, 0, ts, G, c.pp, VB, film, tq, st64);
+                unsigned long long *tst = st64 ? st64 : g_tail_stats;
+                if (DIFF) hipLaunchKernelGGL(k_tail_trace_diff, tgrid, tblk, 0, ts, G, c.pp, VB, film, tq, q, tst);
+                else hipLaunchKernelGGL(k_tail_trace_plain, tgrid, tblk, 0, ts, G, c.pp, VB, film, tq, tst);
                 if ((rc = check_launch("k_tail_trace"))) return rc;
                 if (forked) {
                     hipEvent_t e = next_event();
                     if (!e || hipEventRecord(e, ts) != hipSuccess) return fail(DSDF_ERR_LAUNCH, "tail stream join failed");
                     joins[njoin++] = e;
+                }
+                if (coef_beside) {
+                    // ... and the coefficients of the samples the render kernel queued itself on the OTHER helper stream, beside the tail
+                    // kernel (it waits for the render kernel and the copy above)
+                    hipStream_t cs = chs[1];
+                    hipEvent_t e = next_event();
+                    if (!e || hipEventRecord(e, st) != hipSuccess || hipStreamWaitEvent(cs, e, 0) != hipSuccess)
+                        return fail(DSDF_ERR_LAUNCH, "coefficient stream fork failed");
+                    const dim3 cgrid((ws.nunits + DSDF_BWD_UNITS - 1) / DSDF_BWD_UNITS, nv);
+                    hipLaunchKernelGGL(k_backward_coef, cgrid, dim3(64), 0, cs, G, c.pp, VB, q, (const uint32_t *)nullptr, (uint32_t *)nullptr, (const uint32_t *)ws.count0);
+                    if ((rc = check_launch("k_backward_coef"))) return rc;
+                    hipEvent_t e2 = next_event();
+                    if (!e2 || hipEventRecord(e2, cs) != hipSuccess) return fail(DSDF_ERR_LAUNCH, "coefficient stream join failed");
+                    joins[njoin++] = e2;
+                    c.coef_done_early = true;
                 }
             }
         }
@@ -1707,7 +1751,8 @@ int dsdf_grad_sweep(const float *padded, int rx, int ry, int rz, const dsdf_para
     const Workspace ws = carve(workspace, width, height, spp, n_views, integrator, true);
     ViewBatch VB;
     const Queue q = make_queue(ws, c.direct);
-    c.coef_early = q.coef && backward_split() && coef_early_enabled();
+    c.coef_early = q.coef && backward_split() && coef_early_mode() == 1;
+    c.coef_beside = q.coef && backward_split() && coef_early_mode() == 2;
     int rc2 = run_pass<true>(c, ws, cams, 0, n_views, VB, q, nullptr);
     if (rc2) return rc2;
     if (q.coef && backward_split()) {
@@ -1716,7 +1761,7 @@ int dsdf_grad_sweep(const float *padded, int rx, int ry, int rz, const dsdf_para
         // own samples, only what the tail kernel appended is left.)
         const dim3 grid((ws.nunits + DSDF_BWD_UNITS - 1) / DSDF_BWD_UNITS, n_views);
         hipLaunchKernelGGL(k_backward_coef, grid, dim3(64), 0, c.st, device_view(padded, rx, ry, rz, *prm), c.pp, VB, q,
-                           (const uint32_t *)(c.coef_done_early ? ws.count0 : nullptr), (uint32_t *)nullptr);
+                           (const uint32_t *)(c.coef_done_early ? ws.count0 : nullptr), (uint32_t *)nullptr, (const uint32_t *)nullptr);
         return check_launch("k_backward_coef");
     }
     return DSDF_OK;
@@ -1810,6 +1855,11 @@ int dsdf_share_pixel_skip(void *buffer, size_t bytes) {
             return fail(DSDF_ERR_LAUNCH, "dsdf_share_pixel_skip: hipEventCreate failed");
         sh.device = dev;
     }
+    return DSDF_OK;
+}
+
+int dsdf_tail_stats_arm(unsigned long long *stats) {
+    g_tail_stats = stats;
     return DSDF_OK;
 }
 

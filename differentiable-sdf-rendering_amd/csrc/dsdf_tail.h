@@ -31,7 +31,11 @@
 #define DSDF_TAIL_GRACE 2           /* ... after this many more lock-step iterations */
 #endif
 #ifndef DSDF_PTAIL_HANDOFF
-#define DSDF_PTAIL_HANDOFF 8        /* the same two for the primal (value-only) march */
+#define DSDF_PTAIL_HANDOFF 16       /* the same two for the primal (value-only) march.  8 until the tail waves' refills became cheap (round 5: queue
+                                       scan, padded counters, batched completions): twice the rays handed off (1.78 M instead of 0.86 M of 159 M)
+                                       make the primal call 0.3 ms SLOWER on its own and the two-stream step 0.45 ... 0.7 ms faster -- there the
+                                       primal tail runs beside the sweep's tail, which ends later anyway (12 / 16 / 20 / 24 / 32 rays: -0.3 / -0.5 /
+                                       -0.4 / -0.6 / -0.1 ms in three calls, profiles/r05_ab.md r05z2) */
 #endif
 #ifndef DSDF_PTAIL_GRACE
 #define DSDF_PTAIL_GRACE 4
@@ -50,8 +54,34 @@
                                        beside the primal workers for 15 ms and every gather it does NOT issue is a loaded-L2 round trip off the
                                        chain of its longest rays: step 40.6 -> 38.4 ms (profiles/r05_ab.md) */
 #endif
+#ifndef DSDF_TAIL_BATCH
+#define DSDF_TAIL_BATCH 1           /* a finished ray's sample (film splat, shading lookup, backward-queue entry with its returning atomic) is completed
+                                       when the wave refills -- with the >= DSDF_TAIL_REFILL others that finished since -- instead of inside the march
+                                       step in which the ray ended: a tail wave finishes 0.8 rays per lock-step iteration, so nearly every
+                                       iteration of its longest ray's chain carried a completion.  Same samples, same values (the order of the
+                                       film's float adds moves).  Primal call 19.96 -> 19.49 ms, gradient call 25.64 -> 24.87, step 39.53 -> 38.69 ms
+                                       (two runs each in one call, profiles/r05_ab.md r05u) */
+#endif
+#ifndef DSDF_TAIL_VIEWS_IN_LDS
+#define DSDF_TAIL_VIEWS_IN_LDS 1
+#endif
+#ifndef DSDF_TAIL_DEFER
+#define DSDF_TAIL_DEFER 0           /* (measured, r05u: NOT a gain -- primal call +0.4 ms alone, +0.1 ... +0.3 ms on top of DSDF_TAIL_BATCH; the rays that
+                                       sit an iteration out cost 12 % more lock-step iterations and the wait was not the gather's)
+                                       bit 0: k_tail_trace_plain, bit 1: k_tail_trace_diff overlap the gathers of the rays that change cell with the step of the others */
+#endif
+#ifndef DSDF_TAIL_CNT_STRIDE
+#define DSDF_TAIL_CNT_STRIDE 32     /* uint32 words between the {queued, claimed} pairs of two sub-queues: a 128-byte line each (2 = packed, as before round 5) */
+#endif
+#ifndef DSDF_TAIL_SCAN
+#define DSDF_TAIL_SCAN 1            /* a tail wave that has drained a sub-queue looks at ALL 64 {queued, claimed} pairs in one round trip and goes to the
+                                       next one with unclaimed entries (0: it visits them one by one, with a claim that comes back empty for every
+                                       sub-queue another wave has drained already) */
+#endif
 #define DSDF_TAIL_SUBQ 64           /* sub-queues per launch: 8 per XCD (one per ticket counter of the render kernel's XCD share) */
+#ifndef DSDF_TAIL_REFILL
 #define DSDF_TAIL_REFILL 24         /* idle lanes that trigger a refill in the tail kernels */
+#endif
 #ifndef DSDF_TAIL_BLOCKS_PER_SUBQ
 #define DSDF_TAIL_BLOCKS_PER_SUBQ 4    /* x 4 waves x 64 sub-queues: 1024 persistent tail waves = one per SIMD.  A tail kernel is the chain of its longest rays (2000+ steps); every further resident wave per SIMD slows that chain down (step: 47.2 / 44.4 / 44.0 / 46.0 / 46.6 ms at 1 / 2 / 4 / 8 / 16 blocks, profiles/r04_tail_ab.md) */
 #endif
@@ -74,7 +104,7 @@ __device__ __forceinline__ uint32_t tail_hop(uint32_t first, uint32_t k, uint32_
 }
 
 struct TailQueue {
-    uint32_t *count;   // [DSDF_TAIL_SUBQ][2]: {queued, claimed}
+    uint32_t *count;   // [DSDF_TAIL_SUBQ][DSDF_TAIL_CNT_STRIDE]: {queued, claimed, padding}
     float *state;      // [DSDF_TAIL_SUBQ][cap_sub][words] march states
     uint32_t cap_sub;
     uint32_t per_xcd;  // 1: sub-queue = (XCD of the producer, ticket counter); 0: sub-queue = work-list index % DSDF_TAIL_SUBQ
@@ -90,7 +120,7 @@ __device__ __forceinline__ bool tail_reserve(const TailQueue &tq, uint32_t sub, 
     uint32_t b = 0;
     int ok = 0;
     if (lane_id() == leader) {
-        uint32_t *p = tq.count + 2 * sub;
+        uint32_t *p = tq.count + DSDF_TAIL_CNT_STRIDE * sub;
         uint32_t old = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         while (old + n <= tq.cap_sub) {
             const uint32_t prev = atomicCAS(p, old, old + n);
@@ -165,15 +195,42 @@ __device__ __forceinline__ uint32_t tail_claim(uint32_t *cnt, uint32_t total, ui
 }
 
 // tail statistics (slots 8..10 of the caller's stats rows, include/dsdf.h): lane-steps, lock-step iterations, rays
-__device__ __forceinline__ void tail_stats(unsigned long long *stats, int lane_steps, int wave_steps, int rays) {
+// Slots 11..15 of rows 0..3: diagnostics of the tail waves of ONE launch (include/dsdf.h: dsdf_tail_stats_arm lists them).
+__device__ __forceinline__ void tail_stats(unsigned long long *stats, int lane_steps, int wave_steps, int rays, unsigned long long t0,
+                                           unsigned long long c0, unsigned long long c_refill, const unsigned long long *sec, int row) {
     const int ls = wave_sum_i32(lane_steps), r = wave_sum_i32(rays);
+    const unsigned long long dt = wall_clock64() - t0, dc = (unsigned long long)clock64() - c0;
     if (lane_id() == 0) {
         unsigned long long *st = stats + (size_t)(blockIdx.x & 63u) * DSDF_STAT_SLOTS;
         atomicAdd(st + 8, (unsigned long long)ls);
         atomicAdd(st + 9, (unsigned long long)wave_steps);
         atomicAdd(st + 10, (unsigned long long)r);
+        atomicMax(stats + 11, (unsigned long long)wave_steps);
+        atomicMax(stats + 12, dt);
+        atomicAdd(stats + 13, dt);
+        atomicAdd(stats + 14, dc);
+        atomicAdd(stats + 15, c_refill);
+        // row 1: refills, and the refill clocks by section (completion of finished samples / claim + queue switch / entry, camera ray, march state)
+        for (int q = 0; q < 5; ++q) atomicAdd(stats + DSDF_STAT_SLOTS + 11 + q, sec[q]);
+        // row 2 (primal tail) / 3 (the sweep's tail): earliest / latest start and earliest / latest end of a wave, wall-clock ticks
+        // (the buffer starts zeroed: the minima are kept as maxima of the complement)
+        unsigned long long *w = stats + (size_t)row * DSDF_STAT_SLOTS + 11;
+        const unsigned long long t1 = t0 + dt;
+        atomicMax(w, ~t0); atomicMax(w + 1, t0); atomicMax(w + 2, ~t1); atomicMax(w + 3, t1);
     }
 }
+
+// The views of the launch in LDS.  A tail lane resumes rays of ANY view, so `views[view]` is indexed per lane: out of the kernel
+// arguments that is a chain of dependent global loads (camera, film size, seed, sampler offsets) in every refill and every
+// completion -- a third of a tail wave's residence went into its refills (stats slots 14 / 15, profiles/r05_ab.md r05w).
+#define DSDF_TAIL_VIEWS_LDS(VB, views)                                                                  \
+    __shared__ __attribute__((aligned(16))) uint32_t views##_raw[sizeof(ViewBatch) / 4];                  \
+    {                                                                                                   \
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(&(VB));                                \
+        for (uint32_t w = threadIdx.x; w < sizeof(ViewBatch) / 4; w += blockDim.x) views##_raw[w] = src[w]; \
+        __syncthreads();                                                                                \
+    }                                                                                                   \
+    const ViewArgs *views = reinterpret_cast<const ViewArgs *>(views##_raw)
 
 // Resumes the queued rays of the gradient sweep and finishes their samples: value splat, backward-queue entry.
 __global__ __launch_bounds__(256) void k_tail_trace_diff(GridView G, dsdf_params P, ViewBatch VB, float *__restrict__ blocks,
@@ -183,17 +240,43 @@ __global__ __launch_bounds__(256) void k_tail_trace_diff(GridView G, dsdf_params
     uint32_t hop = 0, total = 0;
     uint32_t *cnt = nullptr;
     const float *ent = nullptr;
-    // opens the next non-empty sub-queue; false when all DSDF_TAIL_SUBQ have been visited
+    // opens the next sub-queue with unclaimed entries; false when there is none left
     auto open_next = [&]() {
+#if DSDF_TAIL_SCAN
+        // lane k looks at the sub-queue this wave would visit k-th: one round trip for all of them (the claimed counters move under
+        // device-scope atomics of other waves: an atomic load, not a cached one)
+        const uint32_t sub_k = tail_hop(first, (uint32_t)lane_id(), tq.per_xcd);
+        uint32_t *c = tq.count + DSDF_TAIL_CNT_STRIDE * sub_k;
+        const uint32_t queued = __hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t claimed = __hip_atomic_load(c + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        uint64_t open = __ballot(claimed < queued);
+        open = hop < 64u ? (open >> hop) << hop : 0ull;
+        if (open == 0) { hop = DSDF_TAIL_SUBQ; return false; }
+        const int k = __builtin_ctzll(open);
+        hop = (uint32_t)k + 1u;
+        const uint32_t sub = tail_hop(first, (uint32_t)k, tq.per_xcd);
+        cnt = tq.count + DSDF_TAIL_CNT_STRIDE * sub;
+        ent = tq.state + (size_t)sub * tq.cap_sub * DSDF_TAIL_WORDS;
+        total = (uint32_t)__builtin_amdgcn_readlane((int)queued, k);
+        return true;
+#else
         while (hop < DSDF_TAIL_SUBQ) {
             const uint32_t sub = tail_hop(first, hop++, tq.per_xcd);
-            cnt = tq.count + 2 * sub;
+            cnt = tq.count + DSDF_TAIL_CNT_STRIDE * sub;
             ent = tq.state + (size_t)sub * tq.cap_sub * DSDF_TAIL_WORDS;
             total = (uint32_t)__builtin_amdgcn_readfirstlane((int)cnt[0]);
             if (total != 0) return true;
         }
         return false;
+#endif
     };
+#if DSDF_TAIL_VIEWS_IN_LDS
+    DSDF_TAIL_VIEWS_LDS(VB, views);
+#else
+    const ViewArgs *views = VB.v;
+#endif
+    const unsigned long long t_start = stats ? wall_clock64() : 0ull, c_start = stats ? (unsigned long long)clock64() : 0ull;
+    unsigned long long c_refill = 0, c_sec[5] = {0, 0, 0, 0, 0};
     if (!open_next()) return;
     DiffMarch m;
     m.active = false;
@@ -205,17 +288,49 @@ __global__ __launch_bounds__(256) void k_tail_trace_diff(GridView G, dsdf_params
     ReuseFetch RF;
 #endif
 
+    // the sample of this lane is complete: what the render pass does after its loop
+    auto complete = [&]() {
+        const ViewArgs &A = views[view];
+        DirectFetch F;
+        TraceOut tr;
+        tr.its_t = refine_hit(G, P, m.o, m.d, m.its_t, m.trace_eps, tr.refine_steps, F);
+        diff_march_finish(m, tr);
+        const float val = shade_value(G, A, L, tr.its_t);
+        if (val != 0.f) {
+            Reproj rp = reproject(A.cam, P, L.ray.o + L.ray.d, A.W, A.H);
+            splat_value_lane(blocks + (size_t)view * 2 * A.Wb * A.Hb, A.Wb, A.Hb, rp.u, rp.v, val, AtomicAdd());
+        }
+        const bool hit = tr.its_t < INFINITY;
+        n_hits += hit ? 1 : 0;
+        const bool warp_cand = (A.flags & DSDF_REPARAM) && warp_weight_positive(G, P, L.ray.o, L.ray.d, tr);
+        if (warp_cand || (hit && A.integrator == DSDF_SIMPLE_SHADING)) {
+            const Queue qv = view_queue(qall, view);
+            const uint32_t unit = sample >> 6;
+            const uint32_t slot = atomicAdd(qv.count + unit, 1u);   // behind the entries the sweep compacted
+            qv.lane[unit * 64 + slot] = sample;
+            store_record(qv.rec + sample, qv.cap, tr);
+            ++n_need;
+        }
+    };
+
+    bool done = false;                                                  // (DSDF_TAIL_BATCH) marched to the end, sample not completed yet
     while (true) {
         const uint64_t idle = __ballot(!m.active);
         if (!exhausted && __popcll(idle) >= DSDF_TAIL_REFILL) {
+            const unsigned long long c_in = stats ? (unsigned long long)clock64() : 0ull;
+#if DSDF_TAIL_BATCH
+            if (done) { complete(); done = false; }
+#endif
+            const unsigned long long c_a = stats ? (unsigned long long)clock64() : 0ull;
             bool drained = false;
             const uint32_t idx = tail_claim(cnt, total, idle, !m.active, drained);
             const float *e = ent + (size_t)idx * DSDF_TAIL_WORDS;       // (read below, before the queue is switched)
             if (drained) exhausted = !open_next();                       // this queue is done: the next refill takes the next one
+            const unsigned long long c_b = stats ? (unsigned long long)clock64() : 0ull;
             if (idx != ~0u) {
                 view = __float_as_uint(e[0]);
                 sample = __float_as_uint(e[1]);
-                const ViewArgs &A = VB.v[view];
+                const ViewArgs &A = views[view];
                 L = lane_setup(A, P, sample);
                 m = diff_march_begin(P, L.ray.o, L.ray.d, L.ray.maxt);
                 m.t = e[2]; m.warp_t = e[3]; m.prev_sd = e[4]; m.wsum = e[5]; m.ews = e[6];
@@ -227,12 +342,67 @@ __global__ __launch_bounds__(256) void k_tail_trace_diff(GridView G, dsdf_params
                 RF.valid = false;
 #endif
             }
+            if (stats) {
+                const unsigned long long c_e = (unsigned long long)clock64();
+                c_refill += c_e - c_in;
+                c_sec[0] += 1; c_sec[1] += c_a - c_in; c_sec[2] += c_b - c_a; c_sec[3] += c_e - c_b; c_sec[4] += (unsigned long long)__popcll(idle);
+            }
         }
-        if (__ballot(m.active) == 0) {
+        const uint64_t am = __ballot(m.active);
+        if (am == 0) {
             if (exhausted) break;
             continue;
         }
+#if DSDF_COOP_TAIL & 2
+        // the queues are drained and a few rays are left in this wave: 16 lanes per ray (dsdf_coop.h)
+        if (exhausted && __popcll(am) <= DSDF_COOP_RAYS) {
+            const bool mine = m.active;
+            const int i0 = m.i;
+            coop_finish_diff(G, P, m, am, lane_id());
+            if (mine) { n_steps += m.i - i0; done = true; }
+            break;
+        }
+#endif
         ++n_wsteps;
+#if (DSDF_TAIL_DEFER & 2) && DSDF_TAIL_DIFF_REUSE
+        if (m.active) {                                                 // (as in k_tail_trace_plain below)
+            const V3 x = fma3(m.t, m.d, m.o);
+            const CubicCell c = cubic_cell(G, x);
+            const bool load = !RF.valid || c.base != RF.base;
+            float stage[64];
+            if (load) {
+                const GlobalRows rows = global_rows(G, c);
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        v2f lo, hi;
+                        rows.get(k, j, lo, hi);
+                        float *r = stage + (k * 4 + j) * 4;
+                        r[0] = lo[0]; r[1] = lo[1]; r[2] = hi[0]; r[3] = hi[1];
+                    }
+            }
+            if (!opaque((int)load)) {
+                RegRows rr;
+                rr.t = RF.taps;
+                float v; V3 g; float H[6];
+                eval_cubic_rows<2>(G, c, rr, v, g, H);
+                diff_march_step(P, m, x, v, g, H);
+                ++n_steps;
+#if DSDF_TAIL_BATCH
+                done = !m.active;
+#else
+                if (!m.active) complete();
+#endif
+            }
+            if (opaque((int)load)) {
+#pragma unroll
+                for (int q = 0; q < 64; ++q) RF.taps[q] = stage[q];
+                RF.base = c.base;
+                RF.valid = true;
+            }
+        }
+#else
         if (m.active) {
             V3 x = fma3(m.t, m.d, m.o);
             float v; V3 g; float H[6];
@@ -243,33 +413,17 @@ __global__ __launch_bounds__(256) void k_tail_trace_diff(GridView G, dsdf_params
 #endif
             diff_march_step(P, m, x, v, g, H);
             ++n_steps;
-            if (!m.active) {                                            // the sample is complete: what the render pass does after its loop
-                const ViewArgs &A = VB.v[view];
-                DirectFetch F;
-                TraceOut tr;
-                tr.its_t = refine_hit(G, P, m.o, m.d, m.its_t, m.trace_eps, tr.refine_steps, F);
-                diff_march_finish(m, tr);
-                const float val = shade_value(G, A, L, tr.its_t);
-                if (val != 0.f) {
-                    Reproj rp = reproject(A.cam, P, L.ray.o + L.ray.d, A.W, A.H);
-                    splat_value_lane(blocks + (size_t)view * 2 * A.Wb * A.Hb, A.Wb, A.Hb, rp.u, rp.v, val, AtomicAdd());
-                }
-                const bool hit = tr.its_t < INFINITY;
-                n_hits += hit ? 1 : 0;
-                const bool warp_cand = (A.flags & DSDF_REPARAM) && warp_weight_positive(G, P, L.ray.o, L.ray.d, tr);
-                if (warp_cand || (hit && A.integrator == DSDF_SIMPLE_SHADING)) {
-                    const Queue qv = view_queue(qall, view);
-                    const uint32_t unit = sample >> 6;
-                    const uint32_t slot = atomicAdd(qv.count + unit, 1u);   // behind the entries the sweep compacted
-                    qv.lane[unit * 64 + slot] = sample;
-                    store_record(qv.rec + sample, qv.cap, tr);
-                    ++n_need;
-                }
-            }
+#if DSDF_TAIL_BATCH
+            done = !m.active;
+#else
+            if (!m.active) complete();
+#endif
         }
+#endif
     }
+    if (done) complete();
     if (stats) {
-        tail_stats(stats, n_steps, n_wsteps, n_rays);
+        tail_stats(stats, n_steps, n_wsteps, n_rays, t_start, c_start, c_refill, c_sec, 3);
         const int h = wave_sum_i32(n_hits), q = wave_sum_i32(n_need);
         if (lane_id() == 0) {
             unsigned long long *st = stats + (size_t)(blockIdx.x & 63u) * DSDF_STAT_SLOTS;
@@ -290,15 +444,41 @@ __global__ __launch_bounds__(256) void k_tail_trace_plain(GridView G, dsdf_param
     uint32_t *cnt = nullptr;
     const float *ent = nullptr;
     auto open_next = [&]() {
+#if DSDF_TAIL_SCAN
+        // lane k looks at the sub-queue this wave would visit k-th: one round trip for all of them (the claimed counters move under
+        // device-scope atomics of other waves: an atomic load, not a cached one)
+        const uint32_t sub_k = tail_hop(first, (uint32_t)lane_id(), tq.per_xcd);
+        uint32_t *c = tq.count + DSDF_TAIL_CNT_STRIDE * sub_k;
+        const uint32_t queued = __hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t claimed = __hip_atomic_load(c + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        uint64_t open = __ballot(claimed < queued);
+        open = hop < 64u ? (open >> hop) << hop : 0ull;
+        if (open == 0) { hop = DSDF_TAIL_SUBQ; return false; }
+        const int k = __builtin_ctzll(open);
+        hop = (uint32_t)k + 1u;
+        const uint32_t sub = tail_hop(first, (uint32_t)k, tq.per_xcd);
+        cnt = tq.count + DSDF_TAIL_CNT_STRIDE * sub;
+        ent = tq.state + (size_t)sub * tq.cap_sub * DSDF_PTAIL_WORDS;
+        total = (uint32_t)__builtin_amdgcn_readlane((int)queued, k);
+        return true;
+#else
         while (hop < DSDF_TAIL_SUBQ) {
             const uint32_t sub = tail_hop(first, hop++, tq.per_xcd);
-            cnt = tq.count + 2 * sub;
+            cnt = tq.count + DSDF_TAIL_CNT_STRIDE * sub;
             ent = tq.state + (size_t)sub * tq.cap_sub * DSDF_PTAIL_WORDS;
             total = (uint32_t)__builtin_amdgcn_readfirstlane((int)cnt[0]);
             if (total != 0) return true;
         }
         return false;
+#endif
     };
+#if DSDF_TAIL_VIEWS_IN_LDS
+    DSDF_TAIL_VIEWS_LDS(VB, views);
+#else
+    const ViewArgs *views = VB.v;
+#endif
+    const unsigned long long t_start = stats ? wall_clock64() : 0ull, c_start = stats ? (unsigned long long)clock64() : 0ull;
+    unsigned long long c_refill = 0, c_sec[5] = {0, 0, 0, 0, 0};
     if (!open_next()) return;
     PlainMarch m;
     m.active = false;
@@ -308,48 +488,119 @@ __global__ __launch_bounds__(256) void k_tail_trace_plain(GridView G, dsdf_param
     bool exhausted = false;
     int n_steps = 0, n_wsteps = 0, n_rays = 0, n_hits = 0, n_ref = 0;
 
+    // a hit: refine, shade, add the value (the weight is on the film)
+    auto complete = [&]() {
+        const ViewArgs &A = views[view];
+        DirectFetch D;
+        int nref;
+        const float its_t = refine_hit(G, P, m.o, m.d, m.its_t, m.trace_eps, nref, D);
+        const float val = shade_value(G, A, L, its_t);
+        if (val != 0.f) {
+            Reproj rp = reproject(A.cam, P, L.ray.o + L.ray.d, A.W, A.H);
+            splat_value_lane(blocks + (size_t)view * 2 * A.Wb * A.Hb, A.Wb, A.Hb, rp.u, rp.v, val, AtomicAdd());
+        }
+        ++n_hits; n_ref += nref;
+    };
+
+    bool done = false;                                                  // (DSDF_TAIL_BATCH) a hit whose sample is not completed yet
     while (true) {
         const uint64_t idle = __ballot(!m.active);
         if (!exhausted && __popcll(idle) >= DSDF_TAIL_REFILL) {
+            const unsigned long long c_in = stats ? (unsigned long long)clock64() : 0ull;
+#if DSDF_TAIL_BATCH
+            if (done) { complete(); done = false; }
+#endif
+            const unsigned long long c_a = stats ? (unsigned long long)clock64() : 0ull;
             bool drained = false;
             const uint32_t idx = tail_claim(cnt, total, idle, !m.active, drained);
             const float *e = ent + (size_t)idx * DSDF_PTAIL_WORDS;      // (read below, before the queue is switched)
             if (drained) exhausted = !open_next();
+            const unsigned long long c_b = stats ? (unsigned long long)clock64() : 0ull;
             if (idx != ~0u) {
                 view = __float_as_uint(e[0]);
-                L = lane_setup(VB.v[view], P, __float_as_uint(e[1]));
+                L = lane_setup(views[view], P, __float_as_uint(e[1]));
                 m = plain_march_begin(P, L.ray.o, L.ray.d, L.ray.maxt);
                 m.t = e[2];
                 F.valid = false;
                 ++n_rays;
             }
+            if (stats) {
+                const unsigned long long c_e = (unsigned long long)clock64();
+                c_refill += c_e - c_in;
+                c_sec[0] += 1; c_sec[1] += c_a - c_in; c_sec[2] += c_b - c_a; c_sec[3] += c_e - c_b; c_sec[4] += (unsigned long long)__popcll(idle);
+            }
         }
-        if (__ballot(m.active) == 0) {
+        const uint64_t am = __ballot(m.active);
+        if (am == 0) {
             if (exhausted) break;
             continue;
         }
+#if DSDF_COOP_TAIL & 1
+        if (exhausted && __popcll(am) <= DSDF_COOP_RAYS) {              // (as in k_tail_trace_diff)
+            const bool mine = m.active;
+            coop_finish_plain(G, m, am, lane_id(), n_steps);
+            if (mine && m.its_t < INFINITY) done = true;
+            break;
+        }
+#endif
         ++n_wsteps;
+#if DSDF_TAIL_DEFER & 1
+        // A ray that enters another cell ISSUES the gather of its 16 rows in this iteration and sits it out; the rays that stay in
+        // their cell take their step meanwhile, and the rows are moved to the lane's tap registers after that -- the wave waits for
+        // what is left of the memory round trip after a step's arithmetic instead of for all of it before.
+        if (m.active) {
+            const CubicCell c = cubic_cell(G, fma3(m.t, m.d, m.o));
+            const bool load = !F.valid || c.base != F.base;
+            float stage[64];
+            if (load) {
+                const GlobalRows rows = global_rows(G, c);
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        v2f lo, hi;
+                        rows.get(k, j, lo, hi);
+                        float *r = stage + (k * 4 + j) * 4;
+                        r[0] = lo[0]; r[1] = lo[1]; r[2] = hi[0]; r[3] = hi[1];
+                    }
+            }
+            if (!opaque((int)load)) {                                   // (opaque: keeps the program order issue -> step -> move)
+                RegRows rr;
+                rr.t = F.taps;
+                float v = 0.f; V3 gd; float Hd[6];
+                eval_cubic_rows<0>(G, c, rr, v, gd, Hd);
+                plain_march_step(m, v);
+                ++n_steps;
+#if DSDF_TAIL_BATCH
+                done = !m.active && m.its_t < INFINITY;
+#else
+                if (!m.active && m.its_t < INFINITY) complete();
+#endif
+            }
+            if (opaque((int)load)) {
+#pragma unroll
+                for (int q = 0; q < 64; ++q) F.taps[q] = stage[q];
+                F.base = c.base;
+                F.valid = true;
+            }
+        }
+#else
         if (m.active) {
             float v = 0.f; V3 gd; float Hd[6];
             F.template eval<0>(G, fma3(m.t, m.d, m.o), true, v, gd, Hd);
             plain_march_step(m, v);
             ++n_steps;
-            if (!m.active && m.its_t < INFINITY) {                      // a hit: refine, shade, add the value (the weight is on the film)
-                const ViewArgs &A = VB.v[view];
-                DirectFetch D;
-                int nref;
-                const float its_t = refine_hit(G, P, m.o, m.d, m.its_t, m.trace_eps, nref, D);
-                const float val = shade_value(G, A, L, its_t);
-                if (val != 0.f) {
-                    Reproj rp = reproject(A.cam, P, L.ray.o + L.ray.d, A.W, A.H);
-                    splat_value_lane(blocks + (size_t)view * 2 * A.Wb * A.Hb, A.Wb, A.Hb, rp.u, rp.v, val, AtomicAdd());
-                }
-                ++n_hits; n_ref += nref;
-            }
+#if DSDF_TAIL_BATCH
+            done = !m.active && m.its_t < INFINITY;
+#else
+            if (!m.active && m.its_t < INFINITY) complete();
+#endif
         }
+#endif
     }
+    if (done) complete();
     if (stats) {
-        tail_stats(stats, n_steps, n_wsteps, n_rays);
+        tail_stats(stats, n_steps, n_wsteps, n_rays, t_start, c_start, c_refill, c_sec, 2);
         const int h = wave_sum_i32(n_hits), r = wave_sum_i32(n_ref);
         if (lane_id() == 0) {
             unsigned long long *st = stats + (size_t)(blockIdx.x & 63u) * DSDF_STAT_SLOTS;

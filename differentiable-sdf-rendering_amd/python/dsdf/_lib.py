@@ -44,13 +44,14 @@ class DsdfError(RuntimeError):
 
 
 _lib = None
-ABI_VERSION = 306          # DSDF_VERSION of include/dsdf.h these ctypes mirrors were written against
+ABI_VERSION = 307          # DSDF_VERSION of include/dsdf.h these ctypes mirrors were written against
 
 # name -> (restype, argtypes); every symbol include/dsdf.h declares
 SYMBOLS = {
     'dsdf_version': (C.c_int, []),
     'dsdf_share_pixel_skip': (C.c_int, [C.c_void_p, C.c_size_t]),
     'dsdf_kernel_timing_arm': (C.c_int, []),
+    'dsdf_tail_stats_arm': (C.c_int, [C.c_void_p]),
     'dsdf_kernel_timing_read': (C.c_int, [C.POINTER(C.c_float)]),
     'dsdf_last_error': (C.c_char_p, []),
     'dsdf_default_params': (None, [C.POINTER(DsdfParams)]),

@@ -832,6 +832,13 @@ def kernel_timing_read():
     return float(ms.value)
 
 
+def tail_stats_arm(stats):
+    """Measurement hook (include/dsdf.h: dsdf_tail_stats_arm): the tail kernels of this thread's later calls that pass no `stats`
+    of their own write their wave diagnostics into `stats` (new_stats(); None disarms).  Read them with stats_dict()."""
+    for lib in {id(l): l for l in (_lib.load(), *_lib._variants.values())}.values():
+        _lib.check(lib.dsdf_tail_stats_arm(_ptr(stats) if stats is not None else None))
+
+
 def new_stats(device):
     return torch.zeros(64, STAT_SLOTS, dtype=torch.int64, device=device)
 
@@ -839,8 +846,21 @@ def new_stats(device):
 def stats_dict(stats):
     """Sums the 64 interleaved copies.  `steps` / `wave_steps` count the render kernel only; `all_steps` adds what the tail
     kernels marched for the rays handed over to them."""
-    d = dict(zip(STAT_NAMES, (int(x) for x in stats.sum(0).cpu())))
+    tot = [int(x) for x in stats.sum(0).cpu()]
+    d = dict(zip(STAT_NAMES, tot))
     d['all_steps'] = d['steps'] + d['tail_steps']
+    # the tail waves of the call (csrc/dsdf_tail.h: tail_stats; meaningful for ONE tail launch per buffer)
+    rows = [[int(x) for x in stats[r].cpu()] for r in range(4)]
+    r0, r1 = rows[0], rows[1]
+    d['tail_waves'] = {'max_wave_steps': r0[11], 'max_us': r0[12] / 100.0, 'sum_us': r0[13] / 100.0, 'sum_clocks': r0[14],
+                       'sum_refill_clocks': r0[15], 'refills': r1[11], 'clocks_completing': r1[12], 'clocks_claiming': r1[13],
+                       'clocks_setting_up': r1[14], 'idle_lanes_at_refill': r1[15]}
+    M = (1 << 64) - 1
+    for name, r in (('primal_tail', rows[2]), ('sweep_tail', rows[3])):
+        if r[12]:                           # wall-clock ticks (10 ns), relative to the earliest wave start of the kernel
+            t0 = M - (r[11] & M)             # (the tensor is int64: the complemented minima read back negative)
+            d['tail_waves'][name] = {'latest_start_us': (r[12] - t0) / 100.0, 'earliest_end_us': ((M - (r[13] & M)) - t0) / 100.0,
+                                     'latest_end_us': (r[14] - t0) / 100.0, 'first_start_tick': t0}
     return d
 
 

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define DSDF_VERSION 306   /* 300: stats rows of DSDF_STAT_SLOTS (16) counters; tail hand-off on library-owned helper streams; 304: DSDF_NO_HIT_PROOF, the grid buffer carries the bounds of the hit proof (dsdf_padded_size); 305: dsdf_params grows by normalize_warp_field, max_reparam_depth; 306: dsdf_render_aovs, dsdf_aov_workspace_size, dsdf_sampler_2d, dsdf_set_grid_transform / dsdf_has_grid_transform, dsdf_shading.bsdf_lobe_samples */
+#define DSDF_VERSION 307   /* 307: dsdf_tail_stats_arm; 300: stats rows of DSDF_STAT_SLOTS (16) counters; tail hand-off on library-owned helper streams; 304: DSDF_NO_HIT_PROOF, the grid buffer carries the bounds of the hit proof (dsdf_padded_size); 305: dsdf_params grows by normalize_warp_field, max_reparam_depth; 306: dsdf_render_aovs, dsdf_aov_workspace_size, dsdf_sampler_2d, dsdf_set_grid_transform / dsdf_has_grid_transform, dsdf_shading.bsdf_lobe_samples */
 #define DSDF_STAT_SLOTS 16
 
 enum dsdf_status {
@@ -202,7 +202,8 @@ size_t dsdf_forward_workspace_size(int width, int height, int spp, int n_views, 
  *               steps, hits, refine_steps, warp_active, queue_len, wave_steps, tail_steps, tail_wave_steps, tail_rays};
  *               wave_steps = lock-step loop iterations of the render kernel summed over its 64-lane waves (trace +
  *               refinement), the unit of the VALU-issue roofline; steps / wave_steps count the render kernel only, the
- *               tail_* slots what the tail kernels added for the rays handed over to them (tail_rays of them)
+ *               tail_* slots what the tail kernels added for the rays handed over to them (tail_rays of them); slots 11..15 of
+ *               rows 0..3 carry the tail waves' diagnostics listed at dsdf_tail_stats_arm (not sums over the 64 copies)
  * Tail kernels run on library-owned helper streams (forked from and joined back into `stream` inside the call).
  */
 int dsdf_render_forward(const float *padded, int rx, int ry, int rz, const dsdf_params *prm,
@@ -356,6 +357,16 @@ int dsdf_share_pixel_skip(void *buffer, size_t bytes);
  * dominant kernel. */
 int dsdf_kernel_timing_arm(void);
 int dsdf_kernel_timing_read(float *ms);
+
+/* Measurement hook: a device buffer int64[64][DSDF_STAT_SLOTS] (zeroed by the caller) in which the TAIL kernels of the calling
+ * thread's later render calls leave their wave diagnostics when the call itself passes no `stats` (dsdf_grad_sweep has none; the
+ * two-stream step's calls pass none): slots 8..10 as in `stats`; row 0, slots 11..15: most lock-step iterations of one tail
+ * wave, longest residence of one wave and the sum over the waves (ticks of the 100 MHz wall clock), sum of the waves' shader
+ * clocks and of the clocks spent refilling; row 1, slots 11..15: refills, refill clocks by section (completing finished
+ * samples / claiming / entry + camera ray + march state), idle lanes summed over the refills; row 2, slots 11..14 (primal tail)
+ * and row 3 (gradient sweep's tail): earliest and latest START of a wave and earliest and latest END, wall-clock ticks.
+ * NULL disarms.  The same slots are filled in a call's own `stats` buffer. */
+int dsdf_tail_stats_arm(unsigned long long *stats);
 
 /* Work counters of the dsdf_redistance call that last used `workspace`, copied into 4 DEVICE int32: {rounds that did work,
  * tile visits, Jacobi passes summed over the visits, status}. */

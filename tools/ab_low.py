@@ -23,4 +23,10 @@ out['step'] = t(lambda: dsdf.render_step(grid, sens, sp, sg, lambda im: gi, g, S
 a = dsdf.render_forward(grid, sens, sp, seeds=S).double(); g.zero_()
 dsdf.render_backward(grid, sens, sg, gi, grad_grid=g, seeds=S)
 out['checksums'] = {'img': [float(a.sum()), float((a * a).sum())], 'grad': [float(g.double().abs().sum()), float((g.double() ** 2).sum())]}
+if os.environ.get('AB_DUMP'):
+    torch.save({'img': a.float().cpu(), 'grad': g.cpu()}, os.environ['AB_DUMP'])
+if os.environ.get('AB_CMP'):          # the same outputs of another build: images to the last bit up to the order of the film's float adds
+    o = torch.load(os.environ['AB_CMP'])
+    out['vs'] = {'img_max_abs': float((a.float().cpu() - o['img']).abs().max()), 'img_differing': int((a.float().cpu() != o['img']).sum()),
+                 'grad_rel_l2': float((g.cpu().double() - o['grad'].double()).norm() / o['grad'].double().norm())}
 print('AB ' + json.dumps(out))

@@ -37,9 +37,12 @@ st = dsdf.new_stats(dev)
 a = dsdf.render_forward(grid, sens, 256, seeds=S, stats=st).double()
 cs = {'img256': [float(a.sum()), float((a * a).sum())]}
 sd = dsdf.stats_dict(st)
-out['primal_stats'] = {k: sd[k] for k in ('lanes', 'steps', 'hits', 'wave_steps', 'tail_rays', 'tail_steps', 'tail_wave_steps') if k in sd}
+out['primal_stats'] = {k: sd[k] for k in ('lanes', 'steps', 'hits', 'wave_steps', 'tail_rays', 'tail_steps', 'tail_wave_steps', 'tail_waves') if k in sd}
 g.zero_()
-dsdf.render_backward(grid, sens, 64, gi, grad_grid=g, seeds=S)
+st = dsdf.new_stats(dev)
+dsdf.render_backward(grid, sens, 64, gi, grad_grid=g, seeds=S, stats=st)
+sd = dsdf.stats_dict(st)
+out['grad_stats'] = {k: sd[k] for k in ('lanes', 'steps', 'wave_steps', 'tail_rays', 'tail_steps', 'tail_wave_steps', 'tail_waves') if k in sd}
 cs['grad64'] = [float(g.double().abs().sum()), float((g.double() ** 2).sum())]
 if '--shade' in sys.argv:
     st = dsdf.new_stats(dev)
