@@ -156,8 +156,8 @@ def side_roofline(model_key, kernel_name, kernel_ms, stats):
 def direct_block(args, dev, grid, sensors, steps=4):
     """BASELINE.json configs[4] sizes on one GPU: sdf_direct_reparam with a 256^3 x 3 albedo volume, the same two-stream step."""
     import dsdf
-    gen = torch.Generator(device=dev); gen.manual_seed(20240)            # (a fixed volume: the checksums below compare across runs)
-    albedo = torch.rand(args.res, args.res, args.res, 3, device=dev, generator=gen) * 0.6 + 0.2
+    torch.manual_seed(20240)                                             # (a fixed volume: the checksums below compare across runs)
+    albedo = torch.rand(args.res, args.res, args.res, 3, device=dev) * 0.6 + 0.2
     sh = dsdf.Shading(albedo, 1.0, hide_emitters=False)
     galb = torch.zeros_like(albedo)
     grad = torch.zeros(args.res, args.res, args.res, device=dev)
@@ -410,8 +410,8 @@ def main():
     shade, galbs = {}, [None, None]
     shapes = [tuple(data.shape)]
     if args.integrator == 'sdf_direct_reparam':
-        gen = torch.Generator(device=dev); gen.manual_seed(20240)            # (a fixed volume: the checksums below compare across runs)
-    albedo = torch.rand(args.res, args.res, args.res, 3, device=dev, generator=gen) * 0.6 + 0.2
+        torch.manual_seed(20240)                                             # (a fixed volume: the checksums below compare across runs)
+        albedo = torch.rand(args.res, args.res, args.res, 3, device=dev) * 0.6 + 0.2
         shade = {'shading': dsdf.Shading(albedo, 1.0, hide_emitters=False)}
         shapes.append(tuple(albedo.shape))
     buckets = [parallel.GradBucket(shapes, dev), parallel.GradBucket(shapes, dev)]

@@ -170,3 +170,17 @@ def test_c_redistance_oracle_properties(built):
     gm = np.sqrt(sum(gi ** 2 for gi in g))
     band = (np.abs(u) > 3 / R) & (np.abs(u) < 0.2)
     assert abs(gm[band].mean() - 1.0) < 0.05
+
+
+def test_driver_entry_points_compile():
+    """bench.py and __graft_entry__.py are run by the driver on the GPU box only: a syntax error in them would surface there, after
+    the last chance to fix it.  Byte-compile them (and every module of the package and of tools/) here."""
+    import glob
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    files = [os.path.join(ROOT, 'bench.py'), os.path.join(ROOT, '__graft_entry__.py')]
+    files += glob.glob(os.path.join(ROOT, 'differentiable-sdf-rendering_amd', 'python', '**', '*.py'), recursive=True)
+    files += glob.glob(os.path.join(ROOT, 'tools', '*.py')) + glob.glob(os.path.join(ROOT, 'oracle', '*.py'))
+    assert len(files) > 30
+    for f in files:
+        with open(f, 'rb') as fh:
+            compile(fh.read(), f, 'exec')                      # (raises SyntaxError / IndentationError; writes nothing)
