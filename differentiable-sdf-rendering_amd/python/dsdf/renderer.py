@@ -834,9 +834,18 @@ def kernel_timing_read():
 
 def tail_stats_arm(stats):
     """Measurement hook (include/dsdf.h: dsdf_tail_stats_arm): the tail kernels of this thread's later calls that pass no `stats`
-    of their own write their wave diagnostics into `stats` (new_stats(); None disarms).  Read them with stats_dict()."""
+    of their own write their wave diagnostics into `stats` (new_stats(); None disarms).  Read them with stats_dict().
+    The library keeps the raw pointer until it is disarmed: the tensor is held here so that it cannot be freed under an armed hook.
+    (Variant libraries loaded AFTER this call are not armed.)"""
+    global _tail_stats_held
+    if stats is not None and (stats.dtype != torch.int64 or stats.numel() < 64 * STAT_SLOTS or not stats.is_contiguous()):
+        raise ValueError("tail_stats_arm: a contiguous int64 tensor of 64 x STAT_SLOTS counters (new_stats()) is expected")
     for lib in {id(l): l for l in (_lib.load(), *_lib._variants.values())}.values():
         _lib.check(lib.dsdf_tail_stats_arm(_ptr(stats) if stats is not None else None))
+    _tail_stats_held = stats
+
+
+_tail_stats_held = None
 
 
 def new_stats(device):
