@@ -45,6 +45,14 @@ sys.path.insert(0, os.path.join(ROOT, 'differentiable-sdf-rendering_amd', 'pytho
 
 import torch
 
+_T0 = time.time()
+
+
+def mark(msg):
+    """Progress marker on stderr (flushed): where a stalled run was when it stopped."""
+    print(f"[bench +{time.time() - _T0:7.1f}s] {msg}", file=sys.stderr, flush=True)
+
+
 VALU_PEAK = 1024 * 2.4e9 / 2.0        # wave64 VALU instructions / s: 256 CUs x 4 SIMD-32, 2 clk per instruction
 FP32_VECTOR_PEAK = 157.3e12           # MI355X_MICROARCH.md: fp32 vector peak = 1024 SIMD-32 x 32 lanes x 2 flop (FMA) x 2.4 GHz (scalar v_fma_f32 at full rate; not a packed-math figure)
 SPLINE_FLOP_PER_EVAL = 168.0          # 64 + 16 + 4 FMAs of one value-only tricubic lookup
@@ -260,6 +268,7 @@ def scaling_prediction_block(args, dev, grid, target, ring, t1_ms, steps=3):
         return {"emulated_rank": r, "world": N, "ms_per_step": rank_ms(r, N)}
     rows = []
     for N in (2, 4, 8):
+        mark(f'scaling_prediction N={N}')
         per = [rank_ms(r, N) for r in range(N)]
         split = args.views % N != 0
         ar = 1e3 * 2.0 * (N - 1) / N * S / link
@@ -341,6 +350,64 @@ def opt_iteration_block(args, dev, data0, ring, iters=6):
                                    f"{args.spp_primal}/{args.spp_grad}, multiscale-L1 + Laplacian (1e-5), Adam, box constraint, redistance"}}
 
 
+def supervise(argv):
+    """Single-GPU runs are SUPERVISED: the measurement runs in a child process (`--child`), this process only relays its JSON lines.
+    A kernel that never returns cannot be interrupted from inside its own process (the host thread sits in hipStreamSynchronize),
+    and round 5's driver run was lost exactly so: 1800 s at 100 % GPU, nothing printed (profiles/r06_bench_stall.md).  Rules:
+      * the child prints the headline line right after the timed region and the enriched line after every side block; every line
+        is relayed at once (flushed), so whatever happens later the last line on stdout is a complete record;
+      * no line within BENCH_HEADLINE_S (300 s) -> the child is killed (its GPU queues die with it) and started ONCE more;
+      * a headline but then silence for BENCH_BLOCK_S (150 s; the longest block, the CPU baseline, takes ~40 s) -> the child is killed,
+        the last line is re-printed with "aborted": <reason>, exit code 0: the headline was measured.
+    Multi-rank runs (torch.distributed.run) are not supervised: killing one rank of a collective helps nobody."""
+    import subprocess
+    import threading
+    import queue
+    head_s = float(os.environ.get('BENCH_HEADLINE_S', 300))
+    block_s = float(os.environ.get('BENCH_BLOCK_S', 150))
+    last = None
+    for attempt in (1, 2):
+        child = subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv) + ['--child'], stdout=subprocess.PIPE, text=True, bufsize=1)
+        q = queue.Queue()
+
+        def pump(f=child.stdout):
+            for line in f:
+                q.put(line)
+            q.put(None)
+        threading.Thread(target=pump, daemon=True).start()
+        reason = None
+        while True:
+            try:
+                line = q.get(timeout=head_s if last is None else block_s)
+            except queue.Empty:
+                reason = (f"no headline within {head_s:.0f} s" if last is None else f"no progress for {block_s:.0f} s after the headline") + f" (attempt {attempt})"
+                break
+            if line is None:
+                break
+            line = line.rstrip('\n')
+            if line.startswith('{'):
+                last = line
+            print(line, flush=True)
+        if reason is None:
+            rc = child.wait()
+            if rc == 0 and last is not None:
+                return 0
+            reason = f"child exited with code {rc} (attempt {attempt})"
+        else:
+            child.kill()
+            child.wait()
+        print(f"[bench supervisor] {reason}", file=sys.stderr, flush=True)
+        if last is not None:
+            try:
+                rec = json.loads(last)
+                rec["aborted"] = reason
+                print(json.dumps(rec), flush=True)
+            except ValueError:
+                print(last, flush=True)
+            return 0
+    return 1
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -360,7 +427,13 @@ def main():
     ap.add_argument('--no-scaling-prediction', action='store_true')
     ap.add_argument('--emulate-rank', default='', help="r/N: time rank r's shard of an N-GPU strong-scaling run alone on this GPU (scaling_prediction)")
     ap.add_argument('--overlap', type=int, default=1, help='1: primal pass and gradient sweep on two HIP streams (dsdf.render_step)')
+    ap.add_argument('--child', action='store_true', help='(internal) the measuring process of a supervised single-GPU run')
     args = ap.parse_args()
+    if int(os.environ.get('WORLD_SIZE', 1)) == 1 and not args.child and os.environ.get('BENCH_INPROCESS') != '1':
+        sys.exit(supervise(sys.argv[1:]))
+    import faulthandler
+    faulthandler.enable()
+    faulthandler.dump_traceback_later(int(os.environ.get('BENCH_TRACEBACK_EVERY', 120)), repeat=True, file=sys.stderr)
 
     rank = int(os.environ.get('RANK', 0))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
@@ -384,6 +457,7 @@ def main():
         else:
             dist.init_process_group(backend)
 
+    mark('library loaded; building grids')
     data = synth_grid(args.res, dev)
     grid = dsdf.SdfGrid(data)
     target = dsdf.SdfGrid(synth_grid(args.res, dev, seed=1))
@@ -502,10 +576,12 @@ def main():
         return elapsed
 
     prim_ms, grad_ms = [], []
+    mark('timed region: warmup + steps')
     elapsed = timed_run(make_step(args.spp_primal, args.spp_grad, prim_ms, grad_ms), args.warmup, args.steps)
     # dL/dsdf of the last timed step (summed over ranks): must agree at every N up to the order of the float atomics
     grad_l1 = float(grads[(args.warmup + args.steps - 1) & 1].double().abs().sum())
     kern_p, kern_g = [], []
+    mark(f'timed region done: {1e3 * elapsed / args.steps:.2f} ms/step; probe launches')
     if nv and not tiled:
         # the roofline needs the dominant kernel's OWN launch time: in the timed region above it shares the chip with the
         # gradient sweep of the other stream, so a few calls are timed alone afterwards, same process, same inputs -- the whole
@@ -531,33 +607,9 @@ def main():
             kern_g.append(dsdf.kernel_timing_read())
         args.overlap, dist = ov, dist_saved
 
-    low = None
-    if not args.no_low_spp:
-        lp, lg = [], []
-        lsteps = max(args.steps, 20)
-        lel = timed_run(make_step(4, 1, lp, lg), 2, lsteps)
-        if args.overlap:
-            lp, lg = [], []
-        low = {"value": lsteps / lel if args.scaling == 'strong' else world * lsteps / lel, "unit": "renders/s", "steps": lsteps,
-               "ms_per_step": 1e3 * lel / lsteps,
-               "config": {"workload": f"{args.res}^3 SDF, {args.views} views x {args.img}^2, {args.integrator}, spp primal/grad 4/1 "
-                                      f"(north_star's >= 50 renders/s point, SURVEY F10)"},
-               "overlap": bool(args.overlap)}
-        if lp:
-            low["primal_ms_per_launch"] = sum(a.elapsed_time(b) for a, b in lp) / len(lp)
-            low["grad_ms_per_launch"] = sum(a.elapsed_time(b) for a, b in lg) / len(lg)
-        if nv and not tiled:
-            lk = []
-            for k in range(3):
-                dsdf.kernel_timing_arm()
-                dsdf.render_forward(grid, sensors, 4, seeds=[(11 * k + i) * 2 for i in range(nv)], integrator=args.integrator, **shade)
-                lk.append(dsdf.kernel_timing_read())
-            lst = dsdf.new_stats(dev)
-            dsdf.render_forward(grid, sensors, 4, seeds=list(range(nv)), integrator=args.integrator, stats=lst, **shade)
-            low["roofline"] = side_roofline('low_primal', 'k_render_pass<false, false> (general pass, 4 spp)', sum(lk) / len(lk), dsdf.stats_dict(lst))
-
     # per-launch statistics (untimed; same launch shape as the timed ones)
     out_cfg, roof = {}, None
+    mark('per-launch statistics')
     if nv and not tiled:
         st_p, st_g = dsdf.new_stats(dev), dsdf.new_stats(dev)
         galb = galbs[0]
@@ -630,49 +682,108 @@ def main():
                    "backward_queue_fraction": sg['queue_len'] / max(nv * (args.img + 4) ** 2 * args.spp_grad, 1),
                    "primal_ms_per_launch": prim_avg, "grad_ms_per_launch": sum(gradt) / len(gradt)}
 
-    direct = opt_it = None
-    if world == 1 and dist is None and args.integrator == 'sdf_silhouette_reparam':
-        if not args.no_direct:
-            dsdf.release_workspaces()
-            direct = direct_block(args, dev, grid, sensors)
-        if not args.no_opt_iteration:
-            dsdf.release_workspaces()
-            opt_it = opt_iteration_block(args, dev, data, ring)
-    scaling_pred = None
-    if world == 1 and dist is None and args.scaling == 'strong' and (args.emulate_rank or not args.no_scaling_prediction):
-        dsdf.release_workspaces()
-        scaling_pred = scaling_prediction_block(args, dev, grid, target, ring, 1e3 * elapsed / args.steps)
+    def low_spp_block():
+        lp, lg = [], []
+        lsteps = max(args.steps, 20)
+        lel = timed_run(make_step(4, 1, lp, lg), 2, lsteps)
+        if args.overlap:
+            lp, lg = [], []
+        low = {"value": lsteps / lel if args.scaling == 'strong' else world * lsteps / lel, "unit": "renders/s", "steps": lsteps,
+               "ms_per_step": 1e3 * lel / lsteps,
+               "config": {"workload": f"{args.res}^3 SDF, {args.views} views x {args.img}^2, {args.integrator}, spp primal/grad 4/1 "
+                                      f"(north_star's >= 50 renders/s point, SURVEY F10)"},
+               "overlap": bool(args.overlap)}
+        if lp:
+            low["primal_ms_per_launch"] = sum(a.elapsed_time(b) for a, b in lp) / len(lp)
+            low["grad_ms_per_launch"] = sum(a.elapsed_time(b) for a, b in lg) / len(lg)
+        if nv and not tiled:
+            lk = []
+            for k in range(3):
+                dsdf.kernel_timing_arm()
+                dsdf.render_forward(grid, sensors, 4, seeds=[(11 * k + i) * 2 for i in range(nv)], integrator=args.integrator, **shade)
+                lk.append(dsdf.kernel_timing_read())
+            lst = dsdf.new_stats(dev)
+            dsdf.render_forward(grid, sensors, 4, seeds=list(range(nv)), integrator=args.integrator, stats=lst, **shade)
+            low["roofline"] = side_roofline('low_primal', 'k_render_pass<false, false> (general pass, 4 spp)', sum(lk) / len(lk), dsdf.stats_dict(lst))
+        return low
 
-    if rank == 0:
-        strong = args.scaling == 'strong'
-        out = {
-            "metric": "diff-renders/sec (fwd+bwd) 256^3 SDF, 512^2, 12 views" if strong else
-                      "weak-scaling diff-renders/sec (fwd+bwd) 256^3 SDF, 512^2, 12 views PER GPU",
-            "value": (1 if strong else world) * args.steps / elapsed, "unit": "renders/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
-            "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": dict({"workload": f"no-tex-12-hq sizes: {args.res}^3 SDF, {args.views} views x {args.img}^2, "
-                                        f"{args.integrator}, spp primal/grad {args.spp_primal}/{args.spp_grad} "
-                                        f"(reference semantics, configs.py:16,19)",
-                            "views_total": args.views if strong else args.views * world, "views_this_rank": nv,
-                            "partition": ("pixel-row windows of views: %d units per rank" % len(parallel.work_partition(args.views, args.img + 4, world)[0])) if tiled else "whole views",
-                            "spp_primal": args.spp_primal, "spp_grad": args.spp_grad, "grad_l1_last_step": grad_l1,
-                            "dist_backend": backend,
-                            "gradient_exchange": None if dist is None else "one non-blocking all-reduce of dL/dsdf per step, overlapped with the next step's rendering (two gradient buffers)",
-                            "schedule": "primal pass and gradient sweep on two HIP streams" if args.overlap else "sequential launches"}, **out_cfg),
-            "roofline": roof,
-        }
-        if low is not None:
-            out["low_spp"] = low
-        if direct is not None:
-            out["direct"] = direct
-        if opt_it is not None:
-            out["opt_iteration"] = opt_it
-        if scaling_pred is not None:
-            out["scaling_prediction"] = scaling_pred
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args)
-        print(json.dumps(out))
+    strong = args.scaling == 'strong'
+    out = {
+        "metric": "diff-renders/sec (fwd+bwd) 256^3 SDF, 512^2, 12 views" if strong else
+                  "weak-scaling diff-renders/sec (fwd+bwd) 256^3 SDF, 512^2, 12 views PER GPU",
+        "value": (1 if strong else world) * args.steps / elapsed, "unit": "renders/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
+        "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": dict({"workload": f"no-tex-12-hq sizes: {args.res}^3 SDF, {args.views} views x {args.img}^2, "
+                                    f"{args.integrator}, spp primal/grad {args.spp_primal}/{args.spp_grad} "
+                                    f"(reference semantics, configs.py:16,19)",
+                        "views_total": args.views if strong else args.views * world, "views_this_rank": nv,
+                        "partition": ("pixel-row windows of views: %d units per rank" % len(parallel.work_partition(args.views, args.img + 4, world)[0])) if tiled else "whole views",
+                        "spp_primal": args.spp_primal, "spp_grad": args.spp_grad, "grad_l1_last_step": grad_l1,
+                        "dist_backend": backend,
+                        "gradient_exchange": None if dist is None else "one non-blocking all-reduce of dL/dsdf per step, overlapped with the next step's rendering (two gradient buffers)",
+                        "schedule": "primal pass and gradient sweep on two HIP streams" if args.overlap else "sequential launches"}, **out_cfg),
+        "roofline": roof,
+    }
+
+    # THE HEADLINE FIRST (a stall in a side block must not lose the measurement).  The line is printed and flushed
+    # here, right after the timed region and its probe launches; every side block that completes re-prints the enriched line (the
+    # driver parses the last one).  A side block that raises is recorded as {"error": ...}; one that would start after the
+    # wall-clock budget is recorded as {"skipped": "budget"}; a block that never returns is the supervisor's business (main()).
+    def emit():
+        if rank == 0:
+            out["bench_wall_s"] = round(time.time() - _T0, 1)
+            print(json.dumps(out), flush=True)
+
+    emit()
+    budget = float(os.environ.get('BENCH_BUDGET_S', 150))
+
+    def side(name, fn, enabled=True):
+        if not enabled:
+            return
+        if dist is None and time.time() - _T0 > budget:      # (one rank only: ranks must not disagree about a collective block)
+            out[name] = {"skipped": "budget", "budget_s": budget}
+            mark(f'{name}: skipped (wall-clock budget of {budget:.0f} s spent)')
+        else:
+            mark(f'{name} block')
+            t0 = time.time()
+            try:
+                res = fn()
+                if res is None:
+                    return
+                out[name] = res
+            except Exception as e:                                   # noqa: BLE001 -- the headline above must survive any side block
+                import traceback
+                traceback.print_exc()
+                out[name] = {"error": f"{type(e).__name__}: {e}"}
+                try:
+                    drain(); torch.cuda.synchronize()
+                except Exception:                                    # noqa: BLE001
+                    pass
+            mark(f'{name} block done in {time.time() - t0:.1f} s')
+        emit()
+
+    solo = world == 1 and dist is None
+    side('cpu_baseline', lambda: cpu_baseline(args), rank == 0 and world == 1 and not args.no_cpu_baseline)
+    side('low_spp', low_spp_block, not args.no_low_spp)
+
+    def run_direct():
+        dsdf.release_workspaces()
+        return direct_block(args, dev, grid, sensors)
+
+    def run_opt():
+        dsdf.release_workspaces()
+        return opt_iteration_block(args, dev, data, ring)
+
+    def run_scaling():
+        dsdf.release_workspaces()
+        return scaling_prediction_block(args, dev, grid, target, ring, 1e3 * elapsed / args.steps)
+
+    silhouette = args.integrator == 'sdf_silhouette_reparam'
+    side('direct', run_direct, solo and silhouette and not args.no_direct)
+    side('opt_iteration', run_opt, solo and silhouette and not args.no_opt_iteration)
+    side('scaling_prediction', run_scaling, solo and strong and bool(args.emulate_rank or not args.no_scaling_prediction))
+    mark('done')
     if dist is not None:
         dist.destroy_process_group()
 

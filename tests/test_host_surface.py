@@ -1,5 +1,6 @@
 """Host-side mirror of the reference's optimisation surface (configs, opt_configs, variables,
 losses, regularisers, .vol IO): pure-torch / Python logic, runs without a GPU."""
+import json
 import math
 import os
 
@@ -184,3 +185,43 @@ def test_driver_entry_points_compile():
     for f in files:
         with open(f, 'rb') as fh:
             compile(fh.read(), f, 'exec')                      # (raises SyntaxError / IndentationError; writes nothing)
+
+
+def test_bench_supervisor_relays_retries_and_aborts(tmp_path, monkeypatch):
+    """bench.supervise: the child's JSON lines are relayed as they come; a child that prints nothing is killed
+    and started once more; a child that stalls after its headline is killed and the headline re-printed with "aborted"."""
+    import importlib.util
+    import io
+    import contextlib
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location('bench_under_test', os.path.join(ROOT, 'bench.py'))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    fake = tmp_path / 'fake_child.py'
+    fake.write_text(
+        "import os, sys, time, json\n"
+        "mode = os.environ['FAKE_MODE']; marker = os.environ['FAKE_MARKER']\n"
+        "first = not os.path.exists(marker); open(marker, 'a').write('x')\n"
+        "if mode == 'silent_then_ok' and first: time.sleep(60)\n"
+        "print(json.dumps({'metric': 'm', 'value': 1.0}), flush=True)\n"
+        "if mode == 'stall_after_headline': time.sleep(60)\n"
+        "print(json.dumps({'metric': 'm', 'value': 1.0, 'low_spp': {}}), flush=True)\n")
+    monkeypatch.setattr(bench, '__file__', str(fake))
+    monkeypatch.setenv('BENCH_HEADLINE_S', '3')
+    monkeypatch.setenv('BENCH_BLOCK_S', '3')
+
+    def run(mode):
+        marker = tmp_path / (mode + '.marker')
+        monkeypatch.setenv('FAKE_MODE', mode)
+        monkeypatch.setenv('FAKE_MARKER', str(marker))
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            rc = bench.supervise([])
+        return rc, [json.loads(l) for l in buf.getvalue().splitlines() if l.startswith('{')], len(marker.read_text())
+
+    rc, rows, starts = run('ok')
+    assert rc == 0 and starts == 1 and len(rows) == 2 and 'low_spp' in rows[-1] and 'aborted' not in rows[-1]
+    rc, rows, starts = run('silent_then_ok')
+    assert rc == 0 and starts == 2 and 'low_spp' in rows[-1]
+    rc, rows, starts = run('stall_after_headline')
+    assert rc == 0 and starts == 1 and rows[-1]['value'] == 1.0 and 'aborted' in rows[-1] and 'low_spp' not in rows[-1]
