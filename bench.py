@@ -230,9 +230,39 @@ def scaling_prediction_block(args, dev, grid, target, ring, t1_ms, steps=3):
     grad = torch.zeros(args.res, args.res, args.res, device=dev)
     tgt_all = torch.cat([dsdf.render_forward(target, s, 64, seeds=[1000 + i]) for i, s in enumerate(ring)])
 
+    def probe_costs():
+        # the row costs a real run's ranks would have all-reduced after the previous step: the proofs of ALL views, once
+        seeds0 = [i * 2 for i in range(args.views)]
+        ops = parallel.HipOps(grid, ring, args.spp_primal, args.spp_grad, seeds0, [x + 1 for x in seeds0], args.integrator, two_streams=False)
+        views = list(range(args.views))
+        ops.begin_group(views)
+        try:
+            ops.sweep(views, (0, args.img + 4))
+        finally:
+            ops.end_group()
+        _, c = ops.row_costs()
+        torch.cuda.synchronize()
+        dsdf.release_workspaces()
+        return c.cpu().numpy()
+
+    cost = probe_costs() if args.partition == 'cost' else None
+
     def rank_ms(r, N):
         split = args.views % N != 0
-        if not split:
+        if cost is not None:
+            part = parallel.cost_partition(cost, N)
+            seeds0 = [i * 2 for i in range(args.views)]
+            ops = parallel.HipOps(grid, ring, args.spp_primal, args.spp_grad, seeds0, [x + 1 for x in seeds0], args.integrator,
+                                  two_streams=bool(args.overlap))
+
+            def step(it):
+                seeds = [(it * args.views + i) * 2 for i in range(args.views)]
+                ops.set_seeds(seeds, [x + 1 for x in seeds])
+                grad.zero_()
+                parallel.render_step(ops, args.views, args.img, args.img, r, N, lambda im, views: torch.sign(im - tgt_all[views]) * scale,
+                                     grad, gather_images=False, partition=part)
+                ops.row_costs()                                       # (a real run's ranks compute these every step)
+        elif not split:
             mine = parallel.strided_view_shard(list(range(args.views)), r, N)
             sensors = [ring[i] for i in mine]
             tgt = tgt_all[mine]
@@ -275,7 +305,8 @@ def scaling_prediction_block(args, dev, grid, target, ring, t1_ms, steps=3):
         film = 1e3 * 2.0 * (2.0 * (N - 1) / N * args.views * (args.img + 4) ** 2 * 2 * 4 / link) if split else 0.0
         comp = max(per)
         pred = max(comp + film, ar)
-        rows.append({"n_gpus": N, "partition": "pixel-row windows" if split else "whole views", "rank_ms": [round(x, 3) for x in per],
+        rows.append({"n_gpus": N, "partition": ("cost-aware " if cost is not None else "") + ("pixel-row windows" if split else "whole views"),
+                     "max_over_min_rank_ms": max(per) / min(per), "rank_ms": [round(x, 3) for x in per],
                      "compute_ms_max_over_ranks": comp, "allreduce_ms_model": ar, "film_exchange_ms_model": film,
                      "predicted_ms_per_step": pred, "predicted_speedup": t1_ms / pred, "predicted_efficiency": t1_ms / pred / N})
     return {"label": "PREDICTED from single-GPU shard timings + a link model; no xGMI / RCCL transfer between two GPUs was measured",
@@ -427,6 +458,9 @@ def main():
     ap.add_argument('--no-scaling-prediction', action='store_true')
     ap.add_argument('--emulate-rank', default='', help="r/N: time rank r's shard of an N-GPU strong-scaling run alone on this GPU (scaling_prediction)")
     ap.add_argument('--overlap', type=int, default=1, help='1: primal pass and gradient sweep on two HIP streams (dsdf.render_step)')
+    ap.add_argument('--partition', choices=('cost', 'uniform'), default='cost',
+                    help="multi-rank strong scaling: 'cost' = parallel.cost_partition of the row costs the ranks measured in the previous step "
+                         "(per-pixel proof flags, one 25 KB all-reduce per step); 'uniform' = round-robin views / even row windows")
     ap.add_argument('--child', action='store_true', help='(internal) the measuring process of a supervised single-GPU run')
     args = ap.parse_args()
     if int(os.environ.get('WORLD_SIZE', 1)) == 1 and not args.child and os.environ.get('BENCH_INPROCESS') != '1':
@@ -468,7 +502,9 @@ def main():
         # GPUs) the views are cut into pixel-row windows (parallel.work_partition: 24 half-views, 3 per rank) and the film
         # blocks are summed across ranks before develop / before the backward (parallel.render_step)
         ring = dsdf.get_regular_cameras(args.views, resx=args.img, resy=args.img)
-        tiled = args.views % world != 0 or os.environ.get('BENCH_FORCE_TILED') == '1'
+        # (the cost-aware partition re-deals views and row windows from step to step: every multi-rank run goes through the film-level
+        # operators of parallel.render_step then, also when the ranks divide the views)
+        tiled = args.views % world != 0 or os.environ.get('BENCH_FORCE_TILED') == '1' or (world > 1 and args.partition == 'cost')
         mine = list(range(args.views)) if tiled else parallel.strided_view_shard(list(range(args.views)), rank, world)
     else:
         # weak scaling: a ring of views*world sensors, `views` per rank
@@ -498,6 +534,7 @@ def main():
 
     ev = lambda: torch.cuda.Event(enable_timing=True)
     hip_ops = {}
+    trackers = {}                               # (spp pair) -> parallel.CostTracker: the row costs all ranks agreed on after the last step
     pending = [None, None]                      # work handles of the all-reduces in flight, per gradient buffer
 
     def make_step(spp_p, spp_g, prim_ms, grad_ms):
@@ -520,10 +557,18 @@ def main():
                 ops = hip_ops[key]
                 ops.set_seeds(seeds, [x + 1 for x in seeds])
                 ops.kw = dict(shade, **({'grad_albedo': galb} if galb is not None else {}))
+                part = None
+                if args.partition == 'cost':
+                    if key not in trackers:
+                        trackers[key] = parallel.CostTracker(args.views, args.img + 4, world, device=dev)
+                    part = trackers[key].partition()
                 _, work = parallel.render_step(ops, args.views, args.img, args.img, rank, world,
                                                lambda im, views: torch.sign(im - tgt[views]) * scale, grad, extra_grads=extra,
-                                               gather_images=False, async_reduce=True, force_reduce=dist is not None)
+                                               gather_images=False, async_reduce=True, force_reduce=dist is not None, partition=part)
                 pending[b] = work
+                if part is not None:
+                    # what this step's proofs say about the work per row -> the next step's partition (one small collective)
+                    trackers[key].update(*ops.row_costs())
                 return
             if nv:
                 seeds = [(it * args.views + i) * 2 for i in mine]
@@ -718,7 +763,8 @@ def main():
                                     f"{args.integrator}, spp primal/grad {args.spp_primal}/{args.spp_grad} "
                                     f"(reference semantics, configs.py:16,19)",
                         "views_total": args.views if strong else args.views * world, "views_this_rank": nv,
-                        "partition": ("pixel-row windows of views: %d units per rank" % len(parallel.work_partition(args.views, args.img + 4, world)[0])) if tiled else "whole views",
+                        "partition": (("cost-aware (parallel.cost_partition of the previous step's row costs): " if args.partition == 'cost' and world > 1 else "uniform: ") +
+                                      "%d units per rank" % len(parallel.work_partition(args.views, args.img + 4, world)[0])) if tiled else "whole views",
                         "spp_primal": args.spp_primal, "spp_grad": args.spp_grad, "grad_l1_last_step": grad_l1,
                         "dist_backend": backend,
                         "gradient_exchange": None if dist is None else "one non-blocking all-reduce of dL/dsdf per step, overlapped with the next step's rendering (two gradient buffers)",

@@ -27,6 +27,16 @@ __device__ __forceinline__ void film_accum_wave(int px, int py, float u, float v
     // of the traced chunks of the bench scene) adds the SAME sums to its value channel -- f * 1.f == f, same order -- instead
     // of transposing them a second time
     const bool all_one = NCH == 2 && __ballot(vals[0] != 1.f) == 0;
+    // ... and a wave of sdf_direct_reparam whose 64 samples carry ONE colour (they all miss: the environment's radiance -- most of the
+    // sampled chunks of a scene with a visible environment) scales the weight sums once per channel instead of reducing three more
+    // times (sum (f c) vs (sum f) c: the rounding of the last bit)
+    float uni[3] = {0.f, 0.f, 0.f};
+    bool uniform = false;
+    if (NCH == 4) {
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) uni[ch] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(vals[ch])));
+        uniform = __ballot(vals[0] != uni[0] || vals[1] != uni[1] || vals[2] != uni[2]) == 0;
+    }
     float wsum[2] = {0.f, 0.f};
 #pragma unroll
     for (int cc = 0; cc < NCH; ++cc) {
@@ -34,6 +44,10 @@ __device__ __forceinline__ void film_accum_wave(int px, int py, float u, float v
         const float val = ch < NCH - 1 ? vals[ch] : 1.f;
         if (ch < NCH - 1 && all_one) {
             if (lid < DSDF_TROWS) { acc[ch][0] += wsum[0]; acc[ch][1] += wsum[1]; }
+            continue;
+        }
+        if (NCH == 4 && ch < NCH - 1 && uniform) {
+            if (lid < DSDF_TROWS && uni[ch < 3 ? ch : 0] != 0.f) { acc[ch][0] += wsum[0] * uni[ch < 3 ? ch : 0]; acc[ch][1] += wsum[1] * uni[ch < 3 ? ch : 0]; }
             continue;
         }
         if (ch < NCH - 1 && __ballot(val != 0.f) == 0) continue;     // pixels nobody hits skip the value channel

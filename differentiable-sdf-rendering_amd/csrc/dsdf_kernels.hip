@@ -410,7 +410,7 @@ void k_render_items(GridView G, dsdf_params P, ViewBatch VB, float *__restrict__
             film_accum_offsets(r0, r1, true, known_hit ? 1.f : 0.f, wave_lds, lid, acc);
             if (known_hit) tr.its_t = 0.f;                 // (statistics: the samples count as hits)
         } else {
-        L = lane_setup(A, P, lane, px, py);
+        L = lane_setup<!DIFF>(A, P, lane, px, py);
         if (known_hit) tr.its_t = 0.f;
         else if (!skip_trace) {
             // (the last few rays of the wave are handed to the tail queue: dsdf_tail.h)
@@ -468,7 +468,7 @@ void k_render_items(GridView G, dsdf_params P, ViewBatch VB, float *__restrict__
 // For spp < 64 (a power of two) a wave takes a tile_w x tile_h PIXEL TILE (64 / spp pixels) instead of 64 / spp consecutive
 // pixels of a row: its rays stay within a few voxels of each other (coherent row gathers, far fewer divergent march
 // lengths).  tile_w == 0: linear order.
-struct LaneMap { int tile_w, tile_h; uint32_t n_lanes; int row0, row1; unsigned deep_mask; };   // rows: film-block row window of the call
+struct LaneMap { int tile_w, tile_h; uint32_t n_lanes; int row0, row1; unsigned deep_mask; int env_fill; };   // rows: film-block row window of the call
 
 __device__ __forceinline__ uint32_t thread_lane(const ViewArgs &A, const LaneMap &M, uint32_t t, bool &valid) {
     if (M.tile_w == 0) {
@@ -518,7 +518,7 @@ __global__ __launch_bounds__(DSDF_BLOCK) void k_render_pass(GridView G, dsdf_par
         if (skip) {
             const unsigned f = skip[(size_t)blockIdx.y * A.Wb * A.Hb + (size_t)py * A.Wb + px];
             skip_trace = (f & (DIFF ? DSDF_PX_EMPTY_G : DSDF_PX_EMPTY)) != 0;
-            far = (f & (DIFF ? DSDF_PX_FAR_G : DSDF_PX_FAR)) != 0 && !(DIRECT && !S.hide_emitters);   // (a visible environment is not zero)
+            far = (f & (DIFF ? DSDF_PX_FAR_G : DSDF_PX_FAR)) != 0 && !(DIRECT && !S.hide_emitters && !M.env_fill);   // (a visible environment is not zero: k_film_env)
             // (hit proof: the samples of a deep pixel only reach film pixels that develop to 1 anyway; M.deep_mask = DSDF_PX_DEEP or 0)
             if (!DIFF && !DIRECT && (f & M.deep_mask) && A.integrator == DSDF_SILHOUETTE) far = true;
             known_hit = !DIFF && !DIRECT && (f & DSDF_PX_HIT) && A.integrator == DSDF_SILHOUETTE;      // (hit proof, dsdf_proof.h)
@@ -534,7 +534,7 @@ __global__ __launch_bounds__(DSDF_BLOCK) void k_render_pass(GridView G, dsdf_par
     constexpr bool COOP = !DIRECT && ((DSDF_COOP >> (DIFF ? 1 : 0)) & 1);        // bit 0: plain traces, bit 1: differentiable traces
     if (COOP) {
         const bool on = !far && !known_hit && !skip_trace;
-        if (!far) L = lane_setup(A, P, lane);
+        if (!far) L = lane_setup<!DIFF>(A, P, lane);
         else { L.ray.o = mk(0.f, 0.f, 0.f); L.ray.d = mk(0.f, 0.f, 1.f); L.ray.maxt = 0.f; }
         if (__ballot(on) != 0) {
             if (DIFF) coop_trace_diff(G, P, L.ray.o, L.ray.d, L.ray.maxt, on, tr, lid);
@@ -545,7 +545,7 @@ __global__ __launch_bounds__(DSDF_BLOCK) void k_render_pass(GridView G, dsdf_par
     constexpr bool COOP = false;
 #endif
     if (!far) {
-        if (!COOP) L = lane_setup(A, P, lane);
+        if (!COOP) L = lane_setup<!DIFF>(A, P, lane);
         if (known_hit) tr.its_t = 0.f;
         else if (!skip_trace && !COOP) {
             if (DIFF) trace_diff(G, P, L.ray.o, L.ray.d, L.ray.maxt, tr);
@@ -1231,6 +1231,8 @@ static bool deep_skip_enabled() { static const int v = env_int("DSDF_DEEP_SKIP",
 // (15 ms resident), and the tail kernel then starts later: step 42.5 vs 40.8 ms.  Default: one launch behind the tail kernel.
 static int coef_early_mode() { static const int v = env_int("DSDF_COEF_EARLY", 0); return v; }
 static int hit_proof_min_spp() { static const int v = env_int("DSDF_HIT_PROOF_MIN_SPP", 16); return v; }
+// DSDF_ENV_FILL=0: sdf_direct_reparam with a visible environment samples its far pixels (as until round 5; A/B)
+static bool env_fill_enabled() { static const int v = env_int("DSDF_ENV_FILL", 1); return v != 0; }
 static bool primal_handoff() { static const int v = env_int("DSDF_PRIMAL_HANDOFF", 1); return v != 0; }
 static int tail_streams_enabled() { static int v = env_int("DSDF_TAIL_STREAMS", 1); return v; }
 // blocks (4 waves) per sub-queue of a tail kernel: DSDF_TAIL_BLOCKS overrides the built-in value
@@ -1388,11 +1390,19 @@ static int run_pass(PassCtx &c, const Workspace &ws, const dsdf_camera *cams, in
         hipLaunchKernelGGL(k_film_ones, dim3((unsigned)((npix + 255) / 256), nv), dim3(256), 0, st, VB, skip, film, c.row0, c.row1, st64);
         if ((rc = check_launch("k_film_ones"))) return rc;
     }
+    const bool env_fill = c.direct && skip && !S.hide_emitters && env_fill_enabled();
+    if (env_fill) {
+        hipLaunchKernelGGL(k_film_env, dim3((unsigned)((npix + 255) / 256), nv), dim3(256), 0, st, VB, skip, film, c.row0, c.row1,
+                           DIFF ? DSDF_PX_EMPTY_G : DSDF_PX_EMPTY, S.env[0], S.env[1], S.env[2]);
+        if ((rc = check_launch("k_film_env"))) return rc;
+    }
     if (c.spp % 64 == 0) {
         // persistent workers over the compacted list of pixels that must be sampled
         // (sdf_direct_reparam with a visible environment: the background is not zero, every pixel is sampled)
         // (for the silhouette primal also the pixels whose samples only reach film pixels of value 1: DSDF_PX_DEEP, k_skip_dilate)
-        const unsigned far_bit = (c.direct && !S.hide_emitters) ? 0u : (DIFF ? DSDF_PX_FAR_G : (DSDF_PX_FAR | (deep_skip ? DSDF_PX_DEEP : 0u)));
+        // (sdf_direct_reparam with a visible environment: far pixels are skipped too since round 6 -- k_film_env above gives the film
+        // pixels they alone would have reached the environment's radiance)
+        const unsigned far_bit = (c.direct && !S.hide_emitters && !env_fill) ? 0u : (DIFF ? DSDF_PX_FAR_G : (DSDF_PX_FAR | (deep_skip ? DSDF_PX_DEEP : 0u)));
         if (hipMemsetAsync(ws.items, 0, (size_t)DSDF_MAX_GROUPS * DSDF_ITEM_HDR * sizeof(uint32_t), st) != hipSuccess)
             return fail(DSDF_ERR_LAUNCH, "hipMemsetAsync(work list) failed");
         // tile-major order: a tile = DSDF_ITEM_SEG chunks of 64 samples (16 x 16 pixels at 256 spp, 32 x 32 at 64 spp)
@@ -1516,7 +1526,7 @@ static int run_pass(PassCtx &c, const Workspace &ws, const dsdf_camera *cams, in
         LaneMap M;
         size_t nunits;
         pass_shape(c.W, c.H, c.spp, M.tile_w, M.tile_h, nunits);
-        M.n_lanes = c.nl; M.row0 = c.row0; M.row1 = c.row1; M.deep_mask = deep_skip ? DSDF_PX_DEEP : 0u;
+        M.n_lanes = c.nl; M.row0 = c.row0; M.row1 = c.row1; M.deep_mask = deep_skip ? DSDF_PX_DEEP : 0u; M.env_fill = env_fill ? 1 : 0;
         const dim3 grid((unsigned)(nunits / 4), nv), blk(DSDF_BLOCK);
         timing_mark(0, st);
         if (c.direct) hipLaunchKernelGGL((k_render_pass<DIFF, true>), grid, blk, 0, st, G, c.pp, VB, film, q, st64, M, skip, S);

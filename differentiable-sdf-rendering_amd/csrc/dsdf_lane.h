@@ -57,12 +57,16 @@ DSDF_HD void lane_pixel(const ViewArgs &A, uint32_t lane, int &px, int &py) {
 
 // lane -> pixel, jitter, camera ray (reparam.py:140-171, 90-95).  The second form takes the pixel from the caller: the work-list
 // kernel knows it (wave-uniform), and lane_pixel's two divisions by run-time values are ~50 instructions per chunk.
+// FASTCAM: camera_ray's switch (dsdf_math.h) -- true only in the primal passes.
+template <bool FASTCAM = false>
 DSDF_HD Lane lane_setup(const ViewArgs &A, const dsdf_params &P, uint32_t lane, int px, int py);
+template <bool FASTCAM = false>
 DSDF_HD Lane lane_setup(const ViewArgs &A, const dsdf_params &P, uint32_t lane) {
     int px, py;
     lane_pixel(A, lane, px, py);
-    return lane_setup(A, P, lane, px, py);
+    return lane_setup<FASTCAM>(A, P, lane, px, py);
 }
+template <bool FASTCAM>
 DSDF_HD Lane lane_setup(const ViewArgs &A, const dsdf_params &P, uint32_t lane, int px, int py) {
     Lane L;
     L.px = px; L.py = py;
@@ -72,7 +76,7 @@ DSDF_HD Lane lane_setup(const ViewArgs &A, const dsdf_params &P, uint32_t lane, 
     L.r0 = r0; L.r1 = r1;
     float fx = (float)(L.px - DSDF_BORDER) + r0;
     float fy = (float)(L.py - DSDF_BORDER) + r1;
-    L.ray = camera_ray(A.cam, P, fx, fy, A.W, A.H);
+    L.ray = camera_ray<FASTCAM>(A.cam, P, fx, fy, A.W, A.H);
     return L;
 }
 
@@ -86,7 +90,7 @@ DSDF_HD float shade_value(const GridView &G, const ViewArgs &A, const Lane &L, f
     // simple shading: n = normalize(grad sdf(o + t d)) ; max(n.l, 0)
     float v; V3 g; float H[6];
     eval_cubic<1>(G, fma3(its_t, L.ray.d, L.ray.o), v, g, H);
-    V3 n = g * rsqf(dot(g, g));
+    V3 n = g * rsqf_s<5>(dot(g, g));
     return fmaxf(dot(n, light_dir(A)), 0.f);
 }
 
@@ -322,7 +326,7 @@ DSDF_HD bool direct_setup(const GridView &G, const ViewArgs &A, const Lane &L, u
     h.p = fma3(its_t, L.ray.d, L.ray.o);
     float v; float H[6];
     eval_cubic<1>(G, h.p, v, h.g, H);
-    h.n = h.g * rsqf(dot(h.g, h.g));
+    h.n = h.g * rsqf_s<5>(dot(h.g, h.g));
     float e0, e1;
     emitter_sample(A, lane, e0, e1);
     h.sr = spawn_shadow_ray(h.p, h.n, square_to_uniform_sphere(e0, e1));

@@ -52,6 +52,19 @@ DSDF_HD float rcpf(float x) {
     return 1.f / x;
 #endif
 }
+// Per-SITE choice of the IEEE sequence in an otherwise fast build (DSDF_IEEE_SITES bit mask; precision bisection of round 6,
+// profiles/r06_ieee_sites.md): 0 trace weight, 1 extra-weight denominator, 2 ray-direction normalisation, 3 camera ray, 4 re-projection,
+// 5 shading normals, 6 box slabs, 7 film filter.
+// DEFAULT = site 3, the camera ray (normalisation of the local direction, 1 / d_z): with v_rsq_f32 / v_rcp_f32 there, every ray
+// direction carries a 1-ulp error of its own, and the estimator turns that input rounding into 5 x the reference's fp32 floor on the
+// C1-size simple-shading case (c1_spp4 shade: 1.09e-3 against the reference's fp64 result where the reference's own fp32 run is at
+// 2.1e-4; with the IEEE sequence 1.1e-4; geometric mean over the 11 reference-fp32 runs 1.40 -> 0.95).  The other seven sites, one
+// at a time: no change (1.32 ... 1.40) -- in particular NOT the cubed reciprocal of the trace weight.  profiles/r06_ieee_sites.md
+#ifndef DSDF_IEEE_SITES
+#define DSDF_IEEE_SITES 8
+#endif
+template <int SITE> DSDF_HD float rcpf_s(float x) { return ((DSDF_IEEE_SITES >> SITE) & 1) ? 1.f / x : rcpf(x); }
+template <int SITE> DSDF_HD float rsqf_s(float x) { return ((DSDF_IEEE_SITES >> SITE) & 1) ? 1.f / sqrtf(x) : rsqf(x); }
 // symmetric 3x3 (xx,yy,zz,xy,xz,yz) times vector
 DSDF_HD V3 symmul(const float H[6], V3 a) {
     return mk(H[0] * a.x + H[3] * a.y + H[4] * a.z,
@@ -498,7 +511,7 @@ DSDF_HD BoxHit bbox_ray_intersect(B lo, B hi, V3 o, V3 d) {
     BoxHit b;
     bool ok = (d.x != 0.f || o.x > bx(lo) || o.x < bx(hi)) && (d.y != 0.f || o.y > by(lo) || o.y < by(hi)) &&
               (d.z != 0.f || o.z > bz(lo) || o.z < bz(hi));
-    float rx = rcpf(d.x), ry = rcpf(d.y), rz = rcpf(d.z);
+    float rx = rcpf_s<6>(d.x), ry = rcpf_s<6>(d.y), rz = rcpf_s<6>(d.z);
     float t1x = (bx(lo) - o.x) * rx, t2x = (bx(hi) - o.x) * rx;
     float t1y = (by(lo) - o.y) * ry, t2y = (by(hi) - o.y) * ry;
     float t1z = (bz(lo) - o.z) * rz, t2z = (bz(hi) - o.z) * rz;
@@ -523,9 +536,9 @@ DSDF_HD float eval_trace_weight(const dsdf_params &P, V3 d, int i, B lo, B hi, V
                                 float v, V3 g, const float H[6], V3 &weight_d) {
     float n_dot_d = dot(g, d);
     float n_dot_n = dot(g, g);
-    float ratio = n_dot_d * rcpf(n_dot_n);
+    float ratio = n_dot_d * rcpf_s<0>(n_dot_n);
     float denom = P.sil_weight_epsilon + fabsf(v) + P.sil_weight_offset * n_dot_d * ratio;
-    float inv_denom = rcpf(denom);
+    float inv_denom = rcpf_s<0>(denom);
     float dist_w = inv_denom * inv_denom * inv_denom;
     // (Round 5 measured a bit-identical short cut here -- outside the fade zone bw is exactly 1 and its gradient exactly 0, so the
     // nearest-face logic can be skipped: 30 fewer instructions per step and 166 -> 125 VGPRs for the sweep, 3 -> 4 waves per SIMD,
@@ -577,7 +590,7 @@ struct PlainMarch { V3 o, d; float t, maxt, trace_eps, its_t; bool active; };
 
 DSDF_HD PlainMarch plain_march_begin(const dsdf_params &P, V3 o, V3 d_in, float ray_maxt) {
     PlainMarch m;
-    float inv = rsqf(dot(d_in, d_in));
+    float inv = rsqf_s<2>(dot(d_in, d_in));
     m.o = o;
     m.d = d_in * inv;
     const BoxBound lo = box_lo(P), hi = box_hi(P);
@@ -636,7 +649,7 @@ DSDF_HD void trace_plain(const GridView &G, const dsdf_params &P, V3 o, V3 d_in,
 // with the weighted warp-t accumulation and its analytic direction derivative.
 template <class Fetch, class Ctl>
 DSDF_HD void trace_diff(const GridView &G, const dsdf_params &P, V3 o, V3 d_in, float ray_maxt, TraceOut &out, Fetch &F, Ctl &C) {
-    float invn = rsqf(dot(d_in, d_in));
+    float invn = rsqf_s<2>(dot(d_in, d_in));
     V3 d = d_in * invn;                                              // :124
     const BoxBound lo = box_lo(P), hi = box_hi(P);
     BoxHit b = bbox_ray_intersect(lo, hi, o, d);
@@ -666,7 +679,7 @@ DSDF_HD void trace_diff(const GridView &G, const dsdf_params &P, V3 o, V3 d_in, 
             float sd = fabsf(v);
             V3 w_d;
             float w = eval_trace_weight(P, d, i, lo, hi, x, v, g, H, w_d);   // :188
-            float inv_den = rcpf(fminf(P.extra_thresh, sd));         // :198
+            float inv_den = rcpf_s<1>(fminf(P.extra_thresh, sd));         // :198
             float diff = prev_sd - sd;
             ews += (diff >= 0.f) ? diff * inv_den : 0.f;
             ews = fminf(ews, 1.f);                                   // :201
@@ -734,7 +747,7 @@ struct DiffMarch {
 
 DSDF_HD DiffMarch diff_march_begin(const dsdf_params &P, V3 o, V3 d_in, float ray_maxt) {
     DiffMarch m;
-    float invn = rsqf(dot(d_in, d_in));
+    float invn = rsqf_s<2>(dot(d_in, d_in));
     m.o = o;
     m.d = d_in * invn;                                               // :124
     const BoxBound lo = box_lo(P), hi = box_hi(P);
@@ -767,7 +780,7 @@ DSDF_HD void diff_march_step(const dsdf_params &P, DiffMarch &m, V3 x, float v, 
     float sd = fabsf(v);
     V3 w_d;
     float w = eval_trace_weight(P, d, m.i, lo, hi, x, v, g, H, w_d); // :188
-    float inv_den = rcpf(fminf(P.extra_thresh, sd));                 // :198
+    float inv_den = rcpf_s<1>(fminf(P.extra_thresh, sd));                 // :198
     float diff = m.prev_sd - sd;
     m.ews += (diff >= 0.f) ? diff * inv_den : 0.f;
     m.ews = fminf(m.ews, 1.f);                                       // :201
@@ -841,18 +854,23 @@ DSDF_HD void trace_diff(const GridView &G, const dsdf_params &P, V3 o, V3 d, flo
 // ---------------------------------------------------------------------------
 struct CamRay { V3 o, d, dl; float maxt; };
 
+// FASTCAM: the hardware reciprocals for the two operations below (site 3 of DSDF_IEEE_SITES) -- the PRIMAL passes, whose images keep
+// 1e-7 either way; the gradient passes (sweep, tails of the sweep, backward kernels: the same ray must be rebuilt bit for bit) use the
+// IEEE sequences, which is what the reference-fp32 comparison asks for (profiles/r06_ieee_sites.md) and costs the primal launch
+// 0.7 ms if applied there too.
+template <bool FASTCAM = false>
 DSDF_HD CamRay camera_ray(const dsdf_camera &c, const dsdf_params &P, float px, float py, int W, int H) {
     // (W, H are wave-uniform: their reciprocals are scalar work)
     float inv_w = 1.f / (float)W, inv_h = 1.f / (float)H;
     float sx = px * inv_w, sy = py * inv_h;
     V3 dl = mk((1.f - 2.f * sx) * c.tan_half_fov, (1.f - 2.f * sy) * c.tan_half_fov * ((float)H * inv_w), 1.f);
-    dl = dl * rsqf(dot(dl, dl));
+    dl = dl * (FASTCAM ? rsqf(dot(dl, dl)) : rsqf_s<3>(dot(dl, dl)));
     CamRay r;
     r.dl = dl;
     r.d = mk(c.left[0] * dl.x + c.up[0] * dl.y + c.dir[0] * dl.z,
              c.left[1] * dl.x + c.up[1] * dl.y + c.dir[1] * dl.z,
              c.left[2] * dl.x + c.up[2] * dl.y + c.dir[2] * dl.z);
-    float inv_z = rcpf(dl.z);
+    float inv_z = FASTCAM ? rcpf(dl.z) : rcpf_s<3>(dl.z);
     float near_t = P.near_clip * inv_z;
     r.o = mk(c.origin[0], c.origin[1], c.origin[2]) + near_t * r.d;
     r.maxt = P.far_clip * inv_z - near_t;
@@ -871,7 +889,7 @@ DSDF_HD Reproj reproject(const dsdf_camera &c, const dsdf_params &P, V3 p, int W
                c.dir[0] * q.x + c.dir[1] * q.y + c.dir[2] * q.z);
     float aspect = (float)W / (float)H;
     float cot = 1.f / c.tan_half_fov;
-    float inv_z = rcpf(r.ref.z);
+    float inv_z = rcpf_s<4>(r.ref.z);
     float sx = 0.5f - 0.5f * cot * r.ref.x * inv_z;
     float sy = 0.5f - 0.5f * aspect * cot * r.ref.y * inv_z;
     r.inside = r.ref.z >= P.near_clip && r.ref.z <= P.far_clip && sx >= 0.f && sx <= 1.f && sy >= 0.f && sy <= 1.f;
@@ -887,7 +905,7 @@ DSDF_HD Reproj reproject(const dsdf_camera &c, const dsdf_params &P, V3 p, int W
 
 // exp(alpha x^2): v_exp_f32 (2^x, 1 ulp) on the device instead of the range-reduced expf sequence
 DSDF_HD float gauss_exp(float x) {
-#if defined(__HIP_DEVICE_COMPILE__) && DSDF_FAST_RCP
+#if defined(__HIP_DEVICE_COMPILE__) && DSDF_FAST_RCP && !((DSDF_IEEE_SITES >> 7) & 1)
     return __builtin_amdgcn_exp2f((DSDF_FILTER_ALPHA * 1.4426950408889634f) * x * x);
 #else
     return expf(DSDF_FILTER_ALPHA * x * x);

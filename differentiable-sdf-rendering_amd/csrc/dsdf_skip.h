@@ -133,6 +133,29 @@ __global__ void k_skip_dilate(ViewBatch VB, unsigned char *__restrict__ flags) {
     f[i] = (unsigned char)((f[i] & DSDF_PX_KEEP) | ((m & 3u) << 2) | ((m & DSDF_PX_HIT) ? DSDF_PX_DEEP : 0u) | (near ? DSDF_PX_ONE : 0u));
 }
 
+// sdf_direct_reparam with a VISIBLE environment (round 6): a sample that misses carries the environment's radiance, so "far" pixels
+// used to be sampled all the same (82 % of the chunks of the C5 workload: sampler, camera ray, a 4-channel film reduce each).  But a
+// film pixel ALL of whose contributors (the pixels within +-2) are proven empty receives only samples of value `env`: it develops to
+// env whatever their weights are.  k_film_env adds (env, 1) to every such film pixel of the call's row window; the samples of a far
+// pixel (bit 2 / 3: everything within +-4 proven empty) only ever reach such film pixels and are not generated.  Where samples of
+// near pixels still arrive, (env + sum w env) / (1 + sum w) = env.  pass_bit: DSDF_PX_EMPTY (primal) or DSDF_PX_EMPTY_G (gradient pass:
+// its film is developed too, and no backward lane reads the adjoint of such a pixel).
+__global__ void k_film_env(ViewBatch VB, const unsigned char *__restrict__ flags, float *__restrict__ blocks, int row0, int row1,
+                           unsigned pass_bit, float er, float eg, float eb) {
+    const ViewArgs &A = VB.v[blockIdx.y];
+    const int i = blockIdx.x * blockDim.x + threadIdx.x, npix = A.Wb * A.Hb;
+    if (i >= npix) return;
+    const int py = i / A.Wb, px = i - py * A.Wb;
+    if (py < row0 || py >= row1) return;
+    const unsigned char *f = flags + (size_t)blockIdx.y * npix;
+    unsigned m = pass_bit;
+    for (int y = max(py - 2, 0); y <= min(py + 2, A.Hb - 1); ++y)
+        for (int x = max(px - 2, 0); x <= min(px + 2, A.Wb - 1); ++x) m &= f[y * A.Wb + x];
+    if (!m) return;
+    float *b = blocks + ((size_t)blockIdx.y * npix + i) * 4;
+    atomicAdd(b, er); atomicAdd(b + 1, eg); atomicAdd(b + 2, eb); atomicAdd(b + 3, 1.f);
+}
+
 // (1, 1) for the film pixels of the call's row window that receive hits only (bit 6): see k_skip_dilate.  The samples of the
 // deep pixels (bit 5) are proven hits that nobody generates: the caller's statistics count them as hits all the same.
 __global__ void k_film_ones(ViewBatch VB, const unsigned char *__restrict__ flags, float *__restrict__ blocks, int row0, int row1,

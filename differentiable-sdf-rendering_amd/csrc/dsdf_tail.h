@@ -518,7 +518,7 @@ __global__ __launch_bounds__(256) void k_tail_trace_plain(GridView G, dsdf_param
             const unsigned long long c_b = stats ? (unsigned long long)clock64() : 0ull;
             if (idx != ~0u) {
                 view = __float_as_uint(e[0]);
-                L = lane_setup(views[view], P, __float_as_uint(e[1]));
+                L = lane_setup<true>(views[view], P, __float_as_uint(e[1]));
                 m = plain_march_begin(P, L.ray.o, L.ray.d, L.ray.maxt);
                 m.t = e[2];
                 F.valid = false;

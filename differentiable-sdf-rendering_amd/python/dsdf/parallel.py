@@ -48,6 +48,73 @@ def work_partition(n_views, film_rows, world):
     return [units[r::world] for r in range(world)]
 
 
+def cost_partition(cost, world):
+    """COST-AWARE work units (round 6).  `cost`: (n_views, film_rows) array of predicted work per film-block
+    row of every view (row_costs() below: from the per-pixel proofs of the previous step -- the pixels whose samples are traced
+    dominate, pixels that are proven away cost their film weights, far pixels nothing).  The uniform deal of work_partition() left
+    the ranks of the bench scene 1.36 x (N = 4) and 1.64 x (N = 8) apart (profiles/r05last_bench.json) because views and upper /
+    lower halves of views differ that much in silhouette length.
+
+    Shape of the result = shape of work_partition(): with G = gcd(n_views, world) the views form G groups of n_views / G views,
+    every group is cut into t = world / G row windows, rank g * t + k renders window k of the views of group g -- so a rank still
+    makes ONE library call per pass (all its units share a row window).  What changes:
+      * the views are dealt to the groups by predicted cost (largest first, each to the lightest group that has room), not round-robin;
+      * a group's windows are cut where its summed row costs reach k / t of its total, not at k / t of the rows.
+    Deterministic in `cost` (every rank computes the same partition from the same all-reduced matrix)."""
+    import numpy as np
+    cost = np.asarray(cost, np.float64)
+    if cost.ndim != 2 or world < 1:
+        raise ValueError("cost must be (n_views, film_rows)")
+    n_views, rows = cost.shape
+    G = math.gcd(n_views, world)
+    tiles, per_group = world // G, n_views // G
+    if rows < tiles:
+        raise ValueError("more row windows than film rows")
+    cost = np.where(np.isfinite(cost) & (cost > 0), cost, 0.0)
+    vc = cost.sum(1)
+    groups, sums = [[] for _ in range(G)], [0.0] * G
+    for v in sorted(range(n_views), key=lambda i: (-vc[i], i)):
+        g = min((g for g in range(G) if len(groups[g]) < per_group), key=lambda g: (sums[g], g))
+        groups[g].append(v); sums[g] += vc[v]
+    out = []
+    for g in range(G):
+        views = sorted(groups[g])
+        h = cost[views].sum(0) + 1e-12 * max(vc.sum(), 1.0) / rows          # (a floor: an all-zero histogram is cut evenly)
+        c = np.concatenate([[0.0], np.cumsum(h)])
+        edges = [0]
+        for k in range(1, tiles):
+            e = int(np.searchsorted(c, c[-1] * k / tiles))
+            # the row whose inclusion crosses the target goes to the side that leaves the smaller error
+            if e > 0 and abs(c[e - 1] - c[-1] * k / tiles) <= abs(c[e] - c[-1] * k / tiles):
+                e -= 1
+            e = max(edges[-1] + 1, min(e, rows - (tiles - k)))              # every window keeps at least one row
+            edges.append(e)
+        edges.append(rows)
+        for k in range(tiles):
+            out.append([(v, edges[k], edges[k + 1]) for v in views])
+    return out
+
+
+def row_costs(flags, n_views, Wb, Hb, spp, spp_grad, silhouette=True):
+    """Predicted work per film-block row from the per-pixel proof flags of a step (csrc/dsdf_proof.h: bit 0 / 1 = every sample misses
+    in the primal / gradient pass, 2 / 3 = ... and so does every pixel within +-4, 4 = every sample hits, 5 = deep inside), as a
+    (n_views, Hb) float64 tensor on the flags' device.  Weights = wave instructions per 64-sample chunk of the bench scene
+    (profiles/valu_model.json: a traced primal chunk ~ 24 wave iterations x 176 + 1454, a proven one ~ 500, a traced chunk of the
+    sweep ~ 20 x 759): only their RATIOS matter."""
+    import torch
+    f = flags[:n_views * Wb * Hb].view(n_views, Hb, Wb)
+    empty, empty_g, far, far_g, hit, deep = ((f & b) != 0 for b in (1, 2, 4, 8, 16, 32))
+    listed_p = ~far & ~(deep if silhouette else torch.zeros_like(deep))
+    proven_p = listed_p & (empty | (hit if silhouette else torch.zeros_like(hit)))
+    traced_p = listed_p & ~proven_p
+    listed_g = ~far_g
+    traced_g = listed_g & ~empty_g
+    cp, cg = spp / 64.0, spp_grad / 64.0
+    c = cp * (5600.0 * traced_p.sum(2, dtype=torch.float64) + 500.0 * proven_p.sum(2, dtype=torch.float64)) + \
+        cg * (15000.0 * traced_g.sum(2, dtype=torch.float64) + 500.0 * (listed_g & ~traced_g).sum(2, dtype=torch.float64))
+    return c
+
+
 def rank_windows(units):
     """Groups a rank's (view, row0, row1) units by row window: [((row0, row1), [views...]), ...] -- one library call per
     window renders all of the rank's views that share it."""
@@ -76,7 +143,7 @@ def _call_loss_grad(loss_grad, images, views):
 
 
 def render_step(ops, n_views, W, H, rank, world, loss_grad, grad_grid, group=None, extra_grads=(), gather_images=True,
-                async_reduce=False, force_reduce=False):
+                async_reduce=False, force_reduce=False, partition=None):
     """One differentiable render of `n_views` views shared by `world` ranks, split by views and -- when world does not
     divide them -- by pixel tiles (work_partition).  `ops` supplies the four film-level operators of the renderer for a
     list of views and a row window (dsdf.render_film / develop / GradSweep on a GPU; the oracle's in the CPU tests):
@@ -95,7 +162,10 @@ def render_step(ops, n_views, W, H, rank, world, loss_grad, grad_grid, group=Non
     all-gathered when gather_images, else only this rank's rows are filled), or (images, work) with async_reduce."""
     import torch
     import torch.distributed as dist
-    units = work_partition(n_views, H + 4, world)[rank]
+    # (partition: the units of ALL ranks, e.g. cost_partition(...) of the previous step's row costs; default: the uniform deal)
+    if partition is not None and len(partition) != world:
+        raise ValueError("partition must list the units of every rank")
+    units = (partition if partition is not None else work_partition(n_views, H + 4, world))[rank]
     wins = rank_windows(units)
     split = world // math.gcd(n_views, world) > 1
     mine = sorted({v for v, _, _ in units})
@@ -153,6 +223,44 @@ def render_step(ops, n_views, W, H, rank, world, loss_grad, grad_grid, group=Non
     return (images, work) if async_reduce else images
 
 
+class CostTracker:
+    """Row costs of all views as the ranks measure them, one step behind: after a step every rank writes the rows it has proofs
+    for (ops.row_costs(views)), one all-reduce of the (n_views, rows) matrix and of its hit counts (25 KB at 12 x 516) gives every
+    rank the same matrix, and partition() is cost_partition() of it -- the uniform deal until the first measurement."""
+
+    def __init__(self, n_views, rows, world, device=None):
+        import numpy as np
+        self.n_views, self.rows, self.world = n_views, rows, world
+        self.device = device                        # where the collective's buffer lives (RCCL reduces device tensors)
+        self.cost = None
+        self._np = np
+
+    def partition(self):
+        return work_partition(self.n_views, self.rows, self.world) if self.cost is None else cost_partition(self.cost, self.world)
+
+    def update(self, views, costs, group=None):
+        """views: the views this rank has row costs for; costs: (len(views), rows) tensor.  Collective (every rank calls it)."""
+        import torch
+        import torch.distributed as dist
+        dev = self.device if self.device is not None else (costs.device if hasattr(costs, 'device') else 'cpu')
+        m = torch.zeros(2, self.n_views, self.rows, dtype=torch.float64, device=dev)
+        if len(views) and costs is not None:
+            m[0, list(views)] = torch.as_tensor(costs, dtype=torch.float64, device=dev)
+            m[1, list(views)] = 1.0
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+            dist.all_reduce(m, op=dist.ReduceOp.SUM, group=group)
+        m = m.cpu().numpy()
+        seen = m[1] > 0
+        new = self._np.where(seen, m[0] / self._np.maximum(m[1], 1.0), 0.0)
+        if self.cost is None:
+            # views nobody measured yet (cannot happen with a full partition) get the mean row cost
+            fill = new[seen].mean() if seen.any() else 1.0
+            self.cost = self._np.where(seen, new, fill)
+        else:
+            self.cost = self._np.where(seen, new, self.cost)
+        return self.cost
+
+
 def _wants_views(loss_grad):
     import inspect
     try:
@@ -199,8 +307,17 @@ class HipOps:
         from . import _lib
         dev = self.grid.device
         n = len(views) * (self.W + 4) * (self.H + 4)
-        if getattr(self, '_flags', None) is None or self._flags.numel() < n:
-            self._flags = torch.empty(n, dtype=torch.uint8, device=dev)
+        self._group_views = list(views)
+        # ONE flags buffer PER window group of a step: group k + 1's sweep writes its flags on the side stream while group
+        # k's film kernels may still read theirs on the main stream -- nothing orders that writer after that reader
+        bufs = self.__dict__.setdefault('_flag_bufs', [])
+        gi = getattr(self, '_group_i', 0)
+        self._group_i = gi + 1
+        while len(bufs) <= gi:
+            bufs.append(None)
+        if bufs[gi] is None or bufs[gi].numel() < n:
+            bufs[gi] = torch.empty(n, dtype=torch.uint8, device=dev)
+        self._flags = bufs[gi]
         self._share_lib = self.grid.lib(self.r._needs_extended(self.kw.get('shading')))
         with torch.cuda.device(dev):
             _lib.check(self._share_lib.dsdf_share_pixel_skip(self.r._ptr(self._flags), self._flags.numel()))
@@ -209,11 +326,23 @@ class HipOps:
         import torch
         with torch.cuda.device(self.grid.device):
             self._share_lib.dsdf_share_pixel_skip(None, 0)
+        self._flag_views = getattr(self, '_group_views', None)
+
+    def row_costs(self):
+        """(views, costs): the views of the LAST window group and their predicted work per film-block row (parallel.row_costs of the
+        group's proof flags -- a proof covers all rows of its views, whatever the window)."""
+        views = getattr(self, '_flag_views', None)
+        if not views or getattr(self, '_flags', None) is None:
+            return [], None
+        from .renderer import DSDF_SILHOUETTE
+        sil = self.integrator in (DSDF_SILHOUETTE, 'sdf_silhouette_reparam')
+        return list(views), row_costs(self._flags, len(views), self.W + 4, self.H + 4, self.spp, self.spp_grad, sil)
 
     # ---- sweeps: on the side stream, between begin_sweeps() and end_sweeps(); joined before the backward
     def begin_sweeps(self):
         import torch
         self._next_ws = 0
+        self._group_i = 0
         if self._side is not None:
             self._side.wait_stream(torch.cuda.current_stream(self.grid.device))
             self._in_sweeps = True

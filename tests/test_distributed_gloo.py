@@ -67,7 +67,7 @@ def _worker(rank, world, port, out):
     dist.destroy_process_group()
 
 
-def _tile_worker(rank, world, port, out, n_views, variant=False):
+def _tile_worker(rank, world, port, out, n_views, variant=False, cost_aware=False):
     """render_step (dsdf/parallel.py) with the ORACLE's film-level operators: the split by views and by pixel tiles, the two
     film sums and the gradient sum reproduce the single-process image and gradient."""
     for p in (os.path.join(ROOT, 'oracle'), os.path.join(ROOT, 'differentiable-sdf-rendering_amd', 'python'), os.path.join(ROOT, 'tests')):
@@ -112,7 +112,21 @@ def _tile_worker(rank, world, port, out, n_views, variant=False):
                 grad_grid += leaf.grad
 
     g = torch.zeros(R, R, R, dtype=torch.float64)
-    if variant:
+    part = None
+    if cost_aware:
+        # the COST-AWARE split (parallel.cost_partition) of a skewed cost matrix: uneven windows, views dealt by cost -- and through the
+        # CostTracker's collective update, so that both ranks derive the partition from the same all-reduced matrix
+        import numpy as np
+        full = np.outer(np.linspace(1.0, 3.0, n_views), np.linspace(0.1, 4.0, H + 4) ** 2)
+        tr = parallel.CostTracker(n_views, H + 4, world)
+        assert tr.partition() == parallel.work_partition(n_views, H + 4, world)
+        mine0 = sorted({v for v, _, _ in tr.partition()[rank]})
+        tr.update(mine0, torch.from_numpy(full[mine0]))
+        part = tr.partition()
+        assert part == parallel.cost_partition(full, world)
+    if cost_aware:
+        images = parallel.render_step(Ops(), n_views, W, H, rank, world, lambda im: 2.0 * (im - tgt), g, partition=part)
+    elif variant:
         # whole views without the image gather, loss gradient per owned view, a second gradient tensor in the bucket, and the
         # non-blocking reduce
         extra = torch.full((5,), float(rank + 1), dtype=torch.float64)
@@ -134,7 +148,7 @@ def _tile_worker(rank, world, port, out, n_views, variant=False):
         ref = torch.stack([O.render(O.Grid3d(leaf), cams[v], W, H, spp, offs[v], integ) for v in range(n_views)])
         ((ref - tgt) ** 2).sum().backward()
         out.put((float((images - ref.detach()).abs().max()), float((g - leaf.grad).abs().max()), float(leaf.grad.abs().max()),
-                 parallel.work_partition(n_views, H + 4, world)[0]))
+                 part[0] if part is not None else parallel.work_partition(n_views, H + 4, world)[0]))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -157,6 +171,56 @@ def test_tile_split_equals_single_process(n_views):
         assert units == [(0, 0, 6)]                       # rank 0 renders rows [0, 6) of the 12-row film block of view 0
     if n_views == 2:
         assert units == [(0, 0, 12)]
+
+
+@pytest.mark.parametrize('n_views', [1, 3, 4])
+def test_cost_aware_split_equals_single_process(n_views):
+    """world 2 with parallel.cost_partition of a skewed cost matrix (uneven row windows for 1 and 3 views, whole views dealt by cost
+    for 4): image and gradient equal the single-process result, as with the uniform deal."""
+    ctx = mp.get_context('spawn')
+    out = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000) + 300 + 7 * n_views
+    procs = [ctx.Process(target=_tile_worker, args=(r, 2, port, out, n_views, False, True)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=600)
+        assert p.exitcode == 0
+    err_img, err_g, mag, units = out.get(timeout=10)
+    assert mag > 0 and err_img < 1e-12 and err_g <= 1e-10 * max(mag, 1.0), (err_img, err_g, mag)
+    if n_views in (1, 3):
+        assert all(r0 == 0 and r1 > 6 for _, r0, r1 in units), units        # the rows are cheap at the top: rank 0's window is the larger one
+    else:
+        assert sorted(v for v, _, _ in units) == [0, 3] and all((r0, r1) == (0, 12) for _, r0, r1 in units), units   # LPT: {3, 0} / {2, 1}
+
+
+def test_cost_partition():
+    sys.path.insert(0, os.path.join(ROOT, 'differentiable-sdf-rendering_amd', 'python'))
+    import numpy as np
+    from dsdf import parallel
+    rng = np.random.default_rng(1)
+    for n in (1, 3, 12, 48):
+        for world in (1, 2, 4, 5, 8):
+            if n * 516 < world:
+                continue
+            cost = rng.random((n, 516)) * np.linspace(0.2, 2.0, 516)[None] * (0.5 + rng.random((n, 1)))
+            P, U = parallel.cost_partition(cost, world), parallel.work_partition(n, 516, world)
+            assert len(P) == world and [len(u) for u in P] == [len(u) for u in U]        # the same shape as the uniform deal
+            cover = {}
+            for u in P:
+                assert len({(r0, r1) for _, r0, r1 in u}) == 1                            # ONE row window per rank
+                for v, r0, r1 in u:
+                    cover.setdefault(v, []).append((r0, r1))
+            for v in range(n):                                                            # every view: windows tile [0, 516) exactly once
+                w = sorted(cover[v])
+                assert w[0][0] == 0 and w[-1][1] == 516 and all(a[1] == b[0] and a[0] < a[1] for a, b in zip(w, w[1:] + [(516, 517)]))
+            load = lambda part: [sum(cost[v, a:b].sum() for v, a, b in u) for u in part]
+            lp, lu = load(P), load(U)
+            assert max(lp) / min(lp) <= max(1.05 * max(lu) / min(lu), 1.10), (n, world, lp, lu)   # as good as the uniform deal, or within 10 %
+    cost = np.outer(np.ones(12), np.linspace(0.0, 1.0, 516))                              # all work in the lower rows
+    l8 = [sum(cost[v, a:b].sum() for v, a, b in u) for u in parallel.cost_partition(cost, 8)]
+    assert max(l8) / min(l8) < 1.02
+    assert parallel.cost_partition(np.zeros((3, 12)), 2) == parallel.work_partition(3, 12, 2)   # no information: the even cut
 
 
 def test_whole_views_async_bucket_no_gather():

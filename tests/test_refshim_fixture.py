@@ -363,7 +363,10 @@ def test_fixture_is_what_the_reference_code_produces(tmp_path):
 # the nine runs the GEOMETRIC MEAN of e64 / floor <= 2 -- "as close to the reference's exact result as the reference's own fp32
 # evaluation is, within a factor two".  (The per-case gates of the tests above, from the ORACLES' fp32 floors with their
 # one-footprint rule, stay in force; these add the reference's own code at its own precision as the third witness.)
-REF32_RUN_FACTOR, REF32_MEAN_FACTOR = 6.0, 2.0
+# Round 6: per run 3 x (was 6 x) with the one-footprint rule of check_fp32_gradient, geometric mean 1.5 (was 2) --
+# possible since the camera ray of the gradient passes is built with the IEEE sequences (profiles/r06_ieee_sites.md: the hardware
+# reciprocals THERE were the whole 5 x of `c1_spp4 shade`; GPU geometric mean 1.40 -> 0.95).
+REF32_RUN_FACTOR, REF32_MEAN_FACTOR = 3.0, 1.5
 FP32_RUNS = [('sphere16', 'sil'), ('sphere16', 'shade'), ('sphere16', 'direct'), ('blob32', 'sil'), ('blob32', 'shade'), ('blob32', 'direct'),
              ('blob32', 'direct_mis'), ('blob32_spp64', 'sil'), ('blob32_spp64', 'shade'),
              # BASELINE.json configs[0] sizes (64^3, 128 x 128; spp 4: 70 k lanes) -- the reference's own CPU-runnable case
@@ -417,7 +420,12 @@ def _three_columns(kind, name, tag, gg):
     e64, e32 = rel_l2(gg, r64[f'grad_{tag}']), rel_l2(gg, r32[f'grad_{tag}'])
     P.record(kind, case=name, tag=tag, ref32_vs_ref64=f, hip_vs_ref64=e64, hip_vs_ref32=e32)
     gate = max(REF32_RUN_FACTOR * f, P.NORTH_STAR)
-    assert e64 <= gate, (kind, name, tag, dict(ref32_vs_ref64=f, vs_ref64=e64, vs_ref32=e32, gate=gate))
+    if e64 > gate:
+        # ONE sample footprint may be set aside (check_fp32_gradient): the rest must pass, the footprint itself be reproduced to 0.5 %
+        rest, centres, keep = P.greedy_blocks(gg, r64[f'grad_{tag}'], gate, max_blocks=1)
+        inside = rel_l2(np.asarray(gg)[~keep], np.asarray(r64[f'grad_{tag}'])[~keep])
+        P.record(kind + '_footprint', case=name, tag=tag, plain=e64, rest=rest, inside=inside, gate=gate, centre=list(centres[0]) if centres else None)
+        assert rest <= gate and inside < 5e-3, (kind, name, tag, dict(ref32_vs_ref64=f, vs_ref64=e64, vs_ref32=e32, gate=gate, rest=rest, inside=inside))
     return e64 / f
 
 

@@ -59,11 +59,19 @@ def case_inputs(name):
            'blob32_spp64': (32, 3, 2, 12, 12, 64, 3),                # (the same tuples as tests/cases.py)
            # BASELINE.json configs[0] -- "sphere 64^3 SDF, 1 view, 128 x 128", the reference's own CPU-runnable case -- at spp 4
            # (tests/precision.py: C1_spp4; 70 k lanes)
-           'c1_spp4': (64, 1, 0, 128, 128, 4, 21)}[name]
+           'c1_spp4': (64, 1, 0, 128, 128, 4, 21),
+           # round 6: the same case at spp 16 (279 k lanes) and a BASELINE.json configs[1]-size case -- bench.py's
+           # 128^3 blob scene, view 0 of the 12-ring, 256 x 256, spp 4 (270 k lanes); tests/precision.py: C1_spp16, C2 sizes
+           'c1_spp16': (64, 1, 0, 128, 128, 16, 22), 'c2_spp4': (128, 12, 0, 256, 256, 4, 29)}[name]
     R, ncam, icam, W, H, spp, seed = cfg
     sys.path.insert(0, os.path.join(ROOT, 'oracle'))
     import sdf_oracle as O                                          # grids + camera ring: plain torch, no product code
-    grid = (O.sphere_grid(16) if name == 'sphere16' else (O.sphere_grid(64) if name == 'c1_spp4' else O.blob_grid(32, n=6, seed=1))).float().numpy()
+    if name == 'c2_spp4':
+        sys.path.insert(0, ROOT)
+        import bench                                                # (the bench scene's generator: plain torch, no product code)
+        grid = bench.synth_grid(128, 'cpu').float().numpy()
+    else:
+        grid = (O.sphere_grid(16) if name == 'sphere16' else (O.sphere_grid(64) if name.startswith('c1_') else O.blob_grid(32, n=6, seed=1))).float().numpy()
     gen = torch.Generator().manual_seed(seed)
     torch.rand((W + 4) * (H + 4) * spp, 2, generator=gen, dtype=torch.float32)      # (cases.py draws the explicit offsets first)
     grad_image = torch.randn(H, W, 3, generator=gen, dtype=torch.float32).numpy()
