@@ -246,11 +246,12 @@ def scaling_prediction_block(args, dev, grid, target, ring, t1_ms, steps=3):
         return c.cpu().numpy()
 
     cost = probe_costs() if args.partition == 'cost' else None
+    tracker = {}
 
     def rank_ms(r, N):
         split = args.views % N != 0
         if cost is not None:
-            part = parallel.cost_partition(cost, N)
+            part = tracker[N]._last
             seeds0 = [i * 2 for i in range(args.views)]
             ops = parallel.HipOps(grid, ring, args.spp_primal, args.spp_grad, seeds0, [x + 1 for x in seeds0], args.integrator,
                                   two_streams=bool(args.overlap))
@@ -295,11 +296,29 @@ def scaling_prediction_block(args, dev, grid, target, ring, t1_ms, steps=3):
 
     if args.emulate_rank:
         r, N = (int(x) for x in args.emulate_rank.split('/'))
+        if cost is not None:
+            tracker[N] = parallel.CostTracker(args.views, args.img + 4, N)
+            tracker[N].cost = cost
+            tracker[N].partition()
         return {"emulated_rank": r, "world": N, "ms_per_step": rank_ms(r, N)}
     rows = []
     for N in (2, 4, 8):
         mark(f'scaling_prediction N={N}')
-        per = [rank_ms(r, N) for r in range(N)]
+        first = None
+        if cost is not None:
+            # the ranks' partition as a real run reaches it: the proxy's cut first, then `rounds` steps of time feedback
+            # (parallel.CostTracker.apply_times: the rows of slow shards get heavier)
+            tracker[N] = parallel.CostTracker(args.views, args.img + 4, N)
+            tracker[N].cost = cost
+            for rnd in range(3):
+                tracker[N].partition()
+                per = [rank_ms(r, N) for r in range(N)]
+                if first is None:
+                    first = per
+                if rnd < 2:
+                    tracker[N].apply_times(per)
+        else:
+            per = [rank_ms(r, N) for r in range(N)]
         split = args.views % N != 0
         ar = 1e3 * 2.0 * (N - 1) / N * S / link
         film = 1e3 * 2.0 * (2.0 * (N - 1) / N * args.views * (args.img + 4) ** 2 * 2 * 4 / link) if split else 0.0
@@ -307,6 +326,7 @@ def scaling_prediction_block(args, dev, grid, target, ring, t1_ms, steps=3):
         pred = max(comp + film, ar)
         rows.append({"n_gpus": N, "partition": ("cost-aware " if cost is not None else "") + ("pixel-row windows" if split else "whole views"),
                      "max_over_min_rank_ms": max(per) / min(per), "rank_ms": [round(x, 3) for x in per],
+                     "rank_ms_before_time_feedback": None if first is None else [round(x, 3) for x in first],
                      "compute_ms_max_over_ranks": comp, "allreduce_ms_model": ar, "film_exchange_ms_model": film,
                      "predicted_ms_per_step": pred, "predicted_speedup": t1_ms / pred, "predicted_efficiency": t1_ms / pred / N})
     return {"label": "PREDICTED from single-GPU shard timings + a link model; no xGMI / RCCL transfer between two GPUs was measured",
@@ -535,6 +555,7 @@ def main():
     ev = lambda: torch.cuda.Event(enable_timing=True)
     hip_ops = {}
     trackers = {}                               # (spp pair) -> parallel.CostTracker: the row costs all ranks agreed on after the last step
+    step_events = {}                            # (spp pair) -> HIP events around this rank's last step
     pending = [None, None]                      # work handles of the all-reduces in flight, per gradient buffer
 
     def make_step(spp_p, spp_g, prim_ms, grad_ms):
@@ -562,13 +583,20 @@ def main():
                     if key not in trackers:
                         trackers[key] = parallel.CostTracker(args.views, args.img + 4, world, device=dev)
                     part = trackers[key].partition()
+                t0, t1 = ev(), ev()
+                t0.record()
                 _, work = parallel.render_step(ops, args.views, args.img, args.img, rank, world,
                                                lambda im, views: torch.sign(im - tgt[views]) * scale, grad, extra_grads=extra,
                                                gather_images=False, async_reduce=True, force_reduce=dist is not None, partition=part)
+                t1.record()
                 pending[b] = work
                 if part is not None:
-                    # what this step's proofs say about the work per row -> the next step's partition (one small collective)
-                    trackers[key].update(*ops.row_costs())
+                    # what this step's proofs say about the work per row, and how long the PREVIOUS step took on this rank (its events
+                    # have completed; this step's have not) -> the next step's partition.  One small collective.
+                    prev = step_events.get(key)
+                    ms = prev[0].elapsed_time(prev[1]) if prev is not None and prev[1].query() else 0.0
+                    step_events[key] = (t0, t1)
+                    trackers[key].update(*ops.row_costs(), rank=rank, step_ms=ms)
                 return
             if nv:
                 seeds = [(it * args.views + i) * 2 for i in mine]

@@ -225,40 +225,73 @@ def render_step(ops, n_views, W, H, rank, world, loss_grad, grad_grid, group=Non
 
 class CostTracker:
     """Row costs of all views as the ranks measure them, one step behind: after a step every rank writes the rows it has proofs
-    for (ops.row_costs(views)), one all-reduce of the (n_views, rows) matrix and of its hit counts (25 KB at 12 x 516) gives every
-    rank the same matrix, and partition() is cost_partition() of it -- the uniform deal until the first measurement."""
+    for (ops.row_costs()) and how long its step took, ONE all-reduce (25 KB at 12 x 516) gives every rank the same matrix and the
+    same vector of rank times, and partition() is cost_partition() of it -- the uniform deal until the first measurement.
 
-    def __init__(self, n_views, rows, world, device=None):
+    TIME FEEDBACK.  The proxy of row_costs() counts traced and proven chunks; what a rank's step takes also contains the latency of
+    its longest rays (the tail kernels: ~4 ms whatever the shard, profiles/r06_scaling.md), so equal predicted cost left the emulated
+    ranks of the bench scene 1.23 x (N = 4) / 1.55 x (N = 8) apart.  Every update therefore multiplies the rows a rank rendered by
+    (its time / the mean time) ^ feedback (1.0; clipped to [0.5, 2] per step): rows in slow shards get heavier, the next cut gives that shard
+    fewer of them.  Static geometry converges in two or three steps; a moving one is followed with one step of delay."""
+
+    def __init__(self, n_views, rows, world, device=None, feedback=1.0):
         import numpy as np
         self.n_views, self.rows, self.world = n_views, rows, world
         self.device = device                        # where the collective's buffer lives (RCCL reduces device tensors)
+        self.feedback = feedback
         self.cost = None
+        self.corr = np.ones((n_views, rows))
+        self.times = None
+        self._last = None                           # the partition the last step was rendered with
         self._np = np
 
     def partition(self):
-        return work_partition(self.n_views, self.rows, self.world) if self.cost is None else cost_partition(self.cost, self.world)
+        if self.cost is None:
+            self._last = work_partition(self.n_views, self.rows, self.world)
+        else:
+            self._last = cost_partition(self.cost * self.corr, self.world)
+        return self._last
 
-    def update(self, views, costs, group=None):
-        """views: the views this rank has row costs for; costs: (len(views), rows) tensor.  Collective (every rank calls it)."""
+    def update(self, views, costs, rank=0, step_ms=None, group=None):
+        """views: the views this rank has row costs for; costs: (len(views), rows) tensor; step_ms: how long this rank's last step
+        took (None / 0: no time feedback).  Collective (every rank calls it)."""
         import torch
         import torch.distributed as dist
+        np = self._np
         dev = self.device if self.device is not None else (costs.device if hasattr(costs, 'device') else 'cpu')
-        m = torch.zeros(2, self.n_views, self.rows, dtype=torch.float64, device=dev)
+        m = torch.zeros(2 * self.n_views * self.rows + self.world, dtype=torch.float64, device=dev)
+        planes = m[:2 * self.n_views * self.rows].view(2, self.n_views, self.rows)
         if len(views) and costs is not None:
-            m[0, list(views)] = torch.as_tensor(costs, dtype=torch.float64, device=dev)
-            m[1, list(views)] = 1.0
+            planes[0, list(views)] = torch.as_tensor(costs, dtype=torch.float64, device=dev)
+            planes[1, list(views)] = 1.0
+        if step_ms:
+            m[2 * self.n_views * self.rows + rank] = float(step_ms)
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
             dist.all_reduce(m, op=dist.ReduceOp.SUM, group=group)
         m = m.cpu().numpy()
-        seen = m[1] > 0
-        new = self._np.where(seen, m[0] / self._np.maximum(m[1], 1.0), 0.0)
+        pl = m[:2 * self.n_views * self.rows].reshape(2, self.n_views, self.rows)
+        seen = pl[1] > 0
+        new = np.where(seen, pl[0] / np.maximum(pl[1], 1.0), 0.0)
         if self.cost is None:
-            # views nobody measured yet (cannot happen with a full partition) get the mean row cost
             fill = new[seen].mean() if seen.any() else 1.0
-            self.cost = self._np.where(seen, new, fill)
+            self.cost = np.where(seen, new, fill)
         else:
-            self.cost = self._np.where(seen, new, self.cost)
+            self.cost = np.where(seen, new, self.cost)
+        self.apply_times(m[2 * self.n_views * self.rows:])
         return self.cost
+
+    def apply_times(self, times):
+        """The feedback step on its own (the single-GPU emulation of bench.py feeds it the emulated ranks' times)."""
+        np = self._np
+        t = np.asarray(times, np.float64)
+        self.times = t
+        if self.feedback and self._last is not None and len(t) == self.world and (t > 0).all():
+            mean = t.mean()
+            for r, units in enumerate(self._last):
+                f = float(np.clip((t[r] / mean) ** self.feedback, 0.5, 2.0))
+                for v, r0, r1 in units:
+                    self.corr[v, r0:r1] *= f
+            self.corr /= self.corr.mean()
 
 
 def _wants_views(loss_grad):
