@@ -73,6 +73,25 @@ __global__ void k_pad_grid(const float *__restrict__ data, int rx, int ry, int r
     }
 }
 
+// The row-block copy of the padded grid (dsdf_math.h: DSDF_TLAYOUT): T[xc][z][y][0..7] = padded[z][y][4 xc .. 4 xc + 7] (x clamped to
+// the padded row: the taps beyond it are never part of a cell).  One thread per 16-byte half row.
+__global__ void k_tlayout(const float *__restrict__ padded, int sx, int sy, int sz, int nxc, float *__restrict__ out) {
+    const size_t n = (size_t)nxc * sz * sy * 2;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int h = (int)(i & 1);
+        size_t r = i >> 1;
+        const int y = (int)(r % sy); r /= sy;
+        const int z = (int)(r % sz);
+        const int xc = (int)(r / sz);
+        const float *row = padded + ((size_t)z * sy + y) * sx;
+        const int x0 = 4 * xc + 4 * h;
+        float4 t;
+        t.x = row[x0 < sx ? x0 : sx - 1]; t.y = row[x0 + 1 < sx ? x0 + 1 : sx - 1];
+        t.z = row[x0 + 2 < sx ? x0 + 2 : sx - 1]; t.w = row[x0 + 3 < sx ? x0 + 3 : sx - 1];
+        reinterpret_cast<float4 *>(out)[i] = t;
+    }
+}
+
 __global__ void k_eval_cubic(GridView G, const float *__restrict__ pts, int64_t n, int order,
                              float *__restrict__ v, float *__restrict__ g, float *__restrict__ H) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1047,7 +1066,11 @@ void dsdf_default_params(dsdf_params *p) {
 size_t dsdf_padded_size(int rx, int ry, int rz) {
     size_t n = padded_floats(rx, ry, rz);
     for (int l = 0; l < DSDF_COARSE_LEVELS; ++l) n += 2 * coarse_cells(rx, ry, rz, l);
-    return n + 2 * hit_cells(rx, ry, rz) + 2 * (size_t)rx * ry * rz;      // (+ fine window maxima and their scratch)
+    n += 2 * hit_cells(rx, ry, rz) + 2 * (size_t)rx * ry * rz;            // (+ fine window maxima and their scratch)
+#if DSDF_TLAYOUT
+    n = tlayout_offset(rx, ry, rz) + tlayout_floats(rx, ry, rz);          // (+ the row-block copy the device lookups read)
+#endif
+    return n;
 }
 
 int dsdf_pad_grid(const float *data, int rx, int ry, int rz, float *padded, void *stream) {
@@ -1057,6 +1080,18 @@ int dsdf_pad_grid(const float *data, int rx, int ry, int rz, float *padded, void
     hipLaunchKernelGGL(k_pad_grid, dim3(grid), dim3(256), 0, (hipStream_t)stream, data, rx, ry, rz, padded);
     int rc = check_launch("k_pad_grid");
     if (rc) return rc;
+#if DSDF_TLAYOUT
+    {
+        if ((uint64_t)32 * (ry + 2 * DSDF_APRON) * (rz + 2 * DSDF_APRON) >= (1u << 24) || tlayout_floats(rx, ry, rz) * 4 >= ((uint64_t)1 << 32))
+            return fail(DSDF_ERR_INVALID_ARG, "dsdf_pad_grid: grid too large for the row-block copy (24-bit stride, 32-bit offsets: about 717^3)");
+        const int sx = rx + 2 * DSDF_APRON, sy = ry + 2 * DSDF_APRON, sz = rz + 2 * DSDF_APRON, nxc = (int)tlayout_chunks(rx);
+        const size_t nt = (size_t)nxc * sz * sy * 2;
+        const int tg = (int)((nt + 255) / 256 < 16384 ? (nt + 255) / 256 : 16384);
+        hipLaunchKernelGGL(k_tlayout, dim3(tg), dim3(256), 0, (hipStream_t)stream, (const float *)padded, sx, sy, sz, nxc,
+                           padded + tlayout_offset(rx, ry, rz));
+        if ((rc = check_launch("k_tlayout"))) return rc;
+    }
+#endif
     // conservative min-grids for the empty-space proof, max-grid for the hit proof
     float *c0 = padded + n;
     for (int l = 0; l < DSDF_COARSE_LEVELS; ++l) {
@@ -1094,7 +1129,7 @@ int dsdf_eval_cubic(const float *padded, int rx, int ry, int rz, const dsdf_para
     if (n == 0) return DSDF_OK;                     // empty input: nothing to do (pointers may be null)
     if (!padded || !prm || !points || n < 0 || order < 0 || order > 2)
         return fail(DSDF_ERR_INVALID_ARG, "dsdf_eval_cubic: bad argument");
-    GridView G = make_view(padded, rx, ry, rz, *prm);
+    GridView G = device_view(padded, rx, ry, rz, *prm);
     hipLaunchKernelGGL(k_eval_cubic, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, G, points, n,
                        order, v, g, H);
     return check_launch("k_eval_cubic");
@@ -1105,7 +1140,7 @@ int dsdf_trace(const float *padded, int rx, int ry, int rz, const dsdf_params *p
                float *warp_t_d, float *warp_weight, float *warp_weight_d, int32_t *steps, void *stream) {
     if (n == 0) return DSDF_OK;                     // empty input: nothing to do (pointers may be null)
     if (!padded || !prm || !rays_o || !rays_d || !maxt || n < 0) return fail(DSDF_ERR_INVALID_ARG, "dsdf_trace: bad argument");
-    GridView G = make_view(padded, rx, ry, rz, *prm);
+    GridView G = device_view(padded, rx, ry, rz, *prm);
     hipLaunchKernelGGL(k_trace, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, G, *prm, rays_o,
                        rays_d, maxt, n, differentiable, its_t, warp_t, warp_t_d, warp_weight, warp_weight_d, steps);
     return check_launch("k_trace");
@@ -1117,7 +1152,7 @@ int dsdf_warp_eval(const float *padded, int rx, int ry, int rz, const dsdf_param
     if (n == 0) return DSDF_OK;
     if (!padded || !prm || !rays_o || !rays_d || !warp_t || !warp_t_d || !warp_weight || !warp_weight_d || n < 0)
         return fail(DSDF_ERR_INVALID_ARG, "dsdf_warp_eval: bad argument");
-    GridView G = make_view(padded, rx, ry, rz, *prm);
+    GridView G = device_view(padded, rx, ry, rz, *prm);
     hipLaunchKernelGGL(k_warp_eval, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, G, *prm, rays_o, rays_d,
                        warp_t, warp_t_d, warp_weight, warp_weight_d, n, active, cdir, a, b, div);
     return check_launch("k_warp_eval");
@@ -1128,7 +1163,7 @@ int dsdf_surface_interaction(const float *padded, int rx, int ry, int rz, const 
                              float *t_coef, void *stream) {
     if (n == 0) return DSDF_OK;
     if (!padded || !prm || !rays_o || !rays_d || !t || n < 0) return fail(DSDF_ERR_INVALID_ARG, "dsdf_surface_interaction: bad argument");
-    GridView G = make_view(padded, rx, ry, rz, *prm);
+    GridView G = device_view(padded, rx, ry, rz, *prm);
     hipLaunchKernelGGL(k_surface_interaction, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, G, rays_o,
                        rays_d, t, n, p, normal, grad, t_coef);
     return check_launch("k_surface_interaction");
@@ -1478,12 +1513,18 @@ static int run_pass(PassCtx &c, const Workspace &ws, const dsdf_camera *cams, in
                 c.coef_done_early = true;
             }
             bool coef_beside = false;
+            hipEvent_t coef_fork = nullptr;
             hipStream_t chs[2] = {st, st};
             if (DIFF && handoff && c.coef_beside && ngroups == 1 && ws.count0 && helper_streams(st, chs)) {
                 // the queue lengths as the render kernel leaves them: the tail kernel appends behind them from now on
                 if (hipMemcpyAsync(ws.count0, ws.count, (size_t)nv * ws.nunits * sizeof(uint32_t), hipMemcpyDeviceToDevice, st) != hipSuccess)
                     return fail(DSDF_ERR_LAUNCH, "hipMemcpyAsync(queue lengths) failed");
                 coef_beside = true;
+                //  the fork event of the coefficient stream is recorded HERE -- behind the render kernel and the snapshot, in
+                // front of the tail kernel, which with one view group runs on this same stream: recorded after its launch the
+                // coefficients waited for the whole tail kernel and ran after it, not beside it
+                coef_fork = next_event();
+                if (!coef_fork || hipEventRecord(coef_fork, st) != hipSuccess) return fail(DSDF_ERR_LAUNCH, "coefficient stream fork failed");
             }
             if (handoff) {
                 hipStream_t ts = st;
@@ -1507,9 +1548,7 @@ static int run_pass(PassCtx &c, const Workspace &ws, const dsdf_camera *cams, in
                     // ... and the coefficients of the samples the render kernel queued itself on the OTHER helper stream, beside the tail
                     // kernel (it waits for the render kernel and the copy above)
                     hipStream_t cs = chs[1];
-                    hipEvent_t e = next_event();
-                    if (!e || hipEventRecord(e, st) != hipSuccess || hipStreamWaitEvent(cs, e, 0) != hipSuccess)
-                        return fail(DSDF_ERR_LAUNCH, "coefficient stream fork failed");
+                    if (hipStreamWaitEvent(cs, coef_fork, 0) != hipSuccess) return fail(DSDF_ERR_LAUNCH, "coefficient stream fork failed");
                     const dim3 cgrid((ws.nunits + DSDF_BWD_UNITS - 1) / DSDF_BWD_UNITS, nv);
                     hipLaunchKernelGGL(k_backward_coef, cgrid, dim3(64), 0, cs, G, c.pp, VB, q, (const uint32_t *)nullptr, (uint32_t *)nullptr, (const uint32_t *)ws.count0);
                     if ((rc = check_launch("k_backward_coef"))) return rc;

@@ -220,8 +220,7 @@ DSDF_HD bool lane_forward_tangent(const GridView &G, const float *tangent, V3 dp
                                   const Lane &L, const TraceOut &tr, SampleTangent &out) {
     const V3 o = L.ray.o, d = L.ray.d;
     const bool hit = tr.its_t < INFINITY;
-    GridView T = G;
-    T.p = tangent;
+    const GridView T = view_of(G, tangent);
     Reproj rp = reproject(A.cam, P, o + d, A.W, A.H);
     out.u = rp.u; out.v = rp.v;
     out.val = 0.f; out.d_val = 0.f; out.d_w = 0.f; out.d_u = 0.f; out.d_v = 0.f;
@@ -973,8 +972,7 @@ DSDF_HD bool lane_forward_tangent_direct(const GridView &G, const float *tangent
                                          const TraceOut &trb, SampleTangentRgb &out) {
     const V3 o = L.ray.o, d = L.ray.d;
     const bool hit = tr.its_t < INFINITY;
-    GridView T = G;
-    T.p = tangent;
+    const GridView T = view_of(G, tangent);
     const bool has_t = tangent != nullptr;
     Reproj rp = reproject(A.cam, P, o + d, A.W, A.H);
     out.u = rp.u; out.v = rp.v;

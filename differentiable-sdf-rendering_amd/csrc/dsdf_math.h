@@ -80,6 +80,20 @@ DSDF_HD V3 symmul(const float H[6], V3 a) {
 #define DSDF_APRON 3
 #define DSDF_COARSE_LEVELS 2   /* conservative min-grids over blocks of 8^3 (level 0) and 4^3 (level 1) voxels */
 #define DSDF_COARSE_SHIFT(level) (3 - (level))
+// Round 6: the ROW-BLOCK copy of the padded grid that the device lookups read (DSDF_TLAYOUT, on by default).  In the linear copy a
+// 128-byte line holds 32 x-consecutive taps of ONE (y, z) row, so the 16 rows (4 y x 4 z, four x-consecutive taps each) of a B-spline
+// cell sit in 16 different lines and a cell fill is 16 L2 requests for 16 useful bytes each -- the primal march made 2.8 G of them
+// per launch, 0.75 per clock and L2 channel: the request rate of the L2, not its capacity or HBM, bounded the fills.
+// The row-block copy T[xc][z][y][8] stores for every (z, y) and every x chunk xc (stride FOUR taps) the EIGHT taps 4 xc .. 4 xc + 7:
+// the four taps bx .. bx + 3 of any row lie inside chunk bx >> 2 (16 bytes at 4-byte alignment inside a 32-byte row, one load as
+// before), four y-consecutive rows share a line, and a cell's 16 rows sit in 4 (z) x 1-2 lines = 7 on average.  Twice the bytes of
+// the linear copy (every tap twice).  Row (k, j) of the cell at byte offset `base` is at base + k * tz4 + j * 32: the same
+// "base + uniform offsets" form as the linear copy, so every row provider (per-lane gathers, the register-resident cell, the wave
+// cell cache, the 16-lane evaluator) is unchanged but for its two strides; only the cell address costs 4 more instructions.
+// The host build (tests/harness) and -DDSDF_TLAYOUT=0 read the linear copy.
+#ifndef DSDF_TLAYOUT
+#define DSDF_TLAYOUT 1
+#endif
 struct GridView {
     const float *p;
     int rx, ry, rz;
@@ -87,7 +101,15 @@ struct GridView {
     float frx, fry, frz;   // the resolution as floats (kernel arguments: they stay in SGPRs; converting in the kernel made
                            // them VGPR values that were spilled and re-loaded inside the march loop)
     float tx, ty, tz;   // sdf.p translation
+    const float *pt;    // row-block copy (nullptr: none -- the per-ray host paths)
+    uint32_t tz4, tx4;  // its strides in bytes: one z step (32 * (ry + 6)), one x chunk (tz4 * (rz + 6))
 };
+
+// x chunks of the row-block copy: chunk (rx + 2) >> 2 is the last one a cell can start in
+DSDF_HD size_t tlayout_chunks(int rx) { return (size_t)((rx + 2) >> 2) + 1; }
+DSDF_HD size_t tlayout_floats(int rx, int ry, int rz) {
+    return tlayout_chunks(rx) * (size_t)(rz + 2 * DSDF_APRON) * (size_t)(ry + 2 * DSDF_APRON) * 8;
+}
 
 DSDF_HD GridView make_view(const float *padded, int rx, int ry, int rz, const dsdf_params &prm) {
     GridView g;
@@ -95,7 +117,16 @@ DSDF_HD GridView make_view(const float *padded, int rx, int ry, int rz, const ds
     g.sx = rx + 2 * DSDF_APRON; g.sxy = g.sx * (ry + 2 * DSDF_APRON);
     g.frx = (float)rx; g.fry = (float)ry; g.frz = (float)rz;
     g.tx = prm.sdf_p[0]; g.ty = prm.sdf_p[1]; g.tz = prm.sdf_p[2];
+    g.pt = nullptr;
+    g.tz4 = 32u * (uint32_t)(ry + 2 * DSDF_APRON); g.tx4 = g.tz4 * (uint32_t)(rz + 2 * DSDF_APRON);
     return g;
+}
+// The view of ANOTHER grid of the same shape in the same buffer layout (the tangent grid of forward mode)
+DSDF_HD GridView view_of(const GridView &G, const float *other) {
+    GridView T = G;
+    T.p = other;
+    T.pt = (G.pt && other) ? other + (G.pt - G.p) : nullptr;
+    return T;
 }
 
 // Uniform cubic B-spline basis (taps i-1..i+2) and derivatives; Dr.Jit texture.h.
@@ -255,12 +286,27 @@ DSDF_HD CubicCell cubic_cell(const GridView &G, V3 x) {
     asm("v_med3_i32 %0, %1, -2, %2" : "=v"(qx) : "v"(qx), "s"(G.rx));
     asm("v_med3_i32 %0, %1, -2, %2" : "=v"(qy) : "v"(qy), "s"(G.ry));
     asm("v_med3_i32 %0, %1, -2, %2" : "=v"(qz) : "v"(qz), "s"(G.rz));
+#if DSDF_TLAYOUT
+    // row-block copy: base = (bx >> 2) * tx4 + bz * tz4 + by * 32 + (bx & 3) * 4 with b = q + 2 (the "+ 2" of y and z: one uniform constant)
+    int bx, xo, lin;
+    asm("v_add_u32 %0, 2, %1" : "=v"(bx) : "v"(qx));
+    asm("v_lshlrev_b32 %0, 2, %1" : "=v"(xo) : "v"(bx));
+    asm("v_and_b32 %0, 12, %1" : "=v"(xo) : "v"(xo));
+    asm("v_lshrrev_b32 %0, 2, %1" : "=v"(bx) : "v"(bx));
+    asm("v_lshl_add_u32 %0, %1, 5, %2" : "=v"(lin) : "v"(qy), "v"(xo));
+    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(lin) : "v"(qz), "s"(G.tz4), "v"(lin));
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(lin) : "v"(bx), "s"(G.tx4), "v"(lin));
+    const int c4 = 2 * (int)G.tz4 + 64;
+    asm("v_add_u32 %0, %1, %2" : "=v"(cc.base) : "s"(c4), "v"(lin));
+    return cc;
+#else
     int lin;
     asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(lin) : "v"(qy), "s"(G.sx), "v"(qx));
     asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(lin) : "v"(qz), "s"(G.sxy), "v"(lin));
     const int c4 = 8 * (G.sxy + G.sx + 1);
     asm("v_lshl_add_u32 %0, %1, 2, %2" : "=v"(cc.base) : "v"(lin), "s"(c4));
     return cc;
+#endif
 #else
     CubicSetup s = cubic_setup(G, x);
     int bx = iclamp(s.ix, -DSDF_APRON, G.rx - 1) + DSDF_APRON;
@@ -292,7 +338,12 @@ struct GlobalRows {
     }
 };
 DSDF_HD GlobalRows global_rows(const GridView &G, const CubicCell &c) {
-    GlobalRows r; r.p = G.p; r.base = c.base; r.sx4 = 4u * (uint32_t)G.sx; r.sxy4 = 4u * (uint32_t)G.sxy;
+    GlobalRows r;
+#if defined(__HIP_DEVICE_COMPILE__) && DSDF_TLAYOUT
+    r.p = G.pt; r.base = c.base; r.sx4 = 32u; r.sxy4 = G.tz4;      // (row-block copy: y rows 32 bytes apart, z rows tz4)
+#else
+    r.p = G.p; r.base = c.base; r.sx4 = 4u * (uint32_t)G.sx; r.sxy4 = 4u * (uint32_t)G.sxy;
+#endif
     return r;
 }
 

@@ -181,8 +181,14 @@ static size_t padded_floats(int rx, int ry, int rz) {
 }
 
 // The library's grid buffer: [padded grid | per level: block minima, dilated block minima | block maxima, dilated block maxima]
+//                             [.. | fine window maxima, scratch | row-block copy of the padded grid (dsdf_math.h: DSDF_TLAYOUT)]
+static size_t tlayout_offset(int rx, int ry, int rz);
 static GridView device_view(const float *padded, int rx, int ry, int rz, const dsdf_params &prm) {
-    return make_view(padded, rx, ry, rz, prm);
+    GridView G = make_view(padded, rx, ry, rz, prm);
+#if DSDF_TLAYOUT
+    G.pt = padded + tlayout_offset(rx, ry, rz);
+#endif
+    return G;
 }
 static BoundGrid min_bounds(const float *padded, int rx, int ry, int rz, int level) {
     const float *c = padded + padded_floats(rx, ry, rz);
@@ -209,6 +215,13 @@ static float *fine_buffer(const float *padded, int rx, int ry, int rz) {
     const float *c = padded + padded_floats(rx, ry, rz);
     for (int l = 0; l < DSDF_COARSE_LEVELS; ++l) c += 2 * coarse_cells(rx, ry, rz, l);
     return const_cast<float *>(c) + 2 * hit_cells(rx, ry, rz);
+}
+static size_t tlayout_offset(int rx, int ry, int rz) {
+    // (16-byte aligned like the padded grid itself: the rows are read with 4-byte-aligned 16-byte loads, the copy kernel writes float4)
+    size_t n = padded_floats(rx, ry, rz);
+    for (int l = 0; l < DSDF_COARSE_LEVELS; ++l) n += 2 * coarse_cells(rx, ry, rz, l);
+    n += 2 * hit_cells(rx, ry, rz) + 2 * (size_t)rx * ry * rz;
+    return (n + 3) & ~(size_t)3;
 }
 static BoundGrid fine_bounds(const float *padded, int rx, int ry, int rz) {
     BoundGrid B;

@@ -247,9 +247,15 @@ struct WaveCellCache {
             int lf;
             asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lf));
             const int grp = lf >> 4, r = lf & 15;
+#if DSDF_TLAYOUT
+            const uint32_t rowoff = __umul24((uint32_t)(r >> 2), G.tz4) + 32u * (uint32_t)(r & 3);      // (row-block copy, dsdf_math.h)
+            typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+            const char *gp = reinterpret_cast<const char *>(G.pt);
+#else
             const uint32_t rowoff = 4u * (__umul24((uint32_t)(r >> 2), (uint32_t)G.sxy) + __umul24((uint32_t)(r & 3), (uint32_t)G.sx));
             typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
             const char *gp = reinterpret_cast<const char *>(G.p);
+#endif
             float *dst = taps + __umul24((uint32_t)grp, DSDF_SLOT_STRIDE) + r * 4;
             {   // slots 0..7 (87 % of the fills need no more): both loads issued back to back, ONE wait
                 const bool ha = grp < n, hb = grp + 4 < n;

@@ -909,6 +909,8 @@ class _RenderOp(torch.autograd.Function):
             ctx.gr = sh.grad_roughness = torch.zeros_like(sh.roughness.detach(), dtype=torch.float32).contiguous()
         ctx.gp = torch.zeros(3, dtype=torch.float32, device=grid.device) if (p is not None and ctx.needs_input_grad[9]) else None
         ctx.grid = grid
+        ctx.version = grid.version                           # the grid state this render saw: backward() refuses any other
+        ctx.n_backward = 0
         if not eager_sweep_enabled():
             ctx.step = None
             ctx.lazy = (list(sensors), int(spp_grad), [seed_grad + i for i in range(n)], integrator, reparam, sh, grid.version)
@@ -919,11 +921,20 @@ class _RenderOp(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, grad_out):
+        #  every path -- the lazy one, the eager step_finish and its re-trace for a second backward, which would
+        # otherwise stamp the sweep with the CURRENT grid version -- differentiates the grid state the forward pass rendered
+        if ctx.version != ctx.grid.version:
+            raise _lib.DsdfError("the grid was updated between this render and its backward: back-propagate before the optimiser step")
+        # the kernels ACCUMULATE into gp / ga / gr (atomics): a second backward (retain_graph=True) starts from zero again, and what
+        # a backward returns are copies -- the accumulators of this op are never handed out
+        if ctx.n_backward > 0:
+            for t in (ctx.gp, ctx.ga, ctx.gr):
+                if t is not None:
+                    t.zero_()
+        ctx.n_backward += 1
         g = torch.zeros(ctx.grid.shape, dtype=torch.float32, device=ctx.grid.device)
         if ctx.step is None:
             sensors, spp_grad, seeds_grad, integrator, reparam, sh, ver = ctx.lazy
-            if ver != ctx.grid.version:
-                raise _lib.DsdfError("the grid was updated between this render and its backward: back-propagate before the optimiser step")
             render_backward(ctx.grid, sensors, spp_grad, grad_out.contiguous(), grad_grid=g, seeds=seeds_grad, integrator=integrator,
                             reparam=reparam, grad_p=ctx.gp, shading=sh, grad_albedo=ctx.ga)
         else:
@@ -931,10 +942,10 @@ class _RenderOp(torch.autograd.Function):
         gp = ctx.gp
         if gp is not None:
             shape, dtype, dev = ctx.p_meta
-            gp = gp.to(device=dev, dtype=dtype).reshape(shape)
+            gp = gp.to(device=dev, dtype=dtype).reshape(shape).clone()
         return (g.reshape(ctx.data_shape) if ctx.needs_input_grad[0] else None, None, None, None, None, None, None,
-                None, None, gp, ctx.ga if ctx.needs_input_grad[10] else None, None,
-                None if ctx.gr is None else ctx.gr)
+                None, None, gp, ctx.ga.clone() if (ctx.ga is not None and ctx.needs_input_grad[10]) else None, None,
+                None if ctx.gr is None else ctx.gr.clone())
 
 
 def render(data, grid, sensors, spp, seed=0, spp_grad=None, seed_grad=0, integrator=DSDF_SILHOUETTE, reparam=True,

@@ -203,7 +203,10 @@ size_t dsdf_forward_workspace_size(int width, int height, int spp, int n_views, 
  *               wave_steps = lock-step loop iterations of the render kernel summed over its 64-lane waves (trace +
  *               refinement), the unit of the VALU-issue roofline; steps / wave_steps count the render kernel only, the
  *               tail_* slots what the tail kernels added for the rays handed over to them (tail_rays of them); slots 11..15 of
- *               rows 0..3 carry the tail waves' diagnostics listed at dsdf_tail_stats_arm (not sums over the 64 copies)
+ *               rows 0..3 carry the tail waves' diagnostics listed at dsdf_tail_stats_arm.  Those five slots are RESERVED: they hold
+ *               maxima, complemented minima and clock ticks of ONE launch, not additive counters -- sum slots 0..10 over the 64 rows,
+ *               never slots 11..15, and zero the buffer per call if the diagnostics are read (several tail launches into one buffer --
+ *               view groups, a primal and a gradient call -- mix their maxima / minima)
  * Tail kernels run on library-owned helper streams (forked from and joined back into `stream` inside the call).
  */
 int dsdf_render_forward(const float *padded, int rx, int ry, int rz, const dsdf_params *prm,
@@ -336,6 +339,10 @@ int dsdf_redistance_status(const void *workspace, int rx, int ry, int rz, int32_
  * The transform is state of the library instance (one per device): it applies to every later call until it is set again.  Setting the
  * value it already holds costs nothing; a CHANGE first waits for the device (hipDeviceSynchronize) and is written synchronously, so
  * calls enqueued earlier -- on any stream, from any thread -- keep the transform they were enqueued with.  `stream` is unused.
+ * NOT thread-safe across DIFFERENTLY transformed grids: the lock covers the set call only, so a thread that sets another transform
+ * between this thread's set and its render call changes what that render (and its host-side proofs) sees.  Callers that drive
+ * several transformed grids from several threads serialise set + render themselves (python/dsdf: SdfGrid.lib() is called under the
+ * GIL right before every library call of a transformed grid, single-threaded use is safe).
  * dsdf_has_grid_transform(): 1 in the world-space build, 0 in the default one, whose dsdf_set_grid_transform returns an error. */
 int dsdf_has_grid_transform(void);
 int dsdf_set_grid_transform(const float *to_local, const float *aabb_lo, const float *aabb_hi, void *stream);

@@ -36,8 +36,11 @@ def test_default_params_and_sizes(built):
     assert C.sizeof(dsdf.DsdfParams) == 76 and p.normalize_warp_field == 1 and p.max_reparam_depth == -1 and abs(p.light_dir[0] - 3 ** -0.5) < 1e-7 and C.sizeof(dsdf.DsdfCamera) == 64
     # padded copy + coarse min-grids (8^3 and 4^3 blocks) + the hit proof's max-grid (2^3 blocks), each raw and dilated,
     # + the fine window maxima of the hit proof at full resolution and their scratch
-    assert lib.dsdf_padded_size(256, 256, 256) == 262 ** 3 + 2 * 32 ** 3 + 2 * 64 ** 3 + 2 * 128 ** 3 + 2 * 256 ** 3
-    assert lib.dsdf_padded_size(4, 5, 6) == 10 * 11 * 12 + 2 + 2 * (1 * 2 * 2) + 2 * (2 * 3 * 3) + 2 * (4 * 5 * 6)
+    # + (round 6) the row-block copy the device lookups read (csrc/dsdf_math.h: DSDF_TLAYOUT): (rx + 2) // 4 + 1 x chunks of 8 taps for
+    # every (z, y) row of the padded grid, behind the rest rounded up to 4 floats
+    up4 = lambda n: (n + 3) // 4 * 4
+    assert lib.dsdf_padded_size(256, 256, 256) == up4(262 ** 3 + 2 * 32 ** 3 + 2 * 64 ** 3 + 2 * 128 ** 3 + 2 * 256 ** 3) + 65 * 262 * 262 * 8
+    assert lib.dsdf_padded_size(4, 5, 6) == up4(10 * 11 * 12 + 2 + 2 * (1 * 2 * 2) + 2 * (2 * 3 * 3) + 2 * (4 * 5 * 6)) + 2 * 12 * 11 * 8
     ws = lib.dsdf_render_workspace_size(512, 512, 64, 1, 0)
     assert ws >= 516 * 516 * 64 * 40 and lib.dsdf_render_workspace_size(0, 4, 4, 1, 0) == 0
     assert lib.dsdf_render_workspace_size(512, 512, 64, 4, 0) >= 4 * 516 * 516 * 64 * 40

@@ -649,6 +649,19 @@ def test_autograd_render_op_edge_cases(dsdf, monkeypatch):
     (g1,) = torch.autograd.grad((img * w).sum(), data, retain_graph=True)
     (g2,) = torch.autograd.grad((img * w).sum(), data)                 # second backward: re-traced into a private workspace
     assert g1.abs().sum() > 0 and rel_l2(g2.cpu(), g1.cpu()) < 1e-5
+    # ... and the op's OTHER accumulators: dL/dp and dL/d(albedo) of a second backward start from zero again -- they are
+    # not first + second -- and what the first backward returned is not written to by the second
+    pt = torch.zeros(3, device='cuda', requires_grad=True)
+    alb = (torch.rand(4, 4, 4, 3, device='cuda') * 0.6 + 0.2).requires_grad_(True)
+    sh = dsdf.Shading(alb, 1.5, hide_emitters=True)
+    imd = dsdf.render(data, grid, [sen], spp=64, seed=3, spp_grad=64, seed_grad=11, p=pt, integrator='sdf_direct_reparam', shading=sh)
+    wd = torch.rand_like(imd)
+    gd1, gp1, ga1 = torch.autograd.grad((imd * wd).sum(), (data, pt, alb), retain_graph=True)
+    kp, ka = gp1.clone(), ga1.clone()
+    gd2, gp2, ga2 = torch.autograd.grad((imd * wd).sum(), (data, pt, alb))
+    assert torch.equal(gp1, kp) and torch.equal(ga1, ka)                              # the first results are untouched
+    assert gp1.abs().sum() > 0 and ga1.abs().sum() > 0
+    assert rel_l2(gp2.cpu(), gp1.cpu()) < 1e-4 and rel_l2(ga2.cpu(), ga1.cpu()) < 1e-5 and rel_l2(gd2.cpu(), gd1.cpu()) < 1e-5
     # two renders before one backward
     ia = dsdf.render(data, grid, [sen], spp=64, seed=3, spp_grad=64, seed_grad=11)
     ib = dsdf.render(data, grid, [sen], spp=64, seed=4, spp_grad=64, seed_grad=12)

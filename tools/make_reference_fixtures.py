@@ -389,6 +389,11 @@ def main():
                         out[f'{key}_galb_{tag}'] = np.array(dr.grad(params[tkeys[2]])).reshape(c['albedo'].shape).astype(ft)
 
         fn = os.path.join(args.out, f'{prefix}_{name}.npz')
+        if name == 'c2_spp4':
+            # (the 128^3 grid is 7.4 MB of the file and comes from a seeded recipe: stored by name + hash, rebuilt by the tests)
+            import hashlib
+            out['grid_sha256'] = np.bytes_(hashlib.sha256(np.ascontiguousarray(out.pop('grid')).tobytes()).hexdigest())
+            out['grid_recipe'] = np.bytes_('bench.synth_grid(128)')
         np.savez_compressed(fn, **out)
         print(fn, {k: (getattr(v, 'shape', None) or v) for k, v in out.items()})
 
