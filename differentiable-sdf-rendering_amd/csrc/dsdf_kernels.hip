@@ -718,6 +718,8 @@ __global__ __launch_bounds__(64, DIRECT ? DSDF_BWD_DIRECT_MINWAVES : DSDF_BWD_MI
         const uint32_t si = s0 + threadIdx.x;
         ScatterReq req[4];
         req[0].on = false; req[1].on = false; req[2].on = false; req[3].on = false;
+        AlbedoReq areq;
+        areq.on = false;
         if (si < count) {
             const uint32_t lane = q.lane[ug.slot(si)];
             TraceOut tr;
@@ -727,14 +729,15 @@ __global__ __launch_bounds__(64, DIRECT ? DSDF_BWD_DIRECT_MINWAVES : DSDF_BWD_MI
                 TraceOut trs, trb;
                 load_record(q.rec + lane + 9 * (size_t)q.cap, q.cap, trs);
                 if (S.use_mis) load_record(q.rec + lane + 18 * (size_t)q.cap, q.cap, trb); else clear_trace_out(trb, 0.f);
-                AlbedoReq areq;
                 n_did += lane_backward_direct(G, P, A, S, L, lane, tr, trs, trb, block_adj, req, areq) ? 1 : 0;
-                // the albedo volume is small and its adjoint 24 floats per lit sample: plain atomics
-                if (areq.on && S.grad_albedo) scatter_trilinear(S.albedo, S.grad_albedo, areq.x, areq.a_bar, AtomicAdd());
-                if (areq.on && S.grad_rough && areq.r_bar != 0.f) scatter_trilinear1(S.rough, S.grad_rough, areq.x, areq.r_bar, AtomicAdd());
             } else {
                 n_did += lane_backward(G, P, A, L, tr, block_adj, req) ? 1 : 0;
             }
+        }
+        if (DIRECT) {
+            // dL/d(albedo), dL/d(roughness): grouped by trilinear cell over the wave, one atomic per tap and distinct cell (dsdf_wave.h)
+            if (S.grad_albedo) wave_scatter_trilinear<3, DSDF_BWD_TILE_FLOATS / 64>(S.albedo, S.grad_albedo, areq.on, areq.x, areq.a_bar, tile, lid);
+            if (S.grad_rough) wave_scatter_trilinear<1, DSDF_BWD_TILE_FLOATS / 64>(S.rough, S.grad_rough, areq.on && areq.r_bar != 0.f, areq.x, &areq.r_bar, tile, lid);
         }
         DSDF_BWD_SCATTER(G, grad_grid, req[0], tile, lid);
         if (A.integrator != DSDF_SILHOUETTE) DSDF_BWD_SCATTER(G, grad_grid, req[1], tile, lid);

@@ -113,6 +113,65 @@ __device__ __forceinline__ void wave_scatter_t(const GridView &G, float *__restr
     wave_lds_sync();
 }
 
+// dL/d(albedo) of sdf_direct_reparam (and dL/d(roughness) of the principled BSDF) through the same transposed tile: a lit sample's
+// adjoint is 8 trilinear taps x 3 channels = 24 atomics, and the 64 queued samples a wave holds come from a few neighbouring pixels,
+// i.e. from a handful of albedo cells.  Plain per-sample atomics were 12.6 of the 28 ms of k_backward<true> at C5 sizes (0.84 G
+// memory-side read-modify-writes per launch; profiles/r06_ab/bwd_direct_split.jsonl).  Here lane l writes its 24 (NC = 3) or 8
+// (NC = 1) contributions as row l of the tile, the lanes are grouped by trilinear cell with the readlane / ballot loop of
+// wave_scatter_t, and lane k < 8 NC sums column k over a group: one atomic per tap, channel and DISTINCT cell.  The taps of a border
+// cell that clamp onto the same voxel stay separate atomics (same sum).  STRIDE = floats per tile row (either tile of k_backward).
+template <int NC, int STRIDE>
+__device__ __forceinline__ void wave_scatter_trilinear(const AlbedoView &A, float *__restrict__ grad_vol, bool on, V3 x, const float *a_bar,
+                                                       float *T, int lid) {
+    static_assert(8 * NC <= STRIDE && STRIDE % 4 == 0, "a lane's contributions are one row of the tile");
+    uint64_t todo = __ballot(on);
+    if (!todo) return;
+    const TrilinearCell c = trilinear_cell(A, on ? x : mk(0.f, 0.f, 0.f));
+    if (on) {
+        float v[8 * NC];
+#pragma unroll
+        for (int dz = 0; dz < 2; ++dz)
+#pragma unroll
+            for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < 2; ++dx) {
+                    const float w = (dx ? c.a[0] : 1.f - c.a[0]) * (dy ? c.a[1] : 1.f - c.a[1]) * (dz ? c.a[2] : 1.f - c.a[2]);
+#pragma unroll
+                    for (int ch = 0; ch < NC; ++ch) v[((dz * 2 + dy) * 2 + dx) * NC + ch] = w * a_bar[ch];
+                }
+        float4 *row = reinterpret_cast<float4 *>(T + lid * STRIDE);       // (16-byte stores: the rows of consecutive lanes 4 banks apart)
+#pragma unroll
+        for (int i = 0; i < 2 * NC; ++i) row[i] = make_float4(v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]);
+    }
+    wave_lds_sync();
+    // cell key: floor indices in [-1, res - 1] (res <= 2^20 for any volume this library accepts), + 1 each
+    const uint64_t key = ((uint64_t)(uint32_t)(c.i0[2] + 1) << 42) | ((uint64_t)(uint32_t)(c.i0[1] + 1) << 21) | (uint64_t)(uint32_t)(c.i0[0] + 1);
+    const uint32_t klo = (uint32_t)key, khi = (uint32_t)(key >> 32);
+    const int corner = lid / NC, ch = lid - corner * NC;                 // (lanes < 8 NC)
+    const int dx = corner & 1, dy = (corner >> 1) & 1, dz = (corner >> 2) & 1;
+    while (todo != 0) {
+        const int leader = __builtin_ctzll(todo);
+        const uint32_t llo = (uint32_t)__builtin_amdgcn_readlane((int)klo, leader), lhi = (uint32_t)__builtin_amdgcn_readlane((int)khi, leader);
+        const uint64_t grp = __ballot(on && klo == llo && khi == lhi);
+        todo &= ~grp;
+        const int gx = __builtin_amdgcn_readlane(c.i0[0], leader), gy = __builtin_amdgcn_readlane(c.i0[1], leader), gz = __builtin_amdgcn_readlane(c.i0[2], leader);
+        if (lid < 8 * NC) {
+            float sum = 0.f;
+            uint64_t m = grp;
+            while (m != 0) {                                   // wave-uniform: lanes of this cell
+                const int l = __builtin_ctzll(m);
+                m &= m - 1;
+                sum += T[l * STRIDE + lid];
+            }
+            if (sum != 0.f) {
+                const int ix = iclamp(gx + dx, 0, A.rx - 1), iy = iclamp(gy + dy, 0, A.ry - 1), iz = iclamp(gz + dz, 0, A.rz - 1);
+                atomicAdd(grad_vol + NC * (((size_t)iz * A.ry + iy) * A.rx + ix) + ch, sum);
+            }
+        }
+    }
+    wave_lds_sync();
+}
+
 // The same scatter through HALF the tile: the z taps {0, 1} and then {2, 3}, 32 contributions per lane and pass in a 64 x 36
 // tile (9 KB instead of 17 KB).  k_backward_apply is a latency-bound kernel whose occupancy was set by the tile (9 single-wave
 // blocks per CU = 2.25 waves per SIMD); at 9 KB twice as many fit.  Lane k < 32 owns tap (z = 2 * pass + k / 16, y, x) of the pass.
