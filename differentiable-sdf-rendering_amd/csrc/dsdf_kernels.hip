@@ -247,7 +247,7 @@ __device__ __forceinline__ void clear_trace(TraceOut &tr) {
     tr.steps = 0; tr.refine_steps = 0;
 }
 
-struct WaveStats { int lanes, bbox, steps, hits, refine, need, wsteps; };
+struct WaveStats { int lanes, bbox, steps, hits, refine, need, wsteps, ssteps, swsteps, srays; };
 
 __device__ __forceinline__ void add_stats(WaveStats &ws, const TraceOut &tr, bool valid, bool need) {
     ws.lanes += wave_sum_i32(valid ? 1 : 0);
@@ -271,6 +271,7 @@ __device__ __forceinline__ void flush_stats(unsigned long long *stats, const Wav
     atomicAdd(st + 4, (unsigned long long)ws.refine);
     atomicAdd(st + 6, (unsigned long long)ws.need);
     atomicAdd(st + 7, (unsigned long long)ws.wsteps);
+    if (ws.srays) { atomicAdd(st + 8, (unsigned long long)ws.ssteps); atomicAdd(st + 9, (unsigned long long)ws.swsteps); atomicAdd(st + 10, (unsigned long long)ws.srays); }
 }
 
 // wave-level compaction of the samples that need the backward sweep into their unit's slots
@@ -475,6 +476,9 @@ void k_render_items(GridView G, dsdf_params P, ViewBatch VB, float *__restrict__
             queue_unit(view_queue(qall, view), unit, lane, need, lid, tr, DIRECT ? &trs : nullptr, (DIRECT && S.use_mis) ? &trb : nullptr);
         }
         if (STATS) add_stats(wst, tr, true, need);
+        if (STATS && DIRECT) {      // sdf_direct_reparam: the shadow rays' lane steps, lock-step iterations and count (slots 8..10: no tail kernel here)
+            wst.ssteps += wave_sum_i32(trs.steps); wst.swsteps += wave_max_i32(trs.steps); wst.srays += wave_sum_i32(trs.steps > 0 ? 1 : 0);
+        }
       }
         item = (uint32_t)__builtin_amdgcn_readfirstlane((int)next);
         if (lid == 0) next = draw(share);
