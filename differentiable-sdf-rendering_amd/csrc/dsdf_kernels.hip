@@ -361,11 +361,15 @@ __global__ __launch_bounds__(256) void k_build_items(ViewBatch VB, int view0, in
 #ifndef DSDF_DIRECT_SWEEP_MINWAVES
 #define DSDF_DIRECT_SWEEP_MINWAVES 1
 #endif
-template <bool DIFF, bool DIRECT, bool STATS>
+// STORE_T (round 6, the wavefront primal of sdf_direct_reparam): the value-only march of the one-channel integrators
+// (wave cell cache, hand-off to the tail queue) whose samples are not shaded here -- the hit distance of every traced sample goes to
+// hit_t[view][lane] (a handed-off ray stores "miss" and its tail wave overwrites it), no film.
+template <bool DIFF, bool DIRECT, bool STATS, bool STORE_T = false>
 __global__ __launch_bounds__(64, DIRECT ? (DIFF ? DSDF_DIRECT_SWEEP_MINWAVES : DSDF_DIRECT_PRIMAL_MINWAVES) : (DIFF ? DSDF_DIFF_MINWAVES : DSDF_PRIMAL_MINWAVES))
 void k_render_items(GridView G, dsdf_params P, ViewBatch VB, float *__restrict__ blocks, Queue qall, unsigned long long *stats,
                     const unsigned char *__restrict__ skip, ShadeArgs S, TailQueue tq, uint32_t *__restrict__ items,
-                    const uint32_t *__restrict__ list) {
+                    const uint32_t *__restrict__ list, float *__restrict__ hit_t) {
+    static_assert(!STORE_T || (!DIFF && !DIRECT), "STORE_T is a mode of the value-only march");
     constexpr int NCH = DIRECT ? 4 : 2;
     // wave-private LDS scratch: cell cache during tracing, film transpose afterwards
     __shared__ __attribute__((aligned(16))) float wave_lds[DSDF_WAVE_LDS];
@@ -422,9 +426,21 @@ void k_render_items(GridView G, dsdf_params P, ViewBatch VB, float *__restrict__
         // proof: every sample of the silhouette integrator hits) consists of its film weights: the sampler's offsets and the 5 x 5
         // window -- no camera ray, no box test, no re-projection (film_accum_offsets, dsdf_film.h).  Half of the listed chunks of
         // the bench scene.
-        const bool proven = !DIFF && !DIRECT && (known_hit || skip_trace);
+        const bool proven = !DIFF && !DIRECT && !STORE_T && (known_hit || skip_trace);
         Lane L;
-        if (proven) {
+        if (STORE_T) {
+            // (a chunk proven empty needs no entry: the shading pass reads the same flag)
+            if (!skip_trace) {
+                L = lane_setup<true>(A, P, lane, px, py);
+                WaveCellCache F; F.taps = wave_lds; F.lid = lid;
+                if (tq.state) {
+                    PlainHandOff ho;
+                    ho.tq = tq; ho.sub = tq.per_xcd ? my_subq : item % DSDF_TAIL_SUBQ; ho.view = view; ho.lane = lane;
+                    trace_plain(G, P, L.ray.o, L.ray.d, L.ray.maxt, tr, F, ho);
+                } else trace_plain(G, P, L.ray.o, L.ray.d, L.ray.maxt, tr, F);
+                hit_t[(size_t)view * ((size_t)npix * (uint32_t)A.spp) + lane] = tr.its_t;
+            }
+        } else if (proven) {
             float r0, r1;
             sample_offsets(A, lane, r0, r1);
             film_accum_offsets(r0, r1, true, known_hit ? 1.f : 0.f, wave_lds, lid, acc);
@@ -467,7 +483,7 @@ void k_render_items(GridView G, dsdf_params P, ViewBatch VB, float *__restrict__
             film_accum_offsets(L.r0, L.r1, true, val, wave_lds, lid, reinterpret_cast<float (*)[2]>(acc));
         }
         }
-        film_flush_wave<NCH>(block, A, px, py, lid, acc);
+        if (!STORE_T) film_flush_wave<NCH>(block, A, px, py, lid, acc);
         bool need = false;
         if (DIFF) {
             const bool hit = tr.its_t < INFINITY;
@@ -484,6 +500,97 @@ void k_render_items(GridView G, dsdf_params P, ViewBatch VB, float *__restrict__
         if (lid == 0) next = draw(share);
     }
     if (STATS) flush_stats(stats, wst, blockIdx.x, lid);
+}
+
+// The two item passes of the wavefront primal of sdf_direct_reparam, over the SAME work list as the march
+// (k_render_items<false, false, *, true>; the ticket counters are zeroed in between) with the same ticket scheme:
+//   PHASE 0  lists the samples that need a shadow ray: hit (hit_t), both cosines positive (direct_setup) -> one reservation per chunk
+//            in the shadow queue (the primal tail queue's 3-word entries: view, sample, hit distance; when the worker's own sub-queue is
+//            full the next one takes them -- the capacity is the worst case over all sub-queues, a share has no a-priori bound);
+//   PHASE 1  shades: hit distance and occlusion are known (the sign of hit_t, k_shadow_stream), so a sample is its emitter term, an
+//            albedo lookup and the film window (direct_value_known; film_accum_wave / film_flush_wave as in k_render_items).
+template <int PHASE>
+__global__ __launch_bounds__(64) void k_direct_items(GridView G, dsdf_params P, ViewBatch VB, float *__restrict__ blocks,
+                                                     const unsigned char *__restrict__ skip, ShadeArgs S, TailQueue sq, uint32_t *__restrict__ items,
+                                                     const uint32_t *__restrict__ list, float *__restrict__ hit_t) {
+    constexpr int NCH = 4;
+    __shared__ __attribute__((aligned(16))) float wave_lds[DSDF_WAVE_LDS];
+    const int lid = lane_id();
+    const uint32_t npix = (uint32_t)(VB.v[0].Wb * VB.v[0].Hb);
+    const uint32_t chunks = (uint32_t)__builtin_amdgcn_readfirstlane(VB.v[0].spp >> 6);
+    // PHASE 0: an item is a 64-sample chunk as in the march; PHASE 1: an item is a listed PIXEL -- its chunks are accumulated in the
+    // wave's film window and flushed once (100 atomics per pixel instead of per chunk: without a march there is no footprint to keep small)
+    const uint32_t per_item = PHASE == 1 ? chunks : 1u;
+    const uint32_t n_items = (uint32_t)__builtin_amdgcn_readfirstlane((int)items[0]) * (chunks / per_item);
+    const uint32_t sub = (blockIdx.x >> 3) & 7u, first = gridDim.x / DSDF_TICKETS;
+    uint32_t share = blockIdx.x & 7u, hops = 0;
+    const uint32_t my_subq = tail_subq();
+    auto item_of = [&](uint32_t sh, uint32_t j) { return ((j / DSDF_ITEM_SEG) * 8u + sh) * DSDF_ITEM_SEG + j % DSDF_ITEM_SEG; };
+    auto draw = [&](uint32_t sh) { return item_of(sh, sub + 8u * (first + atomicAdd(items + 16 + 16 * (sh * 8u + sub), 1u))); };
+    uint32_t item = item_of(share, blockIdx.x >> 3), next = 0;
+    if (lid == 0) next = draw(share);
+    while (true) {
+        if (item >= n_items) {
+            if (++hops == 8u) break;
+            share = (share + 1u) & 7u;
+            if (lid == 0) next = draw(share);
+            item = (uint32_t)__builtin_amdgcn_readfirstlane((int)next);
+            if (lid == 0) next = draw(share);
+            continue;
+        }
+        {
+            const uint32_t e = (uint32_t)__builtin_amdgcn_readfirstlane((int)list[item / (chunks / per_item)]);
+            const uint32_t view = e / npix, pix = e - view * npix;
+            const ViewArgs &A = VB.v[view];
+            const int py = (int)(pix / (uint32_t)A.Wb), px = (int)(pix - (uint32_t)py * (uint32_t)A.Wb);
+            const unsigned proof = skip ? (unsigned)__builtin_amdgcn_readfirstlane((int)skip[e]) : 0u;
+            const bool skip_trace = (proof & DSDF_PX_EMPTY) != 0;
+            float acc[NCH][2];
+#pragma unroll
+            for (int ch = 0; ch < NCH; ++ch) { acc[ch][0] = 0.f; acc[ch][1] = 0.f; }
+          for (uint32_t ck = 0; ck < per_item; ++ck) {
+            const uint32_t unit = pix * chunks + (PHASE == 1 ? ck : item % chunks);
+            const uint32_t lane = unit * 64u + (uint32_t)lid;
+            float *slot = hit_t + (size_t)view * ((size_t)npix * (uint32_t)A.spp) + lane;
+            const float ht = skip_trace ? INFINITY : *slot;
+            const bool occluded = (__float_as_uint(ht) >> 31) != 0u;
+            const float its_t = fabsf(ht);
+            if (PHASE == 0) {
+                const bool hit = its_t < INFINITY;
+                if (__ballot(hit) != 0) {
+                    // (the samples of a chunk hit within a voxel of each other: the normal's lookup goes through the wave cell cache)
+                    const Lane L = lane_setup<true>(A, P, lane, px, py);
+                    DirectHit h;
+                    WaveCellCache F; F.taps = wave_lds; F.lid = lid;
+                    const bool front = direct_setup(G, A, L, lane, hit ? its_t : 0.f, h, F, hit);
+                    const uint64_t m = __ballot(front);
+                    if (m != 0) {
+                        uint32_t q = my_subq, base = 0;
+                        int tries = 0;
+                        while (!shq_reserve(sq, q, m, base) && ++tries < (int)DSDF_TAIL_SUBQ) q = (q + 1u) & (DSDF_TAIL_SUBQ - 1u);
+                        if (front && tries < (int)DSDF_TAIL_SUBQ) {
+                            float *en = sq.state + ((size_t)q * sq.cap_sub + (base + mask_prefix(m))) * DSDF_PTAIL_WORDS;
+                            en[0] = __uint_as_float(view); en[1] = __uint_as_float(lane); en[2] = its_t;
+                        }
+                        // (every sub-queue full cannot happen: their capacities add up to the worst case plus the slack of one chunk each)
+                    }
+                }
+            } else {
+                const Lane L = lane_setup<true>(A, P, lane, px, py);
+                const Reproj rp = reproject(A.cam, P, L.ray.o + L.ray.d, A.W, A.H);
+                float rgb[3];
+                {
+                    WaveCellCache F; F.taps = wave_lds; F.lid = lid;
+                    direct_value_known(G, A, S, L, lane, its_t, occluded, rgb, F);
+                }
+                film_accum_wave<NCH>(px, py, rp.u, rp.v, rgb, wave_lds, lid, acc);
+            }
+          }
+            if (PHASE == 1) film_flush_wave<NCH>(blocks + (size_t)view * NCH * npix, A, px, py, lid, acc);
+        }
+        item = (uint32_t)__builtin_amdgcn_readfirstlane((int)next);
+        if (lid == 0) next = draw(share);
+    }
 }
 
 // Thread -> sample of the general pass.  The reference's lane order (lane = pixel * spp + sample, pixels row-major,
@@ -931,6 +1038,9 @@ struct Workspace {
     uint32_t *items;       // work lists of the persistent render kernel: DSDF_MAX_GROUPS headers, then one entry per film-block pixel and view
     char *tail;            // tail hand-off queues: DSDF_MAX_GROUPS x (counters | march states)
     size_t tail_bytes;
+    float *hit_t;          // the wavefront primal of sdf_direct_reparam: hit distance per sample and view (sign: shadow ray occluded)
+    char *shq;             // ... and its shadow queue: (counters | 3-word entries), one region for all views of the launch
+    uint32_t shq_cap_sub;
     uint32_t cap, nunits, tail_cap_sub, tail_words, group_views, coef_rows;
     size_t bytes;
 };
@@ -952,7 +1062,7 @@ static Workspace carve(void *base, int W, int H, int spp, int nv, int integrator
     ws.skip = (unsigned char *)(p + off); off += align_up(nv * Wb * Hb, 256);
     ws.items = (uint32_t *)(p + off); off += align_up((DSDF_MAX_GROUPS * DSDF_ITEM_HDR + nv * Wb * Hb) * sizeof(uint32_t), 256);
     ws.block_adj = nullptr; ws.count = nullptr; ws.qlane = nullptr; ws.qrec = nullptr; ws.qcoef = nullptr; ws.coef_rows = 0; ws.count0 = nullptr;
-    ws.tail = nullptr; ws.tail_bytes = 0; ws.tail_cap_sub = 0; ws.tail_words = 0;
+    ws.tail = nullptr; ws.tail_bytes = 0; ws.tail_cap_sub = 0; ws.tail_words = 0; ws.hit_t = nullptr; ws.shq = nullptr; ws.shq_cap_sub = 0;
     ws.group_views = (uint32_t)((nv + DSDF_MAX_GROUPS - 1) / DSDF_MAX_GROUPS);
     if (diff) {
         ws.block_adj = (float *)(p + off); off += align_up(nv * Wb * Hb * nch * sizeof(float), 256);
@@ -965,7 +1075,7 @@ static Workspace carve(void *base, int W, int H, int spp, int nv, int integrator
             ws.count0 = (uint32_t *)(p + off); off += align_up(nv * nunits * sizeof(uint32_t), 256);
         }
     }
-    if (integrator != DSDF_DIRECT && spp % 64 == 0) {
+    if ((integrator != DSDF_DIRECT || !diff) && spp % 64 == 0) {
         // per group: sub-queue `s` serves the chunks with work-list index % DSDF_TAIL_SUBQ == s; a wave hands off at most
         // `handoff` rays per 64-sample chunk
         const size_t handoff = diff ? DSDF_TAIL_HANDOFF : DSDF_PTAIL_HANDOFF;
@@ -975,10 +1085,26 @@ static Workspace carve(void *base, int W, int H, int spp, int nv, int integrator
                         (size_t)DSDF_MAX_GROUPS * align_up((size_t)DSDF_TAIL_SUBQ * ws.tail_cap_sub * ws.tail_words * sizeof(float), 256);
         ws.tail = p + off; off += ws.tail_bytes;
     }
+    if (integrator == DSDF_DIRECT && !diff && spp % 64 == 0) {
+        // the wavefront primal: hit distances, and a shadow queue that holds EVERY sample in the worst case -- the
+        // sub-queues share it evenly plus one chunk of slack each (a producer whose sub-queue is full moves on to the next)
+        ws.hit_t = (float *)(p + off); off += align_up((size_t)nv * cap * sizeof(float), 256);
+        ws.shq_cap_sub = (uint32_t)(((size_t)nv * nunits + DSDF_TAIL_SUBQ - 1) / DSDF_TAIL_SUBQ * 64 + 64);
+        ws.shq = p + off;
+        off += align_up((size_t)DSDF_TAIL_SUBQ * DSDF_TAIL_CNT_STRIDE * sizeof(uint32_t), 256) +
+               align_up((size_t)DSDF_TAIL_SUBQ * ws.shq_cap_sub * DSDF_PTAIL_WORDS * sizeof(float), 256);
+    }
     ws.cap = (uint32_t)cap;
     ws.nunits = (uint32_t)nunits;
     ws.bytes = off;
     return ws;
+}
+
+// Bytes of the cell table of an (rx, ry, rz) grid (dsdf_tail.h: TableFetch), 0 when its byte offsets do not fit 32 bits
+static size_t cell_table_bytes(int rx, int ry, int rz) {
+    if (rx < 1 || ry < 1 || rz < 1) return 0;
+    const uint64_t n = (uint64_t)(rx + 2 * DSDF_APRON) * (uint64_t)(ry + 2 * DSDF_APRON) * (uint64_t)(rz + 2 * DSDF_APRON) * 64u;
+    return (n < ((uint64_t)1 << 32) && (uint64_t)(rx + 2 * DSDF_APRON) * (uint64_t)(ry + 2 * DSDF_APRON) < (1u << 23)) ? (size_t)n : 0;
 }
 
 // Largest number of views (<= DSDF_MAX_BATCH, <= n_views) one launch can take with this workspace.
@@ -1181,6 +1307,8 @@ size_t dsdf_render_workspace_size(int width, int height, int spp, int n_views, i
     return carve(nullptr, width, height, spp, n_views < DSDF_MAX_BATCH ? n_views : DSDF_MAX_BATCH, integrator, true).bytes;
 }
 
+size_t dsdf_cell_table_size(int rx, int ry, int rz) { return cell_table_bytes(rx, ry, rz); }
+
 size_t dsdf_forward_workspace_size(int width, int height, int spp, int n_views, int integrator) {
     if (width < 1 || height < 1 || spp < 1 || n_views < 1) return 0;
     return carve(nullptr, width, height, spp, n_views < DSDF_MAX_BATCH ? n_views : DSDF_MAX_BATCH, integrator, false).bytes;
@@ -1197,6 +1325,7 @@ struct PassCtx {
     size_t Wb, Hb; uint32_t nl;
     int row0, row1;        // film-block rows of this call (multi-GPU pixel-tile split; the whole film by default)
     float *film;           // caller-owned film block to ACCUMULATE into (tile calls), or nullptr: the workspace's, zeroed
+    size_t ws_bytes;       // the caller's workspace (what lies behind the carved part may hold the cell table of the direct primal)
     hipStream_t st;
     bool coef_early;       // gradient sweep: launch k_backward_coef for the render kernel's own samples AHEAD of the tail kernel
     bool coef_beside;      // ... or BESIDE the tail kernel, on the other helper stream, up to a snapshot of the queue lengths (DSDF_COEF_EARLY=2)
@@ -1216,7 +1345,7 @@ static PassCtx make_ctx(const float *padded, int rx, int ry, int rz, const dsdf_
     c.bsdf_u = (c.direct && shading->use_mis) ? shading->bsdf_samples : nullptr;
     c.lobe_u = (c.direct && shading->use_mis && shading->bsdf == 1) ? shading->bsdf_lobe_samples : nullptr;   // (n_views x lanes x 1)
     c.Wb = W + 2 * DSDF_BORDER; c.Hb = H + 2 * DSDF_BORDER; c.nl = (uint32_t)(c.Wb * c.Hb * spp);
-    c.row0 = 0; c.row1 = (int)c.Hb; c.film = nullptr;
+    c.row0 = 0; c.row1 = (int)c.Hb; c.film = nullptr; c.ws_bytes = 0;
     c.st = (hipStream_t)stream;
     c.coef_early = false; c.coef_beside = false; c.coef_done_early = false;
     return c;
@@ -1275,6 +1404,8 @@ static int coef_early_mode() { static const int v = env_int("DSDF_COEF_EARLY", 0
 static int hit_proof_min_spp() { static const int v = env_int("DSDF_HIT_PROOF_MIN_SPP", 16); return v; }
 // DSDF_ENV_FILL=0: sdf_direct_reparam with a visible environment samples its far pixels (as until round 5; A/B)
 static bool env_fill_enabled() { static const int v = env_int("DSDF_ENV_FILL", 1); return v != 0; }
+static bool cell_table_enabled() { static const int v = env_int("DSDF_CELL_TABLE", 1); return v != 0; }
+static bool direct_wavefront_enabled() { static const int v = env_int("DSDF_DIRECT_WAVEFRONT", 1); return v != 0; }
 static bool primal_handoff() { static const int v = env_int("DSDF_PRIMAL_HANDOFF", 1); return v != 0; }
 static int tail_streams_enabled() { static int v = env_int("DSDF_TAIL_STREAMS", 1); return v; }
 // blocks (4 waves) per sub-queue of a tail kernel: DSDF_TAIL_BLOCKS overrides the built-in value
@@ -1462,7 +1593,9 @@ static int run_pass(PassCtx &c, const Workspace &ws, const dsdf_camera *cams, in
         if (DIFF && hipMemsetAsync(ws.count, 0, (size_t)nv * ws.nunits * sizeof(uint32_t), st) != hipSuccess)
             return fail(DSDF_ERR_LAUNCH, "hipMemsetAsync(queue counts) failed");
         // view groups: render kernel g on the caller's stream, tail kernel g on a helper stream beside render kernel g + 1
-        const bool handoff = ws.tail != nullptr && (DIFF || primal_handoff());
+        // sdf_direct_reparam's primal as a wavefront (DSDF_DIRECT_WAVEFRONT=0: the fused worker as before; use_mis keeps it)
+        const bool wavefront = !DIFF && c.direct && !S.use_mis && ws.hit_t != nullptr && direct_wavefront_enabled() && max_groups() == 1;
+        const bool handoff = ws.tail != nullptr && (DIFF || primal_handoff()) && (!c.direct || wavefront);
         const size_t cnt_bytes = align_up((size_t)DSDF_MAX_GROUPS * DSDF_TAIL_SUBQ * DSDF_TAIL_CNT_STRIDE * sizeof(uint32_t), 256);
         const size_t grp_bytes = align_up((size_t)DSDF_TAIL_SUBQ * ws.tail_cap_sub * ws.tail_words * sizeof(float), 256);
         if (handoff && hipMemsetAsync(ws.tail, 0, cnt_bytes, st) != hipSuccess)
@@ -1503,12 +1636,16 @@ static int run_pass(PassCtx &c, const Workspace &ws, const dsdf_camera *cams, in
                 tq.state = (float *)(ws.tail + cnt_bytes + (size_t)g * kreg * grp_bytes);
             }
             if (g == 0) timing_mark(0, st);
-            if (c.direct) {
-                if (st64) hipLaunchKernelGGL((k_render_items<DIFF, true, true>), grid, blk, 0, st, G, c.pp, VB, film, q, st64, skip, S, tq, hdr, list);
-                else hipLaunchKernelGGL((k_render_items<DIFF, true, false>), grid, blk, 0, st, G, c.pp, VB, film, q, st64, skip, S, tq, hdr, list);
+            if (wavefront) {
+                // the value-only march of the primary rays into hit_t (its tail kernel below), then the three wavefront passes
+                if (st64) hipLaunchKernelGGL((k_render_items<false, false, true, true>), grid, blk, 0, st, G, c.pp, VB, film, q, st64, skip, S, tq, hdr, list, ws.hit_t);
+                else hipLaunchKernelGGL((k_render_items<false, false, false, true>), grid, blk, 0, st, G, c.pp, VB, film, q, st64, skip, S, tq, hdr, list, ws.hit_t);
+            } else if (c.direct) {
+                if (st64) hipLaunchKernelGGL((k_render_items<DIFF, true, true>), grid, blk, 0, st, G, c.pp, VB, film, q, st64, skip, S, tq, hdr, list, (float *)nullptr);
+                else hipLaunchKernelGGL((k_render_items<DIFF, true, false>), grid, blk, 0, st, G, c.pp, VB, film, q, st64, skip, S, tq, hdr, list, (float *)nullptr);
             } else {
-                if (st64) hipLaunchKernelGGL((k_render_items<DIFF, false, true>), grid, blk, 0, st, G, c.pp, VB, film, q, st64, skip, S, tq, hdr, list);
-                else hipLaunchKernelGGL((k_render_items<DIFF, false, false>), grid, blk, 0, st, G, c.pp, VB, film, q, st64, skip, S, tq, hdr, list);
+                if (st64) hipLaunchKernelGGL((k_render_items<DIFF, false, true>), grid, blk, 0, st, G, c.pp, VB, film, q, st64, skip, S, tq, hdr, list, (float *)nullptr);
+                else hipLaunchKernelGGL((k_render_items<DIFF, false, false>), grid, blk, 0, st, G, c.pp, VB, film, q, st64, skip, S, tq, hdr, list, (float *)nullptr);
             }
             if ((rc = check_launch("k_render_items"))) return rc;
             if (g == ngroups - 1) timing_mark(1, st);
@@ -1544,7 +1681,8 @@ static int run_pass(PassCtx &c, const Workspace &ws, const dsdf_camera *cams, in
                 const dim3 tgrid(DSDF_TAIL_SUBQ * tail_blocks()), tblk(256);
                 unsigned long long *tst = st64 ? st64 : g_tail_stats;
                 if (DIFF) hipLaunchKernelGGL(k_tail_trace_diff, tgrid, tblk, 0, ts, G, c.pp, VB, film, tq, q, tst);
-                else hipLaunchKernelGGL(k_tail_trace_plain, tgrid, tblk, 0, ts, G, c.pp, VB, film, tq, tst);
+                else hipLaunchKernelGGL(k_tail_trace_plain, tgrid, tblk, 0, ts, G, c.pp, VB, film, tq, wavefront ? (unsigned long long *)nullptr : tst,
+                                        wavefront ? ws.hit_t : (float *)nullptr);
                 if ((rc = check_launch("k_tail_trace"))) return rc;
                 if (forked) {
                     hipEvent_t e = next_event();
@@ -1568,6 +1706,34 @@ static int run_pass(PassCtx &c, const Workspace &ws, const dsdf_camera *cams, in
         }
         for (int k = 0; k < njoin; ++k)
             if (hipStreamWaitEvent(st, joins[k], 0) != hipSuccess) return fail(DSDF_ERR_LAUNCH, "tail stream join failed");
+        if (wavefront) {
+            // (one view group: the list of group 0 is the list of the launch)
+            uint32_t *hdr = ws.items;
+            const uint32_t *list = ws.items + (size_t)DSDF_MAX_GROUPS * DSDF_ITEM_HDR;
+            const size_t scnt = align_up((size_t)DSDF_TAIL_SUBQ * DSDF_TAIL_CNT_STRIDE * sizeof(uint32_t), 256);
+            TailQueue sq;
+            sq.count = (uint32_t *)ws.shq; sq.state = (float *)(ws.shq + scnt); sq.cap_sub = ws.shq_cap_sub; sq.per_xcd = 1u;
+            const size_t tick_bytes = (size_t)16 * DSDF_TICKETS * sizeof(uint32_t);
+            if (hipMemsetAsync(ws.shq, 0, scnt, st) != hipSuccess || hipMemsetAsync(hdr + 16, 0, tick_bytes, st) != hipSuccess)
+                return fail(DSDF_ERR_LAUNCH, "hipMemsetAsync(shadow queue) failed");
+            hipLaunchKernelGGL((k_direct_items<0>), grid, blk, 0, st, G, c.pp, VB, film, skip, S, sq, hdr, list, ws.hit_t);
+            if ((rc = check_launch("k_direct_items<0>"))) return rc;
+            // the cell table the shadow rays read, behind the carved workspace when the caller provided the room (dsdf_cell_table_size)
+            const size_t tb = cell_table_enabled() ? cell_table_bytes(c.rx, c.ry, c.rz) : 0;
+            const size_t toff = align_up(ws.bytes, 256);
+            float *table = (tb && c.ws_bytes >= toff + tb) ? (float *)((char *)ws.block + toff) : nullptr;
+            if (table) {
+                hipLaunchKernelGGL(k_cell_table, dim3(16384), dim3(256), 0, st, c.padded, c.rx + 2 * DSDF_APRON, c.ry + 2 * DSDF_APRON, c.rz + 2 * DSDF_APRON, table);
+                if ((rc = check_launch("k_cell_table"))) return rc;
+                hipLaunchKernelGGL((k_shadow_stream<true>), dim3(DSDF_TAIL_SUBQ * DSDF_SHQ_BLOCKS_PER_SUBQ), dim3(256), 0, st, G, c.pp, VB, sq, ws.hit_t, st64, (const float *)table);
+            } else {
+                hipLaunchKernelGGL((k_shadow_stream<false>), dim3(DSDF_TAIL_SUBQ * DSDF_SHQ_BLOCKS_PER_SUBQ), dim3(256), 0, st, G, c.pp, VB, sq, ws.hit_t, st64, (const float *)nullptr);
+            }
+            if ((rc = check_launch("k_shadow_stream"))) return rc;
+            if (hipMemsetAsync(hdr + 16, 0, tick_bytes, st) != hipSuccess) return fail(DSDF_ERR_LAUNCH, "hipMemsetAsync(tickets) failed");
+            hipLaunchKernelGGL((k_direct_items<1>), grid, blk, 0, st, G, c.pp, VB, film, skip, S, sq, hdr, list, ws.hit_t);
+            if ((rc = check_launch("k_direct_items<1>"))) return rc;
+        }
     } else {
         LaneMap M;
         size_t nunits;
@@ -1609,6 +1775,7 @@ int dsdf_render_forward(const float *padded, int rx, int ry, int rz, const dsdf_
     if (!image_out) return fail(DSDF_ERR_INVALID_ARG, "dsdf_render_forward: image_out is null");
     if (!offsets && !seeds) return fail(DSDF_ERR_INVALID_ARG, "dsdf_render_forward: need offsets or seeds");
     PassCtx c = make_ctx(padded, rx, ry, rz, prm, width, height, spp, offsets, seeds, integrator, flags, shading, stream);
+    c.ws_bytes = workspace_bytes;
     const int nb = batch_size(width, height, spp, n_views, integrator, workspace_bytes, false);
     const Workspace ws = carve(workspace, width, height, spp, nb, integrator, false);
     const Queue q = make_queue(ws, c.direct);
@@ -1720,7 +1887,7 @@ int dsdf_render_film(const float *padded, int rx, int ry, int rz, const dsdf_par
     if (!film) return fail(DSDF_ERR_INVALID_ARG, "dsdf_render_film: film is null");
     if (!offsets && !seeds) return fail(DSDF_ERR_INVALID_ARG, "dsdf_render_film: need offsets or seeds");
     PassCtx c = make_ctx(padded, rx, ry, rz, prm, width, height, spp, offsets, seeds, integrator, flags, shading, stream);
-    c.row0 = row0; c.row1 = row1; c.film = film;
+    c.row0 = row0; c.row1 = row1; c.film = film; c.ws_bytes = workspace_bytes;
     const int nb = batch_size(width, height, spp, n_views, integrator, workspace_bytes, false);
     const Workspace ws = carve(workspace, width, height, spp, nb, integrator, false);
     const Queue q = make_queue(ws, c.direct);

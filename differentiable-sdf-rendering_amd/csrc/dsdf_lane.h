@@ -320,6 +320,21 @@ DSDF_HD void emitter_sample(const ViewArgs &A, uint32_t lane, float &e0, float &
 
 // geometry of the hit and its shadow ray (no tracing); returns false when the BSDF is zero for the sampled
 // direction (diffuse::eval needs both cosines positive)
+// (Fetch: who reads the 16 rows of the hit point's cell -- every lane its own (DirectFetch), or the wave cell cache when the 64 lanes
+// are the samples of one pixel and `on` masks the lanes that hit: the whole wave must call then)
+template <class Fetch>
+DSDF_HD bool direct_setup(const GridView &G, const ViewArgs &A, const Lane &L, uint32_t lane, float its_t, DirectHit &h, Fetch &F, bool on) {
+    h.lit = false;
+    h.p = fma3(its_t, L.ray.d, L.ray.o);
+    float v = 0.f; float H[6];
+    h.g = mk(0.f, 0.f, 1.f);
+    F.template eval<1>(G, h.p, on, v, h.g, H);
+    h.n = h.g * rsqf_s<5>(dot(h.g, h.g));
+    float e0, e1;
+    emitter_sample(A, lane, e0, e1);
+    h.sr = spawn_shadow_ray(h.p, h.n, square_to_uniform_sphere(e0, e1));
+    return on && dot(h.n, h.sr.d) > 0.f && dot(h.n, -L.ray.d) > 0.f;
+}
 DSDF_HD bool direct_setup(const GridView &G, const ViewArgs &A, const Lane &L, uint32_t lane, float its_t, DirectHit &h) {
     h.lit = false;
     h.p = fma3(its_t, L.ray.d, L.ray.o);
@@ -525,6 +540,28 @@ DSDF_HD int direct_value(const GridView &G, const dsdf_params &P, const ViewArgs
     for (int c = 0; c < 3; ++c) rgb[c] = (alb[c] * ke + ks) * S.env[c] + alb[c] * kb * S.env[c];
 #endif
     return lit;
+}
+
+// direct_value for a sample whose traces are KNOWN (the wavefront primal, dsdf_kernels.hip k_direct_items: hit distance from the
+// value-only march, `occluded` from the shadow-ray stream): the same statements as the value-only branch of direct_value without
+// use_mis, the shadow trace replaced by its result.
+template <class Fetch>
+DSDF_HD int direct_value_known(const GridView &G, const ViewArgs &A, const ShadeArgs &S, const Lane &L, uint32_t lane, float its_t,
+                               bool occluded, float rgb[3], Fetch &F) {
+    rgb[0] = rgb[1] = rgb[2] = 0.f;
+    const bool hit = its_t < INFINITY;
+    if (!hit && !S.hide_emitters) { rgb[0] = S.env[0]; rgb[1] = S.env[1]; rgb[2] = S.env[2]; }
+    if (!F.any(hit)) return 0;
+    DirectHit h;
+    const bool front = direct_setup(G, A, L, lane, hit ? its_t : 0.f, h, F, hit);          // (the whole wave calls: the fetch policy may be wave-level)
+    if (!front || occluded) return 0;
+    EmitterTerm e;
+    emitter_term(S, h, L.ray.d, e);
+    float alb[3]; V3 ag[3];
+    eval_trilinear(S.albedo, h.p, alb, ag);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) rgb[c] = (alb[c] * e.ke + e.ks) * S.env[c];
+    return 1;
 }
 
 // One 64-tap scatter into dL/dsdf: grad[tap] += cv * W_tap + cg . (res * dW_tap) at point x.

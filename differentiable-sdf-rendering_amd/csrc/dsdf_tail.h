@@ -133,6 +133,25 @@ __device__ __forceinline__ bool tail_reserve(const TailQueue &tq, uint32_t sub, 
     return __builtin_amdgcn_readlane(ok, leader) != 0;
 }
 
+// Reservation in the shadow queue of the wavefront primal (k_direct_items<0>): a fetch-add -- 128 producers share a counter, and a
+// compare-and-swap by contending waves succeeds once per memory round trip.  A reservation that does not fit is taken
+// back (consumers start after the producers' kernel; while an overshoot is outstanding the counter is above the capacity, so no
+// other reservation can succeed on a stale base) and the caller tries the next sub-queue.
+__device__ __forceinline__ bool shq_reserve(const TailQueue &tq, uint32_t sub, uint64_t m, uint32_t &base) {
+    const int leader = __builtin_ctzll(m);
+    const uint32_t n = (uint32_t)__popcll(m);
+    uint32_t b = 0;
+    int ok = 0;
+    if (lane_id() == leader) {
+        uint32_t *p = tq.count + DSDF_TAIL_CNT_STRIDE * sub;
+        b = atomicAdd(p, n);
+        ok = b + n <= tq.cap_sub ? 1 : 0;
+        if (!ok) atomicSub(p, n);
+    }
+    base = (uint32_t)__builtin_amdgcn_readlane((int)b, leader);
+    return __builtin_amdgcn_readlane(ok, leader) != 0;
+}
+
 // Loop control of trace_diff / trace_plain (dsdf_math.h): stop when at most HANDOFF rays of the wave are still marching and
 // GRACE more iterations have passed; the entries are reserved at that moment (a wave whose queue is full marches on to the end
 // instead), and the state of the rays that are still active is exported right after the loop -- so that the words die before
@@ -436,8 +455,10 @@ __global__ __launch_bounds__(256) void k_tail_trace_diff(GridView G, dsdf_params
 // Resumes the queued rays of the primal pass (value-only march) and adds the film value of those that hit.  The rays that
 // end up here slide along a surface in sub-voxel steps: the lane keeps the 64 taps of its cell in registers (ReuseFetch) and
 // gathers only on entering another cell -- the step is then a dependent ALU chain without a memory round trip.
+// hit_t != nullptr (the wavefront primal of sdf_direct_reparam): a finished ray's sample is not shaded here -- its refined hit
+// distance overwrites the "miss" its render worker stored in hit_t[view][sample].
 __global__ __launch_bounds__(256) void k_tail_trace_plain(GridView G, dsdf_params P, ViewBatch VB, float *__restrict__ blocks,
-                                                          TailQueue tq, unsigned long long *stats) {
+                                                          TailQueue tq, unsigned long long *stats, float *__restrict__ hit_t) {
     __builtin_amdgcn_s_setprio(DSDF_TAIL_PRIO);
     const uint32_t first = tq.per_xcd ? tail_subq() : blockIdx.x % DSDF_TAIL_SUBQ;
     uint32_t hop = 0, total = 0;
@@ -484,7 +505,7 @@ __global__ __launch_bounds__(256) void k_tail_trace_plain(GridView G, dsdf_param
     m.active = false;
     Lane L;
     ReuseFetch F;
-    uint32_t view = 0;
+    uint32_t view = 0, sample = 0;
     bool exhausted = false;
     int n_steps = 0, n_wsteps = 0, n_rays = 0, n_hits = 0, n_ref = 0;
 
@@ -494,6 +515,11 @@ __global__ __launch_bounds__(256) void k_tail_trace_plain(GridView G, dsdf_param
         DirectFetch D;
         int nref;
         const float its_t = refine_hit(G, P, m.o, m.d, m.its_t, m.trace_eps, nref, D);
+        if (hit_t) {
+            hit_t[(size_t)view * ((size_t)(A.Wb * A.Hb) * (uint32_t)A.spp) + sample] = its_t;
+            ++n_hits; n_ref += nref;
+            return;
+        }
         const float val = shade_value(G, A, L, its_t);
         if (val != 0.f) {
             Reproj rp = reproject(A.cam, P, L.ray.o + L.ray.d, A.W, A.H);
@@ -518,7 +544,8 @@ __global__ __launch_bounds__(256) void k_tail_trace_plain(GridView G, dsdf_param
             const unsigned long long c_b = stats ? (unsigned long long)clock64() : 0ull;
             if (idx != ~0u) {
                 view = __float_as_uint(e[0]);
-                L = lane_setup<true>(views[view], P, __float_as_uint(e[1]));
+                sample = __float_as_uint(e[1]);
+                L = lane_setup<true>(views[view], P, sample);
                 m = plain_march_begin(P, L.ray.o, L.ray.d, L.ray.maxt);
                 m.t = e[2];
                 F.valid = false;
@@ -606,6 +633,214 @@ __global__ __launch_bounds__(256) void k_tail_trace_plain(GridView G, dsdf_param
             unsigned long long *st = stats + (size_t)(blockIdx.x & 63u) * DSDF_STAT_SLOTS;
             atomicAdd(st + 3, (unsigned long long)h);
             atomicAdd(st + 4, (unsigned long long)r);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------ shadow rays of sdf_direct_reparam as a wavefront
+// Round 6.  The primal of sdf_direct_reparam traced its shadow rays inside the render worker: 72 M rays per launch at C5
+// sizes (half of the hits face the sampled direction), 25.7 steps on average with a heavy tail -- the lock-step loop of a chunk ran 82
+// iterations for ~32 rays: 15.6 % of the lane slots of two thirds of the kernel's march iterations did work.  Now the render worker's
+// successor lists the samples that need a shadow ray -- (view, sample, hit distance), the 3-word entries of the primal tail queue, in
+// the same per-XCD sub-queues -- and THIS kernel streams through the list: persistent waves, every lane its own ray, the 64 taps of
+// the lane's cell in registers (ReuseFetch: a gather only on entering another cell); a lane whose ray is done waits until
+// DSDF_SHQ_REFILL lanes are idle, then they take the next entries together (camera ray, hit point, normal and emitter sample are
+// recomputed from the sample id: dsdf_lane.h direct_setup).  An occluded sample gets the SIGN of its hit_t entry set; the shading
+// pass (k_direct_items<1>) reads it.  ray_test consumes only isfinite(its_t) (sdf_direct_reparam.py:52-56): no refinement.
+// Shadow rays leave their surface in uniformly sampled directions: no two lanes of a wave share a cell after a few steps and the
+// rays cross the whole grid -- the stream is bound by the bytes a cell visit moves (k_shadow_stream took the same 34 ms with 1024 and
+// with 2048 waves, with and without deferred loads).  In the row-block copy a cell is 7 lines = 896 bytes for 256 useful ones; the
+// CELL TABLE Tab[by][bx][z][4 y][4 x] (the 4 x 4 (y, x) patch of every tap position, z fastest: the 64 taps of a cell are 256
+// contiguous bytes = 2-3 lines) moves 320.  16 x the bytes of the grid (1.15 GB at 256^3), so it lives in the render workspace, is
+// rebuilt by every call (k_cell_table: 0.3 ms) and only exists while its byte offsets fit 32 bits (about 400^3); the coherent
+// marches do not use it (for them its footprint costs more L2 misses than it saves requests).
+struct TableFetch {
+    uint32_t base;
+    bool valid;
+    float taps[64];
+    const char *tab;
+    int sx, sz;         // padded x size, padded z size (cell index = (by * sx + bx) * sz + bz, 64 bytes per index step)
+    __device__ __forceinline__ TableFetch() : base(0u), valid(false) {}
+    __device__ __forceinline__ bool any(bool b) const { return b; }
+    template <int ORDER>
+    __device__ __forceinline__ void eval(const GridView &G, V3 x, bool active, float &v, V3 &g, float H[6]) {
+        if (!active) return;
+        const V3 q = to_grid(G, x);
+        const float pfx = fmaf(q.x, G.frx, -0.5f), pfy = fmaf(q.y, G.fry, -0.5f), pfz = fmaf(q.z, G.frz, -0.5f);
+        CubicCell c;
+        c.ax = __builtin_amdgcn_fractf(pfx); c.ay = __builtin_amdgcn_fractf(pfy); c.az = __builtin_amdgcn_fractf(pfz);
+        int qx, qy, qz;
+        asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(qx) : "v"(pfx));
+        asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(qy) : "v"(pfy));
+        asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(qz) : "v"(pfz));
+        asm("v_med3_i32 %0, %1, -2, %2" : "=v"(qx) : "v"(qx), "s"(G.rx));
+        asm("v_med3_i32 %0, %1, -2, %2" : "=v"(qy) : "v"(qy), "s"(G.ry));
+        asm("v_med3_i32 %0, %1, -2, %2" : "=v"(qz) : "v"(qz), "s"(G.rz));
+        int lin;
+        asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(lin) : "v"(qy), "s"(sx), "v"(qx));
+        asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(lin) : "v"(lin), "s"(sz), "v"(qz));
+        const int c64 = 64 * ((2 * sx + 2) * sz + 2);
+        asm("v_lshl_add_u32 %0, %1, 6, %2" : "=v"(c.base) : "v"(lin), "s"(c64));
+        if (!valid || c.base != base) {
+            typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+            const char *p = tab + c.base;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const f4u t = *reinterpret_cast<const f4u *>(p + 16 * r);
+                taps[4 * r] = t.x; taps[4 * r + 1] = t.y; taps[4 * r + 2] = t.z; taps[4 * r + 3] = t.w;
+            }
+            base = c.base;
+            valid = true;
+        }
+        RegRows rr;
+        rr.t = taps;
+        eval_cubic_rows<ORDER>(G, c, rr, v, g, H);
+    }
+};
+// Tab[by][bx][z][j][0..3] = padded[z][by + j][bx .. bx + 3] (indices clamped to the padded grid: the entries no cell starts in are
+// never read).  One thread per 16-byte row.
+__global__ void k_cell_table(const float *__restrict__ padded, int sx, int sy, int sz, float *__restrict__ out) {
+    const size_t n = (size_t)sy * sx * sz * 4;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int j = (int)(i & 3);
+        size_t r = i >> 2;
+        const int z = (int)(r % sz); r /= sz;
+        const int bx = (int)(r % sx);
+        const int by = (int)(r / sx);
+        const int y = by + j < sy ? by + j : sy - 1;
+        const float *row = padded + ((size_t)z * sy + y) * sx;
+        float4 t;
+        t.x = row[bx < sx ? bx : sx - 1]; t.y = row[bx + 1 < sx ? bx + 1 : sx - 1];
+        t.z = row[bx + 2 < sx ? bx + 2 : sx - 1]; t.w = row[bx + 3 < sx ? bx + 3 : sx - 1];
+        reinterpret_cast<float4 *>(out)[i] = t;
+    }
+}
+
+#ifndef DSDF_SHQ_REFILL
+#define DSDF_SHQ_REFILL 24
+#endif
+#ifndef DSDF_SHQ_DEFER
+#define DSDF_SHQ_DEFER 0
+#endif
+#ifndef DSDF_SHQ_BLOCKS_PER_SUBQ
+#define DSDF_SHQ_BLOCKS_PER_SUBQ 8      /* x 4 waves x 64 sub-queues = 2048 waves: 2 per SIMD at 186 VGPRs (a throughput kernel, unlike the tails) */
+#endif
+template <bool TABLE>
+__global__ __launch_bounds__(256) void k_shadow_stream(GridView G, dsdf_params P, ViewBatch VB, TailQueue tq, float *__restrict__ hit_t,
+                                                       unsigned long long *stats, const float *__restrict__ cell_table) {
+    const uint32_t first = tq.per_xcd ? tail_subq() : blockIdx.x % DSDF_TAIL_SUBQ;
+    uint32_t hop = 0, total = 0;
+    uint32_t *cnt = nullptr;
+    const float *ent = nullptr;
+    auto open_next = [&]() {
+        const uint32_t sub_k = tail_hop(first, (uint32_t)lane_id(), tq.per_xcd);
+        uint32_t *c = tq.count + DSDF_TAIL_CNT_STRIDE * sub_k;
+        const uint32_t queued = __hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t claimed = __hip_atomic_load(c + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        uint64_t open = __ballot(claimed < queued);
+        open = hop < 64u ? (open >> hop) << hop : 0ull;
+        if (open == 0) { hop = DSDF_TAIL_SUBQ; return false; }
+        const int k = __builtin_ctzll(open);
+        hop = (uint32_t)k + 1u;
+        const uint32_t sub = tail_hop(first, (uint32_t)k, tq.per_xcd);
+        cnt = tq.count + DSDF_TAIL_CNT_STRIDE * sub;
+        ent = tq.state + (size_t)sub * tq.cap_sub * DSDF_PTAIL_WORDS;
+        total = (uint32_t)__builtin_amdgcn_readlane((int)queued, k);
+        return true;
+    };
+    DSDF_TAIL_VIEWS_LDS(VB, views);
+    if (!open_next()) return;
+    dsdf_params Ps = P;
+    Ps.refine_steps = 0;
+    PlainMarch m;
+    m.active = false;
+    typename std::conditional<TABLE, TableFetch, ReuseFetch>::type F;
+    if constexpr (TABLE) { F.tab = reinterpret_cast<const char *>(cell_table); F.sx = G.sx; F.sz = G.rz + 2 * DSDF_APRON; }
+    size_t slot = 0;            // this lane's entry of hit_t
+    float my_t = 0.f;
+    bool exhausted = false;
+    int n_steps = 0, n_wsteps = 0, n_rays = 0;
+    while (true) {
+        const uint64_t idle = __ballot(!m.active);
+        if (!exhausted && __popcll(idle) >= DSDF_SHQ_REFILL) {
+            bool drained = false;
+            const uint32_t idx = tail_claim(cnt, total, idle, !m.active, drained);
+            const float *e = ent + (size_t)idx * DSDF_PTAIL_WORDS;      // (read below, before the queue is switched)
+            if (drained) exhausted = !open_next();
+            if (idx != ~0u) {
+                const uint32_t view = __float_as_uint(e[0]), sample = __float_as_uint(e[1]);
+                my_t = e[2];
+                const ViewArgs &A = views[view];
+                const Lane L = lane_setup<true>(A, P, sample);
+                DirectHit h;
+                direct_setup(G, A, L, sample, my_t, h);
+                m = plain_march_begin(Ps, h.sr.o, h.sr.d, h.sr.maxt);
+                slot = (size_t)view * ((size_t)(A.Wb * A.Hb) * (uint32_t)A.spp) + sample;
+                F.valid = false;
+                ++n_rays;
+            }
+        }
+        const uint64_t am = __ballot(m.active);
+        if (am == 0) {
+            if (exhausted) break;
+            continue;
+        }
+        ++n_wsteps;
+#if DSDF_SHQ_DEFER
+        static_assert(!TABLE, "the deferred variant reads the row-block copy");
+        // a ray that enters another cell ISSUES the gather of its 16 rows and sits this iteration out; the rays that stay in their cell
+        // step meanwhile, the rows are moved to the lane's tap registers after that: the wave waits for what is left of the memory
+        // round trip after a step's arithmetic.  (With ~50 marching rays per wave some ray changes its cell in nearly every iteration:
+        // without this every iteration is a round trip.)
+        if (m.active) {
+            const CubicCell c = cubic_cell(G, fma3(m.t, m.d, m.o));
+            const bool load = !F.valid || c.base != F.base;
+            float stage[64];
+            if (load) {
+                const GlobalRows rows = global_rows(G, c);
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        v2f lo, hi;
+                        rows.get(k, j, lo, hi);
+                        float *r = stage + (k * 4 + j) * 4;
+                        r[0] = lo[0]; r[1] = lo[1]; r[2] = hi[0]; r[3] = hi[1];
+                    }
+            }
+            if (!opaque((int)load)) {
+                RegRows rr;
+                rr.t = F.taps;
+                float v = 0.f; V3 gd; float Hd[6];
+                eval_cubic_rows<0>(G, c, rr, v, gd, Hd);
+                plain_march_step(m, v);
+                ++n_steps;
+                if (!m.active && m.its_t < INFINITY) hit_t[slot] = -my_t;   // occluded
+            }
+            if (opaque((int)load)) {
+#pragma unroll
+                for (int q = 0; q < 64; ++q) F.taps[q] = stage[q];
+                F.base = c.base;
+                F.valid = true;
+            }
+        }
+#else
+        if (m.active) {
+            float v = 0.f; V3 gd; float Hd[6];
+            F.template eval<0>(G, fma3(m.t, m.d, m.o), true, v, gd, Hd);
+            plain_march_step(m, v);
+            ++n_steps;
+            if (!m.active && m.its_t < INFINITY) hit_t[slot] = -my_t;       // occluded
+        }
+#endif
+    }
+    if (stats) {
+        const int ls = wave_sum_i32(n_steps), r = wave_sum_i32(n_rays);
+        if (lane_id() == 0) {
+            unsigned long long *st = stats + (size_t)(blockIdx.x & 63u) * DSDF_STAT_SLOTS;
+            atomicAdd(st + 8, (unsigned long long)ls);
+            atomicAdd(st + 9, (unsigned long long)n_wsteps);
+            atomicAdd(st + 10, (unsigned long long)r);
         }
     }
 }

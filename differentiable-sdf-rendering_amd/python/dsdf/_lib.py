@@ -44,7 +44,7 @@ class DsdfError(RuntimeError):
 
 
 _lib = None
-ABI_VERSION = 307          # DSDF_VERSION of include/dsdf.h these ctypes mirrors were written against
+ABI_VERSION = 308          # DSDF_VERSION of include/dsdf.h these ctypes mirrors were written against
 
 # name -> (restype, argtypes); every symbol include/dsdf.h declares
 SYMBOLS = {
@@ -69,6 +69,7 @@ SYMBOLS = {
                                            C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'dsdf_render_workspace_size': (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     'dsdf_forward_workspace_size': (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    'dsdf_cell_table_size': (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     'dsdf_render_forward': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(DsdfParams),
                                       C.POINTER(DsdfCamera), C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                       C.POINTER(C.c_uint32), C.c_int, C.c_int, C.POINTER(DsdfShading), C.c_void_p, C.c_void_p,

@@ -409,7 +409,9 @@ def render_forward(grid, sensors, spp, seeds=None, offsets=None, integrator=DSDF
     offsets, cseeds = _sampler_args(nv, seeds, offsets, n_lanes)
     dev = grid.device
     img = torch.empty(nv, H, W, 3, dtype=torch.float32, device=dev)
-    wsb = lib.dsdf_forward_workspace_size(W, H, int(spp), min(nv, MAX_VIEWS_PER_LAUNCH), INTEGRATORS[integrator])
+    # (sdf_direct_reparam: room for the cell table of the shadow rays behind the workspace proper, include/dsdf.h dsdf_cell_table_size)
+    extra = (int(lib.dsdf_cell_table_size(grid.rx, grid.ry, grid.rz)) + 256) if INTEGRATORS[integrator] == DSDF_DIRECT else 0
+    wsb = lib.dsdf_forward_workspace_size(W, H, int(spp), min(nv, MAX_VIEWS_PER_LAUNCH), INTEGRATORS[integrator]) + extra
     ws = _workspace(dev, wsb, lib.dsdf_forward_workspace_size(W, H, int(spp), 1, INTEGRATORS[integrator]))
     wsb = ws.numel()
     sh, _keep = _shading_arg(integrator, shading, nv, n_lanes, emitter_samples, bsdf_samples=bsdf_samples)
@@ -541,7 +543,9 @@ def render_film(grid, sensors, spp, film, rows, seeds=None, offsets=None, integr
     offsets, cseeds = _sampler_args(nv, seeds, offsets, n_lanes)
     dev = grid.device
     _require_dev(film, 'film')
-    wsb = lib.dsdf_forward_workspace_size(W, H, int(spp), min(nv, MAX_VIEWS_PER_LAUNCH), INTEGRATORS[integrator])
+    # (sdf_direct_reparam: room for the cell table of the shadow rays behind the workspace proper, include/dsdf.h dsdf_cell_table_size)
+    extra = (int(lib.dsdf_cell_table_size(grid.rx, grid.ry, grid.rz)) + 256) if INTEGRATORS[integrator] == DSDF_DIRECT else 0
+    wsb = lib.dsdf_forward_workspace_size(W, H, int(spp), min(nv, MAX_VIEWS_PER_LAUNCH), INTEGRATORS[integrator]) + extra
     ws = _workspace(dev, wsb, lib.dsdf_forward_workspace_size(W, H, int(spp), 1, INTEGRATORS[integrator]))
     sh, _keep = _shading_arg(integrator, shading, nv, n_lanes, emitter_samples)
     with torch.cuda.device(dev):

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define DSDF_VERSION 307   /* 307: dsdf_tail_stats_arm; 300: stats rows of DSDF_STAT_SLOTS (16) counters; tail hand-off on library-owned helper streams; 304: DSDF_NO_HIT_PROOF, the grid buffer carries the bounds of the hit proof (dsdf_padded_size); 305: dsdf_params grows by normalize_warp_field, max_reparam_depth; 306: dsdf_render_aovs, dsdf_aov_workspace_size, dsdf_sampler_2d, dsdf_set_grid_transform / dsdf_has_grid_transform, dsdf_shading.bsdf_lobe_samples */
+#define DSDF_VERSION 308   /* 308: dsdf_cell_table_size, row-block copy in the grid buffer (dsdf_padded_size grew); 307: dsdf_tail_stats_arm; 300: stats rows of DSDF_STAT_SLOTS (16) counters; tail hand-off on library-owned helper streams; 304: DSDF_NO_HIT_PROOF, the grid buffer carries the bounds of the hit proof (dsdf_padded_size); 305: dsdf_params grows by normalize_warp_field, max_reparam_depth; 306: dsdf_render_aovs, dsdf_aov_workspace_size, dsdf_sampler_2d, dsdf_set_grid_transform / dsdf_has_grid_transform, dsdf_shading.bsdf_lobe_samples */
 #define DSDF_STAT_SLOTS 16
 
 enum dsdf_status {
@@ -184,6 +184,13 @@ size_t dsdf_render_workspace_size(int width, int height, int spp, int n_views, i
 /* The same for dsdf_render_forward alone: no backward queue, film-block adjoint or tail queue (a primal render of 12 views
  * x 512^2 x 256 spp needs 0.1 GB instead of the 33 GB a gradient-pass workspace of that shape would take). */
 size_t dsdf_forward_workspace_size(int width, int height, int spp, int n_views, int integrator);
+/* Round 6 (ABI 308).  The primal of sdf_direct_reparam (spp % 64 == 0, no use_mis) is a wavefront: value-only march of the primary rays,
+ * a compacted list of the samples that need a shadow ray, a streaming kernel for those rays, a shading pass.  Its
+ * shadow rays are incoherent, and read the grid through a CELL TABLE (the 64 taps of every B-spline cell as 256 contiguous bytes:
+ * 16 x the grid) when the caller's workspace has room for it BEHIND the dsdf_forward_workspace_size() bytes (rounded up to 256):
+ * dsdf_cell_table_size() more bytes, 0 for grids whose table would need 64-bit offsets (about 400^3) -- the rays then read the
+ * grid buffer like every other lookup.  The table is rebuilt by each call (0.3 ms at 256^3); a workspace without the room works too. */
+size_t dsdf_cell_table_size(int rx, int ry, int rz);
 
 /* `ReparamIntegrator.render` (python/integrators/reparam.py:120-185) for n_views
  * sensors: ray generation (Mitsuba perspective sensor), sphere tracing,

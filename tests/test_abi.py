@@ -24,7 +24,7 @@ def test_every_header_symbol_exported(built):
     for s in syms:
         assert hasattr(lib, s), f"{s} declared in include/dsdf.h but not exported"
     assert set(syms) == set(dsdf._lib.SYMBOLS), "ctypes prototypes out of sync with the header"
-    assert lib.dsdf_version() == 307 == dsdf._lib.ABI_VERSION
+    assert lib.dsdf_version() == 308 == dsdf._lib.ABI_VERSION
 
 
 def test_default_params_and_sizes(built):
