@@ -369,7 +369,7 @@ __global__ __launch_bounds__(64, DIRECT ? (DIFF ? DSDF_DIRECT_SWEEP_MINWAVES : D
 void k_render_items(GridView G, dsdf_params P, ViewBatch VB, float *__restrict__ blocks, Queue qall, unsigned long long *stats,
                     const unsigned char *__restrict__ skip, ShadeArgs S, TailQueue tq, uint32_t *__restrict__ items,
                     const uint32_t *__restrict__ list, float *__restrict__ hit_t) {
-    static_assert(!STORE_T || (!DIFF && !DIRECT), "STORE_T is a mode of the value-only march");
+    static_assert(!STORE_T || !DIRECT, "STORE_T is a mode of the one-channel marches");
     constexpr int NCH = DIRECT ? 4 : 2;
     // wave-private LDS scratch: cell cache during tracing, film transpose afterwards
     __shared__ __attribute__((aligned(16))) float wave_lds[DSDF_WAVE_LDS];
@@ -431,14 +431,26 @@ void k_render_items(GridView G, dsdf_params P, ViewBatch VB, float *__restrict__
         if (STORE_T) {
             // (a chunk proven empty needs no entry: the shading pass reads the same flag)
             if (!skip_trace) {
-                L = lane_setup<true>(A, P, lane, px, py);
-                WaveCellCache F; F.taps = wave_lds; F.lid = lid;
-                if (tq.state) {
-                    PlainHandOff ho;
-                    ho.tq = tq; ho.sub = tq.per_xcd ? my_subq : item % DSDF_TAIL_SUBQ; ho.view = view; ho.lane = lane;
-                    trace_plain(G, P, L.ray.o, L.ray.d, L.ray.maxt, tr, F, ho);
-                } else trace_plain(G, P, L.ray.o, L.ray.d, L.ray.maxt, tr, F);
-                hit_t[(size_t)view * ((size_t)npix * (uint32_t)A.spp) + lane] = tr.its_t;
+                L = lane_setup<!DIFF>(A, P, lane, px, py);
+                if (DIFF) {
+                    // (gradient sweep: the whole record of the primary ray, dense by sample; a handed-off ray's tail wave overwrites it)
+                    DirectFetch F;
+                    if (tq.state) {
+                        HandOff ho;
+                        ho.tq = tq; ho.sub = tq.per_xcd ? my_subq : item % DSDF_TAIL_SUBQ; ho.view = view; ho.lane = lane;
+                        trace_diff(G, P, L.ray.o, L.ray.d, L.ray.maxt, tr, F, ho);
+                    } else trace_diff(G, P, L.ray.o, L.ray.d, L.ray.maxt, tr, F);
+                    const Queue qv = view_queue(qall, view);
+                    store_record(qv.rec + lane, qv.cap, tr);
+                } else {
+                    WaveCellCache F; F.taps = wave_lds; F.lid = lid;
+                    if (tq.state) {
+                        PlainHandOff ho;
+                        ho.tq = tq; ho.sub = tq.per_xcd ? my_subq : item % DSDF_TAIL_SUBQ; ho.view = view; ho.lane = lane;
+                        trace_plain(G, P, L.ray.o, L.ray.d, L.ray.maxt, tr, F, ho);
+                    } else trace_plain(G, P, L.ray.o, L.ray.d, L.ray.maxt, tr, F);
+                    hit_t[(size_t)view * ((size_t)npix * (uint32_t)A.spp) + lane] = tr.its_t;
+                }
             }
         } else if (proven) {
             float r0, r1;
@@ -485,7 +497,7 @@ void k_render_items(GridView G, dsdf_params P, ViewBatch VB, float *__restrict__
         }
         if (!STORE_T) film_flush_wave<NCH>(block, A, px, py, lid, acc);
         bool need = false;
-        if (DIFF) {
+        if (DIFF && !STORE_T) {
             const bool hit = tr.its_t < INFINITY;
             const bool warp_cand = (A.flags & DSDF_REPARAM) && warp_weight_positive(G, P, L.ray.o, L.ray.d, tr);
             need = warp_cand || (DIRECT ? lit != 0 : (hit && A.integrator == DSDF_SIMPLE_SHADING));
@@ -509,10 +521,14 @@ void k_render_items(GridView G, dsdf_params P, ViewBatch VB, float *__restrict__
 //            full the next one takes them -- the capacity is the worst case over all sub-queues, a share has no a-priori bound);
 //   PHASE 1  shades: hit distance and occlusion are known (the sign of hit_t, k_shadow_stream), so a sample is its emitter term, an
 //            albedo lookup and the film window (direct_value_known; film_accum_wave / film_flush_wave as in k_render_items).
-template <int PHASE>
+// The gradient sweep runs the same scheme (DIFF): the primary rays' differentiable march stores every sample's record in the backward
+// queue's record rows (k_render_items<true, false, *, true>), PHASE 0 lists the shadow rays from the stored hit distance, the stream
+// (k_shadow_stream_diff) writes the shadow record of every listed sample into rows 9..17, and PHASE 1 is what the fused worker did
+// after its traces: value, film, the exact test for the backward queue, wave-level queue compaction.
+template <int PHASE, bool DIFF>
 __global__ __launch_bounds__(64) void k_direct_items(GridView G, dsdf_params P, ViewBatch VB, float *__restrict__ blocks,
                                                      const unsigned char *__restrict__ skip, ShadeArgs S, TailQueue sq, uint32_t *__restrict__ items,
-                                                     const uint32_t *__restrict__ list, float *__restrict__ hit_t) {
+                                                     const uint32_t *__restrict__ list, float *__restrict__ hit_t, Queue qall) {
     constexpr int NCH = 4;
     __shared__ __attribute__((aligned(16))) float wave_lds[DSDF_WAVE_LDS];
     const int lid = lane_id();
@@ -520,7 +536,7 @@ __global__ __launch_bounds__(64) void k_direct_items(GridView G, dsdf_params P, 
     const uint32_t chunks = (uint32_t)__builtin_amdgcn_readfirstlane(VB.v[0].spp >> 6);
     // PHASE 0: an item is a 64-sample chunk as in the march; PHASE 1: an item is a listed PIXEL -- its chunks are accumulated in the
     // wave's film window and flushed once (100 atomics per pixel instead of per chunk: without a march there is no footprint to keep small)
-    const uint32_t per_item = PHASE == 1 ? chunks : 1u;
+    const uint32_t per_item = (PHASE == 1 && !DIFF) ? chunks : 1u;      // (the sweep's queue compaction is per 64-sample unit)
     const uint32_t n_items = (uint32_t)__builtin_amdgcn_readfirstlane((int)items[0]) * (chunks / per_item);
     const uint32_t sub = (blockIdx.x >> 3) & 7u, first = gridDim.x / DSDF_TICKETS;
     uint32_t share = blockIdx.x & 7u, hops = 0;
@@ -544,22 +560,23 @@ __global__ __launch_bounds__(64) void k_direct_items(GridView G, dsdf_params P, 
             const ViewArgs &A = VB.v[view];
             const int py = (int)(pix / (uint32_t)A.Wb), px = (int)(pix - (uint32_t)py * (uint32_t)A.Wb);
             const unsigned proof = skip ? (unsigned)__builtin_amdgcn_readfirstlane((int)skip[e]) : 0u;
-            const bool skip_trace = (proof & DSDF_PX_EMPTY) != 0;
+            const bool skip_trace = (proof & (DIFF ? DSDF_PX_EMPTY_G : DSDF_PX_EMPTY)) != 0;
             float acc[NCH][2];
 #pragma unroll
             for (int ch = 0; ch < NCH; ++ch) { acc[ch][0] = 0.f; acc[ch][1] = 0.f; }
           for (uint32_t ck = 0; ck < per_item; ++ck) {
-            const uint32_t unit = pix * chunks + (PHASE == 1 ? ck : item % chunks);
+            const uint32_t unit = pix * chunks + ((PHASE == 1 && !DIFF) ? ck : item % chunks);
             const uint32_t lane = unit * 64u + (uint32_t)lid;
-            float *slot = hit_t + (size_t)view * ((size_t)npix * (uint32_t)A.spp) + lane;
-            const float ht = skip_trace ? INFINITY : *slot;
-            const bool occluded = (__float_as_uint(ht) >> 31) != 0u;
-            const float its_t = fabsf(ht);
+            const Queue qv = view_queue(qall, view);
+            // the primary ray's hit distance: hit_t (primal; its sign = the shadow ray was occluded) / row 0 of the sample's record (sweep)
+            const float ht = skip_trace ? INFINITY : (DIFF ? qv.rec[lane] : hit_t[(size_t)view * ((size_t)npix * (uint32_t)A.spp) + lane]);
+            const bool occluded = !DIFF && (__float_as_uint(ht) >> 31) != 0u;
+            const float its_t = DIFF ? ht : fabsf(ht);
             if (PHASE == 0) {
                 const bool hit = its_t < INFINITY;
                 if (__ballot(hit) != 0) {
                     // (the samples of a chunk hit within a voxel of each other: the normal's lookup goes through the wave cell cache)
-                    const Lane L = lane_setup<true>(A, P, lane, px, py);
+                    const Lane L = lane_setup<!DIFF>(A, P, lane, px, py);
                     DirectHit h;
                     WaveCellCache F; F.taps = wave_lds; F.lid = lid;
                     const bool front = direct_setup(G, A, L, lane, hit ? its_t : 0.f, h, F, hit);
@@ -575,7 +592,7 @@ __global__ __launch_bounds__(64) void k_direct_items(GridView G, dsdf_params P, 
                         // (every sub-queue full cannot happen: their capacities add up to the worst case plus the slack of one chunk each)
                     }
                 }
-            } else {
+            } else if (!DIFF) {
                 const Lane L = lane_setup<true>(A, P, lane, px, py);
                 const Reproj rp = reproject(A.cam, P, L.ray.o + L.ray.d, A.W, A.H);
                 float rgb[3];
@@ -584,6 +601,37 @@ __global__ __launch_bounds__(64) void k_direct_items(GridView G, dsdf_params P, 
                     direct_value_known(G, A, S, L, lane, its_t, occluded, rgb, F);
                 }
                 film_accum_wave<NCH>(px, py, rp.u, rp.v, rgb, wave_lds, lid, acc);
+            } else {
+                // the sweep's sample: records of the primary ray and (front-facing samples) of the shadow ray, then as k_render_items
+                const Lane L = lane_setup<false>(A, P, lane, px, py);
+                const Reproj rp = reproject(A.cam, P, L.ray.o + L.ray.d, A.W, A.H);
+                TraceOut tr, trs;
+                if (skip_trace) clear_trace(tr); else load_record(qv.rec + lane, qv.cap, tr);
+                clear_trace_out(trs, 0.f);
+                float rgb[3] = {0.f, 0.f, 0.f};
+                const bool hit = tr.its_t < INFINITY;
+                if (!hit && !S.hide_emitters) { rgb[0] = S.env[0]; rgb[1] = S.env[1]; rgb[2] = S.env[2]; }
+                int lit = 0;
+                if (__ballot(hit) != 0) {
+                    DirectHit h;
+                    WaveCellCache F; F.taps = wave_lds; F.lid = lid;
+                    const bool front = direct_setup(G, A, L, lane, hit ? tr.its_t : 0.f, h, F, hit);
+                    if (front) {
+                        load_record(qv.rec + lane + 9 * (size_t)qv.cap, qv.cap, trs);
+                        if (!(trs.its_t < INFINITY)) {
+                            EmitterTerm e;
+                            emitter_term(S, h, L.ray.d, e);
+                            float alb[3]; V3 ag[3];
+                            eval_trilinear(S.albedo, h.p, alb, ag);
+#pragma unroll
+                            for (int c = 0; c < 3; ++c) rgb[c] = (alb[c] * e.ke + e.ks) * S.env[c];
+                            lit = 1;
+                        }
+                    }
+                }
+                film_accum_wave<NCH>(px, py, rp.u, rp.v, rgb, wave_lds, lid, acc);
+                const bool warp_cand = (A.flags & DSDF_REPARAM) && warp_weight_positive(G, P, L.ray.o, L.ray.d, tr);
+                queue_unit(qv, unit, lane, warp_cand || lit != 0, lid, tr, &trs, nullptr);
             }
           }
             if (PHASE == 1) film_flush_wave<NCH>(blocks + (size_t)view * NCH * npix, A, px, py, lid, acc);
@@ -1075,7 +1123,7 @@ static Workspace carve(void *base, int W, int H, int spp, int nv, int integrator
             ws.count0 = (uint32_t *)(p + off); off += align_up(nv * nunits * sizeof(uint32_t), 256);
         }
     }
-    if ((integrator != DSDF_DIRECT || !diff) && spp % 64 == 0) {
+    if (spp % 64 == 0) {
         // per group: sub-queue `s` serves the chunks with work-list index % DSDF_TAIL_SUBQ == s; a wave hands off at most
         // `handoff` rays per 64-sample chunk
         const size_t handoff = diff ? DSDF_TAIL_HANDOFF : DSDF_PTAIL_HANDOFF;
@@ -1085,10 +1133,11 @@ static Workspace carve(void *base, int W, int H, int spp, int nv, int integrator
                         (size_t)DSDF_MAX_GROUPS * align_up((size_t)DSDF_TAIL_SUBQ * ws.tail_cap_sub * ws.tail_words * sizeof(float), 256);
         ws.tail = p + off; off += ws.tail_bytes;
     }
-    if (integrator == DSDF_DIRECT && !diff && spp % 64 == 0) {
-        // the wavefront primal: hit distances, and a shadow queue that holds EVERY sample in the worst case -- the
-        // sub-queues share it evenly plus one chunk of slack each (a producer whose sub-queue is full moves on to the next)
-        ws.hit_t = (float *)(p + off); off += align_up((size_t)nv * cap * sizeof(float), 256);
+    if (integrator == DSDF_DIRECT && spp % 64 == 0) {
+        // the wavefront passes: hit distances (primal; the sweep keeps whole records in the queue's rows), and a shadow
+        // queue that holds EVERY sample in the worst case -- the sub-queues share it evenly plus one chunk of slack each (a producer
+        // whose sub-queue is full moves on to the next)
+        if (!diff) { ws.hit_t = (float *)(p + off); off += align_up((size_t)nv * cap * sizeof(float), 256); }
         ws.shq_cap_sub = (uint32_t)(((size_t)nv * nunits + DSDF_TAIL_SUBQ - 1) / DSDF_TAIL_SUBQ * 64 + 64);
         ws.shq = p + off;
         off += align_up((size_t)DSDF_TAIL_SUBQ * DSDF_TAIL_CNT_STRIDE * sizeof(uint32_t), 256) +
@@ -1405,7 +1454,8 @@ static int hit_proof_min_spp() { static const int v = env_int("DSDF_HIT_PROOF_MI
 // DSDF_ENV_FILL=0: sdf_direct_reparam with a visible environment samples its far pixels (as until round 5; A/B)
 static bool env_fill_enabled() { static const int v = env_int("DSDF_ENV_FILL", 1); return v != 0; }
 static bool cell_table_enabled() { static const int v = env_int("DSDF_CELL_TABLE", 1); return v != 0; }
-static bool direct_wavefront_enabled() { static const int v = env_int("DSDF_DIRECT_WAVEFRONT", 1); return v != 0; }
+// DSDF_DIRECT_WAVEFRONT: 0 = the fused workers of sdf_direct_reparam as until round 6, 1 = the primal as a wavefront, 2 = the gradient sweep too
+static int direct_wavefront_enabled() { static const int v = env_int("DSDF_DIRECT_WAVEFRONT", 2); return v; }
 static bool primal_handoff() { static const int v = env_int("DSDF_PRIMAL_HANDOFF", 1); return v != 0; }
 static int tail_streams_enabled() { static int v = env_int("DSDF_TAIL_STREAMS", 1); return v; }
 // blocks (4 waves) per sub-queue of a tail kernel: DSDF_TAIL_BLOCKS overrides the built-in value
@@ -1594,7 +1644,8 @@ static int run_pass(PassCtx &c, const Workspace &ws, const dsdf_camera *cams, in
             return fail(DSDF_ERR_LAUNCH, "hipMemsetAsync(queue counts) failed");
         // view groups: render kernel g on the caller's stream, tail kernel g on a helper stream beside render kernel g + 1
         // sdf_direct_reparam's primal as a wavefront (DSDF_DIRECT_WAVEFRONT=0: the fused worker as before; use_mis keeps it)
-        const bool wavefront = !DIFF && c.direct && !S.use_mis && ws.hit_t != nullptr && direct_wavefront_enabled() && max_groups() == 1;
+        const bool wavefront = c.direct && !S.use_mis && ws.shq != nullptr && (DIFF || ws.hit_t != nullptr) && direct_wavefront_enabled() &&
+                               (!DIFF || direct_wavefront_enabled() > 1) && max_groups() == 1;
         const bool handoff = ws.tail != nullptr && (DIFF || primal_handoff()) && (!c.direct || wavefront);
         const size_t cnt_bytes = align_up((size_t)DSDF_MAX_GROUPS * DSDF_TAIL_SUBQ * DSDF_TAIL_CNT_STRIDE * sizeof(uint32_t), 256);
         const size_t grp_bytes = align_up((size_t)DSDF_TAIL_SUBQ * ws.tail_cap_sub * ws.tail_words * sizeof(float), 256);
@@ -1637,9 +1688,9 @@ static int run_pass(PassCtx &c, const Workspace &ws, const dsdf_camera *cams, in
             }
             if (g == 0) timing_mark(0, st);
             if (wavefront) {
-                // the value-only march of the primary rays into hit_t (its tail kernel below), then the three wavefront passes
-                if (st64) hipLaunchKernelGGL((k_render_items<false, false, true, true>), grid, blk, 0, st, G, c.pp, VB, film, q, st64, skip, S, tq, hdr, list, ws.hit_t);
-                else hipLaunchKernelGGL((k_render_items<false, false, false, true>), grid, blk, 0, st, G, c.pp, VB, film, q, st64, skip, S, tq, hdr, list, ws.hit_t);
+                // the march of the primary rays into hit_t / the record rows (its tail kernel below), then the three wavefront passes
+                if (st64) hipLaunchKernelGGL((k_render_items<DIFF, false, true, true>), grid, blk, 0, st, G, c.pp, VB, film, q, st64, skip, S, tq, hdr, list, ws.hit_t);
+                else hipLaunchKernelGGL((k_render_items<DIFF, false, false, true>), grid, blk, 0, st, G, c.pp, VB, film, q, st64, skip, S, tq, hdr, list, ws.hit_t);
             } else if (c.direct) {
                 if (st64) hipLaunchKernelGGL((k_render_items<DIFF, true, true>), grid, blk, 0, st, G, c.pp, VB, film, q, st64, skip, S, tq, hdr, list, (float *)nullptr);
                 else hipLaunchKernelGGL((k_render_items<DIFF, true, false>), grid, blk, 0, st, G, c.pp, VB, film, q, st64, skip, S, tq, hdr, list, (float *)nullptr);
@@ -1680,7 +1731,8 @@ static int run_pass(PassCtx &c, const Workspace &ws, const dsdf_camera *cams, in
                 }
                 const dim3 tgrid(DSDF_TAIL_SUBQ * tail_blocks()), tblk(256);
                 unsigned long long *tst = st64 ? st64 : g_tail_stats;
-                if (DIFF) hipLaunchKernelGGL(k_tail_trace_diff, tgrid, tblk, 0, ts, G, c.pp, VB, film, tq, q, tst);
+                if (DIFF && wavefront) hipLaunchKernelGGL((k_tail_trace_diff<true>), tgrid, tblk, 0, ts, G, c.pp, VB, film, tq, q, (unsigned long long *)nullptr);
+                else if (DIFF) hipLaunchKernelGGL((k_tail_trace_diff<false>), tgrid, tblk, 0, ts, G, c.pp, VB, film, tq, q, tst);
                 else hipLaunchKernelGGL(k_tail_trace_plain, tgrid, tblk, 0, ts, G, c.pp, VB, film, tq, wavefront ? (unsigned long long *)nullptr : tst,
                                         wavefront ? ws.hit_t : (float *)nullptr);
                 if ((rc = check_launch("k_tail_trace"))) return rc;
@@ -1716,8 +1768,12 @@ static int run_pass(PassCtx &c, const Workspace &ws, const dsdf_camera *cams, in
             const size_t tick_bytes = (size_t)16 * DSDF_TICKETS * sizeof(uint32_t);
             if (hipMemsetAsync(ws.shq, 0, scnt, st) != hipSuccess || hipMemsetAsync(hdr + 16, 0, tick_bytes, st) != hipSuccess)
                 return fail(DSDF_ERR_LAUNCH, "hipMemsetAsync(shadow queue) failed");
-            hipLaunchKernelGGL((k_direct_items<0>), grid, blk, 0, st, G, c.pp, VB, film, skip, S, sq, hdr, list, ws.hit_t);
+            hipLaunchKernelGGL((k_direct_items<0, DIFF>), grid, blk, 0, st, G, c.pp, VB, film, skip, S, sq, hdr, list, ws.hit_t, q);
             if ((rc = check_launch("k_direct_items<0>"))) return rc;
+            if (DIFF) {
+                hipLaunchKernelGGL(k_shadow_stream_diff, dim3(DSDF_TAIL_SUBQ * DSDF_SHQ_BLOCKS_PER_SUBQ), dim3(256), 0, st, G, c.pp, VB, sq, q, st64);
+                if ((rc = check_launch("k_shadow_stream_diff"))) return rc;
+            } else {
             // the cell table the shadow rays read, behind the carved workspace when the caller provided the room (dsdf_cell_table_size)
             const size_t tb = cell_table_enabled() ? cell_table_bytes(c.rx, c.ry, c.rz) : 0;
             const size_t toff = align_up(ws.bytes, 256);
@@ -1730,8 +1786,9 @@ static int run_pass(PassCtx &c, const Workspace &ws, const dsdf_camera *cams, in
                 hipLaunchKernelGGL((k_shadow_stream<false>), dim3(DSDF_TAIL_SUBQ * DSDF_SHQ_BLOCKS_PER_SUBQ), dim3(256), 0, st, G, c.pp, VB, sq, ws.hit_t, st64, (const float *)nullptr);
             }
             if ((rc = check_launch("k_shadow_stream"))) return rc;
+            }
             if (hipMemsetAsync(hdr + 16, 0, tick_bytes, st) != hipSuccess) return fail(DSDF_ERR_LAUNCH, "hipMemsetAsync(tickets) failed");
-            hipLaunchKernelGGL((k_direct_items<1>), grid, blk, 0, st, G, c.pp, VB, film, skip, S, sq, hdr, list, ws.hit_t);
+            hipLaunchKernelGGL((k_direct_items<1, DIFF>), grid, blk, 0, st, G, c.pp, VB, film, skip, S, sq, hdr, list, ws.hit_t, q);
             if ((rc = check_launch("k_direct_items<1>"))) return rc;
         }
     } else {

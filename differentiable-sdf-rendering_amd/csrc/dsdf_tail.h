@@ -252,6 +252,8 @@ __device__ __forceinline__ void tail_stats(unsigned long long *stats, int lane_s
     const ViewArgs *views = reinterpret_cast<const ViewArgs *>(views##_raw)
 
 // Resumes the queued rays of the gradient sweep and finishes their samples: value splat, backward-queue entry.
+// STORE (the wavefront sweep of sdf_direct_reparam): the finished ray's record goes to its sample's record rows, nothing else.
+template <bool STORE>
 __global__ __launch_bounds__(256) void k_tail_trace_diff(GridView G, dsdf_params P, ViewBatch VB, float *__restrict__ blocks,
                                                          TailQueue tq, Queue qall, unsigned long long *stats) {
     __builtin_amdgcn_s_setprio(DSDF_TAIL_PRIO);
@@ -314,6 +316,13 @@ __global__ __launch_bounds__(256) void k_tail_trace_diff(GridView G, dsdf_params
         TraceOut tr;
         tr.its_t = refine_hit(G, P, m.o, m.d, m.its_t, m.trace_eps, tr.refine_steps, F);
         diff_march_finish(m, tr);
+        if (STORE) {
+            // (the record of the primary ray, nothing else -- k_direct_items<1, true> shades)
+            const Queue qv = view_queue(qall, view);
+            store_record(qv.rec + sample, qv.cap, tr);
+            n_hits += tr.its_t < INFINITY ? 1 : 0;
+            return;
+        }
         const float val = shade_value(G, A, L, tr.its_t);
         if (val != 0.f) {
             Reproj rp = reproject(A.cam, P, L.ray.o + L.ray.d, A.W, A.H);
@@ -834,6 +843,102 @@ __global__ __launch_bounds__(256) void k_shadow_stream(GridView G, dsdf_params P
         }
 #endif
     }
+    if (stats) {
+        const int ls = wave_sum_i32(n_steps), r = wave_sum_i32(n_rays);
+        if (lane_id() == 0) {
+            unsigned long long *st = stats + (size_t)(blockIdx.x & 63u) * DSDF_STAT_SLOTS;
+            atomicAdd(st + 8, (unsigned long long)ls);
+            atomicAdd(st + 9, (unsigned long long)n_wsteps);
+            atomicAdd(st + 10, (unsigned long long)r);
+        }
+    }
+}
+
+// The same stream for the gradient sweep: the differentiable march of the listed shadow rays (ray_intersect with the warp
+// accumulators, sdf_direct_reparam.py:52; no refinement: ray_test consumes isfinite(its_t) and the warp outputs), every lane its own
+// ray with the register-resident cell of the sweep's tail kernel; a finished ray's record -- what the fused worker kept in `trs` --
+// goes to rows 9..17 of the sample's backward-queue record, where the shading pass and k_backward<true> read it.
+__global__ __launch_bounds__(256) void k_shadow_stream_diff(GridView G, dsdf_params P, ViewBatch VB, TailQueue tq, Queue qall,
+                                                            unsigned long long *stats) {
+    const uint32_t first = tq.per_xcd ? tail_subq() : blockIdx.x % DSDF_TAIL_SUBQ;
+    uint32_t hop = 0, total = 0;
+    uint32_t *cnt = nullptr;
+    const float *ent = nullptr;
+    auto open_next = [&]() {
+        const uint32_t sub_k = tail_hop(first, (uint32_t)lane_id(), tq.per_xcd);
+        uint32_t *c = tq.count + DSDF_TAIL_CNT_STRIDE * sub_k;
+        const uint32_t queued = __hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t claimed = __hip_atomic_load(c + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        uint64_t open = __ballot(claimed < queued);
+        open = hop < 64u ? (open >> hop) << hop : 0ull;
+        if (open == 0) { hop = DSDF_TAIL_SUBQ; return false; }
+        const int k = __builtin_ctzll(open);
+        hop = (uint32_t)k + 1u;
+        const uint32_t sub = tail_hop(first, (uint32_t)k, tq.per_xcd);
+        cnt = tq.count + DSDF_TAIL_CNT_STRIDE * sub;
+        ent = tq.state + (size_t)sub * tq.cap_sub * DSDF_PTAIL_WORDS;
+        total = (uint32_t)__builtin_amdgcn_readlane((int)queued, k);
+        return true;
+    };
+    DSDF_TAIL_VIEWS_LDS(VB, views);
+    if (!open_next()) return;
+    dsdf_params Ps = P;
+    Ps.refine_steps = 0;
+    const bool keep_warp = reparam_depth1(P);
+    DiffMarch m;
+    m.active = false;
+    ReuseFetch RF;
+    float *rec = nullptr;       // this lane's sample in the record rows of its view (row stride `cap`)
+    size_t cap = 0;
+    bool exhausted = false, pending = false;
+    int n_steps = 0, n_wsteps = 0, n_rays = 0;
+    auto complete = [&]() {
+        TraceOut trs;
+        trs.its_t = m.its_t;
+        trs.refine_steps = 0;
+        diff_march_finish(m, trs);
+        if (!keep_warp) drop_warp(trs);
+        store_record(rec + 9 * cap, cap, trs);
+    };
+    while (true) {
+        const uint64_t idle = __ballot(!m.active);
+        if (!exhausted && __popcll(idle) >= DSDF_SHQ_REFILL) {
+            if (pending) { complete(); pending = false; }
+            bool drained = false;
+            const uint32_t idx = tail_claim(cnt, total, idle, !m.active, drained);
+            const float *e = ent + (size_t)idx * DSDF_PTAIL_WORDS;
+            if (drained) exhausted = !open_next();
+            if (idx != ~0u) {
+                const uint32_t view = __float_as_uint(e[0]), sample = __float_as_uint(e[1]);
+                const float its_t = e[2];
+                const ViewArgs &A = views[view];
+                const Lane L = lane_setup<false>(A, P, sample);
+                DirectHit h;
+                direct_setup(G, A, L, sample, its_t, h);
+                m = diff_march_begin(Ps, h.sr.o, h.sr.d, h.sr.maxt);
+                const Queue qv = view_queue(qall, view);
+                rec = qv.rec + sample; cap = qv.cap;
+                RF.valid = false;
+                pending = !m.active;                                     // (a ray that misses the box: its record is "no hit, no warp")
+                ++n_rays;
+            }
+        }
+        const uint64_t am = __ballot(m.active);
+        if (am == 0) {
+            if (exhausted) break;
+            continue;
+        }
+        ++n_wsteps;
+        if (m.active) {
+            const V3 x = fma3(m.t, m.d, m.o);
+            float v = 0.f; V3 g = mk(0.f, 0.f, 0.f); float H[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            RF.template eval<2>(G, x, true, v, g, H);
+            diff_march_step(Ps, m, x, v, g, H);
+            ++n_steps;
+            pending = !m.active;
+        }
+    }
+    if (pending) complete();
     if (stats) {
         const int ls = wave_sum_i32(n_steps), r = wave_sum_i32(n_rays);
         if (lane_id() == 0) {
