@@ -421,7 +421,7 @@ def supervise(argv):
         child = subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv) + ['--child'], stdout=subprocess.PIPE, text=True, bufsize=1)
         q = queue.Queue()
 
-        def pump(f=child.stdout):
+        def pump(f=child.stdout, q=q):            # (q bound NOW: the pump of a killed first child ends after the second attempt has made its queue)
             for line in f:
                 q.put(line)
             q.put(None)

@@ -842,27 +842,32 @@ struct UnitGather {
 #ifndef DSDF_BWD_MINWAVES
 #define DSDF_BWD_MINWAVES 1
 #endif
-// DSDF_BWD_HALF_TILE=1: the scatters of the fused k_backward go through the 9 KB half tile as well (wave_scatter_half): with the
-// 17 KB tile the LDS allows 9 single-wave blocks per CU = 2.25 waves per SIMD, fewer than the registers of k_backward<true> do
+// The scatters of the fused k_backward go through the 17 KB tile (wave_scatter_t) or the 9 KB half tile (wave_scatter_half): with
+// the full tile the LDS allows 9 single-wave blocks per CU = 2.25 waves per SIMD.  Round 6: k_backward<true> takes the HALF tile and
+// 256 registers (2 waves per SIMD, 472 instead of 1000 bytes of scratch per lane): gradient call of C5 56.4 -> 53.9 ms, the other
+// combinations measured beside it lose (profiles/r06_ab/bwd_direct_tile.jsonl).  The silhouette / simple-shading kernel keeps the full tile.
 #ifndef DSDF_BWD_HALF_TILE
 #define DSDF_BWD_HALF_TILE 0
 #endif
-#if DSDF_BWD_HALF_TILE
-#define DSDF_BWD_TILE_FLOATS DSDF_SCATH_FLOATS
-#define DSDF_BWD_SCATTER wave_scatter_half
-#else
-#define DSDF_BWD_TILE_FLOATS DSDF_SCAT_FLOATS
-#define DSDF_BWD_SCATTER wave_scatter_t
+#ifndef DSDF_BWD_DIRECT_HALF_TILE
+#define DSDF_BWD_DIRECT_HALF_TILE 1
 #endif
+template <bool HALF> struct BwdTile {
+    static constexpr int floats = HALF ? DSDF_SCATH_FLOATS : DSDF_SCAT_FLOATS;
+    static __device__ __forceinline__ void scatter(const GridView &G, float *__restrict__ grad, const ScatterReq &rq, float *T, int lid) {
+        if (HALF) wave_scatter_half(G, grad, rq, T, lid); else wave_scatter_t(G, grad, rq, T, lid);
+    }
+};
 template <bool DIRECT>
 #ifndef DSDF_BWD_DIRECT_MINWAVES
-#define DSDF_BWD_DIRECT_MINWAVES 3   /* 168 VGPRs + 1 KB of scratch per lane, 3 waves per SIMD instead of 413 registers and ONE: a kernel at 5 % VALU and 83 % L2 misses wants the waves (gradient call of C5: 98.2 -> 93.7 ms, checksums equal; profiles/r04_tail_ab.md) */
+#define DSDF_BWD_DIRECT_MINWAVES 2   /* (round 4: 3 -- 168 VGPRs + 1 KB of scratch per lane instead of 413 registers and ONE wave; round 6, with the half tile: 2) */
 #endif
 __global__ __launch_bounds__(64, DIRECT ? DSDF_BWD_DIRECT_MINWAVES : DSDF_BWD_MINWAVES) void k_backward(GridView G, dsdf_params P, ViewBatch VB, Queue qall,
                                                  const float *__restrict__ block_adjs,
                                                  float *__restrict__ grad_grid, float *__restrict__ grad_p,
                                                  unsigned long long *stats, ShadeArgs S) {
-    __shared__ __attribute__((aligned(16))) float tile[DSDF_BWD_TILE_FLOATS];
+    typedef BwdTile<DIRECT ? (DSDF_BWD_DIRECT_HALF_TILE != 0) : (DSDF_BWD_HALF_TILE != 0)> Tile;
+    __shared__ __attribute__((aligned(16))) float tile[Tile::floats];
     const ViewArgs &A = VB.v[blockIdx.y];
     constexpr int NCH = DIRECT ? 4 : 2;
     const float *__restrict__ block_adj = block_adjs + (size_t)blockIdx.y * NCH * A.Wb * A.Hb;
@@ -895,13 +900,13 @@ __global__ __launch_bounds__(64, DIRECT ? DSDF_BWD_DIRECT_MINWAVES : DSDF_BWD_MI
         }
         if (DIRECT) {
             // dL/d(albedo), dL/d(roughness): grouped by trilinear cell over the wave, one atomic per tap and distinct cell (dsdf_wave.h)
-            if (S.grad_albedo) wave_scatter_trilinear<3, DSDF_BWD_TILE_FLOATS / 64>(S.albedo, S.grad_albedo, areq.on, areq.x, areq.a_bar, tile, lid);
-            if (S.grad_rough) wave_scatter_trilinear<1, DSDF_BWD_TILE_FLOATS / 64>(S.rough, S.grad_rough, areq.on && areq.r_bar != 0.f, areq.x, &areq.r_bar, tile, lid);
+            if (S.grad_albedo) wave_scatter_trilinear<3, Tile::floats / 64>(S.albedo, S.grad_albedo, areq.on, areq.x, areq.a_bar, tile, lid);
+            if (S.grad_rough) wave_scatter_trilinear<1, Tile::floats / 64>(S.rough, S.grad_rough, areq.on && areq.r_bar != 0.f, areq.x, &areq.r_bar, tile, lid);
         }
-        DSDF_BWD_SCATTER(G, grad_grid, req[0], tile, lid);
-        if (A.integrator != DSDF_SILHOUETTE) DSDF_BWD_SCATTER(G, grad_grid, req[1], tile, lid);
-        if (DIRECT) DSDF_BWD_SCATTER(G, grad_grid, req[2], tile, lid);
-        if (DIRECT && S.use_mis) DSDF_BWD_SCATTER(G, grad_grid, req[3], tile, lid);
+        Tile::scatter(G, grad_grid, req[0], tile, lid);
+        if (A.integrator != DSDF_SILHOUETTE) Tile::scatter(G, grad_grid, req[1], tile, lid);
+        if (DIRECT) Tile::scatter(G, grad_grid, req[2], tile, lid);
+        if (DIRECT && S.use_mis) Tile::scatter(G, grad_grid, req[3], tile, lid);
         if (grad_p) {
             if (req[0].on) p_bar = p_bar + req[0].p_bar;
             if (req[1].on) p_bar = p_bar + req[1].p_bar;
