@@ -207,7 +207,7 @@ def direct_block(args, dev, grid, sensors, steps=4):
                                   f"{nv} views x {args.img}^2, sdf_direct_reparam (emitter sampling), spp {args.spp_primal}/{args.spp_grad}"}}
     st = dsdf.new_stats(dev)
     dsdf.render_forward(grid, sensors, args.spp_primal, seeds=list(range(nv)), integrator='sdf_direct_reparam', shading=sh, stats=st)
-    out["roofline"] = side_roofline('direct_primal', 'k_render_items<false, true, false> (primal render kernel of sdf_direct_reparam)', kern_ms,
+    out["roofline"] = side_roofline('direct_primal', 'k_render_items_store<false, false> (march of the primary rays of the wavefront primal of sdf_direct_reparam)', kern_ms,
                                     dsdf.stats_dict(st))
     del albedo, galb, grad, tgt
     return out

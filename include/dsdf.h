@@ -209,7 +209,8 @@ size_t dsdf_cell_table_size(int rx, int ry, int rz);
  *               steps, hits, refine_steps, warp_active, queue_len, wave_steps, tail_steps, tail_wave_steps, tail_rays};
  *               wave_steps = lock-step loop iterations of the render kernel summed over its 64-lane waves (trace +
  *               refinement), the unit of the VALU-issue roofline; steps / wave_steps count the render kernel only, the
- *               tail_* slots what the tail kernels added for the rays handed over to them (tail_rays of them); slots 11..15 of
+ *               tail_* slots what the tail kernels added for the rays handed over to them (tail_rays of them) -- for sdf_direct_reparam
+ *               they count the SHADOW rays instead: lane steps, lock-step iterations of the waves that marched them, rays; slots 11..15 of
  *               rows 0..3 carry the tail waves' diagnostics listed at dsdf_tail_stats_arm.  Those five slots are RESERVED: they hold
  *               maxima, complemented minima and clock ticks of ONE launch, not additive counters -- sum slots 0..10 over the 64 rows,
  *               never slots 11..15, and zero the buffer per call if the diagnostics are read (several tail launches into one buffer --

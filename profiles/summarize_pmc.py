@@ -127,8 +127,8 @@ def main():
         ratio('sweep', 'k_render_items<true, false, false>', 'grad')
         ratio('low_primal', 'k_render_pass<false, false>', 'low_primal')
         ratio('low_sweep', 'k_render_pass<true, false>', 'low_grad')
-        ratio('direct_primal', 'k_render_items<false, true, false>', 'direct_primal')
-        ratio('direct_sweep', 'k_render_items<true, true, false>', 'direct_grad')
+        ratio('direct_primal', 'k_render_items_store<false, false>', 'direct_primal')   # (round 6: the primary march of the wavefront primal)
+        ratio('direct_sweep', 'k_render_items_store<true, false>', 'direct_grad')
         json.dump(model, open(os.path.join(HERE, 'valu_model.json'), 'w'), indent=1, sort_keys=True)
         print('valu_model', json.dumps(model))
     for k, v in res.items():
