@@ -17,6 +17,9 @@
 //                              cell cache, DIFF = 1 Hessian march with the warp accumulators + backward-queue compaction;
 //                              both hand the last few rays of a wave to a tail queue                         [dsdf_tail.h]
 //   k_tail_trace_plain/diff    persistent waves that resume the handed-off rays, per-XCD queues (dsdf_tail.h)
+//   k_render_items_store, k_direct_items<PHASE, DIFF>, k_shadow_stream<TABLE>, k_shadow_stream_diff, k_cell_table
+//                              sdf_direct_reparam as a wavefront (round 6): primary march into per-sample records, compacted shadow
+//                              queue, streaming shadow rays (one per lane, refill), shading pass            [dsdf_items_body.h, dsdf_tail.h]
 //   k_render_pass<DIFF,DIRECT> any spp: one lane per sample; for spp < 64 a wave = a pixel tile with an LDS film window
 //   k_render_aovs, k_develop_aov   debug images `i` / `weight_sum` of use_aovs + return_aovs (one lane per sample)
 //   k_sampler_2d               the film offsets of the built-in sampler (or their mirror images: antithetic_sampling)
@@ -384,14 +387,14 @@ void k_render_items_store(GridView G, dsdf_params P, ViewBatch VB, Queue qall, u
 }
 
 // The two item passes of the wavefront primal of sdf_direct_reparam, over the SAME work list as the march
-// (k_render_items<false, false, *, true>; the ticket counters are zeroed in between) with the same ticket scheme:
+// (k_render_items_store; the ticket counters are zeroed in between) with the same ticket scheme:
 //   PHASE 0  lists the samples that need a shadow ray: hit (hit_t), both cosines positive (direct_setup) -> one reservation per chunk
 //            in the shadow queue (the primal tail queue's 3-word entries: view, sample, hit distance; when the worker's own sub-queue is
 //            full the next one takes them -- the capacity is the worst case over all sub-queues, a share has no a-priori bound);
 //   PHASE 1  shades: hit distance and occlusion are known (the sign of hit_t, k_shadow_stream), so a sample is its emitter term, an
 //            albedo lookup and the film window (direct_value_known; film_accum_wave / film_flush_wave as in k_render_items).
 // The gradient sweep runs the same scheme (DIFF): the primary rays' differentiable march stores every sample's record in the backward
-// queue's record rows (k_render_items<true, false, *, true>), PHASE 0 lists the shadow rays from the stored hit distance, the stream
+// queue's record rows (k_render_items_store<true, *>), PHASE 0 lists the shadow rays from the stored hit distance, the stream
 // (k_shadow_stream_diff) writes the shadow record of every listed sample into rows 9..17, and PHASE 1 is what the fused worker did
 // after its traces: value, film, the exact test for the backward queue, wave-level queue compaction.
 template <int PHASE, bool DIFF>
