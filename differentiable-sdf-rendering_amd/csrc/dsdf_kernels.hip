@@ -1325,8 +1325,13 @@ static bool fine_hit_proof() { static const int v = env_int("DSDF_FINE_HIT_PROOF
 static bool deep_skip_enabled() { static const int v = env_int("DSDF_DEEP_SKIP", 1); return v != 0; }
 // DSDF_COEF_EARLY=1: k_backward_coef for the render kernel's own samples AHEAD of the tail kernel + a second launch for what the
 // tail appended.  Measured (profiles/r04_tail_ab.md): the early launch is starved by the primal workers just like the tail kernel
-// (15 ms resident), and the tail kernel then starts later: step 42.5 vs 40.8 ms.  Default: one launch behind the tail kernel.
-static int coef_early_mode() { static const int v = env_int("DSDF_COEF_EARLY", 0); return v; }
+// (15 ms resident), and the tail kernel then starts later: step 42.5 vs 40.8 ms.
+// DSDF_COEF_EARLY=2 (the default since round 6): the coefficients of the render kernel's own samples on a helper stream BESIDE the tail
+// kernel -- forked behind the render kernel and the snapshot of the queue lengths, in front of the tail kernel (the fork
+// event used to be recorded behind the tail kernel's launch, so "beside" ran after it and measured as no gain) -- and a second launch
+// for what the tail appended: step 36.08 -> 35.86 and 35.52 -> 35.23 ms on two boxes (profiles/r06_ab/coef_beside.jsonl).
+// DSDF_COEF_EARLY=0: one launch behind the tail kernel.
+static int coef_early_mode() { static const int v = env_int("DSDF_COEF_EARLY", 2); return v; }
 static int hit_proof_min_spp() { static const int v = env_int("DSDF_HIT_PROOF_MIN_SPP", 16); return v; }
 // DSDF_ENV_FILL=0: sdf_direct_reparam with a visible environment samples its far pixels (as until round 5; A/B)
 static bool env_fill_enabled() { static const int v = env_int("DSDF_ENV_FILL", 1); return v != 0; }
