@@ -306,8 +306,10 @@ __device__ __forceinline__ void queue_unit(const Queue &q, uint32_t unit, uint32
 // ~8 ns).  Header of the list: [0] = number of listed pixels, then the counters (16 words apart).
 #define DSDF_TICKETS 64
 #define DSDF_ITEM_HDR (16 + 16 * DSDF_TICKETS)
+#ifndef DSDF_ITEM_SEG
 #define DSDF_ITEM_SEG 1024u         /* items per segment = the resident waves of an XCD; the list is tile-major with 1024-chunk tiles
                                        (measured: 28.9 / 28.7 / 28.6 / 28.5 ms at 256 / 512 / 1024 / 4096) */
+#endif
 struct ItemOrder { int tw_log2, th_log2; uint32_t tiles_x, per_view; };    // candidate index -> pixel: tile-major within a view
 
 __global__ __launch_bounds__(256) void k_build_items(ViewBatch VB, int view0, int nv, const unsigned char *__restrict__ skip, unsigned far_bit,
